@@ -1,0 +1,189 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by running the REAL reference
+(/root/reference, imported via oracle/ref_import.py) on seeded inputs.  Run in the build container:
+
+    python oracle/gen_golden.py
+
+The outputs are data (inputs + expected outputs), committed under tests/golden/.  No reference source
+travels.  Weights are NOT stored: they are regenerated anywhere by learner_oracle.fill_params (name-keyed
+deterministic fill) and loaded into the reference modules here.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+import learner_oracle as lo  # noqa: E402
+
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+
+from gen_batch import make_batch  # noqa: E402
+
+
+def load_params_into_reference(model, params):
+    sd = model.state_dict()
+    for k in sd:
+        sd[k] = params[k.replace("_model_list.0.", "")].clone()
+    model.load_state_dict(sd)
+
+
+def gen_learner(tag, size, heat, depth, B, seed):
+    cfg, model, crit = ref_import.build_reference_model_and_criterion(size, heat, depth, center_idx=0, seed=seed)
+    params = lo.fill_params(lo.param_shapes(22, depth), seed=seed)
+    load_params_into_reference(model, params)
+    batch = make_batch(B, size, seed + 100)
+    out = {}
+    for mode in ("train", "eval"):
+        model.train(mode == "train")
+        feats = {}
+        hb = model._model_list[0]
+        hooks = [hb.backbone.register_forward_hook(lambda m, i, o: feats.update(o)),
+                 hb.hybrid_head.final_layer.register_forward_hook(lambda m, i, o: feats.update(logits=o))]
+        preds = model(batch)["HybridBaseline"]
+        for h in hooks:
+            h.remove()
+        for k, v in preds.items():
+            out[f"{mode}.pred.{k}"] = v.detach().numpy().copy()
+        for k in ("res_layer1", "res_layer2", "res_layer3", "res_layer4"):
+            f = feats[k].detach()
+            out[f"{mode}.feat.{k}.mean_c"] = f.mean(dim=(0, 2, 3)).numpy().copy()
+            out[f"{mode}.feat.{k}.sample"] = f[:, ::16, ::3, ::3].numpy().copy()
+        out[f"{mode}.feat.res_layer4_mean"] = feats["res_layer4_mean"].detach().numpy().copy()
+        lg = feats["logits"].detach()
+        out[f"{mode}.logits.sample"] = lg[:, ::37, ::5, ::5].numpy().copy()
+        out[f"{mode}.logits.absmean"] = lg.abs().mean().numpy().copy()
+        if mode == "train":
+            # losses with pinned RNG (ordinal.py draws from torch + python global RNGs)
+            random.seed(seed + 7)
+            torch.manual_seed(seed + 7)
+            model.zero_grad()
+            total, losses = crit.compute_losses(preds, batch)
+            total.backward()
+            for k, v in losses.items():
+                out[f"loss.{k}"] = v.detach().numpy().copy()
+            gn = {}
+            for n, p in model.named_parameters():
+                if p.grad is None:
+                    continue
+                k = n.replace("_model_list.0.", "")
+                gn[k] = float(p.grad.norm())
+            out["grad.names"] = np.array(list(gn.keys()))
+            out["grad.norms"] = np.array(list(gn.values()), dtype=np.float64)
+            named = dict(model.named_parameters())
+            out["grad.conv1.sample"] = named["_model_list.0.backbone.conv1.weight"].grad[::8, :, ::3, ::3].numpy().copy()
+            out["grad.final_bias"] = named["_model_list.0.hybrid_head.final_layer.bias"].grad.numpy().copy()
+            out["grad.box4.weight"] = named["_model_list.0.box_head.layers.4.weight"].grad.numpy().copy()
+            out["grad.l3.0.ds.sample"] = named["_model_list.0.backbone.layer3.0.downsample.0.weight"].grad[::16, ::16, 0, 0].numpy().copy()
+            out["grad.deconv3.sample"] = named["_model_list.0.hybrid_head.deconv_layers.3.weight"].grad[::32, ::32].numpy().copy()
+            # running stats after one training forward
+            sd = model.state_dict()
+            out["stat.bn1.running_mean"] = sd["_model_list.0.backbone.bn1.running_mean"].numpy().copy()
+            out["stat.bn1.running_var"] = sd["_model_list.0.backbone.bn1.running_var"].numpy().copy()
+            out["stat.l4.2.bn2.running_var"] = sd["_model_list.0.backbone.layer4.2.bn2.running_var"].numpy().copy()
+            # one optimiser step exactly as train_artiboost.py:91-96
+            opt = torch.optim.Adam(model.models_params, lr=5e-5, weight_decay=0.0)
+            tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.001)
+            opt.step()
+            out["opt.total_norm"] = tn.numpy().copy()
+            named = dict(model.named_parameters())
+            out["opt.conv1.delta.sample"] = (named["_model_list.0.backbone.conv1.weight"].detach()
+                                             - params["backbone.conv1.weight"])[::8, :, ::3, ::3].numpy().copy()
+            out["opt.final_bias.delta"] = (named["_model_list.0.hybrid_head.final_layer.bias"].detach()
+                                           - params["hybrid_head.final_layer.bias"]).numpy().copy()
+            load_params_into_reference(model, params)  # restore for the eval pass
+    out["meta"] = np.array([size, heat, depth, B, seed])
+    np.savez_compressed(os.path.join(OUT, f"learner_{tag}.npz"), **out)
+    print("wrote", tag, sum(v.nbytes for v in out.values()) / 1e3, "KB")
+
+
+def gen_head_only(seed=3):
+    """softmax+integral head alone (simplebaseline.py:16-71,177-190) at both geometries, small B."""
+    ref_import.load()
+    from anakin.models.simplebaseline import norm_heatmap, integral_heatmap3d
+    out = {}
+    for tag, (C, D, H, W) in {"g224": (22, 28, 28, 28), "g256": (22, 28, 32, 32), "tiny": (3, 4, 5, 6)}.items():
+        g = torch.Generator().manual_seed(seed)
+        B = 2
+        logits = (4.0 * torch.randn(B, C * D, H, W, generator=g)).requires_grad_(True)
+        x = logits.reshape(B, C, -1)
+        x = norm_heatmap("softmax", x)
+        conf = torch.max(x, dim=-1).values
+        x = x / (x.sum(dim=-1, keepdim=True) + 1e-7)
+        x = x.contiguous().view(B, C, D, H, W)
+        uvd = integral_heatmap3d(x)
+        gu = torch.randn(uvd.shape, generator=g)
+        gc = torch.randn(conf.shape, generator=g)
+        ((uvd * gu).sum() + (conf * gc).sum()).backward()
+        out[f"{tag}.seed"] = np.array([seed, B, C, D, H, W])
+        out[f"{tag}.uvd"] = uvd.detach().numpy().copy()
+        out[f"{tag}.conf"] = conf.detach().numpy().copy()
+        out[f"{tag}.g_uvd"] = gu.numpy().copy()
+        out[f"{tag}.g_conf"] = gc.numpy().copy()
+        dl = logits.grad
+        out[f"{tag}.dlogits.sample"] = dl.reshape(B, C, -1)[:, :, ::97].numpy().copy()
+        out[f"{tag}.dlogits.abs_sum"] = dl.abs().sum().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "head.npz"), **out)
+    print("wrote head")
+
+
+def gen_misc(seed=5):
+    """Pure helper functions: affine transform, CCV update/row-col, view alignment, symmetry table, metric."""
+    ref_import.load_control_plane()
+    from anakin.utils import transform as T
+    out = {}
+    rng = np.random.default_rng(seed)
+    cs, ss, rs, tots, posts = [], [], [], [], []
+    for i in range(6):
+        c = rng.integers(150, 350, size=2).astype(np.float64)
+        s = float(rng.uniform(120, 300))
+        r = float(rng.uniform(-0.6, 0.6))
+        tot, post = T.get_affine_transform(c, s, [256.0, 256.0], [224, 224] if i % 2 else [256, 256], rot=r)
+        cs.append(c); ss.append(s); rs.append(r); tots.append(tot); posts.append(post)
+    out["affine.center"] = np.array(cs); out["affine.scale"] = np.array(ss); out["affine.rot"] = np.array(rs)
+    out["affine.total"] = np.array(tots); out["affine.post"] = np.array(posts)
+    pts = rng.uniform(0, 512, size=(9, 2))
+    out["coords.pts"] = pts
+    out["coords.out"] = T.transform_coords(pts, tots[0])
+    from anakin.datasets.hodata import HOdata
+    out["annot.center"] = HOdata.get_annot_center(pts)
+    out["annot.scale"] = np.array(HOdata.get_annot_scale(pts))
+    # CCV
+    from anakin.artiboost.artiboost_loader import ArtiBoostLoader
+    from anakin.artiboost.ovg_set import OVGSet
+    from anakin.artiboost.view_engine import ViewEngine
+    w = torch.ones(4, 288, 50)
+    ids = [(int(a), int(b), int(c)) for a, b, c in zip(rng.integers(0, 4, 40), rng.integers(0, 288, 40), rng.integers(0, 50, 40))]
+    vals = rng.uniform(5, 60, 40)
+    res = dict(zip(ids, vals.tolist()))
+    out["ccv.ids"] = np.array(list(res.keys())); out["ccv.vals"] = np.array(list(res.values()))
+    for m in (1, 2, 3):
+        fn = getattr(ArtiBoostLoader, f"update_method_{m}")
+        r = fn(w.clone(), res, 0.1, 10.0, dist_lower_threshold=8.0, dist_upper_threshold=16.0, epoch_idx=3, n_epochs=10)
+        out[f"ccv.m{m}"] = np.array([float(r["sample_weight_map"][i]) for i in res.keys()])
+    t = torch.tensor(rng.integers(0, 4 * 288 * 50, 64))
+    b, r_, c = OVGSet.row_col_calc(t, 288, 50)
+    out["ccv.tidx"] = t.numpy().copy(); out["ccv.bidx"] = b.numpy().copy(); out["ccv.ridx"] = r_.numpy().copy(); out["ccv.cidx"] = c.numpy().copy()
+    vecs = rng.normal(size=(8, 3)); vecs[0] = [0, 0, 1]; vecs[1] = [0, 0, -1]
+    out["view.vecs"] = vecs
+    out["view.align"] = np.array([ViewEngine.caculate_align_mat(v.copy()) for v in vecs])
+    # symmetry table (bop_misc.py:18-65) on a synthetic models_info
+    from anakin.utils.bop_toolkit.bop_misc import get_symmetry_transformations
+    info = {"symmetries_discrete": [[-1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]],
+            "symmetries_continuous": [{"axis": [0, 0, 1], "offset": [1.0, 2.0, 0.0]}]}
+    tr = get_symmetry_transformations(info, 0.25)
+    out["sym.R"] = np.array([x["R"] for x in tr]); out["sym.t"] = np.array([x["t"] for x in tr])
+    np.savez_compressed(os.path.join(OUT, "misc.npz"), **out)
+    print("wrote misc")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_head_only()
+    gen_misc()
+    gen_learner("g224", 224, 28, 28, B=2, seed=1)
+    gen_learner("g256", 256, 32, 28, B=2, seed=2)

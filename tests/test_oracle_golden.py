@@ -1,0 +1,108 @@
+"""CPU: pin oracle/learner_oracle.py (our restatement) against golden vectors produced by the REAL reference
+(oracle/gen_golden.py imported /root/reference).  These are the 'oracle is trustworthy' tests."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import learner_oracle as lo
+from gen_batch import make_batch
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "g224", "g256"])
+def test_softargmax_head_matches_reference(golden_dir, tag):
+    g = _load(golden_dir, "head.npz")
+    seed, B, C, D, H, W = [int(x) for x in g[f"{tag}.seed"]]
+    gen = torch.Generator().manual_seed(seed)
+    logits = (4.0 * torch.randn(B, C * D, H, W, generator=gen)).requires_grad_(True)
+    uvd, conf = lo.softargmax3d(logits, C, D, H, W)
+    np.testing.assert_allclose(uvd.detach().numpy(), g[f"{tag}.uvd"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(conf.detach().numpy(), g[f"{tag}.conf"], rtol=1e-5, atol=1e-7)
+    ((uvd * torch.from_numpy(g[f"{tag}.g_uvd"])).sum() + (conf * torch.from_numpy(g[f"{tag}.g_conf"])).sum()).backward()
+    dl = logits.grad.reshape(B, C, -1)[:, :, ::97].numpy()
+    np.testing.assert_allclose(dl, g[f"{tag}.dlogits.sample"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["g224", "g256"])
+def test_learner_forward_backward_matches_reference(golden_dir, tag):
+    g = _load(golden_dir, f"learner_{tag}.npz")
+    size, heat, depth, B, seed = [int(x) for x in g["meta"]]
+    params = lo.fill_params(lo.param_shapes(22, depth), seed=seed)
+    batch = make_batch(B, size, seed + 100)
+    # eval mode
+    with torch.no_grad():
+        keep = {}
+        preds = lo.hybrid_forward(params, batch, [size, size], 22, depth, 0, training=False, keep=keep)
+    for k in ("joints_3d_abs", "corners_3d_abs", "joints_3d", "corners_3d", "2d_uvd", "boxroot_3d_abs", "box_rot_rotmat"):
+        np.testing.assert_allclose(preds[k].numpy(), g[f"eval.pred.{k}"], rtol=1e-4, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(keep["logits"][:, ::37, ::5, ::5].numpy(), g["eval.logits.sample"], rtol=1e-3, atol=1e-4)
+    # train mode + losses + grads
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+            for k, v in params.items()}
+    stats, keep = {}, {}
+    preds = lo.hybrid_forward(leaf, batch, [size, size], 22, depth, 0, training=True, stats=stats, keep=keep)
+    for k in ("joints_3d_abs", "corners_3d_abs", "2d_uvd", "box_rot_rotmat"):
+        np.testing.assert_allclose(preds[k].detach().numpy(), g[f"train.pred.{k}"], rtol=1e-4, atol=2e-5, err_msg=k)
+    for k in ("res_layer1", "res_layer2", "res_layer3", "res_layer4"):
+        np.testing.assert_allclose(keep[k].detach().mean(dim=(0, 2, 3)).numpy(), g[f"train.feat.{k}.mean_c"],
+                                   rtol=1e-3, atol=1e-4)
+    random.seed(seed + 7)
+    torch.manual_seed(seed + 7)
+    total, losses, _ = lo.criterion(preds, batch)
+    for k in ("joints_3d_loss", "corners_3d_loss", "joint_ord_loss", "part_ord_loss", "scene_ord_loss", "final_loss"):
+        np.testing.assert_allclose(losses[k].detach().numpy().reshape(-1), g[f"loss.{k}"].reshape(-1),
+                                   rtol=2e-4, atol=1e-7, err_msg=k)
+    total.backward()
+    names = [str(n) for n in g["grad.names"]]
+    ref = dict(zip(names, g["grad.norms"]))
+    for n in names:
+        got = float(leaf[n].grad.norm())
+        assert abs(got - ref[n]) <= 1e-2 * ref[n] + 1e-9, (n, got, ref[n])
+    assert leaf["backbone.fc.weight"].grad is None
+    np.testing.assert_allclose(leaf["hybrid_head.final_layer.bias"].grad.numpy(), g["grad.final_bias"], rtol=2e-3, atol=1e-9)
+    ref_s = g["grad.conv1.sample"]  # deepest gradient: fp32 round-off through 36 layers differs by reduction order
+    np.testing.assert_allclose(leaf["backbone.conv1.weight"].grad[::8, :, ::3, ::3].numpy(), ref_s,
+                               rtol=2e-2, atol=1e-2 * np.abs(ref_s).max())
+    np.testing.assert_allclose(stats["backbone.bn1.running_var"].numpy(), g["stat.bn1.running_var"], rtol=1e-5)
+    np.testing.assert_allclose(stats["backbone.layer4.2.bn2.running_var"].numpy(), g["stat.l4.2.bn2.running_var"], rtol=1e-4)
+    # optimiser step (clip 0.001 + Adam lr 5e-5)
+    names_g = [n for n in leaf if leaf[n].dtype.is_floating_point and getattr(leaf[n], "grad", None) is not None]
+    ps = [leaf[n].detach().clone() for n in names_g]
+    gs = [leaf[n].grad for n in names_g]
+    m = [torch.zeros_like(p) for p in ps]
+    v = [torch.zeros_like(p) for p in ps]
+    tn = lo.clip_and_adam(ps, gs, m, v, step=1)
+    np.testing.assert_allclose(float(tn), float(g["opt.total_norm"]), rtol=1e-3)
+    i = names_g.index("hybrid_head.final_layer.bias")
+    np.testing.assert_allclose((ps[i] - params["hybrid_head.final_layer.bias"]).numpy(), g["opt.final_bias.delta"],
+                               rtol=2e-2, atol=2e-7)
+
+
+def test_misc_helpers_match_reference(golden_dir):
+    g = _load(golden_dir, "misc.npz")
+    import pose_oracle as po
+    for i in range(len(g["affine.scale"])):
+        res = [224, 224] if i % 2 else [256, 256]
+        tot, post = po.get_affine_transform(g["affine.center"][i], float(g["affine.scale"][i]), [256.0, 256.0], res,
+                                            float(g["affine.rot"][i]))
+        np.testing.assert_allclose(tot, g["affine.total"][i], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(post, g["affine.post"][i], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(po.transform_coords(g["coords.pts"], g["affine.total"][0]), g["coords.out"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_array_equal(po.annot_center(g["coords.pts"]), g["annot.center"])
+    np.testing.assert_allclose(po.annot_scale(g["coords.pts"]), g["annot.scale"])
+    ids = [tuple(int(x) for x in r) for r in g["ccv.ids"]]
+    res = dict(zip(ids, g["ccv.vals"].tolist()))
+    w = lo.ccv_update_method_1(torch.ones(4, 288, 50), res, 0.1, 10.0)
+    np.testing.assert_allclose(np.array([float(w[i]) for i in res]), g["ccv.m1"], rtol=1e-6)
+    b, r, c = lo.ccv_row_col(torch.from_numpy(g["ccv.tidx"]), 288, 50)
+    np.testing.assert_array_equal(b.numpy(), g["ccv.bidx"])
+    np.testing.assert_array_equal(r.numpy(), g["ccv.ridx"])
+    np.testing.assert_array_equal(c.numpy(), g["ccv.cidx"])
+    for v, m in zip(g["view.vecs"], g["view.align"]):
+        np.testing.assert_allclose(po.align_mat(v), m, rtol=1e-9, atol=1e-12)
