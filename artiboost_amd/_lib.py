@@ -1,0 +1,70 @@
+"""ctypes binding of libartiboost_hip.so (the C ABI declared in include/artiboost_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is raised."""
+import ctypes
+import os
+import re
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libartiboost_hip.so")
+HEADER = os.path.join(HERE, "..", "include", "artiboost_hip.h")
+
+_lib = None
+
+DT_F32, DT_BF16 = 0, 1
+_DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16}
+
+
+def declared_symbols():
+    """Names of every function declared in include/artiboost_hip.h."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|void|int64_t|size_t)\s+(ab_\w+)\s*\(", txt)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m artiboost_amd.build` (there is no CPU fallback)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name in declared_symbols():
+            fn = getattr(_lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = ctypes.c_int
+    return _lib
+
+
+def dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype} (float32 or bfloat16 expected)")
+
+
+def ptr(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("artiboost_hip ops need device tensors (HIP); got a CPU tensor")
+    if not t.is_contiguous():
+        raise RuntimeError("artiboost_hip ops need contiguous tensors")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}" + (" (hipError)" if rc > 0 else " (argument error)"))
+
+
+def f(x):
+    return ctypes.c_float(float(x))
+
+
+def i(x):
+    return ctypes.c_int(int(x))

@@ -1,0 +1,80 @@
+"""GPU parity: HIP soft-argmax head (through the C ABI) vs the CPU oracle and vs the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import learner_oracle as lo
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(logits_nchw):
+    return logits_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("tag", ["tiny", "g224", "g256"])
+def test_head_vs_reference_golden(golden_dir, tag):
+    from artiboost_amd.head import softargmax3d
+    g = np.load(os.path.join(golden_dir, "head.npz"))
+    seed, B, C, D, H, W = [int(x) for x in g[f"{tag}.seed"]]
+    gen = torch.Generator().manual_seed(seed)
+    logits = 4.0 * torch.randn(B, C * D, H, W, generator=gen)
+    x = _nhwc(logits).cuda().requires_grad_(True)
+    uvd, conf = softargmax3d(x, C, D)
+    np.testing.assert_allclose(uvd.detach().cpu().numpy(), g[f"{tag}.uvd"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(conf.detach().cpu().numpy(), g[f"{tag}.conf"], rtol=2e-5, atol=1e-7)
+    gu = torch.from_numpy(g[f"{tag}.g_uvd"]).cuda()
+    gc = torch.from_numpy(g[f"{tag}.g_conf"]).cuda()
+    ((uvd * gu).sum() + (conf * gc).sum()).backward()
+    dl = x.grad.permute(0, 3, 1, 2).reshape(B, C, -1)[:, :, ::97].cpu().numpy()
+    ref = g[f"{tag}.dlogits.sample"]
+    np.testing.assert_allclose(dl, ref, rtol=2e-4, atol=1e-6 * np.abs(ref).max() + 1e-9)
+    np.testing.assert_allclose(float(x.grad.abs().sum()), float(g[f"{tag}.dlogits.abs_sum"]), rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-6), (torch.bfloat16, 3e-6)])
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1, 1), (3, 22, 28, 7, 5), (64, 22, 28, 32, 32), (2, 5, 9, 65, 3)])
+def test_head_vs_oracle(dtype, tol, shape):
+    """bf16 logits are upcast exactly, so the oracle is fed the same rounded values and the tolerance is the fp32 one."""
+    from artiboost_amd.head import softargmax3d
+    B, C, D, H, W = shape
+    gen = torch.Generator().manual_seed(B * 131 + C)
+    logits = (3.0 * torch.randn(B, C * D, H, W, generator=gen)).to(dtype)
+    ref_in = logits.float().requires_grad_(True)
+    uvd_r, conf_r = lo.softargmax3d(ref_in, C, D, H, W)
+    x = _nhwc(logits).cuda().requires_grad_(True)
+    uvd, conf = softargmax3d(x, C, D)
+    np.testing.assert_allclose(uvd.detach().cpu().numpy(), uvd_r.detach().numpy(), rtol=0, atol=tol)
+    np.testing.assert_allclose(conf.detach().cpu().numpy(), conf_r.detach().numpy(), rtol=3e-5, atol=1e-8)
+    gu = torch.randn(uvd_r.shape, generator=gen)
+    (uvd_r * gu).sum().backward()
+    (uvd * gu.cuda()).sum().backward()
+    got = x.grad.float().permute(0, 3, 1, 2).cpu().numpy()
+    ref = ref_in.grad.numpy()
+    scale = np.abs(ref).max() + 1e-12
+    atol = (1e-5 if dtype == torch.float32 else 1e-2) * scale   # bf16 output rounding: 2^-8 relative
+    np.testing.assert_allclose(got, ref, rtol=1e-4 if dtype == torch.float32 else 1e-2, atol=atol)
+
+
+def test_head_properties_full_size():
+    """Size-independent properties at the benchmark geometry (B=64, 22x28x32x32): shift invariance, one-hot peak,
+    uniform logits -> centre of mass of the grid."""
+    from artiboost_amd.head import softargmax3d
+    B, C, D, H, W = 64, 22, 28, 32, 32
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(B, H, W, C * D, generator=gen).cuda()
+    u0, c0 = softargmax3d(x, C, D)
+    u1, c1 = softargmax3d(x + 37.5, C, D)
+    np.testing.assert_allclose(u1.cpu().numpy(), u0.cpu().numpy(), atol=2e-6)
+    z = torch.zeros(B, H, W, C * D).cuda()
+    uz, cz = softargmax3d(z, C, D)
+    exp = np.array([(W - 1) / 2 / W, (H - 1) / 2 / H, (D - 1) / 2 / D], dtype=np.float32)
+    np.testing.assert_allclose(uz.cpu().numpy(), np.broadcast_to(exp, (B, C, 3)), atol=2e-6)
+    np.testing.assert_allclose(cz.cpu().numpy(), 1.0 / (D * H * W), rtol=1e-5)
+    peak = torch.full((B, H, W, C * D), -50.0)
+    peak[:, 5, 9, 3::D] = 50.0  # every class: d=3, h=5, w=9
+    up, cp = softargmax3d(peak.cuda(), C, D)
+    np.testing.assert_allclose(up.cpu().numpy(), np.broadcast_to(np.array([9 / W, 5 / H, 3 / D], np.float32), (B, C, 3)), atol=1e-6)
+    np.testing.assert_allclose(cp.cpu().numpy(), 1.0, rtol=1e-6)
