@@ -21,7 +21,13 @@ def declared_symbols():
     """Names of every function declared in include/artiboost_hip.h."""
     txt = open(HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|void|int64_t|size_t)\s+(ab_\w+)\s*\(", txt)))
+    return sorted(set(n for _, n in re.findall(r"\b(int|long|void|int64_t|size_t)\s+(ab_\w+)\s*\(", txt)))
+
+
+def _long_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\blong\s+(ab_\w+)\s*\(", txt))
 
 
 def lib():
@@ -30,9 +36,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -m artiboost_amd.build` (there is no CPU fallback)")
         _lib = ctypes.CDLL(LIB_PATH)
+        longs = _long_symbols()
         for name in declared_symbols():
             fn = getattr(_lib, name)  # AttributeError if a declared symbol is not exported
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_long if name in longs else ctypes.c_int
     return _lib
 
 
@@ -68,3 +75,7 @@ def f(x):
 
 def i(x):
     return ctypes.c_int(int(x))
+
+
+def l(x):
+    return ctypes.c_long(int(x))

@@ -1,0 +1,323 @@
+// Implicit-GEMM convolution on MFMA (gfx950), NHWC activations, K-contiguous ("OHWI") weights.
+//
+// One kernel covers: conv forward (any k/stride/pad), conv data-gradient (stride 1 and 2, by output parity class),
+// ConvTranspose forward (== data-gradient of the mirrored conv) and 1x1 / linear layers.  A launch computes
+//     Out[pix(m), j] = sum_{t < ntaps} sum_{c < Ca} A[apix(m, t), c] * Bw[j, koff[t] + c]   (+bias[j]) (+addend)
+// with m = (n, p, q) enumerating an output sub-grid.  M = N*P*Q rows, Cn columns, K = ntaps*Ca.
+//
+// Tiling: BM x BN output tile per 256-thread workgroup (4 waves as 2x2), 64 bytes of K per step (32 bf16 / 16 f32),
+// register-staged double-buffered LDS with 80-byte row pitch (conflict-free ds_read_b128 for the MFMA fragments),
+// v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact f32 path used by the parity tests).
+// Epilogue: optional bias, optional addend (residual gradient), optional per-column (sum, sum^2) partials for the
+// following training-mode BatchNorm (deterministic: one partial row per M-tile, reduced by bn_finalize).
+#include "common.h"
+
+#define CG_MAXTAPS 16
+#define CG_PITCH 80          // bytes per LDS row (64 data + 16 pad)
+
+struct ConvGemmArgs {
+    const void* A; const void* Bw; void* Out;
+    const float* bias; const void* addend; float* stats;   // stats: [gridM][Cn][2]
+    int N, Ha, Wa, Ca;          // A tensor dims (Ca = channel pitch in elements)
+    int P, Q;                   // output sub-grid
+    int Ho, Wo, Cn;             // full output tensor dims
+    int out_sh, out_sw, out_oh, out_ow;
+    int a_sh, a_sw;
+    int ntaps, cpt;             // cpt = K-steps per tap (Ca / BK, or 1 for the padded stem rows)
+    int ktot;                   // Bw row length in elements
+    int M;
+    int relu;                   // apply ReLU in the epilogue (linear layers)
+    int8_t dh[CG_MAXTAPS], dw[CG_MAXTAPS];
+    int koff[CG_MAXTAPS];
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Elem;
+template <> struct Elem<bf16_t> { static constexpr int BK = 32; };
+template <> struct Elem<float> { static constexpr int BK = 16; };
+
+template <typename T>
+__device__ __forceinline__ void mma_chunk(f32x16& acc, const uint4& a, const uint4& b);
+template <>
+__device__ __forceinline__ void mma_chunk<bf16_t>(f32x16& acc, const uint4& a, const uint4& b) {
+    bf16x8 av = __builtin_bit_cast(bf16x8, a), bv = __builtin_bit_cast(bf16x8, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<float>(f32x16& acc, const uint4& a, const uint4& b) {
+    // lanes 0-31 hold k = 0..3 of the chunk pair, lanes 32-63 hold k = 4..7: four K=2 MFMAs cover all eight
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs g) {
+    constexpr int BK = Elem<T>::BK;
+    constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave in each direction
+    constexpr int RA = BM / 64, RB = BN / 64;   // staging rows per thread (64 rows per pass)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * CG_PITCH + BM * 4 + 2 * 2 * BN * 4];
+    constexpr int BUFSZ = (BM + BN) * CG_PITCH;
+#define SA(buf) (smem + (buf) * BUFSZ)
+#define SB(buf) (smem + (buf) * BUFSZ + BM * CG_PITCH)
+    int* s_outpix = (int*)(smem + 2 * (BM + BN) * CG_PITCH);
+    float* s_stat = (float*)(s_outpix + BM);    // [2 (wave_m)][BN][2]
+
+    // XCD-friendly tile order: consecutive workgroups walk the N dimension first so they share the A tile in L2
+    const int tiles_n = (g.Cn + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int chunk = tid & 3, srow = tid >> 2;
+    const T* __restrict__ A = (const T*)g.A;
+    const T* __restrict__ Bw = (const T*)g.Bw;
+    const int PQ = g.P * g.Q;
+
+    // per-thread staging rows
+    int a_h[RA], a_w[RA]; long a_base[RA]; bool a_ok[RA];
+#pragma unroll
+    for (int s = 0; s < RA; ++s) {
+        int m = m0 + srow + 64 * s;
+        a_ok[s] = m < g.M;
+        int mm = a_ok[s] ? m : 0;
+        int n = mm / PQ, r = mm - n * PQ;
+        int p = r / g.Q, q = r - p * g.Q;
+        a_h[s] = p * g.a_sh; a_w[s] = q * g.a_sw;
+        a_base[s] = (long)n * g.Ha * g.Wa;
+        if (chunk == 0) {
+            int op = (n * g.Ho + p * g.out_sh + g.out_oh) * g.Wo + q * g.out_sw + g.out_ow;
+            s_outpix[srow + 64 * s] = a_ok[s] ? op : -1;
+        }
+    }
+    long b_off[RB]; bool b_ok[RB];
+#pragma unroll
+    for (int s = 0; s < RB; ++s) {
+        int j = n0 + srow + 64 * s;
+        b_ok[s] = j < g.Cn;
+        b_off[s] = (long)(b_ok[s] ? j : 0) * g.ktot;
+    }
+    const int nsteps = g.ntaps * g.cpt;
+    constexpr int CE = 16 / sizeof(T);   // elements per 16-byte chunk
+
+    uint4 ra[RA], rb[RB];
+    auto gload = [&](int step) {
+        int t = step / g.cpt, c0 = (step - t * g.cpt) * BK + chunk * CE;
+        int dh = g.dh[t], dw = g.dw[t], ko = g.koff[t];
+#pragma unroll
+        for (int s = 0; s < RA; ++s) {
+            int hi = a_h[s] + dh, wi = a_w[s] + dw;
+            bool ok = a_ok[s] && (unsigned)hi < (unsigned)g.Ha && (unsigned)wi < (unsigned)g.Wa;
+            ra[s] = make_uint4(0, 0, 0, 0);
+            if (ok) ra[s] = *(const uint4*)(A + ((a_base[s] + (long)hi * g.Wa + wi) * g.Ca + c0));
+        }
+#pragma unroll
+        for (int s = 0; s < RB; ++s) {
+            rb[s] = make_uint4(0, 0, 0, 0);
+            if (b_ok[s]) rb[s] = *(const uint4*)(Bw + (b_off[s] + ko + c0));
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < RA; ++s) *(uint4*)(SA(buf) + (srow + 64 * s) * CG_PITCH + chunk * 16) = ra[s];
+#pragma unroll
+        for (int s = 0; s < RB; ++s) *(uint4*)(SB(buf) + (srow + 64 * s) * CG_PITCH + chunk * 16) = rb[s];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int frow = lane & 31, fhalf = lane >> 5;
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < nsteps) gload(step + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *(const uint4*)(SA(cur) + (wave_m * TM * 32 + i * 32 + frow) * CG_PITCH + (kk * 2 + fhalf) * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *(const uint4*)(SB(cur) + (wave_n * TN * 32 + j * 32 + frow) * CG_PITCH + (kk * 2 + fhalf) * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mma_chunk<T>(acc[i][j], fa[i], fb[j]);
+        }
+        if (step + 1 < nsteps) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    T* __restrict__ Out = (T*)g.Out;
+    const T* __restrict__ Add = (const T*)g.addend;
+    float csum[TN], csq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wave_n * TN * 32 + j * 32 + (lane & 31);
+        const bool cok = col < g.Cn;
+        const float bj = (g.bias && cok) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = wave_m * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                int op = s_outpix[row];
+                float v = acc[i][j][r] + bj;
+                if (op >= 0 && cok) {
+                    long o = (long)op * g.Cn + col;
+                    if (Add) v += ld_f32(Add + o);
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    st_f32(Out + o, v);
+                    csum[j] += v; csq[j] += v * v;
+                }
+            }
+        }
+    }
+    if (g.stats) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+            float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+            if (lane < 32) {
+                int cl = wave_n * TN * 32 + j * 32 + lane;
+                s_stat[(wave_m * BN + cl) * 2] = s;
+                s_stat[(wave_m * BN + cl) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            int col = n0 + c;
+            if (col < g.Cn) {
+                float s = s_stat[c * 2] + s_stat[(BN + c) * 2];
+                float q = s_stat[c * 2 + 1] + s_stat[(BN + c) * 2 + 1];
+                g.stats[((long)tile_m * g.Cn + col) * 2] = s;
+                g.stats[((long)tile_m * g.Cn + col) * 2 + 1] = q;
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_conv_gemm(const ConvGemmArgs& g, int bm, int bn, hipStream_t st) {
+    int tiles = ((g.M + bm - 1) / bm) * ((g.Cn + bn - 1) / bn);
+    if (bm == 128 && bn == 128) conv_gemm_kernel<T, 128, 128><<<tiles, 256, 0, st>>>(g);
+    else if (bm == 128 && bn == 64) conv_gemm_kernel<T, 128, 64><<<tiles, 256, 0, st>>>(g);
+    else if (bm == 64 && bn == 128) conv_gemm_kernel<T, 64, 128><<<tiles, 256, 0, st>>>(g);
+    else conv_gemm_kernel<T, 64, 64><<<tiles, 256, 0, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+static void pick_tile(int M, int Cn, int* bm, int* bn) {
+    // fill >= ~2 waves of the 256 CUs when the problem allows; smaller tiles for the small late layers
+    *bn = (Cn >= 128) ? 128 : 64;
+    *bm = 128;
+    long tiles = (long)((M + 127) / 128) * ((Cn + *bn - 1) / *bn);
+    if (tiles < 512) { *bm = 64; tiles = (long)((M + 63) / 64) * ((Cn + *bn - 1) / *bn); }
+    if (tiles < 512 && *bn == 128) { *bn = 64; }
+}
+
+extern "C" int ab_conv_gemm_mtiles(int M, int Cn) {
+    int bm, bn; pick_tile(M, Cn, &bm, &bn);
+    return (M + bm - 1) / bm;
+}
+
+static int run(ConvGemmArgs& g, int dtype, hipStream_t st) {
+    int bm, bn; pick_tile(g.M, g.Cn, &bm, &bn);
+    if (dtype == AB_DT_BF16) return launch_conv_gemm<bf16_t>(g, bm, bn, st);
+    if (dtype == AB_DT_F32) return launch_conv_gemm<float>(g, bm, bn, st);
+    return AB_EINVAL;
+}
+
+static int bk_of(int dtype) { return dtype == AB_DT_BF16 ? 32 : 16; }
+
+extern "C" int ab_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int H, int W, int Cin, int Cout,
+                             int kh, int kw, int stride, int pad, const float* bias, float* stats, int relu,
+                             void* stream) {
+    if (!x || !w || !y) return AB_EINVAL;
+    if (kh * kw > CG_MAXTAPS || Cin % bk_of(dtype)) return AB_ESHAPE;
+    ConvGemmArgs g = {};
+    g.A = x; g.Bw = w; g.Out = y; g.bias = bias; g.stats = stats; g.relu = relu;
+    g.N = N; g.Ha = H; g.Wa = W; g.Ca = Cin;
+    g.Ho = (H + 2 * pad - kh) / stride + 1; g.Wo = (W + 2 * pad - kw) / stride + 1; g.Cn = Cout;
+    g.P = g.Ho; g.Q = g.Wo; g.out_sh = g.out_sw = 1; g.a_sh = g.a_sw = stride;
+    g.ntaps = kh * kw; g.cpt = Cin / bk_of(dtype); g.ktot = kh * kw * Cin; g.M = N * g.P * g.Q;
+    for (int i = 0; i < kh; ++i) for (int j = 0; j < kw; ++j) {
+        g.dh[i * kw + j] = (int8_t)(i - pad); g.dw[i * kw + j] = (int8_t)(j - pad); g.koff[i * kw + j] = (i * kw + j) * Cin;
+    }
+    return run(g, dtype, as_stream(stream));
+}
+
+// Stem: 7x7 / stride 2 / pad 3 on a zero-bordered NHWC4 image [N, H+6, W+8, 4] (3 px border, +2 px right slack):
+// each kh contributes one contiguous run of 8 px * 4 ch = 32 elements, so no bounds checks and K = 7*32.
+// w: [Cout][7][8][4] (px 7 and ch 3 zero).  Output NHWC [N, H/2, W/2, Cout].
+extern "C" int ab_conv2d_stem_fwd(const void* xpad, const void* w, void* y, int dtype, int N, int H, int W, int Cout,
+                                  float* stats, void* stream) {
+    if (!xpad || !w || !y) return AB_EINVAL;
+    if ((H & 1) || (W & 1)) return AB_ESHAPE;
+    ConvGemmArgs g = {};
+    g.A = xpad; g.Bw = w; g.Out = y; g.stats = stats;
+    g.N = N; g.Ha = H + 6; g.Wa = W + 8; g.Ca = 4;
+    g.Ho = H / 2; g.Wo = W / 2; g.Cn = Cout; g.P = g.Ho; g.Q = g.Wo; g.out_sh = g.out_sw = 1; g.a_sh = g.a_sw = 2;
+    const int bk = bk_of(dtype), per = 32 / bk;     // K-steps per kh row (1 for bf16, 2 for f32)
+    g.ntaps = 7 * per; g.cpt = 1; g.ktot = 7 * 32; g.M = N * g.P * g.Q;
+    if (g.ntaps > CG_MAXTAPS) return AB_ESHAPE;
+    for (int i = 0; i < 7; ++i) for (int s = 0; s < per; ++s) {
+        g.dh[i * per + s] = (int8_t)i; g.dw[i * per + s] = (int8_t)(s * (bk / 4)); g.koff[i * per + s] = i * 32 + s * bk;
+    }
+    return run(g, dtype, as_stream(stream));
+}
+
+// Data gradient of conv2d(x, w, stride, pad): dx[N,H,W,Cin] from dy[N,Ho,Wo,Cout] and wt = [Cin][kh][kw][Cout].
+// Also == ConvTranspose2d forward (x:=dy).  stride 1 or 2; for stride 2 one launch per output parity class.
+// addend (same shape as dx, may be NULL) is added in the epilogue (residual-branch gradient).
+extern "C" int ab_conv2d_dgrad(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int Cin,
+                               int Cout, int kh, int kw, int stride, int pad, const void* addend, float* stats,
+                               void* stream) {
+    if (!dy || !wt || !dx) return AB_EINVAL;
+    if (Cout % bk_of(dtype) || (stride != 1 && stride != 2)) return AB_ESHAPE;
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (stride == 2 && ((H & 1) || (W & 1))) return AB_ESHAPE;
+    if (stats && stride != 1) return AB_ESHAPE;   // BN partials are per M-tile of ONE launch
+    for (int a = 0; a < stride; ++a) for (int b = 0; b < stride; ++b) {
+        ConvGemmArgs g = {};
+        g.A = dy; g.Bw = wt; g.Out = dx; g.addend = addend; g.stats = stats;
+        g.N = N; g.Ha = Ho; g.Wa = Wo; g.Ca = Cout;
+        g.Ho = H; g.Wo = W; g.Cn = Cin;
+        g.P = H / stride; g.Q = W / stride; g.out_sh = g.out_sw = stride; g.out_oh = a; g.out_ow = b;
+        g.a_sh = g.a_sw = 1; g.cpt = Cout / bk_of(dtype); g.ktot = kh * kw * Cout; g.M = N * g.P * g.Q;
+        int nt = 0;
+        for (int i = 0; i < kh; ++i) {
+            if ((a + pad - i) % stride) continue;       // (hi + pad - i) must be divisible by stride
+            for (int j = 0; j < kw; ++j) {
+                if ((b + pad - j) % stride) continue;
+                if (nt >= CG_MAXTAPS) return AB_ESHAPE;
+                // floor division also for negative numerators (they are multiples of stride here)
+                g.dh[nt] = (int8_t)((a + pad - i) / stride); g.dw[nt] = (int8_t)((b + pad - j) / stride);
+                g.koff[nt] = (i * kw + j) * Cout; ++nt;
+            }
+        }
+        g.ntaps = nt;
+        if (nt == 0) {   // this parity class receives no gradient (1x1 stride-2): write zeros / the addend
+            g.ntaps = 1; g.cpt = 1; g.dh[0] = 127; g.dw[0] = 127; g.koff[0] = 0;   // always out of bounds -> zero rows
+        }
+        int rc = run(g, dtype, as_stream(stream));
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -1,0 +1,445 @@
+// HBM-bound NHWC elementwise / reduction kernels around the conv stack: training-mode BatchNorm (statistics, apply,
+// backward), ReLU and residual fusion, 3x3/2 max-pool, global average pool, precision packing.
+// All tensors are [M = N*H*W pixels][C channels] with C % 8 == 0; every access is a 16-byte vector per lane.
+#include "common.h"
+
+template <typename T> struct Vec;
+template <> struct Vec<float> { static constexpr int N = 4; };
+template <> struct Vec<bf16_t> { static constexpr int N = 8; };
+
+template <typename T> __device__ __forceinline__ void vload(const T* p, float* f);
+template <> __device__ __forceinline__ void vload<float>(const float* p, float* f) {
+    float4 v = *(const float4*)p; f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <> __device__ __forceinline__ void vload<bf16_t>(const bf16_t* p, float* f) {
+    uint4 v = *(const uint4*)p;
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ void vstore(T* p, const float* f);
+template <> __device__ __forceinline__ void vstore<float>(float* p, const float* f) {
+    *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+}
+template <> __device__ __forceinline__ void vstore<bf16_t>(bf16_t* p, const float* f) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(f[2 * i]) | ((uint32_t)f32_to_bf16(f[2 * i + 1]) << 16);
+    *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+#define RED_ROWS_PER_BLOCK 2048
+
+// ---------------------------------------------------------------- column partial sums: (sum x, sum x^2) per block
+template <typename T>
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x, long M, int C, float* __restrict__ part) {
+    constexpr int V = Vec<T>::N;
+    const int vc = C / V;                  // vector lanes along channels
+    const int rl = 256 / vc;               // row lanes
+    const int cv = threadIdx.x % vc, rr = threadIdx.x / vc;
+    long r0 = (long)blockIdx.x * RED_ROWS_PER_BLOCK;
+    long r1 = r0 + RED_ROWS_PER_BLOCK; if (r1 > M) r1 = M;
+    float s[V], q[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    if (rr < rl)
+        for (long r = r0 + rr; r < r1; r += rl) {
+            float f[V]; vload<T>(x + r * C + cv * V, f);
+#pragma unroll
+            for (int i = 0; i < V; ++i) { s[i] += f[i]; q[i] += f[i] * f[i]; }
+        }
+    extern __shared__ float sm[];          // [rl][C][2]
+    if (rr < rl)
+#pragma unroll
+        for (int i = 0; i < V; ++i) { sm[(rr * C + cv * V + i) * 2] = s[i]; sm[(rr * C + cv * V + i) * 2 + 1] = q[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < rl; ++k) { a += sm[(k * C + c) * 2]; b += sm[(k * C + c) * 2 + 1]; }
+        part[((long)blockIdx.x * C + c) * 2] = a; part[((long)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+}
+
+// ---------------------------------------------------------------- BN finalize: partials -> scale/shift, saved stats
+// bnp: float [4][C] = scale (gamma*invstd), shift, mean, invstd.  running stats updated in place when non-null.
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, long count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ bnp) {
+    // block: 256 threads = 64 channels x 4 part-lanes
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int k = pl; k < nparts; k += 4) { s += part[((long)k * C + c) * 2]; q += part[((long)k * C + c) * 2 + 1]; }
+    __shared__ double sm[4][64][2];
+    sm[pl][threadIdx.x & 63][0] = s; sm[pl][threadIdx.x & 63][1] = q;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int k = 1; k < 4; ++k) { s += sm[k][threadIdx.x][0]; q += sm[k][threadIdx.x][1]; }
+        double mean = s / (double)count;
+        double var = q / (double)count - mean * mean; if (var < 0) var = 0;
+        float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        float sc = gamma[c] * invstd;
+        bnp[c] = sc; bnp[C + c] = beta[c] - (float)mean * sc; bnp[2 * C + c] = (float)mean; bnp[3 * C + c] = invstd;
+        if (running_mean) {
+            double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        }
+    }
+}
+
+// eval-mode: scale/shift from running statistics
+__global__ void bn_eval_params_kernel(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* bnp) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float invstd = 1.f / sqrtf(rv[c] + eps);
+    float sc = gamma[c] * invstd;
+    bnp[c] = sc; bnp[C + c] = beta[c] - rm[c] * sc; bnp[2 * C + c] = rm[c]; bnp[3 * C + c] = invstd;
+}
+
+// ---------------------------------------------------------------- BN apply (+residual) (+ReLU)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res,
+                                                       const float* __restrict__ bnp, long nvec, int C, int relu,
+                                                       T* __restrict__ out) {
+    constexpr int V = Vec<T>::N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        long e = i * V; int c = (int)(e % C);
+        float f[V]; vload<T>(y + e, f);
+        float r[V];
+        if (res) vload<T>(res + e, r);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float v = f[k] * bnp[c + k] + bnp[C + c + k];
+            if (res) v += r[k];
+            if (relu) v = fmaxf(v, 0.f);
+            f[k] = v;
+        }
+        vstore<T>(out + e, f);
+    }
+}
+
+// ---------------------------------------------------------------- BN backward
+// pass 1: dz = dout * (out > 0 if relu); partial sums of dz and dz * xhat per channel
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                            const T* __restrict__ y, const float* __restrict__ bnp,
+                                                            long M, int C, int relu, float* __restrict__ part) {
+    constexpr int V = Vec<T>::N;
+    const int vc = C / V, rl = 256 / vc;
+    const int cv = threadIdx.x % vc, rr = threadIdx.x / vc;
+    long r0 = (long)blockIdx.x * RED_ROWS_PER_BLOCK;
+    long r1 = r0 + RED_ROWS_PER_BLOCK; if (r1 > M) r1 = M;
+    float s[V], q[V], mean[V], istd[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; mean[i] = bnp[2 * C + cv * V + i]; istd[i] = bnp[3 * C + cv * V + i]; }
+    if (rr < rl)
+        for (long r = r0 + rr; r < r1; r += rl) {
+            long e = r * C + cv * V;
+            float g[V], o[V], yy[V];
+            vload<T>(dout + e, g); vload<T>(y + e, yy);
+            if (relu) vload<T>(out + e, o);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float dz = (relu && !(o[i] > 0.f)) ? 0.f : g[i];
+                s[i] += dz; q[i] += dz * ((yy[i] - mean[i]) * istd[i]);
+            }
+        }
+    extern __shared__ float sm[];
+    if (rr < rl)
+#pragma unroll
+        for (int i = 0; i < V; ++i) { sm[(rr * C + cv * V + i) * 2] = s[i]; sm[(rr * C + cv * V + i) * 2 + 1] = q[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < rl; ++k) { a += sm[(k * C + c) * 2]; b += sm[(k * C + c) * 2 + 1]; }
+        part[((long)blockIdx.x * C + c) * 2] = a; part[((long)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+}
+
+// reduce partials -> dgamma, dbeta (written to the flat grad buffer) and bwdp[2][C] = (sum dz, sum dz*xhat)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ bwdp) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int k = pl; k < nparts; k += 4) { s += part[((long)k * C + c) * 2]; q += part[((long)k * C + c) * 2 + 1]; }
+    __shared__ double sm[4][64][2];
+    sm[pl][threadIdx.x & 63][0] = s; sm[pl][threadIdx.x & 63][1] = q;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        for (int k = 1; k < 4; ++k) { s += sm[k][threadIdx.x][0]; q += sm[k][threadIdx.x][1]; }
+        dbeta[c] = (float)s; dgamma[c] = (float)q;
+        bwdp[c] = (float)s; bwdp[C + c] = (float)q;
+    }
+}
+
+// pass 2: dy = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat));  optionally also writes dz (residual gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                           const T* __restrict__ y, const float* __restrict__ bnp,
+                                                           const float* __restrict__ bwdp, long nvec, int C, long M,
+                                                           int relu, T* __restrict__ dy, T* __restrict__ dz_out) {
+    constexpr int V = Vec<T>::N;
+    const float invM = 1.f / (float)M;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        long e = i * V; int c = (int)(e % C);
+        float g[V], o[V], yy[V], d[V];
+        vload<T>(dout + e, g); vload<T>(y + e, yy);
+        if (relu) vload<T>(out + e, o);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float dz = (relu && !(o[k] > 0.f)) ? 0.f : g[k];
+            float xhat = (yy[k] - bnp[2 * C + c + k]) * bnp[3 * C + c + k];
+            d[k] = bnp[c + k] * (dz - bwdp[c + k] * invM - xhat * bwdp[C + c + k] * invM);   // bnp[c] = gamma*invstd
+            g[k] = dz;
+        }
+        vstore<T>(dy + e, d);
+        if (dz_out) vstore<T>(dz_out + e, g);
+    }
+}
+
+// ---------------------------------------------------------------- elementwise add (gradient accumulation)
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, long nvec, T* __restrict__ out) {
+    constexpr int V = Vec<T>::N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        float x[V], y[V]; vload<T>(a + i * V, x); vload<T>(b + i * V, y);
+#pragma unroll
+        for (int k = 0; k < V; ++k) x[k] += y[k];
+        vstore<T>(out + i * V, x);
+    }
+}
+
+// ---------------------------------------------------------------- 3x3 / stride 2 / pad 1 max-pool (resnet.py:157)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C,
+                                                          T* __restrict__ out) {
+    constexpr int V = Vec<T>::N;
+    const int Ho = H / 2, Wo = W / 2, vc = C / V;
+    long nvec = (long)N * Ho * Wo * vc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        int cv = (int)(i % vc); long pix = i / vc;
+        int wo = (int)(pix % Wo); long t = pix / Wo; int ho = (int)(t % Ho); int n = (int)(t / Ho);
+        float m[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = -INFINITY;
+        for (int dh = -1; dh <= 1; ++dh) {
+            int h = ho * 2 + dh; if ((unsigned)h >= (unsigned)H) continue;
+            for (int dw = -1; dw <= 1; ++dw) {
+                int w = wo * 2 + dw; if ((unsigned)w >= (unsigned)W) continue;
+                float f[V]; vload<T>(x + (((long)n * H + h) * W + w) * C + cv * V, f);
+#pragma unroll
+                for (int k = 0; k < V; ++k) m[k] = fmaxf(m[k], f[k]);
+            }
+        }
+        vstore<T>(out + i * V, m);
+    }
+}
+// backward: dx[h,w] = sum over windows containing (h,w) whose FIRST maximum (row-major scan, torch semantics) is (h,w)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dout, int N,
+                                                          int H, int W, int C, T* __restrict__ dx) {
+    constexpr int V = Vec<T>::N;
+    const int Ho = H / 2, Wo = W / 2, vc = C / V;
+    long nvec = (long)N * H * W * vc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        int cv = (int)(i % vc); long pix = i / vc;
+        int w = (int)(pix % W); long t = pix / W; int h = (int)(t % H); int n = (int)(t / H);
+        float xc[V], acc[V];
+        vload<T>(x + i * V, xc);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = 0.f;
+        // windows (ho, wo) with ho*2-1 <= h <= ho*2+1
+        for (int ho = (h) / 2; ho <= (h + 1) / 2; ++ho) {
+            if (ho >= Ho) continue;
+            for (int wo = (w) / 2; wo <= (w + 1) / 2; ++wo) {
+                if (wo >= Wo) continue;
+                bool first[V];
+#pragma unroll
+                for (int k = 0; k < V; ++k) first[k] = true;
+                for (int dh = -1; dh <= 1; ++dh) {
+                    int hh = ho * 2 + dh; if ((unsigned)hh >= (unsigned)H) continue;
+                    for (int dw = -1; dw <= 1; ++dw) {
+                        int ww = wo * 2 + dw; if ((unsigned)ww >= (unsigned)W) continue;
+                        if (hh == h && ww == w) continue;
+                        float f[V]; vload<T>(x + (((long)n * H + hh) * W + ww) * C + cv * V, f);
+                        bool before = (hh < h) || (hh == h && ww < w);
+#pragma unroll
+                        for (int k = 0; k < V; ++k) if (before ? (f[k] >= xc[k]) : (f[k] > xc[k])) first[k] = false;
+                    }
+                }
+                float g[V]; vload<T>(dout + (((long)n * Ho + ho) * Wo + wo) * C + cv * V, g);
+#pragma unroll
+                for (int k = 0; k < V; ++k) if (first[k]) acc[k] += g[k];
+            }
+        }
+        vstore<T>(dx + i * V, acc);
+    }
+}
+
+// ---------------------------------------------------------------- global average pool (resnet.py:219) fwd / bwd
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ out) {
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += ld_f32(x + ((long)n * HW + p) * C + c);
+        out[(long)n * C + c] = s / (float)HW;
+    }
+}
+// dx[n,p,c] (+)= g[n,c] / HW
+template <typename T>
+__global__ void avgpool_bwd_kernel(const float* __restrict__ g, int HW, int C, T* __restrict__ dx, int accumulate) {
+    const int n = blockIdx.x;
+    for (int i = threadIdx.x; i < HW * C; i += blockDim.x) {
+        int c = i % C;
+        float v = g[(long)n * C + c] / (float)HW;
+        long o = (long)n * HW * C + i;
+        if (accumulate) v += ld_f32(dx + o);
+        st_f32(dx + o, v);
+    }
+}
+
+// ---------------------------------------------------------------- precision / layout packing
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, long n, bf16_t* __restrict__ dst) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = f32_to_bf16(src[i]);
+}
+// src [O][K][I] (OHWI, K = kh*kw) -> dst [I][K][O], optionally converting to bf16
+template <typename T>
+__global__ void transpose_oki_kernel(const float* __restrict__ src, int O, int K, int I, T* __restrict__ dst) {
+    long n = (long)O * K * I;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        int o = (int)(e % O); long t = e / O; int k = (int)(t % K); int i = (int)(t / K);
+        st_f32(dst + e, src[((long)o * K + k) * I + i]);
+    }
+}
+// image NCHW float [N,3,H,W] -> zero-bordered NHWC4 [N, H+6, W+8, 4] in T (border 3 px, channel 3 = 0)
+template <typename T>
+__global__ void image_pad_kernel(const float* __restrict__ img, int N, int H, int W, T* __restrict__ out) {
+    const int Hp = H + 6, Wp = W + 8;
+    long n = (long)N * Hp * Wp;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        int wp = (int)(e % Wp); long t = e / Wp; int hp = (int)(t % Hp); int b = (int)(t / Hp);
+        int h = hp - 3, w = wp - 3;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W)
+            for (int c = 0; c < 3; ++c) v[c] = img[(((long)b * 3 + c) * H + h) * W + w];
+        for (int c = 0; c < 4; ++c) st_f32(out + e * 4 + c, v[c]);
+    }
+}
+
+// ================================================================ C ABI
+static inline int grid_for(long nvec) { long b = (nvec + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+#define DISPATCH(dtype, CALL_F, CALL_B) do { if ((dtype) == AB_DT_F32) { CALL_F; } else if ((dtype) == AB_DT_BF16) { CALL_B; } else return AB_EINVAL; } while (0)
+
+extern "C" int ab_col_stats_nparts(long M) { return (int)((M + RED_ROWS_PER_BLOCK - 1) / RED_ROWS_PER_BLOCK); }
+
+extern "C" int ab_col_stats(const void* x, int dtype, long M, int C, float* part, void* stream) {
+    if (!x || !part) return AB_EINVAL;
+    int V = dtype == AB_DT_F32 ? 4 : 8;
+    if (C % V || C / V > 256) return AB_ESHAPE;
+    int np = ab_col_stats_nparts(M); int rl = 256 / (C / V); size_t sh = (size_t)rl * C * 2 * 4;
+    DISPATCH(dtype, (col_stats_kernel<float><<<np, 256, sh, as_stream(stream)>>>((const float*)x, M, C, part)),
+             (col_stats_kernel<bf16_t><<<np, 256, sh, as_stream(stream)>>>((const bf16_t*)x, M, C, part)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_bn_finalize(const float* part, int nparts, int C, long count, const float* gamma, const float* beta,
+                              float eps, float momentum, float* running_mean, float* running_var, float* bnp,
+                              void* stream) {
+    if (!part || !gamma || !beta || !bnp) return AB_EINVAL;
+    bn_finalize_kernel<<<(C + 63) / 64, 256, 0, as_stream(stream)>>>(part, nparts, C, count, gamma, beta, eps, momentum,
+                                                                    running_mean, running_var, bnp);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_bn_eval_params(int C, const float* gamma, const float* beta, const float* rm, const float* rv,
+                                 float eps, float* bnp, void* stream) {
+    if (!gamma || !beta || !rm || !rv || !bnp) return AB_EINVAL;
+    bn_eval_params_kernel<<<(C + 255) / 256, 256, 0, as_stream(stream)>>>(C, gamma, beta, rm, rv, eps, bnp);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_bn_apply(const void* y, const void* res, const float* bnp, int dtype, long M, int C, int relu,
+                           void* out, void* stream) {
+    if (!y || !bnp || !out) return AB_EINVAL;
+    int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V) return AB_ESHAPE;
+    long nvec = M * C / V;
+    DISPATCH(dtype, (bn_apply_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)y, (const float*)res, bnp, nvec, C, relu, (float*)out)),
+             (bn_apply_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)y, (const bf16_t*)res, bnp, nvec, C, relu, (bf16_t*)out)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C,
+                         int relu, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out,
+                         void* stream) {
+    if (!dout || !y || !bnp || !part || !bwdp || !dgamma || !dbeta || !dy || (relu && !out)) return AB_EINVAL;
+    int V = dtype == AB_DT_F32 ? 4 : 8;
+    if (C % V || C / V > 256) return AB_ESHAPE;
+    int np = ab_col_stats_nparts(M); int rl = 256 / (C / V); size_t sh = (size_t)rl * C * 2 * 4;
+    hipStream_t st = as_stream(stream);
+    DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, part)),
+             (bn_bwd_reduce_kernel<bf16_t><<<np, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, part)));
+    AB_LAUNCH_CHECK();
+    bn_bwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(part, np, C, dgamma, dbeta, bwdp);
+    AB_LAUNCH_CHECK();
+    long nvec = M * C / V;
+    DISPATCH(dtype, (bn_bwd_apply_kernel<float><<<grid_for(nvec), 256, 0, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, bwdp, nvec, C, M, relu, (float*)dy, (float*)dz_out)),
+             (bn_bwd_apply_kernel<bf16_t><<<grid_for(nvec), 256, 0, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, bwdp, nvec, C, M, relu, (bf16_t*)dy, (bf16_t*)dz_out)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_add(const void* a, const void* b, int dtype, long n, void* out, void* stream) {
+    int V = dtype == AB_DT_F32 ? 4 : 8; if (n % V) return AB_ESHAPE;
+    long nvec = n / V;
+    DISPATCH(dtype, (add_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)a, (const float*)b, nvec, (float*)out)),
+             (add_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)a, (const bf16_t*)b, nvec, (bf16_t*)out)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* stream) {
+    int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
+    long nvec = (long)N * (H / 2) * (W / 2) * C / V;
+    DISPATCH(dtype, (maxpool_fwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)x, N, H, W, C, (float*)out)),
+             (maxpool_fwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)x, N, H, W, C, (bf16_t*)out)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+extern "C" int ab_maxpool3x3s2_bwd(const void* x, const void* dout, int dtype, int N, int H, int W, int C, void* dx,
+                                   void* stream) {
+    int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
+    long nvec = (long)N * H * W * C / V;
+    DISPATCH(dtype, (maxpool_bwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)x, (const float*)dout, N, H, W, C, (float*)dx)),
+             (maxpool_bwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)x, (const bf16_t*)dout, N, H, W, C, (bf16_t*)dx)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, float* out, void* stream) {
+    DISPATCH(dtype, (avgpool_fwd_kernel<float><<<N, 256, 0, as_stream(stream)>>>((const float*)x, HW, C, out)),
+             (avgpool_fwd_kernel<bf16_t><<<N, 256, 0, as_stream(stream)>>>((const bf16_t*)x, HW, C, out)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+extern "C" int ab_avgpool_bwd(const float* g, int dtype, int N, int HW, int C, void* dx, int accumulate, void* stream) {
+    DISPATCH(dtype, (avgpool_bwd_kernel<float><<<N, 256, 0, as_stream(stream)>>>(g, HW, C, (float*)dx, accumulate)),
+             (avgpool_bwd_kernel<bf16_t><<<N, 256, 0, as_stream(stream)>>>(g, HW, C, (bf16_t*)dx, accumulate)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_cast_f32_bf16(const float* src, long n, void* dst, void* stream) {
+    cast_f32_bf16_kernel<<<grid_for(n), 256, 0, as_stream(stream)>>>(src, n, (bf16_t*)dst);
+    AB_LAUNCH_CHECK(); return 0;
+}
+extern "C" int ab_transpose_oki(const float* src, int O, int K, int I, int dtype, void* dst, void* stream) {
+    long n = (long)O * K * I;
+    DISPATCH(dtype, (transpose_oki_kernel<float><<<grid_for(n), 256, 0, as_stream(stream)>>>(src, O, K, I, (float*)dst)),
+             (transpose_oki_kernel<bf16_t><<<grid_for(n), 256, 0, as_stream(stream)>>>(src, O, K, I, (bf16_t*)dst)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+extern "C" int ab_image_pad_nhwc4(const float* img_nchw, int dtype, int N, int H, int W, void* out, void* stream) {
+    long n = (long)N * (H + 6) * (W + 8);
+    DISPATCH(dtype, (image_pad_kernel<float><<<grid_for(n), 256, 0, as_stream(stream)>>>(img_nchw, N, H, W, (float*)out)),
+             (image_pad_kernel<bf16_t><<<grid_for(n), 256, 0, as_stream(stream)>>>(img_nchw, N, H, W, (bf16_t*)out)));
+    AB_LAUNCH_CHECK(); return 0;
+}

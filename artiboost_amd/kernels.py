@@ -1,0 +1,207 @@
+"""Tensor-level wrappers over the C ABI (include/artiboost_hip.h).  No autograd here: every function launches HIP
+kernels on the current stream and returns device tensors.  Layouts: activations NHWC, weights OHWI / IHWO."""
+import torch
+
+from . import _lib as L
+
+
+def _empty(shape, like, dtype=None):
+    return torch.empty(shape, dtype=dtype or like.dtype, device=like.device)
+
+
+def conv_out(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, want_stats=False, relu=False):
+    """x [N,H,W,Cin], w [Cout,kh,kw,Cin] -> y [N,Ho,Wo,Cout] (+ per-tile BN partials)."""
+    N, H, W, Cin = x.shape
+    Cout, kh, kw, _ = w_ohwi.shape
+    Ho, Wo = conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad)
+    y = _empty((N, Ho, Wo, Cout), x)
+    lib = L.lib()
+    stats = None
+    if want_stats:
+        nt = lib.ab_conv_gemm_mtiles(L.i(N * Ho * Wo), L.i(Cout))
+        stats = torch.empty((nt, Cout, 2), dtype=torch.float32, device=x.device)
+    L.check(lib.ab_conv2d_fwd(L.ptr(x), L.ptr(w_ohwi), L.ptr(y), L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                              L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(bias), L.ptr(stats),
+                              L.i(1 if relu else 0), L.stream()), "ab_conv2d_fwd")
+    return (y, stats) if want_stats else y
+
+
+def conv2d_stem_fwd(xpad, w_stem, H, W, want_stats=False):
+    """xpad [N,H+6,W+8,4], w_stem [Cout,7,8,4] -> y [N,H/2,W/2,Cout]."""
+    N = xpad.shape[0]
+    Cout = w_stem.shape[0]
+    y = _empty((N, H // 2, W // 2, Cout), xpad)
+    lib = L.lib()
+    stats = None
+    if want_stats:
+        nt = lib.ab_conv_gemm_mtiles(L.i(N * (H // 2) * (W // 2)), L.i(Cout))
+        stats = torch.empty((nt, Cout, 2), dtype=torch.float32, device=xpad.device)
+    L.check(lib.ab_conv2d_stem_fwd(L.ptr(xpad), L.ptr(w_stem), L.ptr(y), L.i(L.dt(xpad)), L.i(N), L.i(H), L.i(W),
+                                   L.i(Cout), L.ptr(stats), L.stream()), "ab_conv2d_stem_fwd")
+    return (y, stats) if want_stats else y
+
+
+def conv2d_dgrad(dy, w_ihwo, in_hw, stride, pad, addend=None, want_stats=False):
+    """dy [N,Ho,Wo,Cout], w [Cin,kh,kw,Cout] -> dx [N,H,W,Cin]  (== ConvTranspose2d forward when x:=dy)."""
+    N, Ho, Wo, Cout = dy.shape
+    Cin, kh, kw, _ = w_ihwo.shape
+    H, W = in_hw
+    dx = _empty((N, H, W, Cin), dy)
+    lib = L.lib()
+    stats = None
+    if want_stats:
+        nt = lib.ab_conv_gemm_mtiles(L.i(N * H * W), L.i(Cin))
+        stats = torch.empty((nt, Cin, 2), dtype=torch.float32, device=dy.device)
+    L.check(lib.ab_conv2d_dgrad(L.ptr(dy), L.ptr(w_ihwo), L.ptr(dx), L.i(L.dt(dy)), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(addend), L.ptr(stats),
+                                L.stream()), "ab_conv2d_dgrad")
+    return (dx, stats) if want_stats else dx
+
+
+_ws = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    w = _ws.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = w
+    return w
+
+
+def conv2d_wgrad(x, dy, kh, kw, stride, pad, out=None, accumulate=False):
+    """x [N,H,W,Cin], dy [N,Ho,Wo,Cout] -> dw float32 [Cout,kh,kw,Cin]."""
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    lib = L.lib()
+    M = dy.shape[0] * dy.shape[1] * dy.shape[2]
+    ws = _workspace(lib.ab_conv2d_wgrad_workspace(L.i(M), L.i(Cout), L.i(kh * kw * Cin)), x.device)
+    dw = out if out is not None else torch.empty((Cout, kh, kw, Cin), dtype=torch.float32, device=x.device)
+    L.check(lib.ab_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(ws),
+                                L.i(1 if accumulate else 0), L.stream()), "ab_conv2d_wgrad")
+    return dw
+
+
+def conv2d_stem_wgrad(xpad, dy, H, W, out=None):
+    N = xpad.shape[0]
+    Cout = dy.shape[3]
+    lib = L.lib()
+    ws = _workspace(lib.ab_conv2d_stem_wgrad_workspace(L.i(N), L.i(H), L.i(W), L.i(Cout)), xpad.device)
+    dw = out if out is not None else torch.empty((Cout, 7, 8, 4), dtype=torch.float32, device=xpad.device)
+    L.check(lib.ab_conv2d_stem_wgrad(L.ptr(xpad), L.ptr(dy), L.ptr(dw), L.i(L.dt(xpad)), L.i(N), L.i(H), L.i(W),
+                                     L.i(Cout), L.ptr(ws), L.stream()), "ab_conv2d_stem_wgrad")
+    return dw
+
+
+def col_stats(x2d):
+    M, C = x2d.shape[:-1].numel(), x2d.shape[-1]
+    lib = L.lib()
+    part = torch.empty((lib.ab_col_stats_nparts(L.l(M)), C, 2), dtype=torch.float32, device=x2d.device)
+    L.check(lib.ab_col_stats(L.ptr(x2d), L.i(L.dt(x2d)), L.l(M), L.i(C), L.ptr(part), L.stream()), "ab_col_stats")
+    return part
+
+
+def bn_finalize(part, count, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, out=None):
+    C = gamma.numel()
+    bnp = out if out is not None else torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    L.check(L.lib().ab_bn_finalize(L.ptr(part), L.i(part.shape[0]), L.i(C), L.l(count), L.ptr(gamma), L.ptr(beta),
+                                   L.f(eps), L.f(momentum), L.ptr(running_mean), L.ptr(running_var), L.ptr(bnp),
+                                   L.stream()), "ab_bn_finalize")
+    return bnp
+
+
+def bn_eval_params(gamma, beta, rm, rv, eps=1e-5):
+    C = gamma.numel()
+    bnp = torch.empty((4, C), dtype=torch.float32, device=gamma.device)
+    L.check(L.lib().ab_bn_eval_params(L.i(C), L.ptr(gamma), L.ptr(beta), L.ptr(rm), L.ptr(rv), L.f(eps), L.ptr(bnp),
+                                      L.stream()), "ab_bn_eval_params")
+    return bnp
+
+
+def bn_apply(y, bnp, res=None, relu=True, out=None):
+    C = y.shape[-1]
+    M = y.numel() // C
+    o = out if out is not None else torch.empty_like(y)
+    L.check(L.lib().ab_bn_apply(L.ptr(y), L.ptr(res), L.ptr(bnp), L.i(L.dt(y)), L.l(M), L.i(C), L.i(1 if relu else 0),
+                                L.ptr(o), L.stream()), "ab_bn_apply")
+    return o
+
+
+def bn_bwd(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, dy_out=None):
+    """-> dy (grad wrt the conv output y) [, dz = dout*relu_mask]."""
+    C = y.shape[-1]
+    M = y.numel() // C
+    lib = L.lib()
+    part = torch.empty((lib.ab_col_stats_nparts(L.l(M)), C, 2), dtype=torch.float32, device=y.device)
+    bwdp = torch.empty((2, C), dtype=torch.float32, device=y.device)
+    dy = dy_out if dy_out is not None else torch.empty_like(y)
+    dz = torch.empty_like(y) if want_dz else None
+    L.check(lib.ab_bn_bwd(L.ptr(dout), L.ptr(out if relu else None), L.ptr(y), L.ptr(bnp), L.i(L.dt(y)), L.l(M), L.i(C),
+                          L.i(1 if relu else 0), L.ptr(part), L.ptr(bwdp), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy),
+                          L.ptr(dz), L.stream()), "ab_bn_bwd")
+    return (dy, dz) if want_dz else dy
+
+
+def add(a, b, out=None):
+    o = out if out is not None else torch.empty_like(a)
+    L.check(L.lib().ab_add(L.ptr(a), L.ptr(b), L.i(L.dt(a)), L.l(a.numel()), L.ptr(o), L.stream()), "ab_add")
+    return o
+
+
+def maxpool_fwd(x):
+    N, H, W, C = x.shape
+    o = _empty((N, H // 2, W // 2, C), x)
+    L.check(L.lib().ab_maxpool3x3s2_fwd(L.ptr(x), L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(C), L.ptr(o), L.stream()),
+            "ab_maxpool3x3s2_fwd")
+    return o
+
+
+def maxpool_bwd(x, dout):
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    L.check(L.lib().ab_maxpool3x3s2_bwd(L.ptr(x), L.ptr(dout), L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(C), L.ptr(dx),
+                                        L.stream()), "ab_maxpool3x3s2_bwd")
+    return dx
+
+
+def avgpool_fwd(x):
+    N, H, W, C = x.shape
+    o = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    L.check(L.lib().ab_avgpool_fwd(L.ptr(x), L.i(L.dt(x)), L.i(N), L.i(H * W), L.i(C), L.ptr(o), L.stream()),
+            "ab_avgpool_fwd")
+    return o
+
+
+def avgpool_bwd(g, dx, accumulate):
+    N, H, W, C = dx.shape
+    L.check(L.lib().ab_avgpool_bwd(L.ptr(g), L.i(L.dt(dx)), L.i(N), L.i(H * W), L.i(C), L.ptr(dx),
+                                   L.i(1 if accumulate else 0), L.stream()), "ab_avgpool_bwd")
+    return dx
+
+
+def cast_bf16(src_f32, dst_bf16):
+    L.check(L.lib().ab_cast_f32_bf16(L.ptr(src_f32), L.l(src_f32.numel()), L.ptr(dst_bf16), L.stream()),
+            "ab_cast_f32_bf16")
+    return dst_bf16
+
+
+def transpose_oki(src_f32_oki, dst):
+    O, K, I = src_f32_oki.shape
+    L.check(L.lib().ab_transpose_oki(L.ptr(src_f32_oki), L.i(O), L.i(K), L.i(I), L.i(L.dt(dst)), L.ptr(dst),
+                                     L.stream()), "ab_transpose_oki")
+    return dst
+
+
+def image_pad_nhwc4(img_nchw_f32, dtype):
+    N, C, H, W = img_nchw_f32.shape
+    assert C == 3
+    out = torch.empty((N, H + 6, W + 8, 4), dtype=dtype, device=img_nchw_f32.device)
+    L.check(L.lib().ab_image_pad_nhwc4(L.ptr(img_nchw_f32), L.i(L.dt(out)), L.i(N), L.i(H), L.i(W), L.ptr(out),
+                                       L.stream()), "ab_image_pad_nhwc4")
+    return out

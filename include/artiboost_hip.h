@@ -45,6 +45,57 @@ int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, int D, int 
                         const float* uvd, const float* conf, const float* stat,
                         const float* g_uvd, const float* g_conf, void* dlogits, void* stream);
 
+/* ---- M1/M2: convolution stack (implicit GEMM on MFMA) ----------------------------------------------------------
+ * replaces cuDNN behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear:
+ *   anakin/models/resnet.py:154 (stem), :41-44 conv3x3 in BasicBlock (:85-101), :181-184 (1x1 downsample)
+ *   anakin/models/simplebaseline.py:161-170 (ConvTranspose2d 4x4 s2 p1), :95-101 (final 1x1 conv + bias)
+ *   anakin/models/mlp.py:15-22 (Linear + ReLU)
+ * Layouts: activations NHWC; weights "OHWI" = [Cout][kh][kw][Cin] (K-contiguous) in the activation dtype;
+ * data-gradient weights "IHWO" = [Cin][kh][kw][Cout].  Cin (fwd) / Cout (dgrad) must be a multiple of 32 (bf16)
+ * or 16 (f32).  stats (optional): float [ab_conv_gemm_mtiles(M, Cout)][Cout][2] per-tile (sum, sum^2) partials of
+ * the OUTPUT for the following training-mode BatchNorm (finalised by ab_bn_finalize).                           */
+int ab_conv_gemm_mtiles(int M, int Cn);
+int ab_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int H, int W, int Cin, int Cout,
+                  int kh, int kw, int stride, int pad, const float* bias, float* stats, int relu, void* stream);
+/* stem 7x7/2 pad 3 on a zero-bordered NHWC4 image [N, H+6, W+8, 4] (see ab_image_pad_nhwc4); w [Cout][7][8][4]  */
+int ab_conv2d_stem_fwd(const void* xpad, const void* w, void* y, int dtype, int N, int H, int W, int Cout,
+                       float* stats, void* stream);
+/* dx of conv2d(x,w,stride,pad) (also == ConvTranspose2d forward).  H,W,Cin describe dx.  addend (optional, dx-shaped)
+ * is added in the epilogue.  stats only for stride 1.                                                          */
+int ab_conv2d_dgrad(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int Cin, int Cout,
+                    int kh, int kw, int stride, int pad, const void* addend, float* stats, void* stream);
+/* dw (float, OHWI) of conv2d; workspace of ab_conv2d_wgrad_workspace(N*Ho*Wo, Cout, kh*kw*Cin) bytes           */
+long ab_conv2d_wgrad_workspace(int M, int Cout, int jtot);
+int ab_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int H, int W, int Cin, int Cout,
+                    int kh, int kw, int stride, int pad, void* workspace, int accumulate, void* stream);
+long ab_conv2d_stem_wgrad_workspace(int N, int H, int W, int Cout);
+int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw, int dtype, int N, int H, int W, int Cout,
+                         void* workspace, void* stream);
+
+/* ---- M1/M2: training-mode BatchNorm, ReLU, residual, pooling (HBM-bound NHWC kernels) ---------------------------
+ * replaces nn.BatchNorm2d / ReLU / MaxPool2d / mean-pool: anakin/models/resnet.py:85-101,155-157,219;
+ * anakin/models/simplebaseline.py:171-172.
+ * bnp: float [4][C] = (gamma*invstd, beta-mean*gamma*invstd, mean, invstd).                                     */
+int ab_col_stats_nparts(long M);
+int ab_col_stats(const void* x, int dtype, long M, int C, float* part, void* stream);
+int ab_bn_finalize(const float* part, int nparts, int C, long count, const float* gamma, const float* beta,
+                   float eps, float momentum, float* running_mean, float* running_var, float* bnp, void* stream);
+int ab_bn_eval_params(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                      float* bnp, void* stream);
+int ab_bn_apply(const void* y, const void* res, const float* bnp, int dtype, long M, int C, int relu, void* out,
+                void* stream);
+/* part: float [ab_col_stats_nparts(M)][C][2]; bwdp: float [2][C]; dz_out optional (gradient of the residual branch) */
+int ab_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C, int relu,
+              float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out, void* stream);
+int ab_add(const void* a, const void* b, int dtype, long n, void* out, void* stream);
+int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* stream);
+int ab_maxpool3x3s2_bwd(const void* x, const void* dout, int dtype, int N, int H, int W, int C, void* dx, void* stream);
+int ab_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, float* out, void* stream);
+int ab_avgpool_bwd(const float* g, int dtype, int N, int HW, int C, void* dx, int accumulate, void* stream);
+int ab_cast_f32_bf16(const float* src, long n, void* dst, void* stream);
+int ab_transpose_oki(const float* src, int O, int K, int I, int dtype, void* dst, void* stream);
+int ab_image_pad_nhwc4(const float* img_nchw, int dtype, int N, int H, int W, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,208 @@
+"""GPU parity of the conv-stack kernels (through the C ABI) against torch-CPU fp32 (what oracle/learner_oracle.py
+is built from).  f32 path: MFMA f32 is an exact fmaf chain -> tight tolerance.  bf16 path: operands are rounded to
+bf16 on the host first so both sides see identical inputs; the tolerance then covers fp32-accumulate ordering and
+the bf16 rounding of the stored output (2^-8 relative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, ref):
+    s = float(ref.abs().max()) + 1e-12
+    return (dict(rtol=2e-5, atol=2e-5 * s) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=8e-3 * s))
+
+
+def rnd(shape, gen, dtype, scale=1.0):
+    return (scale * torch.randn(shape, generator=gen)).to(dtype).float()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (3, 14, 10, 64, 128, 3, 2, 1),
+    (2, 8, 8, 128, 128, 3, 1, 1),
+    (2, 14, 14, 64, 128, 1, 2, 0),
+    (1, 7, 7, 512, 512, 3, 1, 1),
+    (2, 9, 5, 256, 616, 1, 1, 0),     # final layer: ragged N (616), ragged M, with bias
+    (5, 6, 6, 256, 256, 3, 1, 1),
+    (2, 8, 8, 256, 512, 4, 2, 1),     # == ConvTranspose backward-data shape
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(case, dtype):
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = rnd((N, Cin, H, W), g, dtype)
+    w = rnd((Cout, Cin, k, k), g, dtype, (2.0 / (Cin * k * k)) ** 0.5)
+    b = torch.randn(Cout, generator=g) if Cout == 616 else None
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    y, stats = K.conv2d_fwd(nhwc(x).to(dtype).cuda(), w.permute(0, 2, 3, 1).contiguous().to(dtype).cuda(), s, p,
+                            bias=b.cuda() if b is not None else None, want_stats=True)
+    got = nchw(y.float().cpu())
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), **tol(dtype, ref))
+    # fused BN partials: sum and sum of squares of the (stored-precision) output per channel
+    st = stats.double().sum(0).cpu()
+    yy = y.double().cpu().reshape(-1, Cout)
+    np.testing.assert_allclose(st[:, 0].numpy(), yy.sum(0).numpy(), rtol=2e-3, atol=2e-3 * float(yy.abs().sum(0).max()))
+    np.testing.assert_allclose(st[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("nhw", [(2, 32, 32), (1, 224, 224), (3, 20, 12)])
+def test_stem_fwd_wgrad(nhw, dtype):
+    from artiboost_amd import kernels as K
+    N, H, W = nhw
+    g = torch.Generator().manual_seed(N * H)
+    x = rnd((N, 3, H, W), g, dtype)
+    w = rnd((64, 3, 7, 7), g, dtype, 0.1)
+    ref = F.conv2d(x, w, stride=2, padding=3)
+    xpad = K.image_pad_nhwc4(x.cuda(), dtype)
+    wst = torch.zeros(64, 7, 8, 4)
+    wst[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    y = K.conv2d_stem_fwd(xpad, wst.to(dtype).cuda(), H, W)
+    np.testing.assert_allclose(nchw(y.float().cpu()).numpy(), ref.numpy(), **tol(dtype, ref))
+    dy = rnd(ref.shape, g, dtype)
+    xr = x.clone().requires_grad_(False)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, stride=2, padding=3).backward(dy)
+    dw = K.conv2d_stem_wgrad(xpad, nhwc(dy).to(dtype).cuda(), H, W).cpu()
+    assert float(dw[:, :, 7, :].abs().max()) == 0.0 and float(dw[:, :, :, 3].abs().max()) == 0.0
+    got = dw[:, :, :7, :3].permute(0, 3, 1, 2)
+    t = tol(dtype, wr.grad)
+    if dtype == torch.bfloat16:
+        t = dict(rtol=2e-3, atol=2e-3 * float(wr.grad.abs().max()))   # fp32 output, only accumulation order differs
+    np.testing.assert_allclose(got.numpy(), wr.grad.numpy(), **t)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", CONV_CASES[:7])
+def test_conv_dgrad_wgrad(case, dtype):
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout, k, s, p = case
+    if s == 2 and (H % 2 or W % 2):
+        H, W = H + H % 2, W + W % 2
+    if Cout == 616:
+        Cout = 640       # wgrad/dgrad need channel multiples of 64/32
+    g = torch.Generator().manual_seed(hash(case) % 977)
+    x = rnd((N, Cin, H, W), g, dtype).requires_grad_(True)
+    w = rnd((Cout, Cin, k, k), g, dtype, (2.0 / (Cin * k * k)) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    dy = rnd(y.shape, g, dtype)
+    y.backward(dy)
+    add = rnd(x.shape, g, dtype)
+    dyd = nhwc(dy).to(dtype).cuda()
+    wt = w.detach().permute(1, 2, 3, 0).contiguous().to(dtype).cuda()   # [Cin][kh][kw][Cout]
+    dx = K.conv2d_dgrad(dyd, wt, (H, W), s, p, addend=nhwc(add).to(dtype).cuda())
+    ref = x.grad + add
+    np.testing.assert_allclose(nchw(dx.float().cpu()).numpy(), ref.numpy(), **tol(dtype, ref))
+    dw = K.conv2d_wgrad(nhwc(x.detach()).to(dtype).cuda(), dyd, k, k, s, p).cpu().permute(0, 3, 1, 2)
+    t = tol(dtype, w.grad)
+    if dtype == torch.bfloat16:
+        t = dict(rtol=2e-3, atol=2e-3 * float(w.grad.abs().max()))
+    np.testing.assert_allclose(dw.numpy(), w.grad.numpy(), **t)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(2, 7, 7, 512, 256), (2, 16, 16, 256, 256), (1, 5, 3, 64, 64)])
+def test_conv_transpose_4x4s2(case, dtype):
+    """ConvTranspose2d(k4,s2,p1) forward/backward (simplebaseline.py:161-170) expressed with the three conv kernels."""
+    from artiboost_amd import kernels as K
+    N, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(Ci + H)
+    x = rnd((N, Ci, H, W), g, dtype).requires_grad_(True)
+    wt = rnd((Ci, Co, 4, 4), g, dtype, (2.0 / (Ci * 4)) ** 0.5).requires_grad_(True)
+    y = F.conv_transpose2d(x, wt, stride=2, padding=1)
+    dy = rnd(y.shape, g, dtype)
+    y.backward(dy)
+    # mirrored conv C: (Co -> Ci), weight w_conv[co=Ci][ci=Co][kh][kw] = wt
+    w_ihwo = wt.detach().permute(1, 2, 3, 0).contiguous().to(dtype).cuda()      # [Co][kh][kw][Ci] = dgrad layout of C
+    w_ohwi = wt.detach().permute(0, 2, 3, 1).contiguous().to(dtype).cuda()      # [Ci][kh][kw][Co] = fwd layout of C
+    xd = nhwc(x.detach()).to(dtype).cuda()
+    yd = K.conv2d_dgrad(xd, w_ihwo, (2 * H, 2 * W), 2, 1)
+    np.testing.assert_allclose(nchw(yd.float().cpu()).numpy(), y.detach().numpy(), **tol(dtype, y.detach()))
+    dyd = nhwc(dy).to(dtype).cuda()
+    dx = K.conv2d_fwd(dyd, w_ohwi, 2, 1)
+    np.testing.assert_allclose(nchw(dx.float().cpu()).numpy(), x.grad.numpy(), **tol(dtype, x.grad))
+    dwc = K.conv2d_wgrad(dyd, xd, 4, 4, 2, 1).cpu()          # [Ci][kh][kw][Co]
+    got = dwc.permute(0, 3, 1, 2)                             # -> [Ci][Co][kh][kw]
+    t = tol(dtype, wt.grad)
+    if dtype == torch.bfloat16:
+        t = dict(rtol=2e-3, atol=2e-3 * float(wt.grad.abs().max()))
+    np.testing.assert_allclose(got.numpy(), wt.grad.numpy(), **t)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64), (3, 5, 7, 256), (64, 4, 4, 512), (1, 60, 60, 128)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_batchnorm_train_fwd_bwd(shape, dtype, relu, res):
+    from artiboost_amd import kernels as K
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(C + N)
+    y = rnd((N, C, H, W), g, dtype, 1.5).add_(0.3).to(dtype).float().requires_grad_(True)
+    gamma = (0.5 + torch.rand(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    r = rnd((N, C, H, W), g, dtype).requires_grad_(True) if res else None
+    rm, rv = torch.zeros(C), torch.ones(C)
+    ref = F.batch_norm(y, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    dout = rnd(ref.shape, g, dtype)
+    ref.backward(dout)
+    yd = nhwc(y.detach()).to(dtype).cuda()
+    part = K.col_stats(yd)
+    rm_d, rv_d = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    bnp = K.bn_finalize(part, N * H * W, gamma.detach().cuda(), beta.detach().cuda(), rm_d, rv_d)
+    np.testing.assert_allclose(rm_d.cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(rv_d.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-6)
+    rd = nhwc(r.detach()).to(dtype).cuda() if res else None
+    out = K.bn_apply(yd, bnp, res=rd, relu=relu)
+    np.testing.assert_allclose(nchw(out.float().cpu()).numpy(), ref.detach().numpy(), **tol(dtype, ref.detach()))
+    dgamma, dbeta = torch.empty(C).cuda(), torch.empty(C).cuda()
+    # feed the oracle's `out` (rounded to dtype) as the relu mask source so both sides agree on the mask
+    dy, dz = K.bn_bwd(nhwc(dout).to(dtype).cuda(), out, yd, bnp, dgamma, dbeta, relu=relu, want_dz=True)
+    t = tol(dtype, y.grad)
+    if dtype == torch.bfloat16:
+        t = dict(rtol=3e-2, atol=2e-2 * float(y.grad.abs().max()))
+    np.testing.assert_allclose(nchw(dy.float().cpu()).numpy(), y.grad.numpy(), **t)
+    np.testing.assert_allclose(dgamma.cpu().numpy(), gamma.grad.numpy(), rtol=2e-3, atol=2e-3 * float(gamma.grad.abs().max()))
+    np.testing.assert_allclose(dbeta.cpu().numpy(), beta.grad.numpy(), rtol=2e-3, atol=2e-3 * float(beta.grad.abs().max()))
+    if res:
+        np.testing.assert_allclose(nchw(dz.float().cpu()).numpy(), r.grad.numpy(), **tol(dtype, r.grad))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 8, 8, 64), (1, 112, 112, 64), (3, 6, 10, 128)])
+def test_maxpool_avgpool(shape, dtype):
+    from artiboost_amd import kernels as K
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(H)
+    x = rnd((N, C, H, W), g, dtype)
+    x = F.relu(x).requires_grad_(True)            # post-ReLU input: many exact ties at 0 (first-max semantics matter)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    dout = rnd(ref.shape, g, dtype)
+    ref.backward(dout)
+    xd = nhwc(x.detach()).to(dtype).cuda()
+    out = K.maxpool_fwd(xd)
+    np.testing.assert_array_equal(nchw(out.float().cpu()).numpy(), ref.detach().numpy())
+    dx = K.maxpool_bwd(xd, nhwc(dout).to(dtype).cuda())
+    np.testing.assert_allclose(nchw(dx.float().cpu()).numpy(), x.grad.numpy(), **tol(dtype, x.grad))
+    m = K.avgpool_fwd(xd)
+    np.testing.assert_allclose(m.cpu().numpy(), x.detach().mean(3).mean(2).numpy(), rtol=1e-5, atol=1e-6)

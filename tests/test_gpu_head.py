@@ -42,7 +42,7 @@ def test_head_vs_oracle(dtype, tol, shape):
     B, C, D, H, W = shape
     gen = torch.Generator().manual_seed(B * 131 + C)
     logits = (3.0 * torch.randn(B, C * D, H, W, generator=gen)).to(dtype)
-    ref_in = logits.float().requires_grad_(True)
+    ref_in = logits.float().clone().requires_grad_(True)
     uvd_r, conf_r = lo.softargmax3d(ref_in, C, D, H, W)
     x = _nhwc(logits).cuda().requires_grad_(True)
     uvd, conf = softargmax3d(x, C, D)
