@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 
 // dW[e] (+)= sum_s slabs[s][e]; optionally drops padded taps: dst row layout [Cout][dst_j], src [Cout][src_j]
 __global__ void wgrad_reduce(const float* __restrict__ slabs, int nslices, long slab_elems, int src_j, int dst_j,
-                             float* __restrict__ dst, int accumulate) {
+                             float* __restrict__ dst, int accumulate, int stem_mask) {
     long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     long total = (slab_elems / src_j) * dst_j;
     if (e >= total) return;
@@ -183,6 +183,7 @@ __global__ void wgrad_reduce(const float* __restrict__ slabs, int nslices, long 
     long se = row * src_j + col;
     float s = 0.f;
     for (int k = 0; k < nslices; ++k) s += slabs[(long)k * slab_elems + se];
+    if (stem_mask && ((col & 31) >= 28 || (col & 3) == 3)) s = 0.f;   // padding taps of the [7][8][4] stem layout
     dst[e] = accumulate ? dst[e] + s : s;
 }
 
@@ -213,14 +214,14 @@ static int launch_wgrad(const WgradArgs& g, int bi, int bj, hipStream_t st) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
-static int run_wgrad(WgradArgs& g, int dtype, float* dw, int dst_j, int accumulate, hipStream_t st) {
+static int run_wgrad(WgradArgs& g, int dtype, float* dw, int dst_j, int accumulate, hipStream_t st, int stem_mask = 0) {
     int bi, bj, ns, rows; pick_wgrad(g.M, g.Cout, g.jtot, &bi, &bj, &ns, &rows);
     if (g.Cout % bi || g.jtot % bj) return AB_ESHAPE;
     g.nslices = ns; g.rows_per_slice = rows;
     int rc = dtype == AB_DT_BF16 ? launch_wgrad<bf16_t>(g, bi, bj, st) : dtype == AB_DT_F32 ? launch_wgrad<float>(g, bi, bj, st) : AB_EINVAL;
     if (rc) return rc;
     long slab = (long)g.Cout * g.jtot, total = (long)g.Cout * dst_j;
-    wgrad_reduce<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(g.slabs, ns, slab, g.jtot, dst_j, dw, accumulate);
+    wgrad_reduce<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(g.slabs, ns, slab, g.jtot, dst_j, dw, accumulate, stem_mask);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -251,7 +252,7 @@ extern "C" int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw,
     g.P = H / 2; g.Q = W / 2; g.Cout = Cout; g.a_sh = g.a_sw = 2;
     g.ntaps = 8; g.seglen = 32; g.jtot = 256; g.M = N * g.P * g.Q;      // tap 7 is padding (in-bounds row, dropped below)
     for (int i = 0; i < 8; ++i) { g.dh[i] = (int8_t)i; g.dw[i] = 0; }
-    return run_wgrad(g, dtype, dw, 7 * 32, 0, as_stream(stream));
+    return run_wgrad(g, dtype, dw, 7 * 32, 0, as_stream(stream), 1);
 }
 
 extern "C" long ab_conv2d_stem_wgrad_workspace(int N, int H, int W, int Cout) {
