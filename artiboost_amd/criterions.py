@@ -1,0 +1,243 @@
+"""Loss plugin classes with the reference's names, config keys and RNG behaviour
+(anakin/criterions/criterion.py:8-67, jointloss.py:14-67, ordinal.py:17-306, symcornerloss.py:18-102).
+
+The ordinal losses draw from the same global RNGs in the same order as the reference (torch.rand for the virtual
+view vectors, random.shuffle for the pair subsets), so seeding `random` and `torch` identically reproduces the
+reference's loss values.  Tensors here are tiny ((B,21,3)-sized); the arithmetic runs as device torch ops."""
+import random
+from itertools import combinations, product
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .registry import CONST, LOSS, Queries, camel_to_snake
+
+
+class TensorLoss(object):
+    def __init__(self):
+        self.output_key = f"{camel_to_snake(type(self).__name__)}_output"
+
+    def __call__(self, preds: Dict, targs: Dict, **kwargs) -> Tuple[torch.Tensor, Dict]:
+        dev = None
+        for v in preds.values():
+            if isinstance(v, torch.Tensor):
+                dev = v.device
+                break
+        if dev is None:
+            raise RuntimeError("Cannot found valid Tensor with device")
+        return torch.zeros(1, dtype=torch.float32, device=dev), {}
+
+
+class Criterion(TensorLoss):
+    def __init__(self, cfg: Dict, loss_list: List[TensorLoss]) -> None:
+        super().__init__()
+        self._loss_list = loss_list
+        lambdas = list(cfg["LAMBDAS"])
+        self._loss_lambdas = {type(l).__name__: lambdas[i] for i, l in enumerate(loss_list)}
+
+    @property
+    def loss_list(self):
+        return self._loss_list
+
+    @property
+    def loss_lambdas(self):
+        return self._loss_lambdas
+
+    def compute_losses(self, preds: Dict, targs: Dict, **kwargs):
+        total, out = super().__call__(preds, targs, **kwargs)
+        for loss in self.loss_list:
+            fl, d = loss(preds, targs, **kwargs)
+            total = total + self.loss_lambdas[type(loss).__name__] * fl
+            out.update(d)
+        assert "final_loss" not in out
+        out["final_loss"] = total
+        return total, out
+
+
+def _abs_masked(preds, targs, dev):
+    root = targs[Queries.ROOT_JOINT].to(dev)
+    jv = targs[Queries.JOINTS_VIS].to(dev)[..., None]
+    cv = targs[Queries.CORNERS_VIS].to(dev)[..., None]
+    jt = (targs[Queries.JOINTS_3D].to(dev) + root[:, None]) * jv
+    ct = (targs[Queries.CORNERS_3D].to(dev) + root[:, None]) * cv
+    return preds["joints_3d_abs"] * jv, jt, preds["corners_3d_abs"] * cv, ct
+
+
+@LOSS.register_module
+class JointsLoss(TensorLoss):
+    def __init__(self, **cfg):
+        super().__init__()
+        self.lambda_joints_3d = cfg.get("LAMBDA_JOINTS_3D", 0.0)
+        self.lambda_corners_3d = cfg.get("LAMBDA_CORNERS_3D", 0.0)
+
+    def __call__(self, preds, targs, **kwargs):
+        final_loss, losses = super().__call__(preds, targs, **kwargs)
+        jp, jt, cp, ct = _abs_masked(preds, targs, final_loss.device)
+        lj = F.mse_loss(jp, jt) if self.lambda_joints_3d else None
+        lc = F.mse_loss(cp, ct) if self.lambda_corners_3d else None
+        if lj is not None:
+            final_loss = final_loss + self.lambda_joints_3d * lj
+        if lc is not None:
+            final_loss = final_loss + self.lambda_corners_3d * lc
+        losses["joints_3d_loss"] = lj
+        losses["corners_3d_loss"] = lc
+        losses[self.output_key] = final_loss
+        return final_loss, losses
+
+
+def sample_view_vectors(n_virtual_views=20):
+    """ordinal.py:59-71 (CPU draws from the global torch RNG: rand(n) for theta, then rand(n) for u)."""
+    cam_vec = torch.Tensor([0.0, 0.0, 1.0]).unsqueeze(0)
+    theta = torch.rand(n_virtual_views) * 2.0 * np.pi
+    u = torch.rand(n_virtual_views)
+    s = torch.sqrt(1.0 - u ** 2)
+    nv = torch.cat([(s * torch.cos(theta)).unsqueeze(1), (s * torch.sin(theta)).unsqueeze(1), u.unsqueeze(1)], dim=1)
+    return torch.cat([cam_vec, nv], dim=0)
+
+
+def _shuffled_third(n):
+    idx = list(range(n))
+    random.shuffle(idx)
+    return idx[: n // 3]
+
+
+def _ord(a, b, views):      # jointlevel_ordinal_relation (ordinal.py:39-56)
+    return torch.einsum("bpk,vk->bpv", a - b, views)
+
+
+@LOSS.register_module
+class HandOrdLoss(TensorLoss):
+    def __init__(self, **cfg):
+        super().__init__()
+        self.lambda_part_lev = float(cfg.get("LAMBDA_PART_LEVEL", 1.0))
+        self.lambda_joint_lev = float(cfg.get("LAMBDA_JOINTS_LEVEL", 1.0))
+        self.n_virtual_views = int(cfg.get("N_VIRTUAL_VIEWS", 20))
+        self.joint_pairs_idx = list(combinations(range(CONST.NUM_JOINTS), 2))
+        self.parts_pairs_idx = list(combinations(range(CONST.NUM_JOINTS - 1), 2))
+
+    def __call__(self, preds, targs, **kwargs):
+        final_loss, losses = super().__call__(preds, targs, **kwargs)
+        dev = final_loss.device
+        jp, jt, _, _ = _abs_masked(preds, targs, dev)
+        views = sample_view_vectors(self.n_virtual_views).to(dev)
+        sel = _shuffled_third(len(self.joint_pairs_idx))
+        i0 = [self.joint_pairs_idx[i][0] for i in sel]
+        i1 = [self.joint_pairs_idx[i][1] for i in sel]
+        gt = _ord(jt[:, i0], jt[:, i1], views)
+        pr = _ord(jp[:, i0], jp[:, i1], views)
+        joint_ord_loss = torch.log(1.0 + F.relu(-1.0 * torch.sign(gt) * pr)).mean()
+        final_loss = final_loss + self.lambda_joint_lev * joint_ord_loss
+        losses["joint_ord_loss"] = joint_ord_loss
+
+        def parts(j):   # joints_2_part_pairs (ordinal.py:98-121)
+            return (j - j[:, CONST.JOINTS_IDX_PARENTS])[:, 1:]
+
+        pp, pt = parts(jp), parts(jt)
+        sel = _shuffled_third(len(self.parts_pairs_idx))
+        a0 = [self.parts_pairs_idx[i][0] for i in sel]
+        a1 = [self.parts_pairs_idx[i][1] for i in sel]
+        gt = torch.einsum("bpk,vk->bpv", torch.cross(pt[:, a0], pt[:, a1], dim=-1), views)
+        pr = torch.einsum("bpk,vk->bpv", torch.cross(pp[:, a0], pp[:, a1], dim=-1), views)
+        part_ord_loss = F.relu(-1.0 * torch.sign(gt) * pr).mean()
+        final_loss = final_loss + self.lambda_part_lev * part_ord_loss
+        losses["part_ord_loss"] = part_ord_loss
+        losses[self.output_key] = final_loss
+        return final_loss, losses
+
+
+@LOSS.register_module
+class SceneOrdLoss(TensorLoss):
+    def __init__(self, **cfg):
+        super().__init__()
+        self.lambda_scene_lev = float(cfg.get("LAMBDA_SCENE_LEVEL", 1.0))
+        self.n_virtual_views = int(cfg.get("N_VIRTUAL_VIEWS", 40))
+        self.ho_pairs_idx = list(product(range(CONST.NUM_JOINTS), range(CONST.NUM_CORNERS)))
+
+    def __call__(self, preds, targs, **kwargs):
+        final_loss, losses = super().__call__(preds, targs, **kwargs)
+        dev = final_loss.device
+        jp, jt, cp, ct = _abs_masked(preds, targs, dev)
+        views = sample_view_vectors(self.n_virtual_views).to(dev)
+        sel = _shuffled_third(len(self.ho_pairs_idx))
+        i0 = [self.ho_pairs_idx[i][0] for i in sel]
+        i1 = [self.ho_pairs_idx[i][1] for i in sel]
+        gt = _ord(jt[:, i0], ct[:, i1], views)
+        pr = _ord(jp[:, i0], cp[:, i1], views)
+        scene_ord_loss = torch.log(1.0 + F.relu(-1.0 * torch.sign(gt) * pr)).mean()
+        final_loss = final_loss + self.lambda_scene_lev * scene_ord_loss
+        losses["scene_ord_loss"] = scene_ord_loss
+        return final_loss, losses
+
+
+def get_symmetry_transformations(model_info, max_sym_disc_step):
+    """anakin/utils/bop_toolkit/bop_misc.py:18-65 (BOP toolkit): discrete x discretised-continuous symmetries."""
+    trans_disc = [{"R": np.eye(3), "t": np.array([[0, 0, 0]]).T}]
+    for sym in model_info.get("symmetries_discrete", []):
+        s = np.reshape(sym, (4, 4))
+        trans_disc.append({"R": s[:3, :3], "t": s[:3, 3].reshape((3, 1))})
+    trans_cont = []
+    for sym in model_info.get("symmetries_continuous", []):
+        axis = np.array(sym["axis"], dtype=np.float64)
+        offset = np.array(sym["offset"], dtype=np.float64).reshape((3, 1))
+        steps = int(np.ceil(np.pi / max_sym_disc_step))
+        step = 2.0 * np.pi / steps
+        axis_n = axis / np.linalg.norm(axis)
+        for i in range(1, steps):
+            a = i * step
+            K_ = np.array([[0, -axis_n[2], axis_n[1]], [axis_n[2], 0, -axis_n[0]], [-axis_n[1], axis_n[0], 0]])
+            R = np.cos(a) * np.eye(3) + (1 - np.cos(a)) * np.outer(axis_n, axis_n) + np.sin(a) * K_
+            trans_cont.append({"R": R, "t": -R.dot(offset) + offset})
+    trans = []
+    for td in trans_disc:
+        if trans_cont:
+            for tc in trans_cont:
+                trans.append({"R": tc["R"].dot(td["R"]), "t": tc["R"].dot(td["t"]) + tc["t"]})
+        else:
+            trans.append(td)
+    return trans
+
+
+@LOSS.register_module
+class SymCornerLoss(TensorLoss):
+    def __init__(self, **cfg):
+        super().__init__()
+        self.lambda_sym_corners_3d = cfg.get("LAMBDA_SYM_CORNERS_3D", 0.0)
+        info = cfg.get("MODEL_INFO")
+        if info is None:
+            import json
+            info = json.load(open(cfg["MODEL_INFO_PATH"], "r"))
+        step = cfg.get("MAX_SYM_DISC_STEP", 0.01)
+        if cfg.get("USE_HO3D_YCB", False):
+            raise NotImplementedError("USE_HO3D_YCB")
+        syms = [get_symmetry_transformations(info[str(i)], step) for i in range(1, len(info) + 1)]
+        kmax = max(len(s) for s in syms)
+        R = np.tile(np.eye(3), (len(syms), kmax, 1, 1))
+        t = np.zeros((len(syms), kmax, 3, 1))
+        for i, s in enumerate(syms):
+            for k, tr in enumerate(s):
+                R[i, k] = tr["R"]
+                t[i, k] = tr["t"] / 1000.0
+        self.R = torch.Tensor(R)
+        self.t = torch.Tensor(t)
+
+    def __call__(self, preds, targs, **kwargs):
+        final_loss, losses = super().__call__(preds, targs, **kwargs)
+        dev = final_loss.device
+        loss = None
+        if self.lambda_sym_corners_3d:
+            obj = (targs[Queries.OBJ_IDX] - 1).long().to(dev)
+            Rs, ts = self.R.to(dev)[obj], self.t.to(dev)[obj]
+            T = targs[Queries.OBJ_TRANSF].to(dev)
+            can = targs[Queries.CORNERS_CAN].to(dev).permute(0, 2, 1)[:, None]
+            sym_can = torch.matmul(Rs, can) + ts
+            gt = (torch.matmul(T[:, None, :3, :3], sym_can) + T[:, None, :3, 3:]).permute(0, 1, 3, 2)
+            vis = targs[Queries.CORNERS_VIS].to(dev)
+            pred = (preds["corners_3d_abs"] * vis[..., None])[:, None]
+            gt = gt * vis[:, None, :, None]
+            loss = ((gt - pred) ** 2).mean(-1).mean(-1).min(dim=-1)[0].mean()
+            final_loss = final_loss + self.lambda_sym_corners_3d * loss
+        losses["sym_corners_3d_loss"] = loss
+        losses[self.output_key] = final_loss
+        return final_loss, losses

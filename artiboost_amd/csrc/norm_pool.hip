@@ -331,6 +331,25 @@ __global__ void image_pad_kernel(const float* __restrict__ img, int N, int H, in
     }
 }
 
+// ---------------------------------------------------------------- ReLU backward, column-sum finalize (bias grads)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, long nvec, T* __restrict__ dz) {
+    constexpr int V = Vec<T>::N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        float g[V], o[V]; vload<T>(dout + i * V, g); vload<T>(out + i * V, o);
+#pragma unroll
+        for (int k = 0; k < V; ++k) g[k] = (o[k] > 0.f) ? g[k] : 0.f;
+        vstore<T>(dz + i * V, g);
+    }
+}
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int k = 0; k < nparts; ++k) s += part[((long)k * C + c) * 2];
+    out[c] = (float)s;
+}
+
 // ================================================================ C ABI
 static inline int grid_for(long nvec) { long b = (nvec + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 #define DISPATCH(dtype, CALL_F, CALL_B) do { if ((dtype) == AB_DT_F32) { CALL_F; } else if ((dtype) == AB_DT_BF16) { CALL_B; } else return AB_EINVAL; } while (0)
@@ -441,5 +460,20 @@ extern "C" int ab_image_pad_nhwc4(const float* img_nchw, int dtype, int N, int H
     long n = (long)N * (H + 6) * (W + 8);
     DISPATCH(dtype, (image_pad_kernel<float><<<grid_for(n), 256, 0, as_stream(stream)>>>(img_nchw, N, H, W, (float*)out)),
              (image_pad_kernel<bf16_t><<<grid_for(n), 256, 0, as_stream(stream)>>>(img_nchw, N, H, W, (bf16_t*)out)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_relu_bwd(const void* dout, const void* out, int dtype, long n, void* dz, void* stream) {
+    int V = dtype == AB_DT_F32 ? 4 : 8; if (n % V) return AB_ESHAPE;
+    long nvec = n / V;
+    DISPATCH(dtype, (relu_bwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)dout, (const float*)out, nvec, (float*)dz)),
+             (relu_bwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)dout, (const bf16_t*)out, nvec, (bf16_t*)dz)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+// column sums (bias gradient) of x [M][C]: part = float [ab_col_stats_nparts(M)][C][2] workspace, out float [C]
+extern "C" int ab_col_sum(const void* x, int dtype, long M, int C, float* part, float* out, void* stream) {
+    int rc = ab_col_stats(x, dtype, M, C, part, stream);
+    if (rc) return rc;
+    colsum_finalize_kernel<<<(C + 255) / 256, 256, 0, as_stream(stream)>>>(part, ab_col_stats_nparts(M), C, out);
     AB_LAUNCH_CHECK(); return 0;
 }

@@ -25,10 +25,10 @@ __device__ __forceinline__ void acc_merge(Acc& a, const Acc& b) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ logits, int C, int D, int H, int W,
+__global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                           int ntile, float* __restrict__ part) {
     // grid: (ntile, B).  4 waves; wave w handles pixels w, w+4, ... of the tile; lane handles channels lane+64k.
-    const int CD = C * D;
+    const int CD = C * DP;   // channel = c*DP + d, d < D valid (DP >= D: padded depth pitch)
     const int b = blockIdx.y, tile = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int npix = H * W;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ 
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             int ch = lane + 64 * k;
-            if (ch < CD) {
+            if (ch < CD && (ch % DP) < D) {
                 float x = ld_f32(row + ch);
                 float m = fmaxf(acc[k].m, x);
                 float f = (acc[k].m == -INFINITY) ? 0.f : __expf(acc[k].m - m);
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ 
         Acc r = {-INFINITY, 0.f, 0.f, 0.f, 0.f};
         const float invD = 1.f / D;
         for (int d = 0; d < D; ++d) {
-            int ch = c * D + d;
+            int ch = c * DP + d;
             for (int wv = 0; wv < 4; ++wv) {
                 Acc t = {sm[wv][ch][0], sm[wv][ch][1], sm[wv][ch][2], sm[wv][ch][3], 0.f};
                 t.sd = t.s * (d * invD);
@@ -120,12 +120,12 @@ __global__ void sam_stage2(const float* __restrict__ part, int C, int ntile, flo
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int C, int D, int H, int W,
+__global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                const float* __restrict__ uvd, const float* __restrict__ conf,
                                                const float* __restrict__ stat, const float* __restrict__ g_uvd,
                                                const float* __restrict__ g_conf, T* __restrict__ dlogits) {
     // grid: (ceil(npix / 4), B); each wave handles one pixel row of C*D channels
-    const int CD = C * D, npix = H * W;
+    const int CD = C * DP, npix = H * W;
     const int b = blockIdx.y;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
     const T* row = logits + ((size_t)b * npix + p) * CD;
     T* drow = dlogits + ((size_t)b * npix + p) * CD;
     for (int ch = lane; ch < CD; ch += 64) {
-        int c = ch / D, d = ch - c * D;
+        int c = ch / DP, d = ch - c * DP;
+        if (d >= D) { st_f32(drow + ch, 0.f); continue; }
         int bc = b * C + c;
         float x = ld_f32(row + ch);
         float m = stat[bc * 2], s = stat[bc * 2 + 1];
@@ -154,16 +155,16 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
 
 extern "C" int ab_softargmax3d_ntiles(int H, int W) { return (H * W + SAM_TILE_PIX - 1) / SAM_TILE_PIX; }
 
-extern "C" int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, int D, int H, int W, float* part,
+extern "C" int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, float* part,
                                    float* uvd, float* conf, float* stat, void* stream) {
     if (!logits || !part || !uvd || !conf || !stat) return AB_EINVAL;
-    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || C * D > SAM_MAXCH) return AB_ESHAPE;
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH) return AB_ESHAPE;
     int ntile = ab_softargmax3d_ntiles(H, W);
     dim3 grid(ntile, B);
     if (dtype == AB_DT_F32)
-        sam_stage1<float><<<grid, SAM_THREADS, 0, as_stream(stream)>>>((const float*)logits, C, D, H, W, ntile, part);
+        sam_stage1<float><<<grid, SAM_THREADS, 0, as_stream(stream)>>>((const float*)logits, C, D, DP, H, W, ntile, part);
     else if (dtype == AB_DT_BF16)
-        sam_stage1<bf16_t><<<grid, SAM_THREADS, 0, as_stream(stream)>>>((const bf16_t*)logits, C, D, H, W, ntile, part);
+        sam_stage1<bf16_t><<<grid, SAM_THREADS, 0, as_stream(stream)>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
     else return AB_EINVAL;
     AB_LAUNCH_CHECK();
     sam_stage2<<<B * C, 64, 0, as_stream(stream)>>>(part, C, ntile, uvd, conf, stat);
@@ -171,17 +172,17 @@ extern "C" int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, 
     return 0;
 }
 
-extern "C" int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, int D, int H, int W, const float* uvd,
+extern "C" int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, const float* uvd,
                                    const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
                                    void* dlogits, void* stream) {
     if (!logits || !uvd || !conf || !stat || !g_uvd || !dlogits) return AB_EINVAL;
-    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || C * D > SAM_MAXCH) return AB_ESHAPE;
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH) return AB_ESHAPE;
     dim3 grid((H * W + 3) / 4, B);
     if (dtype == AB_DT_F32)
-        sam_bwd<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)logits, C, D, H, W, uvd, conf, stat, g_uvd,
+        sam_bwd<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)logits, C, D, DP, H, W, uvd, conf, stat, g_uvd,
                                                            g_conf, (float*)dlogits);
     else if (dtype == AB_DT_BF16)
-        sam_bwd<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)logits, C, D, H, W, uvd, conf, stat, g_uvd,
+        sam_bwd<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)logits, C, D, DP, H, W, uvd, conf, stat, g_uvd,
                                                             g_conf, (bf16_t*)dlogits);
     else return AB_EINVAL;
     AB_LAUNCH_CHECK();

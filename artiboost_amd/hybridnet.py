@@ -1,0 +1,426 @@
+"""HybridBaseline (ResNet-34 + IntegralDeconvHead(22 x D) + MLP_O) executed on the hand-written HIP kernels.
+
+Reference: anakin/models/hybridbaseline.py:18-96, anakin/models/resnet.py:72-101,142-230,243-248,
+anakin/models/simplebaseline.py:75-190, anakin/models/mlp.py:11-25.
+
+Design (MI355X-first, not a translation of the nn.Module tree):
+  * all learnable parameters live in ONE flat fp32 buffer in *kernel layout* (conv weights OHWI / K-contiguous, the
+    7x7 stem as [64][7][8][4] rows over a zero-bordered NHWC4 image, ConvTranspose weights as the OHWI weights of the
+    mirrored conv, the heat-map depth padded 28 -> 32 so every class is one aligned channel run).  Gradients live in
+    a second flat buffer of the same shape, so the global-norm clip + Adam are two passes over contiguous memory and
+    the DDP all-reduce is a handful of large buckets.
+  * activations are NHWC in the compute dtype (bf16 for speed, f32 for parity); forward and backward are explicit
+    kernel sequences (no autograd graph); training-mode BatchNorm statistics come for free from the conv epilogue.
+  * state_dict()/load_state_dict() speak the reference's key names and tensor layouts (torchvision-compatible
+    `backbone.*`, `hybrid_head.deconv_layers.*`, `hybrid_head.final_layer.*`, `box_head.layers.*`).
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import kernels as K
+from .head import softargmax3d_fwd, softargmax3d_bwd
+
+RESNET34_LAYERS = [3, 4, 6, 3]
+DEPTH_PITCH = 32
+BOX_OUT_PAD = 64
+
+
+class _Entry:
+    __slots__ = ("name", "kind", "ref_shape", "kshape", "offset", "numel", "bn")
+
+    def __init__(self, name, kind, ref_shape, kshape):
+        self.name, self.kind, self.ref_shape, self.kshape = name, kind, tuple(ref_shape), tuple(kshape)
+        self.numel = 1
+        for d in kshape:
+            self.numel *= d
+        self.offset = 0
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class ParamStore:
+    """Flat parameter / gradient / running-stat storage with reference <-> kernel layout conversion."""
+
+    def __init__(self, nclasses=22, depth=28, device="cuda"):
+        self.nclasses, self.depth = nclasses, depth
+        self.entries = OrderedDict()
+        self.buffers = OrderedDict()   # running stats: name -> (offset, C)
+        self._build_table()
+        off = 0
+        for e in self.entries.values():
+            e.offset = off
+            off += _round_up(e.numel, 64)          # keep every tensor 256-byte aligned
+        self.total = off
+        boff = 0
+        for k in list(self.buffers):
+            self.buffers[k] = (boff, self.buffers[k][1])
+            boff += _round_up(self.buffers[k][1], 64)
+        self.device = torch.device(device)
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros(boff, dtype=torch.float32, device=self.device)
+        self.num_batches_tracked = 0
+
+    # ------------------------------------------------------------------ table
+    def _add(self, name, kind, ref_shape, kshape):
+        self.entries[name] = _Entry(name, kind, ref_shape, kshape)
+
+    def _add_bn(self, prefix, c):
+        self._add(prefix + ".weight", "vec", (c,), (c,))
+        self._add(prefix + ".bias", "vec", (c,), (c,))
+        self.buffers[prefix + ".running_mean"] = (0, c)
+        self.buffers[prefix + ".running_var"] = (0, c)
+
+    def _build_table(self):
+        C, D = self.nclasses, self.depth
+        self._add("backbone.conv1.weight", "stem", (64, 3, 7, 7), (64, 7, 8, 4))
+        self._add_bn("backbone.bn1", 64)
+        inpl = 64
+        for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET34_LAYERS), start=1):
+            for b in range(nblk):
+                stride = 2 if (b == 0 and li > 1) else 1
+                p = f"backbone.layer{li}.{b}"
+                self._add(p + ".conv1.weight", "conv", (planes, inpl, 3, 3), (planes, 3, 3, inpl))
+                self._add_bn(p + ".bn1", planes)
+                self._add(p + ".conv2.weight", "conv", (planes, planes, 3, 3), (planes, 3, 3, planes))
+                self._add_bn(p + ".bn2", planes)
+                if stride != 1 or inpl != planes:
+                    self._add(p + ".downsample.0.weight", "conv", (planes, inpl, 1, 1), (planes, 1, 1, inpl))
+                    self._add_bn(p + ".downsample.1", planes)
+                inpl = planes
+        # backbone.fc exists in the reference state_dict (resnet.py:164) but never receives a gradient
+        self._add("backbone.fc.weight", "frozen", (1000, 512), (1000, 512))
+        self._add("backbone.fc.bias", "frozen", (1000,), (1000,))
+        self._add("hybrid_head.deconv_layers.0.weight", "deconv", (512, 256, 4, 4), (512, 4, 4, 256))
+        self._add_bn("hybrid_head.deconv_layers.1", 256)
+        self._add("hybrid_head.deconv_layers.3.weight", "deconv", (256, 256, 4, 4), (256, 4, 4, 256))
+        self._add_bn("hybrid_head.deconv_layers.4", 256)
+        self._add("hybrid_head.final_layer.weight", "final_w", (C * D, 256, 1, 1), (C * DEPTH_PITCH, 1, 1, 256))
+        self._add("hybrid_head.final_layer.bias", "final_b", (C * D,), (C * DEPTH_PITCH,))
+        self._add("box_head.layers.0.weight", "linear", (256, 512), (256, 1, 1, 512))
+        self._add("box_head.layers.0.bias", "vec", (256,), (256,))
+        self._add("box_head.layers.2.weight", "linear", (128, 256), (128, 1, 1, 256))
+        self._add("box_head.layers.2.bias", "vec", (128,), (128,))
+        self._add("box_head.layers.4.weight", "linear_pad", (6, 128), (BOX_OUT_PAD, 1, 1, 128))
+        self._add("box_head.layers.4.bias", "vec_pad", (6,), (BOX_OUT_PAD,))
+
+    # ------------------------------------------------------------------ views
+    def view(self, name, buf=None):
+        e = self.entries[name]
+        return (self.flat if buf is None else buf)[e.offset:e.offset + e.numel].view(e.kshape)
+
+    def gview(self, name):
+        return self.view(name, self.grad)
+
+    def stat(self, name):
+        off, c = self.buffers[name]
+        return self.stats[off:off + c]
+
+    def trainable_numel(self):
+        return sum(e.numel for e in self.entries.values() if e.kind != "frozen")
+
+    # ------------------------------------------------------------------ layout conversion
+    def _to_kernel(self, e, t):
+        t = t.to(torch.float32)
+        C, D = self.nclasses, self.depth
+        if e.kind == "stem":
+            k = torch.zeros(e.kshape, dtype=torch.float32, device=t.device)
+            k[:, :, :7, :3] = t.permute(0, 2, 3, 1)
+            return k
+        if e.kind == "conv":
+            return t.permute(0, 2, 3, 1).contiguous()
+        if e.kind == "deconv":       # ConvT weight [Cin_t, Cout_t, kh, kw] -> OHWI of the mirrored conv [Cin_t, kh, kw, Cout_t]
+            return t.permute(0, 2, 3, 1).contiguous()
+        if e.kind == "final_w":
+            k = torch.zeros((C, DEPTH_PITCH, 256), dtype=torch.float32, device=t.device)
+            k[:, :D] = t.reshape(C, D, 256)
+            return k.reshape(e.kshape)
+        if e.kind == "final_b":
+            k = torch.zeros((C, DEPTH_PITCH), dtype=torch.float32, device=t.device)
+            k[:, :D] = t.reshape(C, D)
+            return k.reshape(e.kshape)
+        if e.kind == "linear":
+            return t.reshape(e.kshape)
+        if e.kind == "linear_pad":
+            k = torch.zeros(e.kshape, dtype=torch.float32, device=t.device)
+            k[:t.shape[0], 0, 0] = t
+            return k
+        if e.kind == "vec_pad":
+            k = torch.zeros(e.kshape, dtype=torch.float32, device=t.device)
+            k[:t.shape[0]] = t
+            return k
+        return t.reshape(e.kshape)
+
+    def _to_reference(self, e, k):
+        C, D = self.nclasses, self.depth
+        if e.kind == "stem":
+            return k[:, :, :7, :3].permute(0, 3, 1, 2).contiguous()
+        if e.kind in ("conv", "deconv"):
+            return k.permute(0, 3, 1, 2).contiguous()
+        if e.kind == "final_w":
+            return k.reshape(C, DEPTH_PITCH, 256)[:, :D].reshape(e.ref_shape).contiguous()
+        if e.kind == "final_b":
+            return k.reshape(C, DEPTH_PITCH)[:, :D].reshape(e.ref_shape).contiguous()
+        if e.kind == "linear":
+            return k.reshape(e.ref_shape).contiguous()
+        if e.kind == "linear_pad":
+            return k[:e.ref_shape[0], 0, 0].contiguous()
+        if e.kind == "vec_pad":
+            return k[:e.ref_shape[0]].contiguous()
+        return k.reshape(e.ref_shape).contiguous()
+
+    def load_reference_state_dict(self, sd, strict=True):
+        """sd: reference-format tensors keyed like the reference (an optional '_model_list.0.' / 'module.' prefix is
+        stripped, hybridbaseline.py:111-126)."""
+        clean = {}
+        for k, v in sd.items():
+            for pre in ("module.", "_model_list.0."):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+            clean[k] = v
+        missing = []
+        for name, e in self.entries.items():
+            if name not in clean:
+                missing.append(name)
+                continue
+            t = clean[name]
+            if tuple(t.shape) != e.ref_shape:
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != {e.ref_shape}")
+            self.view(name).copy_(self._to_kernel(e, t.to(self.device)))
+        for name in self.buffers:
+            if name in clean:
+                self.stat(name).copy_(clean[name].to(self.device).float())
+            else:
+                missing.append(name)
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:5]}... ({len(missing)})")
+        return missing
+
+    def reference_state_dict(self, grads=False):
+        out = OrderedDict()
+        for name, e in self.entries.items():
+            out[name] = self._to_reference(e, self.view(name, self.grad if grads else None))
+        if not grads:
+            for name in self.buffers:
+                out[name] = self.stat(name).clone()
+        return out
+
+    def init_reference_like(self, seed=1):
+        """kaiming_normal_(fan_out, relu) for convs / deconvs / final conv, BN weight 1 bias 0 (resnet.py:170-176,
+        simplebaseline.py:104-118), torch default Linear init for the box head and backbone.fc."""
+        g = torch.Generator().manual_seed(seed)
+        sd = {}
+        import math
+        for name, e in self.entries.items():
+            shp = e.ref_shape
+            if e.kind in ("stem", "conv", "final_w"):
+                fan_out = shp[0] * shp[2] * shp[3]
+                sd[name] = math.sqrt(2.0 / fan_out) * torch.randn(shp, generator=g)
+            elif e.kind == "deconv":
+                fan_out = shp[0] * shp[2] * shp[3]     # torch's fan_out of a ConvTranspose weight tensor
+                sd[name] = math.sqrt(2.0 / fan_out) * torch.randn(shp, generator=g)
+            elif e.kind in ("linear", "linear_pad", "frozen") and len(shp) == 2:
+                bound = 1.0 / math.sqrt(shp[1])
+                sd[name] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+            elif name.endswith(".weight") and e.kind == "vec":
+                sd[name] = torch.ones(shp)
+            elif "box_head" in name or "fc.bias" in name:
+                fan_in = self.entries[name.replace(".bias", ".weight")].ref_shape[1]
+                sd[name] = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(fan_in)
+            else:
+                sd[name] = torch.zeros(shp)
+        for name, (_, c) in self.buffers.items():
+            sd[name] = torch.ones(c) if name.endswith("running_var") else torch.zeros(c)
+        self.load_reference_state_dict(sd)
+
+
+class HybridNet:
+    """Explicit forward / backward of HybridBaseline on the HIP kernels."""
+
+    def __init__(self, store: ParamStore, image_size=(256, 256), compute_dtype=torch.bfloat16):
+        self.p = store
+        self.W, self.H = int(image_size[0]), int(image_size[1])
+        self.dtype = compute_dtype
+        self.training = True
+        self.lp = None           # low-precision copy of the flat params (bf16 mode)
+        self.tr = {}             # IHWO (data-gradient) copies of conv weights in the compute dtype
+        self._packed = False
+        self.saved = None
+
+    # ------------------------------------------------------------------ weights in compute precision
+    def _dgrad_names(self):
+        names = []
+        for name, e in self.p.entries.items():
+            if e.kind in ("conv", "deconv", "final_w") and name != "backbone.layer1.0.conv1.weight_never":
+                names.append(name)
+        return names
+
+    def pack_weights(self):
+        """Refresh compute-precision copies after an optimizer step: one cast pass + IHWO transposes."""
+        p = self.p
+        if self.dtype == torch.bfloat16:
+            if self.lp is None:
+                self.lp = torch.empty(p.total, dtype=torch.bfloat16, device=p.device)
+            K.cast_bf16(p.flat, self.lp)
+        else:
+            self.lp = p.flat
+        for name in self._dgrad_names():
+            e = p.entries[name]
+            O, kh, kw, I = e.kshape
+            dst = self.tr.get(name)
+            if dst is None:
+                dst = torch.empty((I, kh, kw, O), dtype=self.dtype, device=p.device)
+                self.tr[name] = dst
+            K.transpose_oki(p.view(name).reshape(O, kh * kw, I), dst)
+        self._packed = True
+
+    def w(self, name):
+        e = self.p.entries[name]
+        return self.lp[e.offset:e.offset + e.numel].view(e.kshape)
+
+    # ------------------------------------------------------------------ BN helper
+    def _bn(self, prefix, y, stats_part, count, res=None, relu=True):
+        p = self.p
+        if self.training:
+            bnp = K.bn_finalize(stats_part, count, p.view(prefix + ".weight"), p.view(prefix + ".bias"),
+                                p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
+        else:
+            bnp = K.bn_eval_params(p.view(prefix + ".weight"), p.view(prefix + ".bias"),
+                                   p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
+        out = K.bn_apply(y, bnp, res=res, relu=relu)
+        return out, bnp
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, image=None, xpad=None):
+        """image: float32 NCHW [N,3,H,W] in [-0.5,0.5]   or   xpad: NHWC4 zero-bordered [N,H+6,W+8,4] compute dtype
+        (what the renderer writes directly).  Returns kp3d [N,22,3] f32, conf [N,22] f32, box6d [N,6] f32."""
+        if not self._packed:
+            self.pack_weights()
+        p, tr, dt = self.p, self.training, self.dtype
+        if xpad is None:
+            xpad = K.image_pad_nhwc4(image.contiguous().float(), dt)
+        N = xpad.shape[0]
+        H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
+        S = {"xpad": xpad, "N": N, "HW": (H, W), "blocks": []}
+        y0, st = K.conv2d_stem_fwd(xpad, self.w("backbone.conv1.weight"), H, W, want_stats=True)
+        a0, bnp0 = self._bn("backbone.bn1", y0, st, N * (H // 2) * (W // 2))
+        x = K.maxpool_fwd(a0)
+        S.update(y0=y0, a0=a0, bnp0=bnp0)
+        inpl = 64
+        for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET34_LAYERS), start=1):
+            for b in range(nblk):
+                stride = 2 if (b == 0 and li > 1) else 1
+                pre = f"backbone.layer{li}.{b}"
+                y1, st1 = K.conv2d_fwd(x, self.w(pre + ".conv1.weight"), stride, 1, want_stats=True)
+                cnt = y1.shape[0] * y1.shape[1] * y1.shape[2]
+                a1, bnp1 = self._bn(pre + ".bn1", y1, st1, cnt)
+                y2, st2 = K.conv2d_fwd(a1, self.w(pre + ".conv2.weight"), 1, 1, want_stats=True)
+                rec = dict(pre=pre, stride=stride, x=x, y1=y1, a1=a1, bnp1=bnp1, y2=y2, ds=False)
+                if stride != 1 or inpl != planes:
+                    yd, std_ = K.conv2d_fwd(x, self.w(pre + ".downsample.0.weight"), stride, 0, want_stats=True)
+                    r, bnpd = self._bn(pre + ".downsample.1", yd, std_, cnt, relu=False)
+                    rec.update(ds=True, yd=yd, bnpd=bnpd)
+                else:
+                    r = x
+                out, bnp2 = self._bn(pre + ".bn2", y2, st2, cnt, res=r, relu=True)
+                rec.update(bnp2=bnp2, out=out)
+                if not tr:
+                    rec = dict(pre=pre)
+                S["blocks"].append(rec)
+                x = out
+                inpl = planes
+        feat = x                                         # res_layer4 [N,h,w,512]
+        fmean = K.avgpool_fwd(feat)                      # res_layer4_mean [N,512] f32 (resnet.py:219)
+        h4, w4 = feat.shape[1], feat.shape[2]
+        # ---- IntegralDeconvHead: ConvT == data-gradient of the mirrored stride-2 conv
+        d1 = K.conv2d_dgrad(feat, self.tr["hybrid_head.deconv_layers.0.weight"], (2 * h4, 2 * w4), 2, 1)
+        e1, bnpd1 = self._bn("hybrid_head.deconv_layers.1", d1, K.col_stats(d1) if tr else None, N * 4 * h4 * w4)
+        d2 = K.conv2d_dgrad(e1, self.tr["hybrid_head.deconv_layers.3.weight"], (4 * h4, 4 * w4), 2, 1)
+        e2, bnpd2 = self._bn("hybrid_head.deconv_layers.4", d2, K.col_stats(d2) if tr else None, N * 16 * h4 * w4)
+        logits = K.conv2d_fwd(e2, self.w("hybrid_head.final_layer.weight"), 1, 0,
+                              bias=p.view("hybrid_head.final_layer.bias"))
+        # ---- MLP_O box head, always f32 (tiny; keeps the 6-D rotation at full precision)
+        m0 = fmean.view(N, 1, 1, 512)
+        b1 = K.conv2d_fwd(m0, p.view("box_head.layers.0.weight"), 1, 0, bias=p.view("box_head.layers.0.bias"), relu=True)
+        b2 = K.conv2d_fwd(b1, p.view("box_head.layers.2.weight"), 1, 0, bias=p.view("box_head.layers.2.bias"), relu=True)
+        b3 = K.conv2d_fwd(b2, p.view("box_head.layers.4.weight"), 1, 0, bias=p.view("box_head.layers.4.bias"))
+        box6d = b3.view(N, BOX_OUT_PAD)[:, :6]
+        S.update(feat=feat, d1=d1, e1=e1, bnpd1=bnpd1, d2=d2, e2=e2, bnpd2=bnpd2, logits=logits, m0=m0, b1=b1, b2=b2)
+        self.saved = S if tr else None
+        self.last = dict(feat=feat, fmean=fmean, logits=logits)
+        return logits, box6d
+
+    def head_fwd(self, logits):
+        """-> kp3d [N,22,3], conf [N,22], stat (kept for head_bwd)."""
+        return softargmax3d_fwd(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH)
+
+    def head_bwd(self, logits, kp3d, conf, stat, g_kp3d, g_conf=None):
+        """dlogits, written in place over the logits buffer (they are not needed again)."""
+        return softargmax3d_bwd(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf,
+                                inplace=True)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dlogits, g_box6d):
+        """dlogits: gradient wrt the logits [N,h,w,22*32] (compute dtype); g_box6d [N,6] f32.
+        Fills self.p.grad (overwrites).  Returns nothing (no gradient to the image)."""
+        S, p, dt = self.saved, self.p, self.dtype
+        if S is None:
+            raise RuntimeError("backward() without a training-mode forward()")
+        N = S["N"]
+        gv = p.gview
+        # ---- box head (f32)
+        g3 = torch.zeros((N, 1, 1, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
+        g3.view(N, BOX_OUT_PAD)[:, :6] = g_box6d
+        K.conv2d_wgrad(S["b2"], g3, 1, 1, 1, 0, out=gv("box_head.layers.4.weight"))
+        K.col_sum(g3, gv("box_head.layers.4.bias"))
+        w4t = p.view("box_head.layers.4.weight").permute(3, 1, 2, 0).contiguous()
+        gb2 = K.relu_bwd(K.conv2d_dgrad(g3, w4t, (1, 1), 1, 0), S["b2"])
+        K.conv2d_wgrad(S["b1"], gb2, 1, 1, 1, 0, out=gv("box_head.layers.2.weight"))
+        K.col_sum(gb2, gv("box_head.layers.2.bias"))
+        w2t = p.view("box_head.layers.2.weight").permute(3, 1, 2, 0).contiguous()
+        gb1 = K.relu_bwd(K.conv2d_dgrad(gb2, w2t, (1, 1), 1, 0), S["b1"])
+        K.conv2d_wgrad(S["m0"], gb1, 1, 1, 1, 0, out=gv("box_head.layers.0.weight"))
+        K.col_sum(gb1, gv("box_head.layers.0.bias"))
+        w0t = p.view("box_head.layers.0.weight").permute(3, 1, 2, 0).contiguous()
+        g_mean = K.conv2d_dgrad(gb1, w0t, (1, 1), 1, 0).view(N, 512)
+        # ---- head
+        e2, e1, feat = S["e2"], S["e1"], S["feat"]
+        K.conv2d_wgrad(e2, dlogits, 1, 1, 1, 0, out=gv("hybrid_head.final_layer.weight"))
+        K.col_sum(dlogits, gv("hybrid_head.final_layer.bias"))
+        de2 = K.conv2d_dgrad(dlogits, self.tr["hybrid_head.final_layer.weight"], (e2.shape[1], e2.shape[2]), 1, 0)
+        dd2 = K.bn_bwd(de2, e2, S["d2"], S["bnpd2"], gv("hybrid_head.deconv_layers.4.weight"),
+                       gv("hybrid_head.deconv_layers.4.bias"), relu=True)
+        K.conv2d_wgrad(dd2, e1, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.3.weight"))
+        de1 = K.conv2d_fwd(dd2, self.w("hybrid_head.deconv_layers.3.weight"), 2, 1)
+        dd1 = K.bn_bwd(de1, e1, S["d1"], S["bnpd1"], gv("hybrid_head.deconv_layers.1.weight"),
+                       gv("hybrid_head.deconv_layers.1.bias"), relu=True)
+        K.conv2d_wgrad(dd1, feat, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.0.weight"))
+        dout = K.conv2d_fwd(dd1, self.w("hybrid_head.deconv_layers.0.weight"), 2, 1)
+        K.avgpool_bwd(g_mean, dout, accumulate=True)
+        # ---- backbone, last block first
+        for rec in reversed(S["blocks"]):
+            pre, stride, x = rec["pre"], rec["stride"], rec["x"]
+            dy2, dz = K.bn_bwd(dout, rec["out"], rec["y2"], rec["bnp2"], gv(pre + ".bn2.weight"), gv(pre + ".bn2.bias"),
+                               relu=True, want_dz=True)
+            K.conv2d_wgrad(rec["a1"], dy2, 3, 3, 1, 1, out=gv(pre + ".conv2.weight"))
+            da1 = K.conv2d_dgrad(dy2, self.tr[pre + ".conv2.weight"], (dy2.shape[1], dy2.shape[2]), 1, 1)
+            dy1 = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["bnp1"], gv(pre + ".bn1.weight"), gv(pre + ".bn1.bias"), relu=True)
+            K.conv2d_wgrad(x, dy1, 3, 3, stride, 1, out=gv(pre + ".conv1.weight"))
+            if rec["ds"]:
+                dyd = K.bn_bwd(dz, None, rec["yd"], rec["bnpd"], gv(pre + ".downsample.1.weight"),
+                               gv(pre + ".downsample.1.bias"), relu=False)
+                K.conv2d_wgrad(x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
+                dx = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1)
+                dout = K.conv2d_dgrad(dyd, self.tr[pre + ".downsample.0.weight"], (x.shape[1], x.shape[2]), stride, 0,
+                                      addend=dx)
+            else:
+                dout = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1, addend=dz)
+        # ---- stem
+        da0 = K.maxpool_bwd(S["a0"], dout)
+        dy0 = K.bn_bwd(da0, S["a0"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"), relu=True)
+        H, W = S["HW"]
+        K.conv2d_stem_wgrad(S["xpad"], dy0, H, W, out=gv("backbone.conv1.weight"))
+        self.saved = None

@@ -205,3 +205,19 @@ def image_pad_nhwc4(img_nchw_f32, dtype):
     L.check(L.lib().ab_image_pad_nhwc4(L.ptr(img_nchw_f32), L.i(L.dt(out)), L.i(N), L.i(H), L.i(W), L.ptr(out),
                                        L.stream()), "ab_image_pad_nhwc4")
     return out
+
+
+def relu_bwd(dout, out):
+    dz = torch.empty_like(dout)
+    L.check(L.lib().ab_relu_bwd(L.ptr(dout), L.ptr(out), L.i(L.dt(dout)), L.l(dout.numel()), L.ptr(dz), L.stream()),
+            "ab_relu_bwd")
+    return dz
+
+
+def col_sum(x, out):
+    C = x.shape[-1]
+    M = x.numel() // C
+    lib = L.lib()
+    part = torch.empty((lib.ab_col_stats_nparts(L.l(M)), C, 2), dtype=torch.float32, device=x.device)
+    L.check(lib.ab_col_sum(L.ptr(x), L.i(L.dt(x)), L.l(M), L.i(C), L.ptr(part), L.ptr(out), L.stream()), "ab_col_sum")
+    return out

@@ -1,0 +1,203 @@
+"""Model plugin classes with the reference's names and call contract (anakin/models/arch.py:11-72,
+anakin/models/hybridbaseline.py:18-129) on top of the HIP executor (hybridnet.HybridNet).
+
+`Arch(cfg, model_list)(batch) -> {TYPE: preds}`; `preds` carries the 7 keys of hybridbaseline.py:86-96.
+`final_loss.backward()` on anything computed from `preds` runs the hand-written backward kernels and leaves the
+gradient in `model.flat_param.grad` (one flat tensor -> clip_grad_norm_ / Adam see one parameter)."""
+from collections import OrderedDict
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .hybridnet import HybridNet, ParamStore
+from .registry import MODEL, Queries, enable_lower_param
+
+
+def ortho6d_to_rotmat(poses):
+    """compute_rotation_matrix_from_ortho6d (anakin/utils/transform.py:578-618)."""
+    def nrm(v):
+        mag = torch.sqrt(v.pow(2).sum(1))
+        mag = torch.max(mag, v.new_tensor([1e-8]))
+        return v / mag[:, None]
+
+    x = nrm(poses[:, 0:3])
+    z = nrm(torch.cross(x, poses[:, 3:6], dim=1))
+    y = torch.cross(z, x, dim=1)
+    return torch.stack([x, y, z], dim=2)
+
+
+def batch_uvd2xyz(uvd, root_joint, intr, inp_res, depth_range=0.4):
+    """anakin/utils/transform.py:512-546 (ref_bone_len == 1)."""
+    res = uvd.new_tensor([float(inp_res[0]), float(inp_res[1])])
+    uv = uvd[:, :, :2] * res
+    z = (uvd[:, :, 2] - 0.5) * depth_range + root_joint[:, 2:3]
+    f = torch.stack([intr[:, 0, 0], intr[:, 1, 1]], 1)[:, None, :]
+    c = torch.stack([intr[:, 0, 2], intr[:, 1, 2]], 1)[:, None, :]
+    xy = (uv - c) / f * z[..., None]
+    return torch.cat([xy, z[..., None]], -1)
+
+
+class _NetBridge(torch.autograd.Function):
+    """Autograd boundary: forward = HIP forward + fused soft-argmax; backward = HIP backward into the flat grad."""
+
+    @staticmethod
+    def forward(ctx, flat_param, owner, image, xpad):
+        net = owner.net
+        logits, box6d = net.forward(image=image, xpad=xpad)
+        kp3d, conf, stat = net.head_fwd(logits)
+        ctx.owner = owner
+        ctx.pack = (logits, kp3d, conf, stat)
+        ctx.mark_non_differentiable(conf)
+        return kp3d, conf, box6d.contiguous()
+
+    @staticmethod
+    def backward(ctx, g_kp3d, g_conf, g_box6d):
+        owner = ctx.owner
+        net = owner.net
+        logits, kp3d, conf, stat = ctx.pack
+        if g_kp3d is None:
+            g_kp3d = torch.zeros_like(kp3d)
+        if g_box6d is None:
+            g_box6d = torch.zeros((kp3d.shape[0], 6), dtype=torch.float32, device=kp3d.device)
+        dlogits = net.head_bwd(logits, kp3d, conf, stat, g_kp3d)
+        net.backward(dlogits, g_box6d.contiguous().float())
+        owner.flat_param.grad = owner.store.grad      # the kernels wrote it; no copy, no accumulation
+        return None, None, None, None
+
+
+@MODEL.register_module
+class HybridBaseline(nn.Module):
+    @enable_lower_param
+    def __init__(self, **cfg):
+        super().__init__()
+        preset = cfg["DATA_PRESET"]
+        self.center_idx = preset.get("CENTER_IDX", 9)
+        self.inp_res = preset["IMAGE_SIZE"]
+        head = cfg["HYBRID_HEAD"]
+        self.nclasses = head["NCLASSES"]
+        self.depth_res = head["DEPTH_RESOLUTION"]
+        if cfg["BACKBONE"]["TYPE"] != "ResNet34":
+            raise NotImplementedError("the HIP path implements the ResNet34 backbone of the clasbased configs")
+        if head.get("NORM_TYPE", "softmax") != "softmax" or head.get("FINAL_CONV_KERNEL", 1) != 1:
+            raise NotImplementedError("IntegralDeconvHead: softmax norm + 1x1 final conv only")
+        if cfg["BACKBONE"].get("FREEZE_BATCHNORM", False):
+            raise NotImplementedError("FREEZE_BATCHNORM")
+        dev = cfg.get("DEVICE", "cuda")
+        cd = cfg.get("COMPUTE_DTYPE", "bf16")
+        self.store = ParamStore(self.nclasses, self.depth_res, device=dev)
+        self.store.init_reference_like(seed=int(cfg.get("INIT_SEED", 1)))
+        self.net = HybridNet(self.store, image_size=self.inp_res,
+                             compute_dtype=torch.bfloat16 if cd in ("bf16", torch.bfloat16) else torch.float32)
+        self.flat_param = nn.Parameter(self.store.flat, requires_grad=True)   # shares storage with the store
+        pretrained = cfg.get("PRETRAINED", "")
+        if pretrained:
+            self.load_pretrained(pretrained)
+
+    # --- reference-compatible checkpoint I/O (hybridbaseline.py:98-129, utils/io_utils.py:19-51)
+    def load_pretrained(self, path):
+        ckpt = torch.load(path, map_location="cpu")
+        sd = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+        self.store.load_reference_state_dict(sd, strict=False)
+        self.net._packed = False
+
+    def state_dict(self, *a, **k):
+        return OrderedDict((k_, v.cpu()) for k_, v in self.store.reference_state_dict().items())
+
+    def load_state_dict(self, sd, strict=True):
+        self.store.load_reference_state_dict(sd, strict=strict)
+        self.net._packed = False
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.net.training = mode
+        return self
+
+    def params_updated(self):
+        """Call after the optimizer changed flat_param (refreshes the compute-precision weight copies)."""
+        self.net._packed = False
+
+    def forward(self, inputs: Dict):
+        dev = self.store.device
+        image = inputs.get(Queries.IMAGE)
+        xpad = inputs.get("image_nhwc4_padded")
+        if xpad is None:
+            image = image.to(dev, non_blocking=True)
+            H, W = image.shape[2], image.shape[3]
+        else:
+            H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
+        if not self.net._packed or self.flat_param._version != getattr(self, "_seen_version", -1):
+            self.net.pack_weights()
+            self._seen_version = self.flat_param._version
+        if self.training and torch.is_grad_enabled():
+            kp3d, conf, box6d = _NetBridge.apply(self.flat_param, self, image, xpad)
+        else:
+            with torch.no_grad():
+                logits, box6d = self.net.forward(image=image, xpad=xpad)
+                kp3d, conf, _ = self.net.head_fwd(logits)
+        root_in = inputs[Queries.ROOT_JOINT].to(dev)
+        intr = inputs[Queries.CAM_INTR].to(dev)
+        pose_3d_abs = batch_uvd2xyz(kp3d, root_in, intr, self.inp_res)
+        joints_3d_abs = pose_3d_abs[:, 0:21, :]
+        boxroot_3d_abs = pose_3d_abs[:, 21:22, :]
+        corners_can_3d = inputs[Queries.CORNERS_CAN].to(dev)
+        box_rot_rotmat = ortho6d_to_rotmat(box6d)
+        corners_3d_abs = torch.matmul(box_rot_rotmat, corners_can_3d.permute(0, 2, 1)).permute(0, 2, 1) + boxroot_3d_abs
+        root_joint = joints_3d_abs[:, self.center_idx, :]
+        corners_2d = torch.matmul(intr, corners_3d_abs.permute(0, 2, 1)).permute(0, 2, 1)
+        corners_2d = corners_2d[:, :, 0:2] / corners_2d[:, :, 2:3]
+        corners_2d = torch.stack([corners_2d[:, :, 0] / W, corners_2d[:, :, 1] / H], dim=2)
+        corners_2d_uvd = torch.cat((corners_2d, torch.zeros_like(corners_2d[:, :, 0:1])), dim=2)
+        final_2d_uvd = torch.cat((kp3d[:, 0:21, :], corners_2d_uvd, kp3d[:, 21:22, :]), dim=1)
+        return {
+            "joints_3d_abs": joints_3d_abs,
+            "corners_3d_abs": corners_3d_abs,
+            "joints_3d": joints_3d_abs - root_joint.unsqueeze(1),
+            "corners_3d": corners_3d_abs - root_joint.unsqueeze(1),
+            "2d_uvd": final_2d_uvd,
+            "boxroot_3d_abs": boxroot_3d_abs,
+            "box_rot_rotmat": box_rot_rotmat,
+            "kp3d": kp3d,
+            "kp3d_confd": conf,
+        }
+
+
+class Arch(nn.Module):
+    """anakin/models/arch.py:11-72: DAG of models keyed by TYPE with PREVIOUS edges."""
+
+    def __init__(self, cfg: Dict, model_list):
+        super().__init__()
+        self._model_list = nn.ModuleList(model_list)
+        self._cfg = cfg
+        items = cfg["ARCH"]
+        if isinstance(items, dict):
+            items = [items]
+        self.models = {it["TYPE"]: {"id": i, "previous": it["PREVIOUS"]} for i, it in enumerate(items)}
+        outdeg = [0] * len(items)
+        for v in self.models.values():
+            for p in v["previous"]:
+                outdeg[self.models[p]["id"]] += 1
+        if outdeg.count(0) != 1:
+            raise Exception("Arch has multiple roots, a circle or other illegal input.!")
+        self.root = items[outdeg.index(0)]["TYPE"]
+
+    @property
+    def model_list(self):
+        return self._model_list
+
+    @property
+    def models_params(self):
+        return [{"params": filter(lambda p: p.requires_grad, m.parameters())} for m in self._model_list]
+
+    def forward(self, input: Dict):
+        self.outputs = {}
+        self._forward(self.root, input)
+        return self.outputs
+
+    def _forward(self, mtype, input):
+        inputs = dict(input)
+        for p in self.models[mtype]["previous"]:
+            if p not in self.outputs:
+                self._forward(p, input)
+            inputs.update(self.outputs[p])
+        self.outputs[mtype] = self._model_list[self.models[mtype]["id"]](inputs)

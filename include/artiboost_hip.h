@@ -31,17 +31,18 @@ int ab_abi_version(void);
 /* ---- M3: fused softmax + 3-D integral (soft-argmax) head ------------------------------------------------------
  * replaces: norm_heatmap('softmax') + max + renorm + view_to_bcdhw + integral_heatmap3d
  *           anakin/models/simplebaseline.py:16-40, 43-71, 183-189
- * logits : [B, H, W, C*D] (NHWC of the reference's (B, C*D, H, W); channel = c*D + d), dtype f32|bf16
+ * logits : [B, H, W, C*DP] (NHWC of the reference's (B, C*D, H, W); channel = c*DP + d, d < D; DP >= D is the
+ *          padded depth pitch -- the model uses DP = 32 so every class is one aligned 64/128-byte run), f32|bf16
  * part   : workspace, float [B, ntile, C, 8]  (ntile from ab_softargmax3d_ntiles)
  * uvd    : float [B, C, 3]  (u = width, v = height, d = depth, each in [0,1))
  * conf   : float [B, C]     (max softmax probability)
  * stat   : float [B, C, 2]  (global max, sum exp(x - max)) kept for backward                                  */
 int ab_softargmax3d_ntiles(int H, int W);
-int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, int D, int H, int W,
+int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W,
                         float* part, float* uvd, float* conf, float* stat, void* stream);
 /* dlogits[b,h,w,c*D+d] = p * ( g_uvd . (coord - uvd) ) / (1+1e-7) + g_conf * conf * (argmax? 1 : 0 - p)
  * g_conf may be NULL.  dlogits has the dtype/layout of logits (may alias logits: in-place is allowed).        */
-int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, int D, int H, int W,
+int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W,
                         const float* uvd, const float* conf, const float* stat,
                         const float* g_uvd, const float* g_conf, void* dlogits, void* stream);
 
@@ -87,6 +88,8 @@ int ab_bn_apply(const void* y, const void* res, const float* bnp, int dtype, lon
 /* part: float [ab_col_stats_nparts(M)][C][2]; bwdp: float [2][C]; dz_out optional (gradient of the residual branch) */
 int ab_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C, int relu,
               float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out, void* stream);
+int ab_relu_bwd(const void* dout, const void* out, int dtype, long n, void* dz, void* stream);
+int ab_col_sum(const void* x, int dtype, long M, int C, float* part, float* out, void* stream);
 int ab_add(const void* a, const void* b, int dtype, long n, void* out, void* stream);
 int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* stream);
 int ab_maxpool3x3s2_bwd(const void* x, const void* dout, int dtype, int N, int H, int W, int C, void* dx, void* stream);

@@ -1,0 +1,112 @@
+"""GPU parity of the whole learner (HybridBaseline forward, losses, backward, clip+Adam) against the REAL reference's
+golden vectors (tests/golden/learner_*.npz) and against the CPU oracle on the same seeded inputs."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import learner_oracle as lo
+from gen_batch import make_batch
+
+pytestmark = pytest.mark.gpu
+
+REF_YAML_ARCH = {
+    "TYPE": "HybridBaseline", "PRETRAINED": "",
+    "BACKBONE": {"TYPE": "ResNet34", "PRETRAINED": False, "FREEZE_BATCHNORM": False},
+    "HYBRID_HEAD": {"TYPE": "IntegralDeconvHead", "NCLASSES": 22, "DECONV_WITH_BIAS": False, "NORM_TYPE": "softmax",
+                    "INPUT_CHANNEL": 512, "DEPTH_RESOLUTION": 28, "NUM_DECONV_LAYERS": 2,
+                    "NUM_DECONV_FILTERS": [256, 256], "NUM_DECONV_KERNELS": [4, 4], "FINAL_CONV_KERNEL": 1},
+    "BOX_HEAD": {"TYPE": "MLP_O", "LAYERS_N": [512, 256, 128], "OUT_CHANNEL": 6},
+    "PREVIOUS": [],
+}
+
+
+def build(size, heat, dtype, seed):
+    from artiboost_amd import registry as R
+    from artiboost_amd.models import Arch
+    from artiboost_amd.criterions import Criterion
+    import artiboost_amd.criterions  # noqa: F401 (registers losses)
+    preset = {"IMAGE_SIZE": [size, size], "HEATMAP_SIZE": [heat, heat], "CENTER_IDX": 0}
+    arch_cfg = dict(REF_YAML_ARCH, COMPUTE_DTYPE=dtype)
+    cfg = {"ARCH": arch_cfg, "LAMBDAS": [0.5, 0.2, 0.1],
+           "CRITERION": [{"TYPE": "JointsLoss", "LAMBDA_JOINTS_3D": 1.0, "LAMBDA_CORNERS_3D": 0.2},
+                         {"TYPE": "HandOrdLoss"}, {"TYPE": "SceneOrdLoss"}]}
+    model = Arch(cfg, R.build_arch_model_list(arch_cfg, preset_cfg=preset))
+    crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=preset, LAMBDAS=cfg["LAMBDAS"]))
+    params = lo.fill_params(lo.param_shapes(22, 28), seed=seed)
+    model.model_list[0].load_state_dict(params)
+    return model, crit, params
+
+
+@pytest.mark.parametrize("tag", ["g224", "g256"])
+def test_f32_path_matches_reference_golden(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"learner_{tag}.npz"))
+    size, heat, depth, B, seed = [int(x) for x in g["meta"]]
+    model, crit, params = build(size, heat, "f32", seed)
+    hb = model.model_list[0]
+    batch = make_batch(B, size, seed + 100)
+    # ---- eval
+    model.eval()
+    with torch.no_grad():
+        preds = model(batch)["HybridBaseline"]
+    for k in ("joints_3d_abs", "corners_3d_abs", "joints_3d", "corners_3d", "2d_uvd", "boxroot_3d_abs", "box_rot_rotmat"):
+        np.testing.assert_allclose(preds[k].cpu().numpy(), g[f"eval.pred.{k}"], rtol=1e-4, atol=3e-5, err_msg=k)
+    lg = hb.net.last["logits"].float().cpu().reshape(B, heat, heat, 22, 32)[..., :28].permute(0, 3, 4, 1, 2).reshape(B, 616, heat, heat)
+    np.testing.assert_allclose(lg[:, ::37, ::5, ::5].numpy(), g["eval.logits.sample"], rtol=2e-3, atol=2e-4)
+    # ---- train: forward, losses with the reference's RNG seeding, backward
+    model.train()
+    preds = model(batch)["HybridBaseline"]
+    for k in ("joints_3d_abs", "corners_3d_abs", "2d_uvd", "box_rot_rotmat"):
+        np.testing.assert_allclose(preds[k].detach().cpu().numpy(), g[f"train.pred.{k}"], rtol=1e-4, atol=3e-5, err_msg=k)
+    random.seed(seed + 7)
+    torch.manual_seed(seed + 7)
+    total, losses = crit.compute_losses(preds, batch)
+    for k in ("joints_3d_loss", "corners_3d_loss", "joint_ord_loss", "part_ord_loss", "scene_ord_loss", "final_loss"):
+        np.testing.assert_allclose(losses[k].detach().cpu().numpy().reshape(-1), g[f"loss.{k}"].reshape(-1),
+                                   rtol=3e-4, atol=1e-7, err_msg=k)
+    total.backward()
+    grads = hb.store.reference_state_dict(grads=True)
+    ref = dict(zip([str(n) for n in g["grad.names"]], g["grad.norms"]))
+    for n, r in ref.items():
+        got = float(grads[n].norm())
+        assert abs(got - r) <= 1e-2 * r + 1e-9, (n, got, r)
+    np.testing.assert_allclose(grads["hybrid_head.final_layer.bias"].cpu().numpy(), g["grad.final_bias"], rtol=3e-3, atol=1e-9)
+    np.testing.assert_allclose(grads["box_head.layers.4.weight"].cpu().numpy(), g["grad.box4.weight"], rtol=3e-3, atol=1e-9)
+    rs = g["grad.conv1.sample"]
+    np.testing.assert_allclose(grads["backbone.conv1.weight"][::8, :, ::3, ::3].cpu().numpy(), rs, rtol=2e-2, atol=3e-2 * np.abs(rs).max())
+    rs = g["grad.deconv3.sample"]
+    np.testing.assert_allclose(grads["hybrid_head.deconv_layers.3.weight"][::32, ::32].cpu().numpy(), rs, rtol=1e-2, atol=1e-2 * np.abs(rs).max())
+    rs = g["grad.l3.0.ds.sample"]
+    np.testing.assert_allclose(grads["backbone.layer3.0.downsample.0.weight"][::16, ::16, 0, 0].cpu().numpy(), rs, rtol=2e-2, atol=2e-2 * np.abs(rs).max())
+    sd = hb.state_dict()
+    np.testing.assert_allclose(sd["backbone.bn1.running_var"].numpy(), g["stat.bn1.running_var"], rtol=1e-4)
+    np.testing.assert_allclose(sd["backbone.layer4.2.bn2.running_var"].numpy(), g["stat.l4.2.bn2.running_var"], rtol=1e-3)
+    assert float(grads["backbone.fc.weight"].abs().max()) == 0.0
+
+
+def test_bf16_path_within_north_star_tolerance(golden_dir):
+    """bf16 conv operands / activations, fp32 accumulate: 3-D joints and corners within 1e-3 (m) of the reference."""
+    g = np.load(os.path.join(golden_dir, "learner_g256.npz"))
+    size, heat, depth, B, seed = [int(x) for x in g["meta"]]
+    model, crit, params = build(size, heat, "bf16", seed)
+    batch = make_batch(B, size, seed + 100)
+    model.eval()
+    with torch.no_grad():
+        preds = model(batch)["HybridBaseline"]
+    for k in ("joints_3d_abs", "corners_3d_abs"):
+        np.testing.assert_allclose(preds[k].cpu().numpy(), g[f"eval.pred.{k}"], rtol=0, atol=1e-3, err_msg=k)
+    model.train()
+    preds = model(batch)["HybridBaseline"]
+    for k in ("joints_3d_abs", "corners_3d_abs"):
+        np.testing.assert_allclose(preds[k].detach().cpu().numpy(), g[f"train.pred.{k}"], rtol=0, atol=1e-3, err_msg=k)
+    random.seed(seed + 7)
+    torch.manual_seed(seed + 7)
+    total, losses = crit.compute_losses(preds, batch)
+    np.testing.assert_allclose(float(total), float(g["loss.final_loss"].reshape(-1)[0]), rtol=2e-2)
+    total.backward()
+    grads = model.model_list[0].store.reference_state_dict(grads=True)
+    ref = dict(zip([str(n) for n in g["grad.names"]], g["grad.norms"]))
+    bad = [(n, float(grads[n].norm()), r) for n, r in ref.items() if abs(float(grads[n].norm()) - r) > 0.15 * r + 1e-9]
+    assert not bad, bad[:5]
