@@ -188,7 +188,7 @@ __global__ void wgrad_reduce(const float* __restrict__ slabs, int nslices, long 
 }
 
 static void pick_wgrad(int M, int Cout, int jtot, int* bi, int* bj, int* nslices, int* rows) {
-    *bi = (Cout >= 128) ? 128 : 64;
+    *bi = (Cout % 128 == 0) ? 128 : 64;
     *bj = (jtot % 128 == 0) ? 128 : 64;
     long tiles = (long)(Cout / *bi) * (jtot / *bj);
     int want = (int)((640 + tiles - 1) / tiles);            // ~2.5 workgroups per CU
