@@ -258,13 +258,19 @@ class HybridNet:
                 names.append(name)
         return names
 
-    def pack_weights(self):
+    def refresh_after_update(self, lp_fresh=False):
+        """Called by the fused optimizer: the bf16 copy was refreshed in the Adam pass; redo only the transposes."""
+        self.pack_weights(skip_cast=lp_fresh)
+
+    def pack_weights(self, skip_cast=False):
         """Refresh compute-precision copies after an optimizer step: one cast pass + IHWO transposes."""
         p = self.p
         if self.dtype == torch.bfloat16:
-            if self.lp is None:
+            if self.lp is None or self.lp.dtype != torch.bfloat16:
                 self.lp = torch.empty(p.total, dtype=torch.bfloat16, device=p.device)
-            K.cast_bf16(p.flat, self.lp)
+                skip_cast = False
+            if not skip_cast:
+                K.cast_bf16(p.flat, self.lp)
         else:
             self.lp = p.flat
         for name in self._dgrad_names():

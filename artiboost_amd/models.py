@@ -127,7 +127,7 @@ class HybridBaseline(nn.Module):
         else:
             H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
         if not self.net._packed or self.flat_param._version != getattr(self, "_seen_version", -1):
-            self.net.pack_weights()
+            self.net.pack_weights()      # torch-side update (e.g. torch.optim.Adam); the fused optimizer repacks itself
             self._seen_version = self.flat_param._version
         if self.training and torch.is_grad_enabled():
             kp3d, conf, box6d = _NetBridge.apply(self.flat_param, self, image, xpad)

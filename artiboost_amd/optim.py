@@ -1,0 +1,56 @@
+"""Fused global-norm clip + Adam over the flat parameter buffer (HIP), with the torch.optim interface the reference
+loop expects (train/train_artiboost.py:91-96; anakin/utils/netutils.py:26-33)."""
+import torch
+
+from . import _lib as L
+
+
+class FusedClipAdam(torch.optim.Optimizer):
+    """Adam(lr, betas, eps, weight_decay=0) on ONE flat fp32 parameter whose .grad is the flat gradient buffer.
+    `max_norm` folds clip_grad_norm_ into the same pass; when the caller already clipped (the reference loop calls
+    torch.nn.utils.clip_grad_norm_ itself) construct with max_norm=None."""
+
+    def __init__(self, params, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None, model=None):
+        if weight_decay:
+            raise NotImplementedError("weight_decay (the reference trains with WEIGHT_DECAY: 0)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.max_norm = max_norm
+        self.model = model
+        self._part = None
+        self.total_norm = None
+
+    def grad_norm(self, grad):
+        if self._part is None:
+            self._part = torch.empty(1024, dtype=torch.float32, device=grad.device)
+            self.total_norm = torch.empty(1, dtype=torch.float32, device=grad.device)
+        L.check(L.lib().ab_grad_norm(L.ptr(grad), L.l(grad.numel()), L.ptr(self._part), L.ptr(self.total_norm),
+                                     L.stream()), "ab_grad_norm")
+        return self.total_norm
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] += 1
+                g = p.grad
+                tn = self.grad_norm(g) if self.max_norm else None
+                lp = None
+                if self.model is not None and self.model.net.dtype == torch.bfloat16 and p is self.model.flat_param:
+                    if self.model.net.lp is None or self.model.net.lp.dtype != torch.bfloat16:
+                        self.model.net.lp = torch.empty(p.numel(), dtype=torch.bfloat16, device=p.device)
+                    lp = self.model.net.lp
+                b1, b2 = group["betas"]
+                L.check(L.lib().ab_clip_adam(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                                             L.l(p.numel()), L.ptr(tn), L.f(self.max_norm or 0.0), L.f(group["lr"]),
+                                             L.f(b1), L.f(b2), L.f(group["eps"]), L.i(st["step"]), L.ptr(lp),
+                                             L.stream()), "ab_clip_adam")
+                if self.model is not None and p is self.model.flat_param:
+                    self.model.net.refresh_after_update(lp_fresh=lp is not None)
+        return None

@@ -99,6 +99,13 @@ int ab_cast_f32_bf16(const float* src, long n, void* dst, void* stream);
 int ab_transpose_oki(const float* src, int O, int K, int I, int dtype, void* dst, void* stream);
 int ab_image_pad_nhwc4(const float* img_nchw, int dtype, int N, int H, int W, void* out, void* stream);
 
+/* ---- T1: global-norm clip + Adam on the flat parameter buffer ---------------------------------------------------
+ * replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step: train/train_artiboost.py:91-96,
+ * anakin/utils/netutils.py:26-33.  part: float[1024] workspace, total_norm: float[1] (device).                  */
+int ab_grad_norm(const float* grad, long n, float* part, float* total_norm, void* stream);
+int ab_clip_adam(float* param, const float* grad, float* m, float* v, long n, const float* total_norm,
+                 float max_norm, float lr, float beta1, float beta2, float eps, int step, void* lp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
