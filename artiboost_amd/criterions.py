@@ -45,6 +45,17 @@ class Criterion(TensorLoss):
     def loss_lambdas(self):
         return self._loss_lambdas
 
+    def draw(self, dev):
+        """Refresh the random draws of every loss (host RNG, reference order) into their device buffers."""
+        for loss in self.loss_list:
+            if hasattr(loss, "draw"):
+                loss.draw(dev)
+
+    def freeze_draws(self, frozen=True):
+        for loss in self.loss_list:
+            if hasattr(loss, "draws"):
+                loss.draws.frozen = frozen
+
     def compute_losses(self, preds: Dict, targs: Dict, **kwargs):
         total, out = super().__call__(preds, targs, **kwargs)
         for loss in self.loss_list:
@@ -103,6 +114,26 @@ def _shuffled_third(n):
     return idx[: n // 3]
 
 
+class _Draws:
+    """Per-call random draws of the ordinal losses, kept in persistent device buffers so that the arithmetic can be
+    captured in a hipGraph: `draw()` (host RNG, same order as the reference) refreshes the buffers with async H2D
+    copies OUTSIDE the graph; the captured ops only read them."""
+
+    def __init__(self):
+        self.dev = None
+        self.bufs = {}
+        self.frozen = False     # True while a captured graph owns the call: __call__ must not draw
+
+    def put(self, name, cpu_tensor, dev):
+        b = self.bufs.get(name)
+        if b is None or b.device != dev or b.shape != cpu_tensor.shape:
+            b = torch.empty(cpu_tensor.shape, dtype=cpu_tensor.dtype, device=dev)
+            self.bufs[name] = b
+        src = cpu_tensor.pin_memory() if dev.type == "cuda" else cpu_tensor
+        b.copy_(src, non_blocking=True)
+        return b
+
+
 def _ord(a, b, views):      # jointlevel_ordinal_relation (ordinal.py:39-56)
     return torch.einsum("bpk,vk->bpv", a - b, views)
 
@@ -116,17 +147,29 @@ class HandOrdLoss(TensorLoss):
         self.n_virtual_views = int(cfg.get("N_VIRTUAL_VIEWS", 20))
         self.joint_pairs_idx = list(combinations(range(CONST.NUM_JOINTS), 2))
         self.parts_pairs_idx = list(combinations(range(CONST.NUM_JOINTS - 1), 2))
+        self.draws = _Draws()
+
+    def draw(self, dev):
+        """RNG order of the reference (ordinal.py:159,165-166,202-203): views, joint-pair shuffle, part-pair shuffle."""
+        d = self.draws
+        d.put("views", sample_view_vectors(self.n_virtual_views), dev)
+        sel = _shuffled_third(len(self.joint_pairs_idx))
+        d.put("j0", torch.tensor([self.joint_pairs_idx[i][0] for i in sel]), dev)
+        d.put("j1", torch.tensor([self.joint_pairs_idx[i][1] for i in sel]), dev)
+        sel = _shuffled_third(len(self.parts_pairs_idx))
+        d.put("p0", torch.tensor([self.parts_pairs_idx[i][0] for i in sel]), dev)
+        d.put("p1", torch.tensor([self.parts_pairs_idx[i][1] for i in sel]), dev)
 
     def __call__(self, preds, targs, **kwargs):
         final_loss, losses = super().__call__(preds, targs, **kwargs)
         dev = final_loss.device
         jp, jt, _, _ = _abs_masked(preds, targs, dev)
-        views = sample_view_vectors(self.n_virtual_views).to(dev)
-        sel = _shuffled_third(len(self.joint_pairs_idx))
-        i0 = [self.joint_pairs_idx[i][0] for i in sel]
-        i1 = [self.joint_pairs_idx[i][1] for i in sel]
-        gt = _ord(jt[:, i0], jt[:, i1], views)
-        pr = _ord(jp[:, i0], jp[:, i1], views)
+        if not self.draws.frozen:
+            self.draw(dev)
+        b = self.draws.bufs
+        views, i0, i1 = b["views"], b["j0"], b["j1"]
+        gt = _ord(jt.index_select(1, i0), jt.index_select(1, i1), views)
+        pr = _ord(jp.index_select(1, i0), jp.index_select(1, i1), views)
         joint_ord_loss = torch.log(1.0 + F.relu(-1.0 * torch.sign(gt) * pr)).mean()
         final_loss = final_loss + self.lambda_joint_lev * joint_ord_loss
         losses["joint_ord_loss"] = joint_ord_loss
@@ -135,11 +178,9 @@ class HandOrdLoss(TensorLoss):
             return (j - j[:, CONST.JOINTS_IDX_PARENTS])[:, 1:]
 
         pp, pt = parts(jp), parts(jt)
-        sel = _shuffled_third(len(self.parts_pairs_idx))
-        a0 = [self.parts_pairs_idx[i][0] for i in sel]
-        a1 = [self.parts_pairs_idx[i][1] for i in sel]
-        gt = torch.einsum("bpk,vk->bpv", torch.cross(pt[:, a0], pt[:, a1], dim=-1), views)
-        pr = torch.einsum("bpk,vk->bpv", torch.cross(pp[:, a0], pp[:, a1], dim=-1), views)
+        a0, a1 = b["p0"], b["p1"]
+        gt = torch.einsum("bpk,vk->bpv", torch.cross(pt.index_select(1, a0), pt.index_select(1, a1), dim=-1), views)
+        pr = torch.einsum("bpk,vk->bpv", torch.cross(pp.index_select(1, a0), pp.index_select(1, a1), dim=-1), views)
         part_ord_loss = F.relu(-1.0 * torch.sign(gt) * pr).mean()
         final_loss = final_loss + self.lambda_part_lev * part_ord_loss
         losses["part_ord_loss"] = part_ord_loss
@@ -154,17 +195,25 @@ class SceneOrdLoss(TensorLoss):
         self.lambda_scene_lev = float(cfg.get("LAMBDA_SCENE_LEVEL", 1.0))
         self.n_virtual_views = int(cfg.get("N_VIRTUAL_VIEWS", 40))
         self.ho_pairs_idx = list(product(range(CONST.NUM_JOINTS), range(CONST.NUM_CORNERS)))
+        self.draws = _Draws()
+
+    def draw(self, dev):
+        d = self.draws
+        d.put("views", sample_view_vectors(self.n_virtual_views), dev)
+        sel = _shuffled_third(len(self.ho_pairs_idx))
+        d.put("i0", torch.tensor([self.ho_pairs_idx[i][0] for i in sel]), dev)
+        d.put("i1", torch.tensor([self.ho_pairs_idx[i][1] for i in sel]), dev)
 
     def __call__(self, preds, targs, **kwargs):
         final_loss, losses = super().__call__(preds, targs, **kwargs)
         dev = final_loss.device
         jp, jt, cp, ct = _abs_masked(preds, targs, dev)
-        views = sample_view_vectors(self.n_virtual_views).to(dev)
-        sel = _shuffled_third(len(self.ho_pairs_idx))
-        i0 = [self.ho_pairs_idx[i][0] for i in sel]
-        i1 = [self.ho_pairs_idx[i][1] for i in sel]
-        gt = _ord(jt[:, i0], ct[:, i1], views)
-        pr = _ord(jp[:, i0], cp[:, i1], views)
+        if not self.draws.frozen:
+            self.draw(dev)
+        b = self.draws.bufs
+        views, i0, i1 = b["views"], b["i0"], b["i1"]
+        gt = _ord(jt.index_select(1, i0), ct.index_select(1, i1), views)
+        pr = _ord(jp.index_select(1, i0), cp.index_select(1, i1), views)
         scene_ord_loss = torch.log(1.0 + F.relu(-1.0 * torch.sign(gt) * pr)).mean()
         final_loss = final_loss + self.lambda_scene_lev * scene_ord_loss
         losses["scene_ord_loss"] = scene_ord_loss

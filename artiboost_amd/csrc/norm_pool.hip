@@ -28,17 +28,18 @@ template <> __device__ __forceinline__ void vstore<bf16_t>(bf16_t* p, const floa
     *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-#define RED_ROWS_PER_BLOCK 2048
+// rows of the [M][C] matrix reduced by one workgroup: ~1024 workgroups for large M, never fewer than 64 rows
+static inline int red_rows(long M) { long r = (M + 1023) / 1024; if (r < 64) r = 64; return (int)((r + 63) / 64 * 64); }
 
 // ---------------------------------------------------------------- column partial sums: (sum x, sum x^2) per block
 template <typename T>
-__global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x, long M, int C, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x, long M, int C, int rows_per_block, float* __restrict__ part) {
     constexpr int V = Vec<T>::N;
     const int vc = C / V;                  // vector lanes along channels
     const int rl = 256 / vc;               // row lanes
     const int cv = threadIdx.x % vc, rr = threadIdx.x / vc;
-    long r0 = (long)blockIdx.x * RED_ROWS_PER_BLOCK;
-    long r1 = r0 + RED_ROWS_PER_BLOCK; if (r1 > M) r1 = M;
+    long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
     float s[V], q[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; }
@@ -62,20 +63,20 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x,
 
 // ---------------------------------------------------------------- BN finalize: partials -> scale/shift, saved stats
 // bnp: float [4][C] = scale (gamma*invstd), shift, mean, invstd.  running stats updated in place when non-null.
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, long count,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, long count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ bnp) {
-    // block: 256 threads = 64 channels x 4 part-lanes
+    // block: 1024 threads = 64 channels x 16 part-lanes
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int k = pl; k < nparts; k += 4) { s += part[((long)k * C + c) * 2]; q += part[((long)k * C + c) * 2 + 1]; }
-    __shared__ double sm[4][64][2];
+        for (int k = pl; k < nparts; k += 16) { s += part[((long)k * C + c) * 2]; q += part[((long)k * C + c) * 2 + 1]; }
+    __shared__ double sm[16][64][2];
     sm[pl][threadIdx.x & 63][0] = s; sm[pl][threadIdx.x & 63][1] = q;
     __syncthreads();
     if (pl == 0 && c < C) {
-        for (int k = 1; k < 4; ++k) { s += sm[k][threadIdx.x][0]; q += sm[k][threadIdx.x][1]; }
+        for (int k = 1; k < 16; ++k) { s += sm[k][threadIdx.x][0]; q += sm[k][threadIdx.x][1]; }
         double mean = s / (double)count;
         double var = q / (double)count - mean * mean; if (var < 0) var = 0;
         float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -126,12 +127,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ y, const float* __restrict__ bnp,
-                                                            long M, int C, int relu, float* __restrict__ part) {
+                                                            long M, int C, int relu, int rows_per_block, float* __restrict__ part) {
     constexpr int V = Vec<T>::N;
     const int vc = C / V, rl = 256 / vc;
     const int cv = threadIdx.x % vc, rr = threadIdx.x / vc;
-    long r0 = (long)blockIdx.x * RED_ROWS_PER_BLOCK;
-    long r1 = r0 + RED_ROWS_PER_BLOCK; if (r1 > M) r1 = M;
+    long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
     float s[V], q[V], mean[V], istd[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; mean[i] = bnp[2 * C + cv * V + i]; istd[i] = bnp[3 * C + cv * V + i]; }
@@ -160,17 +161,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // reduce partials -> dgamma, dbeta (written to the flat grad buffer) and bwdp[2][C] = (sum dz, sum dz*xhat)
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ bwdp) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int k = pl; k < nparts; k += 4) { s += part[((long)k * C + c) * 2]; q += part[((long)k * C + c) * 2 + 1]; }
-    __shared__ double sm[4][64][2];
+        for (int k = pl; k < nparts; k += 16) { s += part[((long)k * C + c) * 2]; q += part[((long)k * C + c) * 2 + 1]; }
+    __shared__ double sm[16][64][2];
     sm[pl][threadIdx.x & 63][0] = s; sm[pl][threadIdx.x & 63][1] = q;
     __syncthreads();
     if (pl == 0 && c < C) {
-        for (int k = 1; k < 4; ++k) { s += sm[k][threadIdx.x][0]; q += sm[k][threadIdx.x][1]; }
+        for (int k = 1; k < 16; ++k) { s += sm[k][threadIdx.x][0]; q += sm[k][threadIdx.x][1]; }
         dbeta[c] = (float)s; dgamma[c] = (float)q;
         bwdp[c] = (float)s; bwdp[C + c] = (float)q;
     }
@@ -214,66 +215,75 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 }
 
 // ---------------------------------------------------------------- 3x3 / stride 2 / pad 1 max-pool (resnet.py:157)
+// forward also records WHICH of the 9 taps won (first maximum in row-major scan order == torch semantics), one byte
+// per output element; backward then gathers from the <= 4 windows covering an input pixel without re-reading x.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C,
-                                                          T* __restrict__ out) {
+                                                          T* __restrict__ out, uint8_t* __restrict__ idx) {
     constexpr int V = Vec<T>::N;
     const int Ho = H / 2, Wo = W / 2, vc = C / V;
     long nvec = (long)N * Ho * Wo * vc;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
         int cv = (int)(i % vc); long pix = i / vc;
         int wo = (int)(pix % Wo); long t = pix / Wo; int ho = (int)(t % Ho); int n = (int)(t / Ho);
-        float m[V];
+        float m[V]; uint8_t am[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) m[k] = -INFINITY;
-        for (int dh = -1; dh <= 1; ++dh) {
-            int h = ho * 2 + dh; if ((unsigned)h >= (unsigned)H) continue;
-            for (int dw = -1; dw <= 1; ++dw) {
-                int w = wo * 2 + dw; if ((unsigned)w >= (unsigned)W) continue;
+        for (int k = 0; k < V; ++k) { m[k] = -INFINITY; am[k] = 0; }
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            int h = ho * 2 + dh - 1; if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                int w = wo * 2 + dw - 1; if ((unsigned)w >= (unsigned)W) continue;
                 float f[V]; vload<T>(x + (((long)n * H + h) * W + w) * C + cv * V, f);
 #pragma unroll
-                for (int k = 0; k < V; ++k) m[k] = fmaxf(m[k], f[k]);
+                for (int k = 0; k < V; ++k) if (f[k] > m[k]) { m[k] = f[k]; am[k] = (uint8_t)(dh * 3 + dw); }
             }
         }
         vstore<T>(out + i * V, m);
+        if (idx) {
+            if constexpr (V == 8) {
+                uint2 o; o.x = am[0] | (am[1] << 8) | (am[2] << 16) | ((uint32_t)am[3] << 24);
+                o.y = am[4] | (am[5] << 8) | (am[6] << 16) | ((uint32_t)am[7] << 24);
+                *(uint2*)(idx + i * V) = o;
+            } else {
+                *(uint32_t*)(idx + i * V) = am[0] | (am[1] << 8) | (am[2] << 16) | ((uint32_t)am[3] << 24);
+            }
+        }
     }
 }
-// backward: dx[h,w] = sum over windows containing (h,w) whose FIRST maximum (row-major scan, torch semantics) is (h,w)
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dout, int N,
-                                                          int H, int W, int C, T* __restrict__ dx) {
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dout,
+                                                          int N, int H, int W, int C, T* __restrict__ dx) {
     constexpr int V = Vec<T>::N;
     const int Ho = H / 2, Wo = W / 2, vc = C / V;
     long nvec = (long)N * H * W * vc;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
         int cv = (int)(i % vc); long pix = i / vc;
         int w = (int)(pix % W); long t = pix / W; int h = (int)(t % H); int n = (int)(t / H);
-        float xc[V], acc[V];
-        vload<T>(x + i * V, xc);
+        float acc[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[k] = 0.f;
-        // windows (ho, wo) with ho*2-1 <= h <= ho*2+1
-        for (int ho = (h) / 2; ho <= (h + 1) / 2; ++ho) {
+        for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
             if (ho >= Ho) continue;
-            for (int wo = (w) / 2; wo <= (w + 1) / 2; ++wo) {
+            int dh = h - (ho * 2 - 1);
+            for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
                 if (wo >= Wo) continue;
-                bool first[V];
+                int code = dh * 3 + (w - (wo * 2 - 1));
+                long o = (((long)n * Ho + ho) * Wo + wo) * C + cv * V;
+                uint8_t am[V];
+                if constexpr (V == 8) {
+                    uint2 q = *(const uint2*)(idx + o);
 #pragma unroll
-                for (int k = 0; k < V; ++k) first[k] = true;
-                for (int dh = -1; dh <= 1; ++dh) {
-                    int hh = ho * 2 + dh; if ((unsigned)hh >= (unsigned)H) continue;
-                    for (int dw = -1; dw <= 1; ++dw) {
-                        int ww = wo * 2 + dw; if ((unsigned)ww >= (unsigned)W) continue;
-                        if (hh == h && ww == w) continue;
-                        float f[V]; vload<T>(x + (((long)n * H + hh) * W + ww) * C + cv * V, f);
-                        bool before = (hh < h) || (hh == h && ww < w);
+                    for (int k = 0; k < 4; ++k) { am[k] = (q.x >> (8 * k)) & 0xff; am[4 + k] = (q.y >> (8 * k)) & 0xff; }
+                } else {
+                    uint32_t q = *(const uint32_t*)(idx + o);
 #pragma unroll
-                        for (int k = 0; k < V; ++k) if (before ? (f[k] >= xc[k]) : (f[k] > xc[k])) first[k] = false;
-                    }
+                    for (int k = 0; k < 4; ++k) am[k] = (q >> (8 * k)) & 0xff;
                 }
-                float g[V]; vload<T>(dout + (((long)n * Ho + ho) * Wo + wo) * C + cv * V, g);
+                float g[V]; vload<T>(dout + o, g);
 #pragma unroll
-                for (int k = 0; k < V; ++k) if (first[k]) acc[k] += g[k];
+                for (int k = 0; k < V; ++k) if (am[k] == code) acc[k] += g[k];
             }
         }
         vstore<T>(dx + i * V, acc);
@@ -354,15 +364,15 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ part, int npart
 static inline int grid_for(long nvec) { long b = (nvec + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 #define DISPATCH(dtype, CALL_F, CALL_B) do { if ((dtype) == AB_DT_F32) { CALL_F; } else if ((dtype) == AB_DT_BF16) { CALL_B; } else return AB_EINVAL; } while (0)
 
-extern "C" int ab_col_stats_nparts(long M) { return (int)((M + RED_ROWS_PER_BLOCK - 1) / RED_ROWS_PER_BLOCK); }
+extern "C" int ab_col_stats_nparts(long M) { int r = red_rows(M); return (int)((M + r - 1) / r); }
 
 extern "C" int ab_col_stats(const void* x, int dtype, long M, int C, float* part, void* stream) {
     if (!x || !part) return AB_EINVAL;
     int V = dtype == AB_DT_F32 ? 4 : 8;
     if (C % V || C / V > 256) return AB_ESHAPE;
     int np = ab_col_stats_nparts(M); int rl = 256 / (C / V); size_t sh = (size_t)rl * C * 2 * 4;
-    DISPATCH(dtype, (col_stats_kernel<float><<<np, 256, sh, as_stream(stream)>>>((const float*)x, M, C, part)),
-             (col_stats_kernel<bf16_t><<<np, 256, sh, as_stream(stream)>>>((const bf16_t*)x, M, C, part)));
+    DISPATCH(dtype, (col_stats_kernel<float><<<np, 256, sh, as_stream(stream)>>>((const float*)x, M, C, red_rows(M), part)),
+             (col_stats_kernel<bf16_t><<<np, 256, sh, as_stream(stream)>>>((const bf16_t*)x, M, C, red_rows(M), part)));
     AB_LAUNCH_CHECK(); return 0;
 }
 
@@ -370,7 +380,7 @@ extern "C" int ab_bn_finalize(const float* part, int nparts, int C, long count, 
                               float eps, float momentum, float* running_mean, float* running_var, float* bnp,
                               void* stream) {
     if (!part || !gamma || !beta || !bnp) return AB_EINVAL;
-    bn_finalize_kernel<<<(C + 63) / 64, 256, 0, as_stream(stream)>>>(part, nparts, C, count, gamma, beta, eps, momentum,
+    bn_finalize_kernel<<<(C + 63) / 64, 1024, 0, as_stream(stream)>>>(part, nparts, C, count, gamma, beta, eps, momentum,
                                                                     running_mean, running_var, bnp);
     AB_LAUNCH_CHECK(); return 0;
 }
@@ -400,10 +410,10 @@ extern "C" int ab_bn_bwd(const void* dout, const void* out, const void* y, const
     if (C % V || C / V > 256) return AB_ESHAPE;
     int np = ab_col_stats_nparts(M); int rl = 256 / (C / V); size_t sh = (size_t)rl * C * 2 * 4;
     hipStream_t st = as_stream(stream);
-    DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, part)),
-             (bn_bwd_reduce_kernel<bf16_t><<<np, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, part)));
+    DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, red_rows(M), part)),
+             (bn_bwd_reduce_kernel<bf16_t><<<np, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, red_rows(M), part)));
     AB_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<(C + 63) / 64, 256, 0, st>>>(part, np, C, dgamma, dbeta, bwdp);
+    bn_bwd_finalize_kernel<<<(C + 63) / 64, 1024, 0, st>>>(part, np, C, dgamma, dbeta, bwdp);
     AB_LAUNCH_CHECK();
     long nvec = M * C / V;
     DISPATCH(dtype, (bn_bwd_apply_kernel<float><<<grid_for(nvec), 256, 0, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, bwdp, nvec, C, M, relu, (float*)dy, (float*)dz_out)),
@@ -419,19 +429,19 @@ extern "C" int ab_add(const void* a, const void* b, int dtype, long n, void* out
     AB_LAUNCH_CHECK(); return 0;
 }
 
-extern "C" int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* stream) {
+extern "C" int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* idx, void* stream) {
     int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
     long nvec = (long)N * (H / 2) * (W / 2) * C / V;
-    DISPATCH(dtype, (maxpool_fwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)x, N, H, W, C, (float*)out)),
-             (maxpool_fwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)x, N, H, W, C, (bf16_t*)out)));
+    DISPATCH(dtype, (maxpool_fwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)x, N, H, W, C, (float*)out, (uint8_t*)idx)),
+             (maxpool_fwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)x, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
     AB_LAUNCH_CHECK(); return 0;
 }
-extern "C" int ab_maxpool3x3s2_bwd(const void* x, const void* dout, int dtype, int N, int H, int W, int C, void* dx,
+extern "C" int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx,
                                    void* stream) {
     int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
     long nvec = (long)N * H * W * C / V;
-    DISPATCH(dtype, (maxpool_bwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)x, (const float*)dout, N, H, W, C, (float*)dx)),
-             (maxpool_bwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)x, (const bf16_t*)dout, N, H, W, C, (bf16_t*)dx)));
+    DISPATCH(dtype, (maxpool_bwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const uint8_t*)idx, (const float*)dout, N, H, W, C, (float*)dx)),
+             (maxpool_bwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const uint8_t*)idx, (const bf16_t*)dout, N, H, W, C, (bf16_t*)dx)));
     AB_LAUNCH_CHECK(); return 0;
 }
 

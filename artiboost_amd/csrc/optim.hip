@@ -37,7 +37,9 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __restric
                                                                 float* __restrict__ m, float* __restrict__ v, long n,
                                                                 const float* __restrict__ total_norm, float max_norm,
                                                                 float lr, float b1, float b2, float eps, float bc1,
-                                                                float bc2_sqrt, bf16_t* __restrict__ lp) {
+                                                                float bc2_sqrt, const float* __restrict__ hyper,
+                                                                bf16_t* __restrict__ lp) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }   // device-side step state (hipGraph replay)
     float coef = 1.f;
     if (max_norm > 0.f) { coef = max_norm / (total_norm[0] + 1e-6f); coef = coef > 1.f ? 1.f : coef; }
     const float step = lr / bc1;
@@ -80,16 +82,18 @@ extern "C" int ab_grad_norm(const float* grad, long n, float* part, float* total
 }
 
 // step: 1-based.  max_norm <= 0 disables clipping.  lp (optional): bf16 copy of the updated params.
+// hyper (optional, device float[3] = {lr, 1-beta1^step, sqrt(1-beta2^step)}) overrides lr/step so that a captured
+// hipGraph can be replayed with per-step values.
 extern "C" int ab_clip_adam(float* param, const float* grad, float* m, float* v, long n, const float* total_norm,
-                            float max_norm, float lr, float beta1, float beta2, float eps, int step, void* lp,
-                            void* stream) {
+                            float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                            const float* hyper, void* lp, void* stream) {
     if (!param || !grad || !m || !v || (max_norm > 0.f && !total_norm)) return AB_EINVAL;
     if (n % 4 || step < 1) return AB_ESHAPE;
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     long b = (n / 4 + OPT_THREADS - 1) / OPT_THREADS;
     int nb = (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
     clip_adam_kernel<<<nb, OPT_THREADS, 0, as_stream(stream)>>>(param, grad, m, v, n, total_norm, max_norm, lr, beta1,
-                                                                beta2, eps, (float)bc1, (float)sqrt(bc2), (bf16_t*)lp);
+                                                                beta2, eps, (float)bc1, (float)sqrt(bc2), hyper, (bf16_t*)lp);
     AB_LAUNCH_CHECK();
     return 0;
 }

@@ -313,8 +313,8 @@ class HybridNet:
         S = {"xpad": xpad, "N": N, "HW": (H, W), "blocks": []}
         y0, st = K.conv2d_stem_fwd(xpad, self.w("backbone.conv1.weight"), H, W, want_stats=True)
         a0, bnp0 = self._bn("backbone.bn1", y0, st, N * (H // 2) * (W // 2))
-        x = K.maxpool_fwd(a0)
-        S.update(y0=y0, a0=a0, bnp0=bnp0)
+        x, pool_idx = K.maxpool_fwd(a0)
+        S.update(y0=y0, a0=a0, bnp0=bnp0, pool_idx=pool_idx)
         inpl = 64
         for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET34_LAYERS), start=1):
             for b in range(nblk):
@@ -425,7 +425,7 @@ class HybridNet:
             else:
                 dout = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1, addend=dz)
         # ---- stem
-        da0 = K.maxpool_bwd(S["a0"], dout)
+        da0 = K.maxpool_bwd(S["pool_idx"], dout, (S["a0"].shape[1], S["a0"].shape[2]))
         dy0 = K.bn_bwd(da0, S["a0"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"), relu=True)
         H, W = S["HW"]
         K.conv2d_stem_wgrad(S["xpad"], dy0, H, W, out=gv("backbone.conv1.weight"))

@@ -154,19 +154,21 @@ def add(a, b, out=None):
     return o
 
 
-def maxpool_fwd(x):
+def maxpool_fwd(x, want_idx=True):
     N, H, W, C = x.shape
     o = _empty((N, H // 2, W // 2, C), x)
-    L.check(L.lib().ab_maxpool3x3s2_fwd(L.ptr(x), L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(C), L.ptr(o), L.stream()),
-            "ab_maxpool3x3s2_fwd")
-    return o
+    idx = torch.empty((N, H // 2, W // 2, C), dtype=torch.uint8, device=x.device) if want_idx else None
+    L.check(L.lib().ab_maxpool3x3s2_fwd(L.ptr(x), L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(C), L.ptr(o), L.ptr(idx),
+                                        L.stream()), "ab_maxpool3x3s2_fwd")
+    return (o, idx) if want_idx else o
 
 
-def maxpool_bwd(x, dout):
-    N, H, W, C = x.shape
-    dx = torch.empty_like(x)
-    L.check(L.lib().ab_maxpool3x3s2_bwd(L.ptr(x), L.ptr(dout), L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(C), L.ptr(dx),
-                                        L.stream()), "ab_maxpool3x3s2_bwd")
+def maxpool_bwd(idx, dout, in_hw):
+    N, Ho, Wo, C = dout.shape
+    H, W = in_hw
+    dx = _empty((N, H, W, C), dout)
+    L.check(L.lib().ab_maxpool3x3s2_bwd(L.ptr(idx), L.ptr(dout), L.i(L.dt(dout)), L.i(N), L.i(H), L.i(W), L.i(C),
+                                        L.ptr(dx), L.stream()), "ab_maxpool3x3s2_bwd")
     return dx
 
 

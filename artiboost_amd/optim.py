@@ -18,6 +18,23 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.model = model
         self._part = None
         self.total_norm = None
+        self.hyper = None           # device float[3]; set by use_device_hyper() for hipGraph replay
+        self._hyper_host = None
+        self.graph_steps = 0
+
+    def use_device_hyper(self, device):
+        self.hyper = torch.zeros(3, dtype=torch.float32, device=device)
+        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+
+    def advance_hyper(self):
+        """Host side of a replayed step: bump the step count and push {lr, bias corrections} to the device."""
+        self.graph_steps += 1
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        self._hyper_host[0] = g["lr"]
+        self._hyper_host[1] = 1.0 - b1 ** self.graph_steps
+        self._hyper_host[2] = (1.0 - b2 ** self.graph_steps) ** 0.5
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
 
     def grad_norm(self, grad):
         if self._part is None:
@@ -49,8 +66,8 @@ class FusedClipAdam(torch.optim.Optimizer):
                 b1, b2 = group["betas"]
                 L.check(L.lib().ab_clip_adam(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
                                              L.l(p.numel()), L.ptr(tn), L.f(self.max_norm or 0.0), L.f(group["lr"]),
-                                             L.f(b1), L.f(b2), L.f(group["eps"]), L.i(st["step"]), L.ptr(lp),
-                                             L.stream()), "ab_clip_adam")
+                                             L.f(b1), L.f(b2), L.f(group["eps"]), L.i(st["step"]), L.ptr(self.hyper),
+                                             L.ptr(lp), L.stream()), "ab_clip_adam")
                 if self.model is not None and p is self.model.flat_param:
                     self.model.net.refresh_after_update(lp_fresh=lp is not None)
         return None

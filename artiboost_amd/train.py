@@ -1,0 +1,110 @@
+"""One training step of the coupled hot path (train/train_artiboost.py:66-96 `epoch_pass` body):
+   [render next synthetic batch] -> arch_model(batch) -> criterion -> backward -> [grad all-reduce] -> clip -> Adam.
+
+`TrainStep` runs it eagerly (reference-shaped, every call re-issues ~600 launches from Python) or as replayed
+hipGraphs (one capture, then ~tens of microseconds of host work per step): everything between the batch being
+resident in HBM and the parameters being updated is device work on one stream; per-step host inputs (loss RNG draws,
+Adam bias corrections, CCV sample descriptors) go through small pinned -> device copies issued before the replay.
+With world_size > 1 the step is split in two graphs around the RCCL all-reduce of the flat gradient buffer, which
+runs on a side stream and overlaps with the render of the next batch."""
+import torch
+
+from .registry import Queries
+
+
+class TrainStep:
+    def __init__(self, arch_model, criterion, optimizer, example_batch, use_graph=True, dist_group=None,
+                 renderer=None):
+        self.model = arch_model
+        self.hb = arch_model.model_list[0]
+        self.crit = criterion
+        self.opt = optimizer
+        self.dev = self.hb.store.device
+        self.use_graph = use_graph
+        self.renderer = renderer          # object with .render_into(static_batch) enqueuing device work
+        self.group = dist_group
+        self.world = torch.distributed.get_world_size(dist_group) if dist_group is not None else 1
+        self.static = {k: (v.to(self.dev).clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        self.out = None
+        self.g_fwd_bwd = None
+        self.g_opt = None
+        self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+        self.steps = 0
+        if use_graph:
+            self.opt.use_device_hyper(self.dev)
+
+    # ------------------------------------------------------------------ pieces
+    def _fwd_bwd(self):
+        if self.renderer is not None:
+            self.renderer.render_into(self.static)
+        preds = self.model(self.static)["HybridBaseline"]
+        total, losses = self.crit.compute_losses(preds, self.static)
+        self.opt.zero_grad(set_to_none=True)
+        total.backward()
+        return preds, total, losses
+
+    def _optim(self):
+        self.opt.step()
+
+    def _allreduce(self):
+        """Average the flat gradient across ranks on the side stream (RCCL over xGMI), bucketed so the first buckets'
+        transfer overlaps the later ones' launch; clip uses the post-all-reduce norm (single-process semantics)."""
+        g = self.hb.store.grad
+        cur = torch.cuda.current_stream(self.dev)
+        self.comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self.comm_stream):
+            n = g.numel()
+            bucket = 8 << 20          # 8 Mi floats = 32 MiB per bucket
+            for s in range(0, n, bucket):
+                torch.distributed.all_reduce(g[s:s + bucket], op=torch.distributed.ReduceOp.SUM, group=self.group)
+            g.mul_(1.0 / self.world)
+        cur.wait_stream(self.comm_stream)
+
+    # ------------------------------------------------------------------ capture
+    def _capture(self):
+        self.crit.draw(self.dev)
+        self.opt.advance_hyper()
+        self.opt.graph_steps = 0
+        torch.cuda.synchronize(self.dev)
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):          # warm-up on a side stream (allocator, lazy state) before capture
+            self.crit.freeze_draws(True)
+            self._fwd_bwd()
+            self._optim()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        self.g_fwd_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd_bwd):
+            self.out = self._fwd_bwd()
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt, pool=self.g_fwd_bwd.pool()):
+            self._optim()
+        self.opt.graph_steps = 1            # the warm-up above performed one real update
+
+    # ------------------------------------------------------------------ public
+    def load_batch(self, batch):
+        """Copy a host/device batch into the static input buffers (async on the current stream)."""
+        for k, v in batch.items():
+            if torch.is_tensor(v) and k in self.static:
+                self.static[k].copy_(v, non_blocking=True)
+
+    def __call__(self, batch=None):
+        if batch is not None:
+            self.load_batch(batch)
+        if not self.use_graph:
+            self.out = self._fwd_bwd()
+            if self.world > 1:
+                self._allreduce()
+            self._optim()
+        else:
+            if self.g_fwd_bwd is None:
+                self._capture()
+            self.crit.draw(self.dev)
+            self.opt.advance_hyper()
+            self.g_fwd_bwd.replay()
+            if self.world > 1:
+                self._allreduce()
+            self.g_opt.replay()
+        self.steps += 1
+        return self.out

@@ -91,8 +91,9 @@ int ab_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp
 int ab_relu_bwd(const void* dout, const void* out, int dtype, long n, void* dz, void* stream);
 int ab_col_sum(const void* x, int dtype, long M, int C, float* part, float* out, void* stream);
 int ab_add(const void* a, const void* b, int dtype, long n, void* out, void* stream);
-int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* stream);
-int ab_maxpool3x3s2_bwd(const void* x, const void* dout, int dtype, int N, int H, int W, int C, void* dx, void* stream);
+/* idx: uint8 [N,H/2,W/2,C] winning tap (0..8, first maximum in row-major order); H,W describe the pool INPUT          */
+int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* idx, void* stream);
+int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx, void* stream);
 int ab_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, float* out, void* stream);
 int ab_avgpool_bwd(const float* g, int dtype, int N, int HW, int C, void* dx, int accumulate, void* stream);
 int ab_cast_f32_bf16(const float* src, long n, void* dst, void* stream);
@@ -101,10 +102,12 @@ int ab_image_pad_nhwc4(const float* img_nchw, int dtype, int N, int H, int W, vo
 
 /* ---- T1: global-norm clip + Adam on the flat parameter buffer ---------------------------------------------------
  * replaces torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step: train/train_artiboost.py:91-96,
- * anakin/utils/netutils.py:26-33.  part: float[1024] workspace, total_norm: float[1] (device).                  */
+ * anakin/utils/netutils.py:26-33.  part: float[1024] workspace, total_norm: float[1] (device).  hyper (optional):
+ * device float[3] = {lr, 1-beta1^step, sqrt(1-beta2^step)} overriding lr/step (per-step values under graph replay). */
 int ab_grad_norm(const float* grad, long n, float* part, float* total_norm, void* stream);
 int ab_clip_adam(float* param, const float* grad, float* m, float* v, long n, const float* total_norm,
-                 float max_norm, float lr, float beta1, float beta2, float eps, int step, void* lp, void* stream);
+                 float max_norm, float lr, float beta1, float beta2, float eps, int step, const float* hyper,
+                 void* lp, void* stream);
 
 #ifdef __cplusplus
 }

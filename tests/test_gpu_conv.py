@@ -200,9 +200,9 @@ def test_maxpool_avgpool(shape, dtype):
     dout = rnd(ref.shape, g, dtype)
     ref.backward(dout)
     xd = nhwc(x.detach()).to(dtype).cuda()
-    out = K.maxpool_fwd(xd)
+    out, idx = K.maxpool_fwd(xd)
     np.testing.assert_array_equal(nchw(out.float().cpu()).numpy(), ref.detach().numpy())
-    dx = K.maxpool_bwd(xd, nhwc(dout).to(dtype).cuda())
+    dx = K.maxpool_bwd(idx, nhwc(dout).to(dtype).cuda(), (H, W))
     np.testing.assert_allclose(nchw(dx.float().cpu()).numpy(), x.grad.numpy(), **tol(dtype, x.grad))
     m = K.avgpool_fwd(xd)
     np.testing.assert_allclose(m.cpu().numpy(), x.detach().mean(3).mean(2).numpy(), rtol=1e-5, atol=1e-6)

@@ -28,7 +28,7 @@ def test_clip_adam_matches_oracle(n, max_norm):
         if max_norm:
             np.testing.assert_allclose(float(opt.total_norm), float(tn), rtol=1e-5)
         np.testing.assert_allclose(p.detach().cpu().numpy(), ps[0].numpy(), rtol=1e-6, atol=1e-7)
-        np.testing.assert_allclose(opt.state[p]["exp_avg_sq"].cpu().numpy(), v[0].numpy(), rtol=1e-5, atol=1e-30)
+        np.testing.assert_allclose(opt.state[p]["exp_avg_sq"].cpu().numpy(), v[0].numpy(), rtol=1e-4, atol=1e-30)
 
 
 def test_learner_step_matches_reference_golden(golden_dir):
