@@ -290,3 +290,71 @@ class SymCornerLoss(TensorLoss):
         losses["sym_corners_3d_loss"] = loss
         losses[self.output_key] = final_loss
         return final_loss, losses
+
+
+class FusedPoseCriterion:
+    """Pose assembly + JointsLoss + HandOrdLoss + SceneOrdLoss + per-sample EPE + backward in ONE HIP kernel
+    (csrc/pose_loss.hip).  Built from a `Criterion` whose loss list is [JointsLoss, HandOrdLoss, SceneOrdLoss] (any
+    subset); uses that criterion's draw buffers so the RNG behaviour is the reference's."""
+
+    def __init__(self, criterion: Criterion, inp_res, center_idx=0):
+        import ctypes
+        self.crit = criterion
+        self.inp_res = inp_res
+        self.center_idx = center_idx
+        w = [0.0] * 8
+        self.hand = self.scene = None
+        for loss in criterion.loss_list:
+            lam = criterion.loss_lambdas[type(loss).__name__]
+            if isinstance(loss, JointsLoss):
+                w[0], w[1], w[5] = float(loss.lambda_joints_3d), float(loss.lambda_corners_3d), float(lam)
+            elif isinstance(loss, HandOrdLoss):
+                w[2], w[3], w[6] = loss.lambda_joint_lev, loss.lambda_part_lev, float(lam)
+                self.hand = loss
+            elif isinstance(loss, SceneOrdLoss):
+                w[4], w[7] = loss.lambda_scene_lev, float(lam)
+                self.scene = loss
+            else:
+                raise NotImplementedError(f"{type(loss).__name__} is not part of the fused criterion")
+        self.weights = (ctypes.c_float * 8)(*w)
+        self.out = None
+
+    def draw(self, dev):
+        self.crit.draw(dev)
+
+    def _alloc(self, B, dev):
+        z = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)   # noqa: E731
+        self.out = dict(joints_3d_abs=z(B, 21, 3), corners_3d_abs=z(B, 8, 3), box_rot_rotmat=z(B, 3, 3),
+                        uvd2d=z(B, 30, 3), sample_part=z(B, 8), losses=z(8), g_kp3d=z(B, 22, 3), g_box6d=z(B, 6))
+
+    def __call__(self, kp3d, box6d_buf, box_stride, targs, backward=True):
+        """kp3d [B,22,3] f32; box6d_buf: f32 buffer whose rows (pitch box_stride) start with the 6-D rotation."""
+        from . import _lib as L
+        B, dev = kp3d.shape[0], kp3d.device
+        if self.out is None or self.out["g_kp3d"].shape[0] != B:
+            self._alloc(B, dev)
+        o = self.out
+        hb = self.hand.draws.bufs if self.hand is not None else {}
+        sb = self.scene.draws.bufs if self.scene is not None else {}
+        nvh = hb["views"].shape[0] if hb else 0
+        nvs = sb["views"].shape[0] if sb else 0
+        t = lambda k: targs[k]   # noqa: E731
+        L.check(L.lib().ab_pose_loss(
+            L.ptr(kp3d), L.ptr(box6d_buf), L.i(box_stride), L.ptr(t(Queries.ROOT_JOINT)), L.ptr(t(Queries.CAM_INTR)),
+            L.ptr(t(Queries.CORNERS_CAN)), L.ptr(t(Queries.JOINTS_3D)), L.ptr(t(Queries.CORNERS_3D)),
+            L.ptr(t(Queries.JOINTS_VIS)), L.ptr(t(Queries.CORNERS_VIS)),
+            L.ptr(hb.get("views")), L.i(nvh), L.ptr(hb.get("j0")), L.ptr(hb.get("j1")), L.i(hb["j0"].numel() if hb else 0),
+            L.ptr(hb.get("p0")), L.ptr(hb.get("p1")), L.i(hb["p0"].numel() if hb else 0),
+            L.ptr(sb.get("views")), L.i(nvs), L.ptr(sb.get("i0")), L.ptr(sb.get("i1")), L.i(sb["i0"].numel() if sb else 0),
+            L.i(B), L.i(self.center_idx), L.f(self.inp_res[0]), L.f(self.inp_res[1]), self.weights,
+            L.ptr(o["joints_3d_abs"]), L.ptr(o["corners_3d_abs"]), L.ptr(o["box_rot_rotmat"]), L.ptr(o["uvd2d"]),
+            L.ptr(o["sample_part"]), L.ptr(o["losses"]), L.ptr(o["g_kp3d"] if backward else None),
+            L.ptr(o["g_box6d"] if backward else None), L.stream()), "ab_pose_loss")
+        return o
+
+    LOSS_KEYS = ("joints_3d_loss", "corners_3d_loss", "joint_ord_loss", "part_ord_loss", "scene_ord_loss", "final_loss")
+
+    def losses_dict(self):
+        """Host view of the loss scalars of the last call (synchronises)."""
+        v = self.out["losses"].cpu()
+        return {k: v[i] for i, k in enumerate(self.LOSS_KEYS)}

@@ -1,0 +1,341 @@
+// Fused pose assembly + criterion, forward AND backward, one wave per sample.
+//
+// replaces ~150 tiny torch kernels per step:
+//   pose assembly   anakin/models/hybridbaseline.py:49-96 (batch_uvd2xyz utils/transform.py:512-546,
+//                   compute_rotation_matrix_from_ortho6d utils/transform.py:578-618, corners = R*can + boxroot)
+//   JointsLoss      anakin/criterions/jointloss.py:25-67      (vis-masked MSE, joints + 0.2 corners)
+//   HandOrdLoss     anakin/criterions/ordinal.py:144-227      (joint-pair log(1+relu) + part-pair relu, 1+20 views)
+//   SceneOrdLoss    anakin/criterions/ordinal.py:262-306      (joint-corner pairs, 1+40 views)
+//   Criterion       anakin/criterions/criterion.py:57-67      (lambda-weighted sum)
+//   per-sample EPE  anakin/metrics/val_metric.py:84-106       (mm, feeds the CCV re-weighting)
+// and their autograd backward down to d(kp3d) and d(box6d).  The random draws (view vectors, pair subsets) are
+// inputs, drawn on the host in the reference's RNG order.  Deterministic: no atomics; fixed reduction order.
+#include "common.h"
+
+#define PL_NJ 21
+#define PL_NC 8
+#define PL_MAXPAIR 96
+#define PL_MAXVIEW 48
+
+struct PoseLossArgs {
+    const float* kp3d;      // [B,22,3] uvd in [0,1)
+    const float* box6d;     // [B,box_stride] first 6 valid
+    int box_stride;
+    const float* root_joint;   // [B,3]
+    const float* cam_intr;     // [B,3,3]
+    const float* corners_can;  // [B,8,3]
+    const float* joints_3d;    // [B,21,3] root-relative targets
+    const float* corners_3d;   // [B,8,3]
+    const float* joints_vis;   // [B,21]
+    const float* corners_vis;  // [B,8]
+    const float* hand_views;   // [nvh,3]
+    const float* scene_views;  // [nvs,3]
+    const int64_t* j0; const int64_t* j1;   // [njp] joint pairs
+    const int64_t* p0; const int64_t* p1;   // [npp] part pairs (indices into the 20 parts)
+    const int64_t* s0; const int64_t* s1;   // [nsp] (joint, corner) pairs
+    int nvh, nvs, njp, npp, nsp;
+    int B, center_idx;
+    float res_w, res_h, depth_range;
+    float lam_joints, lam_corners;          // inside JointsLoss (1.0, 0.2)
+    float lam_hand_joint, lam_hand_part, lam_scene;   // inside the ordinal losses (1,1,1)
+    float w_jointsloss, w_handord, w_sceneord;        // Criterion LAMBDAS (0.5, 0.2, 0.1); 0 disables a loss
+    // outputs
+    float* joints_abs;      // [B,21,3]
+    float* corners_abs;     // [B,8,3]
+    float* rotmat;          // [B,3,3]
+    float* uvd2d;           // [B,30,3]  (2d_uvd: 21 joints uvd, 8 corners (u,v,0), boxroot uvd)
+    float* sample_part;     // [B,8] per-sample loss partial sums + EPE: Lj, Lc, jo, po, so, epe_j_mm, epe_c_mm, -
+    float* g_kp3d;          // [B,22,3]   (may be NULL: forward only)
+    float* g_box6d;         // [B,6]
+};
+
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+__constant__ int c_parents[21] = {0, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 0, 13, 14, 15, 0, 17, 18, 19};
+
+__global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ float P[22][3];        // predicted abs positions (21 joints + boxroot)
+    __shared__ float C[8][3];         // predicted abs corners
+    __shared__ float mP[21][3], mT[21][3], mC[8][3], mTC[8][3];   // vis-masked pred / target
+    __shared__ float T[21][3], TC[8][3];
+    __shared__ float part_p[20][3], part_t[20][3];
+    __shared__ float vj[21], vc[8];
+    __shared__ float R[3][3], xh[3], yh[3], zh[3], zraw[3], avec[3], bvec[3], an, zn;
+    __shared__ float hv[PL_MAXVIEW][3], sv[PL_MAXVIEW][3];
+    __shared__ float gjp[PL_MAXPAIR][3];                 // gradient wrt (mP_a - mP_b) per joint pair
+    __shared__ float gpp[PL_MAXPAIR][3], gpq[PL_MAXPAIR][3];   // gradient wrt part_p, part_q per part pair
+    __shared__ float gsp[PL_MAXPAIR][3];                 // gradient wrt (mP_a - mC_c) per scene pair
+    __shared__ float gpart[20][3];
+    __shared__ float gP[22][3], gC[8][3];
+    __shared__ float red[64][5];
+    __shared__ float fx, fy, cx, cy, rootz;
+
+    const float* kp = a.kp3d + (long)b * 66;
+    if (lane == 0) {
+        const float* K = a.cam_intr + (long)b * 9;
+        fx = K[0]; fy = K[4]; cx = K[2]; cy = K[5]; rootz = a.root_joint[b * 3 + 2];
+    }
+    for (int i = lane; i < a.nvh * 3; i += 64) hv[i / 3][i % 3] = a.hand_views[i];
+    for (int i = lane; i < a.nvs * 3; i += 64) sv[i / 3][i % 3] = a.scene_views[i];
+    if (lane < 21) vj[lane] = a.joints_vis[b * 21 + lane];
+    if (lane < 8) vc[lane] = a.corners_vis[b * 8 + lane];
+    if (lane < 3) { avec[lane] = a.box6d[(long)b * a.box_stride + lane]; bvec[lane] = a.box6d[(long)b * a.box_stride + 3 + lane]; }
+    __syncthreads();
+    // ---- uvd -> xyz (transform.py:512-546)
+    if (lane < 22) {
+        float u = kp[lane * 3], v = kp[lane * 3 + 1], d = kp[lane * 3 + 2];
+        float z = (d - 0.5f) * a.depth_range + rootz;
+        P[lane][0] = (u * a.res_w - cx) / fx * z;
+        P[lane][1] = (v * a.res_h - cy) / fy * z;
+        P[lane][2] = z;
+    }
+    // ---- ortho6d -> R (transform.py:578-618)
+    if (lane == 0) {
+        float n = sqrtf(dot3(avec, avec)); n = fmaxf(n, 1e-8f); an = n;
+        for (int i = 0; i < 3; ++i) xh[i] = avec[i] / n;
+        cross3(xh, bvec, zraw);
+        float m = sqrtf(dot3(zraw, zraw)); m = fmaxf(m, 1e-8f); zn = m;
+        for (int i = 0; i < 3; ++i) zh[i] = zraw[i] / m;
+        cross3(zh, xh, yh);
+        for (int i = 0; i < 3; ++i) { R[i][0] = xh[i]; R[i][1] = yh[i]; R[i][2] = zh[i]; }
+    }
+    __syncthreads();
+    if (lane < 24) {
+        int c = lane / 3, i = lane % 3;
+        const float* can = a.corners_can + ((long)b * 8 + c) * 3;
+        C[c][i] = R[i][0] * can[0] + R[i][1] * can[1] + R[i][2] * can[2] + P[21][i];
+    }
+    if (lane < 63) {
+        int k = lane / 3, i = lane % 3;
+        float t = a.joints_3d[((long)b * 21 + k) * 3 + i] + a.root_joint[b * 3 + i];
+        T[k][i] = t; mT[k][i] = t * vj[k]; mP[k][i] = P[k][i] * vj[k];
+    }
+    __syncthreads();
+    if (lane < 24) {
+        int c = lane / 3, i = lane % 3;
+        float t = a.corners_3d[((long)b * 8 + c) * 3 + i] + a.root_joint[b * 3 + i];
+        TC[c][i] = t; mTC[c][i] = t * vc[c]; mC[c][i] = C[c][i] * vc[c];
+    }
+    if (lane < 60) {
+        int k = lane / 3 + 1, i = lane % 3;
+        part_p[k - 1][i] = mP[k][i] - mP[c_parents[k]][i];
+        part_t[k - 1][i] = mT[k][i] - mT[c_parents[k]][i];
+    }
+    __syncthreads();
+    // ---- outputs
+    if (lane < 63) a.joints_abs[(long)b * 63 + lane] = P[lane / 3][lane % 3];
+    if (lane < 24) a.corners_abs[(long)b * 24 + lane] = C[lane / 3][lane % 3];
+    if (lane < 9) a.rotmat[(long)b * 9 + lane] = R[lane / 3][lane % 3];
+    if (a.uvd2d) {
+        float* o = a.uvd2d + (long)b * 90;
+        if (lane < 21) { o[lane * 3] = kp[lane * 3]; o[lane * 3 + 1] = kp[lane * 3 + 1]; o[lane * 3 + 2] = kp[lane * 3 + 2]; }
+        if (lane < 8) {
+            const float* K = a.cam_intr + (long)b * 9;
+            float X = C[lane][0], Y = C[lane][1], Z = C[lane][2];
+            float hx = K[0] * X + K[1] * Y + K[2] * Z, hy = K[3] * X + K[4] * Y + K[5] * Z, hz = K[6] * X + K[7] * Y + K[8] * Z;
+            o[(21 + lane) * 3] = hx / hz / a.res_w; o[(21 + lane) * 3 + 1] = hy / hz / a.res_h; o[(21 + lane) * 3 + 2] = 0.f;
+        }
+        if (lane < 3) o[29 * 3 + lane] = kp[21 * 3 + lane];
+    }
+    // ---- losses: per-lane partial sums   [Lj, Lc, jo, po, so]
+    float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const float B_ = (float)a.B;
+    const float nJ = B_ * 63.f, nC = B_ * 24.f;
+    const float nJO = B_ * a.njp * a.nvh, nPO = B_ * a.npp * a.nvh, nSO = B_ * a.nsp * a.nvs;
+    if (lane < 63) { float d = mP[lane / 3][lane % 3] - mT[lane / 3][lane % 3]; acc[0] = d * d; }
+    if (lane < 24) { float d = mC[lane / 3][lane % 3] - mTC[lane / 3][lane % 3]; acc[1] = d * d; }
+    // joint-level ordinal: one pair per lane-iteration, loop over views
+    const float wjo = a.w_handord * a.lam_hand_joint / nJO;
+    for (int pi = lane; pi < a.njp; pi += 64) {
+        int i0 = (int)a.j0[pi], i1 = (int)a.j1[pi];
+        float dt[3], dp[3], g[3] = {0.f, 0.f, 0.f};
+        for (int i = 0; i < 3; ++i) { dt[i] = mT[i0][i] - mT[i1][i]; dp[i] = mP[i0][i] - mP[i1][i]; }
+        for (int v = 0; v < a.nvh; ++v) {
+            float s = sgn(dot3(dt, hv[v])), t = -s * dot3(dp, hv[v]);
+            if (t > 0.f) {
+                acc[2] += log1pf(t);
+                float c = wjo * (-s) / (1.f + t);
+                g[0] += c * hv[v][0]; g[1] += c * hv[v][1]; g[2] += c * hv[v][2];
+            }
+        }
+        gjp[pi][0] = g[0]; gjp[pi][1] = g[1]; gjp[pi][2] = g[2];
+    }
+    // part-level ordinal
+    const float wpo = a.w_handord * a.lam_hand_part / nPO;
+    for (int pi = lane; pi < a.npp; pi += 64) {
+        int i0 = (int)a.p0[pi], i1 = (int)a.p1[pi];
+        float ct[3], cp[3], gp[3] = {0.f, 0.f, 0.f}, gq[3] = {0.f, 0.f, 0.f};
+        cross3(part_t[i0], part_t[i1], ct);
+        cross3(part_p[i0], part_p[i1], cp);
+        for (int v = 0; v < a.nvh; ++v) {
+            float s = sgn(dot3(ct, hv[v])), t = -s * dot3(cp, hv[v]);
+            if (t > 0.f) {
+                acc[3] += t;
+                float c = wpo * (-s);
+                float qn[3], np_[3];
+                cross3(part_p[i1], hv[v], qn);       // d((p x q).n)/dp = q x n
+                cross3(hv[v], part_p[i0], np_);      // d((p x q).n)/dq = n x p
+                for (int i = 0; i < 3; ++i) { gp[i] += c * qn[i]; gq[i] += c * np_[i]; }
+            }
+        }
+        for (int i = 0; i < 3; ++i) { gpp[pi][i] = gp[i]; gpq[pi][i] = gq[i]; }
+    }
+    // scene ordinal
+    const float wso = a.w_sceneord * a.lam_scene / nSO;
+    for (int pi = lane; pi < a.nsp; pi += 64) {
+        int i0 = (int)a.s0[pi], i1 = (int)a.s1[pi];
+        float dt[3], dp[3], g[3] = {0.f, 0.f, 0.f};
+        for (int i = 0; i < 3; ++i) { dt[i] = mT[i0][i] - mTC[i1][i]; dp[i] = mP[i0][i] - mC[i1][i]; }
+        for (int v = 0; v < a.nvs; ++v) {
+            float s = sgn(dot3(dt, sv[v])), t = -s * dot3(dp, sv[v]);
+            if (t > 0.f) {
+                acc[4] += log1pf(t);
+                float c = wso * (-s) / (1.f + t);
+                g[0] += c * sv[v][0]; g[1] += c * sv[v][1]; g[2] += c * sv[v][2];
+            }
+        }
+        gsp[pi][0] = g[0]; gsp[pi][1] = g[1]; gsp[pi][2] = g[2];
+    }
+    for (int i = 0; i < 5; ++i) red[lane][i] = acc[i];
+    __syncthreads();
+    if (lane < 5) {
+        float s = 0.f;
+        for (int l = 0; l < 64; ++l) s += red[l][lane];
+        a.sample_part[(long)b * 8 + lane] = s;
+    }
+    if (lane == 5 || lane == 6) {     // per-sample EPE in mm (unmasked, absolute), val_metric.py:96-104
+        float s = 0.f;
+        if (lane == 5) { for (int k = 0; k < 21; ++k) { float d[3] = {P[k][0] - T[k][0], P[k][1] - T[k][1], P[k][2] - T[k][2]}; s += sqrtf(dot3(d, d)); } s = s / 21.f * 1000.f; }
+        else { for (int k = 0; k < 8; ++k) { float d[3] = {C[k][0] - TC[k][0], C[k][1] - TC[k][1], C[k][2] - TC[k][2]}; s += sqrtf(dot3(d, d)); } s = s / 8.f * 1000.f; }
+        a.sample_part[(long)b * 8 + lane] = s;
+    }
+    if (!a.g_kp3d) return;
+    // ---- backward, deterministic gather
+    // part gradients: gpart[k] = sum over part pairs containing k
+    if (lane < 60) {
+        int k = lane / 3, i = lane % 3;
+        float s = 0.f;
+        for (int pi = 0; pi < a.npp; ++pi) { if ((int)a.p0[pi] == k) s += gpp[pi][i]; if ((int)a.p1[pi] == k) s += gpq[pi][i]; }
+        gpart[k][i] = s;
+    }
+    __syncthreads();
+    const float wJ = a.w_jointsloss * a.lam_joints * 2.f / nJ, wC = a.w_jointsloss * a.lam_corners * 2.f / nC;
+    if (lane < 63) {      // gradient wrt masked joint mP[k][i], then * vis
+        int k = lane / 3, i = lane % 3;
+        float s = wJ * (mP[k][i] - mT[k][i]);
+        for (int pi = 0; pi < a.njp; ++pi) { if ((int)a.j0[pi] == k) s += gjp[pi][i]; if ((int)a.j1[pi] == k) s -= gjp[pi][i]; }
+        for (int pi = 0; pi < a.nsp; ++pi) if ((int)a.s0[pi] == k) s += gsp[pi][i];
+        if (k >= 1) s += gpart[k - 1][i];
+        for (int c = 1; c < 21; ++c) if (c_parents[c] == k) s -= gpart[c - 1][i];
+        gP[k][i] = s * vj[k];
+    }
+    if (lane < 24) {
+        int c = lane / 3, i = lane % 3;
+        float s = wC * (mC[c][i] - mTC[c][i]);
+        for (int pi = 0; pi < a.nsp; ++pi) if ((int)a.s1[pi] == c) s -= gsp[pi][i];
+        gC[c][i] = s * vc[c];
+    }
+    __syncthreads();
+    if (lane < 3) {      // boxroot receives every corner gradient
+        float s = 0.f;
+        for (int c = 0; c < 8; ++c) s += gC[c][lane];
+        gP[21][lane] = s;
+    }
+    __syncthreads();
+    if (lane < 22) {     // xyz -> uvd
+        float u = kp[lane * 3], v = kp[lane * 3 + 1];
+        float z = P[lane][2];
+        float gx = gP[lane][0], gy = gP[lane][1], gz = gP[lane][2];
+        float* o = a.g_kp3d + (long)b * 66 + lane * 3;
+        o[0] = gx * a.res_w / fx * z;
+        o[1] = gy * a.res_h / fy * z;
+        o[2] = a.depth_range * (gx * (u * a.res_w - cx) / fx + gy * (v * a.res_h - cy) / fy + gz);
+    }
+    if (lane == 0) {     // R -> 6D
+        float GR[3][3];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            float s = 0.f;
+            for (int c = 0; c < 8; ++c) s += gC[c][i] * a.corners_can[((long)b * 8 + c) * 3 + j];
+            GR[i][j] = s;
+        }
+        float gx[3] = {GR[0][0], GR[1][0], GR[2][0]}, gy[3] = {GR[0][1], GR[1][1], GR[2][1]}, gz[3] = {GR[0][2], GR[1][2], GR[2][2]};
+        float t[3];
+        cross3(xh, gy, t); for (int i = 0; i < 3; ++i) gz[i] += t[i];        // y = z x x
+        cross3(gy, zh, t); for (int i = 0; i < 3; ++i) gx[i] += t[i];
+        float gzr[3]; float dz = dot3(zh, gz);
+        for (int i = 0; i < 3; ++i) gzr[i] = (gz[i] - zh[i] * dz) / zn;       // z = zraw / |zraw|
+        cross3(bvec, gzr, t); for (int i = 0; i < 3; ++i) gx[i] += t[i];      // zraw = x x b
+        float gb[3]; cross3(gzr, xh, gb);
+        float dx = dot3(xh, gx), ga[3];
+        for (int i = 0; i < 3; ++i) ga[i] = (gx[i] - xh[i] * dx) / an;        // x = a / |a|
+        float* o = a.g_box6d + (long)b * 6;
+        o[0] = ga[0]; o[1] = ga[1]; o[2] = ga[2]; o[3] = gb[0]; o[4] = gb[1]; o[5] = gb[2];
+    }
+}
+
+// losses[8]: joints_3d_loss, corners_3d_loss, joint_ord_loss, part_ord_loss, scene_ord_loss, final_loss, mean epe_j, mean epe_c
+__global__ void pose_loss_finalize(const float* __restrict__ sample_part, PoseLossArgs a, float* __restrict__ losses) {
+    const int lane = threadIdx.x;
+    if (lane < 7) {
+        double s = 0.0;
+        for (int b = 0; b < a.B; ++b) s += sample_part[(long)b * 8 + lane];
+        float B_ = (float)a.B, v = 0.f;
+        if (lane == 0) v = (float)(s / (B_ * 63.f));
+        if (lane == 1) v = (float)(s / (B_ * 24.f));
+        if (lane == 2) v = (float)(s / (B_ * a.njp * a.nvh));
+        if (lane == 3) v = (float)(s / (B_ * a.npp * a.nvh));
+        if (lane == 4) v = (float)(s / (B_ * a.nsp * a.nvs));
+        if (lane >= 5) v = (float)(s / B_);
+        losses[lane < 5 ? lane : lane + 1] = v;
+    }
+    __syncthreads();
+    if (lane == 0)
+        losses[5] = a.w_jointsloss * (a.lam_joints * losses[0] + a.lam_corners * losses[1]) +
+                    a.w_handord * (a.lam_hand_joint * losses[2] + a.lam_hand_part * losses[3]) +
+                    a.w_sceneord * (a.lam_scene * losses[4]);
+}
+
+extern "C" int ab_pose_loss(const float* kp3d, const float* box6d, int box_stride, const float* root_joint,
+                            const float* cam_intr, const float* corners_can, const float* joints_3d,
+                            const float* corners_3d, const float* joints_vis, const float* corners_vis,
+                            const float* hand_views, int nvh, const int64_t* j0, const int64_t* j1, int njp,
+                            const int64_t* p0, const int64_t* p1, int npp, const float* scene_views, int nvs,
+                            const int64_t* s0, const int64_t* s1, int nsp, int B, int center_idx, float res_w,
+                            float res_h, const float* weights8_host, float* joints_abs, float* corners_abs, float* rotmat,
+                            float* uvd2d, float* sample_part, float* losses, float* g_kp3d, float* g_box6d,
+                            void* stream) {
+    if (!kp3d || !box6d || !root_joint || !cam_intr || !corners_can || !joints_3d || !corners_3d || !joints_vis ||
+        !corners_vis || !weights8_host || !joints_abs || !corners_abs || !rotmat || !sample_part || !losses)
+        return AB_EINVAL;
+    if (njp > PL_MAXPAIR || npp > PL_MAXPAIR || nsp > PL_MAXPAIR || nvh > PL_MAXVIEW || nvs > PL_MAXVIEW || B < 1) return AB_ESHAPE;
+    if ((weights8_host[5] != 0.f || weights8_host[6] != 0.f) && (!hand_views || !j0 || !j1 || !p0 || !p1)) return AB_EINVAL;
+    if (weights8_host[7] != 0.f && (!scene_views || !s0 || !s1)) return AB_EINVAL;
+    PoseLossArgs a = {};
+    a.kp3d = kp3d; a.box6d = box6d; a.box_stride = box_stride; a.root_joint = root_joint; a.cam_intr = cam_intr;
+    a.corners_can = corners_can; a.joints_3d = joints_3d; a.corners_3d = corners_3d; a.joints_vis = joints_vis;
+    a.corners_vis = corners_vis; a.hand_views = hand_views; a.scene_views = scene_views;
+    a.j0 = j0; a.j1 = j1; a.p0 = p0; a.p1 = p1; a.s0 = s0; a.s1 = s1;
+    a.nvh = weights8_host[5] != 0.f || weights8_host[6] != 0.f ? nvh : 0; a.nvs = weights8_host[7] != 0.f ? nvs : 0;
+    a.njp = a.nvh ? njp : 0; a.npp = a.nvh ? npp : 0; a.nsp = a.nvs ? nsp : 0;
+    a.B = B; a.center_idx = center_idx; a.res_w = res_w; a.res_h = res_h; a.depth_range = 0.4f;
+    // weights8_host = {lam_joints, lam_corners, lam_hand_joint, lam_hand_part, lam_scene, w_JointsLoss, w_HandOrdLoss, w_SceneOrdLoss}
+    a.lam_joints = weights8_host[0]; a.lam_corners = weights8_host[1]; a.lam_hand_joint = weights8_host[2]; a.lam_hand_part = weights8_host[3];
+    a.lam_scene = weights8_host[4]; a.w_jointsloss = weights8_host[5]; a.w_handord = weights8_host[6]; a.w_sceneord = weights8_host[7];
+    a.joints_abs = joints_abs; a.corners_abs = corners_abs; a.rotmat = rotmat; a.uvd2d = uvd2d;
+    a.sample_part = sample_part; a.g_kp3d = g_kp3d; a.g_box6d = g_box6d;
+    if (a.njp == 0) a.njp = 0;
+    pose_loss_kernel<<<B, 64, 0, as_stream(stream)>>>(a);
+    AB_LAUNCH_CHECK();
+    // guard the normalisers of disabled losses
+    PoseLossArgs f = a;
+    if (f.njp == 0) { f.njp = 1; f.npp = 1; f.nvh = 1; }
+    if (f.nsp == 0) { f.nsp = 1; f.nvs = 1; }
+    pose_loss_finalize<<<1, 64, 0, as_stream(stream)>>>(sample_part, f, losses);
+    AB_LAUNCH_CHECK();
+    return 0;
+}

@@ -356,7 +356,7 @@ class HybridNet:
         box6d = b3.view(N, BOX_OUT_PAD)[:, :6]
         S.update(feat=feat, d1=d1, e1=e1, bnpd1=bnpd1, d2=d2, e2=e2, bnpd2=bnpd2, logits=logits, m0=m0, b1=b1, b2=b2)
         self.saved = S if tr else None
-        self.last = dict(feat=feat, fmean=fmean, logits=logits)
+        self.last = dict(feat=feat, fmean=fmean, logits=logits, box_raw=b3.view(N, BOX_OUT_PAD))
         return logits, box6d
 
     def head_fwd(self, logits):
@@ -379,7 +379,7 @@ class HybridNet:
         gv = p.gview
         # ---- box head (f32)
         g3 = torch.zeros((N, 1, 1, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
-        g3.view(N, BOX_OUT_PAD)[:, :6] = g_box6d
+        g3.view(N, BOX_OUT_PAD)[:, :6].copy_(g_box6d)
         K.conv2d_wgrad(S["b2"], g3, 1, 1, 1, 0, out=gv("box_head.layers.4.weight"))
         K.col_sum(g3, gv("box_head.layers.4.bias"))
         w4t = p.view("box_head.layers.4.weight").permute(3, 1, 2, 0).contiguous()

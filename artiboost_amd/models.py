@@ -17,8 +17,7 @@ from .registry import MODEL, Queries, enable_lower_param
 def ortho6d_to_rotmat(poses):
     """compute_rotation_matrix_from_ortho6d (anakin/utils/transform.py:578-618)."""
     def nrm(v):
-        mag = torch.sqrt(v.pow(2).sum(1))
-        mag = torch.max(mag, v.new_tensor([1e-8]))
+        mag = torch.clamp(torch.sqrt(v.pow(2).sum(1)), min=1e-8)
         return v / mag[:, None]
 
     x = nrm(poses[:, 0:3])
@@ -29,8 +28,7 @@ def ortho6d_to_rotmat(poses):
 
 def batch_uvd2xyz(uvd, root_joint, intr, inp_res, depth_range=0.4):
     """anakin/utils/transform.py:512-546 (ref_bone_len == 1)."""
-    res = uvd.new_tensor([float(inp_res[0]), float(inp_res[1])])
-    uv = uvd[:, :, :2] * res
+    uv = torch.stack([uvd[:, :, 0] * float(inp_res[0]), uvd[:, :, 1] * float(inp_res[1])], dim=2)
     z = (uvd[:, :, 2] - 0.5) * depth_range + root_joint[:, 2:3]
     f = torch.stack([intr[:, 0, 0], intr[:, 1, 1]], 1)[:, None, :]
     c = torch.stack([intr[:, 0, 2], intr[:, 1, 2]], 1)[:, None, :]

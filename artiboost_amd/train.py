@@ -14,7 +14,7 @@ from .registry import Queries
 
 class TrainStep:
     def __init__(self, arch_model, criterion, optimizer, example_batch, use_graph=True, dist_group=None,
-                 renderer=None):
+                 renderer=None, fused_criterion=True):
         self.model = arch_model
         self.hb = arch_model.model_list[0]
         self.crit = criterion
@@ -32,16 +32,37 @@ class TrainStep:
         self.steps = 0
         if use_graph:
             self.opt.use_device_hyper(self.dev)
+        self.fused = None
+        if fused_criterion:
+            from .criterions import FusedPoseCriterion
+            self.fused = FusedPoseCriterion(criterion, self.hb.inp_res, self.hb.center_idx)
 
     # ------------------------------------------------------------------ pieces
     def _fwd_bwd(self):
         if self.renderer is not None:
             self.renderer.render_into(self.static)
+        if self.fused is not None:
+            return self._fwd_bwd_fused()
         preds = self.model(self.static)["HybridBaseline"]
         total, losses = self.crit.compute_losses(preds, self.static)
         self.opt.zero_grad(set_to_none=True)
         total.backward()
         return preds, total, losses
+
+    def _fwd_bwd_fused(self):
+        """Autograd-free path: HIP forward -> fused soft-argmax -> fused pose+criterion(+backward) -> HIP backward."""
+        hb, net, st = self.hb, self.hb.net, self.static
+        net.training = True
+        if not net._packed:
+            net.pack_weights()
+        logits, _ = net.forward(image=st.get(Queries.IMAGE), xpad=st.get("image_nhwc4_padded"))
+        kp3d, conf, stat = net.head_fwd(logits)
+        o = self.fused(kp3d, net.last["box_raw"], net.last["box_raw"].shape[-1], st)
+        dlogits = net.head_bwd(logits, kp3d, conf, stat, o["g_kp3d"])
+        net.backward(dlogits, o["g_box6d"])
+        hb.flat_param.grad = hb.store.grad
+        preds = dict(o, kp3d=kp3d, kp3d_confd=conf)
+        return preds, o["losses"], o
 
     def _optim(self):
         self.opt.step()

@@ -109,6 +109,25 @@ int ab_clip_adam(float* param, const float* grad, float* m, float* v, long n, co
                  float max_norm, float lr, float beta1, float beta2, float eps, int step, const float* hyper,
                  void* lp, void* stream);
 
+/* ---- M4 + L1-L3 + V1: fused pose assembly + criterion, forward and backward --------------------------------------
+ * replaces (one wave per sample, deterministic): anakin/models/hybridbaseline.py:49-96 (uvd->xyz, 6D->R, corners),
+ * anakin/criterions/jointloss.py:25-67, ordinal.py:144-227, 262-306, criterion.py:57-67 and the per-sample EPE of
+ * anakin/metrics/val_metric.py:84-106.  Random draws are inputs (host RNG, reference order): views [nv,3] float,
+ * pair index lists int64.  weights8_host (HOST pointer) = {LAMBDA_JOINTS_3D, LAMBDA_CORNERS_3D, LAMBDA_JOINTS_LEVEL,
+ * LAMBDA_PART_LEVEL, LAMBDA_SCENE_LEVEL, LAMBDAS[JointsLoss], LAMBDAS[HandOrdLoss], LAMBDAS[SceneOrdLoss]}.
+ * outputs: joints_abs [B,21,3], corners_abs [B,8,3], rotmat [B,3,3], uvd2d [B,30,3] (optional), sample_part [B,8]
+ * (per-sample partial sums; [5],[6] = joint / corner EPE in mm), losses float[8] = joints_3d_loss, corners_3d_loss,
+ * joint_ord_loss, part_ord_loss, scene_ord_loss, final_loss, mean EPE joints, mean EPE corners;
+ * g_kp3d [B,22,3], g_box6d [B,6] = d final_loss / d input (NULL g_kp3d: forward only).                          */
+int ab_pose_loss(const float* kp3d, const float* box6d, int box_stride, const float* root_joint,
+                 const float* cam_intr, const float* corners_can, const float* joints_3d, const float* corners_3d,
+                 const float* joints_vis, const float* corners_vis, const float* hand_views, int nvh,
+                 const int64_t* j0, const int64_t* j1, int njp, const int64_t* p0, const int64_t* p1, int npp,
+                 const float* scene_views, int nvs, const int64_t* s0, const int64_t* s1, int nsp, int B,
+                 int center_idx, float res_w, float res_h, const float* weights8_host, float* joints_abs,
+                 float* corners_abs, float* rotmat, float* uvd2d, float* sample_part, float* losses, float* g_kp3d,
+                 float* g_box6d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
