@@ -114,6 +114,8 @@ class TrainStep:
         if batch is not None:
             self.load_batch(batch)
         if not self.use_graph:
+            if self.fused is not None:
+                self.crit.draw(self.dev)
             self.out = self._fwd_bwd()
             if self.world > 1:
                 self._allreduce()
