@@ -1,0 +1,446 @@
+// Online synthesis on the training GPU: triangle setup -> tiled z-buffer rasteriser in LDS -> deferred shading +
+// background composite -> PIL-semantics colour jitter -> nearest-neighbour affine crop, writing the network input
+// (zero-bordered NHWC4) directly.  Replaces the reference's per-image pipeline
+//   anakin/utils/renderer.py:101-136 (pyrender/OpenGL draw + np.putmask background), anakin/artiboost/render_infra.py
+//   (two multiprocessing queue hops per image) and rendered_dataset.py:256-270 + utils/img_augment.py (PIL on CPU workers)
+// with batched kernels: one launch renders all B images.
+//
+// Integer rules (vertex snapping 1/256 px, int64 edge functions, top-left rule, 24-bit depth, key = depth<<32|face)
+// are DEFINED in oracle/render_oracle.c (the reference's rasteriser is the GL driver: parity unpinned); this file
+// must match that oracle bit for bit.  Float work uses the same operation order and no FMA contraction.
+//
+// Rasteriser: one workgroup per 32x32-pixel tile; the tile's z-buffer is 1024 u64 keys in LDS; each lane takes one
+// triangle record at a time (the meshes are 1-20 px per face at this camera distance, so lane-per-triangle keeps all
+// 64 lanes busy) and resolves visibility with ds_min_u64; tiles outside the sample's screen bounding box skip
+// straight to the background.  The HBM side is small (a 48-byte record per face, 4 bytes per pixel out).
+#include "common.h"
+
+#define HAND_FACES 1538
+#define HAND_VERTS 778
+#define NEAR_INV 20.0f
+#define FAR_INV 0.01f
+#define ZMAX 16777215.0f
+#define KD 0.0716f
+#define TILE 32
+
+struct SceneDev {    // mirrors ab_scene (host struct of device pointers)
+    const int32_t* hand_faces; const float* hand_normals; const float* hand_uv; const uint8_t* hand_tex; int hts;
+    const float* obj_verts; const float* obj_normals; const float* obj_uv; const int32_t* obj_faces;
+    const int32_t* obj_vert_off; const int32_t* obj_face_off; const uint8_t* obj_tex; int ots;
+    const uint8_t* bg; int bgs; const float* srgb2lin; const uint8_t* lin2srgb;
+    float fx, fy, cx, cy; int W, H;
+};
+struct SampleDev {
+    int32_t obj_id, hand_tex_id, bg_id, bg_x0, bg_y0, bg_w, bg_h; float light; float obj_pose[16];
+};
+struct TriRec { int32_t x[3], y[3]; uint32_t z[3]; int32_t valid; int16_t bx0, bx1, by0, by1; };   // 48 bytes
+
+__device__ __forceinline__ int32_t snapf(float x) { return (int32_t)floorf(x * 256.0f + 0.5f); }
+__device__ __forceinline__ uint32_t quant_z(float Z) {
+    float inv = 1.0f / Z;
+    float z01 = (inv - NEAR_INV) / (FAR_INV - NEAR_INV);
+    float q = floorf(z01 * ZMAX + 0.5f);
+    if (q < 0.f) q = 0.f;
+    if (q > ZMAX) q = ZMAX;
+    return (uint32_t)q;
+}
+
+__device__ __forceinline__ void face_verts(const SceneDev& sc, const SampleDev& sm, const float* hv, int gid,
+                                           float P[3][3], int vid[3]) {
+    if (gid < HAND_FACES) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int v = sc.hand_faces[gid * 3 + k];
+            vid[k] = v;
+            P[k][0] = hv[v * 3]; P[k][1] = hv[v * 3 + 1]; P[k][2] = hv[v * 3 + 2];
+        }
+    } else {
+        int o = sm.obj_id;
+        int f = sc.obj_face_off[o] + (gid - HAND_FACES);
+        const float* T = sm.obj_pose;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int v = sc.obj_vert_off[o] + sc.obj_faces[f * 3 + k];
+            vid[k] = v;
+            const float* p = sc.obj_verts + (size_t)v * 3;
+            P[k][0] = (T[0] * p[0] + T[1] * p[1]) + (T[2] * p[2] + T[3]);
+            P[k][1] = (T[4] * p[0] + T[5] * p[1]) + (T[6] * p[2] + T[7]);
+            P[k][2] = (T[8] * p[0] + T[9] * p[1]) + (T[10] * p[2] + T[11]);
+        }
+    }
+}
+
+__device__ __forceinline__ void setup_tri(const SceneDev& sc, const SampleDev& sm, const float* hv, int gid, TriRec& t) {
+    float P[3][3]; int vid[3];
+    face_verts(sc, sm, hv, gid, P, vid);
+    t.valid = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if (!(P[k][2] > 0.05f)) return;
+    if (gid >= HAND_FACES) {
+        float e1[3] = {P[1][0] - P[0][0], P[1][1] - P[0][1], P[1][2] - P[0][2]};
+        float e2[3] = {P[2][0] - P[0][0], P[2][1] - P[0][1], P[2][2] - P[0][2]};
+        float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        float d = (n[0] * P[0][0] + n[1] * P[0][1]) + n[2] * P[0][2];
+        if (!(d < 0.f)) return;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float x = (sc.fx * P[k][0]) / P[k][2] + sc.cx;
+        float y = (sc.fy * P[k][1]) / P[k][2] + sc.cy;
+        if (!(fabsf(x) < 1.0e6f) || !(fabsf(y) < 1.0e6f)) return;
+        t.x[k] = snapf(x); t.y[k] = snapf(y); t.z[k] = quant_z(P[k][2]);
+    }
+    int64_t area = (int64_t)(t.x[1] - t.x[0]) * (t.y[2] - t.y[0]) - (int64_t)(t.y[1] - t.y[0]) * (t.x[2] - t.x[0]);
+    if (area == 0) return;
+    if (area < 0) {
+        int32_t a = t.x[1]; t.x[1] = t.x[2]; t.x[2] = a;
+        a = t.y[1]; t.y[1] = t.y[2]; t.y[2] = a;
+        uint32_t b = t.z[1]; t.z[1] = t.z[2]; t.z[2] = b;
+        t.valid = 2;
+    } else t.valid = 1;
+}
+
+__device__ __forceinline__ int64_t edgef(int32_t ax, int32_t ay, int32_t bx, int32_t by, int32_t px, int32_t py) {
+    return (int64_t)(bx - ax) * (py - ay) - (int64_t)(by - ay) * (px - ax);
+}
+__device__ __forceinline__ bool edge_incl(int32_t ax, int32_t ay, int32_t bx, int32_t by) {
+    int32_t dx = bx - ax, dy = by - ay;
+    return (dy > 0) || (dy == 0 && dx < 0);
+}
+__device__ __forceinline__ bool cover(const TriRec& t, int32_t px, int32_t py, int64_t w[3]) {
+    w[0] = edgef(t.x[1], t.y[1], t.x[2], t.y[2], px, py);
+    w[1] = edgef(t.x[2], t.y[2], t.x[0], t.y[0], px, py);
+    w[2] = edgef(t.x[0], t.y[0], t.x[1], t.y[1], px, py);
+    if (w[0] < 0 || w[1] < 0 || w[2] < 0) return false;
+    if (w[0] == 0 && !edge_incl(t.x[1], t.y[1], t.x[2], t.y[2])) return false;
+    if (w[1] == 0 && !edge_incl(t.x[2], t.y[2], t.x[0], t.y[0])) return false;
+    if (w[2] == 0 && !edge_incl(t.x[0], t.y[0], t.x[1], t.y[1])) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------ kernel 1: triangle setup
+// tri: [B][maxf] records; sbox: int [B][4] = minx, maxx, miny, maxy in pixels (init +inf/-inf by the launcher)
+__global__ __launch_bounds__(256) void raster_setup_kernel(SceneDev sc, const SampleDev* __restrict__ samples,
+                                                           const float* __restrict__ hand_verts, int maxf,
+                                                           TriRec* __restrict__ tri, int* __restrict__ sbox) {
+    const int b = blockIdx.y;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const SampleDev sm = samples[b];
+    const int nf = HAND_FACES + (sc.obj_face_off[sm.obj_id + 1] - sc.obj_face_off[sm.obj_id]);
+    if (gid >= maxf) return;
+    TriRec t;
+    t.valid = 0;
+    if (gid < nf) setup_tri(sc, sm, hand_verts + (size_t)b * HAND_VERTS * 3, gid, t);
+    if (t.valid) {
+        int32_t minx = min(t.x[0], min(t.x[1], t.x[2])), maxx = max(t.x[0], max(t.x[1], t.x[2]));
+        int32_t miny = min(t.y[0], min(t.y[1], t.y[2])), maxy = max(t.y[0], max(t.y[1], t.y[2]));
+        int x0 = (minx - 128 + 255) >> 8, x1 = (maxx - 128) >> 8, y0 = (miny - 128 + 255) >> 8, y1 = (maxy - 128) >> 8;
+        x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, sc.W - 1); y1 = min(y1, sc.H - 1);
+        if (x0 > x1 || y0 > y1) t.valid = 0;
+        else {
+            t.bx0 = (int16_t)x0; t.bx1 = (int16_t)x1; t.by0 = (int16_t)y0; t.by1 = (int16_t)y1;
+            atomicMin(&sbox[b * 4 + 0], x0); atomicMax(&sbox[b * 4 + 1], x1);
+            atomicMin(&sbox[b * 4 + 2], y0); atomicMax(&sbox[b * 4 + 3], y1);
+        }
+    }
+    tri[(size_t)b * maxf + gid] = t;
+}
+
+__global__ void sbox_init_kernel(int* sbox, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { sbox[i * 4] = 1 << 30; sbox[i * 4 + 1] = -(1 << 30); sbox[i * 4 + 2] = 1 << 30; sbox[i * 4 + 3] = -(1 << 30); }
+}
+
+// ------------------------------------------------------------------ kernel 2: tile raster + shade
+__device__ __forceinline__ void shade_pixel(const SceneDev& sc, const SampleDev& sm, const float* hv, uint64_t key, int x,
+                                            int y, uint8_t o[4]) {
+    if (key == ~(uint64_t)0) {
+        int sx = sm.bg_x0 + (int)(((int64_t)(2 * x + 1) * sm.bg_w) / (2 * sc.W));
+        int sy = sm.bg_y0 + (int)(((int64_t)(2 * y + 1) * sm.bg_h) / (2 * sc.H));
+        const uint8_t* p = sc.bg + (((size_t)sm.bg_id * sc.bgs + sy) * sc.bgs + sx) * 3;
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = 0;
+        return;
+    }
+    int gid = (int)(uint32_t)key;
+    TriRec t; setup_tri(sc, sm, hv, gid, t);
+    float P[3][3]; int vid[3];
+    face_verts(sc, sm, hv, gid, P, vid);
+    if (t.valid == 2) {
+        int a = vid[1]; vid[1] = vid[2]; vid[2] = a;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { float f = P[1][i]; P[1][i] = P[2][i]; P[2][i] = f; }
+    }
+    int64_t w[3]; cover(t, x * 256 + 128, y * 256 + 128, w);
+    float ws = (float)(w[0] + w[1] + w[2]);
+    float l0 = (float)w[0] / ws, l1 = (float)w[1] / ws, l2 = (float)w[2] / ws;
+    float i0 = 1.0f / P[0][2], i1 = 1.0f / P[1][2], i2 = 1.0f / P[2][2];
+    float d = (l0 * i0 + l1 * i1) + l2 * i2;
+    float m0 = (l0 * i0) / d, m1 = (l1 * i1) / d, m2 = (l2 * i2) / d;
+    float nn[3][3], uu[3][2];
+    const uint8_t* tex; int ts;
+    if (gid < HAND_FACES) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            nn[k][0] = sc.hand_normals[vid[k] * 3]; nn[k][1] = sc.hand_normals[vid[k] * 3 + 1]; nn[k][2] = sc.hand_normals[vid[k] * 3 + 2];
+            uu[k][0] = sc.hand_uv[vid[k] * 2]; uu[k][1] = sc.hand_uv[vid[k] * 2 + 1];
+        }
+        ts = sc.hts; tex = sc.hand_tex + (size_t)sm.hand_tex_id * ts * ts * 3;
+    } else {
+        const float* T = sm.obj_pose;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* n = sc.obj_normals + (size_t)vid[k] * 3;
+            nn[k][0] = (T[0] * n[0] + T[1] * n[1]) + T[2] * n[2];
+            nn[k][1] = (T[4] * n[0] + T[5] * n[1]) + T[6] * n[2];
+            nn[k][2] = (T[8] * n[0] + T[9] * n[1]) + T[10] * n[2];
+            uu[k][0] = sc.obj_uv[(size_t)vid[k] * 2]; uu[k][1] = sc.obj_uv[(size_t)vid[k] * 2 + 1];
+        }
+        ts = sc.ots; tex = sc.obj_tex + (size_t)sm.obj_id * ts * ts * 3;
+    }
+    float n[3], p[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        n[i] = (m0 * nn[0][i] + m1 * nn[1][i]) + m2 * nn[2][i];
+        p[i] = (m0 * P[0][i] + m1 * P[1][i]) + m2 * P[2][i];
+    }
+    float u = (m0 * uu[0][0] + m1 * uu[1][0]) + m2 * uu[2][0], v = (m0 * uu[0][1] + m1 * uu[1][1]) + m2 * uu[2][1];
+    float nl = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]); if (nl < 1e-20f) nl = 1e-20f;
+    float d2 = (p[0] * p[0] + p[1] * p[1]) + p[2] * p[2];
+    float dl = sqrtf(d2);
+    float ndl = -((n[0] * p[0] + n[1] * p[1]) + n[2] * p[2]) / (nl * dl);
+    if (gid < HAND_FACES) ndl = fabsf(ndl);
+    if (ndl < 0.f) ndl = 0.f;
+    float shade = 0.8f + (KD * sm.light) * ndl / d2;
+    u = u - floorf(u); v = v - floorf(v);
+    int tx = (int)(u * (float)ts), ty = (int)(v * (float)ts);
+    if (tx > ts - 1) tx = ts - 1;
+    if (ty > ts - 1) ty = ts - 1;
+    const uint8_t* texel = tex + ((size_t)ty * ts + tx) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float lin = sc.srgb2lin[texel[c]] * shade;
+        if (lin < 0.f) lin = 0.f;
+        if (lin > 1.f) lin = 1.f;
+        o[c] = sc.lin2srgb[(int)(lin * 4095.0f + 0.5f)];
+    }
+    o[3] = 255;
+}
+
+__global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const SampleDev* __restrict__ samples,
+                                                           const float* __restrict__ hand_verts, int maxf,
+                                                           const TriRec* __restrict__ tri, const int* __restrict__ sbox,
+                                                           uint8_t* __restrict__ rgbx, uint64_t* __restrict__ keys_out) {
+    __shared__ unsigned long long zb[TILE * TILE];
+    const int b = blockIdx.y;
+    const int tiles_x = sc.W / TILE;
+    const int ty0 = (blockIdx.x / tiles_x) * TILE, tx0 = (blockIdx.x % tiles_x) * TILE;
+    const SampleDev sm = samples[b];
+    const float* hv = hand_verts + (size_t)b * HAND_VERTS * 3;
+    for (int i = threadIdx.x; i < TILE * TILE; i += 256) zb[i] = ~0ull;
+    __syncthreads();
+    const int bx0 = sbox[b * 4], bx1 = sbox[b * 4 + 1], by0 = sbox[b * 4 + 2], by1 = sbox[b * 4 + 3];
+    const bool active = !(bx1 < tx0 || bx0 > tx0 + TILE - 1 || by1 < ty0 || by0 > ty0 + TILE - 1);
+    if (active) {
+        const int nf = HAND_FACES + (sc.obj_face_off[sm.obj_id + 1] - sc.obj_face_off[sm.obj_id]);
+        const TriRec* tb = tri + (size_t)b * maxf;
+        for (int gid = threadIdx.x; gid < nf; gid += 256) {
+            // bbox test on the 8-byte tail first (cheap reject), full record only for overlapping triangles
+            const int4 tail = *(const int4*)((const char*)(tb + gid) + 32);   // z[2]? no: bytes 32..47 = z[2], valid, bbox
+            const int valid = tail.y;
+            if (!valid) continue;
+            const int16_t qx0 = (int16_t)(tail.z & 0xffff), qx1 = (int16_t)((uint32_t)tail.z >> 16);
+            const int16_t qy0 = (int16_t)(tail.w & 0xffff), qy1 = (int16_t)((uint32_t)tail.w >> 16);
+            int x0 = max((int)qx0, tx0), x1 = min((int)qx1, tx0 + TILE - 1);
+            int y0 = max((int)qy0, ty0), y1 = min((int)qy1, ty0 + TILE - 1);
+            if (x0 > x1 || y0 > y1) continue;
+            const TriRec t = tb[gid];
+            for (int y = y0; y <= y1; ++y)
+                for (int x = x0; x <= x1; ++x) {
+                    int64_t w[3];
+                    if (!cover(t, x * 256 + 128, y * 256 + 128, w)) continue;
+                    int64_t sum = w[0] + w[1] + w[2];
+                    uint64_t z = (uint64_t)((w[0] * (int64_t)t.z[0] + w[1] * (int64_t)t.z[1] + w[2] * (int64_t)t.z[2]) / sum);
+                    unsigned long long key = (z << 32) | (uint32_t)gid;
+                    atomicMin(&zb[(y - ty0) * TILE + (x - tx0)], key);
+                }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE * TILE; i += 256) {
+        int y = ty0 + i / TILE, x = tx0 + i % TILE;
+        uint64_t key = zb[i];
+        uint8_t o[4];
+        shade_pixel(sc, sm, hv, key, x, y, o);
+        size_t pix = ((size_t)b * sc.H + y) * sc.W + x;
+        *(uint32_t*)(rgbx + pix * 4) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+        if (keys_out) keys_out[pix] = key;
+    }
+}
+
+// ------------------------------------------------------------------ PIL-semantics colour jitter (see the oracle)
+__device__ __forceinline__ uint8_t blend8(int in1, int in2, float f) {
+    float t = (float)in1 + f * (float)(in2 - in1);
+    if (f >= 0.f && f <= 1.f) return (uint8_t)t;
+    if (t <= 0.f) return 0;
+    if (t >= 255.f) return 255;
+    return (uint8_t)t;
+}
+__device__ __forceinline__ int luma8(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+__device__ __forceinline__ void rgb2hsv8(const uint8_t* in, uint8_t* out) {
+    int r = in[0], g = in[1], b = in[2];
+    int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+    uint8_t uh, us, uv = (uint8_t)maxc;
+    if (minc == maxc) { uh = 0; us = 0; }
+    else {
+        float cr = (float)(maxc - minc);
+        float s = cr / (float)maxc;
+        float rc = ((float)(maxc - r)) / cr, gc = ((float)(maxc - g)) / cr, bc = ((float)(maxc - b)) / cr;
+        float h;
+        if (r == maxc) h = bc - gc;
+        else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+        else h = (float)(4.0 + (double)gc - (double)rc);
+        h = (float)fmod(((double)h / 6.0 + 1.0), 1.0);
+        int ih = (int)((double)h * 255.0), is = (int)((double)s * 255.0);
+        uh = (uint8_t)(ih < 0 ? 0 : ih > 255 ? 255 : ih);
+        us = (uint8_t)(is < 0 ? 0 : is > 255 ? 255 : is);
+    }
+    out[0] = uh; out[1] = us; out[2] = uv;
+}
+__device__ __forceinline__ void hsv2rgb8(const uint8_t* in, uint8_t* out) {
+    uint8_t h = in[0], s = in[1], v = in[2];
+    if (s == 0) { out[0] = out[1] = out[2] = v; return; }
+    int i = (int)floor((double)(float)h * 6.0 / 255.0);
+    float f = (float)((double)(float)h * 6.0 / 255.0 - (double)(float)i);
+    float fs = (float)((double)(float)s / 255.0);
+    int p = (int)round((double)(float)v * (1.0 - (double)fs));
+    int q = (int)round((double)(float)v * (1.0 - (double)fs * (double)f));
+    int t = (int)round((double)(float)v * (1.0 - (double)fs * (1.0 - (double)f)));
+    p = p < 0 ? 0 : p > 255 ? 255 : p; q = q < 0 ? 0 : q > 255 ? 255 : q; t = t < 0 ? 0 : t > 255 ? 255 : t;
+    switch (i % 6) {
+        case 0: out[0] = v; out[1] = (uint8_t)t; out[2] = (uint8_t)p; break;
+        case 1: out[0] = (uint8_t)q; out[1] = v; out[2] = (uint8_t)p; break;
+        case 2: out[0] = (uint8_t)p; out[1] = v; out[2] = (uint8_t)t; break;
+        case 3: out[0] = (uint8_t)p; out[1] = (uint8_t)q; out[2] = v; break;
+        case 4: out[0] = (uint8_t)t; out[1] = (uint8_t)p; out[2] = v; break;
+        default: out[0] = v; out[1] = (uint8_t)p; out[2] = (uint8_t)q; break;
+    }
+}
+__device__ __forceinline__ void jitter_op(int op, float f, int mean_gray, uint8_t* px) {
+    if (op == 0) { for (int c = 0; c < 3; ++c) px[c] = blend8(0, px[c], f); }
+    else if (op == 1) { int l = luma8(px[0], px[1], px[2]); for (int c = 0; c < 3; ++c) px[c] = blend8(l, px[c], f); }
+    else if (op == 2) { uint8_t hsv[3]; rgb2hsv8(px, hsv); hsv[0] = (uint8_t)(hsv[0] + (uint8_t)(int)(f * 255.0f)); hsv2rgb8(hsv, px); }
+    else { for (int c = 0; c < 3; ++c) px[c] = blend8(mean_gray, px[c], f); }
+}
+
+// kernel 3: luma sum of the image as it is when the contrast op is reached (ops before it applied on the fly)
+__global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __restrict__ rgbx, int npix,
+                                                           const int32_t* __restrict__ order, const float* __restrict__ factor,
+                                                           unsigned long long* __restrict__ lsum) {
+    const int b = blockIdx.y;
+    const int32_t* ord = order + b * 4; const float* fac = factor + b * 4;
+    int kc = 0;
+    while (kc < 4 && ord[kc] != 3) ++kc;
+    unsigned long long s = 0;
+    if (kc < 4)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+            uint32_t q = *(const uint32_t*)(rgbx + ((size_t)b * npix + i) * 4);
+            uint8_t px[3] = {(uint8_t)q, (uint8_t)(q >> 8), (uint8_t)(q >> 16)};
+            for (int k = 0; k < kc; ++k) jitter_op(ord[k], fac[k], 0, px);
+            s += (unsigned long long)luma8(px[0], px[1], px[2]);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&lsum[b], s);     // integer: order-independent, exact
+}
+
+// kernel 4: nearest-neighbour affine crop + full jitter chain + normalise; writes zero-bordered NHWC4 and/or CHW f32
+template <typename T>
+__global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restrict__ rgbx, int W, int H,
+                                                          const int32_t* __restrict__ order, const float* __restrict__ factor,
+                                                          const float* __restrict__ inv_affine,
+                                                          const unsigned long long* __restrict__ lsum, int ow, int oh,
+                                                          T* __restrict__ out_pad, float* __restrict__ out_chw) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ow * oh) return;
+    const int y = i / ow, x = i - y * ow;
+    const float* inv = inv_affine + b * 6;
+    float xin = (inv[0] * ((float)x + 0.5f) + inv[1] * ((float)y + 0.5f)) + inv[2];
+    float yin = (inv[3] * ((float)x + 0.5f) + inv[4] * ((float)y + 0.5f)) + inv[5];
+    int sx = (int)floorf(xin), sy = (int)floorf(yin);
+    float v[3] = {0.f, 0.f, 0.f};
+    if (sx >= 0 && sx < W && sy >= 0 && sy < H) {
+        uint32_t q = *(const uint32_t*)(rgbx + (((size_t)b * H + sy) * W + sx) * 4);
+        uint8_t px[3] = {(uint8_t)q, (uint8_t)(q >> 8), (uint8_t)(q >> 16)};
+        int mean = (int)((double)lsum[b] / (double)(W * H) + 0.5);
+        for (int k = 0; k < 4; ++k) jitter_op(order[b * 4 + k], factor[b * 4 + k], mean, px);
+        v[0] = (float)px[0]; v[1] = (float)px[1]; v[2] = (float)px[2];
+    }
+    float o[3] = {v[0] / 255.0f - 0.5f, v[1] / 255.0f - 0.5f, v[2] / 255.0f - 0.5f};
+    if (out_pad) {
+        T* p = out_pad + (((size_t)b * (oh + 6) + (y + 3)) * (ow + 8) + (x + 3)) * 4;
+        st_f32(p, o[0]); st_f32(p + 1, o[1]); st_f32(p + 2, o[2]); st_f32(p + 3, 0.f);
+    }
+    if (out_chw) {
+        size_t plane = (size_t)oh * ow;
+        float* p = out_chw + (size_t)b * 3 * plane + (size_t)y * ow + x;
+        p[0] = o[0]; p[plane] = o[1]; p[2 * plane] = o[2];
+    }
+}
+
+// ================================================================ C ABI
+static SceneDev to_dev(const ab_scene* s) {
+    SceneDev d;
+    d.hand_faces = (const int32_t*)s->hand_faces; d.hand_normals = (const float*)s->hand_normals; d.hand_uv = (const float*)s->hand_uv;
+    d.hand_tex = (const uint8_t*)s->hand_tex; d.hts = s->hts; d.obj_verts = (const float*)s->obj_verts;
+    d.obj_normals = (const float*)s->obj_normals; d.obj_uv = (const float*)s->obj_uv; d.obj_faces = (const int32_t*)s->obj_faces;
+    d.obj_vert_off = (const int32_t*)s->obj_vert_off; d.obj_face_off = (const int32_t*)s->obj_face_off;
+    d.obj_tex = (const uint8_t*)s->obj_tex; d.ots = s->ots; d.bg = (const uint8_t*)s->bg; d.bgs = s->bgs;
+    d.srgb2lin = (const float*)s->srgb2lin; d.lin2srgb = (const uint8_t*)s->lin2srgb;
+    d.fx = s->fx; d.fy = s->fy; d.cx = s->cx; d.cy = s->cy; d.W = s->W; d.H = s->H;
+    return d;
+}
+
+extern "C" long ab_render_workspace_bytes(int B, int W, int H, int max_faces) {
+    // tri records + rgbx + lsum + sbox, each 256-byte aligned
+    auto al = [](long x) { return (x + 255) / 256 * 256; };
+    return al((long)B * max_faces * 48) + al((long)B * W * H * 4) + al((long)B * 8) + al((long)B * 16);
+}
+
+extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, const float* hand_verts,
+                               const int32_t* order, const float* factor, const float* inv_affine, int B,
+                               int max_faces, int ow, int oh, int out_dtype, void* out_pad, float* out_chw,
+                               void* workspace, void* keys_out, void* rgbx_out, void* stream) {
+    if (!scene_host || !samples || !hand_verts || !order || !factor || !inv_affine || !workspace) return AB_EINVAL;
+    if (!out_pad && !out_chw) return AB_EINVAL;
+    SceneDev sc = to_dev(scene_host);
+    if (sc.W % TILE || sc.H % TILE || B < 1 || max_faces < HAND_FACES) return AB_ESHAPE;
+    hipStream_t st = as_stream(stream);
+    auto al = [](long x) { return (x + 255) / 256 * 256; };
+    char* ws = (char*)workspace;
+    TriRec* tri = (TriRec*)ws; ws += al((long)B * max_faces * 48);
+    uint8_t* rgbx = rgbx_out ? (uint8_t*)rgbx_out : (uint8_t*)ws; ws += al((long)B * sc.W * sc.H * 4);
+    unsigned long long* lsum = (unsigned long long*)ws; ws += al((long)B * 8);
+    int* sbox = (int*)ws;
+    hipError_t e = hipMemsetAsync(lsum, 0, (size_t)B * 8, st);
+    if (e != hipSuccess) return (int)e;
+    sbox_init_kernel<<<(B + 63) / 64, 64, 0, st>>>(sbox, B);
+    raster_setup_kernel<<<dim3((max_faces + 255) / 256, B), 256, 0, st>>>(sc, (const SampleDev*)samples, hand_verts,
+                                                                           max_faces, tri, sbox);
+    AB_LAUNCH_CHECK();
+    raster_shade_kernel<<<dim3((sc.W / TILE) * (sc.H / TILE), B), 256, 0, st>>>(sc, (const SampleDev*)samples, hand_verts,
+                                                                                 max_faces, tri, sbox, rgbx,
+                                                                                 (uint64_t*)keys_out);
+    AB_LAUNCH_CHECK();
+    int npix = sc.W * sc.H;
+    jitter_stats_kernel<<<dim3(64, B), 256, 0, st>>>(rgbx, npix, order, factor, lsum);
+    AB_LAUNCH_CHECK();
+    dim3 g((ow * oh + 255) / 256, B);
+    if (out_dtype == AB_DT_F32)
+        warp_jitter_kernel<float><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (float*)out_pad, out_chw);
+    else if (out_dtype == AB_DT_BF16)
+        warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw);
+    else return AB_EINVAL;
+    AB_LAUNCH_CHECK();
+    return 0;
+}

@@ -128,6 +128,32 @@ int ab_pose_loss(const float* kp3d, const float* box6d, int box_stride, const fl
                  float* corners_abs, float* rotmat, float* uvd2d, float* sample_part, float* losses, float* g_kp3d,
                  float* g_box6d, void* stream);
 
+/* ---- R3/R4/R5: batched online synthesis (rasterise + z-buffer + shade + background + colour jitter + crop) --------
+ * replaces: anakin/utils/renderer.py:101-136 (Renderer.__call__: pyrender/OpenGL draw, background putmask),
+ *           anakin/utils/frender_utils.py:36-46,116-118 (per-frame vertex upload, stale normals),
+ *           anakin/artiboost/render_infra.py:14-59 (render server + two queue hops per image),
+ *           anakin/artiboost/rendered_dataset.py:256-270 + anakin/utils/img_augment.py:6-80 (PIL jitter, affine, to_tensor)
+ * ab_scene: HOST struct of DEVICE pointers to the immutable assets (one packed table for all object meshes).
+ * samples : device array of 96-byte records {int32 obj_id, hand_tex_id, bg_id, bg_x0, bg_y0, bg_w, bg_h; float light;
+ *           float obj_pose[16] (row-major 4x4)}.  hand_verts: float [B,778,3] camera frame.
+ * order/factor: int32/float [B,4] colour-jitter op ids (0 brightness, 1 saturation, 2 hue, 3 contrast) and factors in
+ * application order.  inv_affine: float [B,6] output-pixel-centre -> render-pixel map (PIL AFFINE data).
+ * out_pad: zero-bordered NHWC4 [B, oh+6, ow+8, 4] in out_dtype (interior written; border must already be zero);
+ * out_chw: optional float [B,3,oh,ow] (the reference's `image` tensor).  keys_out (optional) uint64 [B,H,W]:
+ * depth24<<32 | face id, ~0 = background.  rgbx_out (optional) uint8 [B,H,W,4] pre-jitter render.                 */
+typedef struct ab_scene {
+    const void* hand_faces; const void* hand_normals; const void* hand_uv; const void* hand_tex; int hts;
+    const void* obj_verts; const void* obj_normals; const void* obj_uv; const void* obj_faces;
+    const void* obj_vert_off; const void* obj_face_off; const void* obj_tex; int ots;
+    const void* bg; int bgs; const void* srgb2lin; const void* lin2srgb;
+    float fx, fy, cx, cy; int W, H;
+} ab_scene;
+long ab_render_workspace_bytes(int B, int W, int H, int max_faces);
+int ab_render_batch(const ab_scene* scene_host, const void* samples, const float* hand_verts, const int32_t* order,
+                    const float* factor, const float* inv_affine, int B, int max_faces, int ow, int oh,
+                    int out_dtype, void* out_pad, float* out_chw, void* workspace, void* keys_out, void* rgbx_out,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif
