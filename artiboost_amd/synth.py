@@ -1,0 +1,474 @@
+"""Online synthesis control plane + device data plane: the ArtiBoostLoader of this package.
+
+Reference: anakin/artiboost/artiboost_loader.py:49-340,503-598 (CCV weight map, per-epoch pose generation, mining /
+re-weighting), ovg_set.py:104-178 (Categorical sampling of (object, view, grasp) triplets), view_engine.py:17-86,
+grasp_engine.py:47-53, preprocessor.py:20-99 + scrambler.py:65-81 (pose generator), rendered_dataset.py:103-274 (GT
+assembly + augmentation draws), render_infra.py / utils/renderer.py (render servers).
+
+What changed structurally (MI355X-first):
+  * no render-server processes, no multiprocessing queues, no one-pickle-per-sample cache on /dev/shm: `prepare()`
+    generates the epoch's poses in batches of 256 on the GPU (HIP LBS kernel) and keeps them as device-resident SoA
+    tensors; every training step renders its own batch on the training GPU's stream (render.DeviceRenderer);
+  * CCV sampling, view / grasp lookup, GT geometry (bbox crop, jitter, affine, visibility) stay on the host exactly as
+    in the reference (float64 numpy, integer truncations included) but vectorised over the epoch;
+  * the GrabNet refiner (refiner.py) is not part of this path (weights are a download).
+"""
+import math
+import random
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .registry import Queries, SynthQueries
+from .render import SAMPLE_DTYPE, DeviceRenderer
+
+
+# --------------------------------------------------------------------------- rotations (pytorch3d semantics)
+def aa_to_rotmat(aa):
+    """axis_angle_to_matrix (wrapper anakin/utils/transform.py:42-55)."""
+    ang = torch.norm(aa, dim=-1, keepdim=True)
+    half = 0.5 * ang
+    small = ang.abs() < 1e-6
+    k = torch.where(small, 0.5 - ang * ang / 48.0, torch.sin(half) / torch.where(small, torch.ones_like(ang), ang))
+    w = torch.cos(half)[..., 0]
+    x, y, z = (aa * k).unbind(-1)
+    two_s = 2.0 / (w * w + x * x + y * y + z * z)
+    R = torch.stack([1 - two_s * (y * y + z * z), two_s * (x * y - z * w), two_s * (x * z + y * w),
+                     two_s * (x * y + z * w), 1 - two_s * (x * x + z * z), two_s * (y * z - x * w),
+                     two_s * (x * z - y * w), two_s * (y * z + x * w), 1 - two_s * (x * x + y * y)], dim=-1)
+    return R.reshape(aa.shape[:-1] + (3, 3))
+
+
+def rotmat_to_aa(R):
+    """matrix_to_quaternion + quaternion_to_axis_angle (wrapper anakin/utils/transform.py:291-306)."""
+    m00, m01, m02 = R[..., 0, 0], R[..., 0, 1], R[..., 0, 2]
+    m10, m11, m12 = R[..., 1, 0], R[..., 1, 1], R[..., 1, 2]
+    m20, m21, m22 = R[..., 2, 0], R[..., 2, 1], R[..., 2, 2]
+    q_abs = torch.sqrt(torch.clamp(torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22,
+                                                1 - m00 - m11 + m22], -1), min=0.0))
+    cand = torch.stack([torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+                        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], -1),
+                        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], -1),
+                        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1)], -2)
+    cand = cand / (2.0 * torch.clamp(q_abs[..., None], min=0.1))
+    best = q_abs.argmax(dim=-1)
+    q = torch.gather(cand, -2, best[..., None, None].expand(best.shape + (1, 4)))[..., 0, :]
+    norms = torch.norm(q[..., 1:], dim=-1, keepdim=True)
+    half = torch.atan2(norms, q[..., :1])
+    ang = 2 * half
+    small = ang.abs() < 1e-6
+    k = torch.where(small, 0.5 - ang * ang / 48.0, torch.sin(half) / torch.where(small, torch.ones_like(ang), ang))
+    return q[..., 1:] / k
+
+
+# --------------------------------------------------------------------------- R1: MANO layer on the HIP kernel
+class ManoLayerHIP:
+    """ManoLayer(rot_mode='axisang', center_idx=None, flat_hand_mean=True) call contract (grasp_engine.py:90-95):
+    __call__(pose [B,48], betas [B,10]) -> verts [B,778,3], joints [B,21,3], transforms_abs [B,16,4,4]."""
+
+    def __init__(self, hand_model, device="cuda"):
+        self.dev = torch.device(device)
+        f = lambda k: torch.from_numpy(np.ascontiguousarray(hand_model[k], np.float32)).to(self.dev)   # noqa: E731
+        self.v_template, self.shapedirs, self.posedirs = f("v_template"), f("shapedirs"), f("posedirs")
+        self.J_regressor, self.weights, self.hands_mean = f("J_regressor"), f("weights"), f("hands_mean")
+
+    def __call__(self, pose, betas):
+        B = pose.shape[0]
+        pose = pose.contiguous().float()
+        betas = betas.contiguous().float()
+        verts = torch.empty((B, 778, 3), dtype=torch.float32, device=self.dev)
+        joints = torch.empty((B, 21, 3), dtype=torch.float32, device=self.dev)
+        T = torch.empty((B, 16, 4, 4), dtype=torch.float32, device=self.dev)
+        L.check(L.lib().ab_mano_lbs(L.ptr(pose), L.ptr(betas), L.ptr(self.v_template), L.ptr(self.shapedirs),
+                                    L.ptr(self.posedirs), L.ptr(self.J_regressor), L.ptr(self.weights),
+                                    L.ptr(self.hands_mean), L.i(B), L.ptr(verts), L.ptr(joints), L.ptr(T), L.stream()),
+                "ab_mano_lbs")
+        return verts, joints, T
+
+    def get_rotation_center(self, betas):
+        vs = self.v_template[None] + torch.einsum("vkl,bl->bvk", self.shapedirs, betas)
+        return torch.einsum("v,bvk->bk", self.J_regressor[0], vs)
+
+
+class PoseGenerator:
+    """PreProcessorPoseGenerator.forward (preprocessor.py:20-99) with the RandomScrambler (scrambler.py:65-81);
+    batched device tensors in, (obj_pose [B,4,4], hand_verts [B,778,3], joints [B,21,3]) out."""
+
+    def __init__(self, mano: ManoLayerHIP, tsl_sigma=0.01, pose_sigma=0.1):
+        self.mano, self.tsl_sigma, self.pose_sigma = mano, tsl_sigma, pose_sigma
+
+    def __call__(self, hand_pose, hand_shape, hand_tsl, persp_rotmat, camera_free_transf, z_offset, rand_pose_angle=None,
+                 rand_tsl=None):
+        B = hand_pose.shape[0]
+        verts, joints, T = self.mano(hand_pose, hand_shape)
+        joints = joints + hand_tsl[:, None]
+        Rinv = persp_rotmat.transpose(1, 2)
+        op_offset = torch.bmm(Rinv, joints[:, 9, :, None])[..., 0] / 2.0
+        cam_sys_offset = z_offset - op_offset
+        obj_pose = torch.eye(4, device=verts.device).repeat(B, 1, 1)
+        obj_pose[:, :3, :3] = Rinv
+        obj_pose[:, :3, 3] = cam_sys_offset
+        obj_pose = torch.bmm(camera_free_transf, obj_pose)
+        new_glob = rotmat_to_aa(torch.bmm(Rinv, T[:, 0, :3, :3]))
+        new_pose = torch.cat([new_glob, hand_pose[:, 3:]], dim=1)
+        center = self.mano.get_rotation_center(hand_shape)
+        off0 = center - torch.bmm(aa_to_rotmat(hand_pose[:, :3]), center[..., None])[..., 0]
+        off1 = center - torch.bmm(aa_to_rotmat(new_pose[:, :3]), center[..., None])[..., 0]
+        new_tsl = torch.bmm(Rinv, (off0 + hand_tsl)[..., None])[..., 0] - off1
+        if rand_pose_angle is not None:
+            hp = new_pose.reshape(B, 16, 3)
+            nrm = torch.norm(hp, dim=-1, keepdim=True)
+            axis = hp / torch.clamp(nrm, min=1e-7)
+            new_pose = (axis * (nrm[..., 0] + rand_pose_angle)[..., None]).reshape(B, 48)
+        if rand_tsl is not None:
+            new_tsl = new_tsl + rand_tsl
+        v2, j2, _ = self.mano(new_pose, hand_shape)
+        off = (new_tsl + cam_sys_offset)[:, None]
+        Rf = camera_free_transf[:, :3, :3]
+        final_verts = torch.bmm(v2 + off, Rf.transpose(1, 2))
+        final_joints = torch.bmm(j2 + off, Rf.transpose(1, 2))
+        return obj_pose, final_verts.contiguous(), final_joints.contiguous()
+
+
+# --------------------------------------------------------------------------- host geometry (reference semantics)
+def align_mat(vec):
+    """ViewEngine.caculate_align_mat (view_engine.py:61-86)."""
+    vec = vec / np.linalg.norm(vec)
+    z = np.array([0.0, 0.0, 1.0])
+    zc = np.cross(z, vec)
+    K = np.array([[0, -zc[2], zc[1]], [zc[2], 0, -zc[0]], [-zc[1], zc[0], 0]])
+    d = float(np.dot(z, vec))
+    if d == -1:
+        return -np.eye(3)
+    if d == 1:
+        return np.eye(3)
+    return np.eye(3) + K + K.dot(K) / (1 + d)
+
+
+def perspective_rotmat(persp_id, u_off, th_off, u_bins, theta_bins):
+    """ViewEngine.get_perspective_from_id (view_engine.py:35-57)."""
+    u_id, th_id = persp_id // theta_bins, persp_id % theta_bins
+    u_unit, th_unit = 2 / u_bins, (2 * np.pi) / theta_bins
+    u = np.clip((-1 + u_unit / 2) + u_id * u_unit + u_off * u_unit, -1, 1)
+    th = np.clip(th_unit / 2 + th_id * th_unit + th_off * th_unit, 0, 2 * np.pi)
+    s = np.sqrt(1 - u * u)
+    return align_mat(np.array([s * np.cos(th), s * np.sin(th), u]))
+
+
+def _affine_no_rot(center, scale, res):
+    a = np.zeros((3, 3))
+    ratio = float(res[0]) / float(res[1])
+    a[0, 0] = float(res[0]) / scale
+    a[1, 1] = float(res[1]) / scale * ratio
+    a[0, 2] = res[0] * (-float(center[0]) / scale + 0.5)
+    a[1, 2] = res[1] * (-float(center[1]) / scale * ratio + 0.5)
+    a[2, 2] = 1
+    return a
+
+
+def get_affine_transform(center, scale, optical_center, out_res, rot=0.0):
+    """anakin/utils/transform.py:434-482."""
+    rm = np.zeros((3, 3))
+    sn, cs = np.sin(rot), np.cos(rot)
+    rm[0, :2] = [cs, -sn]
+    rm[1, :2] = [sn, cs]
+    rm[2, 2] = 1
+    ch = np.array([center[0], center[1], 1.0])
+    t = np.eye(3)
+    t[0, 2], t[1, 2] = -optical_center[0], -optical_center[1]
+    ti = t.copy()
+    ti[:2, 2] *= -1
+    tc = ti.dot(rm).dot(t).dot(ch)
+    total = _affine_no_rot(rm.dot(ch)[:2], scale, out_res).dot(rm)
+    return total.astype(np.float32), _affine_no_rot(tc[:2], scale, out_res).astype(np.float32)
+
+
+def assemble_gt(K, joints, obj_pose, corners_can, image_size, raw_size, center_jit_draw, scale_draw, rot, center_idx=0,
+                bbox_expand=1.2, center_jit=0.1, scale_jit=0.1):
+    """RenderedDataset.__getitem__ geometry for CROP_MODEL root_obj (rendered_dataset.py:127-133,155-254,276-316)."""
+    j2d = (K @ joints.T).T
+    j2d = j2d[:, :2] / (j2d[:, 2:3] + 1e-8)
+    c3d = (obj_pose[:3, :3] @ corners_can.T).T + obj_pose[:3, 3]
+    c2d = (K @ c3d.T).T
+    c2d = c2d[:, :2] / (c2d[:, 2:3] + 1e-8)
+    all2d = np.concatenate([j2d[[0]], c2d], 0)
+    mn, mx = all2d.min(0), all2d.max(0)
+    center = np.asarray([int((mx[0] + mn[0]) / 2), int((mx[1] + mn[1]) / 2)])      # hodata.py:178-186
+    scale = max(mx[0] - mn[0], mx[1] - mn[1]) * bbox_expand
+    center = center + (center_jit * scale * np.asarray(center_jit_draw)).astype(int)
+    scale = scale * np.clip(scale_draw + 1.0, 1 - scale_jit, 1 + scale_jit)
+    rm = np.array([[np.cos(rot), -np.sin(rot), 0], [np.sin(rot), np.cos(rot), 0], [0, 0, 1]]).astype(np.float32)
+    aff, post = get_affine_transform(center, scale, [K[0, 2], K[1, 2]], image_size, rot)
+    out = {"affine": aff, Queries.CAM_INTR: post.dot(K).astype(np.float32)}
+    j3 = rm.dot(joints.astype(np.float32).T).T
+    root = j3[center_idx]
+    out[Queries.ROOT_JOINT] = root
+    out[Queries.JOINTS_3D] = j3 - root
+    hom = lambda p: aff.dot(np.concatenate([p, np.ones((p.shape[0], 1))], 1).T).T[:, :2]   # noqa: E731
+    j2a = hom(j2d.astype(np.float32)).astype(np.float32)
+    out[Queries.JOINTS_2D] = j2a
+
+    def vis(raw2d, aug2d, n):
+        v = (raw2d[:, 0] >= 0) & (raw2d[:, 0] < raw_size[0]) & (raw2d[:, 1] >= 0) & (raw2d[:, 1] < raw_size[1])
+        if v.sum() < n * 0.4:
+            return np.zeros(n, np.float32)
+        va = ((aug2d[:, 0] >= 0) & (aug2d[:, 0] < image_size[0]) & (aug2d[:, 1] >= 0) &
+              (aug2d[:, 1] < image_size[1])).astype(np.float32)
+        return np.zeros(n, np.float32) if va.sum() < n * 0.4 else va
+
+    out[Queries.JOINTS_VIS] = vis(j2d, j2a, 21)
+    c3 = rm.dot(c3d.astype(np.float32).T).T
+    out[Queries.CORNERS_3D] = c3 - root
+    c2a = hom(c2d.astype(np.float32))
+    out[Queries.CORNERS_2D] = c2a.astype(np.float32)
+    out[Queries.CORNERS_VIS] = vis(c2d, c2a, 8)
+    out[Queries.CORNERS_CAN] = corners_can.astype(np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = rm @ obj_pose[:3, :3].astype(np.float32)
+    T[:3, 3] = rm.dot(obj_pose[:3, 3].astype(np.float32))
+    out[Queries.OBJ_TRANSF] = T
+    return out
+
+
+# --------------------------------------------------------------------------- the loader
+class ArtiBoostLoader:
+    """Synthetic half of the reference's ArtiBoostLoader (artiboost_loader.py:49-340): same public surface
+    (prepare / __iter__ / __len__ / step_eval / sample_weight_map / occurence_map / use_synth / update_method_*),
+    batches produced by the on-GPU renderer.  `real_train_set` mixing (MixedDataset) is out of scope here: the real
+    datasets are downloads."""
+
+    def __init__(self, assets, cfg, cfg_preset, batch_size, synth_len, device="cuda", compute_dtype=torch.bfloat16,
+                 random_seed=1, rank=0, world_size=1, grasps=None):
+        self.assets, self.cfg, self.preset = assets, cfg, cfg_preset
+        self.dev = torch.device(device)
+        self.batch_size, self.synth_len = batch_size, int(synth_len)
+        self.rank, self.world = rank, world_size
+        self.dtype = compute_dtype
+        ve = cfg["VIEW_ENGINE"]
+        self.u_bins, self.theta_bins = ve["PERSP_U_BINS"], ve["PERSP_THETA_BINS"]
+        self.z_range = ve["CAMERA_Z_RANGE"]
+        self.n_obj = assets.n_obj
+        self.n_persp = self.u_bins * self.theta_bins
+        self.n_grasp = cfg["GRASP_ENGINE"]["GRASP_NUM"]
+        cam = cfg["RENDERER"]["CAM_PARAM"]
+        self.render_size = cfg["RENDERER"]["RENDER_SIZE"]
+        self.K = np.array([[cam["FX"], 0, cam["CX"]], [0, cam["FY"], cam["CY"]], [0, 0, 1.0]])
+        self.image_size = list(cfg_preset["IMAGE_SIZE"])
+        self.center_idx = cfg_preset.get("CENTER_IDX", 0)
+        self.bbox_expand = float(cfg_preset.get("BBOX_EXPAND_RATIO", 1.2))
+        self.sample_weight_map = torch.ones((self.n_obj, self.n_persp, self.n_grasp), dtype=torch.float32)
+        self.occurence_map = torch.zeros((self.n_obj, self.n_persp, self.n_grasp), dtype=torch.bool)
+        wu = cfg.get("WEIGHT_UPDATE", {"LOWER": 0.1, "UPPER": 10.0})
+        self.sample_weight_lower_bound, self.sample_weight_upper_bound = wu["LOWER"], wu["UPPER"]
+        dt = cfg.get("DIST_THRESHOLD", {"LOWER": 8.0, "UPPER": 16.0})
+        self.dist_lower_threshold, self.dist_upper_threshold = dt["LOWER"], dt["UPPER"]
+        self.update_method_key = cfg.get("UPDATE_METHOD", "method_1")
+        self.n_epochs = cfg.get("EPOCH", 100)
+        self.use_synth = self.synth_len > 0
+        self.rng = np.random.default_rng(random_seed)
+        self.torch_gen = torch.Generator().manual_seed(random_seed)
+        from .assets import make_grasps
+        self.grasps = grasps if grasps is not None else make_grasps(self.n_obj, self.n_grasp, seed=random_seed + 5)
+        self.mano = ManoLayerHIP(assets.hand, device)
+        sc = cfg.get("SCRAMBLER", {"HAND_TSL_SIGMA": 0.01, "HAND_POSE_SIGMA": 0.1})
+        self.pose_generator = PoseGenerator(self.mano, sc["HAND_TSL_SIGMA"], sc["HAND_POSE_SIGMA"])
+        self.renderer = DeviceRenderer(assets, self.K, self.render_size[0], self.render_size[1], device)
+        self.epoch = None
+        self.cursor = 0
+
+    # ------------------------------------------------------------------ CCV sampling (ovg_set.py:104-132,162-178)
+    def _sample_ccv(self):
+        dist = torch.distributions.Categorical(self.sample_weight_map.reshape(-1))
+        idx = dist.sample(sample_shape=(self.synth_len,))
+        o = torch.div(idx, self.n_persp * self.n_grasp, rounding_mode="floor")
+        v = torch.div(idx, self.n_grasp, rounding_mode="floor") % self.n_persp
+        g = idx % self.n_grasp
+        occ = torch.zeros_like(self.occurence_map)
+        occ[o, v, g] = True
+        self.occurence_map |= occ
+        return o.numpy(), v.numpy(), g.numpy()
+
+    # ------------------------------------------------------------------ prepare(): per-epoch pose generation
+    def prepare(self):
+        """artiboost_loader.py:279-291,352-400: sample CCV triplets, generate poses (GPU, batches of 256), assemble GT
+        (host), upload the epoch as device SoA tensors.  Under DDP every rank draws the same epoch (same seed) and
+        keeps its own slice idx[rank::world]."""
+        if not self.use_synth:
+            self.epoch = None
+            return
+        o, v, g = self._sample_ccv()
+        sl = slice(self.rank, None, self.world)
+        rng = self.rng
+        S_all = self.synth_len
+        u_off, th_off = rng.uniform(-0.5, 0.5, S_all), rng.uniform(-0.5, 0.5, S_all)
+        free = rng.uniform(0, 2 * np.pi, S_all)
+        zoff = rng.uniform(self.z_range[0], self.z_range[1], S_all)
+        d_pose = self.pose_generator.pose_sigma * rng.standard_normal((S_all, 16))
+        d_tsl = self.pose_generator.tsl_sigma * rng.standard_normal((S_all, 3))
+        aug = dict(center=rng.uniform(-1, 1, (S_all, 2)), scale=rng.normal(0, 0.1 / 3.0, S_all),
+                   rot=rng.uniform(-0.2 * np.pi, 0.2 * np.pi, S_all), hid=rng.integers(0, self.assets.hand_tex.shape[0], S_all),
+                   light=rng.uniform(1.0, 5.0, S_all), bid=rng.integers(0, self.assets.backgrounds.shape[0], S_all),
+                   bcrop=rng.integers(self.render_size[0], self.assets.backgrounds.shape[1] + 1, S_all),
+                   bx=rng.uniform(0, 1, S_all), by=rng.uniform(0, 1, S_all),
+                   order=np.stack([rng.permutation(4) for _ in range(S_all)]),
+                   bright=rng.uniform(0.9, 1.1, S_all), contrast=rng.uniform(0.9, 1.1, S_all),
+                   sat=rng.uniform(0.9, 1.1, S_all), hue=rng.uniform(-0.075, 0.075, S_all))
+        o, v, g = o[sl], v[sl], g[sl]
+        pick = lambda a: a[sl]   # noqa: E731
+        S = len(o)
+        Rp = np.stack([perspective_rotmat(int(p), a, b, self.u_bins, self.theta_bins) for p, a, b in zip(v, pick(u_off), pick(th_off))])
+        fr = pick(free)
+        Tf = np.tile(np.eye(4), (S, 1, 1))
+        Tf[:, 0, 0], Tf[:, 0, 1], Tf[:, 1, 0], Tf[:, 1, 1] = np.cos(fr), -np.sin(fr), np.sin(fr), np.cos(fr)
+        z3 = np.zeros((S, 3))
+        z3[:, 2] = pick(zoff)
+        gp, gs, gt_ = self.grasps
+        dev = self.dev
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)   # noqa: E731
+        obj_pose, verts, joints = [], [], []
+        for s0 in range(0, S, 256):
+            s1 = min(S, s0 + 256)
+            op, hv, jt = self.pose_generator(t(gp[o[s0:s1], g[s0:s1]]), t(gs[o[s0:s1], g[s0:s1]]), t(gt_[o[s0:s1], g[s0:s1]]),
+                                             t(Rp[s0:s1]), t(Tf[s0:s1]), t(z3[s0:s1]), t(pick(d_pose)[s0:s1]), t(pick(d_tsl)[s0:s1]))
+            obj_pose.append(op); verts.append(hv); joints.append(jt)
+        obj_pose_d, verts_d, joints_d = torch.cat(obj_pose), torch.cat(verts), torch.cat(joints)
+        obj_pose_h, joints_h = obj_pose_d.cpu().numpy().astype(np.float64), joints_d.cpu().numpy().astype(np.float64)
+        # ---- host: GT assembly + render descriptors
+        a = {k: pick(val) for k, val in aug.items()}
+        samples = np.zeros(S, SAMPLE_DTYPE)
+        samples["obj_id"], samples["hand_tex_id"], samples["bg_id"] = o, a["hid"], a["bid"]
+        bgs = self.assets.backgrounds.shape[1]
+        samples["bg_w"] = samples["bg_h"] = a["bcrop"]
+        samples["bg_x0"] = np.floor(a["bx"] * (bgs - a["bcrop"] + 1)).astype(np.int32)
+        samples["bg_y0"] = np.floor(a["by"] * (bgs - a["bcrop"] + 1)).astype(np.int32)
+        samples["light"] = a["light"]
+        samples["obj_pose"] = obj_pose_h.reshape(S, 16).astype(np.float32)
+        fac_of = {0: a["bright"], 1: a["sat"], 2: a["hue"], 3: a["contrast"]}
+        order = a["order"].astype(np.int32)
+        factor = np.stack([np.choose(order[:, k], [fac_of[0], fac_of[1], fac_of[2], fac_of[3]]) for k in range(4)], 1).astype(np.float32)
+        keys = (Queries.CAM_INTR, Queries.ROOT_JOINT, Queries.JOINTS_3D, Queries.JOINTS_2D, Queries.JOINTS_VIS,
+                Queries.CORNERS_3D, Queries.CORNERS_2D, Queries.CORNERS_VIS, Queries.CORNERS_CAN, Queries.OBJ_TRANSF)
+        gt = {k: [] for k in keys}
+        inv = np.zeros((S, 6), np.float32)
+        for i in range(S):
+            r = assemble_gt(self.K, joints_h[i], obj_pose_h[i], self.assets.corners_can[o[i]].astype(np.float64), self.image_size,
+                            self.render_size, a["center"][i], a["scale"][i], a["rot"][i], self.center_idx, self.bbox_expand)
+            for k in keys:
+                gt[k].append(r[k])
+            inv[i] = np.linalg.inv(np.vstack([r["affine"][:2], [0, 0, 1]]).astype(np.float64))[:2].reshape(-1)
+        ep = {k: t(np.stack(val)) for k, val in gt.items()}
+        ep[Queries.OBJ_IDX] = torch.from_numpy(self.assets.obj_idx[o]).to(dev)
+        ep[SynthQueries.OBJ_ID] = torch.from_numpy(o.astype(np.int64)).to(dev)
+        ep[SynthQueries.PERSP_ID] = torch.from_numpy(v.astype(np.int64)).to(dev)
+        ep[SynthQueries.GRASP_ID] = torch.from_numpy(g.astype(np.int64)).to(dev)
+        ep[SynthQueries.IS_SYNTH] = torch.ones(S, dtype=torch.bool, device=dev)
+        ep[Queries.SAMPLE_IDX] = torch.arange(S, device=dev)
+        ep["_samples"] = torch.from_numpy(samples.view(np.uint8).reshape(S, -1)).to(dev)
+        ep["_hand_verts"] = verts_d
+        ep["_order"] = torch.from_numpy(order).to(dev)
+        ep["_factor"] = torch.from_numpy(factor).to(dev)
+        ep["_inv_affine"] = torch.from_numpy(inv).to(dev)
+        self.epoch, self.epoch_len, self.cursor = ep, S, 0
+
+    # ------------------------------------------------------------------ iteration
+    def __len__(self):
+        return (self.epoch_len // self.batch_size) if self.epoch is not None else 0
+
+    def new_static_batch(self):
+        """Static device buffers one batch wide (inputs of a captured hipGraph)."""
+        B, (W, H) = self.batch_size, self.image_size
+        ep = self.epoch
+        st = {k: torch.empty((B,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.dev) for k, v in ep.items()}
+        st["image_nhwc4_padded"] = torch.zeros((B, H + 6, W + 8, 4), dtype=self.dtype, device=self.dev)
+        return st
+
+    def load_batch(self, static, batch_idx):
+        """Gather batch `batch_idx` of the epoch into the static buffers (small async device copies)."""
+        s0 = batch_idx * self.batch_size
+        for k, v in self.epoch.items():
+            static[k].copy_(v[s0:s0 + self.batch_size], non_blocking=True)
+
+    def render_into(self, static, want_chw=False):
+        """Enqueue the batched render of the samples currently in `static` (hipGraph-capturable)."""
+        W, H = self.image_size
+        chw = None
+        if want_chw:
+            chw = static.get(Queries.IMAGE)
+            if chw is None:
+                chw = static[Queries.IMAGE] = torch.empty((self.batch_size, 3, H, W), dtype=torch.float32, device=self.dev)
+        self.renderer.render(static["_samples"], static["_hand_verts"], static["_order"], static["_factor"],
+                             static["_inv_affine"], W, H, out_pad=static["image_nhwc4_padded"], out_chw=chw)
+
+    def __iter__(self):
+        """Reference-shaped iteration: yields batch dicts (device tensors, `image` as float CHW like the reference's
+        collated batch plus the NHWC4 tensor the HIP model consumes directly)."""
+        if self.epoch is None:
+            return
+        static = self.new_static_batch()
+        for bi in range(len(self)):
+            self.load_batch(static, bi)
+            self.render_into(static, want_chw=True)
+            yield {k: v for k, v in static.items() if not k.startswith("_")}
+
+    # ------------------------------------------------------------------ mining (artiboost_loader.py:292-340,503-598)
+    def step_eval(self, epoch_idx, evaluator):
+        from .metrics import ValMetricMean3DEPE2
+        res = [m.get_measures_averaged() for m in evaluator.metrics_list if isinstance(m, ValMetricMean3DEPE2)]
+        if not res:
+            raise ValueError("No validation metric have been found")
+        merged = {k: sum(r[k] for r in res) / len(res) for k in res[0]}
+        self.sample_reweight(merged, epoch_idx)
+
+    def sample_reweight(self, eval_res, epoch_idx):
+        fn = {"method_1": self.update_method_1, "method_2": self.update_method_2, "method_3": self.update_method_3,
+              "method_4": self.update_method_4}[self.update_method_key]
+        out = fn(self.sample_weight_map, eval_res, self.sample_weight_lower_bound, self.sample_weight_upper_bound,
+                 dist_lower_threshold=self.dist_lower_threshold, dist_upper_threshold=self.dist_upper_threshold,
+                 epoch_idx=epoch_idx, n_epochs=self.n_epochs)
+        self.sample_weight_map = out["sample_weight_map"]
+
+    @staticmethod
+    def _confidence(val_res):
+        vals = np.array(list(val_res.values()))
+        return list(val_res.keys()), vals, (vals.max() - vals) / ((vals.max() - vals.min()) + 1e-8)
+
+    @staticmethod
+    def update_method_1(sample_weight_map, val_res, lower, upper, **kw):
+        ids, _, conf = ArtiBoostLoader._confidence(val_res)
+        upd = (1.0 / (conf + 0.5)).tolist()
+        for i, ovg in enumerate(ids):
+            sample_weight_map[ovg[0], ovg[1], ovg[2]] *= upd[i]
+        return {"sample_weight_map": torch.clamp(sample_weight_map, lower, upper)}
+
+    @staticmethod
+    def update_method_2(sample_weight_map, val_res, lower, upper, **kw):
+        ids, _, conf = ArtiBoostLoader._confidence(val_res)
+        for i, ovg in enumerate(ids):
+            sample_weight_map[ovg[0], ovg[1], ovg[2]] += (-0.1 if conf[i] > 0.5 else 0.1)
+        return {"sample_weight_map": torch.clamp(sample_weight_map, lower, upper)}
+
+    @staticmethod
+    def update_method_3(sample_weight_map, val_res, lower, upper, **kw):
+        ids, vals, _ = ArtiBoostLoader._confidence(val_res)
+        lo_m, hi_m = vals < kw["dist_lower_threshold"], vals > kw["dist_upper_threshold"]
+        for i, ovg in enumerate(ids):
+            if lo_m[i]:
+                sample_weight_map[ovg[0], ovg[1], ovg[2]] = 0.0
+            elif hi_m[i]:
+                sample_weight_map[ovg[0], ovg[1], ovg[2]] = 1.0
+            else:
+                sample_weight_map[ovg[0], ovg[1], ovg[2]] *= 0.5
+        return {"sample_weight_map": sample_weight_map, "dist_lower_ratio": lo_m.sum() / len(lo_m)}
+
+    @staticmethod
+    def update_method_4(sample_weight_map, val_res, lower, upper, **kw):
+        if float(kw["epoch_idx"]) / kw["n_epochs"] < 0.75:
+            out = ArtiBoostLoader.update_method_1(sample_weight_map, val_res, lower, upper)
+            out["dist_lower_ratio"] = -1.0
+            return out
+        return ArtiBoostLoader.update_method_3(sample_weight_map, val_res, lower, upper, **kw)
+
+    def synth_shutdown(self):
+        self.use_synth = False
+        self.epoch = None

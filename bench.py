@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- synthesized-samples/sec of the coupled hot path on N MI355X (one process per GPU).
+
+A "step" = one pass of the hot path over one per-GPU batch of 64 synthetic CCV samples at 256x256:
+   gather sample -> rasterise/z-buffer/shade 512x512 -> colour jitter -> affine crop (HIP render kernels)
+   -> HybridBaseline ResNet-34 forward -> fused soft-argmax -> fused pose+criterion (+backward) -> backward
+   -> [RCCL all-reduce of the flat gradient] -> global-norm clip + Adam (HIP)
+Inputs (epoch pose cache, assets, weights) are resident in HBM when the timed region starts; the per-step host work
+(loss RNG draws, Adam bias corrections, batch gather) is inside it.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel family (implicit-GEMM conv on MFMA): algorithmic
+FLOPs of the conv stack per step / summed conv-kernel time measured with HIP events on the compute stream.
+`cpu_baseline` times the CPU oracle of the same step (oracle/: C rasteriser + torch-CPU fp32 learner) on a bounded
+sample on this box's host cores."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_FWD_BWD_PER_SAMPLE = {224: 24.336, 256: 31.785}      # SURVEY.md section 8d (torch flop counter on the reference module)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}          # MI355X_MICROARCH.md (dense)
+
+
+def ref_cfg(size):
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["DATA_PRESET"]["IMAGE_SIZE"] = [size, size]
+    cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [size // 8, size // 8]
+    cfg["ARCH"]["BACKBONE"]["PRETRAINED"] = False       # ImageNet weights are a download; random init (stated in `data`)
+    return cfg
+
+
+def build_everything(args, rank, world, device):
+    import torch
+    from artiboost_amd import registry as R
+    from artiboost_amd.assets import SceneAssets
+    from artiboost_amd.criterions import Criterion
+    from artiboost_amd.models import Arch
+    from artiboost_amd.optim import FusedClipAdam
+    from artiboost_amd.synth import ArtiBoostLoader
+    from artiboost_amd.train import TrainStep
+    cfg = ref_cfg(args.size)
+    arch_cfg = dict(cfg["ARCH"], COMPUTE_DTYPE=args.dtype, DEVICE=device, INIT_SEED=cfg["TRAIN"]["MANUAL_SEED"])
+    model = Arch({"ARCH": arch_cfg}, R.build_arch_model_list(arch_cfg, preset_cfg=cfg["DATA_PRESET"]))
+    crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+    hb = model.model_list[0]
+    opt = FusedClipAdam(model.models_params, lr=cfg["TRAIN"]["LR"], max_norm=cfg["TRAIN"]["GRAD_CLIP"], model=hb)
+    assets = SceneAssets(args.dataset, seed=1)
+    mgr = dict(cfg["MANAGER"], EPOCH=cfg["TRAIN"]["EPOCH"])
+    synth_len = args.bs * world * max(args.steps + args.warmup + 2, 4)
+    loader = ArtiBoostLoader(assets, mgr, cfg["DATA_PRESET"], args.bs, synth_len, device=device,
+                             compute_dtype=hb.net.dtype, random_seed=cfg["TRAIN"]["MANUAL_SEED"], rank=rank, world_size=world)
+    loader.prepare()
+    static = loader.new_static_batch()
+    loader.load_batch(static, 0)
+    group = torch.distributed.group.WORLD if world > 1 else None
+    model.train()
+    ts = TrainStep(model, crit, opt, static, use_graph=not args.eager, dist_group=group, renderer=loader)
+    ts.static = static
+    return cfg, model, crit, opt, loader, ts, static
+
+
+def conv_kernel_time_ms(ts, loader, static, iters=3):
+    """Average per-step time of the conv-stack MFMA kernels, measured with HIP events on the compute stream by
+    running the step eagerly with events around every conv launch (kernels.py hooks)."""
+    import torch
+    from artiboost_amd import kernels as K
+    names = ["conv2d_fwd", "conv2d_stem_fwd", "conv2d_dgrad", "conv2d_wgrad", "conv2d_stem_wgrad"]
+    orig = {n: getattr(K, n) for n in names}
+    spans = []
+
+    def wrap(fn):
+        def f(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            spans.append((e0, e1))
+            return r
+        return f
+
+    total = 0.0
+    try:
+        for n in names:
+            setattr(K, n, wrap(orig[n]))
+        for it in range(iters):
+            spans.clear()
+            loader.load_batch(static, it % max(len(loader), 1))
+            ts.crit.draw(ts.dev)
+            ts._fwd_bwd()
+            torch.cuda.synchronize()
+            total += sum(a.elapsed_time(b) for a, b in spans)
+            nl = len(spans)
+    finally:
+        for n in names:
+            setattr(K, n, orig[n])
+    return total / iters, nl
+
+
+def cpu_baseline(args, cfg):
+    """The CPU oracle of the same step on this box's host cores: C software renderer (OpenMP over samples) + torch-CPU
+    fp32 HybridBaseline forward/loss/backward/clip+Adam.  Bounded sample."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_scene
+    import learner_oracle as lo
+    import render_oracle as ro
+    from artiboost_amd.assets import SceneAssets
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = args.cpu_samples
+    assets = SceneAssets(args.dataset, seed=1)
+    sc = gen_scene.make_samples(assets, n, 1, out_res=(args.size, args.size))
+    holder = ro.SceneHolder(assets)
+    t0 = time.time()
+    img, _, _ = holder.render_batch(sc["samples"], sc["hand_verts"], sc["order"], sc["factor"], sc["inv_affine"], args.size, args.size)
+    t_render = time.time() - t0
+    params = lo.fill_params(lo.param_shapes(22, 28), seed=1)
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in params.items()}
+    gt = sc["gt"]
+    batch = {"image": torch.from_numpy(img)}
+    for k in ("root_joint", "cam_intr", "corners_can", "joints_3d", "corners_3d", "joints_vis", "corners_vis"):
+        batch[k] = torch.from_numpy(np.stack([g[k] for g in gt]).astype(np.float32))
+    t0 = time.time()
+    preds = lo.hybrid_forward(leaf, batch, [args.size, args.size], 22, 28, 0, training=True)
+    total, _, _ = lo.criterion(preds, batch)
+    total.backward()
+    names = [k for k, v in leaf.items() if v.dtype.is_floating_point and getattr(v, "grad", None) is not None]
+    ps = [leaf[k].detach() for k in names]
+    lo.clip_and_adam(ps, [leaf[k].grad for k in names], [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps], 1)
+    t_learn = time.time() - t0
+    return {"value": round(n / (t_render + t_learn), 3), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic {args.dataset}-like CCV samples at {args.size}x{args.size}: C oracle render "
+                      f"(OpenMP, {t_render:.2f}s) + torch-CPU fp32 HybridBaseline fwd+loss+bwd+clip/Adam ({t_learn:.2f}s)",
+            "render_samples_per_s": round(n / t_render, 2), "learner_samples_per_s": round(n / t_learn, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bs", type=int, default=64)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dataset", default="HO3D", choices=["HO3D", "DexYCB"])
+    ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    device = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    cfg, model, crit, opt, loader, ts, static = build_everything(args, rank, world, device)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    nb = len(loader)
+    for i in range(args.warmup):
+        loader.load_batch(static, i % nb)
+        ts()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loader.load_batch(static, (args.warmup + i) % nb)
+        ts()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms = dt / args.steps * 1e3
+    value = args.bs * world * args.steps / dt
+    out = None
+    if rank == 0:
+        losses = ts.out[1].float().cpu().tolist() if ts.fused is not None else []
+        roof = None
+        try:
+            conv_ms, nlaunch = conv_kernel_time_ms(ts, loader, static)
+            flops = GFLOP_FWD_BWD_PER_SAMPLE.get(args.size, 31.785) * 1e9 * args.bs
+            ach = flops / (conv_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "kernel": "conv_gemm_kernel + wgrad_kernel (implicit-GEMM conv stack)",
+                    "conv_ms_per_step": round(conv_ms, 3), "conv_launches_per_step": nlaunch}
+        except Exception as e:   # noqa: BLE001
+            roof = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": None,
+                    "traffic": None, "error": repr(e)}
+        base = None
+        if world == 1 and not args.no_cpu_baseline:
+            base = cpu_baseline(args, cfg)
+        out = {"metric": "synth samples/sec (render+fwd+bwd) 256x256 bs=64", "value": round(value, 2), "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+               "data": "synthetic (seeded stand-in meshes/textures/grasps; random-init weights)",
+               "config": {"workload": f"train_artiboost HO3Dv2-clasbased (HybridBaseline/ResNet-34, 22x28x{args.size // 8}x{args.size // 8} heat-map) "
+                                      f"+ online CCV render 512->{args.size}, per-GPU batch {args.bs}, {args.dataset}-like objects",
+                          "global_batch": args.bs * world, "image": args.size, "parallelism": f"dp{world}",
+                          "graph": not args.eager},
+               "final_loss": losses[5] if losses else None,
+               "roofline": roof, "cpu_baseline": base}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -154,6 +154,16 @@ int ab_render_batch(const ab_scene* scene_host, const void* samples, const float
                     int out_dtype, void* out_pad, float* out_chw, void* workspace, void* keys_out, void* rgbx_out,
                     void* stream);
 
+/* ---- R1: MANO linear-blend skinning ------------------------------------------------------------------------------
+ * replaces manotorch.manolayer.ManoLayer.forward (third party, un-pinned git dependency, requirements.txt:178) at
+ * anakin/artiboost/preprocessor.py:25,62, refiner.py:138,193,216,265, grasp_engine.py:90-95; maths as in the in-tree
+ * anakin/postprocess/iknet/manolayer.py:182-276 (center_idx=None).  pose [B,48] axis-angle, betas [B,10];
+ * model tables: v_template [778,3], shapedirs [778,3,10], posedirs [778,3,135], J_regressor [16,778],
+ * weights [778,16], hands_mean [45].  Outputs verts [B,778,3], joints [B,21,3], T_abs [B,16,4,4] (optional).     */
+int ab_mano_lbs(const float* pose, const float* betas, const float* v_template, const float* shapedirs,
+                const float* posedirs, const float* J_regressor, const float* weights, const float* hands_mean,
+                int B, float* verts, float* joints, float* T_abs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
