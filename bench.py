@@ -111,8 +111,11 @@ def cpu_baseline(args, cfg):
     import learner_oracle as lo
     import render_oracle as ro
     from artiboost_amd.assets import SceneAssets
-    cores = os.cpu_count() or 1
+    # 32 threads: torch's CPU convolutions stop scaling (and collapse under oversubscription) well before the 256
+    # hardware threads of the GPU box; `cores` reports the threads actually used
+    cores = min(os.cpu_count() or 1, args.cpu_threads)
     torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     n = args.cpu_samples
     assets = SceneAssets(args.dataset, seed=1)
     sc = gen_scene.make_samples(assets, n, 1, out_res=(args.size, args.size))
@@ -152,6 +155,7 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-samples", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
 
     import torch
