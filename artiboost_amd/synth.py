@@ -270,17 +270,22 @@ class ArtiBoostLoader:
         self.torch_gen = torch.Generator().manual_seed(random_seed)
         from .assets import make_grasps
         self.grasps = grasps if grasps is not None else make_grasps(self.n_obj, self.n_grasp, seed=random_seed + 5)
-        self.mano = ManoLayerHIP(assets.hand, device)
         sc = cfg.get("SCRAMBLER", {"HAND_TSL_SIGMA": 0.01, "HAND_POSE_SIGMA": 0.1})
+        if self.dev.type == "cuda":
+            self.mano = ManoLayerHIP(assets.hand, device)
+            self.renderer = DeviceRenderer(assets, self.K, self.render_size[0], self.render_size[1], device)
+        else:       # host-only instance (epoch planning / CCV bookkeeping); prepare() needs the GPU
+            self.mano = self.renderer = None
         self.pose_generator = PoseGenerator(self.mano, sc["HAND_TSL_SIGMA"], sc["HAND_POSE_SIGMA"])
-        self.renderer = DeviceRenderer(assets, self.K, self.render_size[0], self.render_size[1], device)
         self.epoch = None
         self.cursor = 0
 
     # ------------------------------------------------------------------ CCV sampling (ovg_set.py:104-132,162-178)
     def _sample_ccv(self):
-        dist = torch.distributions.Categorical(self.sample_weight_map.reshape(-1))
-        idx = dist.sample(sample_shape=(self.synth_len,))
+        # == torch.distributions.Categorical(w).sample((n,)) (ovg_set.py:113-114: multinomial with replacement over the
+        # normalised weights) but from the loader's own seeded generator, so every DDP rank draws the same epoch
+        w = self.sample_weight_map.reshape(-1)
+        idx = torch.multinomial(w / w.sum(), self.synth_len, replacement=True, generator=self.torch_gen)
         o = torch.div(idx, self.n_persp * self.n_grasp, rounding_mode="floor")
         v = torch.div(idx, self.n_grasp, rounding_mode="floor") % self.n_persp
         g = idx % self.n_grasp
@@ -288,6 +293,32 @@ class ArtiBoostLoader:
         occ[o, v, g] = True
         self.occurence_map |= occ
         return o.numpy(), v.numpy(), g.numpy()
+
+    # ------------------------------------------------------------------ epoch plan (host only; testable without a GPU)
+    def plan_epoch(self):
+        """Draw the epoch's CCV triplets and every per-sample random draw from the shared seed, then keep this rank's
+        slice idx[rank::world] (SURVEY.md section 8e): all ranks consume identical RNG streams, so the union over ranks
+        is exactly the single-process epoch and the slices are disjoint."""
+        o, v, g = self._sample_ccv()
+        sl = slice(self.rank, None, self.world)
+        rng = self.rng
+        S_all = self.synth_len
+        plan = dict(u_off=rng.uniform(-0.5, 0.5, S_all), th_off=rng.uniform(-0.5, 0.5, S_all),
+                    free=rng.uniform(0, 2 * np.pi, S_all), zoff=rng.uniform(self.z_range[0], self.z_range[1], S_all),
+                    d_pose=self.pose_generator.pose_sigma * rng.standard_normal((S_all, 16)),
+                    d_tsl=self.pose_generator.tsl_sigma * rng.standard_normal((S_all, 3)))
+        aug = dict(center=rng.uniform(-1, 1, (S_all, 2)), scale=rng.normal(0, 0.1 / 3.0, S_all),
+                   rot=rng.uniform(-0.2 * np.pi, 0.2 * np.pi, S_all), hid=rng.integers(0, self.assets.hand_tex.shape[0], S_all),
+                   light=rng.uniform(1.0, 5.0, S_all), bid=rng.integers(0, self.assets.backgrounds.shape[0], S_all),
+                   bcrop=rng.integers(self.render_size[0], self.assets.backgrounds.shape[1] + 1, S_all),
+                   bx=rng.uniform(0, 1, S_all), by=rng.uniform(0, 1, S_all),
+                   order=np.stack([rng.permutation(4) for _ in range(S_all)]),
+                   bright=rng.uniform(0.9, 1.1, S_all), contrast=rng.uniform(0.9, 1.1, S_all),
+                   sat=rng.uniform(0.9, 1.1, S_all), hue=rng.uniform(-0.075, 0.075, S_all))
+        plan = {k: val[sl] for k, val in plan.items()}
+        plan["aug"] = {k: val[sl] for k, val in aug.items()}
+        plan.update(o=o[sl], v=v[sl], g=g[sl], global_index=np.arange(S_all)[sl])
+        return plan
 
     # ------------------------------------------------------------------ prepare(): per-epoch pose generation
     def prepare(self):
@@ -297,25 +328,12 @@ class ArtiBoostLoader:
         if not self.use_synth:
             self.epoch = None
             return
-        o, v, g = self._sample_ccv()
-        sl = slice(self.rank, None, self.world)
-        rng = self.rng
-        S_all = self.synth_len
-        u_off, th_off = rng.uniform(-0.5, 0.5, S_all), rng.uniform(-0.5, 0.5, S_all)
-        free = rng.uniform(0, 2 * np.pi, S_all)
-        zoff = rng.uniform(self.z_range[0], self.z_range[1], S_all)
-        d_pose = self.pose_generator.pose_sigma * rng.standard_normal((S_all, 16))
-        d_tsl = self.pose_generator.tsl_sigma * rng.standard_normal((S_all, 3))
-        aug = dict(center=rng.uniform(-1, 1, (S_all, 2)), scale=rng.normal(0, 0.1 / 3.0, S_all),
-                   rot=rng.uniform(-0.2 * np.pi, 0.2 * np.pi, S_all), hid=rng.integers(0, self.assets.hand_tex.shape[0], S_all),
-                   light=rng.uniform(1.0, 5.0, S_all), bid=rng.integers(0, self.assets.backgrounds.shape[0], S_all),
-                   bcrop=rng.integers(self.render_size[0], self.assets.backgrounds.shape[1] + 1, S_all),
-                   bx=rng.uniform(0, 1, S_all), by=rng.uniform(0, 1, S_all),
-                   order=np.stack([rng.permutation(4) for _ in range(S_all)]),
-                   bright=rng.uniform(0.9, 1.1, S_all), contrast=rng.uniform(0.9, 1.1, S_all),
-                   sat=rng.uniform(0.9, 1.1, S_all), hue=rng.uniform(-0.075, 0.075, S_all))
-        o, v, g = o[sl], v[sl], g[sl]
-        pick = lambda a: a[sl]   # noqa: E731
+        if self.mano is None:
+            raise RuntimeError("ArtiBoostLoader.prepare() renders on the GPU: construct the loader with a cuda device")
+        plan = self.plan_epoch()
+        o, v, g, aug = plan["o"], plan["v"], plan["g"], plan["aug"]
+        u_off, th_off, free, zoff, d_pose, d_tsl = (plan[k] for k in ("u_off", "th_off", "free", "zoff", "d_pose", "d_tsl"))
+        pick = lambda a: a   # noqa: E731  (plan_epoch already sliced to this rank)
         S = len(o)
         Rp = np.stack([perspective_rotmat(int(p), a, b, self.u_bins, self.theta_bins) for p, a, b in zip(v, pick(u_off), pick(th_off))])
         fr = pick(free)
@@ -335,7 +353,7 @@ class ArtiBoostLoader:
         obj_pose_d, verts_d, joints_d = torch.cat(obj_pose), torch.cat(verts), torch.cat(joints)
         obj_pose_h, joints_h = obj_pose_d.cpu().numpy().astype(np.float64), joints_d.cpu().numpy().astype(np.float64)
         # ---- host: GT assembly + render descriptors
-        a = {k: pick(val) for k, val in aug.items()}
+        a = aug
         samples = np.zeros(S, SAMPLE_DTYPE)
         samples["obj_id"], samples["hand_tex_id"], samples["bg_id"] = o, a["hid"], a["bid"]
         bgs = self.assets.backgrounds.shape[1]

@@ -12,6 +12,17 @@ import torch
 from .registry import Queries
 
 
+def allreduce_flat_(g, world, group=None, bucket_elems=8 << 20):
+    """In-place average of the flat gradient over `world` ranks in fixed-size buckets (32 MiB of fp32 by default:
+    large enough to run RCCL at link rate over xGMI, small enough that the first bucket is on the wire while the
+    later ones are still being enqueued).  Works for any backend (RCCL on GPU, gloo in the CPU tests)."""
+    n = g.numel()
+    for s in range(0, n, bucket_elems):
+        torch.distributed.all_reduce(g[s:s + bucket_elems], op=torch.distributed.ReduceOp.SUM, group=group)
+    g.mul_(1.0 / world)
+    return g
+
+
 class TrainStep:
     def __init__(self, arch_model, criterion, optimizer, example_batch, use_graph=True, dist_group=None,
                  renderer=None, fused_criterion=True):
@@ -74,11 +85,7 @@ class TrainStep:
         cur = torch.cuda.current_stream(self.dev)
         self.comm_stream.wait_stream(cur)
         with torch.cuda.stream(self.comm_stream):
-            n = g.numel()
-            bucket = 8 << 20          # 8 Mi floats = 32 MiB per bucket
-            for s in range(0, n, bucket):
-                torch.distributed.all_reduce(g[s:s + bucket], op=torch.distributed.ReduceOp.SUM, group=self.group)
-            g.mul_(1.0 / self.world)
+            allreduce_flat_(g, self.world, self.group)
         cur.wait_stream(self.comm_stream)
 
     # ------------------------------------------------------------------ capture

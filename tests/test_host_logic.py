@@ -1,0 +1,190 @@
+"""CPU: host-side logic of the package (registry/config, parameter layout conversion, CCV bookkeeping, GT geometry,
+rotations) against the reference's golden vectors and the oracle; the N>1 data-parallel pieces under gloo, world 2."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import learner_oracle as lo
+import pose_oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg():
+    return yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+
+
+def test_registry_builds_reference_yaml_schema():
+    from artiboost_amd import registry as R
+    import artiboost_amd.criterions  # noqa: F401
+    import artiboost_amd.metrics  # noqa: F401
+    cfg = _cfg()
+    losses = R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"])
+    assert [type(l).__name__ for l in losses] == ["JointsLoss", "HandOrdLoss", "SceneOrdLoss"]
+    metrics = R.build_evaluator_metric_list(cfg["EVALUATOR"], preset_cfg=cfg["DATA_PRESET"])
+    assert [type(m).__name__ for m in metrics] == ["LossesMetric", "Mean3DEPE", "ValMetricMean3DEPE2"]
+    with pytest.raises(KeyError):
+        R.build_from_cfg({"TYPE": "Nope"}, R.LOSS)
+
+
+def test_criterion_cpu_matches_reference_golden(golden_dir):
+    """The plugin-level losses are device-agnostic torch code: check them on CPU against the reference's golden."""
+    import random
+    from artiboost_amd import registry as R
+    from artiboost_amd.criterions import Criterion
+    from gen_batch import make_batch
+    g = np.load(os.path.join(golden_dir, "learner_g224.npz"))
+    size, heat, depth, B, seed = [int(x) for x in g["meta"]]
+    cfg = _cfg()
+    crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+    batch = make_batch(B, size, seed + 100)
+    preds = {"joints_3d_abs": torch.from_numpy(g["train.pred.joints_3d_abs"]), "corners_3d_abs": torch.from_numpy(g["train.pred.corners_3d_abs"])}
+    random.seed(seed + 7); torch.manual_seed(seed + 7)
+    total, losses = crit.compute_losses(preds, batch)
+    for k in ("joints_3d_loss", "corners_3d_loss", "joint_ord_loss", "part_ord_loss", "scene_ord_loss", "final_loss"):
+        np.testing.assert_allclose(losses[k].numpy().reshape(-1), g[f"loss.{k}"].reshape(-1), rtol=1e-4, atol=1e-8, err_msg=k)
+
+
+def test_param_store_roundtrip_and_layouts():
+    from artiboost_amd.hybridnet import ParamStore
+    st = ParamStore(22, 28, device="cpu")
+    params = lo.fill_params(lo.param_shapes(22, 28), seed=3)
+    st.load_reference_state_dict({"_model_list.0." + k: v for k, v in params.items()})
+    back = st.reference_state_dict()
+    for k, v in params.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        np.testing.assert_array_equal(back[k].numpy(), v.numpy(), err_msg=k)
+    # layout spot checks: OHWI, padded stem, padded depth, padded box head
+    w = params["backbone.layer2.0.conv1.weight"]
+    np.testing.assert_array_equal(st.view("backbone.layer2.0.conv1.weight")[5, 2, 1, 7].item(), w[5, 7, 2, 1].item())
+    stem = st.view("backbone.conv1.weight")
+    assert stem.shape == (64, 7, 8, 4) and float(stem[:, :, 7].abs().max()) == 0 and float(stem[..., 3].abs().max()) == 0
+    fw = st.view("hybrid_head.final_layer.weight").reshape(22, 32, 256)
+    assert float(fw[:, 28:].abs().max()) == 0
+    np.testing.assert_array_equal(fw[3, 5].numpy(), params["hybrid_head.final_layer.weight"][3 * 28 + 5, :, 0, 0].numpy())
+    assert st.total % 64 == 0 and st.trainable_numel() < st.total
+    with pytest.raises(ValueError):
+        st.load_reference_state_dict({"backbone.conv1.weight": torch.zeros(64, 3, 3, 3)}, strict=False)
+
+
+def test_gt_geometry_and_views_match_reference(golden_dir):
+    from artiboost_amd import synth
+    g = np.load(os.path.join(golden_dir, "misc.npz"))
+    for i in range(len(g["affine.scale"])):
+        res = [224, 224] if i % 2 else [256, 256]
+        tot, post = synth.get_affine_transform(g["affine.center"][i], float(g["affine.scale"][i]), [256.0, 256.0], res, float(g["affine.rot"][i]))
+        np.testing.assert_allclose(tot, g["affine.total"][i], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(post, g["affine.post"][i], rtol=1e-6, atol=1e-5)
+    for v, m in zip(g["view.vecs"], g["view.align"]):
+        np.testing.assert_allclose(synth.align_mat(v.copy()), m, rtol=1e-9, atol=1e-12)
+    # assemble_gt (product) == pose_oracle.assemble_sample_gt (restatement of rendered_dataset.py:155-254)
+    rng = np.random.default_rng(0)
+    K = np.array([[435.0, 0, 256.0], [0, 435.0, 256.0], [0, 0, 1.0]])
+    for _ in range(5):
+        joints = np.array([0.0, 0.0, 0.5]) + 0.05 * rng.standard_normal((21, 3))
+        pose = np.eye(4); pose[:3, :3] = po.aa_to_rotmat(rng.standard_normal(3)); pose[:3, 3] = [0.02, -0.01, 0.5]
+        can = np.array([[sx, sy, sz] for sx in (-.04, .04) for sy in (-.06, .06) for sz in (-.03, .03)])
+        d = dict(center=rng.uniform(-1, 1, 2), scale=rng.normal(0, 0.03), rot=rng.uniform(-0.6, 0.6))
+        ref = po.assemble_sample_gt(K, joints, pose, can, [256, 256], d, raw_size=[512, 512])
+        got = synth.assemble_gt(K, joints, pose, can, [256, 256], [512, 512], d["center"], d["scale"], d["rot"])
+        for k in ("cam_intr", "root_joint", "joints_3d", "joints_2d", "joints_vis", "corners_3d", "corners_2d", "corners_vis", "obj_transf"):
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-6, atol=1e-6, err_msg=k)
+
+
+def test_rotations_vs_scipy_and_oracle():
+    from scipy.spatial.transform import Rotation
+    from artiboost_amd import synth
+    rng = np.random.default_rng(1)
+    aa = rng.standard_normal((64, 3)) * rng.uniform(0.01, 3.0, (64, 1))
+    aa[0] = 0
+    R = synth.aa_to_rotmat(torch.from_numpy(aa)).numpy()
+    np.testing.assert_allclose(R, Rotation.from_rotvec(aa).as_matrix(), atol=1e-12)
+    np.testing.assert_allclose(R, po.aa_to_rotmat(aa), atol=1e-12)
+    back = synth.rotmat_to_aa(torch.from_numpy(R)).numpy()
+    np.testing.assert_allclose(Rotation.from_rotvec(back).as_matrix(), R, atol=1e-9)
+    np.testing.assert_allclose(back, po.rotmat_to_aa(R), atol=1e-9)
+
+
+def test_ccv_update_methods_match_reference(golden_dir):
+    from artiboost_amd.synth import ArtiBoostLoader as AL
+    g = np.load(os.path.join(golden_dir, "misc.npz"))
+    ids = [tuple(int(x) for x in r) for r in g["ccv.ids"]]
+    res = dict(zip(ids, g["ccv.vals"].tolist()))
+    for m in (1, 2, 3):
+        fn = getattr(AL, f"update_method_{m}")
+        out = fn(torch.ones(4, 288, 50), res, 0.1, 10.0, dist_lower_threshold=8.0, dist_upper_threshold=16.0, epoch_idx=3, n_epochs=10)
+        np.testing.assert_allclose(np.array([float(out["sample_weight_map"][i]) for i in res]), g[f"ccv.m{m}"], rtol=1e-6)
+
+
+def test_metrics_epe_and_val_metric():
+    from artiboost_amd.metrics import Mean3DEPE, ValMetricMean3DEPE2
+    g = torch.Generator().manual_seed(0)
+    B = 6
+    preds = {"joints_3d_abs": torch.randn(B, 21, 3, generator=g), "corners_3d_abs": torch.randn(B, 8, 3, generator=g)}
+    targs = {"joints_3d": torch.randn(B, 21, 3, generator=g), "corners_3d": torch.randn(B, 8, 3, generator=g),
+             "root_joint": torch.randn(B, 3, generator=g), "is_synth": torch.tensor([1, 1, 0, 1, 1, 1], dtype=torch.bool),
+             "obj_id": torch.tensor([0, 1, -1, 1, 2, 3]), "persp_id": torch.tensor([5, 6, -1, 6, 7, 8]), "grasp_id": torch.tensor([1, 2, -1, 2, 3, 4])}
+    m = Mean3DEPE(VAL_KEYS=["corners_3d_abs", "joints_3d_abs"], MILLIMETERS=True)
+    m.feed(preds, targs)
+    ref = lo.mean_epe_mm(preds["joints_3d_abs"], targs["joints_3d"], targs["root_joint"])
+    np.testing.assert_allclose(m.get_measures()["joints_3d_abs_mepe"], float(ref.mean()), rtol=1e-5)
+    vm = ValMetricMean3DEPE2(VAL_KEYS=["corners_3d_abs", "joints_3d_abs"], MILLIMETERS=True)
+    vm.feed(preds, targs)
+    avg = vm.get_measures_averaged()
+    assert set(avg) == {(0, 5, 1), (1, 6, 2), (2, 7, 3), (3, 8, 4)}          # real sample dropped, duplicate key: last write wins
+    refc = lo.mean_epe_mm(preds["corners_3d_abs"], targs["corners_3d"], targs["root_joint"])
+    np.testing.assert_allclose(avg[(1, 6, 2)], 0.5 * (float(ref[3]) + float(refc[3])), rtol=1e-5)
+
+
+# ------------------------------------------------------------------ N > 1 (gloo, world_size 2, CPU)
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from artiboost_amd.assets import SceneAssets
+    from artiboost_amd.synth import ArtiBoostLoader
+    from artiboost_amd.train import allreduce_flat_
+    # (1) bucketed gradient averaging == mean of the per-rank gradients
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    allreduce_flat_(g, world, bucket_elems=256)
+    ok1 = torch.allclose(g, torch.arange(1000, dtype=torch.float32) * 1.5)
+    # (2) epoch sharding: same seed on every rank, disjoint slices, union == single-process epoch
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    assets = SceneAssets.__new__(SceneAssets)      # planning needs only a few fields; skip mesh generation
+    assets.n_obj, assets.hand_tex, assets.backgrounds = 4, np.zeros((51, 1, 1, 3), np.uint8), np.zeros((16, 768, 1, 3), np.uint8)
+    assets.hand = None
+    ld = ArtiBoostLoader(assets, cfg["MANAGER"], cfg["DATA_PRESET"], 4, 40, device="cpu", random_seed=7, rank=rank, world_size=world,
+                         grasps=(None, None, None))
+    plan = ld.plan_epoch()
+    ld1 = ArtiBoostLoader(assets, cfg["MANAGER"], cfg["DATA_PRESET"], 4, 40, device="cpu", random_seed=7, rank=0, world_size=1,
+                          grasps=(None, None, None))
+    full = ld1.plan_epoch()
+    idx = plan["global_index"]
+    ok2 = (np.array_equal(plan["o"], full["o"][idx]) and np.array_equal(plan["aug"]["rot"], full["aug"]["rot"][idx])
+           and np.array_equal(idx, np.arange(40)[rank::world]))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, idx.tolist())
+    ok3 = sorted(sum(gathered, [])) == list(range(40))
+    q.put((rank, bool(ok1), bool(ok2), bool(ok3)))
+    dist.destroy_process_group()
+
+
+def test_ddp_pieces_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True, True, True), (1, True, True, True)], res
