@@ -126,7 +126,7 @@ class _Draws:
 
     def put(self, name, cpu_tensor, dev):
         b = self.bufs.get(name)
-        if b is None or b.device != dev or b.shape != cpu_tensor.shape:
+        if b is None or b.shape != cpu_tensor.shape:      # buffers are persistent: a captured hipGraph holds their addresses
             b = torch.empty(cpu_tensor.shape, dtype=cpu_tensor.dtype, device=dev)
             self.bufs[name] = b
         src = cpu_tensor.pin_memory() if dev.type == "cuda" else cpu_tensor

@@ -13,7 +13,6 @@
 #include "common.h"
 
 #define CG_MAXTAPS 16
-#define CG_PITCH 80          // bytes per LDS row (64 data + 16 pad)
 
 struct ConvGemmArgs {
     const void* A; const void* Bw; void* Out;
@@ -34,9 +33,10 @@ struct ConvGemmArgs {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <typename T> struct Elem;
-template <> struct Elem<bf16_t> { static constexpr int BK = 32; };
-template <> struct Elem<float> { static constexpr int BK = 16; };
+// K bytes per step: 128 (64 bf16) on the fast path -- full 128-byte rows per pixel keep the gather on whole cache
+// lines and put 16 MFMAs between barriers; 64 (16 f32) on the exact parity path.  LDS row pitch = KB + 16 bytes:
+// 16 consecutive rows then land on 16 distinct 16-byte slots (conflict-free ds_read_b128 / ds_write_b128).
+// (template parameter KB; the 7x7 stem keeps 64-byte steps because one kernel row of the NHWC4 image is 32 elements)
 
 template <typename T>
 __device__ __forceinline__ void mma_chunk(f32x16& acc, const uint4& a, const uint4& b);
@@ -54,12 +54,15 @@ __device__ __forceinline__ void mma_chunk<float>(f32x16& acc, const uint4& a, co
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int KB>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs g) {
-    constexpr int BK = Elem<T>::BK;
+    constexpr int BK = KB / (int)sizeof(T);
+    constexpr int CG_PITCH = KB + 16;
+    constexpr int CPR = KB / 16;                // 16-byte chunks per row
+    constexpr int RPP = 256 / CPR;              // rows staged per pass of the 256 threads
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave in each direction
-    constexpr int RA = BM / 64, RB = BN / 64;   // staging rows per thread (64 rows per pass)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * CG_PITCH + BM * 4 + 2 * 2 * BN * 4];
+    constexpr int RA = BM / RPP, RB = BN / RPP; // staging rows per thread
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * (KB + 16) + BM * 4 + 2 * 2 * BN * 4];
     constexpr int BUFSZ = (BM + BN) * CG_PITCH;
 #define SA(buf) (smem + (buf) * BUFSZ)
 #define SB(buf) (smem + (buf) * BUFSZ + BM * CG_PITCH)
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs g) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave >> 1, wave_n = wave & 1;
-    const int chunk = tid & 3, srow = tid >> 2;
+    const int chunk = tid % CPR, srow = tid / CPR;
     const T* __restrict__ A = (const T*)g.A;
     const T* __restrict__ Bw = (const T*)g.Bw;
     const int PQ = g.P * g.Q;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs g) {
     int a_h[RA], a_w[RA]; long a_base[RA]; bool a_ok[RA];
 #pragma unroll
     for (int s = 0; s < RA; ++s) {
-        int m = m0 + srow + 64 * s;
+        int m = m0 + srow + RPP * s;
         a_ok[s] = m < g.M;
         int mm = a_ok[s] ? m : 0;
         int n = mm / PQ, r = mm - n * PQ;
@@ -90,13 +93,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs g) {
         a_base[s] = (long)n * g.Ha * g.Wa;
         if (chunk == 0) {
             int op = (n * g.Ho + p * g.out_sh + g.out_oh) * g.Wo + q * g.out_sw + g.out_ow;
-            s_outpix[srow + 64 * s] = a_ok[s] ? op : -1;
+            s_outpix[srow + RPP * s] = a_ok[s] ? op : -1;
         }
     }
     long b_off[RB]; bool b_ok[RB];
 #pragma unroll
     for (int s = 0; s < RB; ++s) {
-        int j = n0 + srow + 64 * s;
+        int j = n0 + srow + RPP * s;
         b_ok[s] = j < g.Cn;
         b_off[s] = (long)(b_ok[s] ? j : 0) * g.ktot;
     }
@@ -122,9 +125,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs g) {
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int s = 0; s < RA; ++s) *(uint4*)(SA(buf) + (srow + 64 * s) * CG_PITCH + chunk * 16) = ra[s];
+        for (int s = 0; s < RA; ++s) *(uint4*)(SA(buf) + (srow + RPP * s) * CG_PITCH + chunk * 16) = ra[s];
 #pragma unroll
-        for (int s = 0; s < RB; ++s) *(uint4*)(SB(buf) + (srow + 64 * s) * CG_PITCH + chunk * 16) = rb[s];
+        for (int s = 0; s < RB; ++s) *(uint4*)(SB(buf) + (srow + RPP * s) * CG_PITCH + chunk * 16) = rb[s];
     };
 
     f32x16 acc[TM][TN];
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs g) {
         const int cur = step & 1;
         if (step + 1 < nsteps) gload(step + 1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < CPR / 2; ++kk) {
             uint4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -212,13 +215,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs g) {
     }
 }
 
-template <typename T>
+template <typename T, int KB>
 static int launch_conv_gemm(const ConvGemmArgs& g, int bm, int bn, hipStream_t st) {
     int tiles = ((g.M + bm - 1) / bm) * ((g.Cn + bn - 1) / bn);
-    if (bm == 128 && bn == 128) conv_gemm_kernel<T, 128, 128><<<tiles, 256, 0, st>>>(g);
-    else if (bm == 128 && bn == 64) conv_gemm_kernel<T, 128, 64><<<tiles, 256, 0, st>>>(g);
-    else if (bm == 64 && bn == 128) conv_gemm_kernel<T, 64, 128><<<tiles, 256, 0, st>>>(g);
-    else conv_gemm_kernel<T, 64, 64><<<tiles, 256, 0, st>>>(g);
+    if (bm == 128 && bn == 128) conv_gemm_kernel<T, 128, 128, KB><<<tiles, 256, 0, st>>>(g);
+    else if (bm == 128 && bn == 64) conv_gemm_kernel<T, 128, 64, KB><<<tiles, 256, 0, st>>>(g);
+    else if (bm == 64 && bn == 128) conv_gemm_kernel<T, 64, 128, KB><<<tiles, 256, 0, st>>>(g);
+    else conv_gemm_kernel<T, 64, 64, KB><<<tiles, 256, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -237,14 +240,14 @@ extern "C" int ab_conv_gemm_mtiles(int M, int Cn) {
     return (M + bm - 1) / bm;
 }
 
-static int run(ConvGemmArgs& g, int dtype, hipStream_t st) {
+static int run(ConvGemmArgs& g, int dtype, hipStream_t st, bool stem = false) {
     int bm, bn; pick_tile(g.M, g.Cn, &bm, &bn);
-    if (dtype == AB_DT_BF16) return launch_conv_gemm<bf16_t>(g, bm, bn, st);
-    if (dtype == AB_DT_F32) return launch_conv_gemm<float>(g, bm, bn, st);
+    if (dtype == AB_DT_BF16) return stem ? launch_conv_gemm<bf16_t, 64>(g, bm, bn, st) : launch_conv_gemm<bf16_t, 128>(g, bm, bn, st);
+    if (dtype == AB_DT_F32) return launch_conv_gemm<float, 64>(g, bm, bn, st);
     return AB_EINVAL;
 }
 
-static int bk_of(int dtype) { return dtype == AB_DT_BF16 ? 32 : 16; }
+static int bk_of(int dtype) { return dtype == AB_DT_BF16 ? 64 : 16; }
 
 extern "C" int ab_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int H, int W, int Cin, int Cout,
                              int kh, int kw, int stride, int pad, const float* bias, float* stats, int relu,
@@ -274,13 +277,13 @@ extern "C" int ab_conv2d_stem_fwd(const void* xpad, const void* w, void* y, int 
     g.A = xpad; g.Bw = w; g.Out = y; g.stats = stats;
     g.N = N; g.Ha = H + 6; g.Wa = W + 8; g.Ca = 4;
     g.Ho = H / 2; g.Wo = W / 2; g.Cn = Cout; g.P = g.Ho; g.Q = g.Wo; g.out_sh = g.out_sw = 1; g.a_sh = g.a_sw = 2;
-    const int bk = bk_of(dtype), per = 32 / bk;     // K-steps per kh row (1 for bf16, 2 for f32)
+    const int bk = dtype == AB_DT_BF16 ? 32 : 16, per = 32 / bk;     // K-steps per kh row (1 for bf16, 2 for f32)
     g.ntaps = 7 * per; g.cpt = 1; g.ktot = 7 * 32; g.M = N * g.P * g.Q;
     if (g.ntaps > CG_MAXTAPS) return AB_ESHAPE;
     for (int i = 0; i < 7; ++i) for (int s = 0; s < per; ++s) {
         g.dh[i * per + s] = (int8_t)i; g.dw[i * per + s] = (int8_t)(s * (bk / 4)); g.koff[i * per + s] = i * 32 + s * bk;
     }
-    return run(g, dtype, as_stream(stream));
+    return run(g, dtype, as_stream(stream), true);
 }
 
 // Data gradient of conv2d(x, w, stride, pad): dx[N,H,W,Cin] from dy[N,Ho,Wo,Cout] and wt = [Cin][kh][kw][Cout].

@@ -63,20 +63,24 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x,
 
 // ---------------------------------------------------------------- BN finalize: partials -> scale/shift, saved stats
 // bnp: float [4][C] = scale (gamma*invstd), shift, mean, invstd.  running stats updated in place when non-null.
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, long count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ bnp) {
-    // block: 1024 threads = 64 channels x 16 part-lanes
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+// block = 8 channels x 32 part-lanes (32 consecutive bytes per partial row per lane group), grid = ceil(C/8)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, long count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* __restrict__ running_mean,
+                                                          float* __restrict__ running_var, float* __restrict__ bnp) {
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int k = pl; k < nparts; k += 16) { s += part[((long)k * C + c) * 2]; q += part[((long)k * C + c) * 2 + 1]; }
-    __shared__ double sm[16][64][2];
-    sm[pl][threadIdx.x & 63][0] = s; sm[pl][threadIdx.x & 63][1] = q;
+        for (int k = pl; k < nparts; k += 32) {
+            float2 v = *(const float2*)(part + ((long)k * C + c) * 2);
+            s += v.x; q += v.y;
+        }
+    __shared__ double sm[32][8][2];
+    sm[pl][cl][0] = s; sm[pl][cl][1] = q;
     __syncthreads();
     if (pl == 0 && c < C) {
-        for (int k = 1; k < 16; ++k) { s += sm[k][threadIdx.x][0]; q += sm[k][threadIdx.x][1]; }
+        for (int k = 1; k < 32; ++k) { s += sm[k][cl][0]; q += sm[k][cl][1]; }
         double mean = s / (double)count;
         double var = q / (double)count - mean * mean; if (var < 0) var = 0;
         float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -106,14 +110,27 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                                                        const float* __restrict__ bnp, long nvec, int C, int relu,
                                                        T* __restrict__ out) {
     constexpr int V = Vec<T>::N;
+    // grid stride (gridDim*256 vectors) is a multiple of C/V whenever 256*V % C == 0: the thread's channels are fixed
+    const bool fixed = ((256 * V) % C) == 0;
+    float sc[V], sh[V];
+    if (fixed) {
+        int c = (int)(((long)threadIdx.x * V) % C);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { sc[k] = bnp[c + k]; sh[k] = bnp[C + c + k]; }
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-        long e = i * V; int c = (int)(e % C);
+        long e = i * V;
+        if (!fixed) {
+            int c = (int)(e % C);
+#pragma unroll
+            for (int k = 0; k < V; ++k) { sc[k] = bnp[c + k]; sh[k] = bnp[C + c + k]; }
+        }
         float f[V]; vload<T>(y + e, f);
         float r[V];
         if (res) vload<T>(res + e, r);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            float v = f[k] * bnp[c + k] + bnp[C + c + k];
+            float v = f[k] * sc[k] + sh[k];
             if (res) v += r[k];
             if (relu) v = fmaxf(v, 0.f);
             f[k] = v;
@@ -161,17 +178,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // reduce partials -> dgamma, dbeta (written to the flat grad buffer) and bwdp[2][C] = (sum dz, sum dz*xhat)
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ bwdp) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ bwdp) {
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int k = pl; k < nparts; k += 16) { s += part[((long)k * C + c) * 2]; q += part[((long)k * C + c) * 2 + 1]; }
-    __shared__ double sm[16][64][2];
-    sm[pl][threadIdx.x & 63][0] = s; sm[pl][threadIdx.x & 63][1] = q;
+        for (int k = pl; k < nparts; k += 32) {
+            float2 v = *(const float2*)(part + ((long)k * C + c) * 2);
+            s += v.x; q += v.y;
+        }
+    __shared__ double sm[32][8][2];
+    sm[pl][cl][0] = s; sm[pl][cl][1] = q;
     __syncthreads();
     if (pl == 0 && c < C) {
-        for (int k = 1; k < 16; ++k) { s += sm[k][threadIdx.x][0]; q += sm[k][threadIdx.x][1]; }
+        for (int k = 1; k < 32; ++k) { s += sm[k][cl][0]; q += sm[k][cl][1]; }
         dbeta[c] = (float)s; dgamma[c] = (float)q;
         bwdp[c] = (float)s; bwdp[C + c] = (float)q;
     }
@@ -185,16 +207,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            int relu, T* __restrict__ dy, T* __restrict__ dz_out) {
     constexpr int V = Vec<T>::N;
     const float invM = 1.f / (float)M;
+    const bool fixed = ((256 * V) % C) == 0;
+    float ga[V], mu[V], is[V], k1[V], k2[V];    // gamma*invstd, mean, invstd, mean(dz), mean(dz*xhat)
+    auto loadp = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            ga[k] = bnp[c + k]; mu[k] = bnp[2 * C + c + k]; is[k] = bnp[3 * C + c + k];
+            k1[k] = bwdp[c + k] * invM; k2[k] = bwdp[C + c + k] * invM;
+        }
+    };
+    if (fixed) loadp((int)(((long)threadIdx.x * V) % C));
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-        long e = i * V; int c = (int)(e % C);
+        long e = i * V;
+        if (!fixed) loadp((int)(e % C));
         float g[V], o[V], yy[V], d[V];
         vload<T>(dout + e, g); vload<T>(y + e, yy);
         if (relu) vload<T>(out + e, o);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
             float dz = (relu && !(o[k] > 0.f)) ? 0.f : g[k];
-            float xhat = (yy[k] - bnp[2 * C + c + k]) * bnp[3 * C + c + k];
-            d[k] = bnp[c + k] * (dz - bwdp[c + k] * invM - xhat * bwdp[C + c + k] * invM);   // bnp[c] = gamma*invstd
+            float xhat = (yy[k] - mu[k]) * is[k];
+            d[k] = ga[k] * (dz - k1[k] - xhat * k2[k]);
             g[k] = dz;
         }
         vstore<T>(dy + e, d);
@@ -352,12 +385,15 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dou
         vstore<T>(dz + i * V, g);
     }
 }
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double s = 0.0;
-    for (int k = 0; k < nparts; ++k) s += part[((long)k * C + c) * 2];
-    out[c] = (float)s;
+    if (c < C) for (int k = pl; k < nparts; k += 32) s += part[((long)k * C + c) * 2];
+    __shared__ double sm[32][8];
+    sm[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) { for (int k = 1; k < 32; ++k) s += sm[k][cl]; out[c] = (float)s; }
 }
 
 // ================================================================ C ABI
@@ -380,7 +416,7 @@ extern "C" int ab_bn_finalize(const float* part, int nparts, int C, long count, 
                               float eps, float momentum, float* running_mean, float* running_var, float* bnp,
                               void* stream) {
     if (!part || !gamma || !beta || !bnp) return AB_EINVAL;
-    bn_finalize_kernel<<<(C + 63) / 64, 1024, 0, as_stream(stream)>>>(part, nparts, C, count, gamma, beta, eps, momentum,
+    bn_finalize_kernel<<<(C + 7) / 8, 256, 0, as_stream(stream)>>>(part, nparts, C, count, gamma, beta, eps, momentum,
                                                                     running_mean, running_var, bnp);
     AB_LAUNCH_CHECK(); return 0;
 }
@@ -413,7 +449,7 @@ extern "C" int ab_bn_bwd(const void* dout, const void* out, const void* y, const
     DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, red_rows(M), part)),
              (bn_bwd_reduce_kernel<bf16_t><<<np, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, red_rows(M), part)));
     AB_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<(C + 63) / 64, 1024, 0, st>>>(part, np, C, dgamma, dbeta, bwdp);
+    bn_bwd_finalize_kernel<<<(C + 7) / 8, 256, 0, st>>>(part, np, C, dgamma, dbeta, bwdp);
     AB_LAUNCH_CHECK();
     long nvec = M * C / V;
     DISPATCH(dtype, (bn_bwd_apply_kernel<float><<<grid_for(nvec), 256, 0, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, bwdp, nvec, C, M, relu, (float*)dy, (float*)dz_out)),
@@ -484,6 +520,6 @@ extern "C" int ab_relu_bwd(const void* dout, const void* out, int dtype, long n,
 extern "C" int ab_col_sum(const void* x, int dtype, long M, int C, float* part, float* out, void* stream) {
     int rc = ab_col_stats(x, dtype, M, C, part, stream);
     if (rc) return rc;
-    colsum_finalize_kernel<<<(C + 255) / 256, 256, 0, as_stream(stream)>>>(part, ab_col_stats_nparts(M), C, out);
+    colsum_finalize_kernel<<<(C + 7) / 8, 256, 0, as_stream(stream)>>>(part, ab_col_stats_nparts(M), C, out);
     AB_LAUNCH_CHECK(); return 0;
 }
