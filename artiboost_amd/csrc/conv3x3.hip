@@ -1,0 +1,330 @@
+// 3x3 / stride 1 / pad 1 convolution (forward, and data-gradient via flipped taps) with an LDS-resident input halo.
+//
+// Why: measured on MI355X the tap-by-tap implicit GEMM (conv_gemm*.hip) is bound by L2->LDS load throughput
+// (~10 TB/s), not by MFMA: every tap re-fetches the same input pixels, 9x redundant traffic.  Here a workgroup owns a
+// TH x TW tile of output pixels; per 64-channel chunk it loads the (TH+2) x (TW+2) input patch ONCE (direct-to-LDS,
+// 128 bytes per pixel) and serves all 9 taps from it by shifting the fragment read address; only the weights stream
+// per tap (3-deep LDS ring, counted vmcnt, raw s_barrier).  Activation traffic drops ~9x and the bytes loaded per
+// FLOP are set by the weight stream alone: BN x 128 B per (BM x BN x 64) MACs.
+//
+// LDS image (both operands are lane-linear global_load_lds fills, so the swizzle sits on the source address):
+//   patch : pixel pp = py*(TW+2) + px at byte pp*128, logical chunk c stored at slot c ^ ((px >> 1) & 7)
+//   weight: row r (output channel) at byte r*128, logical chunk c at slot c ^ ((r >> 1) & 7)
+// Both are conflict-free for the 16-lane groups of ds_read_b128 (for TW = 16 two half-rows complement each other).
+#include "conv_common.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+static __device__ uint4 c3_zero_page[2];     // zero-initialised: source of every out-of-image chunk
+
+struct Conv3Args {
+    const void* X; const void* Wt; void* Out; const void* addend; float* stats;
+    int N, H, W, C;          // input  [N,H,W,C]  (C % 64 == 0)
+    int Cn;                  // output [N,H,W,Cn]
+    int ktot;                // weight row length (9*C)
+    int tiles_x, tiles_y;    // tiles per image
+    int flip;                // 0: tap t reads input (t/3-1, t%3-1); 1 (data gradient): (1-t/3, 1-t%3).  Weight K offset = t*C.
+};                           // (no per-tap tables: a dynamically indexed kernarg array becomes a VMEM load inside the K loop,
+                             //  and the vmcnt wait for it would drain the in-flight LDS-DMA prefetch)
+
+// saddr-form LDS-DMA: per-lane 32-bit byte offset + wave-uniform 64-bit base (no VALU 64-bit address arithmetic)
+__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+
+template <int BM, int TW, int BN, int WM, int WN, int FLIP>
+__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args g) {
+    constexpr int TH = BM / TW, PW = TW + 2, PH = TH + 2;
+    constexpr int NPIX = PH * PW;
+    constexpr int PI = (NPIX + 7) / 8;                 // 1-KiB instructions per patch
+    constexpr int LP = (PI + 3) / 4;                   // per wave
+    constexpr int PATCH_BYTES = LP * 4 * 1024;         // every wave issues exactly LP fills; the tail past NPIX is slack
+    constexpr int IB = BN / 8, LB = IB / 4;            // weight-tile instructions: total / per wave
+    constexpr int BBYTES = BN * 128;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NRING = 3;
+    constexpr int PATCH0 = NRING * BBYTES;             // LDS: [weight ring x3][patch 0][patch 1][stats]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* s_stat = (float*)(smem + PATCH0 + (g.C > 64 ? 2 : 1) * PATCH_BYTES);      // [WM][BN][2]; one patch buffer if one chunk
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WN, wave_n = wave % WN;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, within = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int tiles_n = (g.Cn + BN - 1) / BN;
+    const int tile_sp = logical / tiles_n, tile_n = logical - tile_sp * tiles_n;
+    const int tpi = g.tiles_x * g.tiles_y;
+    const int img = tile_sp / tpi, trem = tile_sp - img * tpi;
+    const int ty0 = (trem / g.tiles_x) * TH, tx0 = (trem % g.tiles_x) * TW;
+    const int n0 = tile_n * BN;
+    const bf16_t* __restrict__ X = (const bf16_t*)g.X;
+    const bf16_t* __restrict__ Wt = (const bf16_t*)g.Wt;
+    const bf16_t* zp = (const bf16_t*)c3_zero_page;
+    const int nchunks = g.C / 64;
+    const unsigned lds0 = lds_addr_of(smem);
+
+    // ---- per-lane load assignment
+    const bf16_t* p_src[LP];                           // chunk-0 source of this lane's patch fills (zero page when outside)
+    bool p_ok[LP];
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+        int ii = wave * LP + j;
+        int pp = ii * 8 + (lane >> 3);
+        int py = pp / PW, px = pp - py * PW;
+        int y = ty0 + py - 1, x = tx0 + px - 1;
+        p_ok[j] = (ii < PI) && (pp < NPIX) && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+        int c = (lane & 7) ^ ((px >> 1) & 7);
+        p_src[j] = p_ok[j] ? X + ((((long)img * g.H + y) * g.W + x) * g.C + c * 8) : zp;
+    }
+    unsigned b_voff[LB];                               // byte offset of this lane's weight-row chunk from the step's base
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        int ii = wave * LB + j;
+        int r = ii * 8 + (lane >> 3);
+        int col = min(n0 + r, g.Cn - 1);               // rows past Cn are loaded from a valid row and never stored
+        b_voff[j] = (unsigned)(((long)col * g.ktot + (((lane & 7) ^ ((r >> 1) & 7)) * 8)) * 2);
+    }
+    // ---- per-lane fragment addresses (LDS byte offsets)
+    const int l32 = lane & 31, fhalf = lane >> 5;
+    unsigned b_rel[TN][4], a_rel[TM][3][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int r = (wave_n * TN + j) * 32 + l32;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) b_rel[j][kk] = lds0 + r * 128 + (((kk * 2 + fhalf) ^ ((r >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int row = (wave_m * TM + i) * 32 + l32;        // row-major over the TH x TW output tile
+        int oy = row / TW, ox = row - oy * TW;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            int px = ox + d;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                a_rel[i][d][kk] = lds0 + PATCH0 + (oy * PW + px) * 128 + (((kk * 2 + fhalf) ^ ((px >> 1) & 7)) << 4);
+        }
+    }
+
+    auto issue_patch = [&](int chunk, int pbuf) {
+#pragma unroll
+        for (int j = 0; j < LP; ++j) {
+            const int ii = wave * LP + j;
+            glds16(p_ok[j] ? (const void*)(p_src[j] + chunk * 64) : (const void*)zp,
+                   __builtin_amdgcn_readfirstlane(lds0 + PATCH0 + pbuf * PATCH_BYTES + ii * 1024));
+        }
+    };
+    auto issue_b = [&](int chunk, int tap, int ring) {  // weights of (chunk, tap) into ring slot `ring`
+        const bf16_t* base = Wt + ((long)tap * g.C + chunk * 64);
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            const int ii = wave * LB + j;
+            glds16_s(b_voff[j], base, __builtin_amdgcn_readfirstlane(lds0 + ring * BBYTES + ii * 1024));
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- software pipeline.  Issue order: P(0) B(0,0) B(0,1) | per step s after its barrier: B(s+2), and at tap 0
+    // of chunk c also P(c+1).  All loads are inline asm (invisible to hipcc's wait counting): the waits below are exact.
+    issue_patch(0, 0);
+    issue_b(0, 0, 0);
+    issue_b(0, 1, 1);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        const unsigned pbase = (chunk & 1) * PATCH_BYTES;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            constexpr int dummy = 0; (void)dummy;
+            // loads issued after B(step): B(step+1) [+ P(chunk+1) for t == 1, 2]
+            const bool last = !more && t == 8;
+            if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if ((t == 1 || t == 2) && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB + LP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 2 < 9) issue_b(chunk, t + 2, (t + 2) % 3);
+            else if (more) issue_b(chunk + 1, t + 2 - 9, (t + 2) % 3);
+            if (t == 0 && more) issue_patch(chunk + 1, (chunk + 1) & 1);
+            const int t3 = t / 3, tr = t % 3;
+            const int dh = FLIP ? 2 - t3 : t3, dw = FLIP ? 2 - tr : tr;     // compile-time per unrolled tap
+            const unsigned aoff = pbase + dh * PW * 128;
+            u32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *(const lds_u32x4*)(a_rel[i][dw][0] + aoff);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = *(const lds_u32x4*)(b_rel[j][0] + (t % 3) * BBYTES);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk < 3) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[(kk + 1) & 1][i] = *(const lds_u32x4*)(a_rel[i][dw][kk + 1] + aoff);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        fb[(kk + 1) & 1][j] = *(const lds_u32x4*)(b_rel[j][kk + 1] + (t % 3) * BBYTES);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kk & 1][i]),
+                                                                           __builtin_bit_cast(bf16x8, fb[kk & 1][j]), acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The tile is transposed through
+    // LDS (free after the K loop) so that HBM sees whole 16-byte vectors / full lines instead of 2-byte scatters.
+    bf16_t* __restrict__ Out = (bf16_t*)g.Out;
+    const bf16_t* __restrict__ Add = (const bf16_t*)g.addend;
+    constexpr int SPITCH = BN * 2 + 16;                   // staging row pitch (bytes): +16 spreads rows over banks
+    float csum[TN], csq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = (wave_m * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int cl = (wave_n * TN + j) * 32 + l32;
+                float v = acc[i][j][r];
+                *(bf16_t*)(smem + row * SPITCH + cl * 2) = f32_to_bf16(v);
+                int yy = ty0 + row / TW, xx = tx0 + row % TW;
+                if (yy < g.H && xx < g.W && n0 + cl < g.Cn) { csum[j] += v; csq[j] += v * v; }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPR = BN / 8;                        // 16-byte chunks per tile row
+        for (int id = tid; id < BM * CPR; id += 256) {
+            int row = id / CPR, c8 = id - row * CPR;
+            int yy = ty0 + row / TW, xx = tx0 + row % TW, col = n0 + c8 * 8;
+            if (yy < g.H && xx < g.W && col < g.Cn) {
+                uint4 v = *(const uint4*)(smem + row * SPITCH + c8 * 16);
+                long o = (((long)img * g.H + yy) * g.W + xx) * g.Cn + col;
+                if (Add) {          // residual-branch gradient: added in f32, rounded once more to bf16
+                    uint4 a = *(const uint4*)(Add + o);
+                    uint32_t vw[4] = {v.x, v.y, v.z, v.w}, aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float lo = __uint_as_float(vw[k] << 16) + __uint_as_float(aw[k] << 16);
+                        float hi = __uint_as_float(vw[k] & 0xffff0000u) + __uint_as_float(aw[k] & 0xffff0000u);
+                        vw[k] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+                    }
+                    v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                }
+                *(uint4*)(Out + o) = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (g.stats) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+            float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+            if (lane < 32) {
+                int cl = (wave_n * TN + j) * 32 + lane;
+                s_stat[(wave_m * BN + cl) * 2] = s;
+                s_stat[(wave_m * BN + cl) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            int col = n0 + c;
+            if (col < g.Cn) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm) { s += s_stat[(wm * BN + c) * 2]; q += s_stat[(wm * BN + c) * 2 + 1]; }
+                g.stats[((long)tile_sp * g.Cn + col) * 2] = s;
+                g.stats[((long)tile_sp * g.Cn + col) * 2 + 1] = q;
+            }
+        }
+    }
+}
+
+template <int BM, int TW, int BN, int WM, int WN>
+static size_t c3_lds(int nchunks) {
+    constexpr int TH = BM / TW, NPIX = (TH + 2) * (TW + 2), PI = (NPIX + 7) / 8, LP = (PI + 3) / 4;
+    size_t need = (size_t)(nchunks > 1 ? 2 : 1) * LP * 4 * 1024 + 3 * BN * 128 + WM * BN * 8;
+    size_t stage = (size_t)BM * (BN * 2 + 16);          // epilogue staging tile
+    return need > stage ? need : stage;
+}
+
+// config choice: 0 = unsupported, 1 = <128,32,64,2,2>, 2 = <256,32,128,2,2>, 3 = <128,16,128,2,2>, 4 = <128,16,64,2,2>
+static int c3_config(int N, int H, int W, int C, int Cn) {
+    if (C % 64 || Cn % 8 || getenv("AB_CONV3_OFF")) return 0;
+    if (W >= 24) return (Cn <= 64) ? 1 : 2;
+    if (W >= 12) return (Cn <= 64) ? 4 : 3;
+    return 0;
+}
+static void c3_geom(int cfg, int* bm, int* tw, int* bn) {
+    if (cfg == 1) { *bm = 128; *tw = 32; *bn = 64; }
+    else if (cfg == 2) { *bm = 256; *tw = 32; *bn = 128; }
+    else if (cfg == 3) { *bm = 128; *tw = 16; *bn = 128; }
+    else { *bm = 128; *tw = 16; *bn = 64; }
+}
+
+// number of BN-partial rows (spatial tiles) this kernel writes; 0 when the shape is not handled here
+int conv3x3_tiles(int N, int H, int W, int C, int Cn) {
+    int cfg = c3_config(N, H, W, C, Cn);
+    if (!cfg) return 0;
+    int bm, tw, bn; c3_geom(cfg, &bm, &tw, &bn);
+    int th = bm / tw;
+    return N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
+}
+
+template <int BM, int TW, int BN, int WM, int WN, int FLIP>
+static int c3_launch(Conv3Args& g, hipStream_t st) {
+    constexpr int TH = BM / TW;
+    g.tiles_x = (g.W + TW - 1) / TW; g.tiles_y = (g.H + TH - 1) / TH;
+    int blocks = g.N * g.tiles_x * g.tiles_y * ((g.Cn + BN - 1) / BN);
+    size_t lds = c3_lds<BM, TW, BN, WM, WN>(g.C / 64);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<BM, TW, BN, WM, WN, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)c3_lds<BM, TW, BN, WM, WN>(2));
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    conv3x3_kernel<BM, TW, BN, WM, WN, FLIP><<<blocks, 256, lds, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// x [N,H,W,C] -> out [N,H,W,Cn]; wt rows of length 9*C; flip = 0: forward weights OHWI, taps (kh-1, kw-1);
+// flip = 1: data gradient with IHWO weights, taps (1-kh, 1-kw).  Returns AB_ESHAPE when unsupported.
+int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, int C, int Cn, int flip,
+                const void* addend, float* stats, hipStream_t st) {
+    int cfg = c3_config(N, H, W, C, Cn);
+    if (!cfg) return AB_ESHAPE;
+    Conv3Args g = {};
+    g.X = x; g.Wt = wt; g.Out = out; g.addend = addend; g.stats = stats;
+    g.N = N; g.H = H; g.W = W; g.C = C; g.Cn = Cn; g.ktot = 9 * C;
+    g.flip = flip;
+    if (flip) {
+        if (cfg == 1) return c3_launch<128, 32, 64, 2, 2, 1>(g, st);
+        if (cfg == 2) return c3_launch<256, 32, 128, 2, 2, 1>(g, st);
+        if (cfg == 3) return c3_launch<128, 16, 128, 2, 2, 1>(g, st);
+        return c3_launch<128, 16, 64, 2, 2, 1>(g, st);
+    }
+    if (cfg == 1) return c3_launch<128, 32, 64, 2, 2, 0>(g, st);
+    if (cfg == 2) return c3_launch<256, 32, 128, 2, 2, 0>(g, st);
+    if (cfg == 3) return c3_launch<128, 16, 128, 2, 2, 0>(g, st);
+    return c3_launch<128, 16, 64, 2, 2, 0>(g, st);
+}

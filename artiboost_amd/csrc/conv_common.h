@@ -1,0 +1,44 @@
+// Shared by conv_gemm.hip (register-staged, any dtype) and conv_gemm2.hip (direct-to-LDS bf16 fast path).
+#pragma once
+#include "common.h"
+
+#define CG_MAXTAPS 16
+
+struct ConvGemmArgs {
+    const void* A; const void* Bw; void* Out;
+    const float* bias; const void* addend; float* stats;   // stats: [gridM][Cn][2]
+    int N, Ha, Wa, Ca;          // A tensor dims (Ca = channel pitch in elements)
+    int P, Q;                   // output sub-grid
+    int Ho, Wo, Cn;             // full output tensor dims
+    int out_sh, out_sw, out_oh, out_ow;
+    int a_sh, a_sw;
+    int ntaps, cpt;             // cpt = K-steps per tap (Ca / BK, or 1 for the padded stem rows)
+    int ktot;                   // Bw row length in elements
+    int M;
+    int relu;                   // apply ReLU in the epilogue (linear layers)
+    int8_t dh[CG_MAXTAPS], dw[CG_MAXTAPS];
+    int koff[CG_MAXTAPS];
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// K bytes per step: 128 (64 bf16) on the fast path -- full 128-byte rows per pixel keep the gather on whole cache
+// lines and put 16 MFMAs between barriers; 64 (16 f32) on the exact parity path.  LDS row pitch = KB + 16 bytes:
+// 16 consecutive rows then land on 16 distinct 16-byte slots (conflict-free ds_read_b128 / ds_write_b128).
+
+// Direct-to-LDS 16-byte load (1 KiB per wave instruction: LDS destination = wave-uniform base + lane*16).
+// Issued as inline asm on purpose: hipcc treats a __builtin_amdgcn_global_load_lds as an LDS store that may alias every
+// later ds_read and drains vmcnt to 0 before the first fragment read of each K step (seen in the ISA), which destroys
+// the multi-step prefetch.  As asm the load is invisible to the compiler's wait-count bookkeeping; the kernels place
+// their own counted s_waitcnt vmcnt(N) + s_barrier (cdna_hip_programming.md section 5.7).  M0 is saved/restored.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_byte_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+int conv_gemm2_run(ConvGemmArgs& g, hipStream_t st);     // conv_gemm2.hip; returns AB_ESHAPE when the shape is unsupported

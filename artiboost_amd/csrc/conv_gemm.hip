@@ -10,32 +10,9 @@
 // v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact f32 path used by the parity tests).
 // Epilogue: optional bias, optional addend (residual gradient), optional per-column (sum, sum^2) partials for the
 // following training-mode BatchNorm (deterministic: one partial row per M-tile, reduced by bn_finalize).
-#include "common.h"
+#include <stdlib.h>
+#include "conv_common.h"
 
-#define CG_MAXTAPS 16
-
-struct ConvGemmArgs {
-    const void* A; const void* Bw; void* Out;
-    const float* bias; const void* addend; float* stats;   // stats: [gridM][Cn][2]
-    int N, Ha, Wa, Ca;          // A tensor dims (Ca = channel pitch in elements)
-    int P, Q;                   // output sub-grid
-    int Ho, Wo, Cn;             // full output tensor dims
-    int out_sh, out_sw, out_oh, out_ow;
-    int a_sh, a_sw;
-    int ntaps, cpt;             // cpt = K-steps per tap (Ca / BK, or 1 for the padded stem rows)
-    int ktot;                   // Bw row length in elements
-    int M;
-    int relu;                   // apply ReLU in the epilogue (linear layers)
-    int8_t dh[CG_MAXTAPS], dw[CG_MAXTAPS];
-    int koff[CG_MAXTAPS];
-};
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// K bytes per step: 128 (64 bf16) on the fast path -- full 128-byte rows per pixel keep the gather on whole cache
-// lines and put 16 MFMAs between barriers; 64 (16 f32) on the exact parity path.  LDS row pitch = KB + 16 bytes:
-// 16 consecutive rows then land on 16 distinct 16-byte slots (conflict-free ds_read_b128 / ds_write_b128).
 // (template parameter KB; the 7x7 stem keeps 64-byte steps because one kernel row of the NHWC4 image is 32 elements)
 
 template <typename T>
@@ -235,12 +212,32 @@ static void pick_tile(int M, int Cn, int* bm, int* bn) {
     if (tiles < 512 && *bn == 128) { *bn = 64; }
 }
 
-extern "C" int ab_conv_gemm_mtiles(int M, int Cn) {
-    int bm, bn; pick_tile(M, Cn, &bm, &bn);
+int conv_gemm2_mtiles(int M, int Cn);
+int conv3x3_tiles(int N, int H, int W, int C, int Cn);
+int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, int C, int Cn, int flip,
+                const void* addend, float* stats, hipStream_t st);
+static bool use_v2(int dtype, bool stem, int Ca) { return dtype == AB_DT_BF16 && !stem && Ca % 64 == 0 && !getenv("AB_CONV_V1"); }
+
+static bool use_c3(int dtype, int kh, int kw, int stride, int pad) {
+    return dtype == AB_DT_BF16 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && !getenv("AB_CONV_V1");
+}
+
+// number of BN-partial rows ab_conv2d_fwd / ab_conv2d_stem_fwd (stem != 0) write into `stats` for this problem
+extern "C" int ab_conv2d_stat_rows(int dtype, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride,
+                                   int pad, int stem) {
+    const int Ho = stem ? H / 2 : (H + 2 * pad - kh) / stride + 1, Wo = stem ? W / 2 : (W + 2 * pad - kw) / stride + 1;
+    const int M = N * Ho * Wo;
+    if (!stem && use_c3(dtype, kh, kw, stride, pad)) { int t = conv3x3_tiles(N, H, W, Cin, Cout); if (t) return t; }
+    if (use_v2(dtype, stem != 0, stem ? 0 : Cin)) return conv_gemm2_mtiles(M, Cout);
+    int bm, bn; pick_tile(M, Cout, &bm, &bn);
     return (M + bm - 1) / bm;
 }
 
 static int run(ConvGemmArgs& g, int dtype, hipStream_t st, bool stem = false) {
+    if (use_v2(dtype, stem, g.Ca)) {
+        int rc = conv_gemm2_run(g, st);
+        if (rc != AB_ESHAPE) return rc;
+    }
     int bm, bn; pick_tile(g.M, g.Cn, &bm, &bn);
     if (dtype == AB_DT_BF16) return stem ? launch_conv_gemm<bf16_t, 64>(g, bm, bn, st) : launch_conv_gemm<bf16_t, 128>(g, bm, bn, st);
     if (dtype == AB_DT_F32) return launch_conv_gemm<float, 64>(g, bm, bn, st);
@@ -254,6 +251,10 @@ extern "C" int ab_conv2d_fwd(const void* x, const void* w, void* y, int dtype, i
                              void* stream) {
     if (!x || !w || !y) return AB_EINVAL;
     if (kh * kw > CG_MAXTAPS || Cin % bk_of(dtype)) return AB_ESHAPE;
+    if (use_c3(dtype, kh, kw, stride, pad) && !bias && !relu) {
+        int rc = conv3x3_run(x, w, y, N, H, W, Cin, Cout, 0, nullptr, stats, as_stream(stream));
+        if (rc != AB_ESHAPE) return rc;
+    }
     ConvGemmArgs g = {};
     g.A = x; g.Bw = w; g.Out = y; g.bias = bias; g.stats = stats; g.relu = relu;
     g.N = N; g.Ha = H; g.Wa = W; g.Ca = Cin;
@@ -296,7 +297,11 @@ extern "C" int ab_conv2d_dgrad(const void* dy, const void* wt, void* dx, int dty
     if (Cout % bk_of(dtype) || (stride != 1 && stride != 2)) return AB_ESHAPE;
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (stride == 2 && ((H & 1) || (W & 1))) return AB_ESHAPE;
-    if (stats && stride != 1) return AB_ESHAPE;   // BN partials are per M-tile of ONE launch
+    if (stats) return AB_ESHAPE;                  // BN partials of a data-gradient output: use ab_col_stats
+    if (use_c3(dtype, kh, kw, stride, pad)) {
+        int rc = conv3x3_run(dy, wt, dx, N, H, W, Cout, Cin, 1, addend, nullptr, as_stream(stream));
+        if (rc != AB_ESHAPE) return rc;
+    }
     for (int a = 0; a < stride; ++a) for (int b = 0; b < stride; ++b) {
         ConvGemmArgs g = {};
         g.A = dy; g.Bw = wt; g.Out = dx; g.addend = addend; g.stats = stats;

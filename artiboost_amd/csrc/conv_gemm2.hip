@@ -1,0 +1,238 @@
+// Implicit-GEMM convolution, bf16 fast path: direct-to-LDS loads (global_load_lds_dwordx4), no VGPR staging.
+//
+// Same contract as conv_gemm_kernel (conv_common.h), specialised for the benchmark path:
+//   * every K step moves 128 bytes (64 bf16 channels of one tap) per tile row straight from L2/HBM into LDS with
+//     global_load_lds; a wave instruction fills 1 KiB = 8 rows x 8 chunks, lane-linear, so the bank-conflict
+//     swizzle is applied on the SOURCE side: LDS slot (row r, slot c') holds logical chunk c = c' ^ ((r >> 1) & 7),
+//     and the MFMA fragment reads apply the same involution (conflict-free ds_read_b128 for any 16 distinct rows
+//     mod 16);
+//   * rows that fall outside the image (padding taps, ragged M / N tails) read a 16-byte zero page instead of
+//     branching, so the load stream is uniform;
+//   * workgroups are renumbered so that each XCD (block id mod 8) owns a contiguous range of M tiles: neighbouring
+//     tiles re-read each other's halo pixels and the 9 taps re-read the same rows from that XCD's L2;
+//   * two LDS buffers; the loads of step s+1 are issued before the 16*TM*TN/4 MFMAs of step s and drained at the barrier.
+#include "conv_common.h"
+
+__device__ uint4 ab_zero_page[2];    // zero-initialised device memory: source of every out-of-range chunk
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;     // 32x32 MFMA tiles per wave
+    constexpr int IA = BM / 8, IB = BN / 8;                 // 1-KiB load instructions (8 rows each) for the A / B tile
+    constexpr int BUFSZ = (BM + BN) * 128;
+    constexpr int NBUF = 3;                                  // LDS ring: loads run two K-steps ahead of the MFMAs
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUFSZ + BM * 4 + WM * BN * 8 + 3 * CG_MAXTAPS * 4];
+    int* s_outpix = (int*)(smem + NBUF * BUFSZ);
+    float* s_stat = (float*)(s_outpix + BM);                // [WM][BN][2]
+    // tap tables copied to LDS: indexing the kernarg arrays with the runtime tap id compiles to VMEM loads inside the K
+    // loop, and the vmcnt wait for those would drain the in-flight LDS-DMA prefetch
+    int* s_tap = (int*)(s_stat + WM * BN * 2);              // [3][CG_MAXTAPS] = dh, dw, koff
+    if (threadIdx.x < CG_MAXTAPS) {
+        s_tap[threadIdx.x] = g.dh[threadIdx.x];
+        s_tap[CG_MAXTAPS + threadIdx.x] = g.dw[threadIdx.x];
+        s_tap[2 * CG_MAXTAPS + threadIdx.x] = g.koff[threadIdx.x];
+    }
+    __syncthreads();
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WN, wave_n = wave % WN;
+    // XCD-aware renumbering (bijective for any grid size): XCD x = bid % 8 gets logical ids [start_x, start_x + cnt_x)
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, within = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
+    const int tiles_n = (g.Cn + BN - 1) / BN;
+    const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
+    const bf16_t* __restrict__ Bw = (const bf16_t*)g.Bw;
+    const int PQ = g.P * g.Q;
+    const bf16_t* zp = (const bf16_t*)ab_zero_page;
+
+    // ---- per-lane load assignment: instruction ii (0..IA-1 over the 4 waves) covers rows ii*8 .. ii*8+7
+    const int lrow = lane >> 3, lslot = lane & 7;
+    constexpr int NA = IA / 4, NB = IB / 4;                 // per wave
+    int a_h[NA], a_w[NA], a_chunk[NA]; long a_base[NA]; bool a_ok[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int ii = wave * NA + j;
+        int r = ii * 8 + lrow;
+        int m = m0 + r;
+        a_ok[j] = (ii < IA) && (m < g.M);
+        int mm = a_ok[j] ? m : 0;
+        int n = mm / PQ, rem = mm - n * PQ;
+        int p = rem / g.Q, q = rem - p * g.Q;
+        a_h[j] = p * g.a_sh; a_w[j] = q * g.a_sw;
+        a_base[j] = (long)n * g.Ha * g.Wa;
+        a_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;      // element offset of the logical chunk this lane fetches
+        if (lslot == 0 && ii < IA) {
+            int op = (n * g.Ho + p * g.out_sh + g.out_oh) * g.Wo + q * g.out_sw + g.out_ow;
+            s_outpix[r] = a_ok[j] ? op : -1;
+        }
+    }
+    long b_off[NB]; int b_chunk[NB]; bool b_ok[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int ii = wave * NB + j;
+        int r = ii * 8 + lrow;
+        int col = n0 + r;
+        b_ok[j] = (ii < IB) && (col < g.Cn);
+        b_off[j] = (long)(b_ok[j] ? col : 0) * g.ktot;
+        b_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;
+    }
+    const int nsteps = g.ntaps * g.cpt;
+
+    auto issue = [&](int step, int buf) {
+        const int t = step / g.cpt, c0 = (step - t * g.cpt) * 64;
+        const int dh = s_tap[t], dw = s_tap[CG_MAXTAPS + t], ko = s_tap[2 * CG_MAXTAPS + t];
+        unsigned char* base = smem + buf * BUFSZ;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int ii = wave * NA + j;
+            if (ii < IA) {
+                int hi = a_h[j] + dh, wi = a_w[j] + dw;
+                bool ok = a_ok[j] && (unsigned)hi < (unsigned)g.Ha && (unsigned)wi < (unsigned)g.Wa;
+                const bf16_t* src = ok ? (A + ((a_base[j] + (long)hi * g.Wa + wi) * g.Ca + c0 + a_chunk[j])) : zp;
+                glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(base + ii * 1024)));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int ii = wave * NB + j;
+            if (ii < IB) {
+                const bf16_t* src = b_ok[j] ? (Bw + (b_off[j] + ko + c0 + b_chunk[j])) : zp;
+                glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(base + BM * 128 + ii * 1024)));
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // 3-deep ring with counted waits (raw s_barrier: __syncthreads() would drain vmcnt to 0 and kill the overlap):
+    //   step s:  wait until only step s+1's loads are in flight -> barrier (step-s tile visible to all waves, and all
+    //            waves are done reading the buffer of step s-1) -> issue step s+2 into that buffer -> MFMAs of step s
+    constexpr int L = NA + NB;                               // load instructions per wave per step
+    issue(0, 0);
+    if (nsteps > 1) issue(1, 1);
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int cur = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (step + 2 < nsteps) { int nb = cur + 2; if (nb >= NBUF) nb -= NBUF; issue(step + 2, nb); }
+        const unsigned char* sa = smem + cur * BUFSZ;
+        const unsigned char* sb = sa + BM * 128;
+        auto read_frags = [&](int kk, uint4* fa, uint4* fb) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int r = (wave_m * TM + i) * 32 + frow;
+                fa[i] = *(const uint4*)(sa + r * 128 + (((kk * 2 + fhalf) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int r = (wave_n * TN + j) * 32 + frow;
+                fb[j] = *(const uint4*)(sb + r * 128 + (((kk * 2 + fhalf) ^ ((r >> 1) & 7)) << 4));
+            }
+        };
+        // software-pipelined fragments: the ds_reads of k-slice kk+1 are in flight while the MFMAs of kk issue
+        uint4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        read_frags(0, fa0, fb0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            uint4* fa = (kk & 1) ? fa1 : fa0; uint4* fb = (kk & 1) ? fb1 : fb0;
+            if (kk < 3) read_frags(kk + 1, (kk & 1) ? fa0 : fa1, (kk & 1) ? fb0 : fb1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                       __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
+        }
+        if (++cur == NBUF) cur = 0;
+    }
+    __syncthreads();
+
+    // ---- epilogue (as conv_gemm_kernel)
+    bf16_t* __restrict__ Out = (bf16_t*)g.Out;
+    const bf16_t* __restrict__ Add = (const bf16_t*)g.addend;
+    float csum[TN], csq[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wave_n * TN + j) * 32 + (lane & 31);
+        const bool cok = col < g.Cn;
+        const float bj = (g.bias && cok) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = (wave_m * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                int op = s_outpix[row];
+                float v = acc[i][j][r] + bj;
+                if (op >= 0 && cok) {
+                    long o = (long)op * g.Cn + col;
+                    if (Add) v += bf16_to_f32(Add[o]);
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    Out[o] = f32_to_bf16(v);
+                    csum[j] += v; csq[j] += v * v;
+                }
+            }
+        }
+    }
+    if (g.stats) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+            float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+            if (lane < 32) {
+                int cl = (wave_n * TN + j) * 32 + lane;
+                s_stat[(wave_m * BN + cl) * 2] = s;
+                s_stat[(wave_m * BN + cl) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            int col = n0 + c;
+            if (col < g.Cn) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm) { s += s_stat[(wm * BN + c) * 2]; q += s_stat[(wm * BN + c) * 2 + 1]; }
+                g.stats[((long)tile_m * g.Cn + col) * 2] = s;
+                g.stats[((long)tile_m * g.Cn + col) * 2 + 1] = q;
+            }
+        }
+    }
+}
+
+static void pick_tile2(int M, int Cn, int* bm, int* bn) {
+    *bn = (Cn > 64) ? 128 : 64;
+    *bm = 128;
+    long tiles = (long)((M + 127) / 128) * ((Cn + *bn - 1) / *bn);
+    if (tiles < 1024) { *bm = 64; }      // keep >= 2 workgroups per CU in flight
+}
+
+int conv_gemm2_mtiles(int M, int Cn) {
+    int bm, bn; pick_tile2(M, Cn, &bm, &bn);
+    return (M + bm - 1) / bm;
+}
+
+int conv_gemm2_run(ConvGemmArgs& g, hipStream_t st) {
+    if (g.Ca % 64) return AB_ESHAPE;
+    int bm, bn; pick_tile2(g.M, g.Cn, &bm, &bn);
+    int tiles = ((g.M + bm - 1) / bm) * ((g.Cn + bn - 1) / bn);
+    if (bm == 256 && bn == 64) conv_gemm2_kernel<256, 64, 4, 1><<<tiles, 256, 0, st>>>(g);
+    else if (bm == 128 && bn == 128) conv_gemm2_kernel<128, 128, 2, 2><<<tiles, 256, 0, st>>>(g);
+    else if (bm == 128 && bn == 64) conv_gemm2_kernel<128, 64, 2, 2><<<tiles, 256, 0, st>>>(g);
+    else if (bm == 64 && bn == 128) conv_gemm2_kernel<64, 128, 2, 2><<<tiles, 256, 0, st>>>(g);
+    else conv_gemm2_kernel<64, 64, 2, 2><<<tiles, 256, 0, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

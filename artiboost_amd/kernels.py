@@ -22,7 +22,7 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, want_stats=False, relu=False):
     lib = L.lib()
     stats = None
     if want_stats:
-        nt = lib.ab_conv_gemm_mtiles(L.i(N * Ho * Wo), L.i(Cout))
+        nt = lib.ab_conv2d_stat_rows(L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.i(0))
         stats = torch.empty((nt, Cout, 2), dtype=torch.float32, device=x.device)
     L.check(lib.ab_conv2d_fwd(L.ptr(x), L.ptr(w_ohwi), L.ptr(y), L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(Cin),
                               L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(bias), L.ptr(stats),
@@ -38,28 +38,23 @@ def conv2d_stem_fwd(xpad, w_stem, H, W, want_stats=False):
     lib = L.lib()
     stats = None
     if want_stats:
-        nt = lib.ab_conv_gemm_mtiles(L.i(N * (H // 2) * (W // 2)), L.i(Cout))
+        nt = lib.ab_conv2d_stat_rows(L.i(L.dt(xpad)), L.i(N), L.i(H), L.i(W), L.i(4), L.i(Cout), L.i(7), L.i(7), L.i(2), L.i(3), L.i(1))
         stats = torch.empty((nt, Cout, 2), dtype=torch.float32, device=xpad.device)
     L.check(lib.ab_conv2d_stem_fwd(L.ptr(xpad), L.ptr(w_stem), L.ptr(y), L.i(L.dt(xpad)), L.i(N), L.i(H), L.i(W),
                                    L.i(Cout), L.ptr(stats), L.stream()), "ab_conv2d_stem_fwd")
     return (y, stats) if want_stats else y
 
 
-def conv2d_dgrad(dy, w_ihwo, in_hw, stride, pad, addend=None, want_stats=False):
+def conv2d_dgrad(dy, w_ihwo, in_hw, stride, pad, addend=None):
     """dy [N,Ho,Wo,Cout], w [Cin,kh,kw,Cout] -> dx [N,H,W,Cin]  (== ConvTranspose2d forward when x:=dy)."""
     N, Ho, Wo, Cout = dy.shape
     Cin, kh, kw, _ = w_ihwo.shape
     H, W = in_hw
     dx = _empty((N, H, W, Cin), dy)
-    lib = L.lib()
-    stats = None
-    if want_stats:
-        nt = lib.ab_conv_gemm_mtiles(L.i(N * H * W), L.i(Cin))
-        stats = torch.empty((nt, Cin, 2), dtype=torch.float32, device=dy.device)
-    L.check(lib.ab_conv2d_dgrad(L.ptr(dy), L.ptr(w_ihwo), L.ptr(dx), L.i(L.dt(dy)), L.i(N), L.i(H), L.i(W), L.i(Cin),
-                                L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(addend), L.ptr(stats),
-                                L.stream()), "ab_conv2d_dgrad")
-    return (dx, stats) if want_stats else dx
+    L.check(L.lib().ab_conv2d_dgrad(L.ptr(dy), L.ptr(w_ihwo), L.ptr(dx), L.i(L.dt(dy)), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                    L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(addend), L.ptr(None),
+                                    L.stream()), "ab_conv2d_dgrad")
+    return dx
 
 
 _ws = {}

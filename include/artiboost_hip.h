@@ -53,16 +53,16 @@ int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, int D, int 
  *   anakin/models/mlp.py:15-22 (Linear + ReLU)
  * Layouts: activations NHWC; weights "OHWI" = [Cout][kh][kw][Cin] (K-contiguous) in the activation dtype;
  * data-gradient weights "IHWO" = [Cin][kh][kw][Cout].  Cin (fwd) / Cout (dgrad) must be a multiple of 32 (bf16)
- * or 16 (f32).  stats (optional): float [ab_conv_gemm_mtiles(M, Cout)][Cout][2] per-tile (sum, sum^2) partials of
+ * or 16 (f32).  stats (optional): float [ab_conv2d_stat_rows(...)][Cout][2] per-tile (sum, sum^2) partials of
  * the OUTPUT for the following training-mode BatchNorm (finalised by ab_bn_finalize).                           */
-int ab_conv_gemm_mtiles(int M, int Cn);
+int ab_conv2d_stat_rows(int dtype, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, int stem);
 int ab_conv2d_fwd(const void* x, const void* w, void* y, int dtype, int N, int H, int W, int Cin, int Cout,
                   int kh, int kw, int stride, int pad, const float* bias, float* stats, int relu, void* stream);
 /* stem 7x7/2 pad 3 on a zero-bordered NHWC4 image [N, H+6, W+8, 4] (see ab_image_pad_nhwc4); w [Cout][7][8][4]  */
 int ab_conv2d_stem_fwd(const void* xpad, const void* w, void* y, int dtype, int N, int H, int W, int Cout,
                        float* stats, void* stream);
 /* dx of conv2d(x,w,stride,pad) (also == ConvTranspose2d forward).  H,W,Cin describe dx.  addend (optional, dx-shaped)
- * is added in the epilogue.  stats only for stride 1.                                                          */
+ * is added in the epilogue.  stats must be NULL.                                                                 */
 int ab_conv2d_dgrad(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int Cin, int Cout,
                     int kh, int kw, int stride, int pad, const void* addend, float* stats, void* stream);
 /* dw (float, OHWI) of conv2d; workspace of ab_conv2d_wgrad_workspace(N*Ho*Wo, Cout, kh*kw*Cin) bytes           */

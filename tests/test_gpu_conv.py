@@ -39,6 +39,10 @@ CONV_CASES = [
     (2, 9, 5, 256, 616, 1, 1, 0),     # final layer: ragged N (616), ragged M, with bias
     (5, 6, 6, 256, 256, 3, 1, 1),
     (2, 8, 8, 256, 512, 4, 2, 1),     # == ConvTranspose backward-data shape
+    (2, 32, 32, 64, 64, 3, 1, 1),     # LDS-halo 3x3 kernel, 4x32 tiles, single chunk
+    (1, 28, 28, 128, 128, 3, 1, 1),   # LDS-halo, ragged 8x32 tiles (224-geometry layer2), 2 chunks
+    (3, 14, 14, 256, 256, 3, 1, 1),   # LDS-halo, ragged 8x16 tiles (224-geometry layer3), 4 chunks
+    (2, 56, 40, 64, 64, 3, 1, 1),     # LDS-halo, ragged in both directions
 ]
 
 
@@ -91,7 +95,7 @@ def test_stem_fwd_wgrad(nhw, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("case", CONV_CASES[:7])
+@pytest.mark.parametrize("case", CONV_CASES[:7] + CONV_CASES[8:])
 def test_conv_dgrad_wgrad(case, dtype):
     from artiboost_amd import kernels as K
     N, H, W, Cin, Cout, k, s, p = case
