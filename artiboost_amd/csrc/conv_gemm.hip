@@ -212,7 +212,7 @@ static void pick_tile(int M, int Cn, int* bm, int* bn) {
     if (tiles < 512 && *bn == 128) { *bn = 64; }
 }
 
-int conv_gemm2_mtiles(int M, int Cn);
+int conv_gemm2_mtiles(int M, int Cn, int nsteps);
 int conv3x3_tiles(int N, int H, int W, int C, int Cn);
 int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, int C, int Cn, int flip,
                 const void* addend, float* stats, hipStream_t st);
@@ -228,7 +228,7 @@ extern "C" int ab_conv2d_stat_rows(int dtype, int N, int H, int W, int Cin, int 
     const int Ho = stem ? H / 2 : (H + 2 * pad - kh) / stride + 1, Wo = stem ? W / 2 : (W + 2 * pad - kw) / stride + 1;
     const int M = N * Ho * Wo;
     if (!stem && use_c3(dtype, kh, kw, stride, pad)) { int t = conv3x3_tiles(N, H, W, Cin, Cout); if (t) return t; }
-    if (use_v2(dtype, stem != 0, stem ? 0 : Cin)) return conv_gemm2_mtiles(M, Cout);
+    if (use_v2(dtype, stem != 0, stem ? 0 : Cin)) return conv_gemm2_mtiles(M, Cout, kh * kw * (Cin / 64));
     int bm, bn; pick_tile(M, Cout, &bm, &bn);
     return (M + bm - 1) / bm;
 }

@@ -159,15 +159,19 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
     }
     __syncthreads();
 
-    // ---- epilogue (as conv_gemm_kernel)
+    // ---- epilogue: bias / ReLU / BN partials from the f32 accumulators, then the bf16 tile is transposed through LDS
+    // (free after the K loop) and written with 16-byte vectors (the residual-gradient addend is folded in there).
     bf16_t* __restrict__ Out = (bf16_t*)g.Out;
     const bf16_t* __restrict__ Add = (const bf16_t*)g.addend;
+    constexpr int SPITCH = BN * 2 + 16;
+    static_assert(BM * SPITCH <= NBUF * BUFSZ, "staging tile must fit in the K-loop buffers");
     float csum[TN], csq[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wave_n * TN + j) * 32 + (lane & 31);
+        const int cl = (wave_n * TN + j) * 32 + (lane & 31);
+        const int col = n0 + cl;
         const bool cok = col < g.Cn;
         const float bj = (g.bias && cok) ? g.bias[col] : 0.f;
 #pragma unroll
@@ -175,18 +179,47 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int row = (wave_m * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                int op = s_outpix[row];
                 float v = acc[i][j][r] + bj;
-                if (op >= 0 && cok) {
-                    long o = (long)op * g.Cn + col;
-                    if (Add) v += bf16_to_f32(Add[o]);
-                    if (g.relu) v = fmaxf(v, 0.f);
-                    Out[o] = f32_to_bf16(v);
-                    csum[j] += v; csq[j] += v * v;
+                if (g.relu) v = fmaxf(v, 0.f);
+                *(bf16_t*)(smem + row * SPITCH + cl * 2) = f32_to_bf16(v);
+                if (cok && s_outpix[row] >= 0) { csum[j] += v; csq[j] += v * v; }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CPR = BN / 8;
+        const bool vec_ok = (g.Cn & 7) == 0;
+        for (int id = tid; id < BM * CPR; id += 256) {
+            int row = id / CPR, c8 = id - row * CPR;
+            int op = s_outpix[row], col = n0 + c8 * 8;
+            if (op < 0 || col >= g.Cn) continue;
+            long o = (long)op * g.Cn + col;
+            uint4 v = *(const uint4*)(smem + row * SPITCH + c8 * 16);
+            if (vec_ok) {
+                if (Add) {
+                    uint4 a = *(const uint4*)(Add + o);
+                    uint32_t vw[4] = {v.x, v.y, v.z, v.w}, aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float lo = __uint_as_float(vw[k] << 16) + __uint_as_float(aw[k] << 16);
+                        float hi = __uint_as_float(vw[k] & 0xffff0000u) + __uint_as_float(aw[k] & 0xffff0000u);
+                        vw[k] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+                    }
+                    v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                }
+                *(uint4*)(Out + o) = v;
+            } else {      // ragged channel count: element-wise tail
+                const bf16_t* sv = (const bf16_t*)(smem + row * SPITCH + c8 * 16);
+                for (int k = 0; k < 8 && col + k < g.Cn; ++k) {
+                    float x = bf16_to_f32(sv[k]);
+                    if (Add) x += bf16_to_f32(Add[o + k]);
+                    Out[o + k] = f32_to_bf16(x);
                 }
             }
         }
     }
+    __syncthreads();
     if (g.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -212,21 +245,24 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
     }
 }
 
-static void pick_tile2(int M, int Cn, int* bm, int* bn) {
+static void pick_tile2(int M, int Cn, int nsteps, int* bm, int* bn) {
     *bn = (Cn > 64) ? 128 : 64;
     *bm = 128;
     long tiles = (long)((M + 127) / 128) * ((Cn + *bn - 1) / *bn);
     if (tiles < 1024) { *bm = 64; }      // keep >= 2 workgroups per CU in flight
+    // short K loops (1x1 convs): the fill / drain of a workgroup is not amortised, so favour LDS footprints that let
+    // 2-3 workgroups share a CU and overlap each other's prologue and epilogue
+    if (nsteps <= 8) { *bm = 64; }
 }
 
-int conv_gemm2_mtiles(int M, int Cn) {
-    int bm, bn; pick_tile2(M, Cn, &bm, &bn);
+int conv_gemm2_mtiles(int M, int Cn, int nsteps) {
+    int bm, bn; pick_tile2(M, Cn, nsteps, &bm, &bn);
     return (M + bm - 1) / bm;
 }
 
 int conv_gemm2_run(ConvGemmArgs& g, hipStream_t st) {
     if (g.Ca % 64) return AB_ESHAPE;
-    int bm, bn; pick_tile2(g.M, g.Cn, &bm, &bn);
+    int bm, bn; pick_tile2(g.M, g.Cn, g.ntaps * g.cpt, &bm, &bn);
     int tiles = ((g.M + bm - 1) / bm) * ((g.Cn + bn - 1) / bn);
     if (bm == 256 && bn == 64) conv_gemm2_kernel<256, 64, 4, 1><<<tiles, 256, 0, st>>>(g);
     else if (bm == 128 && bn == 128) conv_gemm2_kernel<128, 128, 2, 2><<<tiles, 256, 0, st>>>(g);
