@@ -173,19 +173,44 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
             }
 }
 
-// dW[e] (+)= sum_s slabs[s][e]; optionally drops padded taps: dst row layout [Cout][dst_j], src [Cout][src_j]
-__global__ void wgrad_reduce(const float* __restrict__ slabs, int nslices, long slab_elems, int src_j, int dst_j,
-                             float* __restrict__ dst, int accumulate, int stem_mask) {
-    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    long total = (slab_elems / src_j) * dst_j;
-    if (e >= total) return;
-    long row = e / dst_j; int col = (int)(e - row * dst_j);
-    long se = row * src_j + col;
-    float s = 0.f;
-    for (int k = 0; k < nslices; ++k) s += slabs[(long)k * slab_elems + se];
-    if (stem_mask && ((col & 31) >= 28 || (col & 3) == 3)) s = 0.f;   // padding taps of the [7][8][4] stem layout
-    dst[e] = accumulate ? dst[e] + s : s;
+// dW[e] (+)= sum_s slabs[s][e]; optionally drops padded taps: dst row layout [Cout][dst_j], src [Cout][src_j].
+// 16 element quads x 16 slice lanes per workgroup: lane ky sums slices ky, ky+16, ... in order, the 16 partials are then
+// combined in fixed order through LDS (deterministic; every load is a 16-byte vector, 256 contiguous bytes per row).
+__global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ slabs, int nslices, long slab_elems, int src_j,
+                                                    int dst_j, float* __restrict__ dst, int accumulate, int stem_mask) {
+    __shared__ float4 part[16][17];
+    const int qx = threadIdx.x & 15, ky = threadIdx.x >> 4;
+    const long quad = (long)blockIdx.x * 16 + qx;
+    const long total = (slab_elems / src_j) * dst_j;
+    const long e = quad * 4;
+    const bool live = e < total;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    long row = 0; int col = 0;
+    if (live) {
+        row = e / dst_j; col = (int)(e - row * dst_j);
+        const float* src = slabs + row * src_j + col;
+        for (int k = ky; k < nslices; k += 16) {
+            float4 v = *(const float4*)(src + (long)k * slab_elems);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    part[ky][qx] = s;
+    __syncthreads();
+    if (ky == 0 && live) {
+        float4 t = part[0][qx];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { float4 v = part[k][qx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        if (stem_mask) {                                      // padding taps of the [7][8][4] stem layout
+            if ((col & 31) >= 28) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            t.w = 0.f;
+        }
+        float4* d = (float4*)(dst + e);
+        if (accumulate) { float4 o = *d; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        *d = t;
+    }
 }
+
+static inline unsigned wgrad_reduce_blocks(long total) { return (unsigned)((total / 4 + 15) / 16); }
 
 static void pick_wgrad(int M, int Cout, int jtot, int* bi, int* bj, int* nslices, int* rows) {
     *bi = (Cout % 128 == 0) ? 128 : 64;
@@ -198,9 +223,18 @@ static void pick_wgrad(int M, int Cout, int jtot, int* bi, int* bj, int* nslices
     *nslices = (M + r - 1) / r; *rows = r;
 }
 
+int wgrad3x3_slices(int N, int H, int W, int Cin, int Cout);
+int wgrad3x3_run(const void* x, const void* dy, float* slabs, int N, int H, int W, int Cin, int Cout, hipStream_t st);
+
 extern "C" long ab_conv2d_wgrad_workspace(int M, int Cout, int jtot) {
     int bi, bj, ns, rows; pick_wgrad(M, Cout, jtot, &bi, &bj, &ns, &rows);
-    return (long)ns * Cout * jtot * 4;
+    long bytes = (long)ns * Cout * jtot * 4;
+    if (jtot % 576 == 0 && Cout % 64 == 0) {                 // the all-taps 3x3 kernel uses up to 512/tiles + 1 slabs
+        long tiles = (long)(Cout / 64) * (jtot / 576);
+        long alt = (512 + tiles) * 64 * 576 * 4;
+        if (alt > bytes) bytes = alt;
+    }
+    return bytes;
 }
 
 template <typename T>
@@ -221,7 +255,7 @@ static int run_wgrad(WgradArgs& g, int dtype, float* dw, int dst_j, int accumula
     int rc = dtype == AB_DT_BF16 ? launch_wgrad<bf16_t>(g, bi, bj, st) : dtype == AB_DT_F32 ? launch_wgrad<float>(g, bi, bj, st) : AB_EINVAL;
     if (rc) return rc;
     long slab = (long)g.Cout * g.jtot, total = (long)g.Cout * dst_j;
-    wgrad_reduce<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(g.slabs, ns, slab, g.jtot, dst_j, dw, accumulate, stem_mask);
+    wgrad_reduce<<<wgrad_reduce_blocks(total), 256, 0, st>>>(g.slabs, ns, slab, g.jtot, dst_j, dw, accumulate, stem_mask);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -232,6 +266,17 @@ extern "C" int ab_conv2d_wgrad(const void* x, const void* dy, float* dw, int dty
                                void* stream) {
     if (!x || !dy || !dw || !workspace) return AB_EINVAL;
     if (kh * kw > 16 || Cin % 64 || Cout % 64) return AB_ESHAPE;
+    if (dtype == AB_DT_BF16 && kh == 3 && kw == 3 && stride == 1 && pad == 1) {
+        int ns = wgrad3x3_slices(N, H, W, Cin, Cout);
+        if (ns > 0) {
+            int rc = wgrad3x3_run(x, dy, (float*)workspace, N, H, W, Cin, Cout, as_stream(stream));
+            if (rc) return rc;
+            long slab = (long)Cout * 9 * Cin;
+            wgrad_reduce<<<wgrad_reduce_blocks(slab), 256, 0, as_stream(stream)>>>((float*)workspace, ns, slab, 9 * Cin, 9 * Cin, dw, accumulate, 0);
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? 0 : (int)e;
+        }
+    }
     WgradArgs g = {};
     g.X = x; g.DY = dy; g.slabs = (float*)workspace;
     g.N = N; g.Ha = H; g.Wa = W; g.Ca = Cin;

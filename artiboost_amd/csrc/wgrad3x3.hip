@@ -1,0 +1,237 @@
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution, all nine taps per workgroup (bf16, gfx950).
+//
+//   dW[co][kh][kw][ci] = sum over output pixels (n,y,x) of dy[n,y,x,co] * x[n,y+kh-1,x+kw-1,ci]
+//
+// The tap-by-tap kernel (conv_wgrad.hip) re-reads dy and the input once per tap and is bound by L2->LDS load
+// throughput.  Here a workgroup owns a 64(co) x 64(ci) x 9(tap) block of dW (144 f32 accumulators per lane) and walks a
+// range of "bands" (TH full image rows, TH*W = 128 or 64 pixels): per band it loads the dy band and the input patch
+// with its halo ONCE (direct-to-LDS, double buffered, counted vmcnt) and feeds all nine taps from the patch by
+// shifting the fragment address.  Both MFMA operands are reduction-major in HBM, so fragments come through the
+// gfx950 transpose read ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group), as in conv_wgrad.hip.
+//
+// LDS images (lane-linear LDS-DMA fills; swizzle on the source side): pixel q at byte q*128, logical 16-byte chunk c at
+// slot c ^ (((q >> 1) & 1) << 2)  -- swapping the 64-byte halves of every other pixel pair puts the four consecutive
+// pixels a transpose read touches on four distinct 64-byte bank groups.  The patch row pitch is W+4 pixels (a multiple
+// of 4) so that tap / k-slice displacements never change bit 1 of the pixel index: every fragment read is then
+// "lane base register + compile-time immediate".
+//
+// Partial results of the pixel slices go to separate slabs and are summed in fixed order by wgrad_reduce (no atomics).
+#include "conv_common.h"
+
+typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4_t lds_short4;
+
+static __device__ uint4 wg3_zero_page[2];
+
+struct Wg3Args {
+    const void* X; const void* DY; float* slabs;
+    int N, H, Cin, Cout;
+    int bands_per_slice, nbands;
+};
+
+__device__ __forceinline__ uint4 tr_pair(unsigned addr_lo, unsigned addr_hi) {
+    short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(size_t)addr_lo);
+    short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(size_t)addr_hi);
+    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
+template <int W, int TH>
+__global__ __launch_bounds__(256) void wgrad3x3_kernel(Wg3Args g) {
+    constexpr int BP = TH * W;                       // band pixels (multiple of 16)
+    constexpr int KS = BP / 16;                      // k-slices per band
+    constexpr int PW = W + 4, PH = TH + 2;           // patch: 1-pixel halo (+2 slack columns so PW % 4 == 0)
+    constexpr int NPIX = PH * PW;
+    constexpr int IA = BP / 8, LA = (IA + 3) / 4;    // dy-band fills: total / per wave
+    constexpr int IX = (NPIX + 7) / 8, LX = (IX + 3) / 4;
+    constexpr int ABYTES = LA * 4 * 1024, XBYTES = LX * 4 * 1024;
+    constexpr int BUF = ABYTES + XBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned lds0 = lds_addr_of(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_ci = g.Cin / 64;
+    const int tile_co = blockIdx.x / tiles_ci, tile_ci = blockIdx.x - tile_co * tiles_ci;
+    const int co0 = tile_co * 64, ci0 = tile_ci * 64;
+    const int wco = (wave & 1) * 32, wci = (wave >> 1) * 32;
+    const int band_begin = blockIdx.y * g.bands_per_slice;
+    const int band_end = min(g.nbands, band_begin + g.bands_per_slice);
+    const int bands_per_img = g.H / TH;
+    const bf16_t* __restrict__ X = (const bf16_t*)g.X;
+    const bf16_t* __restrict__ DY = (const bf16_t*)g.DY;
+    const bf16_t* zp = (const bf16_t*)wg3_zero_page;
+
+    // ---- per-lane fill assignment
+    long a_off[LA]; bool a_ok[LA];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        int ii = wave * LA + j;
+        int p = ii * 8 + (lane >> 3);
+        a_ok[j] = ii < IA;
+        int c = (lane & 7) ^ (((p >> 1) & 1) << 2);
+        a_off[j] = (long)p * g.Cout + co0 + c * 8;                 // + band pixel base * Cout
+    }
+    int x_pr[LX], x_pc[LX], x_c[LX]; bool x_in[LX];
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+        int ii = wave * LX + j;
+        int q = ii * 8 + (lane >> 3);
+        x_pr[j] = q / PW; x_pc[j] = q - x_pr[j] * PW;
+        x_in[j] = (ii < IX) && (q < NPIX) && x_pc[j] >= 1 && x_pc[j] <= W;
+        x_c[j] = ((lane & 7) ^ (((q >> 1) & 1) << 2)) * 8;
+    }
+    auto issue_band = [&](int band, int buf) {
+        const int img = band / bands_per_img, y0 = (band - img * bands_per_img) * TH;
+        const long pix0 = ((long)img * g.H + y0) * W;
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const int ii = wave * LA + j;
+            glds16(a_ok[j] ? (const void*)(DY + pix0 * g.Cout + a_off[j]) : (const void*)zp,
+                   __builtin_amdgcn_readfirstlane(lds0 + buf * BUF + ii * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < LX; ++j) {
+            const int ii = wave * LX + j;
+            int y = y0 + x_pr[j] - 1;
+            bool ok = x_in[j] && (unsigned)y < (unsigned)g.H;
+            const bf16_t* src = ok ? X + ((((long)img * g.H + y) * W + (x_pc[j] - 1)) * g.Cin + ci0 + x_c[j]) : zp;
+            glds16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * BUF + ABYTES + ii * 1024));
+        }
+    };
+
+    // ---- per-lane fragment bases (transpose-read geometry: 16-lane group grp, row = k index, 4 columns per lane)
+    const int grp = lane >> 4, l16 = lane & 15;
+    const int krow = (grp >> 1) * 8 + (l16 >> 2);            // k (pixel) index inside a 16-slice; +4 for the second read
+    const int csub = (grp & 1) * 16 + (l16 & 3) * 4;         // column inside the wave's 32
+    // dy band: pixel p = 16*s + krow (+4); chunk / byte inside the pixel
+    unsigned a_base[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        int p = krow + h * 4, col = wco + csub;
+        a_base[h] = p * 128 + (((col >> 3) ^ (((p >> 1) & 1) << 2)) << 4) + (col & 7) * 2;
+    }
+    // patch: pixel q = (ty + kh)*PW + tx + kw + 1  with (ty, tx) of band pixel p; the lane part is q_lane = krow (+4) mapped
+    // through the row layout below; bit 1 of q depends only on (tx + kw + 1): three variants per read half
+    unsigned x_base[3][2];
+    int tx_l[2], ty_l[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { int p = krow + h * 4; ty_l[h] = p / W; tx_l[h] = p - ty_l[h] * W; }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int q = ty_l[h] * PW + tx_l[h] + kw;                    // patch column = (tx + 1) + (kw - 1)
+            int col = wci + csub;
+            x_base[kw][h] = q * 128 + (((col >> 3) ^ (((q >> 1) & 1) << 2)) << 4) + (col & 7) * 2;
+        }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (band_begin < band_end) issue_band(band_begin, 0);
+    int buf = 0;
+    for (int band = band_begin; band < band_end; ++band) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (band + 1 < band_end) issue_band(band + 1, buf ^ 1);
+        const unsigned ab = lds0 + buf * BUF, xb = ab + ABYTES;
+        unsigned a_cur[2] = {ab + a_base[0], ab + a_base[1]};
+        unsigned x_cur[3][2];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) { x_cur[kw][0] = xb + x_base[kw][0]; x_cur[kw][1] = xb + x_base[kw][1]; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            // band pixel 16*s + k: same image row for all 16 k when W >= 16; for W == 8 two rows (k >= 8 -> next row)
+            const int p0 = 16 * s;
+            uint4 fa = tr_pair(a_cur[0] + p0 * 128, a_cur[1] + p0 * 128);
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    // displacement of this k-slice / tap inside the patch, in pixels (compile-time)
+                    // lanes with krow >= 8 may sit on the next image row when W == 8: handled by ty_l/tx_l in x_base,
+                    // so only the slice origin (row/col of pixel p0) is added here
+                    const int oy = p0 / W, ox = p0 % W;
+                    const int disp = ((oy + kh) * PW + ox) * 128;
+                    uint4 fb = tr_pair(x_cur[kw][0] + disp, x_cur[kw][1] + disp);
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
+                                                                              __builtin_bit_cast(bf16x8, fb), acc[kh * 3 + kw], 0, 0, 0);
+                }
+        }
+        buf ^= 1;
+    }
+    // ---- slab write: dW[co][tap][ci] (row length 9*Cin)
+    float* out = g.slabs + (long)blockIdx.y * g.Cout * 9 * g.Cin;
+    const int jt = 9 * g.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            int col = t * g.Cin + ci0 + wci + (lane & 31);
+            out[(long)row * jt + col] = acc[t][r];
+        }
+}
+
+template <int W, int TH>
+static size_t wg3_lds() {
+    constexpr int BP = TH * W, NPIX = (TH + 2) * (W + 4);
+    constexpr int LA = (BP / 8 + 3) / 4, LX = ((NPIX + 7) / 8 + 3) / 4;
+    return (size_t)2 * (LA + LX) * 4 * 1024;
+}
+
+template <int W, int TH>
+static int wg3_launch(Wg3Args& g, int tiles, int nslices, hipStream_t st) {
+    size_t lds = wg3_lds<W, TH>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<W, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    wgrad3x3_kernel<W, TH><<<dim3(tiles, nslices), 256, lds, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+static int wg3_th(int H, int W) {
+    if (W == 64 && H % 2 == 0) return 2;
+    if (W == 32 && H % 4 == 0) return 4;
+    if (W == 16 && H % 8 == 0) return 8;
+    if (W == 8 && H % 8 == 0) return 8;
+    return 0;
+}
+
+// returns the number of slabs (pixel slices) this kernel will write, 0 when the shape is not handled here
+int wgrad3x3_slices(int N, int H, int W, int Cin, int Cout) {
+    int th = wg3_th(H, W);
+    if (!th || Cin % 64 || Cout % 64 || getenv("AB_WGRAD3_OFF")) return 0;
+    int nbands = N * (H / th);
+    int tiles = (Cin / 64) * (Cout / 64);
+    static int target = getenv("AB_WG3_TARGET") ? atoi(getenv("AB_WG3_TARGET")) : 256;
+    int want = (target + tiles - 1) / tiles;
+    int ns = want < 1 ? 1 : want;
+    if (ns > nbands / 2) ns = nbands / 2 > 0 ? nbands / 2 : 1;      // at least two bands per slice (double buffering)
+    if (ns > 256) ns = 256;
+    int bps = (nbands + ns - 1) / ns;
+    return (nbands + bps - 1) / bps;
+}
+
+int wgrad3x3_run(const void* x, const void* dy, float* slabs, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+    int ns = wgrad3x3_slices(N, H, W, Cin, Cout);
+    if (!ns) return AB_ESHAPE;
+    int th = wg3_th(H, W);
+    Wg3Args g = {};
+    g.X = x; g.DY = dy; g.slabs = slabs; g.N = N; g.H = H; g.Cin = Cin; g.Cout = Cout;
+    g.nbands = N * (H / th);
+    g.bands_per_slice = (g.nbands + ns - 1) / ns;
+    int tiles = (Cin / 64) * (Cout / 64);
+    if (W == 64) return wg3_launch<64, 2>(g, tiles, ns, st);
+    if (W == 32) return wg3_launch<32, 4>(g, tiles, ns, st);
+    if (W == 16) return wg3_launch<16, 8>(g, tiles, ns, st);
+    return wg3_launch<8, 8>(g, tiles, ns, st);
+}
