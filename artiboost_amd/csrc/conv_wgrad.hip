@@ -218,7 +218,7 @@ static void pick_wgrad(int M, int Cout, int jtot, int* bi, int* bj, int* nslices
     long tiles = (long)(Cout / *bi) * (jtot / *bj);
     int want = (int)((640 + tiles - 1) / tiles);            // ~2.5 workgroups per CU
     int maxs = (M + 1023) / 1024;                            // at least 1024 pixels per slice
-    int ns = want < 1 ? 1 : want; if (ns > maxs) ns = maxs; if (ns < 1) ns = 1; if (ns > 64) ns = 64;
+    int ns = want < 1 ? 1 : want; if (ns > maxs) ns = maxs; if (ns < 1) ns = 1; if (ns > 512) ns = 512;
     int r = (M + ns - 1) / ns; r = (r + 31) / 32 * 32;
     *nslices = (M + r - 1) / r; *rows = r;
 }

@@ -61,26 +61,47 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x,
     }
 }
 
+// Fixed-order reduction of per-workgroup partials part[nparts][C][2] for 8 channels per workgroup of 1024 threads
+// (8 channel lanes x 128 partial lanes; four independent double accumulators per lane keep the loads in flight).
+// Returns the totals in (s, q) for threads with pl == 0.
+__device__ __forceinline__ void reduce_parts_1024(const float* __restrict__ part, int nparts, int C, int c, double& s, double& q,
+                                                  double (*sm)[8][2]) {
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (c < C) {
+        int k = pl;
+        for (; k + 384 < nparts; k += 512) {
+            float2 a = *(const float2*)(part + ((long)k * C + c) * 2);
+            float2 b = *(const float2*)(part + ((long)(k + 128) * C + c) * 2);
+            float2 d = *(const float2*)(part + ((long)(k + 256) * C + c) * 2);
+            float2 e = *(const float2*)(part + ((long)(k + 384) * C + c) * 2);
+            s0 += a.x; q0 += a.y; s1 += b.x; q1 += b.y; s2 += d.x; q2 += d.y; s3 += e.x; q3 += e.y;
+        }
+        for (; k < nparts; k += 128) { float2 a = *(const float2*)(part + ((long)k * C + c) * 2); s0 += a.x; q0 += a.y; }
+    }
+    sm[pl][cl][0] = (s0 + s1) + (s2 + s3); sm[pl][cl][1] = (q0 + q1) + (q2 + q3);
+    __syncthreads();
+    double a = 0, b = 0;                            // 128 -> 8
+    if (pl < 8) for (int k = pl; k < 128; k += 8) { a += sm[k][cl][0]; b += sm[k][cl][1]; }
+    __syncthreads();
+    if (pl < 8) { sm[pl][cl][0] = a; sm[pl][cl][1] = b; }
+    __syncthreads();
+    s = 0; q = 0;
+    if (pl == 0) for (int k = 0; k < 8; ++k) { s += sm[k][cl][0]; q += sm[k][cl][1]; }
+}
+
 // ---------------------------------------------------------------- BN finalize: partials -> scale/shift, saved stats
 // bnp: float [4][C] = scale (gamma*invstd), shift, mean, invstd.  running stats updated in place when non-null.
-// block = 8 channels x 32 part-lanes (32 consecutive bytes per partial row per lane group), grid = ceil(C/8)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, long count,
+// block = 8 channels x 128 part-lanes, grid = ceil(C/8)
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, long count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ bnp) {
     const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int k = pl; k < nparts; k += 32) {
-            float2 v = *(const float2*)(part + ((long)k * C + c) * 2);
-            s += v.x; q += v.y;
-        }
-    __shared__ double sm[32][8][2];
-    sm[pl][cl][0] = s; sm[pl][cl][1] = q;
-    __syncthreads();
+    __shared__ double sm[128][8][2];
+    double s, q; reduce_parts_1024(part, nparts, C, c, s, q, sm);
     if (pl == 0 && c < C) {
-        for (int k = 1; k < 32; ++k) { s += sm[k][cl][0]; q += sm[k][cl][1]; }
         double mean = s / (double)count;
         double var = q / (double)count - mean * mean; if (var < 0) var = 0;
         float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -178,22 +199,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // reduce partials -> dgamma, dbeta (written to the flat grad buffer) and bwdp[2][C] = (sum dz, sum dz*xhat)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ bwdp) {
     const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int k = pl; k < nparts; k += 32) {
-            float2 v = *(const float2*)(part + ((long)k * C + c) * 2);
-            s += v.x; q += v.y;
-        }
-    __shared__ double sm[32][8][2];
-    sm[pl][cl][0] = s; sm[pl][cl][1] = q;
-    __syncthreads();
+    __shared__ double sm[128][8][2];
+    double s, q; reduce_parts_1024(part, nparts, C, c, s, q, sm);
     if (pl == 0 && c < C) {
-        for (int k = 1; k < 32; ++k) { s += sm[k][cl][0]; q += sm[k][cl][1]; }
         dbeta[c] = (float)s; dgamma[c] = (float)q;
         bwdp[c] = (float)s; bwdp[C + c] = (float)q;
     }
@@ -416,7 +429,7 @@ extern "C" int ab_bn_finalize(const float* part, int nparts, int C, long count, 
                               float eps, float momentum, float* running_mean, float* running_var, float* bnp,
                               void* stream) {
     if (!part || !gamma || !beta || !bnp) return AB_EINVAL;
-    bn_finalize_kernel<<<(C + 7) / 8, 256, 0, as_stream(stream)>>>(part, nparts, C, count, gamma, beta, eps, momentum,
+    bn_finalize_kernel<<<(C + 7) / 8, 1024, 0, as_stream(stream)>>>(part, nparts, C, count, gamma, beta, eps, momentum,
                                                                     running_mean, running_var, bnp);
     AB_LAUNCH_CHECK(); return 0;
 }
@@ -449,7 +462,7 @@ extern "C" int ab_bn_bwd(const void* dout, const void* out, const void* y, const
     DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, red_rows(M), part)),
              (bn_bwd_reduce_kernel<bf16_t><<<np, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, red_rows(M), part)));
     AB_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<(C + 7) / 8, 256, 0, st>>>(part, np, C, dgamma, dbeta, bwdp);
+    bn_bwd_finalize_kernel<<<(C + 7) / 8, 1024, 0, st>>>(part, np, C, dgamma, dbeta, bwdp);
     AB_LAUNCH_CHECK();
     long nvec = M * C / V;
     DISPATCH(dtype, (bn_bwd_apply_kernel<float><<<grid_for(nvec), 256, 0, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, bwdp, nvec, C, M, relu, (float*)dy, (float*)dz_out)),
