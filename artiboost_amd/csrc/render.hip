@@ -254,15 +254,40 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const Sa
             int y0 = max((int)qy0, ty0), y1 = min((int)qy1, ty0 + TILE - 1);
             if (x0 > x1 || y0 > y1) continue;
             const TriRec t = tb[gid];
-            for (int y = y0; y <= y1; ++y)
+            // Same integers as cover()/the oracle, evaluated incrementally: the edge functions are affine in the pixel
+            // index, so one 64-bit add per edge per pixel replaces two 64-bit multiplies; the top-left rule is folded in
+            // as a bias of 1 on the non-inclusive edges (w >= 0 and (w > 0 or inclusive)  <=>  w - bias >= 0); the depth
+            // numerator sum(w_i z_i) steps the same way.  The denominator w0+w1+w2 is the triangle's doubled area.
+            const int32_t ex[3] = {t.x[2] - t.x[1], t.x[0] - t.x[2], t.x[1] - t.x[0]};     // b - a per edge (1,2) (2,0) (0,1)
+            const int32_t ey[3] = {t.y[2] - t.y[1], t.y[0] - t.y[2], t.y[1] - t.y[0]};
+            const int32_t axv[3] = {t.x[1], t.x[2], t.x[0]}, ayv[3] = {t.y[1], t.y[2], t.y[0]};
+            const int32_t px0 = x0 * 256 + 128, py0 = y0 * 256 + 128;
+            int64_t wrow[3], sx[3], sy[3], nrow = 0, nsx = 0, nsy = 0, sum = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int64_t w = (int64_t)ex[k] * (py0 - ayv[k]) - (int64_t)ey[k] * (px0 - axv[k]);
+                sx[k] = -(int64_t)ey[k] * 256; sy[k] = (int64_t)ex[k] * 256;
+                sum += w;
+                nrow += w * (int64_t)t.z[k]; nsx += sx[k] * (int64_t)t.z[k]; nsy += sy[k] * (int64_t)t.z[k];
+                const bool incl = (ey[k] > 0) || (ey[k] == 0 && ex[k] < 0);
+                wrow[k] = w - (incl ? 0 : 1);
+            }
+            const double inv = 1.0 / (double)sum;
+            for (int y = y0; y <= y1; ++y) {
+                int64_t w0 = wrow[0], w1 = wrow[1], w2 = wrow[2], num = nrow;
                 for (int x = x0; x <= x1; ++x) {
-                    int64_t w[3];
-                    if (!cover(t, x * 256 + 128, y * 256 + 128, w)) continue;
-                    int64_t sum = w[0] + w[1] + w[2];
-                    uint64_t z = (uint64_t)((w[0] * (int64_t)t.z[0] + w[1] * (int64_t)t.z[1] + w[2] * (int64_t)t.z[2]) / sum);
-                    unsigned long long key = (z << 32) | (uint32_t)gid;
-                    atomicMin(&zb[(y - ty0) * TILE + (x - tx0)], key);
+                    if ((w0 | w1 | w2) >= 0) {
+                        // exact floor(num / sum): double estimate (error < 1) + integer fix-up
+                        int64_t q = (int64_t)((double)num * inv);
+                        int64_t r = num - q * sum;
+                        if (r < 0) --q; else if (r >= sum) ++q;
+                        unsigned long long key = ((unsigned long long)q << 32) | (uint32_t)gid;
+                        atomicMin(&zb[(y - ty0) * TILE + (x - tx0)], key);
+                    }
+                    w0 += sx[0]; w1 += sx[1]; w2 += sx[2]; num += nsx;
                 }
+                wrow[0] += sy[0]; wrow[1] += sy[1]; wrow[2] += sy[2]; nrow += nsy;
+            }
         }
     }
     __syncthreads();

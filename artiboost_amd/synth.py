@@ -401,10 +401,13 @@ class ArtiBoostLoader:
         st["image_nhwc4_padded"] = torch.zeros((B, H + 6, W + 8, 4), dtype=self.dtype, device=self.dev)
         return st
 
-    def load_batch(self, static, batch_idx):
-        """Gather batch `batch_idx` of the epoch into the static buffers (small async device copies)."""
+    def load_batch(self, static, batch_idx, which="all"):
+        """Gather batch `batch_idx` of the epoch into the static buffers (small async device copies).
+        which: "all", "gt" (ground-truth / non-underscore keys) or "render" (the `_`-prefixed render inputs)."""
         s0 = batch_idx * self.batch_size
         for k, v in self.epoch.items():
+            if which != "all" and (k.startswith("_") != (which == "render")):
+                continue
             static[k].copy_(v[s0:s0 + self.batch_size], non_blocking=True)
 
     def render_into(self, static, want_chw=False):

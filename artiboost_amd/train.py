@@ -25,7 +25,7 @@ def allreduce_flat_(g, world, group=None, bucket_elems=8 << 20):
 
 class TrainStep:
     def __init__(self, arch_model, criterion, optimizer, example_batch, use_graph=True, dist_group=None,
-                 renderer=None, fused_criterion=True):
+                 renderer=None, fused_criterion=True, pipeline_render=False):
         self.model = arch_model
         self.hb = arch_model.model_list[0]
         self.crit = criterion
@@ -41,6 +41,17 @@ class TrainStep:
         self.g_opt = None
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.steps = 0
+        # Render/learn pipelining (the reference overlaps them through DataLoader worker processes,
+        # artiboost_loader.py:195-260): the batch for step i+1 is rendered on a side stream while step i trains.
+        # `rstatic` holds the render inputs of the NEXT batch and its own image buffer; the image is handed over by one
+        # device copy at the end of the step, so a single captured graph with fixed addresses serves every step.
+        self.pipeline = bool(pipeline_render and renderer is not None)
+        self.rstatic = None
+        self.render_stream = None
+        if self.pipeline:
+            self.rstatic = {k: v.clone() for k, v in self.static.items() if torch.is_tensor(v) and k.startswith("_")}
+            self.rstatic["image_nhwc4_padded"] = torch.zeros_like(self.static["image_nhwc4_padded"])
+            self.render_stream = torch.cuda.Stream(device=self.dev)
         if use_graph:
             self.opt.use_device_hyper(self.dev)
         self.fused = None
@@ -50,8 +61,20 @@ class TrainStep:
 
     # ------------------------------------------------------------------ pieces
     def _fwd_bwd(self):
+        if self.pipeline:
+            cur = torch.cuda.current_stream(self.dev)
+            self.render_stream.wait_stream(cur)
+            with torch.cuda.stream(self.render_stream):
+                self.renderer.render_into(self.rstatic)
+            out = self._learn()
+            cur.wait_stream(self.render_stream)
+            self.static["image_nhwc4_padded"].copy_(self.rstatic["image_nhwc4_padded"])
+            return out
         if self.renderer is not None:
             self.renderer.render_into(self.static)
+        return self._learn()
+
+    def _learn(self):
         if self.fused is not None:
             return self._fwd_bwd_fused()
         preds = self.model(self.static)["HybridBaseline"]
@@ -111,6 +134,23 @@ class TrainStep:
         self.opt.graph_steps = 1            # the warm-up above performed one real update
 
     # ------------------------------------------------------------------ public
+    def stage(self, loader, batch_idx):
+        """Gather the inputs of step `batch_idx` from the loader's planned epoch: ground truth of this batch and, when
+        pipelined, the render inputs of the next one (whose image this step produces)."""
+        if not self.pipeline:
+            loader.load_batch(self.static, batch_idx)
+            return
+        loader.load_batch(self.static, batch_idx, which="gt")
+        loader.load_batch(self.rstatic, (batch_idx + 1) % max(len(loader), 1), which="render")
+
+    def prime(self, loader, batch_idx):
+        """Pipelined mode: render batch `batch_idx` eagerly so that the first step has an image to learn from."""
+        if not self.pipeline:
+            return
+        loader.load_batch(self.rstatic, batch_idx, which="render")
+        self.renderer.render_into(self.rstatic)
+        self.static["image_nhwc4_padded"].copy_(self.rstatic["image_nhwc4_padded"])
+
     def load_batch(self, batch):
         """Copy a host/device batch into the static input buffers (async on the current stream)."""
         for k, v in batch.items():

@@ -59,7 +59,8 @@ def build_everything(args, rank, world, device):
     loader.load_batch(static, 0)
     group = torch.distributed.group.WORLD if world > 1 else None
     model.train()
-    ts = TrainStep(model, crit, opt, static, use_graph=not args.eager, dist_group=group, renderer=loader)
+    ts = TrainStep(model, crit, opt, static, use_graph=not args.eager, dist_group=group, renderer=loader,
+                   pipeline_render=args.pipeline)
     ts.static = static
     return cfg, model, crit, opt, loader, ts, static
 
@@ -91,7 +92,7 @@ def conv_kernel_time_ms(ts, loader, static, iters=3):
             spans.clear()
             loader.load_batch(static, it % max(len(loader), 1))
             ts.crit.draw(ts.dev)
-            ts._fwd_bwd()
+            ts._learn()
             torch.cuda.synchronize()
             total += sum(a.elapsed_time(b) for a, b in spans)
             nl = len(spans)
@@ -154,6 +155,9 @@ def main():
     ap.add_argument("--dataset", default="HO3D", choices=["HO3D", "DexYCB"])
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="render batch i+1 on a side stream while step i learns (measured slower on one GPU: the conv "
+                         "kernels already fill the chip, co-scheduling the rasteriser only evicts their workgroups)")
     ap.add_argument("--cpu-samples", type=int, default=16)
     ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
@@ -177,13 +181,14 @@ def main():
         torch.cuda.synchronize()
 
     nb = len(loader)
+    ts.prime(loader, 0)
     for i in range(args.warmup):
-        loader.load_batch(static, i % nb)
+        ts.stage(loader, i % nb)
         ts()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loader.load_batch(static, (args.warmup + i) % nb)
+        ts.stage(loader, (args.warmup + i) % nb)
         ts()
     barrier()
     dt = time.perf_counter() - t0

@@ -118,3 +118,50 @@ def test_end_to_end_train_steps_decrease_loss():
         vals.append(float(losses[5]))
     assert np.isfinite(vals).all()
     assert vals[-1] < vals[0], vals
+
+
+@pytest.mark.gpu
+def test_pipelined_render_hands_over_next_batch():
+    """Pipelined TrainStep: step i learns from batch i while batch i+1 is rendered on the side stream; the image handed
+    to the next step must be bit-identical to an inline render of that batch."""
+    import yaml, os
+    from artiboost_amd import registry as R
+    from artiboost_amd.criterions import Criterion
+    from artiboost_amd.models import Arch
+    from artiboost_amd.optim import FusedClipAdam
+    from artiboost_amd.train import TrainStep
+    assets, loader = _loader(torch.bfloat16, bs=8, n=32, size=224)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16")
+    model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
+    crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+    hb = model.model_list[0]
+    opt = FusedClipAdam(model.models_params, lr=1e-3, max_norm=1.0, model=hb)
+    loader.prepare()
+    static = loader.new_static_batch()
+    loader.load_batch(static, 0)
+    model.train()
+    ts = TrainStep(model, crit, opt, static, use_graph=True, renderer=loader, pipeline_render=True)
+    ts.static = static
+    ref = loader.new_static_batch()
+
+    def inline(bi):
+        loader.load_batch(ref, bi)
+        loader.render_into(ref)
+        torch.cuda.synchronize()
+        return ref["image_nhwc4_padded"].clone()
+
+    ts.prime(loader, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(static["image_nhwc4_padded"], inline(0))
+    for bi in range(3):
+        ts.stage(loader, bi)
+        _, losses, _ = ts()
+        torch.cuda.synchronize()
+        assert torch.isfinite(losses).all()
+        assert torch.equal(static["image_nhwc4_padded"], inline((bi + 1) % len(loader)))
+        loader.load_batch(ref, bi)
+        for k, v in ref.items():                      # ground truth in the learn buffers is still batch bi's
+            if not k.startswith("_") and k != "image_nhwc4_padded":
+                assert torch.equal(static[k], v), k
