@@ -8,7 +8,8 @@ import re
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libartiboost_hip.so")
+# ARTIBOOST_HIP_LIB selects another build of the same library (A/B timing of kernel changes); still no CPU fallback
+LIB_PATH = os.environ.get("ARTIBOOST_HIP_LIB") or os.path.join(HERE, "libartiboost_hip.so")
 HEADER = os.path.join(HERE, "..", "include", "artiboost_hip.h")
 
 _lib = None

@@ -171,18 +171,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const int cv = threadIdx.x % vc, rr = threadIdx.x / vc;
     long r0 = (long)blockIdx.x * rows_per_block;
     long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
-    float s[V], q[V], mean[V], istd[V];
+    float s[V], q[V], mean[V], istd[V], sc[V], sh[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) { s[i] = 0.f; q[i] = 0.f; mean[i] = bnp[2 * C + cv * V + i]; istd[i] = bnp[3 * C + cv * V + i]; }
+    for (int i = 0; i < V; ++i) {
+        s[i] = 0.f; q[i] = 0.f; mean[i] = bnp[2 * C + cv * V + i]; istd[i] = bnp[3 * C + cv * V + i];
+        sc[i] = bnp[cv * V + i]; sh[i] = bnp[C + cv * V + i];
+    }
     if (rr < rl)
         for (long r = r0 + rr; r < r1; r += rl) {
             long e = r * C + cv * V;
             float g[V], o[V], yy[V];
             vload<T>(dout + e, g); vload<T>(y + e, yy);
-            if (relu) vload<T>(out + e, o);
+            if (relu == 1) vload<T>(out + e, o);
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-                float dz = (relu && !(o[i] > 0.f)) ? 0.f : g[i];
+                // relu == 2: the mask is recomputed from y with bn_apply's own expression (same f32 value that was
+                // clamped and stored), which saves reading the activation
+                const bool dead = relu == 1 ? !(o[i] > 0.f) : relu == 2 ? !(yy[i] * sc[i] + sh[i] > 0.f) : false;
+                float dz = dead ? 0.f : g[i];
                 s[i] += dz; q[i] += dz * ((yy[i] - mean[i]) * istd[i]);
             }
         }
@@ -221,11 +227,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     constexpr int V = Vec<T>::N;
     const float invM = 1.f / (float)M;
     const bool fixed = ((256 * V) % C) == 0;
-    float ga[V], mu[V], is[V], k1[V], k2[V];    // gamma*invstd, mean, invstd, mean(dz), mean(dz*xhat)
+    float ga[V], sh[V], mu[V], is[V], k1[V], k2[V];    // gamma*invstd, shift, mean, invstd, mean(dz), mean(dz*xhat)
     auto loadp = [&](int c) {
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            ga[k] = bnp[c + k]; mu[k] = bnp[2 * C + c + k]; is[k] = bnp[3 * C + c + k];
+            ga[k] = bnp[c + k]; sh[k] = bnp[C + c + k]; mu[k] = bnp[2 * C + c + k]; is[k] = bnp[3 * C + c + k];
             k1[k] = bwdp[c + k] * invM; k2[k] = bwdp[C + c + k] * invM;
         }
     };
@@ -235,10 +241,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         if (!fixed) loadp((int)(e % C));
         float g[V], o[V], yy[V], d[V];
         vload<T>(dout + e, g); vload<T>(y + e, yy);
-        if (relu) vload<T>(out + e, o);
+        if (relu == 1) vload<T>(out + e, o);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            float dz = (relu && !(o[k] > 0.f)) ? 0.f : g[k];
+            const bool dead = relu == 1 ? !(o[k] > 0.f) : relu == 2 ? !(yy[k] * ga[k] + sh[k] > 0.f) : false;
+            float dz = dead ? 0.f : g[k];
             float xhat = (yy[k] - mu[k]) * is[k];
             d[k] = ga[k] * (dz - k1[k] - xhat * k2[k]);
             g[k] = dz;
@@ -454,7 +461,7 @@ extern "C" int ab_bn_apply(const void* y, const void* res, const float* bnp, int
 extern "C" int ab_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C,
                          int relu, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out,
                          void* stream) {
-    if (!dout || !y || !bnp || !part || !bwdp || !dgamma || !dbeta || !dy || (relu && !out)) return AB_EINVAL;
+    if (!dout || !y || !bnp || !part || !bwdp || !dgamma || !dbeta || !dy || (relu == 1 && !out) || relu < 0 || relu > 2) return AB_EINVAL;
     int V = dtype == AB_DT_F32 ? 4 : 8;
     if (C % V || C / V > 256) return AB_ESHAPE;
     int np = ab_col_stats_nparts(M); int rl = 256 / (C / V); size_t sh = (size_t)rl * C * 2 * 4;

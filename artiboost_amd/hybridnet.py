@@ -398,11 +398,11 @@ class HybridNet:
         K.col_sum(dlogits, gv("hybrid_head.final_layer.bias"))
         de2 = K.conv2d_dgrad(dlogits, self.tr["hybrid_head.final_layer.weight"], (e2.shape[1], e2.shape[2]), 1, 0)
         dd2 = K.bn_bwd(de2, e2, S["d2"], S["bnpd2"], gv("hybrid_head.deconv_layers.4.weight"),
-                       gv("hybrid_head.deconv_layers.4.bias"), relu=True)
+                       gv("hybrid_head.deconv_layers.4.bias"), relu="recompute")
         K.conv2d_wgrad(dd2, e1, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.3.weight"))
         de1 = K.conv2d_fwd(dd2, self.w("hybrid_head.deconv_layers.3.weight"), 2, 1)
         dd1 = K.bn_bwd(de1, e1, S["d1"], S["bnpd1"], gv("hybrid_head.deconv_layers.1.weight"),
-                       gv("hybrid_head.deconv_layers.1.bias"), relu=True)
+                       gv("hybrid_head.deconv_layers.1.bias"), relu="recompute")
         K.conv2d_wgrad(dd1, feat, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.0.weight"))
         dout = K.conv2d_fwd(dd1, self.w("hybrid_head.deconv_layers.0.weight"), 2, 1)
         K.avgpool_bwd(g_mean, dout, accumulate=True)
@@ -413,7 +413,8 @@ class HybridNet:
                                relu=True, want_dz=True)
             K.conv2d_wgrad(rec["a1"], dy2, 3, 3, 1, 1, out=gv(pre + ".conv2.weight"))
             da1 = K.conv2d_dgrad(dy2, self.tr[pre + ".conv2.weight"], (dy2.shape[1], dy2.shape[2]), 1, 1)
-            dy1 = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["bnp1"], gv(pre + ".bn1.weight"), gv(pre + ".bn1.bias"), relu=True)
+            dy1 = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["bnp1"], gv(pre + ".bn1.weight"), gv(pre + ".bn1.bias"),
+                            relu="recompute")
             K.conv2d_wgrad(x, dy1, 3, 3, stride, 1, out=gv(pre + ".conv1.weight"))
             if rec["ds"]:
                 dyd = K.bn_bwd(dz, None, rec["yd"], rec["bnpd"], gv(pre + ".downsample.1.weight"),
@@ -426,7 +427,8 @@ class HybridNet:
                 dout = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1, addend=dz)
         # ---- stem
         da0 = K.maxpool_bwd(S["pool_idx"], dout, (S["a0"].shape[1], S["a0"].shape[2]))
-        dy0 = K.bn_bwd(da0, S["a0"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"), relu=True)
+        dy0 = K.bn_bwd(da0, S["a0"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"),
+                       relu="recompute")
         H, W = S["HW"]
         K.conv2d_stem_wgrad(S["xpad"], dy0, H, W, out=gv("backbone.conv1.weight"))
         self.saved = None

@@ -129,7 +129,9 @@ def bn_apply(y, bnp, res=None, relu=True, out=None):
 
 
 def bn_bwd(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, dy_out=None):
-    """-> dy (grad wrt the conv output y) [, dz = dout*relu_mask]."""
+    """-> dy (grad wrt the conv output y) [, dz = dout*relu_mask].
+    relu: False (no activation), True (mask from the stored activation `out`; required when a residual was added before
+    the ReLU) or "recompute" (mask from y*scale+shift, `out` is not read)."""
     C = y.shape[-1]
     M = y.numel() // C
     lib = L.lib()
@@ -137,8 +139,8 @@ def bn_bwd(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, dy_out=No
     bwdp = torch.empty((2, C), dtype=torch.float32, device=y.device)
     dy = dy_out if dy_out is not None else torch.empty_like(y)
     dz = torch.empty_like(y) if want_dz else None
-    L.check(lib.ab_bn_bwd(L.ptr(dout), L.ptr(out if relu else None), L.ptr(y), L.ptr(bnp), L.i(L.dt(y)), L.l(M), L.i(C),
-                          L.i(1 if relu else 0), L.ptr(part), L.ptr(bwdp), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy),
+    L.check(lib.ab_bn_bwd(L.ptr(dout), L.ptr(out if relu is True else None), L.ptr(y), L.ptr(bnp), L.i(L.dt(y)), L.l(M), L.i(C),
+                          L.i(2 if relu == "recompute" else 1 if relu else 0), L.ptr(part), L.ptr(bwdp), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy),
                           L.ptr(dz), L.stream()), "ab_bn_bwd")
     return (dy, dz) if want_dz else dy
 

@@ -85,7 +85,9 @@ int ab_bn_eval_params(int C, const float* gamma, const float* beta, const float*
                       float* bnp, void* stream);
 int ab_bn_apply(const void* y, const void* res, const float* bnp, int dtype, long M, int C, int relu, void* out,
                 void* stream);
-/* part: float [ab_col_stats_nparts(M)][C][2]; bwdp: float [2][C]; dz_out optional (gradient of the residual branch) */
+/* part: float [ab_col_stats_nparts(M)][C][2]; bwdp: float [2][C]; dz_out optional (gradient of the residual branch).
+ * relu: 0 = no activation followed the BN; 1 = ReLU, mask taken from the stored activation `out` (needed when a residual
+ * was added before the ReLU); 2 = ReLU, mask recomputed as y*bnp[0]+bnp[1] > 0 (`out` may be NULL and is not read).   */
 int ab_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C, int relu,
               float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out, void* stream);
 int ab_relu_bwd(const void* dout, const void* out, int dtype, long n, void* dz, void* stream);

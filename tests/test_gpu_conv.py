@@ -190,6 +190,11 @@ def test_batchnorm_train_fwd_bwd(shape, dtype, relu, res):
     np.testing.assert_allclose(dbeta.cpu().numpy(), beta.grad.numpy(), rtol=2e-3, atol=2e-3 * float(beta.grad.abs().max()))
     if res:
         np.testing.assert_allclose(nchw(dz.float().cpu()).numpy(), r.grad.numpy(), **tol(dtype, r.grad))
+    if relu and not res:
+        # mask recomputed from y*scale+shift instead of read from `out`: same bits
+        dg2, db2 = torch.empty(C).cuda(), torch.empty(C).cuda()
+        dy2, dz2 = K.bn_bwd(nhwc(dout).to(dtype).cuda(), None, yd, bnp, dg2, db2, relu="recompute", want_dz=True)
+        assert torch.equal(dy2, dy) and torch.equal(dz2, dz) and torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
 
 
 @pytest.mark.parametrize("dtype", DT)
