@@ -28,8 +28,9 @@ template <> __device__ __forceinline__ void vstore<bf16_t>(bf16_t* p, const floa
     *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// rows of the [M][C] matrix reduced by one workgroup: ~1024 workgroups for large M, never fewer than 64 rows
-static inline int red_rows(long M) { long r = (M + 1023) / 1024; if (r < 64) r = 64; return (int)((r + 63) / 64 * 64); }
+// rows of the [M][C] matrix reduced by one workgroup: ~1024 workgroups for large M, never fewer than 16 rows (the per-lane
+// row loop is a chain of dependent-latency loads; at small M short chains in more workgroups win)
+static inline int red_rows(long M) { long r = (M + 1023) / 1024; if (r < 16) r = 16; return (int)((r + 15) / 16 * 16); }
 
 // ---------------------------------------------------------------- column partial sums: (sum x, sum x^2) per block
 template <typename T>
