@@ -345,25 +345,48 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
 }
 
 // ---------------------------------------------------------------- global average pool (resnet.py:219) fwd / bwd
+// grid (N, ceil(C / (32*V))): 32 channel-vector lanes x 8 pixel lanes per workgroup, pixel-lane partials combined in
+// fixed order through LDS
 template <typename T>
-__global__ void avgpool_fwd_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ out) {
-    const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < HW; ++p) s += ld_f32(x + ((long)n * HW + p) * C + c);
-        out[(long)n * C + c] = s / (float)HW;
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* __restrict__ x, int HW, int C, float* __restrict__ out) {
+    constexpr int V = Vec<T>::N;
+    __shared__ float sm[8][32 * V + 1];
+    const int n = blockIdx.x, cv = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int c0 = (blockIdx.y * 32 + cv) * V;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    if (c0 < C)
+        for (int p = pl; p < HW; p += 8) {
+            float f[V]; vload<T>(x + ((long)n * HW + p) * C + c0, f);
+#pragma unroll
+            for (int k = 0; k < V; ++k) acc[k] += f[k];
+        }
+#pragma unroll
+    for (int k = 0; k < V; ++k) sm[pl][cv * V + k] = acc[k];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 32 * V; c += 256) {
+        int cg = blockIdx.y * 32 * V + c;
+        if (cg >= C) continue;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][c];
+        out[(long)n * C + cg] = t / (float)HW;
     }
 }
-// dx[n,p,c] (+)= g[n,c] / HW
+// dx[n,p,c] (+)= g[n,c] / HW  (one 16-byte vector per thread)
 template <typename T>
-__global__ void avgpool_bwd_kernel(const float* __restrict__ g, int HW, int C, T* __restrict__ dx, int accumulate) {
-    const int n = blockIdx.x;
-    for (int i = threadIdx.x; i < HW * C; i += blockDim.x) {
-        int c = i % C;
-        float v = g[(long)n * C + c] / (float)HW;
-        long o = (long)n * HW * C + i;
-        if (accumulate) v += ld_f32(dx + o);
-        st_f32(dx + o, v);
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ g, int HW, int C, long nvec,
+                                                          T* __restrict__ dx, int accumulate) {
+    constexpr int V = Vec<T>::N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        long e = i * V;
+        int c = (int)(e % C); long n = e / ((long)HW * C);
+        float v[V];
+        if (accumulate) vload<T>(dx + e, v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) { float t = g[n * C + c + k] / (float)HW; v[k] = accumulate ? v[k] + t : t; }
+        vstore<T>(dx + e, v);
     }
 }
 
@@ -503,13 +526,17 @@ extern "C" int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype,
 }
 
 extern "C" int ab_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, float* out, void* stream) {
-    DISPATCH(dtype, (avgpool_fwd_kernel<float><<<N, 256, 0, as_stream(stream)>>>((const float*)x, HW, C, out)),
-             (avgpool_fwd_kernel<bf16_t><<<N, 256, 0, as_stream(stream)>>>((const bf16_t*)x, HW, C, out)));
+    if (!x || !out) return AB_EINVAL;
+    if (C % (dtype == AB_DT_F32 ? 4 : 8)) return AB_ESHAPE;
+    DISPATCH(dtype, (avgpool_fwd_kernel<float><<<dim3(N, (C + 127) / 128), 256, 0, as_stream(stream)>>>((const float*)x, HW, C, out)),
+             (avgpool_fwd_kernel<bf16_t><<<dim3(N, (C + 255) / 256), 256, 0, as_stream(stream)>>>((const bf16_t*)x, HW, C, out)));
     AB_LAUNCH_CHECK(); return 0;
 }
 extern "C" int ab_avgpool_bwd(const float* g, int dtype, int N, int HW, int C, void* dx, int accumulate, void* stream) {
-    DISPATCH(dtype, (avgpool_bwd_kernel<float><<<N, 256, 0, as_stream(stream)>>>(g, HW, C, (float*)dx, accumulate)),
-             (avgpool_bwd_kernel<bf16_t><<<N, 256, 0, as_stream(stream)>>>(g, HW, C, (bf16_t*)dx, accumulate)));
+    if (!g || !dx) return AB_EINVAL;
+    if (C % (dtype == AB_DT_F32 ? 4 : 8)) return AB_ESHAPE;
+    DISPATCH(dtype, (avgpool_bwd_kernel<float><<<grid_for((long)N * HW * C / 4), 256, 0, as_stream(stream)>>>(g, HW, C, (long)N * HW * C / 4, (float*)dx, accumulate)),
+             (avgpool_bwd_kernel<bf16_t><<<grid_for((long)N * HW * C / 8), 256, 0, as_stream(stream)>>>(g, HW, C, (long)N * HW * C / 8, (bf16_t*)dx, accumulate)));
     AB_LAUNCH_CHECK(); return 0;
 }
 

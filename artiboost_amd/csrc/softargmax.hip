@@ -24,8 +24,9 @@ __device__ __forceinline__ void acc_merge(Acc& a, const Acc& b) {
     a.m = m;
 }
 
+// ---- generic scalar kernels (any C*DP; used when C*DP is odd, where rows are not 4-byte aligned)
 template <typename T>
-__global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
+__global__ __launch_bounds__(SAM_THREADS) void sam_stage1_scalar(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                           int ntile, float* __restrict__ part) {
     // grid: (ntile, B).  4 waves; wave w handles pixels w, w+4, ... of the tile; lane handles channels lane+64k.
     const int CD = C * DP;   // channel = c*DP + d, d < D valid (DP >= D: padded depth pitch)
@@ -87,6 +88,94 @@ __global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ 
     }
 }
 
+
+// ---- pair kernels (C*DP even): a lane owns adjacent channel pairs and moves them with one 4/8-byte access
+template <typename T> __device__ __forceinline__ void ld_pair(const T* p, float& a, float& b);
+template <> __device__ __forceinline__ void ld_pair<float>(const float* p, float& a, float& b) {
+    float2 v = *(const float2*)p; a = v.x; b = v.y;
+}
+template <> __device__ __forceinline__ void ld_pair<bf16_t>(const bf16_t* p, float& a, float& b) {
+    uint32_t v = *(const uint32_t*)p; a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
+}
+
+template <typename T>
+__global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
+                                                          int ntile, float* __restrict__ part) {
+    // grid: (ntile, B).  4 waves; wave w handles pixels w, w+4, ... of the tile, four at a time (all their loads in flight,
+    // one max-rescale per four pixels); a lane owns the channel pairs 2*(lane + 64k), +1.  Branch-free: pixels past the
+    // end contribute x = -inf (exp -> 0); padded / out-of-range channel slots are computed and never read back.
+    const int CD = C * DP;   // channel = c*DP + d, d < D valid (DP >= D: padded depth pitch); even here
+    const int b = blockIdx.y, tile = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int npix = H * W;
+    const int p0 = tile * SAM_TILE_PIX;
+    constexpr int KP = SAM_MAXCH / 128;
+    constexpr int NCH = 2 * KP;
+    constexpr float NEG = -3.0e38f;          // finite stand-in for -inf: exp(NEG - m) == 0 without inf - inf NaNs
+    float am[NCH], as[NCH], asu[NCH], asv[NCH];
+    int choff[KP];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) { am[k] = NEG; as[k] = 0.f; asu[k] = 0.f; asv[k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < KP; ++k) choff[k] = min(2 * (lane + 64 * k), CD - 2);
+    const float invW = 1.f / W, invH = 1.f / H;
+    const T* base = logits + (size_t)b * npix * CD;
+#pragma unroll 1
+    for (int pi = wave; pi < SAM_TILE_PIX; pi += 16) {
+        float x[4][NCH], cu[4], cv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int p = p0 + pi + 4 * j;
+            const bool pv = (pi + 4 * j) < SAM_TILE_PIX && p < npix;
+            int pc = pv ? p : 0;
+            int h = pc / W, w = pc - h * W;
+            cu[j] = w * invW; cv[j] = h * invH;
+            const T* row = base + (size_t)pc * CD;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                float a, c2;
+                ld_pair<T>(row + choff[k], a, c2);
+                x[j][2 * k] = pv ? a : -INFINITY; x[j][2 * k + 1] = pv ? c2 : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            float m = fmaxf(fmaxf(fmaxf(x[0][k], x[1][k]), fmaxf(x[2][k], x[3][k])), am[k]);
+            float f = __expf(am[k] - m);
+            float s = as[k] * f, su = asu[k] * f, sv = asv[k] * f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float e = __expf(x[j][k] - m); s += e; su += e * cu[j]; sv += e * cv[j]; }
+            am[k] = m; as[k] = s; asu[k] = su; asv[k] = sv;
+        }
+    }
+    // per-channel accumulators -> LDS [wave][ch], then reduce over waves and over the D channels of each class
+    __shared__ float sm[4][SAM_MAXCH][4];  // m, s, su, sv   (64 KiB)
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        int ch = 2 * (lane + 64 * (k >> 1)) + (k & 1);
+        if (ch < CD) {
+            sm[wave][ch][0] = am[k]; sm[wave][ch][1] = as[k];
+            sm[wave][ch][2] = asu[k]; sm[wave][ch][3] = asv[k];
+        }
+    }
+    __syncthreads();
+    // one thread per class
+    for (int c = threadIdx.x; c < C; c += SAM_THREADS) {
+        Acc r = {-INFINITY, 0.f, 0.f, 0.f, 0.f};
+        const float invD = 1.f / D;
+        for (int d = 0; d < D; ++d) {
+            int ch = c * DP + d;
+            for (int wv = 0; wv < 4; ++wv) {
+                Acc t = {sm[wv][ch][0], sm[wv][ch][1], sm[wv][ch][2], sm[wv][ch][3], 0.f};
+                t.sd = t.s * (d * invD);
+                acc_merge(r, t);
+            }
+        }
+        float* o = part + (((size_t)b * ntile + tile) * C + c) * 8;
+        o[0] = r.m; o[1] = r.s; o[2] = r.su; o[3] = r.sv; o[4] = r.sd;
+    }
+}
+
 __global__ void sam_stage2(const float* __restrict__ part, int C, int ntile, float* __restrict__ uvd,
                            float* __restrict__ conf, float* __restrict__ stat) {
     // one wave per (b, c)
@@ -120,7 +209,7 @@ __global__ void sam_stage2(const float* __restrict__ part, int C, int ntile, flo
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
+__global__ __launch_bounds__(256) void sam_bwd_scalar(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                const float* __restrict__ uvd, const float* __restrict__ conf,
                                                const float* __restrict__ stat, const float* __restrict__ g_uvd,
                                                const float* __restrict__ g_conf, T* __restrict__ dlogits) {
@@ -153,6 +242,82 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
     }
 }
 
+
+template <typename T> __device__ __forceinline__ void st_pair(T* p, float a, float b);
+template <> __device__ __forceinline__ void st_pair<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
+template <> __device__ __forceinline__ void st_pair<bf16_t>(bf16_t* p, float a, float b) {
+    *(uint32_t*)p = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+
+#define SAM_BWD_PIX 16      // pixels per workgroup (4 per wave)
+
+// d logits = p * (g_u*(cu-u) + g_v*(cv-v) + g_d*(d/D-dd)) / z  [+ g_conf * conf * ([x == max] - p)],  p = exp(x-m)/s.
+// Everything that depends only on (b, channel) is folded into per-lane constants once per workgroup:
+//   out = exp(x - m) * (A*cu + Bv*cv + K),  A = g_u/(s z), Bv = g_v/(s z), K = (g_d*(d/D-dd) - g_u*u - g_v*v)/(s z)
+template <typename T>
+__global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
+                                               const float* __restrict__ uvd, const float* __restrict__ conf,
+                                               const float* __restrict__ stat, const float* __restrict__ g_uvd,
+                                               const float* __restrict__ g_conf, T* __restrict__ dlogits) {
+    const int CD = C * DP, npix = H * W;      // CD even
+    const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int KP = SAM_MAXCH / 128, NCH = 2 * KP;
+    const float z = 1.0f + 1e-7f;
+    // per-channel constants: computed once per workgroup (rolled loop), exchanged through LDS
+    __shared__ float cst[6][SAM_MAXCH];
+#pragma unroll 1
+    for (int ch = threadIdx.x; ch < SAM_MAXCH; ch += 256) {
+        int c = ch / DP, d = ch - c * DP;
+        float m = INFINITY, a = 0.f, bb = 0.f, k0 = 0.f, is = 0.f, gc = 0.f;   // exp(x - inf) = 0: padded slots get zeros
+        if (ch < CD && d < D) {
+            int bc = b * C + c;
+            float s = stat[bc * 2];
+            m = s; s = stat[bc * 2 + 1];
+            float u = uvd[bc * 3] * z, v = uvd[bc * 3 + 1] * z, dd = uvd[bc * 3 + 2] * z;  // sum p*coord
+            float gu = g_uvd[bc * 3], gv = g_uvd[bc * 3 + 1], gd = g_uvd[bc * 3 + 2];
+            float sc = 1.f / (s * z);
+            a = gu * sc; bb = gv * sc;
+            k0 = (gd * ((float)d / D - dd) - gu * u - gv * v) * sc;
+            is = 1.f / s;
+            gc = g_conf ? g_conf[bc] * conf[bc] : 0.f;
+        }
+        cst[0][ch] = m; cst[1][ch] = a; cst[2][ch] = bb; cst[3][ch] = k0; cst[4][ch] = is; cst[5][ch] = gc;
+    }
+    __syncthreads();
+    float cm[NCH], ca[NCH], cb[NCH], ck[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        int ch = 2 * (lane + 64 * (k >> 1)) + (k & 1);
+        cm[k] = cst[0][ch]; ca[k] = cst[1][ch]; cb[k] = cst[2][ch]; ck[k] = cst[3][ch];
+    }
+#pragma unroll 1
+    for (int j = 0; j < SAM_BWD_PIX / 4; ++j) {
+        const int p = blockIdx.x * SAM_BWD_PIX + j * 4 + wave;
+        if (p >= npix) break;
+        const int h = p / W, w = p - h * W;
+        const float cu = (float)w / W, cv = (float)h / H;
+        const T* row = logits + ((size_t)b * npix + p) * CD;
+        T* drow = dlogits + ((size_t)b * npix + p) * CD;
+        float x[NCH];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) ld_pair<T>(row + min(2 * (lane + 64 * k), CD - 2), x[2 * k], x[2 * k + 1]);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            int ch = 2 * (lane + 64 * k);
+            float o[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                int kk = 2 * k + t;
+                float e = __expf(x[kk] - cm[kk]);
+                float out = e * ((ca[kk] * cu + cb[kk] * cv) + ck[kk]);
+                if (g_conf) out += cst[5][ch + t] * ((x[kk] == cm[kk] ? 1.f : 0.f) - e * cst[4][ch + t]);
+                o[t] = out;
+            }
+            if (ch < CD) st_pair<T>(drow + ch, o[0], o[1]);
+        }
+    }
+}
+
 extern "C" int ab_softargmax3d_ntiles(int H, int W) { return (H * W + SAM_TILE_PIX - 1) / SAM_TILE_PIX; }
 
 extern "C" int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, float* part,
@@ -161,11 +326,15 @@ extern "C" int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, 
     if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH) return AB_ESHAPE;
     int ntile = ab_softargmax3d_ntiles(H, W);
     dim3 grid(ntile, B);
-    if (dtype == AB_DT_F32)
-        sam_stage1<float><<<grid, SAM_THREADS, 0, as_stream(stream)>>>((const float*)logits, C, D, DP, H, W, ntile, part);
-    else if (dtype == AB_DT_BF16)
-        sam_stage1<bf16_t><<<grid, SAM_THREADS, 0, as_stream(stream)>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
-    else return AB_EINVAL;
+    const bool pair = ((C * DP) & 1) == 0;
+    hipStream_t st = as_stream(stream);
+    if (dtype == AB_DT_F32) {
+        if (pair) sam_stage1<float><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
+        else sam_stage1_scalar<float><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
+    } else if (dtype == AB_DT_BF16) {
+        if (pair) sam_stage1<bf16_t><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
+        else sam_stage1_scalar<bf16_t><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
+    } else return AB_EINVAL;
     AB_LAUNCH_CHECK();
     sam_stage2<<<B * C, 64, 0, as_stream(stream)>>>(part, C, ntile, uvd, conf, stat);
     AB_LAUNCH_CHECK();
@@ -177,14 +346,18 @@ extern "C" int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, 
                                    void* dlogits, void* stream) {
     if (!logits || !uvd || !conf || !stat || !g_uvd || !dlogits) return AB_EINVAL;
     if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH) return AB_ESHAPE;
-    dim3 grid((H * W + 3) / 4, B);
-    if (dtype == AB_DT_F32)
-        sam_bwd<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)logits, C, D, DP, H, W, uvd, conf, stat, g_uvd,
-                                                           g_conf, (float*)dlogits);
-    else if (dtype == AB_DT_BF16)
-        sam_bwd<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)logits, C, D, DP, H, W, uvd, conf, stat, g_uvd,
-                                                            g_conf, (bf16_t*)dlogits);
-    else return AB_EINVAL;
+    const bool pair = ((C * DP) & 1) == 0;
+    hipStream_t st = as_stream(stream);
+    dim3 grid(pair ? (H * W + SAM_BWD_PIX - 1) / SAM_BWD_PIX : (H * W + 3) / 4, B);
+#define SAM_BWD_ARGS(TT) (const TT*)logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, (TT*)dlogits
+    if (dtype == AB_DT_F32) {
+        if (pair) sam_bwd<float><<<grid, 256, 0, st>>>(SAM_BWD_ARGS(float));
+        else sam_bwd_scalar<float><<<grid, 256, 0, st>>>(SAM_BWD_ARGS(float));
+    } else if (dtype == AB_DT_BF16) {
+        if (pair) sam_bwd<bf16_t><<<grid, 256, 0, st>>>(SAM_BWD_ARGS(bf16_t));
+        else sam_bwd_scalar<bf16_t><<<grid, 256, 0, st>>>(SAM_BWD_ARGS(bf16_t));
+    } else return AB_EINVAL;
+#undef SAM_BWD_ARGS
     AB_LAUNCH_CHECK();
     return 0;
 }
