@@ -102,6 +102,18 @@ def conv_kernel_time_ms(ts, loader, static, iters=3):
     return total / iters, nl
 
 
+def pmc_traffic(args):
+    """HBM bytes per step moved by the conv-stack kernels, from the committed PMC passes of this same workload
+    (tools/pmc_traffic.py; FETCH_SIZE x2 + WRITE_SIZE).  None for any other configuration."""
+    if args.bs != 64 or args.size != 256 or args.dtype != "bf16" or args.dataset != "HO3D":
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc_hbm_traffic.json")) as f:
+            return round(float(json.load(f)["conv_stack_bytes_per_step"]))
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(args, cfg):
     """The CPU oracle of the same step on this box's host cores: C software renderer (OpenMP over samples) + torch-CPU
     fp32 HybridBaseline forward/loss/backward/clip+Adam.  Bounded sample."""
@@ -207,8 +219,10 @@ def main():
             flops = GFLOP_FWD_BWD_PER_SAMPLE.get(args.size, 31.785) * 1e9 * args.bs
             ach = flops / (conv_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4), "traffic": None,
-                    "kernel": "conv_gemm_kernel + wgrad_kernel (implicit-GEMM conv stack)",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4), "traffic": pmc_traffic(args),
+                    "traffic_unit": "HBM bytes per step over the conv-stack launches (PMC, profiles/round1_pmc_hbm_traffic.*)",
+                    "kernel": "implicit-GEMM conv stack: conv3x3_kernel / conv_gemm2_kernel / conv_gemm_kernel (fwd, dgrad) + "
+                              "wgrad3x3_kernel / wgrad_kernel / wgrad_reduce (weight grad)",
                     "conv_ms_per_step": round(conv_ms, 3), "conv_launches_per_step": nlaunch}
         except Exception as e:   # noqa: BLE001
             roof = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": None,
