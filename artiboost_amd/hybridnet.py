@@ -16,6 +16,8 @@ Design (MI355X-first, not a translation of the nn.Module tree):
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 
 from . import kernels as K
@@ -369,6 +371,29 @@ class HybridNet:
                                 inplace=True)
 
     # ------------------------------------------------------------------ backward
+    # Weight gradients are off the critical path (nothing consumes them before the optimizer), so they CAN be issued on
+    # a side stream to co-run with the HBM-bound BatchNorm-backward passes of the layers below.  Measured on MI355X
+    # (B=64, 256x256, graph replay): 7366 samples/s with the side stream vs 7715 without -- co-scheduled workgroups evict
+    # each other's L2 / LDS residency and the single-queue order is faster.  Kept as an opt-in (AB_WGRAD_OVERLAP=1).
+    overlap_wgrad = os.environ.get("AB_WGRAD_OVERLAP", "0") == "1"
+
+    def _wgrad_side(self, fn, *args, **kw):
+        if not self.overlap_wgrad:
+            return fn(*args, **kw)
+        if getattr(self, "_wg_stream", None) is None:
+            self._wg_stream = torch.cuda.Stream(device=self.p.device)
+            self._wg_keep = []
+        main = torch.cuda.current_stream(self.p.device)
+        self._wg_stream.wait_stream(main)
+        with torch.cuda.stream(self._wg_stream):
+            fn(*args, **kw)
+        self._wg_keep.append(args)
+
+    def _wgrad_join(self):
+        if getattr(self, "_wg_stream", None) is not None:
+            torch.cuda.current_stream(self.p.device).wait_stream(self._wg_stream)
+            self._wg_keep.clear()
+
     def backward(self, dlogits, g_box6d):
         """dlogits: gradient wrt the logits [N,h,w,22*32] (compute dtype); g_box6d [N,6] f32.
         Fills self.p.grad (overwrites).  Returns nothing (no gradient to the image)."""
@@ -394,16 +419,16 @@ class HybridNet:
         g_mean = K.conv2d_dgrad(gb1, w0t, (1, 1), 1, 0).view(N, 512)
         # ---- head
         e2, e1, feat = S["e2"], S["e1"], S["feat"]
-        K.conv2d_wgrad(e2, dlogits, 1, 1, 1, 0, out=gv("hybrid_head.final_layer.weight"))
+        self._wgrad_side(K.conv2d_wgrad, e2, dlogits, 1, 1, 1, 0, out=gv("hybrid_head.final_layer.weight"))
         K.col_sum(dlogits, gv("hybrid_head.final_layer.bias"))
         de2 = K.conv2d_dgrad(dlogits, self.tr["hybrid_head.final_layer.weight"], (e2.shape[1], e2.shape[2]), 1, 0)
         dd2 = K.bn_bwd(de2, e2, S["d2"], S["bnpd2"], gv("hybrid_head.deconv_layers.4.weight"),
                        gv("hybrid_head.deconv_layers.4.bias"), relu="recompute")
-        K.conv2d_wgrad(dd2, e1, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.3.weight"))
+        self._wgrad_side(K.conv2d_wgrad, dd2, e1, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.3.weight"))
         de1 = K.conv2d_fwd(dd2, self.w("hybrid_head.deconv_layers.3.weight"), 2, 1)
         dd1 = K.bn_bwd(de1, e1, S["d1"], S["bnpd1"], gv("hybrid_head.deconv_layers.1.weight"),
                        gv("hybrid_head.deconv_layers.1.bias"), relu="recompute")
-        K.conv2d_wgrad(dd1, feat, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.0.weight"))
+        self._wgrad_side(K.conv2d_wgrad, dd1, feat, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.0.weight"))
         dout = K.conv2d_fwd(dd1, self.w("hybrid_head.deconv_layers.0.weight"), 2, 1)
         K.avgpool_bwd(g_mean, dout, accumulate=True)
         # ---- backbone, last block first
@@ -411,15 +436,15 @@ class HybridNet:
             pre, stride, x = rec["pre"], rec["stride"], rec["x"]
             dy2, dz = K.bn_bwd(dout, rec["out"], rec["y2"], rec["bnp2"], gv(pre + ".bn2.weight"), gv(pre + ".bn2.bias"),
                                relu=True, want_dz=True)
-            K.conv2d_wgrad(rec["a1"], dy2, 3, 3, 1, 1, out=gv(pre + ".conv2.weight"))
+            self._wgrad_side(K.conv2d_wgrad, rec["a1"], dy2, 3, 3, 1, 1, out=gv(pre + ".conv2.weight"))
             da1 = K.conv2d_dgrad(dy2, self.tr[pre + ".conv2.weight"], (dy2.shape[1], dy2.shape[2]), 1, 1)
             dy1 = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["bnp1"], gv(pre + ".bn1.weight"), gv(pre + ".bn1.bias"),
                             relu="recompute")
-            K.conv2d_wgrad(x, dy1, 3, 3, stride, 1, out=gv(pre + ".conv1.weight"))
+            self._wgrad_side(K.conv2d_wgrad, x, dy1, 3, 3, stride, 1, out=gv(pre + ".conv1.weight"))
             if rec["ds"]:
                 dyd = K.bn_bwd(dz, None, rec["yd"], rec["bnpd"], gv(pre + ".downsample.1.weight"),
                                gv(pre + ".downsample.1.bias"), relu=False)
-                K.conv2d_wgrad(x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
+                self._wgrad_side(K.conv2d_wgrad, x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
                 dx = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1)
                 dout = K.conv2d_dgrad(dyd, self.tr[pre + ".downsample.0.weight"], (x.shape[1], x.shape[2]), stride, 0,
                                       addend=dx)
@@ -430,5 +455,6 @@ class HybridNet:
         dy0 = K.bn_bwd(da0, S["a0"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"),
                        relu="recompute")
         H, W = S["HW"]
-        K.conv2d_stem_wgrad(S["xpad"], dy0, H, W, out=gv("backbone.conv1.weight"))
+        self._wgrad_side(K.conv2d_stem_wgrad, S["xpad"], dy0, H, W, out=gv("backbone.conv1.weight"))
+        self._wgrad_join()
         self.saved = None
