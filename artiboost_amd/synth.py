@@ -388,6 +388,28 @@ class ArtiBoostLoader:
         ep["_factor"] = torch.from_numpy(factor).to(dev)
         ep["_inv_affine"] = torch.from_numpy(inv).to(dev)
         self.epoch, self.epoch_len, self.cursor = ep, S, 0
+        self._pack_batches()
+
+    def _pack_batches(self):
+        """Batch-major packed copy of the epoch: one contiguous byte row per (batch, group) so that staging a batch is
+        one device copy per group ("gt" / "render") instead of one per tensor (25 launches per step)."""
+        B, nb = self.batch_size, self.epoch_len // self.batch_size
+        self._layout, self._packed = {}, {}
+        for group in ("gt", "render"):
+            off, lay = 0, []
+            for k, v in self.epoch.items():
+                if k.startswith("_") != (group == "render"):
+                    continue
+                nbytes = B * int(np.prod(v.shape[1:], dtype=np.int64)) * v.element_size()
+                lay.append((k, off, nbytes, v.dtype, tuple(v.shape[1:])))
+                off += (nbytes + 255) // 256 * 256
+            self._layout[group] = (lay, off)
+            packed = torch.zeros((max(nb, 1), off), dtype=torch.uint8, device=self.dev)
+            for k, o, nbytes, dt, shp in lay:
+                if nb:
+                    src = self.epoch[k][:nb * B].contiguous().reshape(nb, -1)
+                    packed[:, o:o + nbytes] = src.view(torch.uint8) if dt != torch.bool else src.to(torch.uint8)
+            self._packed[group] = packed
 
     # ------------------------------------------------------------------ iteration
     def __len__(self):
@@ -397,13 +419,24 @@ class ArtiBoostLoader:
         """Static device buffers one batch wide (inputs of a captured hipGraph)."""
         B, (W, H) = self.batch_size, self.image_size
         ep = self.epoch
-        st = {k: torch.empty((B,) + tuple(v.shape[1:]), dtype=v.dtype, device=self.dev) for k, v in ep.items()}
+        st = {}
+        for group in ("gt", "render"):            # typed views into one flat staging buffer per group (see _pack_batches)
+            lay, total = self._layout[group]
+            flat = st["__flat_" + group] = torch.zeros(total, dtype=torch.uint8, device=self.dev)
+            for k, o, nbytes, dt, shp in lay:
+                st[k] = flat[o:o + nbytes].view(dt).view((B,) + shp)
+        assert set(ep) <= set(st)
         st["image_nhwc4_padded"] = torch.zeros((B, H + 6, W + 8, 4), dtype=self.dtype, device=self.dev)
         return st
 
     def load_batch(self, static, batch_idx, which="all"):
         """Gather batch `batch_idx` of the epoch into the static buffers (small async device copies).
         which: "all", "gt" (ground-truth / non-underscore keys) or "render" (the `_`-prefixed render inputs)."""
+        groups = ("gt", "render") if which == "all" else (which,)
+        if all(("__flat_" + g) in static for g in groups):
+            for g in groups:
+                static["__flat_" + g].copy_(self._packed[g][batch_idx], non_blocking=True)
+            return
         s0 = batch_idx * self.batch_size
         for k, v in self.epoch.items():
             if which != "all" and (k.startswith("_") != (which == "render")):

@@ -35,7 +35,9 @@ class TrainStep:
         self.renderer = renderer          # object with .render_into(static_batch) enqueuing device work
         self.group = dist_group
         self.world = torch.distributed.get_world_size(dist_group) if dist_group is not None else 1
-        self.static = {k: (v.to(self.dev).clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        # ("__flat_*" are the loader's packed staging buffers; clones would not alias their typed views)
+        self.static = {k: (v.to(self.dev).clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()
+                       if not k.startswith("__flat_")}
         self.out = None
         self.g_fwd_bwd = None
         self.g_opt = None
@@ -49,7 +51,7 @@ class TrainStep:
         self.rstatic = None
         self.render_stream = None
         if self.pipeline:
-            self.rstatic = {k: v.clone() for k, v in self.static.items() if torch.is_tensor(v) and k.startswith("_")}
+            self.rstatic = {k: v.clone() for k, v in self.static.items() if torch.is_tensor(v) and k.startswith("_") and not k.startswith("__flat_")}
             self.rstatic["image_nhwc4_padded"] = torch.zeros_like(self.static["image_nhwc4_padded"])
             self.render_stream = torch.cuda.Stream(device=self.dev)
         if use_graph:
