@@ -403,6 +403,51 @@ __global__ void transpose_oki_kernel(const float* __restrict__ src, int O, int K
         st_f32(dst + e, src[((long)o * K + k) * I + i]);
     }
 }
+// All dgrad weight copies in one launch: tensor t = desc[t] (see ab_transpose_desc), a workgroup moves one 64(o) x 64(i)
+// tile of one tap k through LDS: 256-byte coalesced row reads of src [O][K][I], 16-byte stores into dst [I][K][O].
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_oki_batch_kernel(const ab_transpose_desc* __restrict__ desc, int ntensors) {
+    __shared__ float sm[64][65];
+    int t = 0;
+    while (t + 1 < ntensors && (long)blockIdx.x >= desc[t + 1].tile_begin) ++t;
+    const ab_transpose_desc d = desc[t];
+    const int O = d.O, K = d.K, I = d.I;
+    const int ti = (I + 63) / 64;
+    long tile = (long)blockIdx.x - d.tile_begin;
+    const int it = (int)(tile % ti); tile /= ti;
+    const int k = (int)(tile % K); const int ot = (int)(tile / K);
+    const int o0 = ot * 64, i0 = it * 64;
+    const float* __restrict__ src = (const float*)d.src;
+    T* __restrict__ dst = (T*)d.dst;
+    {
+        const int c4 = (threadIdx.x & 15) * 4, r = threadIdx.x >> 4;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            int o = o0 + r + pass * 16, i = i0 + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o < O && i < I) v = *(const float4*)(src + ((long)o * K + k) * I + i);
+            sm[r + pass * 16][c4] = v.x; sm[r + pass * 16][c4 + 1] = v.y; sm[r + pass * 16][c4 + 2] = v.z; sm[r + pass * 16][c4 + 3] = v.w;
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int V = Vec<T>::N;                 // 8 bf16 / 4 f32 per 16-byte store
+        constexpr int CL = 64 / V, RP = 256 / CL;    // column lanes, rows per pass
+        const int cv = (threadIdx.x % CL) * V, r = threadIdx.x / CL;
+#pragma unroll
+        for (int pass = 0; pass < 64 / RP; ++pass) {
+            int il = r + pass * RP;
+            int i = i0 + il, o = o0 + cv;
+            if (i < I && o < O) {
+                float f[V];
+#pragma unroll
+                for (int q = 0; q < V; ++q) f[q] = sm[cv + q][il];
+                vstore<T>(dst + ((long)i * K + k) * O + o, f);
+            }
+        }
+    }
+}
+
 // image NCHW float [N,3,H,W] -> zero-bordered NHWC4 [N, H+6, W+8, 4] in T (border 3 px, channel 3 = 0)
 template <typename T>
 __global__ void image_pad_kernel(const float* __restrict__ img, int N, int H, int W, T* __restrict__ out) {
@@ -548,6 +593,13 @@ extern "C" int ab_transpose_oki(const float* src, int O, int K, int I, int dtype
     long n = (long)O * K * I;
     DISPATCH(dtype, (transpose_oki_kernel<float><<<grid_for(n), 256, 0, as_stream(stream)>>>(src, O, K, I, (float*)dst)),
              (transpose_oki_kernel<bf16_t><<<grid_for(n), 256, 0, as_stream(stream)>>>(src, O, K, I, (bf16_t*)dst)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+extern "C" int ab_transpose_oki_batch(const ab_transpose_desc* desc_dev, int ntensors, long total_tiles, int dtype,
+                                      void* stream) {
+    if (!desc_dev || ntensors < 1 || total_tiles < 1 || total_tiles > 0x7fffffffL) return AB_EINVAL;
+    DISPATCH(dtype, (transpose_oki_batch_kernel<float><<<(unsigned)total_tiles, 256, 0, as_stream(stream)>>>(desc_dev, ntensors)),
+             (transpose_oki_batch_kernel<bf16_t><<<(unsigned)total_tiles, 256, 0, as_stream(stream)>>>(desc_dev, ntensors)));
     AB_LAUNCH_CHECK(); return 0;
 }
 extern "C" int ab_image_pad_nhwc4(const float* img_nchw, int dtype, int N, int H, int W, void* out, void* stream) {

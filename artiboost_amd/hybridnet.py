@@ -275,14 +275,19 @@ class HybridNet:
                 K.cast_bf16(p.flat, self.lp)
         else:
             self.lp = p.flat
-        for name in self._dgrad_names():
-            e = p.entries[name]
-            O, kh, kw, I = e.kshape
-            dst = self.tr.get(name)
-            if dst is None:
-                dst = torch.empty((I, kh, kw, O), dtype=self.dtype, device=p.device)
-                self.tr[name] = dst
-            K.transpose_oki(p.view(name).reshape(O, kh * kw, I), dst)
+        if getattr(self, "_tr_plan", None) is None:
+            pairs = []
+            for name in self._dgrad_names():
+                O, kh, kw, I = p.entries[name].kshape
+                dst = self.tr[name] = torch.empty((I, kh, kw, O), dtype=self.dtype, device=p.device)
+                pairs.append((p.view(name).reshape(O, kh * kw, I), dst))
+            self._tr_pairs = pairs                                   # the flat buffer and the copies are persistent
+            self._tr_plan = K.transpose_plan(pairs) or False
+        if self._tr_plan:
+            K.transpose_oki_batch(self._tr_plan)                     # one launch for all IHWO dgrad copies
+        else:
+            for src, dst in self._tr_pairs:
+                K.transpose_oki(src, dst)
         self._packed = True
 
     def w(self, name):

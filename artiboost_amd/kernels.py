@@ -197,6 +197,28 @@ def transpose_oki(src_f32_oki, dst):
     return dst
 
 
+def transpose_plan(pairs):
+    """pairs: [(src f32 [O,K,I], dst [I,K,O])] -> (device descriptor table, n, total_tiles, dtype code) for
+    transpose_oki_batch; None when a shape does not fit the 16-byte vector tiles."""
+    import numpy as np
+    rec = np.zeros(len(pairs), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("O", "<i4"), ("K", "<i4"), ("I", "<i4"),
+                                               ("tile_begin", "<i4")]))
+    tiles = 0
+    for n, (src, dst) in enumerate(pairs):
+        O, Kk, I = src.shape
+        if I % 4 or O % 8 or not src.is_contiguous() or not dst.is_contiguous() or dst.dtype != pairs[0][1].dtype:
+            return None
+        rec[n] = (src.data_ptr(), dst.data_ptr(), O, Kk, I, tiles)
+        tiles += ((O + 63) // 64) * Kk * ((I + 63) // 64)
+    dev = torch.from_numpy(rec.view(np.uint8).copy()).to(pairs[0][0].device)
+    return dev, len(pairs), tiles, L.dt(pairs[0][1])
+
+
+def transpose_oki_batch(plan):
+    dev, n, tiles, dt = plan
+    L.check(L.lib().ab_transpose_oki_batch(L.ptr(dev), L.i(n), L.l(tiles), L.i(dt), L.stream()), "ab_transpose_oki_batch")
+
+
 def image_pad_nhwc4(img_nchw_f32, dtype):
     N, C, H, W = img_nchw_f32.shape
     assert C == 3

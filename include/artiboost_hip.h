@@ -100,6 +100,16 @@ int ab_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, float* out, v
 int ab_avgpool_bwd(const float* g, int dtype, int N, int HW, int C, void* dx, int accumulate, void* stream);
 int ab_cast_f32_bf16(const float* src, long n, void* dst, void* stream);
 int ab_transpose_oki(const float* src, int O, int K, int I, int dtype, void* dst, void* stream);
+/* The same re-layout for many tensors in one launch.  desc_dev: DEVICE array of ntensors descriptors; tensor t owns the
+ * workgroups [tile_begin, tile_begin + ceil(O/64)*K*ceil(I/64)); total_tiles = end of the last range.  Requires
+ * I % 4 == 0 and O % 8 == 0 (16-byte vectors).                                                                      */
+typedef struct ab_transpose_desc {
+    const void* src;   /* float [O][K][I] */
+    void* dst;         /* dtype [I][K][O] */
+    int32_t O, K, I;
+    int32_t tile_begin;
+} ab_transpose_desc;
+int ab_transpose_oki_batch(const ab_transpose_desc* desc_dev, int ntensors, long total_tiles, int dtype, void* stream);
 int ab_image_pad_nhwc4(const float* img_nchw, int dtype, int N, int H, int W, void* out, void* stream);
 
 /* ---- T1: global-norm clip + Adam on the flat parameter buffer ---------------------------------------------------

@@ -215,3 +215,22 @@ def test_maxpool_avgpool(shape, dtype):
     np.testing.assert_allclose(nchw(dx.float().cpu()).numpy(), x.grad.numpy(), **tol(dtype, x.grad))
     m = K.avgpool_fwd(xd)
     np.testing.assert_allclose(m.cpu().numpy(), x.detach().mean(3).mean(2).numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_transpose_oki_batch(dtype):
+    """One-launch OHWI -> IHWO re-layout of several weights == per-tensor permute (bit-exact cast)."""
+    from artiboost_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 9, 64), (128, 1, 64), (704, 1, 256), (256, 16, 512), (72, 3, 36), (8, 2, 4)]
+    pairs = []
+    for O, Kk, I in shapes:
+        src = torch.randn((O, Kk, I), generator=g).cuda()
+        pairs.append((src, torch.empty((I, Kk, O), dtype=dtype, device="cuda")))
+    plan = K.transpose_plan(pairs)
+    assert plan is not None
+    K.transpose_oki_batch(plan)
+    torch.cuda.synchronize()
+    for src, dst in pairs:
+        assert torch.equal(dst, src.permute(2, 1, 0).contiguous().to(dtype))
+    assert K.transpose_plan([(torch.zeros(8, 1, 6).cuda(), torch.empty((6, 1, 8), dtype=dtype, device="cuda"))]) is None
