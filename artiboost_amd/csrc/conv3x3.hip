@@ -37,7 +37,9 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsig
 
 template <int BM, int TW, int BN, int WM, int WN, int FLIP>
 __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args g) {
-    constexpr int TH = BM / TW, PW = TW + 2, PH = TH + 2;
+    // patch row pitch: TW + 2, or TW + 3 for TW = 8 so that consecutive patch rows alternate LDS half (pixel parity) --
+    // a 16-lane fragment read then spans two image rows with the same px set and would otherwise hit the same banks
+    constexpr int TH = BM / TW, PW = (TW == 8) ? TW + 3 : TW + 2, PH = TH + 2;
     constexpr int NPIX = PH * PW;
     constexpr int PI = (NPIX + 7) / 8;                 // 1-KiB instructions per patch
     constexpr int LP = (PI + 3) / 4;                   // per wave
@@ -260,23 +262,26 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args g) {
 
 template <int BM, int TW, int BN, int WM, int WN>
 static size_t c3_lds(int nchunks) {
-    constexpr int TH = BM / TW, NPIX = (TH + 2) * (TW + 2), PI = (NPIX + 7) / 8, LP = (PI + 3) / 4;
+    constexpr int TH = BM / TW, NPIX = (TH + 2) * ((TW == 8) ? TW + 3 : TW + 2), PI = (NPIX + 7) / 8, LP = (PI + 3) / 4;
     size_t need = (size_t)(nchunks > 1 ? 2 : 1) * LP * 4 * 1024 + 3 * BN * 128 + WM * BN * 8;
     size_t stage = (size_t)BM * (BN * 2 + 16);          // epilogue staging tile
     return need > stage ? need : stage;
 }
 
-// config choice: 0 = unsupported, 1 = <128,32,64,2,2>, 2 = <256,32,128,2,2>, 3 = <128,16,128,2,2>, 4 = <128,16,64,2,2>
+// config choice: 0 = unsupported, 1 = <128,32,64,2,2>, 2 = <256,32,128,2,2>, 3 = <128,16,128,2,2>, 4 = <128,16,64,2,2>,
+// 5 = <64,8,128,2,2>
 static int c3_config(int N, int H, int W, int C, int Cn) {
     if (C % 64 || Cn % 8 || getenv("AB_CONV3_OFF")) return 0;
     if (W >= 24) return (Cn <= 64) ? 1 : 2;
     if (W >= 12) return (Cn <= 64) ? 4 : 3;
+    if (W >= 5 && W <= 8 && H <= 8 && Cn > 64) return 5;      // one whole (<= 8x8) image per workgroup
     return 0;
 }
 static void c3_geom(int cfg, int* bm, int* tw, int* bn) {
     if (cfg == 1) { *bm = 128; *tw = 32; *bn = 64; }
     else if (cfg == 2) { *bm = 256; *tw = 32; *bn = 128; }
     else if (cfg == 3) { *bm = 128; *tw = 16; *bn = 128; }
+    else if (cfg == 5) { *bm = 64; *tw = 8; *bn = 128; }
     else { *bm = 128; *tw = 16; *bn = 64; }
 }
 
@@ -321,10 +326,12 @@ int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, i
         if (cfg == 1) return c3_launch<128, 32, 64, 2, 2, 1>(g, st);
         if (cfg == 2) return c3_launch<256, 32, 128, 2, 2, 1>(g, st);
         if (cfg == 3) return c3_launch<128, 16, 128, 2, 2, 1>(g, st);
+        if (cfg == 5) return c3_launch<64, 8, 128, 2, 2, 1>(g, st);
         return c3_launch<128, 16, 64, 2, 2, 1>(g, st);
     }
     if (cfg == 1) return c3_launch<128, 32, 64, 2, 2, 0>(g, st);
     if (cfg == 2) return c3_launch<256, 32, 128, 2, 2, 0>(g, st);
     if (cfg == 3) return c3_launch<128, 16, 128, 2, 2, 0>(g, st);
+    if (cfg == 5) return c3_launch<64, 8, 128, 2, 2, 0>(g, st);
     return c3_launch<128, 16, 64, 2, 2, 0>(g, st);
 }

@@ -16,6 +16,7 @@ struct ConvGemmArgs {
     int ktot;                   // Bw row length in elements
     int M;
     int relu;                   // apply ReLU in the epilogue (linear layers)
+    int nmajor;                 // conv_gemm2: walk the tiles N-major inside an XCD's range (weights > L2, see conv_gemm2_run)
     int8_t dh[CG_MAXTAPS], dw[CG_MAXTAPS];
     int koff[CG_MAXTAPS];
 };

@@ -15,12 +15,16 @@
 
 __device__ uint4 ab_zero_page[2];    // zero-initialised device memory: source of every out-of-range chunk
 
-template <int BM, int BN, int WM, int WN>
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WM, int WN, int NBUF = 3>
 __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;     // 32x32 MFMA tiles per wave
     constexpr int IA = BM / 8, IB = BN / 8;                 // 1-KiB load instructions (8 rows each) for the A / B tile
     constexpr int BUFSZ = (BM + BN) * 128;
-    constexpr int NBUF = 3;                                  // LDS ring: loads run two K-steps ahead of the MFMAs
+    // LDS ring of NBUF stages: loads run NBUF-1 K-steps ahead of the MFMAs.  The fill is latency-bound (bytes in flight
+    // per CU / L2 latency), so grids that put a single workgroup on a CU use a deeper ring (5) than those that co-run 2-3.
+    constexpr int PD = NBUF - 1;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUFSZ + BM * 4 + WM * BN * 8 + 3 * CG_MAXTAPS * 4];
     int* s_outpix = (int*)(smem + NBUF * BUFSZ);
     float* s_stat = (float*)(s_outpix + BM);                // [WM][BN][2]
@@ -40,8 +44,10 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, within = bid >> 3;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
-    const int tiles_n = (g.Cn + BN - 1) / BN;
-    const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+    const int tiles_n = (g.Cn + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    int tile_m, tile_n;
+    if (g.nmajor) { tile_n = logical / tiles_m; tile_m = logical - tile_n * tiles_m; }
+    else { tile_m = logical / tiles_n; tile_n = logical - tile_m * tiles_n; }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t* __restrict__ A = (const bf16_t*)g.A;
     const bf16_t* __restrict__ Bw = (const bf16_t*)g.Bw;
@@ -113,20 +119,26 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // 3-deep ring with counted waits (raw s_barrier: __syncthreads() would drain vmcnt to 0 and kill the overlap):
-    //   step s:  wait until only step s+1's loads are in flight -> barrier (step-s tile visible to all waves, and all
-    //            waves are done reading the buffer of step s-1) -> issue step s+2 into that buffer -> MFMAs of step s
+    // ring with counted waits (raw s_barrier: __syncthreads() would drain vmcnt to 0 and kill the overlap):
+    //   step s:  wait until only the loads of steps s+1 .. s+PD-1 are in flight -> barrier (step-s tile visible to all
+    //            waves, and all waves are done reading the buffer of step s-1) -> issue step s+PD into that buffer ->
+    //            MFMAs of step s
     constexpr int L = NA + NB;                               // load instructions per wave per step
-    issue(0, 0);
-    if (nsteps > 1) issue(1, 1);
+#pragma unroll
+    for (int d = 0; d < PD; ++d) if (d < nsteps) issue(d, d);
     const int frow = lane & 31, fhalf = lane >> 5;
     int cur = 0;
     for (int step = 0; step < nsteps; ++step) {
-        if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // wait until only the later steps' loads (at most PD-1 of them) are still in flight
+        const int ahead = min(PD - 1, nsteps - 1 - step);
+        if (ahead >= 4) wait_vm<(PD >= 5 ? 4 : 0) * L>();
+        else if (ahead == 3) wait_vm<(PD >= 4 ? 3 : 0) * L>();
+        else if (ahead == 2) wait_vm<(PD >= 3 ? 2 : 0) * L>();
+        else if (ahead == 1) wait_vm<L>();
+        else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (step + 2 < nsteps) { int nb = cur + 2; if (nb >= NBUF) nb -= NBUF; issue(step + 2, nb); }
+        if (step + PD < nsteps) { int nb = cur + PD; if (nb >= NBUF) nb -= NBUF; issue(step + PD, nb); }
         const unsigned char* sa = smem + cur * BUFSZ;
         const unsigned char* sb = sa + BM * 128;
         auto read_frags = [&](int kk, uint4* fa, uint4* fb) {
@@ -264,11 +276,24 @@ int conv_gemm2_run(ConvGemmArgs& g, hipStream_t st) {
     if (g.Ca % 64) return AB_ESHAPE;
     int bm, bn; pick_tile2(g.M, g.Cn, g.ntaps * g.cpt, &bm, &bn);
     int tiles = ((g.M + bm - 1) / bm) * ((g.Cn + bn - 1) / bn);
+    // Tile order inside an XCD's contiguous id range.  M-major (default): an XCD streams a band of pixels against ALL the
+    // weights -- right when the weights fit its 4 MiB L2.  When they do not (l4: 512x4608 bf16 = 4.7 MB) every XCD thrashes
+    // on them; N-major gives each XCD one or two N tiles (1.2 MB of weights) and the whole, small, activation tensor.
+    static const int nm_env = getenv("AB_GEMM2_NMAJOR") ? atoi(getenv("AB_GEMM2_NMAJOR")) : -1;
+    const long wbytes = (long)g.Cn * g.ktot * 2, abytes = (long)g.N * g.Ha * g.Wa * g.Ca * 2;
+    g.nmajor = nm_env >= 0 ? nm_env : (wbytes > (3L << 20) && abytes <= (8L << 20) && g.Cn > bn);
+    static const int deep_max = getenv("AB_GEMM2_DEEP") ? atoi(getenv("AB_GEMM2_DEEP")) : 0;
+    const bool deep = tiles <= deep_max && g.ntaps * g.cpt >= 8;     // one workgroup per CU: deeper prefetch ring
     if (bm == 256 && bn == 64) conv_gemm2_kernel<256, 64, 4, 1><<<tiles, 256, 0, st>>>(g);
     else if (bm == 128 && bn == 128) conv_gemm2_kernel<128, 128, 2, 2><<<tiles, 256, 0, st>>>(g);
     else if (bm == 128 && bn == 64) conv_gemm2_kernel<128, 64, 2, 2><<<tiles, 256, 0, st>>>(g);
-    else if (bm == 64 && bn == 128) conv_gemm2_kernel<64, 128, 2, 2><<<tiles, 256, 0, st>>>(g);
-    else conv_gemm2_kernel<64, 64, 2, 2><<<tiles, 256, 0, st>>>(g);
+    else if (bm == 64 && bn == 128) {
+        if (deep) conv_gemm2_kernel<64, 128, 2, 2, 5><<<tiles, 256, 0, st>>>(g);
+        else conv_gemm2_kernel<64, 128, 2, 2><<<tiles, 256, 0, st>>>(g);
+    } else {
+        if (deep) conv_gemm2_kernel<64, 64, 2, 2, 5><<<tiles, 256, 0, st>>>(g);
+        else conv_gemm2_kernel<64, 64, 2, 2><<<tiles, 256, 0, st>>>(g);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
