@@ -17,6 +17,11 @@ struct ConvGemmArgs {
     int M;
     int relu;                   // apply ReLU in the epilogue (linear layers)
     int nmajor;                 // conv_gemm2: walk the tiles N-major inside an XCD's range (weights > L2, see conv_gemm2_run)
+    // conv_gemm2 only: nclass > 1 runs the output-parity classes of a strided data gradient in ONE grid.  Class c owns the
+    // M tiles [c*tiles_m, (c+1)*tiles_m), writes output pixels (out_oh, out_ow) = (cls_oh[c], cls_ow[c]) and uses the taps
+    // [4c, 4c + cls_ntaps[c]) of dh/dw/koff (0 taps: the class receives no gradient -> zeros / the addend).
+    int nclass;
+    int cls_ntaps[4]; int cls_oh[4], cls_ow[4];
     int8_t dh[CG_MAXTAPS], dw[CG_MAXTAPS];
     int koff[CG_MAXTAPS];
 };

@@ -302,6 +302,34 @@ extern "C" int ab_conv2d_dgrad(const void* dy, const void* wt, void* dx, int dty
         int rc = conv3x3_run(dy, wt, dx, N, H, W, Cout, Cin, 1, addend, nullptr, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
+    if (stride == 2 && kh <= 4 && kw <= 4 && use_v2(dtype, false, Cout)) {
+        // all four output-parity classes in one grid (each alone fills half the chip or less)
+        ConvGemmArgs g = {};
+        g.A = dy; g.Bw = wt; g.Out = dx; g.addend = addend;
+        g.N = N; g.Ha = Ho; g.Wa = Wo; g.Ca = Cout;
+        g.Ho = H; g.Wo = W; g.Cn = Cin;
+        g.P = H / 2; g.Q = W / 2; g.out_sh = g.out_sw = 2;
+        g.a_sh = g.a_sw = 1; g.cpt = Cout / 64; g.ktot = kh * kw * Cout; g.M = N * g.P * g.Q;
+        g.nclass = 4;
+        int maxt = 0;
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+            const int c = a * 2 + b;
+            int nt = 0;
+            for (int i = 0; i < kh; ++i) {
+                if ((a + pad - i) % 2) continue;
+                for (int j = 0; j < kw; ++j) {
+                    if ((b + pad - j) % 2) continue;
+                    g.dh[c * 4 + nt] = (int8_t)((a + pad - i) / 2); g.dw[c * 4 + nt] = (int8_t)((b + pad - j) / 2);
+                    g.koff[c * 4 + nt] = (i * kw + j) * Cout; ++nt;
+                }
+            }
+            g.cls_ntaps[c] = nt; g.cls_oh[c] = a; g.cls_ow[c] = b;
+            if (nt > maxt) maxt = nt;
+        }
+        g.ntaps = maxt;
+        int rc = conv_gemm2_run(g, as_stream(stream));
+        if (rc != AB_ESHAPE) return rc;
+    }
     for (int a = 0; a < stride; ++a) for (int b = 0; b < stride; ++b) {
         ConvGemmArgs g = {};
         g.A = dy; g.Bw = wt; g.Out = dx; g.addend = addend; g.stats = stats;

@@ -31,12 +31,6 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
     // tap tables copied to LDS: indexing the kernarg arrays with the runtime tap id compiles to VMEM loads inside the K
     // loop, and the vmcnt wait for those would drain the in-flight LDS-DMA prefetch
     int* s_tap = (int*)(s_stat + WM * BN * 2);              // [3][CG_MAXTAPS] = dh, dw, koff
-    if (threadIdx.x < CG_MAXTAPS) {
-        s_tap[threadIdx.x] = g.dh[threadIdx.x];
-        s_tap[CG_MAXTAPS + threadIdx.x] = g.dw[threadIdx.x];
-        s_tap[2 * CG_MAXTAPS + threadIdx.x] = g.koff[threadIdx.x];
-    }
-    __syncthreads();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WN, wave_n = wave % WN;
@@ -44,10 +38,23 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, within = bid >> 3;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
-    const int tiles_n = (g.Cn + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    const int tiles_n = (g.Cn + BN - 1) / BN, tiles_mc = (g.M + BM - 1) / BM;      // M tiles per parity class
+    const int tiles_m = tiles_mc * (g.nclass > 1 ? g.nclass : 1);
     int tile_m, tile_n;
     if (g.nmajor) { tile_n = logical / tiles_m; tile_m = logical - tile_n * tiles_m; }
     else { tile_m = logical / tiles_n; tile_n = logical - tile_m * tiles_n; }
+    int ntaps = g.ntaps, out_oh = g.out_oh, out_ow = g.out_ow, tap0 = 0;
+    if (g.nclass > 1) {
+        const int cls = tile_m / tiles_mc;
+        tile_m -= cls * tiles_mc;
+        ntaps = g.cls_ntaps[cls]; out_oh = g.cls_oh[cls]; out_ow = g.cls_ow[cls]; tap0 = cls * 4;
+    }
+    if (threadIdx.x < CG_MAXTAPS - tap0) {
+        s_tap[threadIdx.x] = g.dh[tap0 + threadIdx.x];
+        s_tap[CG_MAXTAPS + threadIdx.x] = g.dw[tap0 + threadIdx.x];
+        s_tap[2 * CG_MAXTAPS + threadIdx.x] = g.koff[tap0 + threadIdx.x];
+    }
+    __syncthreads();
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t* __restrict__ A = (const bf16_t*)g.A;
     const bf16_t* __restrict__ Bw = (const bf16_t*)g.Bw;
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
         a_base[j] = (long)n * g.Ha * g.Wa;
         a_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;      // element offset of the logical chunk this lane fetches
         if (lslot == 0 && ii < IA) {
-            int op = (n * g.Ho + p * g.out_sh + g.out_oh) * g.Wo + q * g.out_sw + g.out_ow;
+            int op = (n * g.Ho + p * g.out_sh + out_oh) * g.Wo + q * g.out_sw + out_ow;
             s_outpix[r] = a_ok[j] ? op : -1;
         }
     }
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
         b_off[j] = (long)(b_ok[j] ? col : 0) * g.ktot;
         b_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;
     }
-    const int nsteps = g.ntaps * g.cpt;
+    const int nsteps = ntaps * g.cpt;
 
     auto issue = [&](int step, int buf) {
         const int t = step / g.cpt, c0 = (step - t * g.cpt) * 64;
@@ -275,7 +282,7 @@ int conv_gemm2_mtiles(int M, int Cn, int nsteps) {
 int conv_gemm2_run(ConvGemmArgs& g, hipStream_t st) {
     if (g.Ca % 64) return AB_ESHAPE;
     int bm, bn; pick_tile2(g.M, g.Cn, g.ntaps * g.cpt, &bm, &bn);
-    int tiles = ((g.M + bm - 1) / bm) * ((g.Cn + bn - 1) / bn);
+    int tiles = ((g.M + bm - 1) / bm) * ((g.Cn + bn - 1) / bn) * (g.nclass > 1 ? g.nclass : 1);
     // Tile order inside an XCD's contiguous id range.  M-major (default): an XCD streams a band of pixels against ALL the
     // weights -- right when the weights fit its 4 MiB L2.  When they do not (l4: 512x4608 bf16 = 4.7 MB) every XCD thrashes
     // on them; N-major gives each XCD one or two N tiles (1.2 MB of weights) and the whole, small, activation tensor.
