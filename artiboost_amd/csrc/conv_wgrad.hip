@@ -225,6 +225,10 @@ static void pick_wgrad(int M, int Cout, int jtot, int* bi, int* bj, int* nslices
 
 int wgrad3x3_slices(int N, int H, int W, int Cin, int Cout);
 int wgrad3x3_run(const void* x, const void* dy, float* slabs, int N, int H, int W, int Cin, int Cout, hipStream_t st);
+int wgrad_gemm2_slices(int M, int Cout, int Cin, int ntaps);
+int wgrad_gemm2_max_slices(int M, int Cout, int jtot);
+int wgrad_gemm2_run(const void* x, const void* dy, float* slabs, int N, int H, int W, int Cin, int Cout, int kh, int kw,
+                    int stride, int pad, hipStream_t st);
 
 extern "C" long ab_conv2d_wgrad_workspace(int M, int Cout, int jtot) {
     int bi, bj, ns, rows; pick_wgrad(M, Cout, jtot, &bi, &bj, &ns, &rows);
@@ -234,6 +238,8 @@ extern "C" long ab_conv2d_wgrad_workspace(int M, int Cout, int jtot) {
         long alt = (512 + tiles) * 64 * 576 * 4;
         if (alt > bytes) bytes = alt;
     }
+    long alt2 = (long)wgrad_gemm2_max_slices(M, Cout, jtot) * Cout * jtot * 4;
+    if (alt2 > bytes) bytes = alt2;
     return bytes;
 }
 
@@ -273,6 +279,18 @@ extern "C" int ab_conv2d_wgrad(const void* x, const void* dy, float* dw, int dty
             if (rc) return rc;
             long slab = (long)Cout * 9 * Cin;
             wgrad_reduce<<<wgrad_reduce_blocks(slab), 256, 0, as_stream(stream)>>>((float*)workspace, ns, slab, 9 * Cin, 9 * Cin, dw, accumulate, 0);
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? 0 : (int)e;
+        }
+    }
+    if (dtype == AB_DT_BF16) {
+        const int M = N * ((H + 2 * pad - kh) / stride + 1) * ((W + 2 * pad - kw) / stride + 1);
+        int ns = wgrad_gemm2_slices(M, Cout, Cin, kh * kw);
+        if (ns > 0) {
+            int rc = wgrad_gemm2_run(x, dy, (float*)workspace, N, H, W, Cin, Cout, kh, kw, stride, pad, as_stream(stream));
+            if (rc) return rc;
+            long slab = (long)Cout * kh * kw * Cin;
+            wgrad_reduce<<<wgrad_reduce_blocks(slab), 256, 0, as_stream(stream)>>>((float*)workspace, ns, slab, kh * kw * Cin, kh * kw * Cin, dw, accumulate, 0);
             hipError_t e = hipGetLastError();
             return e == hipSuccess ? 0 : (int)e;
         }

@@ -1,0 +1,251 @@
+// Generic weight gradient (any tap set / stride), bf16, direct-to-LDS operands:
+//
+//   dW[co][tap][ci] = sum over output pixels m of dy[m][co] * x[pix(m, tap)][ci]
+//
+// Same GEMM as wgrad_kernel (conv_wgrad.hip) -- which stages through registers with one __syncthreads per 32 rows and is
+// latency-bound -- rebuilt on the scheme of the other fast kernels: both operand tiles (64 reduction rows per step) are
+// DMA'd straight into a 3-deep LDS ring (global_load_lds_dwordx4 from inline asm, counted s_waitcnt vmcnt, raw s_barrier),
+// and, being reduction-major in HBM, are read as MFMA fragments through the transpose read ds_read_b64_tr_b16.
+// A workgroup owns BI output channels x BJ columns of ONE tap (BJ | Cin) over a slice of the pixels; slices write
+// separate fp32 slabs that wgrad_reduce sums in fixed order.
+//
+// LDS image of a tile: row r (a pixel) at byte r*P, P = 2*B (128 or 256 bytes, lane-linear DMA so no padding); the
+// 16-byte chunk c of a row is stored at slot c ^ (f(r) << 2) with f(r) = (r >> 1) & 1 for P = 128 and r & 3 for P = 256:
+// the four consecutive rows x 64 bytes a transpose read touches then sit on four distinct 64-byte bank groups.
+// Pixel -> (image, row, col) uses host-made multiply-shift reciprocals (exact and overflow-free for m < 2^21).
+#include "conv_common.h"
+
+typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) short4_t lds_short4;
+
+static __device__ uint4 wg2_zero_page[2];
+
+struct Wg2Args {
+    const void* X; const void* DY; float* slabs;
+    int N, Ha, Wa, Ca;          // x tensor
+    int P, Q, Cout;             // dy tensor [N,P,Q,Cout]
+    int stride;
+    int ntaps, Cin, jtot;
+    int M, rows_per_slice;
+    unsigned long long magic_pq, magic_q;     // floor(2^42 / d) + 1
+    int8_t dh[16], dw[16];
+};
+
+__device__ __forceinline__ int fastdiv(int n, unsigned long long magic) {
+    return (int)(((unsigned long long)(unsigned)n * magic) >> 42);
+}
+
+template <int B> __device__ __forceinline__ int swz(int row) { return (B == 64) ? ((row >> 1) & 1) : (row & 3); }
+
+__device__ __forceinline__ uint4 wg2_tr_pair(unsigned lo_addr, unsigned hi_addr) {
+    short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(size_t)lo_addr);
+    short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(size_t)hi_addr);
+    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_gemm2_kernel(Wg2Args g) {
+    constexpr int BR = 64;                                  // reduction rows per step
+    constexpr int PA = BI * 2, PB = BJ * 2;                 // row pitches (bytes)
+    constexpr int RA = 1024 / PA, RB = 1024 / PB;           // rows per 1-KiB DMA instruction
+    constexpr int IA = BR / RA, IB = BR / RB;               // instructions per tile
+    constexpr int LA = IA / 4, LB = IB / 4;                 // per wave
+    constexpr int ABYTES = BR * PA, STAGE = BR * (PA + PB);
+    constexpr int NBUF = 3;
+    constexpr int TI = BI / 64, TJ = BJ / 64;               // 32x32 tiles per wave (waves 2 x 2)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * STAGE];
+    __shared__ int s_xoff[2][BR];                           // element offset of each row's input pixel (-1: padding / past the end)
+    const unsigned lds0 = lds_addr_of(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_i = wave >> 1, wave_j = wave & 1;
+    const int tiles_j = g.jtot / BJ;
+    const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x - tile_i * tiles_j;
+    const int i0 = tile_i * BI, j0 = tile_j * BJ;
+    const int tap = j0 / g.Cin, ci0 = j0 - tap * g.Cin;
+    const int dh = g.dh[tap], dw = g.dw[tap];               // read once, before any DMA is in flight
+    const int r_begin = blockIdx.y * g.rows_per_slice;
+    const int r_end = min(g.M, r_begin + g.rows_per_slice);
+    const int PQ = g.P * g.Q;
+    const bf16_t* __restrict__ X = (const bf16_t*)g.X;
+    const bf16_t* __restrict__ DY = (const bf16_t*)g.DY;
+    const bf16_t* zp = (const bf16_t*)wg2_zero_page;
+
+    // per-lane DMA assignment: instruction ii covers rows ii*R .. ii*R+R-1; lane -> (row in instr, slot); the lane fetches
+    // the logical chunk that belongs in its slot
+    int a_row[LA], a_col[LA], b_row[LB], b_col[LB];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        constexpr int LPR = PA / 16;                        // lanes (chunks) per row
+        int r = (wave * LA + j) * RA + lane / LPR, slot = lane % LPR;
+        a_row[j] = r; a_col[j] = (slot ^ (swz<BI>(r) << 2)) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        constexpr int LPR = PB / 16;
+        int r = (wave * LB + j) * RB + lane / LPR, slot = lane % LPR;
+        b_row[j] = r; b_col[j] = (slot ^ (swz<BJ>(r) << 2)) * 8;
+    }
+    // The pixel -> input-offset arithmetic (two divisions per row) is done ONCE per row by the first wave and handed to the
+    // loaders through a small LDS table, two steps ahead: as per-load VALU work it outweighed the MFMAs of a step.
+    auto make_table = [&](int rbase, int slot) {
+        if (tid < BR) {
+            int m = rbase + tid, off = -1;
+            if (m < r_end) {
+                int n = fastdiv(m, g.magic_pq), rem = m - n * PQ;
+                int p = fastdiv(rem, g.magic_q), q = rem - p * g.Q;
+                int hi = p * g.stride + dh, wi = q * g.stride + dw;
+                if ((unsigned)hi < (unsigned)g.Ha && (unsigned)wi < (unsigned)g.Wa) off = ((n * g.Ha + hi) * g.Wa + wi) * g.Ca + ci0;
+            }
+            s_xoff[slot][tid] = off;
+        }
+    };
+    auto issue = [&](int rbase, int buf, int slot) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            int m = rbase + a_row[j];
+            const bf16_t* src = m < r_end ? DY + ((long)m * g.Cout + i0 + a_col[j]) : zp;
+            glds16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + (wave * LA + j) * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) {
+            int off = s_xoff[slot][b_row[j]];
+            const bf16_t* src = off >= 0 ? X + (off + b_col[j]) : zp;
+            glds16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + ABYTES + (wave * LB + j) * 1024));
+        }
+    };
+
+    // fragment bases (transpose-read geometry, see conv_wgrad.hip): 16-lane group grp, k row = (grp>>1)*8 + (l16>>2) [+4],
+    // columns (grp&1)*16 + (l16&3)*4 .. +3 of the wave's 32-wide tile
+    const int grp = lane >> 4, l16 = lane & 15;
+    const int krow = (grp >> 1) * 8 + (l16 >> 2), csub = (grp & 1) * 16 + (l16 & 3) * 4;
+    unsigned a_base[TI][2], b_base[TJ][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = krow + 4 * h;
+#pragma unroll
+        for (int a = 0; a < TI; ++a) {
+            int col = (wave_i * TI + a) * 32 + csub;
+            a_base[a][h] = lds0 + r * PA + (((col >> 3) ^ (swz<BI>(r) << 2)) << 4) + (col & 7) * 2;
+        }
+#pragma unroll
+        for (int b = 0; b < TJ; ++b) {
+            int col = (wave_j * TJ + b) * 32 + csub;
+            b_base[b][h] = lds0 + ABYTES + r * PB + (((col >> 3) ^ (swz<BJ>(r) << 2)) << 4) + (col & 7) * 2;
+        }
+    }
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    constexpr int L = LA + LB;
+    const int nsteps = (r_end - r_begin + BR - 1) / BR;
+    // tables: step s uses slot s & 1; the table of step s+3 is written during step s (its slot was last read at step s-1's
+    // issue, i.e. before this step's barrier) and read at step s+1's issue (after the next barrier)
+    make_table(r_begin, 0);
+    make_table(r_begin + BR, 1);
+    __syncthreads();
+    if (nsteps > 0) issue(r_begin, 0, 0);
+    if (nsteps > 1) issue(r_begin + BR, 1, 1);
+    __syncthreads();                                         // both tables consumed (s_waitcnt lgkmcnt is implied by use)
+    make_table(r_begin + 2 * BR, 0);
+    int cur = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (step + 2 < nsteps) { int nb = cur + 2; if (nb >= NBUF) nb -= NBUF; issue(r_begin + (step + 2) * BR, nb, step & 1); }
+        make_table(r_begin + (step + 3) * BR, (step + 1) & 1);
+        const unsigned so = cur * STAGE;
+#pragma unroll
+        for (int s = 0; s < BR / 16; ++s) {
+            uint4 fa[TI], fb[TJ];
+#pragma unroll
+            for (int a = 0; a < TI; ++a) fa[a] = wg2_tr_pair(a_base[a][0] + so + s * 16 * PA, a_base[a][1] + so + s * 16 * PA);
+#pragma unroll
+            for (int b = 0; b < TJ; ++b) fb[b] = wg2_tr_pair(b_base[b][0] + so + s * 16 * PB, b_base[b][1] + so + s * 16 * PB);
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+                for (int b = 0; b < TJ; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a]),
+                                                                       __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+        }
+        if (++cur == NBUF) cur = 0;
+    }
+    float* out = g.slabs + (long)blockIdx.y * g.Cout * g.jtot;
+#pragma unroll
+    for (int a = 0; a < TI; ++a)
+#pragma unroll
+        for (int b = 0; b < TJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = i0 + (wave_i * TI + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                int col = j0 + (wave_j * TJ + b) * 32 + (lane & 31);
+                out[(long)row * g.jtot + col] = acc[a][b][r];
+            }
+}
+
+static void wg2_pick(int M, int Cout, int Cin, int jtot, int* bi, int* bj, int* ns, int* rows) {
+    *bi = (Cout % 128 == 0) ? 128 : 64;
+    *bj = (Cin % 256 == 0 && *bi == 128) ? 256 : (Cin % 128 == 0) ? 128 : 64;
+    long tiles = (long)(Cout / *bi) * (jtot / *bj);
+    // workgroups that fit on a CU side by side (3 x 64 x (BI+BJ) x 2 bytes of LDS ring each): aim at one full wave of them
+    const int per_cu = (160 * 1024) / (3 * 64 * (*bi + *bj) * 2 + 1024);
+    static int target_env = getenv("AB_WG2_TARGET") ? atoi(getenv("AB_WG2_TARGET")) : 0;
+    const int target = target_env ? target_env : 256 * (per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu);
+    int want = (int)((target + tiles - 1) / tiles);
+    int maxs = (M + 511) / 512;                              // at least 512 pixels (8 steps) per slice
+    int n = want < 1 ? 1 : want; if (n > maxs) n = maxs; if (n < 1) n = 1; if (n > 512) n = 512;
+    int r = (M + n - 1) / n; r = (r + 63) / 64 * 64;
+    *ns = (M + r - 1) / r; *rows = r;
+}
+
+// slabs needed (0: shape not handled by this kernel)
+int wgrad_gemm2_slices(int M, int Cout, int Cin, int ntaps) {
+    if (Cout % 64 || Cin % 64 || ntaps > 16 || M >= (1 << 21) || getenv("AB_WGRAD2_OFF")) return 0;
+    int bi, bj, ns, rows; wg2_pick(M, Cout, Cin, ntaps * Cin, &bi, &bj, &ns, &rows);
+    return ns;
+}
+
+int wgrad_gemm2_run(const void* x, const void* dy, float* slabs, int N, int H, int W, int Cin, int Cout, int kh, int kw,
+                    int stride, int pad, hipStream_t st) {
+    Wg2Args g = {};
+    g.X = x; g.DY = dy; g.slabs = slabs;
+    g.N = N; g.Ha = H; g.Wa = W; g.Ca = Cin;
+    g.P = (H + 2 * pad - kh) / stride + 1; g.Q = (W + 2 * pad - kw) / stride + 1; g.Cout = Cout;
+    g.stride = stride; g.ntaps = kh * kw; g.Cin = Cin; g.jtot = kh * kw * Cin; g.M = N * g.P * g.Q;
+    if (!wgrad_gemm2_slices(g.M, Cout, Cin, g.ntaps)) return AB_ESHAPE;
+    for (int i = 0; i < kh; ++i) for (int j = 0; j < kw; ++j) { g.dh[i * kw + j] = (int8_t)(i - pad); g.dw[i * kw + j] = (int8_t)(j - pad); }
+    g.magic_pq = (1ull << 42) / (unsigned long long)(g.P * g.Q) + 1;
+    g.magic_q = (1ull << 42) / (unsigned long long)g.Q + 1;
+    int bi, bj, ns, rows; wg2_pick(g.M, Cout, Cin, g.jtot, &bi, &bj, &ns, &rows);
+    g.rows_per_slice = rows;
+    dim3 grid((Cout / bi) * (g.jtot / bj), ns);
+    if (bi == 128 && bj == 256) wgrad_gemm2_kernel<128, 256><<<grid, 256, 0, st>>>(g);
+    else if (bi == 64 && bj == 256) wgrad_gemm2_kernel<64, 256><<<grid, 256, 0, st>>>(g);
+    else if (bi == 128 && bj == 128) wgrad_gemm2_kernel<128, 128><<<grid, 256, 0, st>>>(g);
+    else if (bi == 128 && bj == 64) wgrad_gemm2_kernel<128, 64><<<grid, 256, 0, st>>>(g);
+    else if (bi == 64 && bj == 128) wgrad_gemm2_kernel<64, 128><<<grid, 256, 0, st>>>(g);
+    else wgrad_gemm2_kernel<64, 64><<<grid, 256, 0, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// upper bound of the slab count for a (M, Cout, jtot) problem whatever its tap split (workspace sizing)
+int wgrad_gemm2_max_slices(int M, int Cout, int jtot) {
+    if (Cout % 64 || jtot % 64 || M >= (1 << 21)) return 0;
+    long ti = Cout / 128 > 0 ? Cout / 128 : 1, tj = jtot / 128 > 0 ? jtot / 128 : 1;
+    const int target = 512;
+    long want = (target + ti * tj - 1) / (ti * tj), maxs = (M + 511) / 512;
+    long n = want < maxs ? want : maxs; if (n < 1) n = 1; if (n > 512) n = 512;
+    return (int)n + 1;
+}
