@@ -28,6 +28,10 @@ template <> __device__ __forceinline__ void vstore<bf16_t>(bf16_t* p, const floa
     *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
 // rows of the [M][C] matrix reduced by one workgroup: ~1024 workgroups for large M, never fewer than 16 rows (the per-lane
 // row loop is a chain of dependent-latency loads; at small M short chains in more workgroups win)
 static inline int red_rows(long M) { long r = (M + 1023) / 1024; if (r < 16) r = 16; return (int)((r + 15) / 16 * 16); }
@@ -161,12 +165,48 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     }
 }
 
+// gradient of the 3x3/2 max-pool input at pixel (n,h,w), channels cv*V..: sum over the <= 4 windows that cover the pixel
+// of dpool where the recorded winner is this pixel (what maxpool_bwd_kernel stores, rounded to T the same way)
+template <typename T>
+__device__ __forceinline__ void pool_gather(const uint8_t* __restrict__ idx, const T* __restrict__ dpool, int n, int h, int w,
+                                            int H, int W, int C, int cv, float* acc) {
+    constexpr int V = Vec<T>::N;
+    const int Ho = H / 2, Wo = W / 2;
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
+        if (ho >= Ho) continue;
+        int dh = h - (ho * 2 - 1);
+        for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
+            if (wo >= Wo) continue;
+            int code = dh * 3 + (w - (wo * 2 - 1));
+            long o = (((long)n * Ho + ho) * Wo + wo) * C + cv * V;
+            uint8_t am[V];
+            if constexpr (V == 8) {
+                uint2 q = *(const uint2*)(idx + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { am[k] = (q.x >> (8 * k)) & 0xff; am[4 + k] = (q.y >> (8 * k)) & 0xff; }
+            } else {
+                uint32_t q = *(const uint32_t*)(idx + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) am[k] = (q >> (8 * k)) & 0xff;
+            }
+            float g[V]; vload<T>(dpool + o, g);
+#pragma unroll
+            for (int k = 0; k < V; ++k) if (am[k] == code) acc[k] += g[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = round_to<T>(acc[k]);
+}
+
 // ---------------------------------------------------------------- BN backward
 // pass 1: dz = dout * (out > 0 if relu); partial sums of dz and dz * xhat per channel
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ y, const float* __restrict__ bnp,
-                                                            long M, int C, int relu, int rows_per_block, float* __restrict__ part) {
+                                                            long M, int C, int relu, int rows_per_block, float* __restrict__ part,
+                                                            const uint8_t* __restrict__ pool_idx = nullptr, int pH = 0, int pW = 0) {
     constexpr int V = Vec<T>::N;
     const int vc = C / V, rl = 256 / vc;
     const int cv = threadIdx.x % vc, rr = threadIdx.x / vc;
@@ -182,7 +222,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         for (long r = r0 + rr; r < r1; r += rl) {
             long e = r * C + cv * V;
             float g[V], o[V], yy[V];
-            vload<T>(dout + e, g); vload<T>(y + e, yy);
+            if (pool_idx) {       // dout is the POOLED gradient: gather this pixel's share (fused max-pool backward)
+                int w = (int)(r % pW); long t = r / pW; int h = (int)(t % pH); int n = (int)(t / pH);
+                pool_gather<T>(pool_idx, dout, n, h, w, pH, pW, C, cv, g);
+            } else vload<T>(dout + e, g);
+            vload<T>(y + e, yy);
             if (relu == 1) vload<T>(out + e, o);
 #pragma unroll
             for (int i = 0; i < V; ++i) {
@@ -224,7 +268,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                            const T* __restrict__ y, const float* __restrict__ bnp,
                                                            const float* __restrict__ bwdp, long nvec, int C, long M,
-                                                           int relu, T* __restrict__ dy, T* __restrict__ dz_out) {
+                                                           int relu, T* __restrict__ dy, T* __restrict__ dz_out,
+                                                           const uint8_t* __restrict__ pool_idx = nullptr, int pH = 0, int pW = 0) {
     constexpr int V = Vec<T>::N;
     const float invM = 1.f / (float)M;
     const bool fixed = ((256 * V) % C) == 0;
@@ -241,7 +286,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         long e = i * V;
         if (!fixed) loadp((int)(e % C));
         float g[V], o[V], yy[V], d[V];
-        vload<T>(dout + e, g); vload<T>(y + e, yy);
+        if (pool_idx) {
+            long r = e / C; int cvv = (int)(e - r * C) / V;
+            int w = (int)(r % pW); long t = r / pW; int h = (int)(t % pH); int n = (int)(t / pH);
+            pool_gather<T>(pool_idx, dout, n, h, w, pH, pW, C, cvv, g);
+        } else vload<T>(dout + e, g);
+        vload<T>(y + e, yy);
         if (relu == 1) vload<T>(out + e, o);
 #pragma unroll
         for (int k = 0; k < V; ++k) {
@@ -271,9 +321,11 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 // ---------------------------------------------------------------- 3x3 / stride 2 / pad 1 max-pool (resnet.py:157)
 // forward also records WHICH of the 9 taps won (first maximum in row-major scan order == torch semantics), one byte
 // per output element; backward then gathers from the <= 4 windows covering an input pixel without re-reading x.
+// bnp != nullptr: the input is a raw conv output and relu(x*scale+shift), rounded to T exactly as ab_bn_apply would store
+// it, is pooled instead (the activation tensor is never materialised).
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C,
-                                                          T* __restrict__ out, uint8_t* __restrict__ idx) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bnp, int N, int H,
+                                                          int W, int C, T* __restrict__ out, uint8_t* __restrict__ idx) {
     constexpr int V = Vec<T>::N;
     const int Ho = H / 2, Wo = W / 2, vc = C / V;
     long nvec = (long)N * Ho * Wo * vc;
@@ -281,6 +333,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         int cv = (int)(i % vc); long pix = i / vc;
         int wo = (int)(pix % Wo); long t = pix / Wo; int ho = (int)(t % Ho); int n = (int)(t / Ho);
         float m[V]; uint8_t am[V];
+        float sc[V], sh[V];
+        if (bnp) {
+#pragma unroll
+            for (int k = 0; k < V; ++k) { sc[k] = bnp[cv * V + k]; sh[k] = bnp[C + cv * V + k]; }
+        }
 #pragma unroll
         for (int k = 0; k < V; ++k) { m[k] = -INFINITY; am[k] = 0; }
 #pragma unroll
@@ -290,6 +347,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
             for (int dw = 0; dw < 3; ++dw) {
                 int w = wo * 2 + dw - 1; if ((unsigned)w >= (unsigned)W) continue;
                 float f[V]; vload<T>(x + (((long)n * H + h) * W + w) * C + cv * V, f);
+                if (bnp) {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) f[k] = round_to<T>(fmaxf(f[k] * sc[k] + sh[k], 0.f));
+                }
 #pragma unroll
                 for (int k = 0; k < V; ++k) if (f[k] > m[k]) { m[k] = f[k]; am[k] = (uint8_t)(dh * 3 + dw); }
             }
@@ -527,23 +588,39 @@ extern "C" int ab_bn_apply(const void* y, const void* res, const float* bnp, int
     AB_LAUNCH_CHECK(); return 0;
 }
 
-extern "C" int ab_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C,
-                         int relu, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out,
-                         void* stream) {
-    if (!dout || !y || !bnp || !part || !bwdp || !dgamma || !dbeta || !dy || (relu == 1 && !out) || relu < 0 || relu > 2) return AB_EINVAL;
+static int bn_bwd_impl(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C,
+                       int relu, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out,
+                       const uint8_t* pool_idx, int pH, int pW, hipStream_t st) {
     int V = dtype == AB_DT_F32 ? 4 : 8;
     if (C % V || C / V > 256) return AB_ESHAPE;
     int np = ab_col_stats_nparts(M); int rl = 256 / (C / V); size_t sh = (size_t)rl * C * 2 * 4;
-    hipStream_t st = as_stream(stream);
-    DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, red_rows(M), part)),
-             (bn_bwd_reduce_kernel<bf16_t><<<np, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, red_rows(M), part)));
+    DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, red_rows(M), part, pool_idx, pH, pW)),
+             (bn_bwd_reduce_kernel<bf16_t><<<np, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, red_rows(M), part, pool_idx, pH, pW)));
     AB_LAUNCH_CHECK();
     bn_bwd_finalize_kernel<<<(C + 7) / 8, 1024, 0, st>>>(part, np, C, dgamma, dbeta, bwdp);
     AB_LAUNCH_CHECK();
     long nvec = M * C / V;
-    DISPATCH(dtype, (bn_bwd_apply_kernel<float><<<grid_for(nvec), 256, 0, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, bwdp, nvec, C, M, relu, (float*)dy, (float*)dz_out)),
-             (bn_bwd_apply_kernel<bf16_t><<<grid_for(nvec), 256, 0, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, bwdp, nvec, C, M, relu, (bf16_t*)dy, (bf16_t*)dz_out)));
+    DISPATCH(dtype, (bn_bwd_apply_kernel<float><<<grid_for(nvec), 256, 0, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, bwdp, nvec, C, M, relu, (float*)dy, (float*)dz_out, pool_idx, pH, pW)),
+             (bn_bwd_apply_kernel<bf16_t><<<grid_for(nvec), 256, 0, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, bwdp, nvec, C, M, relu, (bf16_t*)dy, (bf16_t*)dz_out, pool_idx, pH, pW)));
     AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C,
+                         int relu, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out,
+                         void* stream) {
+    if (!dout || !y || !bnp || !part || !bwdp || !dgamma || !dbeta || !dy || (relu == 1 && !out) || relu < 0 || relu > 2) return AB_EINVAL;
+    return bn_bwd_impl(dout, out, y, bnp, dtype, M, C, relu, part, bwdp, dgamma, dbeta, dy, dz_out, nullptr, 0, 0, as_stream(stream));
+}
+
+// Backward of  maxpool3x3/2( relu( bn(y) ) )  in the two BN passes: the pooled gradient dpool [N,H/2,W/2,C] is scattered
+// on the fly through the recorded winners (idx of ab_bn_relu_maxpool3x3s2_fwd), the ReLU mask is recomputed from y.
+extern "C" int ab_bn_relu_maxpool_bwd(const void* dpool, const void* idx, const void* y, const float* bnp, int dtype, int N,
+                                      int H, int W, int C, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy,
+                                      void* stream) {
+    if (!dpool || !idx || !y || !bnp || !part || !bwdp || !dgamma || !dbeta || !dy) return AB_EINVAL;
+    if ((H & 1) || (W & 1)) return AB_ESHAPE;
+    return bn_bwd_impl(dpool, nullptr, y, bnp, dtype, (long)N * H * W, C, 2, part, bwdp, dgamma, dbeta, dy, nullptr,
+                       (const uint8_t*)idx, H, W, as_stream(stream));
 }
 
 extern "C" int ab_add(const void* a, const void* b, int dtype, long n, void* out, void* stream) {
@@ -557,8 +634,17 @@ extern "C" int ab_add(const void* a, const void* b, int dtype, long n, void* out
 extern "C" int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* idx, void* stream) {
     int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
     long nvec = (long)N * (H / 2) * (W / 2) * C / V;
-    DISPATCH(dtype, (maxpool_fwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)x, N, H, W, C, (float*)out, (uint8_t*)idx)),
-             (maxpool_fwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)x, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
+    DISPATCH(dtype, (maxpool_fwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)x, nullptr, N, H, W, C, (float*)out, (uint8_t*)idx)),
+             (maxpool_fwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)x, nullptr, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+extern "C" int ab_bn_relu_maxpool3x3s2_fwd(const void* y, const float* bnp, int dtype, int N, int H, int W, int C, void* out,
+                                           void* idx, void* stream) {
+    if (!y || !bnp || !out) return AB_EINVAL;
+    int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
+    long nvec = (long)N * (H / 2) * (W / 2) * C / V;
+    DISPATCH(dtype, (maxpool_fwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)y, bnp, N, H, W, C, (float*)out, (uint8_t*)idx)),
+             (maxpool_fwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)y, bnp, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
     AB_LAUNCH_CHECK(); return 0;
 }
 extern "C" int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx,

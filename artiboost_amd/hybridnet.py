@@ -295,14 +295,16 @@ class HybridNet:
         return self.lp[e.offset:e.offset + e.numel].view(e.kshape)
 
     # ------------------------------------------------------------------ BN helper
-    def _bn(self, prefix, y, stats_part, count, res=None, relu=True):
+    def _bn_params(self, prefix, stats_part, count):
         p = self.p
         if self.training:
-            bnp = K.bn_finalize(stats_part, count, p.view(prefix + ".weight"), p.view(prefix + ".bias"),
+            return K.bn_finalize(stats_part, count, p.view(prefix + ".weight"), p.view(prefix + ".bias"),
+                                 p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
+        return K.bn_eval_params(p.view(prefix + ".weight"), p.view(prefix + ".bias"),
                                 p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
-        else:
-            bnp = K.bn_eval_params(p.view(prefix + ".weight"), p.view(prefix + ".bias"),
-                                   p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
+
+    def _bn(self, prefix, y, stats_part, count, res=None, relu=True):
+        bnp = self._bn_params(prefix, stats_part, count)
         out = K.bn_apply(y, bnp, res=res, relu=relu)
         return out, bnp
 
@@ -319,9 +321,13 @@ class HybridNet:
         H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
         S = {"xpad": xpad, "N": N, "HW": (H, W), "blocks": []}
         y0, st = K.conv2d_stem_fwd(xpad, self.w("backbone.conv1.weight"), H, W, want_stats=True)
-        a0, bnp0 = self._bn("backbone.bn1", y0, st, N * (H // 2) * (W // 2))
-        x, pool_idx = K.maxpool_fwd(a0)
-        S.update(y0=y0, a0=a0, bnp0=bnp0, pool_idx=pool_idx)
+        if self.fuse_stem:
+            bnp0 = self._bn_params("backbone.bn1", st, N * (H // 2) * (W // 2))
+            x, pool_idx = K.bn_relu_maxpool_fwd(y0, bnp0)      # BN + ReLU + 3x3/2 max-pool: the 128x128x64 activation is never stored
+        else:
+            a0, bnp0 = self._bn("backbone.bn1", y0, st, N * (H // 2) * (W // 2))
+            x, pool_idx = K.maxpool_fwd(a0)
+        S.update(y0=y0, bnp0=bnp0, pool_idx=pool_idx)
         inpl = 64
         for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET34_LAYERS), start=1):
             for b in range(nblk):
@@ -381,6 +387,8 @@ class HybridNet:
     # (B=64, 256x256, graph replay): 7366 samples/s with the side stream vs 7715 without -- co-scheduled workgroups evict
     # each other's L2 / LDS residency and the single-queue order is faster.  Kept as an opt-in (AB_WGRAD_OVERLAP=1).
     overlap_wgrad = os.environ.get("AB_WGRAD_OVERLAP", "0") == "1"
+    fuse_stem = os.environ.get("AB_STEM_FUSE", "1") != "0"       # stem BN+ReLU+max-pool as one pass (forward)
+    fuse_stem_bwd = os.environ.get("AB_STEM_FUSE_BWD", "0") == "1"   # ... and the gather-based fused backward
 
     def _wgrad_side(self, fn, *args, **kw):
         if not self.overlap_wgrad:
@@ -456,9 +464,12 @@ class HybridNet:
             else:
                 dout = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1, addend=dz)
         # ---- stem
-        da0 = K.maxpool_bwd(S["pool_idx"], dout, (S["a0"].shape[1], S["a0"].shape[2]))
-        dy0 = K.bn_bwd(da0, S["a0"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"),
-                       relu="recompute")
+        if self.fuse_stem_bwd:
+            dy0 = K.bn_relu_maxpool_bwd(dout, S["pool_idx"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"))
+        else:
+            y0 = S["y0"]
+            da0 = K.maxpool_bwd(S["pool_idx"], dout, (y0.shape[1], y0.shape[2]))
+            dy0 = K.bn_bwd(da0, None, y0, S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"), relu="recompute")
         H, W = S["HW"]
         self._wgrad_side(K.conv2d_stem_wgrad, S["xpad"], dy0, H, W, out=gv("backbone.conv1.weight"))
         self._wgrad_join()

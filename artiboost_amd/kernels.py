@@ -160,6 +160,29 @@ def maxpool_fwd(x, want_idx=True):
     return (o, idx) if want_idx else o
 
 
+def bn_relu_maxpool_fwd(y, bnp):
+    """maxpool3x3/2(relu(bn(y))) in one pass -> (pooled, idx); the full-resolution activation is never written."""
+    N, H, W, C = y.shape
+    o = _empty((N, H // 2, W // 2, C), y)
+    idx = torch.empty((N, H // 2, W // 2, C), dtype=torch.uint8, device=y.device)
+    L.check(L.lib().ab_bn_relu_maxpool3x3s2_fwd(L.ptr(y), L.ptr(bnp), L.i(L.dt(y)), L.i(N), L.i(H), L.i(W), L.i(C),
+                                                L.ptr(o), L.ptr(idx), L.stream()), "ab_bn_relu_maxpool3x3s2_fwd")
+    return o, idx
+
+
+def bn_relu_maxpool_bwd(dpool, idx, y, bnp, dgamma, dbeta):
+    """Backward of bn_relu_maxpool_fwd -> dy (gradient wrt the conv output y)."""
+    N, H, W, C = y.shape
+    lib = L.lib()
+    part = torch.empty((lib.ab_col_stats_nparts(L.l(N * H * W)), C, 2), dtype=torch.float32, device=y.device)
+    bwdp = torch.empty((2, C), dtype=torch.float32, device=y.device)
+    dy = torch.empty_like(y)
+    L.check(lib.ab_bn_relu_maxpool_bwd(L.ptr(dpool), L.ptr(idx), L.ptr(y), L.ptr(bnp), L.i(L.dt(y)), L.i(N), L.i(H), L.i(W),
+                                       L.i(C), L.ptr(part), L.ptr(bwdp), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy),
+                                       L.stream()), "ab_bn_relu_maxpool_bwd")
+    return dy
+
+
 def maxpool_bwd(idx, dout, in_hw):
     N, Ho, Wo, C = dout.shape
     H, W = in_hw

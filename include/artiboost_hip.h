@@ -95,6 +95,12 @@ int ab_col_sum(const void* x, int dtype, long M, int C, float* part, float* out,
 int ab_add(const void* a, const void* b, int dtype, long n, void* out, void* stream);
 /* idx: uint8 [N,H/2,W/2,C] winning tap (0..8, first maximum in row-major order); H,W describe the pool INPUT          */
 int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* idx, void* stream);
+/* Stem fusion: out = maxpool3x3/2(relu(y*bnp[0]+bnp[1])) without materialising the activation, and its backward through
+ * both BN passes (dpool: pooled gradient; part/bwdp as in ab_bn_bwd with M = N*H*W).                                 */
+int ab_bn_relu_maxpool3x3s2_fwd(const void* y, const float* bnp, int dtype, int N, int H, int W, int C, void* out,
+                                void* idx, void* stream);
+int ab_bn_relu_maxpool_bwd(const void* dpool, const void* idx, const void* y, const float* bnp, int dtype, int N, int H,
+                           int W, int C, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* stream);
 int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx, void* stream);
 int ab_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, float* out, void* stream);
 int ab_avgpool_bwd(const float* g, int dtype, int N, int HW, int C, void* dx, int accumulate, void* stream);

@@ -234,3 +234,25 @@ def test_transpose_oki_batch(dtype):
     for src, dst in pairs:
         assert torch.equal(dst, src.permute(2, 1, 0).contiguous().to(dtype))
     assert K.transpose_plan([(torch.zeros(8, 1, 6).cuda(), torch.empty((6, 1, 8), dtype=dtype, device="cuda"))]) is None
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (3, 6, 10, 128), (1, 128, 128, 64)])
+def test_fused_stem_bn_relu_maxpool(shape, dtype):
+    """BN+ReLU+max-pool in one pass (and its backward through the two BN passes) == the separate kernels, bit for bit."""
+    from artiboost_amd import kernels as K
+    N, H, W, C = shape
+    g = torch.Generator().manual_seed(H * W)
+    y = (torch.randn((N, H, W, C), generator=g) * 1.3 + 0.2).to(dtype).cuda()
+    gamma = (0.5 + torch.rand(C, generator=g)).cuda(); beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    bnp = K.bn_finalize(K.col_stats(y), N * H * W, gamma, beta)
+    a = K.bn_apply(y, bnp, relu=True)
+    ref_out, ref_idx = K.maxpool_fwd(a)
+    out, idx = K.bn_relu_maxpool_fwd(y, bnp)
+    assert torch.equal(out, ref_out) and torch.equal(idx, ref_idx)
+    dpool = torch.randn((N, H // 2, W // 2, C), generator=g).to(dtype).cuda()
+    dg0, db0, dg1, db1 = (torch.empty(C).cuda() for _ in range(4))
+    da = K.maxpool_bwd(ref_idx, dpool, (H, W))
+    ref_dy = K.bn_bwd(da, None, y, bnp, dg0, db0, relu="recompute")
+    dy = K.bn_relu_maxpool_bwd(dpool, idx, y, bnp, dg1, db1)
+    assert torch.equal(dy, ref_dy) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
