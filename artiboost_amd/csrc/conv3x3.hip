@@ -273,7 +273,11 @@ static size_t c3_lds(int nchunks) {
 static int c3_config(int N, int H, int W, int C, int Cn) {
     if (C % 64 || Cn % 8 || getenv("AB_CONV3_OFF")) return 0;
     if (W >= 24) return (Cn <= 64) ? 1 : 2;
-    if (W >= 12) return (Cn <= 64) ? 4 : 3;
+    if (W >= 12) {
+        static const int alt = getenv("AB_C3_ALT16") ? atoi(getenv("AB_C3_ALT16")) : 0;
+        if (alt && W <= 16 && H % 16 == 0 && Cn % 64 == 0) return 6;      // whole 16x16 image x 64 channels per workgroup
+        return (Cn <= 64) ? 4 : 3;
+    }
     if (W >= 5 && W <= 8 && H <= 8 && Cn > 64) return 5;      // one whole (<= 8x8) image per workgroup
     return 0;
 }
@@ -282,6 +286,7 @@ static void c3_geom(int cfg, int* bm, int* tw, int* bn) {
     else if (cfg == 2) { *bm = 256; *tw = 32; *bn = 128; }
     else if (cfg == 3) { *bm = 128; *tw = 16; *bn = 128; }
     else if (cfg == 5) { *bm = 64; *tw = 8; *bn = 128; }
+    else if (cfg == 6) { *bm = 256; *tw = 16; *bn = 64; }
     else { *bm = 128; *tw = 16; *bn = 64; }
 }
 
@@ -327,11 +332,13 @@ int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, i
         if (cfg == 2) return c3_launch<256, 32, 128, 2, 2, 1>(g, st);
         if (cfg == 3) return c3_launch<128, 16, 128, 2, 2, 1>(g, st);
         if (cfg == 5) return c3_launch<64, 8, 128, 2, 2, 1>(g, st);
+        if (cfg == 6) return c3_launch<256, 16, 64, 4, 1, 1>(g, st);
         return c3_launch<128, 16, 64, 2, 2, 1>(g, st);
     }
     if (cfg == 1) return c3_launch<128, 32, 64, 2, 2, 0>(g, st);
     if (cfg == 2) return c3_launch<256, 32, 128, 2, 2, 0>(g, st);
     if (cfg == 3) return c3_launch<128, 16, 128, 2, 2, 0>(g, st);
     if (cfg == 5) return c3_launch<64, 8, 128, 2, 2, 0>(g, st);
+    if (cfg == 6) return c3_launch<256, 16, 64, 4, 1, 0>(g, st);
     return c3_launch<128, 16, 64, 2, 2, 0>(g, st);
 }

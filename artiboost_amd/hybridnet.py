@@ -407,14 +407,24 @@ class HybridNet:
             torch.cuda.current_stream(self.p.device).wait_stream(self._wg_stream)
             self._wg_keep.clear()
 
-    def backward(self, dlogits, g_box6d):
+    def grad_split_offset(self):
+        """Element offset in the flat gradient where the parameters of layer4 + heads begin: backward(stage="late")
+        fills [offset, total) and backward(stage="early") fills [0, offset) (DDP overlap, train.TrainStep)."""
+        return self.p.entries["backbone.layer4.0.conv1.weight"].offset
+
+    def backward(self, dlogits=None, g_box6d=None, stage=None):
         """dlogits: gradient wrt the logits [N,h,w,22*32] (compute dtype); g_box6d [N,6] f32.
-        Fills self.p.grad (overwrites).  Returns nothing (no gradient to the image)."""
+        Fills self.p.grad (overwrites).  Returns nothing (no gradient to the image).
+        stage=None runs the whole backward; "late" runs box head, heat-map head and layer4 (68 % of the gradient bytes,
+        produced first) and parks the activation gradient; "early" continues with layer3 .. stem."""
         S, p, dt = self.saved, self.p, self.dtype
         if S is None:
             raise RuntimeError("backward() without a training-mode forward()")
         N = S["N"]
         gv = p.gview
+        if stage == "early":
+            dout, blocks = S.pop("_dout"), S.pop("_blocks_left")
+            return self._backward_trunk(S, dout, blocks)
         # ---- box head (f32)
         g3 = torch.zeros((N, 1, 1, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
         g3.view(N, BOX_OUT_PAD)[:, :6].copy_(g_box6d)
@@ -445,7 +455,18 @@ class HybridNet:
         dout = K.conv2d_fwd(dd1, self.w("hybrid_head.deconv_layers.0.weight"), 2, 1)
         K.avgpool_bwd(g_mean, dout, accumulate=True)
         # ---- backbone, last block first
-        for rec in reversed(S["blocks"]):
+        blocks = list(reversed(S["blocks"]))
+        if stage == "late":
+            n4 = sum(1 for r in blocks if r["pre"].startswith("backbone.layer4."))
+            dout = self._backward_blocks(dout, blocks[:n4])
+            S["_dout"], S["_blocks_left"] = dout, blocks[n4:]
+            self._wgrad_join()
+            return
+        self._backward_trunk(S, dout, blocks)
+
+    def _backward_blocks(self, dout, blocks):
+        gv = self.p.gview
+        for rec in blocks:
             pre, stride, x = rec["pre"], rec["stride"], rec["x"]
             dy2, dz = K.bn_bwd(dout, rec["out"], rec["y2"], rec["bnp2"], gv(pre + ".bn2.weight"), gv(pre + ".bn2.bias"),
                                relu=True, want_dz=True)
@@ -463,6 +484,11 @@ class HybridNet:
                                       addend=dx)
             else:
                 dout = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1, addend=dz)
+        return dout
+
+    def _backward_trunk(self, S, dout, blocks):
+        gv = self.p.gview
+        dout = self._backward_blocks(dout, blocks)
         # ---- stem
         if self.fuse_stem_bwd:
             dy0 = K.bn_relu_maxpool_bwd(dout, S["pool_idx"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"))

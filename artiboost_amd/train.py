@@ -7,6 +7,8 @@ resident in HBM and the parameters being updated is device work on one stream; p
 Adam bias corrections, CCV sample descriptors) go through small pinned -> device copies issued before the replay.
 With world_size > 1 the step is split in two graphs around the RCCL all-reduce of the flat gradient buffer, which
 runs on a side stream and overlaps with the render of the next batch."""
+import os
+
 import torch
 
 from .registry import Queries
@@ -17,9 +19,12 @@ def allreduce_flat_(g, world, group=None, bucket_elems=8 << 20):
     large enough to run RCCL at link rate over xGMI, small enough that the first bucket is on the wire while the
     later ones are still being enqueued).  Works for any backend (RCCL on GPU, gloo in the CPU tests)."""
     n = g.numel()
+    avg = torch.distributed.get_backend(group) == "nccl"      # RCCL averages in the collective; gloo has no AVG
+    op = torch.distributed.ReduceOp.AVG if avg else torch.distributed.ReduceOp.SUM
     for s in range(0, n, bucket_elems):
-        torch.distributed.all_reduce(g[s:s + bucket_elems], op=torch.distributed.ReduceOp.SUM, group=group)
-    g.mul_(1.0 / world)
+        torch.distributed.all_reduce(g[s:s + bucket_elems], op=op, group=group)
+    if not avg:
+        g.mul_(1.0 / world)
     return g
 
 
@@ -43,6 +48,12 @@ class TrainStep:
         self.g_opt = None
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.steps = 0
+        # DDP overlap: the backward is captured as two graphs.  "late" (box head, heat-map head, layer4) produces 68 % of
+        # the gradient bytes first; their all-reduce runs on the comm stream while "early" (layer3 .. stem) computes,
+        # so only the last 33 MB are exposed.  AB_DDP_SPLIT=1 forces the split on one GPU (tests), =0 disables it.
+        env = os.environ.get("AB_DDP_SPLIT", "")
+        self.split = bool(use_graph and fused_criterion and (self.world > 1 or env == "1") and env != "0")
+        self.g_bwd_early = None
         # Render/learn pipelining (the reference overlaps them through DataLoader worker processes,
         # artiboost_loader.py:195-260): the batch for step i+1 is rendered on a side stream while step i trains.
         # `rstatic` holds the render inputs of the NEXT batch and its own image buffer; the image is handed over by one
@@ -95,13 +106,22 @@ class TrainStep:
         kp3d, conf, stat = net.head_fwd(logits)
         o = self.fused(kp3d, net.last["box_raw"], net.last["box_raw"].shape[-1], st)
         dlogits = net.head_bwd(logits, kp3d, conf, stat, o["g_kp3d"])
-        net.backward(dlogits, o["g_box6d"])
+        net.backward(dlogits, o["g_box6d"], stage="late" if self._capturing_split else None)
         hb.flat_param.grad = hb.store.grad
         preds = dict(o, kp3d=kp3d, kp3d_confd=conf)
         return preds, o["losses"], o
 
+    _capturing_split = False
+
     def _optim(self):
         self.opt.step()
+
+    def _allreduce_range(self, lo, hi):
+        """Enqueue the averaging all-reduce of grad[lo:hi] on the comm stream, ordered after everything enqueued so far
+        on the compute stream."""
+        self.comm_stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.comm_stream):
+            allreduce_flat_(self.hb.store.grad[lo:hi], self.world, self.group)
 
     def _allreduce(self):
         """Average the flat gradient across ranks on the side stream (RCCL over xGMI), bucketed so the first buckets'
@@ -128,8 +148,19 @@ class TrainStep:
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
         self.g_fwd_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd_bwd):
-            self.out = self._fwd_bwd()
+        if self.split:
+            self._capturing_split = True
+            try:
+                with torch.cuda.graph(self.g_fwd_bwd):
+                    self.out = self._fwd_bwd()                       # ... up to and including layer4's backward
+                self.g_bwd_early = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_bwd_early, pool=self.g_fwd_bwd.pool()):
+                    self.hb.net.backward(stage="early")
+            finally:
+                self._capturing_split = False
+        else:
+            with torch.cuda.graph(self.g_fwd_bwd):
+                self.out = self._fwd_bwd()
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, pool=self.g_fwd_bwd.pool()):
             self._optim()
@@ -175,7 +206,15 @@ class TrainStep:
             self.crit.draw(self.dev)
             self.opt.advance_hyper()
             self.g_fwd_bwd.replay()
-            if self.world > 1:
+            if self.split:
+                off = self.hb.net.grad_split_offset()
+                if self.world > 1:
+                    self._allreduce_range(off, self.hb.store.grad.numel())
+                self.g_bwd_early.replay()
+                if self.world > 1:
+                    self._allreduce_range(0, off)
+                    torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
+            elif self.world > 1:
                 self._allreduce()
             self.g_opt.replay()
         self.steps += 1

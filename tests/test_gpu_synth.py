@@ -165,3 +165,45 @@ def test_pipelined_render_hands_over_next_batch():
         for k, v in ref.items():                      # ground truth in the learn buffers is still batch bi's
             if not k.startswith("_") and k != "image_nhwc4_padded":
                 assert torch.equal(static[k], v), k
+
+
+def _run_steps(monkeypatch, split, nsteps=6):
+    import yaml, os, random
+    from artiboost_amd import registry as R
+    from artiboost_amd.criterions import Criterion
+    from artiboost_amd.models import Arch
+    from artiboost_amd.optim import FusedClipAdam
+    from artiboost_amd.train import TrainStep
+    monkeypatch.setenv("AB_DDP_SPLIT", "1" if split else "0")
+    random.seed(7); torch.manual_seed(7); np.random.seed(7)
+    assets, loader = _loader(torch.bfloat16, bs=8, n=32, size=224)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16", INIT_SEED=3)
+    model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
+    crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+    hb = model.model_list[0]
+    opt = FusedClipAdam(model.models_params, lr=1e-3, max_norm=1.0, model=hb)
+    loader.prepare()
+    static = loader.new_static_batch()
+    loader.load_batch(static, 0)
+    model.train()
+    ts = TrainStep(model, crit, opt, static, use_graph=True, renderer=loader)
+    ts.static = static
+    assert ts.split == split
+    vals = []
+    for i in range(nsteps):
+        loader.load_batch(static, i % len(loader))
+        _, losses, _ = ts()
+        vals.append(losses.float().cpu().numpy().copy())
+    return np.stack(vals), hb.store.flat.detach().cpu().numpy().copy()
+
+
+def test_split_backward_graphs_match_single_graph(monkeypatch):
+    """The DDP-overlap capture (backward in two graphs around the layer4 boundary) runs the same kernels in the same
+    order as the single-graph step: losses and final weights are bit-identical."""
+    l0, w0 = _run_steps(monkeypatch, False)
+    l1, w1 = _run_steps(monkeypatch, True)
+    assert np.isfinite(l0).all()
+    np.testing.assert_array_equal(l0, l1)
+    np.testing.assert_array_equal(w0, w1)
