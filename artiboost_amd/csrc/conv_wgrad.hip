@@ -227,6 +227,8 @@ int wgrad3x3_slices(int N, int H, int W, int Cin, int Cout);
 int wgrad3x3_run(const void* x, const void* dy, float* slabs, int N, int H, int W, int Cin, int Cout, hipStream_t st);
 int wgrad_gemm2_slices(int M, int Cout, int Cin, int ntaps);
 int wgrad_gemm2_max_slices(int M, int Cout, int jtot);
+int wgrad_gemm2_stem_slices(int N, int H, int W, int Cout);
+int wgrad_gemm2_stem_run(const void* xpad, const void* dy, float* slabs, int N, int H, int W, int Cout, hipStream_t st);
 int wgrad_gemm2_run(const void* x, const void* dy, float* slabs, int N, int H, int W, int Cin, int Cout, int kh, int kw,
                     int stride, int pad, hipStream_t st);
 
@@ -309,6 +311,17 @@ extern "C" int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw,
                                     int Cout, void* workspace, void* stream) {
     if (!xpad || !dy || !dw || !workspace) return AB_EINVAL;
     if ((H & 1) || (W & 1) || Cout % 64) return AB_ESHAPE;
+    if (dtype == AB_DT_BF16) {
+        int ns = wgrad_gemm2_stem_slices(N, H, W, Cout);
+        if (ns > 0) {
+            int rc = wgrad_gemm2_stem_run(xpad, dy, (float*)workspace, N, H, W, Cout, as_stream(stream));
+            if (rc) return rc;
+            long slab = (long)Cout * 256, total = (long)Cout * 7 * 32;
+            wgrad_reduce<<<wgrad_reduce_blocks(total), 256, 0, as_stream(stream)>>>((float*)workspace, ns, slab, 256, 7 * 32, dw, 0, 1);
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? 0 : (int)e;
+        }
+    }
     WgradArgs g = {};
     g.X = xpad; g.DY = dy; g.slabs = (float*)workspace;
     g.N = N; g.Ha = H + 6; g.Wa = W + 8; g.Ca = 4;
@@ -319,5 +332,7 @@ extern "C" int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw,
 }
 
 extern "C" long ab_conv2d_stem_wgrad_workspace(int N, int H, int W, int Cout) {
-    return ab_conv2d_wgrad_workspace(N * (H / 2) * (W / 2), Cout, 256);
+    long a = ab_conv2d_wgrad_workspace(N * (H / 2) * (W / 2), Cout, 256);
+    long b = (long)(wgrad_gemm2_stem_slices(N, H, W, Cout) + 1) * Cout * 256 * 4;
+    return a > b ? a : b;
 }

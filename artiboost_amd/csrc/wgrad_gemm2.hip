@@ -44,7 +44,9 @@ __device__ __forceinline__ uint4 wg2_tr_pair(unsigned lo_addr, unsigned hi_addr)
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
-template <int BI, int BJ>
+// STEM: x is the zero-bordered NHWC4 image and a dW row is [8 kernel rows (7 + 1 pad)][8 px][4 ch] = 256 columns (see
+// ab_conv2d_stem_fwd); BJ = 256 covers all of them, the 64-byte segment of kernel row t comes from image row 2p + t.
+template <int BI, int BJ, bool STEM = false>
 __global__ __launch_bounds__(256) void wgrad_gemm2_kernel(Wg2Args g) {
     constexpr int BR = 64;                                  // reduction rows per step
     constexpr int PA = BI * 2, PB = BJ * 2;                 // row pitches (bytes)
@@ -63,8 +65,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm2_kernel(Wg2Args g) {
     const int tiles_j = g.jtot / BJ;
     const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x - tile_i * tiles_j;
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
-    const int tap = j0 / g.Cin, ci0 = j0 - tap * g.Cin;
-    const int dh = g.dh[tap], dw = g.dw[tap];               // read once, before any DMA is in flight
+    const int tap = STEM ? 0 : j0 / g.Cin, ci0 = STEM ? 0 : j0 - tap * g.Cin;
+    const int dh = STEM ? 0 : g.dh[tap], dw = STEM ? 0 : g.dw[tap];   // read once, before any DMA is in flight
     const int r_begin = blockIdx.y * g.rows_per_slice;
     const int r_end = min(g.M, r_begin + g.rows_per_slice);
     const int PQ = g.P * g.Q;
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(256) void wgrad_gemm2_kernel(Wg2Args g) {
     for (int j = 0; j < LB; ++j) {
         constexpr int LPR = PB / 16;
         int r = (wave * LB + j) * RB + lane / LPR, slot = lane % LPR;
-        b_row[j] = r; b_col[j] = (slot ^ (swz<BJ>(r) << 2)) * 8;
+        int c = slot ^ (swz<BJ>(r) << 2);
+        b_row[j] = r; b_col[j] = STEM ? (c >> 2) * g.Wa * 4 + (c & 3) * 8 : c * 8;
     }
     // The pixel -> input-offset arithmetic (two divisions per row) is done ONCE per row by the first wave and handed to the
     // loaders through a small LDS table, two steps ahead: as per-load VALU work it outweighed the MFMAs of a step.
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm2_kernel(Wg2Args g) {
                 int n = fastdiv(m, g.magic_pq), rem = m - n * PQ;
                 int p = fastdiv(rem, g.magic_q), q = rem - p * g.Q;
                 int hi = p * g.stride + dh, wi = q * g.stride + dw;
-                if ((unsigned)hi < (unsigned)g.Ha && (unsigned)wi < (unsigned)g.Wa) off = ((n * g.Ha + hi) * g.Wa + wi) * g.Ca + ci0;
+                if (STEM || ((unsigned)hi < (unsigned)g.Ha && (unsigned)wi < (unsigned)g.Wa)) off = ((n * g.Ha + hi) * g.Wa + wi) * g.Ca + ci0;
             }
             s_xoff[slot][tid] = off;
         }
@@ -248,4 +251,34 @@ int wgrad_gemm2_max_slices(int M, int Cout, int jtot) {
     long want = (target + ti * tj - 1) / (ti * tj), maxs = (M + 511) / 512;
     long n = want < maxs ? want : maxs; if (n < 1) n = 1; if (n > 512) n = 512;
     return (int)n + 1;
+}
+
+// Stem weight gradient (xpad: zero-bordered NHWC4 image [N, H+6, W+8, 4]; dy [N, H/2, W/2, Cout]); slabs hold
+// [Cout][8][8][4] rows.  Returns the slab count, or AB_ESHAPE (< 0) when not handled.
+int wgrad_gemm2_stem_slices(int N, int H, int W, int Cout) {
+    long M = (long)N * (H / 2) * (W / 2);
+    if (Cout % 64 || M >= (1 << 21) || getenv("AB_WGRAD2_OFF")) return 0;
+    long tiles = Cout / 64;
+    int n = (int)((256 + tiles - 1) / tiles);
+    int maxs = (int)((M + 1023) / 1024);
+    if (n > maxs) n = maxs; if (n < 1) n = 1;
+    int r = (int)((M + n - 1) / n); r = (r + 63) / 64 * 64;
+    return (int)((M + r - 1) / r);
+}
+
+int wgrad_gemm2_stem_run(const void* xpad, const void* dy, float* slabs, int N, int H, int W, int Cout, hipStream_t st) {
+    int ns = wgrad_gemm2_stem_slices(N, H, W, Cout);
+    if (!ns) return AB_ESHAPE;
+    Wg2Args g = {};
+    g.X = xpad; g.DY = dy; g.slabs = slabs;
+    g.N = N; g.Ha = H + 6; g.Wa = W + 8; g.Ca = 4;
+    g.P = H / 2; g.Q = W / 2; g.Cout = Cout; g.stride = 2; g.ntaps = 8; g.Cin = 256; g.jtot = 256; g.M = N * g.P * g.Q;
+    g.magic_pq = (1ull << 42) / (unsigned long long)(g.P * g.Q) + 1;
+    g.magic_q = (1ull << 42) / (unsigned long long)g.Q + 1;
+    int r = (g.M + ns - 1) / ns; r = (r + 63) / 64 * 64;
+    g.rows_per_slice = r;
+    dim3 grid(Cout / 64, ns);
+    wgrad_gemm2_kernel<64, 256, true><<<grid, 256, 0, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
