@@ -272,6 +272,8 @@ static void pick_tile2(int M, int Cn, int nsteps, int* bm, int* bn) {
     // short K loops (1x1 convs): the fill / drain of a workgroup is not amortised, so favour LDS footprints that let
     // 2-3 workgroups share a CU and overlap each other's prologue and epilogue
     if (nsteps <= 8) { *bm = 64; }
+    static const int force_bm = getenv("AB_GEMM2_BM") ? atoi(getenv("AB_GEMM2_BM")) : 0;
+    if (force_bm) *bm = force_bm;
 }
 
 int conv_gemm2_mtiles(int M, int Cn, int nsteps) {

@@ -122,7 +122,8 @@ __device__ __forceinline__ bool cover(const TriRec& t, int32_t px, int32_t py, i
 // tri: [B][maxf] records; sbox: int [B][4] = minx, maxx, miny, maxy in pixels (init +inf/-inf by the launcher)
 __global__ __launch_bounds__(256) void raster_setup_kernel(SceneDev sc, const SampleDev* __restrict__ samples,
                                                            const float* __restrict__ hand_verts, int maxf,
-                                                           TriRec* __restrict__ tri, int* __restrict__ sbox) {
+                                                           TriRec* __restrict__ tri, int4* __restrict__ tails,
+                                                           int* __restrict__ sbox) {
     const int b = blockIdx.y;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const SampleDev sm = samples[b];
@@ -144,6 +145,9 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(SceneDev sc, const Sa
         }
     }
     tri[(size_t)b * maxf + gid] = t;
+    // compact copy of (valid, bbox) = bytes 32..47 of the record: the per-tile scan reads only these, fully coalesced
+    tails[(size_t)b * maxf + gid] = make_int4((int)t.z[2], t.valid, (int)((uint16_t)t.bx0 | ((uint32_t)(uint16_t)t.bx1 << 16)),
+                                              (int)((uint16_t)t.by0 | ((uint32_t)(uint16_t)t.by1 << 16)));
 }
 
 __global__ void sbox_init_kernel(int* sbox, int B) {
@@ -155,8 +159,12 @@ __global__ void sbox_init_kernel(int* sbox, int B) {
 __device__ __forceinline__ void shade_pixel(const SceneDev& sc, const SampleDev& sm, const float* hv, uint64_t key, int x,
                                             int y, uint8_t o[4]) {
     if (key == ~(uint64_t)0) {
-        int sx = sm.bg_x0 + (int)(((int64_t)(2 * x + 1) * sm.bg_w) / (2 * sc.W));
-        int sy = sm.bg_y0 + (int)(((int64_t)(2 * y + 1) * sm.bg_h) / (2 * sc.H));
+        // (2x+1)*bg_w / (2W): operands are < 2^31 here (x < W <= 8192, crop side <= 2^16), so the unsigned 32-bit
+        // quotient equals the oracle's 64-bit one; power-of-two render sizes divide by a shift
+        const unsigned nx = (unsigned)(2 * x + 1) * (unsigned)sm.bg_w, ny = (unsigned)(2 * y + 1) * (unsigned)sm.bg_h;
+        const unsigned dx = 2u * (unsigned)sc.W, dy = 2u * (unsigned)sc.H;
+        int sx = sm.bg_x0 + (int)((dx & (dx - 1)) ? nx / dx : nx >> (__ffs(dx) - 1));
+        int sy = sm.bg_y0 + (int)((dy & (dy - 1)) ? ny / dy : ny >> (__ffs(dy) - 1));
         const uint8_t* p = sc.bg + (((size_t)sm.bg_id * sc.bgs + sy) * sc.bgs + sx) * 3;
         o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = 0;
         return;
@@ -228,7 +236,8 @@ __device__ __forceinline__ void shade_pixel(const SceneDev& sc, const SampleDev&
 
 __global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const SampleDev* __restrict__ samples,
                                                            const float* __restrict__ hand_verts, int maxf,
-                                                           const TriRec* __restrict__ tri, const int* __restrict__ sbox,
+                                                           const TriRec* __restrict__ tri, const int4* __restrict__ tails_g,
+                                                           const int* __restrict__ sbox,
                                                            uint8_t* __restrict__ rgbx, uint64_t* __restrict__ keys_out) {
     __shared__ unsigned long long zb[TILE * TILE];
     const int b = blockIdx.y;
@@ -243,9 +252,19 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const Sa
     if (active) {
         const int nf = HAND_FACES + (sc.obj_face_off[sm.obj_id + 1] - sc.obj_face_off[sm.obj_id]);
         const TriRec* tb = tri + (size_t)b * maxf;
-        for (int gid = threadIdx.x; gid < nf; gid += 256) {
-            // bbox test on the 8-byte tail first (cheap reject), full record only for overlapping triangles
-            const int4 tail = *(const int4*)((const char*)(tb + gid) + 32);   // z[2]? no: bytes 32..47 = z[2], valid, bbox
+        // four record tails per lane are fetched before any is examined: the scan is a chain of dependent-latency loads
+        for (int gbase = threadIdx.x; gbase < nf; gbase += 1024) {
+          int4 tails[4];
+          const int4* tl = tails_g + (size_t)b * maxf;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+              const int gq = gbase + u * 256;
+              tails[u] = gq < nf ? tl[gq] : make_int4(0, 0, 0, 0);          // z[2], valid, bbox
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int gid = gbase + u * 256;
+            const int4 tail = tails[u];
             const int valid = tail.y;
             if (!valid) continue;
             const int16_t qx0 = (int16_t)(tail.z & 0xffff), qx1 = (int16_t)((uint32_t)tail.z >> 16);
@@ -288,9 +307,35 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const Sa
                 }
                 wrow[0] += sy[0]; wrow[1] += sy[1]; wrow[2] += sy[2]; nrow += nsy;
             }
+          }
         }
     }
     __syncthreads();
+    if (!active) {
+        // background-only tile (4 of 5 at the benchmark geometry): all four pixels' texel loads are issued before any store
+        constexpr int NP = TILE * TILE / 256;
+        const unsigned dx = 2u * (unsigned)sc.W, dy = 2u * (unsigned)sc.H;
+        const int shx = (dx & (dx - 1)) ? -1 : __ffs(dx) - 1, shy = (dy & (dy - 1)) ? -1 : __ffs(dy) - 1;
+        const uint8_t* bgimg = sc.bg + (size_t)sm.bg_id * sc.bgs * sc.bgs * 3;
+        uint32_t px[NP];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = threadIdx.x + j * 256;
+            const int y = ty0 + i / TILE, x = tx0 + i % TILE;
+            const unsigned nx = (unsigned)(2 * x + 1) * (unsigned)sm.bg_w, ny = (unsigned)(2 * y + 1) * (unsigned)sm.bg_h;
+            const int sx = sm.bg_x0 + (int)(shx < 0 ? nx / dx : nx >> shx), sy = sm.bg_y0 + (int)(shy < 0 ? ny / dy : ny >> shy);
+            const uint8_t* p = bgimg + ((size_t)sy * sc.bgs + sx) * 3;
+            px[j] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = threadIdx.x + j * 256;
+            const size_t pix = ((size_t)b * sc.H + (ty0 + i / TILE)) * sc.W + (tx0 + i % TILE);
+            *(uint32_t*)(rgbx + pix * 4) = px[j];
+            if (keys_out) keys_out[pix] = ~0ull;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < TILE * TILE; i += 256) {
         int y = ty0 + i / TILE, x = tx0 + i % TILE;
         uint64_t key = zb[i];
@@ -427,9 +472,9 @@ static SceneDev to_dev(const ab_scene* s) {
 }
 
 extern "C" long ab_render_workspace_bytes(int B, int W, int H, int max_faces) {
-    // tri records + rgbx + lsum + sbox, each 256-byte aligned
+    // tri records + rgbx + lsum + sbox + compact (valid, bbox) tails, each 256-byte aligned
     auto al = [](long x) { return (x + 255) / 256 * 256; };
-    return al((long)B * max_faces * 48) + al((long)B * W * H * 4) + al((long)B * 8) + al((long)B * 16);
+    return al((long)B * max_faces * 48) + al((long)B * W * H * 4) + al((long)B * 8) + al((long)B * 16) + al((long)B * max_faces * 16);
 }
 
 extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, const float* hand_verts,
@@ -446,15 +491,16 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
     TriRec* tri = (TriRec*)ws; ws += al((long)B * max_faces * 48);
     uint8_t* rgbx = rgbx_out ? (uint8_t*)rgbx_out : (uint8_t*)ws; ws += al((long)B * sc.W * sc.H * 4);
     unsigned long long* lsum = (unsigned long long*)ws; ws += al((long)B * 8);
-    int* sbox = (int*)ws;
+    int* sbox = (int*)ws; ws += al((long)B * 16);
+    int4* tails = (int4*)ws;
     hipError_t e = hipMemsetAsync(lsum, 0, (size_t)B * 8, st);
     if (e != hipSuccess) return (int)e;
     sbox_init_kernel<<<(B + 63) / 64, 64, 0, st>>>(sbox, B);
     raster_setup_kernel<<<dim3((max_faces + 255) / 256, B), 256, 0, st>>>(sc, (const SampleDev*)samples, hand_verts,
-                                                                           max_faces, tri, sbox);
+                                                                           max_faces, tri, tails, sbox);
     AB_LAUNCH_CHECK();
     raster_shade_kernel<<<dim3((sc.W / TILE) * (sc.H / TILE), B), 256, 0, st>>>(sc, (const SampleDev*)samples, hand_verts,
-                                                                                 max_faces, tri, sbox, rgbx,
+                                                                                 max_faces, tri, tails, sbox, rgbx,
                                                                                  (uint64_t*)keys_out);
     AB_LAUNCH_CHECK();
     int npix = sc.W * sc.H;
