@@ -174,13 +174,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 }
 
 // dW[e] (+)= sum_s slabs[s][e]; optionally drops padded taps: dst row layout [Cout][dst_j], src [Cout][src_j].
-// 16 element quads x 16 slice lanes per workgroup: lane ky sums slices ky, ky+16, ... in order, the 16 partials are then
-// combined in fixed order through LDS (deterministic; every load is a 16-byte vector, 256 contiguous bytes per row).
+// (256/KY) element quads x KY slice lanes per workgroup (KY = 4 for few slabs, 16 otherwise): lane ky sums slices ky, ky+KY,
+// ... in order, the KY partials are then combined in fixed order through LDS (deterministic; every load is a 16-byte
+// vector, contiguous along the row).
+template <int KY>
 __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ slabs, int nslices, long slab_elems, int src_j,
                                                     int dst_j, float* __restrict__ dst, int accumulate, int stem_mask) {
-    __shared__ float4 part[16][17];
-    const int qx = threadIdx.x & 15, ky = threadIdx.x >> 4;
-    const long quad = (long)blockIdx.x * 16 + qx;
+    constexpr int QX = 256 / KY;
+    __shared__ float4 part[KY][QX + 1];
+    const int qx = threadIdx.x % QX, ky = threadIdx.x / QX;
+    const long quad = (long)blockIdx.x * QX + qx;
     const long total = (slab_elems / src_j) * dst_j;
     const long e = quad * 4;
     const bool live = e < total;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ sl
     if (live) {
         row = e / dst_j; col = (int)(e - row * dst_j);
         const float* src = slabs + row * src_j + col;
-        for (int k = ky; k < nslices; k += 16) {
+        for (int k = ky; k < nslices; k += KY) {
             float4 v = *(const float4*)(src + (long)k * slab_elems);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ sl
     if (ky == 0 && live) {
         float4 t = part[0][qx];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) { float4 v = part[k][qx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        for (int k = 1; k < KY; ++k) { float4 v = part[k][qx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
         if (stem_mask) {                                      // padding taps of the [7][8][4] stem layout
             if ((col & 31) >= 28) t = make_float4(0.f, 0.f, 0.f, 0.f);
             t.w = 0.f;
@@ -210,7 +213,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ sl
     }
 }
 
-static inline unsigned wgrad_reduce_blocks(long total) { return (unsigned)((total / 4 + 15) / 16); }
+static int launch_reduce(const float* slabs, int ns, long slab_elems, int src_j, int dst_j, float* dst, int accumulate,
+                         int stem_mask, hipStream_t st) {
+    const long total = (slab_elems / src_j) * dst_j;
+    if (ns <= 8) wgrad_reduce<4><<<(unsigned)((total / 4 + 63) / 64), 256, 0, st>>>(slabs, ns, slab_elems, src_j, dst_j, dst, accumulate, stem_mask);
+    else wgrad_reduce<16><<<(unsigned)((total / 4 + 15) / 16), 256, 0, st>>>(slabs, ns, slab_elems, src_j, dst_j, dst, accumulate, stem_mask);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
 
 static void pick_wgrad(int M, int Cout, int jtot, int* bi, int* bj, int* nslices, int* rows) {
     *bi = (Cout % 128 == 0) ? 128 : 64;
@@ -263,9 +273,7 @@ static int run_wgrad(WgradArgs& g, int dtype, float* dw, int dst_j, int accumula
     int rc = dtype == AB_DT_BF16 ? launch_wgrad<bf16_t>(g, bi, bj, st) : dtype == AB_DT_F32 ? launch_wgrad<float>(g, bi, bj, st) : AB_EINVAL;
     if (rc) return rc;
     long slab = (long)g.Cout * g.jtot, total = (long)g.Cout * dst_j;
-    wgrad_reduce<<<wgrad_reduce_blocks(total), 256, 0, st>>>(g.slabs, ns, slab, g.jtot, dst_j, dw, accumulate, stem_mask);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : (int)e;
+    return launch_reduce(g.slabs, ns, slab, g.jtot, dst_j, dw, accumulate, stem_mask, st);
 }
 
 // dw: float [Cout][kh][kw][Cin] (OHWI).  workspace: ab_conv2d_wgrad_workspace(N*Ho*Wo, Cout, kh*kw*Cin) bytes.
@@ -280,9 +288,7 @@ extern "C" int ab_conv2d_wgrad(const void* x, const void* dy, float* dw, int dty
             int rc = wgrad3x3_run(x, dy, (float*)workspace, N, H, W, Cin, Cout, as_stream(stream));
             if (rc) return rc;
             long slab = (long)Cout * 9 * Cin;
-            wgrad_reduce<<<wgrad_reduce_blocks(slab), 256, 0, as_stream(stream)>>>((float*)workspace, ns, slab, 9 * Cin, 9 * Cin, dw, accumulate, 0);
-            hipError_t e = hipGetLastError();
-            return e == hipSuccess ? 0 : (int)e;
+            return launch_reduce((float*)workspace, ns, slab, 9 * Cin, 9 * Cin, dw, accumulate, 0, as_stream(stream));
         }
     }
     if (dtype == AB_DT_BF16) {
@@ -292,9 +298,7 @@ extern "C" int ab_conv2d_wgrad(const void* x, const void* dy, float* dw, int dty
             int rc = wgrad_gemm2_run(x, dy, (float*)workspace, N, H, W, Cin, Cout, kh, kw, stride, pad, as_stream(stream));
             if (rc) return rc;
             long slab = (long)Cout * kh * kw * Cin;
-            wgrad_reduce<<<wgrad_reduce_blocks(slab), 256, 0, as_stream(stream)>>>((float*)workspace, ns, slab, kh * kw * Cin, kh * kw * Cin, dw, accumulate, 0);
-            hipError_t e = hipGetLastError();
-            return e == hipSuccess ? 0 : (int)e;
+            return launch_reduce((float*)workspace, ns, slab, kh * kw * Cin, kh * kw * Cin, dw, accumulate, 0, as_stream(stream));
         }
     }
     WgradArgs g = {};
@@ -316,10 +320,7 @@ extern "C" int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw,
         if (ns > 0) {
             int rc = wgrad_gemm2_stem_run(xpad, dy, (float*)workspace, N, H, W, Cout, as_stream(stream));
             if (rc) return rc;
-            long slab = (long)Cout * 256, total = (long)Cout * 7 * 32;
-            wgrad_reduce<<<wgrad_reduce_blocks(total), 256, 0, as_stream(stream)>>>((float*)workspace, ns, slab, 256, 7 * 32, dw, 0, 1);
-            hipError_t e = hipGetLastError();
-            return e == hipSuccess ? 0 : (int)e;
+            return launch_reduce((float*)workspace, ns, (long)Cout * 256, 256, 7 * 32, dw, 0, 1, as_stream(stream));
         }
     }
     WgradArgs g = {};
