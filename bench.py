@@ -67,7 +67,8 @@ def build_everything(args, rank, world, device):
 
 def conv_kernel_time_ms(ts, loader, static, iters=3):
     """Average per-step time of the conv-stack MFMA kernels, measured with HIP events on the compute stream by
-    running the step eagerly with events around every conv launch (kernels.py hooks)."""
+    running the step eagerly with events around every conv launch (kernels.py hooks); agrees with the per-kernel
+    durations of profiles/round1_*_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this same command)."""
     import torch
     from artiboost_amd import kernels as K
     names = ["conv2d_fwd", "conv2d_stem_fwd", "conv2d_dgrad", "conv2d_wgrad", "conv2d_stem_wgrad"]
@@ -92,9 +93,18 @@ def conv_kernel_time_ms(ts, loader, static, iters=3):
             spans.clear()
             loader.load_batch(static, it % max(len(loader), 1))
             ts.crit.draw(ts.dev)
+            # park the stream behind a long spin so that the whole eager step is ENQUEUED before any of it runs: the
+            # event pairs then bracket back-to-back device execution, not the Python launch latency between them
+            torch.cuda._sleep(120_000_000)
             ts._learn()
+            empties = []
+            for _ in range(16):              # cost of an empty event pair on this stream (marker overhead), removed below
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); e1.record()
+                empties.append((e0, e1))
             torch.cuda.synchronize()
-            total += sum(a.elapsed_time(b) for a, b in spans)
+            empty_ms = sorted(a.elapsed_time(b) for a, b in empties)[len(empties) // 2]
+            total += sum(max(a.elapsed_time(b) - empty_ms, 0.0) for a, b in spans)
             nl = len(spans)
     finally:
         for n in names:
