@@ -36,15 +36,20 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsig
 }
 
 template <int BM, int TW, int BN, int WM, int WN, int FLIP>
-__global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args g) {
+__global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
+    // NW = WM*WN waves (4 or 8).  Measured (tools/probe_fill.hip): a wave pulls ~10 GB/s of L2-resident data into LDS
+    // whatever its queue depth, and a CU's fill rate scales with the number of waves issuing loads (4 waves 10 TB/s
+    // chip-wide, 8 waves 20, 16 waves 30) -- so the same tile is worked by 8 waves where the fill is the limit.
+    constexpr int NW = WM * WN, NT = 64 * NW;
     // patch row pitch: TW + 2, or TW + 3 for TW = 8 so that consecutive patch rows alternate LDS half (pixel parity) --
     // a 16-lane fragment read then spans two image rows with the same px set and would otherwise hit the same banks
     constexpr int TH = BM / TW, PW = (TW == 8) ? TW + 3 : TW + 2, PH = TH + 2;
     constexpr int NPIX = PH * PW;
     constexpr int PI = (NPIX + 7) / 8;                 // 1-KiB instructions per patch
-    constexpr int LP = (PI + 3) / 4;                   // per wave
-    constexpr int PATCH_BYTES = LP * 4 * 1024;         // every wave issues exactly LP fills; the tail past NPIX is slack
-    constexpr int IB = BN / 8, LB = IB / 4;            // weight-tile instructions: total / per wave
+    constexpr int LP = (PI + NW - 1) / NW;             // per wave
+    constexpr int PATCH_BYTES = LP * NW * 1024;        // every wave issues exactly LP fills; the tail past NPIX is slack
+    constexpr int IB = BN / 8, LB = IB / NW;           // weight-tile instructions: total / per wave
+    static_assert(IB % NW == 0, "weight tile rows must split evenly over the waves");
     constexpr int BBYTES = BN * 128;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NRING = 3;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args g) {
     __syncthreads();
     {
         constexpr int CPR = BN / 8;                        // 16-byte chunks per tile row
-        for (int id = tid; id < BM * CPR; id += 256) {
+        for (int id = tid; id < BM * CPR; id += NT) {
             int row = id / CPR, c8 = id - row * CPR;
             int yy = ty0 + row / TW, xx = tx0 + row % TW, col = n0 + c8 * 8;
             if (yy < g.H && xx < g.W && col < g.Cn) {
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args g) {
             }
         }
         __syncthreads();
-        for (int c = tid; c < BN; c += 256) {
+        for (int c = tid; c < BN; c += NT) {
             int col = n0 + c;
             if (col < g.Cn) {
                 float s = 0.f, q = 0.f;
@@ -262,8 +267,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(Conv3Args g) {
 
 template <int BM, int TW, int BN, int WM, int WN>
 static size_t c3_lds(int nchunks) {
-    constexpr int TH = BM / TW, NPIX = (TH + 2) * ((TW == 8) ? TW + 3 : TW + 2), PI = (NPIX + 7) / 8, LP = (PI + 3) / 4;
-    size_t need = (size_t)(nchunks > 1 ? 2 : 1) * LP * 4 * 1024 + 3 * BN * 128 + WM * BN * 8;
+    constexpr int NW = WM * WN;
+    constexpr int TH = BM / TW, NPIX = (TH + 2) * ((TW == 8) ? TW + 3 : TW + 2), PI = (NPIX + 7) / 8, LP = (PI + NW - 1) / NW;
+    size_t need = (size_t)(nchunks > 1 ? 2 : 1) * LP * NW * 1024 + 3 * BN * 128 + WM * BN * 8;
     size_t stage = (size_t)BM * (BN * 2 + 16);          // epilogue staging tile
     return need > stage ? need : stage;
 }
@@ -312,7 +318,7 @@ static int c3_launch(Conv3Args& g, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv3x3_kernel<BM, TW, BN, WM, WN, FLIP><<<blocks, 256, lds, st>>>(g);
+    conv3x3_kernel<BM, TW, BN, WM, WN, FLIP><<<blocks, 64 * WM * WN, lds, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -327,18 +333,30 @@ int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, i
     g.X = x; g.Wt = wt; g.Out = out; g.addend = addend; g.stats = stats;
     g.N = N; g.H = H; g.W = W; g.C = C; g.Cn = Cn; g.ktot = 9 * C;
     g.flip = flip;
-    if (flip) {
-        if (cfg == 1) return c3_launch<128, 32, 64, 2, 2, 1>(g, st);
-        if (cfg == 2) return c3_launch<256, 32, 128, 2, 2, 1>(g, st);
-        if (cfg == 3) return c3_launch<128, 16, 128, 2, 2, 1>(g, st);
-        if (cfg == 5) return c3_launch<64, 8, 128, 2, 2, 1>(g, st);
-        if (cfg == 6) return c3_launch<256, 16, 64, 4, 1, 1>(g, st);
-        return c3_launch<128, 16, 64, 2, 2, 1>(g, st);
-    }
-    if (cfg == 1) return c3_launch<128, 32, 64, 2, 2, 0>(g, st);
-    if (cfg == 2) return c3_launch<256, 32, 128, 2, 2, 0>(g, st);
-    if (cfg == 3) return c3_launch<128, 16, 128, 2, 2, 0>(g, st);
-    if (cfg == 5) return c3_launch<64, 8, 128, 2, 2, 0>(g, st);
-    if (cfg == 6) return c3_launch<256, 16, 64, 4, 1, 0>(g, st);
-    return c3_launch<128, 16, 64, 2, 2, 0>(g, st);
+    static const int w8 = getenv("AB_C3_W8") ? atoi(getenv("AB_C3_W8")) : 2;     // 0: 4 waves, 1: 8 waves, 2: 8 (16 for the 256-pixel tile)
+#define C3_GO(FL) \
+    do { \
+        if (w8 == 2) { \
+            if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, FL>(g, st); \
+            if (cfg == 2) return c3_launch<256, 32, 128, 4, 4, FL>(g, st); \
+            if (cfg == 5) return c3_launch<64, 8, 128, 2, 4, FL>(g, st); \
+        } \
+        if (w8) { \
+            if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, FL>(g, st); \
+            if (cfg == 2) return c3_launch<256, 32, 128, 4, 2, FL>(g, st); \
+            if (cfg == 3) return c3_launch<128, 16, 128, 4, 2, FL>(g, st); \
+            if (cfg == 5) return c3_launch<64, 8, 128, 2, 4, FL>(g, st); \
+            if (cfg == 6) return c3_launch<256, 16, 64, 4, 2, FL>(g, st); \
+            return c3_launch<128, 16, 64, 4, 2, FL>(g, st); \
+        } \
+        if (cfg == 1) return c3_launch<128, 32, 64, 2, 2, FL>(g, st); \
+        if (cfg == 2) return c3_launch<256, 32, 128, 2, 2, FL>(g, st); \
+        if (cfg == 3) return c3_launch<128, 16, 128, 2, 2, FL>(g, st); \
+        if (cfg == 5) return c3_launch<64, 8, 128, 2, 2, FL>(g, st); \
+        if (cfg == 6) return c3_launch<256, 16, 64, 4, 1, FL>(g, st); \
+        return c3_launch<128, 16, 64, 2, 2, FL>(g, st); \
+    } while (0)
+    if (flip) C3_GO(1);
+    C3_GO(0);
+#undef C3_GO
 }
