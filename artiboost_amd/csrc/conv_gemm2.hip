@@ -18,7 +18,8 @@ __device__ uint4 ab_zero_page[2];    // zero-initialised device memory: source o
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int BM, int BN, int WM, int WN, int NBUF = 3>
-__global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g) {
+    constexpr int NW = WM * WN, NT = 64 * NW;                // 4 or 8 waves: the LDS fill rate scales with the waves issuing loads
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;     // 32x32 MFMA tiles per wave
     constexpr int IA = BM / 8, IB = BN / 8;                 // 1-KiB load instructions (8 rows each) for the A / B tile
     constexpr int BUFSZ = (BM + BN) * 128;
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
 
     // ---- per-lane load assignment: instruction ii (0..IA-1 over the 4 waves) covers rows ii*8 .. ii*8+7
     const int lrow = lane >> 3, lslot = lane & 7;
-    constexpr int NA = IA / 4, NB = IB / 4;                 // per wave
+    constexpr int NA = IA / NW, NB = IB / NW;               // per wave
+    static_assert(IA % NW == 0 && IB % NW == 0, "tile rows must split evenly over the waves");
     int a_h[NA], a_w[NA], a_chunk[NA]; long a_base[NA]; bool a_ok[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
     {
         constexpr int CPR = BN / 8;
         const bool vec_ok = (g.Cn & 7) == 0;
-        for (int id = tid; id < BM * CPR; id += 256) {
+        for (int id = tid; id < BM * CPR; id += NT) {
             int row = id / CPR, c8 = id - row * CPR;
             int op = s_outpix[row], col = n0 + c8 * 8;
             if (op < 0 || col >= g.Cn) continue;
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_gemm2_kernel(ConvGemmArgs g) {
             }
         }
         __syncthreads();
-        for (int c = tid; c < BN; c += 256) {
+        for (int c = tid; c < BN; c += NT) {
             int col = n0 + c;
             if (col < g.Cn) {
                 float s = 0.f, q = 0.f;
@@ -293,11 +295,17 @@ int conv_gemm2_run(ConvGemmArgs& g, hipStream_t st) {
     g.nmajor = nm_env >= 0 ? nm_env : (wbytes > (3L << 20) && abytes <= (8L << 20) && g.Cn > bn);
     static const int deep_max = getenv("AB_GEMM2_DEEP") ? atoi(getenv("AB_GEMM2_DEEP")) : 0;
     const bool deep = tiles <= deep_max && g.ntaps * g.cpt >= 8;     // one workgroup per CU: deeper prefetch ring
+    static const int w8 = getenv("AB_GEMM2_W8") ? atoi(getenv("AB_GEMM2_W8")) : 1;
     if (bm == 256 && bn == 64) conv_gemm2_kernel<256, 64, 4, 1><<<tiles, 256, 0, st>>>(g);
-    else if (bm == 128 && bn == 128) conv_gemm2_kernel<128, 128, 2, 2><<<tiles, 256, 0, st>>>(g);
-    else if (bm == 128 && bn == 64) conv_gemm2_kernel<128, 64, 2, 2><<<tiles, 256, 0, st>>>(g);
-    else if (bm == 64 && bn == 128) {
-        if (deep) conv_gemm2_kernel<64, 128, 2, 2, 5><<<tiles, 256, 0, st>>>(g);
+    else if (bm == 128 && bn == 128) {
+        if (w8) conv_gemm2_kernel<128, 128, 4, 2><<<tiles, 512, 0, st>>>(g);
+        else conv_gemm2_kernel<128, 128, 2, 2><<<tiles, 256, 0, st>>>(g);
+    } else if (bm == 128 && bn == 64) {
+        if (w8) conv_gemm2_kernel<128, 64, 4, 2><<<tiles, 512, 0, st>>>(g);
+        else conv_gemm2_kernel<128, 64, 2, 2><<<tiles, 256, 0, st>>>(g);
+    } else if (bm == 64 && bn == 128) {
+        if (w8) conv_gemm2_kernel<64, 128, 2, 4><<<tiles, 512, 0, st>>>(g);
+        else if (deep) conv_gemm2_kernel<64, 128, 2, 2, 5><<<tiles, 256, 0, st>>>(g);
         else conv_gemm2_kernel<64, 128, 2, 2><<<tiles, 256, 0, st>>>(g);
     } else {
         if (deep) conv_gemm2_kernel<64, 64, 2, 2, 5><<<tiles, 256, 0, st>>>(g);

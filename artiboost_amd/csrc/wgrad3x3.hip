@@ -17,6 +17,7 @@
 //
 // Partial results of the pixel slices go to separate slabs and are summed in fixed order by wgrad_reduce (no atomics).
 #include "conv_common.h"
+#include <type_traits>
 
 typedef short short4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) short4_t lds_short4;
@@ -36,15 +37,19 @@ __device__ __forceinline__ uint4 tr_pair(unsigned addr_lo, unsigned addr_hi) {
     return make_uint4(l2.x, l2.y, h2.x, h2.y);
 }
 
-template <int W, int TH>
-__global__ __launch_bounds__(256) void wgrad3x3_kernel(Wg3Args g) {
+// NW = 4: every wave (2 co-halves x 2 ci-halves) accumulates all nine taps.  NW = 8: the taps are split 5 + 4 over two
+// groups of four waves -- twice the waves issue the band / patch DMA (the L2->LDS fill rate scales with the number of
+// issuing waves, tools/probe_fill.hip) and each holds 80 instead of 144 accumulators.
+template <int W, int TH, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
     constexpr int BP = TH * W;                       // band pixels (multiple of 16)
     constexpr int KS = BP / 16;                      // k-slices per band
     constexpr int PW = W + 4, PH = TH + 2;           // patch: 1-pixel halo (+2 slack columns so PW % 4 == 0)
     constexpr int NPIX = PH * PW;
-    constexpr int IA = BP / 8, LA = (IA + 3) / 4;    // dy-band fills: total / per wave
-    constexpr int IX = (NPIX + 7) / 8, LX = (IX + 3) / 4;
-    constexpr int ABYTES = LA * 4 * 1024, XBYTES = LX * 4 * 1024;
+    constexpr int IA = BP / 8, LA = (IA + NW - 1) / NW;    // dy-band fills: total / per wave
+    constexpr int IX = (NPIX + 7) / 8, LX = (IX + NW - 1) / NW;
+    constexpr int ABYTES = LA * NW * 1024, XBYTES = LX * NW * 1024;
+    constexpr int NACC = NW == 8 ? 5 : 9;
     constexpr int BUF = ABYTES + XBYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = lds_addr_of(smem);
@@ -53,7 +58,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(Wg3Args g) {
     const int tiles_ci = g.Cin / 64;
     const int tile_co = blockIdx.x / tiles_ci, tile_ci = blockIdx.x - tile_co * tiles_ci;
     const int co0 = tile_co * 64, ci0 = tile_ci * 64;
-    const int wco = (wave & 1) * 32, wci = (wave >> 1) * 32;
+    const int wco = (wave & 1) * 32, wci = ((wave >> 1) & 1) * 32;
+    const int tg = wave >> 2;                                // tap group (NW = 8): 0 -> taps 0..4, 1 -> taps 5..8
+    const int t0 = (NW == 8 && tg) ? 5 : 0, ntap = NW == 8 ? (tg ? 4 : 5) : 9;
     const int band_begin = blockIdx.y * g.bands_per_slice;
     const int band_end = min(g.nbands, band_begin + g.bands_per_slice);
     const int bands_per_img = g.H / TH;
@@ -125,11 +132,36 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(Wg3Args g) {
             x_base[kw][h] = q * 128 + (((col >> 3) ^ (((q >> 1) & 1) << 2)) << 4) + (col & 7) * 2;
         }
 
-    f32x16 acc[9];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // all MFMAs of one band for the taps T0 .. T0+NTP-1 (compile-time: every fragment address is base + immediate)
+    auto band_compute = [&](auto t0c, auto ntc, unsigned ab, unsigned xb) {
+        constexpr int T0 = decltype(t0c)::value, NTP = decltype(ntc)::value;
+        unsigned a_cur[2] = {ab + a_base[0], ab + a_base[1]};
+        unsigned x_cur[3][2];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) { x_cur[kw][0] = xb + x_base[kw][0]; x_cur[kw][1] = xb + x_base[kw][1]; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            // band pixel 16*s + k: same image row for all 16 k when W >= 16; for W == 8 two rows (k >= 8 -> next row),
+            // handled by ty_l/tx_l in x_base, so only the slice origin (row/col of pixel p0) is added here
+            const int p0 = 16 * s;
+            uint4 fa = tr_pair(a_cur[0] + p0 * 128, a_cur[1] + p0 * 128);
+#pragma unroll
+            for (int tt = 0; tt < NTP; ++tt) {
+                const int kh = (T0 + tt) / 3, kw = (T0 + tt) % 3;
+                const int oy = p0 / W, ox = p0 % W;
+                const int disp = ((oy + kh) * PW + ox) * 128;
+                uint4 fb = tr_pair(x_cur[kw][0] + disp, x_cur[kw][1] + disp);
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
+                                                                  acc[tt], 0, 0, 0);
+            }
+        }
+    };
 
     if (band_begin < band_end) issue_band(band_begin, 0);
     int buf = 0;
@@ -139,28 +171,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(Wg3Args g) {
         asm volatile("" ::: "memory");
         if (band + 1 < band_end) issue_band(band + 1, buf ^ 1);
         const unsigned ab = lds0 + buf * BUF, xb = ab + ABYTES;
-        unsigned a_cur[2] = {ab + a_base[0], ab + a_base[1]};
-        unsigned x_cur[3][2];
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) { x_cur[kw][0] = xb + x_base[kw][0]; x_cur[kw][1] = xb + x_base[kw][1]; }
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            // band pixel 16*s + k: same image row for all 16 k when W >= 16; for W == 8 two rows (k >= 8 -> next row)
-            const int p0 = 16 * s;
-            uint4 fa = tr_pair(a_cur[0] + p0 * 128, a_cur[1] + p0 * 128);
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    // displacement of this k-slice / tap inside the patch, in pixels (compile-time)
-                    // lanes with krow >= 8 may sit on the next image row when W == 8: handled by ty_l/tx_l in x_base,
-                    // so only the slice origin (row/col of pixel p0) is added here
-                    const int oy = p0 / W, ox = p0 % W;
-                    const int disp = ((oy + kh) * PW + ox) * 128;
-                    uint4 fb = tr_pair(x_cur[kw][0] + disp, x_cur[kw][1] + disp);
-                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa),
-                                                                              __builtin_bit_cast(bf16x8, fb), acc[kh * 3 + kw], 0, 0, 0);
-                }
+        if constexpr (NW == 8) {
+            if (tg == 0) band_compute(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, ab, xb);
+            else band_compute(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{}, ab, xb);
+        } else {
+            band_compute(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{}, ab, xb);
         }
         buf ^= 1;
     }
@@ -168,32 +183,34 @@ __global__ __launch_bounds__(256) void wgrad3x3_kernel(Wg3Args g) {
     float* out = g.slabs + (long)blockIdx.y * g.Cout * 9 * g.Cin;
     const int jt = 9 * g.Cin;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int tt = 0; tt < NACC; ++tt) {
+        if (tt >= ntap) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             int row = co0 + wco + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            int col = t * g.Cin + ci0 + wci + (lane & 31);
-            out[(long)row * jt + col] = acc[t][r];
+            int col = (t0 + tt) * g.Cin + ci0 + wci + (lane & 31);
+            out[(long)row * jt + col] = acc[tt][r];
         }
+    }
 }
 
-template <int W, int TH>
+template <int W, int TH, int NW>
 static size_t wg3_lds() {
     constexpr int BP = TH * W, NPIX = (TH + 2) * (W + 4);
-    constexpr int LA = (BP / 8 + 3) / 4, LX = ((NPIX + 7) / 8 + 3) / 4;
-    return (size_t)2 * (LA + LX) * 4 * 1024;
+    constexpr int LA = (BP / 8 + NW - 1) / NW, LX = ((NPIX + 7) / 8 + NW - 1) / NW;
+    return (size_t)2 * (LA + LX) * NW * 1024;
 }
 
-template <int W, int TH>
+template <int W, int TH, int NW>
 static int wg3_launch(Wg3Args& g, int tiles, int nslices, hipStream_t st) {
-    size_t lds = wg3_lds<W, TH>();
+    size_t lds = wg3_lds<W, TH, NW>();
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<W, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<W, TH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    wgrad3x3_kernel<W, TH><<<dim3(tiles, nslices), 256, lds, st>>>(g);
+    wgrad3x3_kernel<W, TH, NW><<<dim3(tiles, nslices), 64 * NW, lds, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -230,8 +247,15 @@ int wgrad3x3_run(const void* x, const void* dy, float* slabs, int N, int H, int 
     g.nbands = N * (H / th);
     g.bands_per_slice = (g.nbands + ns - 1) / ns;
     int tiles = (Cin / 64) * (Cout / 64);
-    if (W == 64) return wg3_launch<64, 2>(g, tiles, ns, st);
-    if (W == 32) return wg3_launch<32, 4>(g, tiles, ns, st);
-    if (W == 16) return wg3_launch<16, 8>(g, tiles, ns, st);
-    return wg3_launch<8, 8>(g, tiles, ns, st);
+    static const int w8 = getenv("AB_WG3_W8") ? atoi(getenv("AB_WG3_W8")) : 1;
+    if (w8) {
+        if (W == 64) return wg3_launch<64, 2, 8>(g, tiles, ns, st);
+        if (W == 32) return wg3_launch<32, 4, 8>(g, tiles, ns, st);
+        if (W == 16) return wg3_launch<16, 8, 8>(g, tiles, ns, st);
+        return wg3_launch<8, 8, 8>(g, tiles, ns, st);
+    }
+    if (W == 64) return wg3_launch<64, 2, 4>(g, tiles, ns, st);
+    if (W == 32) return wg3_launch<32, 4, 4>(g, tiles, ns, st);
+    if (W == 16) return wg3_launch<16, 8, 4>(g, tiles, ns, st);
+    return wg3_launch<8, 8, 4>(g, tiles, ns, st);
 }

@@ -46,22 +46,24 @@ __device__ __forceinline__ uint4 wg2_tr_pair(unsigned lo_addr, unsigned hi_addr)
 
 // STEM: x is the zero-bordered NHWC4 image and a dW row is [8 kernel rows (7 + 1 pad)][8 px][4 ch] = 256 columns (see
 // ab_conv2d_stem_fwd); BJ = 256 covers all of them, the 64-byte segment of kernel row t comes from image row 2p + t.
-template <int BI, int BJ, bool STEM = false>
-__global__ __launch_bounds__(256) void wgrad_gemm2_kernel(Wg2Args g) {
+template <int BI, int BJ, bool STEM = false, int WI = 2, int WJ = 2>
+__global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
+    constexpr int NW = WI * WJ;                             // 4 or 8 waves (the LDS fill rate scales with the waves issuing loads)
     constexpr int BR = 64;                                  // reduction rows per step
     constexpr int PA = BI * 2, PB = BJ * 2;                 // row pitches (bytes)
     constexpr int RA = 1024 / PA, RB = 1024 / PB;           // rows per 1-KiB DMA instruction
     constexpr int IA = BR / RA, IB = BR / RB;               // instructions per tile
-    constexpr int LA = IA / 4, LB = IB / 4;                 // per wave
+    constexpr int LA = IA / NW, LB = IB / NW;               // per wave
+    static_assert(IA % NW == 0 && IB % NW == 0, "tile rows must split evenly over the waves");
     constexpr int ABYTES = BR * PA, STAGE = BR * (PA + PB);
     constexpr int NBUF = 3;
-    constexpr int TI = BI / 64, TJ = BJ / 64;               // 32x32 tiles per wave (waves 2 x 2)
+    constexpr int TI = BI / WI / 32, TJ = BJ / WJ / 32;     // 32x32 tiles per wave (waves WI x WJ)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * STAGE];
     __shared__ int s_xoff[2][BR];                           // element offset of each row's input pixel (-1: padding / past the end)
     const unsigned lds0 = lds_addr_of(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_i = wave >> 1, wave_j = wave & 1;
+    const int wave_i = wave / WJ, wave_j = wave % WJ;
     const int tiles_j = g.jtot / BJ;
     const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x - tile_i * tiles_j;
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
@@ -233,11 +235,12 @@ int wgrad_gemm2_run(const void* x, const void* dy, float* slabs, int N, int H, i
     int bi, bj, ns, rows; wg2_pick(g.M, Cout, Cin, g.jtot, &bi, &bj, &ns, &rows);
     g.rows_per_slice = rows;
     dim3 grid((Cout / bi) * (g.jtot / bj), ns);
-    if (bi == 128 && bj == 256) wgrad_gemm2_kernel<128, 256><<<grid, 256, 0, st>>>(g);
+    static const int w8 = getenv("AB_WG2_W8") ? atoi(getenv("AB_WG2_W8")) : 1;
+    if (bi == 128 && bj == 256) { if (w8) wgrad_gemm2_kernel<128, 256, false, 2, 4><<<grid, 512, 0, st>>>(g); else wgrad_gemm2_kernel<128, 256><<<grid, 256, 0, st>>>(g); }
     else if (bi == 64 && bj == 256) wgrad_gemm2_kernel<64, 256><<<grid, 256, 0, st>>>(g);
-    else if (bi == 128 && bj == 128) wgrad_gemm2_kernel<128, 128><<<grid, 256, 0, st>>>(g);
-    else if (bi == 128 && bj == 64) wgrad_gemm2_kernel<128, 64><<<grid, 256, 0, st>>>(g);
-    else if (bi == 64 && bj == 128) wgrad_gemm2_kernel<64, 128><<<grid, 256, 0, st>>>(g);
+    else if (bi == 128 && bj == 128) { if (w8) wgrad_gemm2_kernel<128, 128, false, 2, 4><<<grid, 512, 0, st>>>(g); else wgrad_gemm2_kernel<128, 128><<<grid, 256, 0, st>>>(g); }
+    else if (bi == 128 && bj == 64) { if (w8) wgrad_gemm2_kernel<128, 64, false, 4, 2><<<grid, 512, 0, st>>>(g); else wgrad_gemm2_kernel<128, 64><<<grid, 256, 0, st>>>(g); }
+    else if (bi == 64 && bj == 128) { if (w8) wgrad_gemm2_kernel<64, 128, false, 2, 4><<<grid, 512, 0, st>>>(g); else wgrad_gemm2_kernel<64, 128><<<grid, 256, 0, st>>>(g); }
     else wgrad_gemm2_kernel<64, 64><<<grid, 256, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -278,7 +281,9 @@ int wgrad_gemm2_stem_run(const void* xpad, const void* dy, float* slabs, int N, 
     int r = (g.M + ns - 1) / ns; r = (r + 63) / 64 * 64;
     g.rows_per_slice = r;
     dim3 grid(Cout / 64, ns);
-    wgrad_gemm2_kernel<64, 256, true><<<grid, 256, 0, st>>>(g);
+    static const int w8 = getenv("AB_WG2_W8") ? atoi(getenv("AB_WG2_W8")) : 1;
+    if (w8) wgrad_gemm2_kernel<64, 256, true, 2, 4><<<grid, 512, 0, st>>>(g);
+    else wgrad_gemm2_kernel<64, 256, true><<<grid, 256, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
