@@ -24,6 +24,8 @@ struct Conv3Args {
     int Cn;                  // output [N,H,W,Cn]
     int ktot;                // weight row length (9*C)
     int tiles_x, tiles_y;    // tiles per image
+    // optional fused BatchNorm-backward reduction over the OUTPUT of this (data-gradient) launch: see ab_conv2d_dgrad_bnstats
+    const void* bn_y; const void* bn_out; const float* bnp; float* bn_part;
     int flip;                // 0: tap t reads input (t/3-1, t%3-1); 1 (data gradient): (1-t/3, 1-t%3).  Weight K offset = t*C.
 };                           // (no per-tap tables: a dynamically indexed kernarg array becomes a VMEM load inside the K loop,
                              //  and the vmcnt wait for it would drain the in-flight LDS-DMA prefetch)
@@ -216,8 +218,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         }
     }
     __syncthreads();
+    constexpr int CPR = BN / 8;                            // 16-byte chunks per tile row
+    static_assert(NT % CPR == 0, "a thread keeps one channel group over all its rows");
+    // Fused BN-backward reduction (data-gradient launches): the tile being stored IS the gradient arriving at
+    // relu(bn(bn_y) [+ residual]); each thread owns one 8-channel group over its rows and accumulates sum(dz) and
+    // sum(dz * xhat) with dz = masked gradient (mask from the stored activation bn_out, or recomputed from bn_y).
+    const bf16_t* __restrict__ BnY = (const bf16_t*)g.bn_y;
+    const bf16_t* __restrict__ BnOut = (const bf16_t*)g.bn_out;
+    float bs[8], bq[8], bmean[8], bistd[8], bsc[8], bsh[8];
+    if (BnY) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int c = min(n0 + (tid % CPR) * 8 + k, g.Cn - 1);
+            bs[k] = 0.f; bq[k] = 0.f;
+            bsc[k] = g.bnp[c]; bsh[k] = g.bnp[g.Cn + c]; bmean[k] = g.bnp[2 * g.Cn + c]; bistd[k] = g.bnp[3 * g.Cn + c];
+        }
+    }
     {
-        constexpr int CPR = BN / 8;                        // 16-byte chunks per tile row
         for (int id = tid; id < BM * CPR; id += NT) {
             int row = id / CPR, c8 = id - row * CPR;
             int yy = ty0 + row / TW, xx = tx0 + row % TW, col = n0 + c8 * 8;
@@ -236,10 +253,44 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
                     v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                 }
                 *(uint4*)(Out + o) = v;
+                if (BnY) {
+                    const uint4 yv = *(const uint4*)(BnY + o);
+                    uint4 ov = make_uint4(0, 0, 0, 0);
+                    if (BnOut) ov = *(const uint4*)(BnOut + o);
+                    const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int sh16 = (k & 1) ? 0 : 16;
+                        const float gv = __uint_as_float((k & 1) ? (vw[k >> 1] & 0xffff0000u) : (vw[k >> 1] << 16));
+                        const float yf = __uint_as_float((k & 1) ? (yw[k >> 1] & 0xffff0000u) : (yw[k >> 1] << 16));
+                        const float of = __uint_as_float((k & 1) ? (ow[k >> 1] & 0xffff0000u) : (ow[k >> 1] << 16));
+                        (void)sh16;
+                        const bool dead = BnOut ? !(of > 0.f) : !(yf * bsc[k] + bsh[k] > 0.f);
+                        const float dz = dead ? 0.f : gv;
+                        bs[k] += dz; bq[k] += dz * ((yf - bmean[k]) * bistd[k]);
+                    }
+                }
             }
         }
     }
     __syncthreads();
+    if (BnY) {
+        constexpr int PART_OFF = (BM * SPITCH + 15) / 16 * 16;
+        float* sp = (float*)(smem + PART_OFF);             // [NT / CPR][BN][2]
+        const int rg = tid / CPR, cb = (tid % CPR) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sp[(rg * BN + cb + k) * 2] = bs[k]; sp[(rg * BN + cb + k) * 2 + 1] = bq[k]; }
+        __syncthreads();
+        for (int c = tid; c < BN; c += NT) {
+            int col = n0 + c;
+            if (col < g.Cn) {
+                float s = 0.f, q = 0.f;
+                for (int r = 0; r < NT / CPR; ++r) { s += sp[(r * BN + c) * 2]; q += sp[(r * BN + c) * 2 + 1]; }
+                g.bn_part[((long)tile_sp * g.Cn + col) * 2] = s;
+                g.bn_part[((long)tile_sp * g.Cn + col) * 2 + 1] = q;
+            }
+        }
+    }
     if (g.stats) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -270,7 +321,8 @@ static size_t c3_lds(int nchunks) {
     constexpr int NW = WM * WN;
     constexpr int TH = BM / TW, NPIX = (TH + 2) * ((TW == 8) ? TW + 3 : TW + 2), PI = (NPIX + 7) / 8, LP = (PI + NW - 1) / NW;
     size_t need = (size_t)(nchunks > 1 ? 2 : 1) * LP * NW * 1024 + 3 * BN * 128 + WM * BN * 8;
-    size_t stage = (size_t)BM * (BN * 2 + 16);          // epilogue staging tile
+    size_t stage = ((size_t)BM * (BN * 2 + 16) + 15) / 16 * 16;      // epilogue staging tile
+    stage += (size_t)(64 * NW / (BN / 8)) * BN * 8;                    // + fused BN-backward partials [NT/CPR][BN][2]
     return need > stage ? need : stage;
 }
 
@@ -326,13 +378,15 @@ static int c3_launch(Conv3Args& g, hipStream_t st) {
 // x [N,H,W,C] -> out [N,H,W,Cn]; wt rows of length 9*C; flip = 0: forward weights OHWI, taps (kh-1, kw-1);
 // flip = 1: data gradient with IHWO weights, taps (1-kh, 1-kw).  Returns AB_ESHAPE when unsupported.
 int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, int C, int Cn, int flip,
-                const void* addend, float* stats, hipStream_t st) {
+                const void* addend, float* stats, hipStream_t st, const void* bn_y, const void* bn_out, const float* bnp,
+                float* bn_part) {
     int cfg = c3_config(N, H, W, C, Cn);
     if (!cfg) return AB_ESHAPE;
     Conv3Args g = {};
     g.X = x; g.Wt = wt; g.Out = out; g.addend = addend; g.stats = stats;
     g.N = N; g.H = H; g.W = W; g.C = C; g.Cn = Cn; g.ktot = 9 * C;
     g.flip = flip;
+    g.bn_y = bn_y; g.bn_out = bn_out; g.bnp = bnp; g.bn_part = bn_part;
     static const int w8 = getenv("AB_C3_W8") ? atoi(getenv("AB_C3_W8")) : 2;     // 0: 4 waves, 1: 8 waves, 2: 8 (16 for the 256-pixel tile)
 #define C3_GO(FL) \
     do { \

@@ -590,10 +590,11 @@ extern "C" int ab_bn_apply(const void* y, const void* res, const float* bnp, int
 
 static int bn_bwd_impl(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C,
                        int relu, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out,
-                       const uint8_t* pool_idx, int pH, int pW, hipStream_t st) {
+                       const uint8_t* pool_idx, int pH, int pW, hipStream_t st, int given_parts = 0) {
     int V = dtype == AB_DT_F32 ? 4 : 8;
     if (C % V || C / V > 256) return AB_ESHAPE;
-    int np = ab_col_stats_nparts(M); int rl = 256 / (C / V); size_t sh = (size_t)rl * C * 2 * 4;
+    int np = given_parts > 0 ? given_parts : ab_col_stats_nparts(M); int rl = 256 / (C / V); size_t sh = (size_t)rl * C * 2 * 4;
+    if (given_parts <= 0)
     DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, red_rows(M), part, pool_idx, pH, pW)),
              (bn_bwd_reduce_kernel<bf16_t><<<np, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, red_rows(M), part, pool_idx, pH, pW)));
     AB_LAUNCH_CHECK();
@@ -610,6 +611,16 @@ extern "C" int ab_bn_bwd(const void* dout, const void* out, const void* y, const
                          void* stream) {
     if (!dout || !y || !bnp || !part || !bwdp || !dgamma || !dbeta || !dy || (relu == 1 && !out) || relu < 0 || relu > 2) return AB_EINVAL;
     return bn_bwd_impl(dout, out, y, bnp, dtype, M, C, relu, part, bwdp, dgamma, dbeta, dy, dz_out, nullptr, 0, 0, as_stream(stream));
+}
+
+// Second half of ab_bn_bwd only (finalize + apply): `part` [nparts][C][2] already holds the per-tile sums (sum dz,
+// sum dz*xhat), written by ab_conv2d_dgrad_bnstats.
+extern "C" int ab_bn_bwd_apply(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C,
+                               int relu, const float* part, int nparts, float* bwdp, float* dgamma, float* dbeta, void* dy,
+                               void* dz_out, void* stream) {
+    if (!dout || !y || !bnp || !part || nparts < 1 || !bwdp || !dgamma || !dbeta || !dy || (relu == 1 && !out) || relu < 0 || relu > 2) return AB_EINVAL;
+    return bn_bwd_impl(dout, out, y, bnp, dtype, M, C, relu, (float*)part, bwdp, dgamma, dbeta, dy, dz_out, nullptr, 0, 0,
+                       as_stream(stream), nparts);
 }
 
 // Backward of  maxpool3x3/2( relu( bn(y) ) )  in the two BN passes: the pooled gradient dpool [N,H/2,W/2,C] is scattered

@@ -423,8 +423,8 @@ class HybridNet:
         N = S["N"]
         gv = p.gview
         if stage == "early":
-            dout, blocks = S.pop("_dout"), S.pop("_blocks_left")
-            return self._backward_trunk(S, dout, blocks)
+            dout, blocks, part = S.pop("_dout"), S.pop("_blocks_left"), S.pop("_dout_part")
+            return self._backward_trunk(S, dout, blocks, part)
         # ---- box head (f32)
         g3 = torch.zeros((N, 1, 1, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
         g3.view(N, BOX_OUT_PAD)[:, :6].copy_(g_box6d)
@@ -458,23 +458,31 @@ class HybridNet:
         blocks = list(reversed(S["blocks"]))
         if stage == "late":
             n4 = sum(1 for r in blocks if r["pre"].startswith("backbone.layer4."))
-            dout = self._backward_blocks(dout, blocks[:n4])
-            S["_dout"], S["_blocks_left"] = dout, blocks[n4:]
+            dout, part = self._backward_blocks(dout, blocks[:n4], below=blocks[n4] if n4 < len(blocks) else None)
+            S["_dout"], S["_blocks_left"], S["_dout_part"] = dout, blocks[n4:], part
             self._wgrad_join()
             return
         self._backward_trunk(S, dout, blocks)
 
-    def _backward_blocks(self, dout, blocks):
+    def _backward_blocks(self, dout, blocks, dout_part=None, below=None):
+        """Backward through `blocks` (last block of the network first).  `dout_part`: BN-backward partial sums for the
+        first block's bn2, if the producer of `dout` already reduced them.  `below`: the block that consumes the gradient
+        leaving the last entry (its bn2 reduction is fused into that data gradient where the kernel allows).
+        Returns (dout, dout_part) for `below`."""
         gv = self.p.gview
-        for rec in blocks:
+        for k, rec in enumerate(blocks):
             pre, stride, x = rec["pre"], rec["stride"], rec["x"]
+            nxt = blocks[k + 1] if k + 1 < len(blocks) else below
             dy2, dz = K.bn_bwd(dout, rec["out"], rec["y2"], rec["bnp2"], gv(pre + ".bn2.weight"), gv(pre + ".bn2.bias"),
-                               relu=True, want_dz=True)
+                               relu=True, want_dz=True, part=dout_part)
             self._wgrad_side(K.conv2d_wgrad, rec["a1"], dy2, 3, 3, 1, 1, out=gv(pre + ".conv2.weight"))
-            da1 = K.conv2d_dgrad(dy2, self.tr[pre + ".conv2.weight"], (dy2.shape[1], dy2.shape[2]), 1, 1)
+            # the BN-backward reduction of bn1 rides in the epilogue of the data gradient that produces its input
+            da1, part1 = K.conv2d_dgrad(dy2, self.tr[pre + ".conv2.weight"], (dy2.shape[1], dy2.shape[2]), 1, 1,
+                                        bn=(rec["y1"], None, rec["bnp1"]))
             dy1 = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["bnp1"], gv(pre + ".bn1.weight"), gv(pre + ".bn1.bias"),
-                            relu="recompute")
+                            relu="recompute", part=part1)
             self._wgrad_side(K.conv2d_wgrad, x, dy1, 3, 3, stride, 1, out=gv(pre + ".conv1.weight"))
+            bn_below = (nxt["y2"], nxt["out"], nxt["bnp2"]) if nxt is not None else None
             if rec["ds"]:
                 dyd = K.bn_bwd(dz, None, rec["yd"], rec["bnpd"], gv(pre + ".downsample.1.weight"),
                                gv(pre + ".downsample.1.bias"), relu=False)
@@ -482,13 +490,18 @@ class HybridNet:
                 dx = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1)
                 dout = K.conv2d_dgrad(dyd, self.tr[pre + ".downsample.0.weight"], (x.shape[1], x.shape[2]), stride, 0,
                                       addend=dx)
+                dout_part = None
+            elif bn_below is not None:
+                dout, dout_part = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1,
+                                                 addend=dz, bn=bn_below)
             else:
                 dout = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1, addend=dz)
-        return dout
+                dout_part = None
+        return dout, dout_part
 
-    def _backward_trunk(self, S, dout, blocks):
+    def _backward_trunk(self, S, dout, blocks, dout_part=None):
         gv = self.p.gview
-        dout = self._backward_blocks(dout, blocks)
+        dout, _ = self._backward_blocks(dout, blocks, dout_part)
         # ---- stem
         if self.fuse_stem_bwd:
             dy0 = K.bn_relu_maxpool_bwd(dout, S["pool_idx"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"))

@@ -45,16 +45,31 @@ def conv2d_stem_fwd(xpad, w_stem, H, W, want_stats=False):
     return (y, stats) if want_stats else y
 
 
-def conv2d_dgrad(dy, w_ihwo, in_hw, stride, pad, addend=None):
-    """dy [N,Ho,Wo,Cout], w [Cin,kh,kw,Cout] -> dx [N,H,W,Cin]  (== ConvTranspose2d forward when x:=dy)."""
+def conv2d_dgrad(dy, w_ihwo, in_hw, stride, pad, addend=None, bn=None):
+    """dy [N,Ho,Wo,Cout], w [Cin,kh,kw,Cout] -> dx [N,H,W,Cin]  (== ConvTranspose2d forward when x:=dy).
+    bn=(bn_y, bn_out_or_None, bnp): also try to fuse the BatchNorm-backward reduction of the layer that produced this
+    conv's input into the epilogue (ab_conv2d_dgrad_bnstats); returns (dx, part) with part=None when the shape has no
+    fused path."""
     N, Ho, Wo, Cout = dy.shape
     Cin, kh, kw, _ = w_ihwo.shape
     H, W = in_hw
     dx = _empty((N, H, W, Cin), dy)
+    if bn is not None:
+        lib = L.lib()
+        rows = lib.ab_conv2d_dgrad_bnstats_rows(L.i(L.dt(dy)), L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw),
+                                                L.i(stride), L.i(pad))
+        if rows > 0:
+            bn_y, bn_out, bnp = bn
+            part = torch.empty((rows, Cin, 2), dtype=torch.float32, device=dy.device)
+            L.check(lib.ab_conv2d_dgrad_bnstats(L.ptr(dy), L.ptr(w_ihwo), L.ptr(dx), L.i(L.dt(dy)), L.i(N), L.i(H), L.i(W),
+                                                L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(addend),
+                                                L.ptr(bn_y), L.ptr(bn_out), L.ptr(bnp), L.ptr(part), L.stream()),
+                    "ab_conv2d_dgrad_bnstats")
+            return dx, part
     L.check(L.lib().ab_conv2d_dgrad(L.ptr(dy), L.ptr(w_ihwo), L.ptr(dx), L.i(L.dt(dy)), L.i(N), L.i(H), L.i(W), L.i(Cin),
                                     L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(addend), L.ptr(None),
                                     L.stream()), "ab_conv2d_dgrad")
-    return dx
+    return (dx, None) if bn is not None else dx
 
 
 _ws = {}
@@ -128,17 +143,24 @@ def bn_apply(y, bnp, res=None, relu=True, out=None):
     return o
 
 
-def bn_bwd(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, dy_out=None):
+def bn_bwd(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, dy_out=None, part=None):
     """-> dy (grad wrt the conv output y) [, dz = dout*relu_mask].
+    part: per-tile sums from conv2d_dgrad(..., bn=...) -- skips the reduction pass.
     relu: False (no activation), True (mask from the stored activation `out`; required when a residual was added before
     the ReLU) or "recompute" (mask from y*scale+shift, `out` is not read)."""
     C = y.shape[-1]
     M = y.numel() // C
     lib = L.lib()
-    part = torch.empty((lib.ab_col_stats_nparts(L.l(M)), C, 2), dtype=torch.float32, device=y.device)
     bwdp = torch.empty((2, C), dtype=torch.float32, device=y.device)
     dy = dy_out if dy_out is not None else torch.empty_like(y)
     dz = torch.empty_like(y) if want_dz else None
+    if part is not None:       # first pass already done in the epilogue of the conv that produced `dout`
+        L.check(lib.ab_bn_bwd_apply(L.ptr(dout), L.ptr(out if relu is True else None), L.ptr(y), L.ptr(bnp), L.i(L.dt(y)),
+                                    L.l(M), L.i(C), L.i(2 if relu == "recompute" else 1 if relu else 0), L.ptr(part),
+                                    L.i(part.shape[0]), L.ptr(bwdp), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy), L.ptr(dz),
+                                    L.stream()), "ab_bn_bwd_apply")
+        return (dy, dz) if want_dz else dy
+    part = torch.empty((lib.ab_col_stats_nparts(L.l(M)), C, 2), dtype=torch.float32, device=y.device)
     L.check(lib.ab_bn_bwd(L.ptr(dout), L.ptr(out if relu is True else None), L.ptr(y), L.ptr(bnp), L.i(L.dt(y)), L.l(M), L.i(C),
                           L.i(2 if relu == "recompute" else 1 if relu else 0), L.ptr(part), L.ptr(bwdp), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy),
                           L.ptr(dz), L.stream()), "ab_bn_bwd")

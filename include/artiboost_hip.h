@@ -95,6 +95,20 @@ int ab_col_sum(const void* x, int dtype, long M, int C, float* part, float* out,
 int ab_add(const void* a, const void* b, int dtype, long n, void* out, void* stream);
 /* idx: uint8 [N,H/2,W/2,C] winning tap (0..8, first maximum in row-major order); H,W describe the pool INPUT          */
 int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* idx, void* stream);
+/* BatchNorm-backward reduction fused into the producer of its input gradient.  ab_conv2d_dgrad_bnstats is
+ * ab_conv2d_dgrad (3x3 / stride 1 / pad 1, bf16) whose epilogue also accumulates, over the dx tile it stores, the sums
+ * (sum dz, sum dz*xhat) of the BatchNorm that produced this conv's INPUT activation: bn_y = that BN's input (the conv
+ * output it normalised), bnp = its (scale, shift, mean, invstd), dz = dx masked by the ReLU that followed (mask from the
+ * stored activation bn_out when non-NULL -- required if a residual was added before the ReLU -- else recomputed from
+ * bn_y).  bn_part: float [rows][Cin][2] with rows = ab_conv2d_dgrad_bnstats_rows(...) (0: no fused path for this shape;
+ * use ab_conv2d_dgrad + ab_bn_bwd).  ab_bn_bwd_apply is the rest of ab_bn_bwd (finalize + apply) from such partials. */
+int ab_conv2d_dgrad_bnstats_rows(int dtype, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+int ab_conv2d_dgrad_bnstats(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int Cin, int Cout,
+                            int kh, int kw, int stride, int pad, const void* addend, const void* bn_y, const void* bn_out,
+                            const float* bnp, float* bn_part, void* stream);
+int ab_bn_bwd_apply(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C, int relu,
+                    const float* part, int nparts, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out,
+                    void* stream);
 /* Stem fusion: out = maxpool3x3/2(relu(y*bnp[0]+bnp[1])) without materialising the activation, and its backward through
  * both BN passes (dpool: pooled gradient; part/bwdp as in ab_bn_bwd with M = N*H*W).                                 */
 int ab_bn_relu_maxpool3x3s2_fwd(const void* y, const float* bnp, int dtype, int N, int H, int W, int C, void* out,

@@ -2,6 +2,8 @@
 is built from).  f32 path: MFMA f32 is an exact fmaf chain -> tight tolerance.  bf16 path: operands are rounded to
 bf16 on the host first so both sides see identical inputs; the tolerance then covers fp32-accumulate ordering and
 the bf16 rounding of the stored output (2^-8 relative)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -256,3 +258,38 @@ def test_fused_stem_bn_relu_maxpool(shape, dtype):
     ref_dy = K.bn_bwd(da, None, y, bnp, dg0, db0, relu="recompute")
     dy = K.bn_relu_maxpool_bwd(dpool, idx, y, bnp, dg1, db1)
     assert torch.equal(dy, ref_dy) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, False), (3, 32, 32, 64, 64, True), (2, 8, 8, 128, 192, True),
+                                  (1, 20, 12, 64, 64, False)])
+def test_dgrad_with_fused_bn_backward_reduction(case, monkeypatch):
+    """ab_conv2d_dgrad_bnstats: the BN-backward sums accumulated in the data-gradient epilogue + ab_bn_bwd_apply give the
+    same dx / dy / dgamma / dbeta as ab_conv2d_dgrad followed by the two-pass ab_bn_bwd."""
+    from artiboost_amd import kernels as K
+    if os.environ.get("AB_BNFUSE_MIN") != "1":
+        pytest.skip("opt-in path: run with AB_BNFUSE_MIN=1 (the library reads the variable once per process)")
+    N, H, W, Cin, Cout, residual = case
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    dt = torch.bfloat16
+    dy = (0.5 * torch.randn((N, H, W, Cout), generator=g)).to(dt).cuda()
+    wt = (0.05 * torch.randn((Cin, 3, 3, Cout), generator=g)).to(dt).cuda()
+    y = (torch.randn((N, H, W, Cin), generator=g) * 1.2 + 0.1).to(dt).cuda()           # the lower BN's input
+    res = torch.randn((N, H, W, Cin), generator=g).to(dt).cuda() if residual else None
+    addend = (0.3 * torch.randn((N, H, W, Cin), generator=g)).to(dt).cuda() if residual else None
+    gamma = (0.5 + torch.rand(Cin, generator=g)).cuda(); beta = (0.1 * torch.randn(Cin, generator=g)).cuda()
+    bnp = K.bn_finalize(K.col_stats(y), N * H * W, gamma, beta)
+    out = K.bn_apply(y, bnp, res=res, relu=True)
+    relu = True if residual else "recompute"
+    # reference: separate kernels
+    dx0 = K.conv2d_dgrad(dy, wt, (H, W), 1, 1, addend=addend)
+    dg0, db0 = torch.empty(Cin).cuda(), torch.empty(Cin).cuda()
+    d0 = K.bn_bwd(dx0, out if residual else None, y, bnp, dg0, db0, relu=relu)
+    # fused
+    dx1, part = K.conv2d_dgrad(dy, wt, (H, W), 1, 1, addend=addend, bn=(y, out if residual else None, bnp))
+    assert part is not None
+    dg1, db1 = torch.empty(Cin).cuda(), torch.empty(Cin).cuda()
+    d1 = K.bn_bwd(dx1, out if residual else None, y, bnp, dg1, db1, relu=relu, part=part)
+    assert torch.equal(dx0, dx1)
+    np.testing.assert_allclose(dg1.cpu().numpy(), dg0.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(dg0.abs().max()))
+    np.testing.assert_allclose(db1.cpu().numpy(), db0.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(db0.abs().max()))
+    np.testing.assert_allclose(d1.float().cpu().numpy(), d0.float().cpu().numpy(), rtol=2e-2, atol=2e-2 * float(d0.float().abs().max()))
