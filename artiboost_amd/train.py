@@ -144,6 +144,8 @@ class TrainStep:
         with torch.cuda.stream(s):          # warm-up on a side stream (allocator, lazy state) before capture
             self.crit.freeze_draws(True)
             self._fwd_bwd()
+            if self.world > 1:                 # the warm-up is a real optimizer step: it must see the averaged gradient too
+                self._allreduce()
             self._optim()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
