@@ -242,7 +242,7 @@ def main():
                     "frac": round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4), "traffic": pmc_traffic(args),
                     "traffic_unit": "HBM bytes per step over the conv-stack launches (PMC, profiles/round1_pmc_hbm_traffic.*)",
                     "kernel": "implicit-GEMM conv stack: conv3x3_kernel / conv_gemm2_kernel / conv_gemm_kernel (fwd, dgrad) + "
-                              "wgrad3x3_kernel / wgrad_kernel / wgrad_reduce (weight grad)",
+                              "wgrad3x3_kernel / wgrad_gemm2_kernel / wgrad_reduce (weight grad)",
                     "conv_ms_per_step": round(conv_ms, 3), "conv_launches_per_step": nlaunch}
         except Exception as e:   # noqa: BLE001
             roof = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": None,
