@@ -22,6 +22,7 @@
 #define ZMAX 16777215.0f
 #define KD 0.0716f
 #define TILE 32
+#define BIN_CAP 1024      // per-tile triangle list capacity (overflowing tiles fall back to scanning all records)
 
 struct SceneDev {    // mirrors ab_scene (host struct of device pointers)
     const int32_t* hand_faces; const float* hand_normals; const float* hand_uv; const uint8_t* hand_tex; int hts;
@@ -119,40 +120,55 @@ __device__ __forceinline__ bool cover(const TriRec& t, int32_t px, int32_t py, i
 }
 
 // ------------------------------------------------------------------ kernel 1: triangle setup
-// tri: [B][maxf] records; sbox: int [B][4] = minx, maxx, miny, maxy in pixels (init +inf/-inf by the launcher)
+// tri: [B][maxf] records; tails: their (valid, bbox) words; bin_count / bin_list: per-tile triangle lists (zeroed by the launcher)
 __global__ __launch_bounds__(256) void raster_setup_kernel(SceneDev sc, const SampleDev* __restrict__ samples,
                                                            const float* __restrict__ hand_verts, int maxf,
                                                            TriRec* __restrict__ tri, int4* __restrict__ tails,
-                                                           int* __restrict__ sbox) {
+                                                           int* __restrict__ bin_count, int* __restrict__ bin_list) {
+    extern __shared__ int s_bin[];                  // [3][ntile]: pairs counted, global base, pairs placed
     const int b = blockIdx.y;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const SampleDev sm = samples[b];
     const int nf = HAND_FACES + (sc.obj_face_off[sm.obj_id + 1] - sc.obj_face_off[sm.obj_id]);
-    if (gid >= maxf) return;
+    const int tiles_x = sc.W / TILE, ntile = tiles_x * (sc.H / TILE);
+    int* lcount = s_bin; int* lbase = s_bin + ntile; int* lplaced = s_bin + 2 * ntile;
+    for (int i = threadIdx.x; i < ntile; i += 256) { lcount[i] = 0; lplaced[i] = 0; }
+    __syncthreads();
     TriRec t;
     t.valid = 0;
+    int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
     if (gid < nf) setup_tri(sc, sm, hand_verts + (size_t)b * HAND_VERTS * 3, gid, t);
     if (t.valid) {
         int32_t minx = min(t.x[0], min(t.x[1], t.x[2])), maxx = max(t.x[0], max(t.x[1], t.x[2]));
         int32_t miny = min(t.y[0], min(t.y[1], t.y[2])), maxy = max(t.y[0], max(t.y[1], t.y[2]));
-        int x0 = (minx - 128 + 255) >> 8, x1 = (maxx - 128) >> 8, y0 = (miny - 128 + 255) >> 8, y1 = (maxy - 128) >> 8;
+        x0 = (minx - 128 + 255) >> 8; x1 = (maxx - 128) >> 8; y0 = (miny - 128 + 255) >> 8; y1 = (maxy - 128) >> 8;
         x0 = max(x0, 0); y0 = max(y0, 0); x1 = min(x1, sc.W - 1); y1 = min(y1, sc.H - 1);
         if (x0 > x1 || y0 > y1) t.valid = 0;
-        else {
-            t.bx0 = (int16_t)x0; t.bx1 = (int16_t)x1; t.by0 = (int16_t)y0; t.by1 = (int16_t)y1;
-            atomicMin(&sbox[b * 4 + 0], x0); atomicMax(&sbox[b * 4 + 1], x1);
-            atomicMin(&sbox[b * 4 + 2], y0); atomicMax(&sbox[b * 4 + 3], y1);
-        }
+        else { t.bx0 = (int16_t)x0; t.bx1 = (int16_t)x1; t.by0 = (int16_t)y0; t.by1 = (int16_t)y1; }
     }
-    tri[(size_t)b * maxf + gid] = t;
-    // compact copy of (valid, bbox) = bytes 32..47 of the record: the per-tile scan reads only these, fully coalesced
-    tails[(size_t)b * maxf + gid] = make_int4((int)t.z[2], t.valid, (int)((uint16_t)t.bx0 | ((uint32_t)(uint16_t)t.bx1 << 16)),
-                                              (int)((uint16_t)t.by0 | ((uint32_t)(uint16_t)t.by1 << 16)));
-}
-
-__global__ void sbox_init_kernel(int* sbox, int B) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) { sbox[i * 4] = 1 << 30; sbox[i * 4 + 1] = -(1 << 30); sbox[i * 4 + 2] = 1 << 30; sbox[i * 4 + 3] = -(1 << 30); }
+    if (gid < maxf) {
+        tri[(size_t)b * maxf + gid] = t;
+        // compact copy of (valid, bbox) = bytes 32..47 of the record: what a tile needs to clip a listed triangle
+        tails[(size_t)b * maxf + gid] = make_int4((int)t.z[2], t.valid, (int)((uint16_t)t.bx0 | ((uint32_t)(uint16_t)t.bx1 << 16)),
+                                                  (int)((uint16_t)t.by0 | ((uint32_t)(uint16_t)t.by1 << 16)));
+    }
+    // Bin the triangle into every tile its pixel bbox touches (append order is irrelevant: the z-test is a commutative
+    // atomic min on (depth, face id)).  (triangle, tile) pairs are counted in LDS first so that a workgroup makes ONE global
+    // reservation per tile it touches instead of one contended atomic per pair.
+    if (t.valid)
+        for (int ty = y0 / TILE; ty <= y1 / TILE; ++ty)
+            for (int tx = x0 / TILE; tx <= x1 / TILE; ++tx) atomicAdd(&lcount[ty * tiles_x + tx], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntile; i += 256)
+        if (lcount[i] > 0) lbase[i] = atomicAdd(&bin_count[b * ntile + i], lcount[i]);
+    __syncthreads();
+    if (t.valid)
+        for (int ty = y0 / TILE; ty <= y1 / TILE; ++ty)
+            for (int tx = x0 / TILE; tx <= x1 / TILE; ++tx) {
+                const int tile = ty * tiles_x + tx;
+                const int slot = lbase[tile] + atomicAdd(&lplaced[tile], 1);
+                if (slot < BIN_CAP) bin_list[((size_t)b * ntile + tile) * BIN_CAP + slot] = gid;
+            }
 }
 
 // ------------------------------------------------------------------ kernel 2: tile raster + shade
@@ -237,7 +253,7 @@ __device__ __forceinline__ void shade_pixel(const SceneDev& sc, const SampleDev&
 __global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const SampleDev* __restrict__ samples,
                                                            const float* __restrict__ hand_verts, int maxf,
                                                            const TriRec* __restrict__ tri, const int4* __restrict__ tails_g,
-                                                           const int* __restrict__ sbox,
+                                                           const int* __restrict__ bin_count, const int* __restrict__ bin_list,
                                                            uint8_t* __restrict__ rgbx, uint64_t* __restrict__ keys_out) {
     __shared__ unsigned long long zb[TILE * TILE];
     const int b = blockIdx.y;
@@ -247,31 +263,21 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const Sa
     const float* hv = hand_verts + (size_t)b * HAND_VERTS * 3;
     for (int i = threadIdx.x; i < TILE * TILE; i += 256) zb[i] = ~0ull;
     __syncthreads();
-    const int bx0 = sbox[b * 4], bx1 = sbox[b * 4 + 1], by0 = sbox[b * 4 + 2], by1 = sbox[b * 4 + 3];
-    const bool active = !(bx1 < tx0 || bx0 > tx0 + TILE - 1 || by1 < ty0 || by0 > ty0 + TILE - 1);
+    const int ntile = tiles_x * (sc.H / TILE);
+    const int nbin = bin_count[b * ntile + blockIdx.x];
+    const bool active = nbin > 0;
     if (active) {
         const int nf = HAND_FACES + (sc.obj_face_off[sm.obj_id + 1] - sc.obj_face_off[sm.obj_id]);
         const TriRec* tb = tri + (size_t)b * maxf;
-        // four record tails per lane are fetched before any is examined: the scan is a chain of dependent-latency loads
-        for (int gbase = threadIdx.x; gbase < nf; gbase += 1024) {
-          int4 tails[4];
-          const int4* tl = tails_g + (size_t)b * maxf;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-              const int gq = gbase + u * 256;
-              tails[u] = gq < nf ? tl[gq] : make_int4(0, 0, 0, 0);          // z[2], valid, bbox
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int gid = gbase + u * 256;
-            const int4 tail = tails[u];
+        const int4* tl = tails_g + (size_t)b * maxf;
+        auto raster_tri = [&](const int gid, const int4 tail) {
             const int valid = tail.y;
-            if (!valid) continue;
+            if (!valid) return;
             const int16_t qx0 = (int16_t)(tail.z & 0xffff), qx1 = (int16_t)((uint32_t)tail.z >> 16);
             const int16_t qy0 = (int16_t)(tail.w & 0xffff), qy1 = (int16_t)((uint32_t)tail.w >> 16);
             int x0 = max((int)qx0, tx0), x1 = min((int)qx1, tx0 + TILE - 1);
             int y0 = max((int)qy0, ty0), y1 = min((int)qy1, ty0 + TILE - 1);
-            if (x0 > x1 || y0 > y1) continue;
+            if (x0 > x1 || y0 > y1) return;
             const TriRec t = tb[gid];
             // Same integers as cover()/the oracle, evaluated incrementally: the edge functions are affine in the pixel
             // index, so one 64-bit add per edge per pixel replaces two 64-bit multiplies; the top-left rule is folded in
@@ -307,7 +313,20 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const Sa
                 }
                 wrow[0] += sy[0]; wrow[1] += sy[1]; wrow[2] += sy[2]; nrow += nsy;
             }
-          }
+        };
+        if (nbin <= BIN_CAP) {
+            // the tile's own list (typically ~100 triangles: one round of the 256 lanes)
+            const int* lst = bin_list + ((size_t)b * ntile + blockIdx.x) * BIN_CAP;
+            for (int i = threadIdx.x; i < nbin; i += 256) { const int gid = lst[i]; raster_tri(gid, tl[gid]); }
+        } else {
+            // overflowed list: scan every record; four tails per lane are fetched before any is examined
+            for (int gbase = threadIdx.x; gbase < nf; gbase += 1024) {
+                int4 tails[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int gq = gbase + u * 256; tails[u] = gq < nf ? tl[gq] : make_int4(0, 0, 0, 0); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) raster_tri(gbase + u * 256, tails[u]);
+            }
         }
     }
     __syncthreads();
@@ -471,10 +490,16 @@ static SceneDev to_dev(const ab_scene* s) {
     return d;
 }
 
+__global__ void zero_words_kernel(unsigned* __restrict__ p, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
 extern "C" long ab_render_workspace_bytes(int B, int W, int H, int max_faces) {
-    // tri records + rgbx + lsum + sbox + compact (valid, bbox) tails, each 256-byte aligned
+    // tri records + rgbx + lsum + sbox + compact (valid, bbox) tails + per-tile bin counts and lists, each 256-byte aligned
     auto al = [](long x) { return (x + 255) / 256 * 256; };
-    return al((long)B * max_faces * 48) + al((long)B * W * H * 4) + al((long)B * 8) + al((long)B * 16) + al((long)B * max_faces * 16);
+    return al((long)B * max_faces * 48) + al((long)B * W * H * 4) + al((long)B * 8) + al((long)B * 16) + al((long)B * max_faces * 16) +
+           al((long)B * (W / TILE) * (H / TILE) * 4) + al((long)B * (W / TILE) * (H / TILE) * BIN_CAP * 4);
 }
 
 extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, const float* hand_verts,
@@ -485,22 +510,28 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
     if (!out_pad && !out_chw) return AB_EINVAL;
     SceneDev sc = to_dev(scene_host);
     if (sc.W % TILE || sc.H % TILE || B < 1 || max_faces < HAND_FACES) return AB_ESHAPE;
+    if ((long)(sc.W / TILE) * (sc.H / TILE) * 12 > 64 * 1024) return AB_ESHAPE;      // per-tile LDS counters of the setup kernel
     hipStream_t st = as_stream(stream);
     auto al = [](long x) { return (x + 255) / 256 * 256; };
     char* ws = (char*)workspace;
     TriRec* tri = (TriRec*)ws; ws += al((long)B * max_faces * 48);
     uint8_t* rgbx = rgbx_out ? (uint8_t*)rgbx_out : (uint8_t*)ws; ws += al((long)B * sc.W * sc.H * 4);
     unsigned long long* lsum = (unsigned long long*)ws; ws += al((long)B * 8);
-    int* sbox = (int*)ws; ws += al((long)B * 16);
-    int4* tails = (int4*)ws;
-    hipError_t e = hipMemsetAsync(lsum, 0, (size_t)B * 8, st);
-    if (e != hipSuccess) return (int)e;
-    sbox_init_kernel<<<(B + 63) / 64, 64, 0, st>>>(sbox, B);
-    raster_setup_kernel<<<dim3((max_faces + 255) / 256, B), 256, 0, st>>>(sc, (const SampleDev*)samples, hand_verts,
-                                                                           max_faces, tri, tails, sbox);
+    ws += al((long)B * 16);                                   // (reserved)
+    int4* tails = (int4*)ws; ws += al((long)B * max_faces * 16);
+    const long ntile = (long)(sc.W / TILE) * (sc.H / TILE);
+    int* bin_count = (int*)ws; ws += al(B * ntile * 4);
+    int* bin_list = (int*)ws;
+    // zeroing by kernel, not hipMemsetAsync: under stream capture the 64 KiB memset node of bin_count faulted on replay
+    // (ROCm 7.2), so neither buffer goes through a memset node
+    zero_words_kernel<<<(unsigned)((B * 2 + 255) / 256), 256, 0, st>>>((unsigned*)lsum, (long)B * 2);
+    zero_words_kernel<<<(unsigned)((B * ntile + 255) / 256), 256, 0, st>>>((unsigned*)bin_count, B * ntile);
+    AB_LAUNCH_CHECK();
+    raster_setup_kernel<<<dim3((max_faces + 255) / 256, B), 256, (size_t)ntile * 12, st>>>(sc, (const SampleDev*)samples, hand_verts,
+                                                                           max_faces, tri, tails, bin_count, bin_list);
     AB_LAUNCH_CHECK();
     raster_shade_kernel<<<dim3((sc.W / TILE) * (sc.H / TILE), B), 256, 0, st>>>(sc, (const SampleDev*)samples, hand_verts,
-                                                                                 max_faces, tri, tails, sbox, rgbx,
+                                                                                 max_faces, tri, tails, bin_count, bin_list, rgbx,
                                                                                  (uint64_t*)keys_out);
     AB_LAUNCH_CHECK();
     int npix = sc.W * sc.H;
