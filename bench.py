@@ -250,7 +250,7 @@ def main():
         base = None
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(args, cfg)
-        out = {"metric": "synth samples/sec (render+fwd+bwd) 256x256 bs=64", "value": round(value, 2), "unit": "samples/s",
+        out = {"metric": f"synth samples/sec (render+fwd+bwd) {args.size}x{args.size} bs={args.bs}", "value": round(value, 2), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic (seeded stand-in meshes/textures/grasps; random-init weights)",
