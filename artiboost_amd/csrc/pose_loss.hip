@@ -74,6 +74,12 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     __shared__ float gP[22][3], gC[8][3];
     __shared__ float red[64][5];
     __shared__ float fx, fy, cx, cy, rootz;
+    // pair index tables staged once: the gradient-gather loops below walk them per lane (70 + 63 + 56 entries, twice),
+    // which as global loads was the latency chain of this kernel
+    __shared__ uint8_t ij0[PL_MAXPAIR], ij1[PL_MAXPAIR], ip0[PL_MAXPAIR], ip1[PL_MAXPAIR], is0[PL_MAXPAIR], is1[PL_MAXPAIR];
+    for (int i = lane; i < a.njp; i += 64) { ij0[i] = (uint8_t)a.j0[i]; ij1[i] = (uint8_t)a.j1[i]; }
+    for (int i = lane; i < a.npp; i += 64) { ip0[i] = (uint8_t)a.p0[i]; ip1[i] = (uint8_t)a.p1[i]; }
+    for (int i = lane; i < a.nsp; i += 64) { is0[i] = (uint8_t)a.s0[i]; is1[i] = (uint8_t)a.s1[i]; }
 
     const float* kp = a.kp3d + (long)b * 66;
     if (lane == 0) {
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     // joint-level ordinal: one pair per lane-iteration, loop over views
     const float wjo = a.w_handord * a.lam_hand_joint / nJO;
     for (int pi = lane; pi < a.njp; pi += 64) {
-        int i0 = (int)a.j0[pi], i1 = (int)a.j1[pi];
+        int i0 = (int)ij0[pi], i1 = (int)ij1[pi];
         float dt[3], dp[3], g[3] = {0.f, 0.f, 0.f};
         for (int i = 0; i < 3; ++i) { dt[i] = mT[i0][i] - mT[i1][i]; dp[i] = mP[i0][i] - mP[i1][i]; }
         for (int v = 0; v < a.nvh; ++v) {
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     // part-level ordinal
     const float wpo = a.w_handord * a.lam_hand_part / nPO;
     for (int pi = lane; pi < a.npp; pi += 64) {
-        int i0 = (int)a.p0[pi], i1 = (int)a.p1[pi];
+        int i0 = (int)ip0[pi], i1 = (int)ip1[pi];
         float ct[3], cp[3], gp[3] = {0.f, 0.f, 0.f}, gq[3] = {0.f, 0.f, 0.f};
         cross3(part_t[i0], part_t[i1], ct);
         cross3(part_p[i0], part_p[i1], cp);
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     // scene ordinal
     const float wso = a.w_sceneord * a.lam_scene / nSO;
     for (int pi = lane; pi < a.nsp; pi += 64) {
-        int i0 = (int)a.s0[pi], i1 = (int)a.s1[pi];
+        int i0 = (int)is0[pi], i1 = (int)is1[pi];
         float dt[3], dp[3], g[3] = {0.f, 0.f, 0.f};
         for (int i = 0; i < 3; ++i) { dt[i] = mT[i0][i] - mTC[i1][i]; dp[i] = mP[i0][i] - mC[i1][i]; }
         for (int v = 0; v < a.nvs; ++v) {
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     if (lane < 60) {
         int k = lane / 3, i = lane % 3;
         float s = 0.f;
-        for (int pi = 0; pi < a.npp; ++pi) { if ((int)a.p0[pi] == k) s += gpp[pi][i]; if ((int)a.p1[pi] == k) s += gpq[pi][i]; }
+        for (int pi = 0; pi < a.npp; ++pi) { if ((int)ip0[pi] == k) s += gpp[pi][i]; if ((int)ip1[pi] == k) s += gpq[pi][i]; }
         gpart[k][i] = s;
     }
     __syncthreads();
@@ -228,8 +234,8 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     if (lane < 63) {      // gradient wrt masked joint mP[k][i], then * vis
         int k = lane / 3, i = lane % 3;
         float s = wJ * (mP[k][i] - mT[k][i]);
-        for (int pi = 0; pi < a.njp; ++pi) { if ((int)a.j0[pi] == k) s += gjp[pi][i]; if ((int)a.j1[pi] == k) s -= gjp[pi][i]; }
-        for (int pi = 0; pi < a.nsp; ++pi) if ((int)a.s0[pi] == k) s += gsp[pi][i];
+        for (int pi = 0; pi < a.njp; ++pi) { if ((int)ij0[pi] == k) s += gjp[pi][i]; if ((int)ij1[pi] == k) s -= gjp[pi][i]; }
+        for (int pi = 0; pi < a.nsp; ++pi) if ((int)is0[pi] == k) s += gsp[pi][i];
         if (k >= 1) s += gpart[k - 1][i];
         for (int c = 1; c < 21; ++c) if (c_parents[c] == k) s -= gpart[c - 1][i];
         gP[k][i] = s * vj[k];
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     if (lane < 24) {
         int c = lane / 3, i = lane % 3;
         float s = wC * (mC[c][i] - mTC[c][i]);
-        for (int pi = 0; pi < a.nsp; ++pi) if ((int)a.s1[pi] == c) s -= gsp[pi][i];
+        for (int pi = 0; pi < a.nsp; ++pi) if ((int)is1[pi] == c) s -= gsp[pi][i];
         gC[c][i] = s * vc[c];
     }
     __syncthreads();
