@@ -407,22 +407,34 @@ class HybridNet:
             torch.cuda.current_stream(self.p.device).wait_stream(self._wg_stream)
             self._wg_keep.clear()
 
-    def grad_split_offset(self):
-        """Element offset in the flat gradient where the parameters of layer4 + heads begin: backward(stage="late")
-        fills [offset, total) and backward(stage="early") fills [0, offset) (DDP overlap, train.TrainStep)."""
-        return self.p.entries["backbone.layer4.0.conv1.weight"].offset
+    BWD_STAGES = 3
+
+    def grad_stage_ranges(self):
+        """[(lo, hi)] element ranges of the flat gradient completed by backward(stage=0), (stage=1), (stage=2): heads +
+        layer4 (68 % of the bytes, produced first), layer3 (27 %), layer2 .. stem (5 %) -- the DDP overlap schedule of
+        train.TrainStep all-reduces each range while the next stage computes."""
+        o4 = self.p.entries["backbone.layer4.0.conv1.weight"].offset
+        o3 = self.p.entries["backbone.layer3.0.conv1.weight"].offset
+        return [(o4, self.p.total), (o3, o4), (0, o3)]
 
     def backward(self, dlogits=None, g_box6d=None, stage=None):
         """dlogits: gradient wrt the logits [N,h,w,22*32] (compute dtype); g_box6d [N,6] f32.
         Fills self.p.grad (overwrites).  Returns nothing (no gradient to the image).
-        stage=None runs the whole backward; "late" runs box head, heat-map head and layer4 (68 % of the gradient bytes,
-        produced first) and parks the activation gradient; "early" continues with layer3 .. stem."""
+        stage=None runs the whole backward; stage=0 runs box head, heat-map head and layer4 and parks the activation
+        gradient, stage=1 continues with layer3, stage=2 with layer2 .. stem (see grad_stage_ranges)."""
         S, p, dt = self.saved, self.p, self.dtype
         if S is None:
             raise RuntimeError("backward() without a training-mode forward()")
         N = S["N"]
         gv = p.gview
-        if stage == "early":
+        if stage == 1:
+            dout, blocks, part = S.pop("_dout"), S.pop("_blocks_left"), S.pop("_dout_part")
+            n3 = sum(1 for r in blocks if r["pre"].startswith("backbone.layer3."))
+            dout, part = self._backward_blocks(dout, blocks[:n3], part, below=blocks[n3] if n3 < len(blocks) else None)
+            S["_dout"], S["_blocks_left"], S["_dout_part"] = dout, blocks[n3:], part
+            self._wgrad_join()
+            return
+        if stage == 2:
             dout, blocks, part = S.pop("_dout"), S.pop("_blocks_left"), S.pop("_dout_part")
             return self._backward_trunk(S, dout, blocks, part)
         # ---- box head (f32)
@@ -456,7 +468,7 @@ class HybridNet:
         K.avgpool_bwd(g_mean, dout, accumulate=True)
         # ---- backbone, last block first
         blocks = list(reversed(S["blocks"]))
-        if stage == "late":
+        if stage == 0:
             n4 = sum(1 for r in blocks if r["pre"].startswith("backbone.layer4."))
             dout, part = self._backward_blocks(dout, blocks[:n4], below=blocks[n4] if n4 < len(blocks) else None)
             S["_dout"], S["_blocks_left"], S["_dout_part"] = dout, blocks[n4:], part

@@ -5,8 +5,8 @@
 hipGraphs (one capture, then ~tens of microseconds of host work per step): everything between the batch being
 resident in HBM and the parameters being updated is device work on one stream; per-step host inputs (loss RNG draws,
 Adam bias corrections, CCV sample descriptors) go through small pinned -> device copies issued before the replay.
-With world_size > 1 the step is split in two graphs around the RCCL all-reduce of the flat gradient buffer, which
-runs on a side stream and overlaps with the render of the next batch."""
+With world_size > 1 the backward is captured as three graphs; the RCCL all-reduce of each finished range of the flat
+gradient buffer runs on a side stream while the next stage computes."""
 import os
 
 import torch
@@ -48,12 +48,13 @@ class TrainStep:
         self.g_opt = None
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
         self.steps = 0
-        # DDP overlap: the backward is captured as two graphs.  "late" (box head, heat-map head, layer4) produces 68 % of
-        # the gradient bytes first; their all-reduce runs on the comm stream while "early" (layer3 .. stem) computes,
-        # so only the last 33 MB are exposed.  AB_DDP_SPLIT=1 forces the split on one GPU (tests), =0 disables it.
+        # DDP overlap: the backward is captured as three graphs (heads + layer4 | layer3 | layer2 .. stem).  The first
+        # stage produces 68 % of the gradient bytes, the second 27 %; each range is all-reduced on the comm stream while
+        # the next stage computes, so only the last 5 MB are exposed.  AB_DDP_SPLIT=1 forces the split on one GPU
+        # (tests), =0 disables it.
         env = os.environ.get("AB_DDP_SPLIT", "")
         self.split = bool(use_graph and fused_criterion and (self.world > 1 or env == "1") and env != "0")
-        self.g_bwd_early = None
+        self.g_bwd_rest = []
         # Render/learn pipelining (the reference overlaps them through DataLoader worker processes,
         # artiboost_loader.py:195-260): the batch for step i+1 is rendered on a side stream while step i trains.
         # `rstatic` holds the render inputs of the NEXT batch and its own image buffer; the image is handed over by one
@@ -106,7 +107,7 @@ class TrainStep:
         kp3d, conf, stat = net.head_fwd(logits)
         o = self.fused(kp3d, net.last["box_raw"], net.last["box_raw"].shape[-1], st)
         dlogits = net.head_bwd(logits, kp3d, conf, stat, o["g_kp3d"])
-        net.backward(dlogits, o["g_box6d"], stage="late" if self._capturing_split else None)
+        net.backward(dlogits, o["g_box6d"], stage=0 if self._capturing_split else None)
         hb.flat_param.grad = hb.store.grad
         preds = dict(o, kp3d=kp3d, kp3d_confd=conf)
         return preds, o["losses"], o
@@ -155,9 +156,12 @@ class TrainStep:
             try:
                 with torch.cuda.graph(self.g_fwd_bwd):
                     self.out = self._fwd_bwd()                       # ... up to and including layer4's backward
-                self.g_bwd_early = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_bwd_early, pool=self.g_fwd_bwd.pool()):
-                    self.hb.net.backward(stage="early")
+                self.g_bwd_rest = []
+                for st in range(1, self.hb.net.BWD_STAGES):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self.g_fwd_bwd.pool()):
+                        self.hb.net.backward(stage=st)
+                    self.g_bwd_rest.append(g)
             finally:
                 self._capturing_split = False
         else:
@@ -209,12 +213,14 @@ class TrainStep:
             self.opt.advance_hyper()
             self.g_fwd_bwd.replay()
             if self.split:
-                off = self.hb.net.grad_split_offset()
+                ranges = self.hb.net.grad_stage_ranges()
                 if self.world > 1:
-                    self._allreduce_range(off, self.hb.store.grad.numel())
-                self.g_bwd_early.replay()
+                    self._allreduce_range(*ranges[0])
+                for g, rng in zip(self.g_bwd_rest, ranges[1:]):
+                    g.replay()
+                    if self.world > 1:
+                        self._allreduce_range(*rng)
                 if self.world > 1:
-                    self._allreduce_range(0, off)
                     torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
             elif self.world > 1:
                 self._allreduce()
