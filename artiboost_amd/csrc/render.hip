@@ -388,23 +388,37 @@ __device__ __forceinline__ void rgb2hsv8(const uint8_t* in, uint8_t* out) {
         if (r == maxc) h = bc - gc;
         else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
         else h = (float)(4.0 + (double)gc - (double)rc);
-        h = (float)fmod(((double)h / 6.0 + 1.0), 1.0);
+        { const double hv6 = (double)h / 6.0 + 1.0; h = (float)(hv6 - floor(hv6)); }   // == fmod(hv6, 1.0) exactly: hv6 is in [5/6, 11/6]
         int ih = (int)((double)h * 255.0), is = (int)((double)s * 255.0);
         uh = (uint8_t)(ih < 0 ? 0 : ih > 255 ? 255 : ih);
         us = (uint8_t)(is < 0 ? 0 : is > 255 ? 255 : is);
     }
     out[0] = uh; out[1] = us; out[2] = uv;
 }
-__device__ __forceinline__ void hsv2rgb8(const uint8_t* in, uint8_t* out) {
+// Per-byte terms of hsv2rgb8, tabulated once per workgroup with the very expressions PIL's C code evaluates per pixel:
+// sector i = floor(h*6/255), fraction f = h*6/255 - i (as float), fs = s/255 (as float).  Three double divisions per
+// pixel become three LDS reads.
+struct HueLut { const uint8_t* sect; const float* frac; const float* sat; };
+__device__ __forceinline__ void hue_lut_fill(uint8_t* sect, float* frac, float* sat) {
+    for (int v = threadIdx.x; v < 256; v += blockDim.x) {
+        const int i = (int)floor((double)(float)v * 6.0 / 255.0);
+        sect[v] = (uint8_t)i;
+        frac[v] = (float)((double)(float)v * 6.0 / 255.0 - (double)(float)i);
+        sat[v] = (float)((double)(float)v / 255.0);
+    }
+}
+// round() for x >= 0 (half away from zero), exact: x - trunc(x) is exact for |x| < 2^52
+__device__ __forceinline__ int round_pos(double x) { const double t = trunc(x); return (int)(x - t >= 0.5 ? t + 1.0 : t); }
+
+__device__ __forceinline__ void hsv2rgb8(const HueLut& lut, const uint8_t* in, uint8_t* out) {
     uint8_t h = in[0], s = in[1], v = in[2];
     if (s == 0) { out[0] = out[1] = out[2] = v; return; }
-    int i = (int)floor((double)(float)h * 6.0 / 255.0);
-    float f = (float)((double)(float)h * 6.0 / 255.0 - (double)(float)i);
-    float fs = (float)((double)(float)s / 255.0);
-    int p = (int)round((double)(float)v * (1.0 - (double)fs));
-    int q = (int)round((double)(float)v * (1.0 - (double)fs * (double)f));
-    int t = (int)round((double)(float)v * (1.0 - (double)fs * (1.0 - (double)f)));
-    p = p < 0 ? 0 : p > 255 ? 255 : p; q = q < 0 ? 0 : q > 255 ? 255 : q; t = t < 0 ? 0 : t > 255 ? 255 : t;
+    const int i = lut.sect[h];
+    const float f = lut.frac[h], fs = lut.sat[s];
+    int p = round_pos((double)(float)v * (1.0 - (double)fs));
+    int q = round_pos((double)(float)v * (1.0 - (double)fs * (double)f));
+    int t = round_pos((double)(float)v * (1.0 - (double)fs * (1.0 - (double)f)));
+    p = p > 255 ? 255 : p; q = q > 255 ? 255 : q; t = t > 255 ? 255 : t;
     switch (i % 6) {
         case 0: out[0] = v; out[1] = (uint8_t)t; out[2] = (uint8_t)p; break;
         case 1: out[0] = (uint8_t)q; out[1] = v; out[2] = (uint8_t)p; break;
@@ -414,10 +428,10 @@ __device__ __forceinline__ void hsv2rgb8(const uint8_t* in, uint8_t* out) {
         default: out[0] = v; out[1] = (uint8_t)p; out[2] = (uint8_t)q; break;
     }
 }
-__device__ __forceinline__ void jitter_op(int op, float f, int mean_gray, uint8_t* px) {
+__device__ __forceinline__ void jitter_op(const HueLut& lut, int op, float f, int mean_gray, uint8_t* px) {
     if (op == 0) { for (int c = 0; c < 3; ++c) px[c] = blend8(0, px[c], f); }
     else if (op == 1) { int l = luma8(px[0], px[1], px[2]); for (int c = 0; c < 3; ++c) px[c] = blend8(l, px[c], f); }
-    else if (op == 2) { uint8_t hsv[3]; rgb2hsv8(px, hsv); hsv[0] = (uint8_t)(hsv[0] + (uint8_t)(int)(f * 255.0f)); hsv2rgb8(hsv, px); }
+    else if (op == 2) { uint8_t hsv[3]; rgb2hsv8(px, hsv); hsv[0] = (uint8_t)(hsv[0] + (uint8_t)(int)(f * 255.0f)); hsv2rgb8(lut, hsv, px); }
     else { for (int c = 0; c < 3; ++c) px[c] = blend8(mean_gray, px[c], f); }
 }
 
@@ -425,6 +439,10 @@ __device__ __forceinline__ void jitter_op(int op, float f, int mean_gray, uint8_
 __global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __restrict__ rgbx, int npix,
                                                            const int32_t* __restrict__ order, const float* __restrict__ factor,
                                                            unsigned long long* __restrict__ lsum) {
+    __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256];
+    hue_lut_fill(l_sect, l_frac, l_sat);
+    __syncthreads();
+    const HueLut lut = {l_sect, l_frac, l_sat};
     const int b = blockIdx.y;
     const int32_t* ord = order + b * 4; const float* fac = factor + b * 4;
     int kc = 0;
@@ -434,7 +452,7 @@ __global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __rest
         for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
             uint32_t q = *(const uint32_t*)(rgbx + ((size_t)b * npix + i) * 4);
             uint8_t px[3] = {(uint8_t)q, (uint8_t)(q >> 8), (uint8_t)(q >> 16)};
-            for (int k = 0; k < kc; ++k) jitter_op(ord[k], fac[k], 0, px);
+            for (int k = 0; k < kc; ++k) jitter_op(lut, ord[k], fac[k], 0, px);
             s += (unsigned long long)luma8(px[0], px[1], px[2]);
         }
 #pragma unroll
@@ -449,6 +467,10 @@ __global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restr
                                                           const float* __restrict__ inv_affine,
                                                           const unsigned long long* __restrict__ lsum, int ow, int oh,
                                                           T* __restrict__ out_pad, float* __restrict__ out_chw) {
+    __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256];
+    hue_lut_fill(l_sect, l_frac, l_sat);
+    __syncthreads();
+    const HueLut lut = {l_sect, l_frac, l_sat};
     const int b = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= ow * oh) return;
@@ -462,7 +484,7 @@ __global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restr
         uint32_t q = *(const uint32_t*)(rgbx + (((size_t)b * H + sy) * W + sx) * 4);
         uint8_t px[3] = {(uint8_t)q, (uint8_t)(q >> 8), (uint8_t)(q >> 16)};
         int mean = (int)((double)lsum[b] / (double)(W * H) + 0.5);
-        for (int k = 0; k < 4; ++k) jitter_op(order[b * 4 + k], factor[b * 4 + k], mean, px);
+        for (int k = 0; k < 4; ++k) jitter_op(lut, order[b * 4 + k], factor[b * 4 + k], mean, px);
         v[0] = (float)px[0]; v[1] = (float)px[1]; v[2] = (float)px[2];
     }
     float o[3] = {v[0] / 255.0f - 0.5f, v[1] / 255.0f - 0.5f, v[2] / 255.0f - 0.5f};
@@ -488,6 +510,25 @@ static SceneDev to_dev(const ab_scene* s) {
     d.srgb2lin = (const float*)s->srgb2lin; d.lin2srgb = (const uint8_t*)s->lin2srgb;
     d.fx = s->fx; d.fy = s->fy; d.cx = s->cx; d.cy = s->cy; d.W = s->W; d.H = s->H;
     return d;
+}
+
+// the full 4-op chain on an RGBX image, in place semantics of the oracle's ro_color_jitter (X byte -> 255)
+__global__ __launch_bounds__(256) void jitter_apply_kernel(const uint8_t* __restrict__ rgbx, int npix,
+                                                           const int32_t* __restrict__ order, const float* __restrict__ factor,
+                                                           const unsigned long long* __restrict__ lsum, uint8_t* __restrict__ out) {
+    __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256];
+    hue_lut_fill(l_sect, l_frac, l_sat);
+    __syncthreads();
+    const HueLut lut = {l_sect, l_frac, l_sat};
+    const int b = blockIdx.y;
+    const int mean = (int)((double)lsum[b] / (double)npix + 0.5);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+        const size_t o = ((size_t)b * npix + i) * 4;
+        uint32_t q = *(const uint32_t*)(rgbx + o);
+        uint8_t px[3] = {(uint8_t)q, (uint8_t)(q >> 8), (uint8_t)(q >> 16)};
+        for (int k = 0; k < 4; ++k) jitter_op(lut, order[b * 4 + k], factor[b * 4 + k], mean, px);
+        *(uint32_t*)(out + o) = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | 0xff000000u;
+    }
 }
 
 __global__ void zero_words_kernel(unsigned* __restrict__ p, long n) {
@@ -543,6 +584,21 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
     else if (out_dtype == AB_DT_BF16)
         warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw);
     else return AB_EINVAL;
+    AB_LAUNCH_CHECK();
+    return 0;
+}
+
+// Colour jitter alone on B RGBX images of npix pixels (the chain ab_render_batch fuses into its crop): out may alias rgbx.
+// lsum_ws: B x 8 bytes of device scratch.
+extern "C" int ab_color_jitter(const void* rgbx, int B, int npix, const int32_t* order, const float* factor, void* out,
+                               void* lsum_ws, void* stream) {
+    if (!rgbx || !order || !factor || !out || !lsum_ws || B < 1 || npix < 1) return AB_EINVAL;
+    hipStream_t st = as_stream(stream);
+    zero_words_kernel<<<(unsigned)((B * 2 + 255) / 256), 256, 0, st>>>((unsigned*)lsum_ws, (long)B * 2);
+    jitter_stats_kernel<<<dim3(64, B), 256, 0, st>>>((const uint8_t*)rgbx, npix, order, factor, (unsigned long long*)lsum_ws);
+    AB_LAUNCH_CHECK();
+    jitter_apply_kernel<<<dim3(256, B), 256, 0, st>>>((const uint8_t*)rgbx, npix, order, factor,
+                                                       (const unsigned long long*)lsum_ws, (uint8_t*)out);
     AB_LAUNCH_CHECK();
     return 0;
 }

@@ -185,6 +185,11 @@ int ab_render_batch(const ab_scene* scene_host, const void* samples, const float
                     const float* factor, const float* inv_affine, int B, int max_faces, int ow, int oh,
                     int out_dtype, void* out_pad, float* out_chw, void* workspace, void* keys_out, void* rgbx_out,
                     void* stream);
+/* The colour-jitter chain of ab_render_batch on its own (anakin/utils/img_augment.py:6-80 on a PIL image): B RGBX images of
+ * npix pixels, order int32 [B][4] (0 brightness, 1 saturation, 2 hue, 3 contrast), factor float [B][4]; out (RGBX, X =
+ * 255) may alias rgbx; lsum_ws: B x 8 bytes of device scratch.                                                        */
+int ab_color_jitter(const void* rgbx, int B, int npix, const int32_t* order, const float* factor, void* out,
+                    void* lsum_ws, void* stream);
 
 /* ---- R1: MANO linear-blend skinning ------------------------------------------------------------------------------
  * replaces manotorch.manolayer.ManoLayer.forward (third party, un-pinned git dependency, requirements.txt:178) at

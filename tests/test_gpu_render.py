@@ -57,3 +57,27 @@ def test_render_properties():
     Z = 1.0 / (20.0 + z * (0.01 - 20.0))
     assert Z.min() > 0.25 and Z.max() < 0.9
     assert np.isfinite(out).all() and out.min() >= -0.5 and out.max() <= 0.5
+
+
+def test_color_jitter_all_rgb_values_vs_oracle():
+    """ab_color_jitter over an image holding all 2^24 RGB triples == the CPU oracle (itself pinned against Pillow in
+    tests/test_render_oracle.py), for hue / saturation / brightness / contrast in several orders and factor signs: the
+    tabulated hsv->rgb terms, the fmod-free hue wrap and the trunc-based rounding are bit-exact."""
+    import ctypes
+    from artiboost_amd import _lib as L
+    v = np.arange(1 << 24, dtype=np.uint32)
+    rgbx = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255, np.full_like(v, 255)], axis=1).astype(np.uint8).reshape(4096, 4096, 4)
+    cases = [([2, 0, 1, 3], [0.075, 1.1, 0.9, 1.05]), ([3, 2, 1, 0], [0.93, -0.075, 1.1, 0.95]),
+             ([1, 3, 0, 2], [1.07, 1.1, 0.9, -0.031]), ([2, 2, 2, 2], [0.5, 0.013, -0.2, 0.33])]
+    src = torch.from_numpy(rgbx).cuda()
+    ws = torch.empty(8, dtype=torch.uint8, device="cuda")
+    for order, factor in cases:
+        ref = ro.color_jitter(rgbx, order, factor)
+        o = torch.tensor([order], dtype=torch.int32, device="cuda")
+        f = torch.tensor([factor], dtype=torch.float32, device="cuda")
+        out = torch.empty_like(src)
+        rc = L.lib().ab_color_jitter(L.ptr(src), L.i(1), L.i(4096 * 4096), L.ptr(o), L.ptr(f), L.ptr(out), L.ptr(ws), L.stream())
+        assert rc == 0
+        got = out.cpu().numpy()
+        bad = np.argwhere((got[..., :3] != ref[..., :3]).any(axis=-1))
+        assert len(bad) == 0, (order, factor, bad[:5], got[tuple(bad[0])], ref[tuple(bad[0])])
