@@ -362,10 +362,11 @@ class HybridNet:
         logits = K.conv2d_fwd(e2, self.w("hybrid_head.final_layer.weight"), 1, 0,
                               bias=p.view("hybrid_head.final_layer.bias"))
         # ---- MLP_O box head, always f32 (tiny; keeps the 6-D rotation at full precision)
-        m0 = fmean.view(N, 1, 1, 512)
-        b1 = K.conv2d_fwd(m0, p.view("box_head.layers.0.weight"), 1, 0, bias=p.view("box_head.layers.0.bias"), relu=True)
-        b2 = K.conv2d_fwd(b1, p.view("box_head.layers.2.weight"), 1, 0, bias=p.view("box_head.layers.2.bias"), relu=True)
-        b3 = K.conv2d_fwd(b2, p.view("box_head.layers.4.weight"), 1, 0, bias=p.view("box_head.layers.4.bias"))
+        m0 = fmean.view(N, 512)
+        lw = lambda n: p.view(n).view(p.entries[n].kshape[0], -1)      # noqa: E731  ([out][in] rows of the 1x1 layout)
+        b1 = K.linear_fwd(m0, lw("box_head.layers.0.weight"), p.view("box_head.layers.0.bias"), relu=True)
+        b2 = K.linear_fwd(b1, lw("box_head.layers.2.weight"), p.view("box_head.layers.2.bias"), relu=True)
+        b3 = K.linear_fwd(b2, lw("box_head.layers.4.weight"), p.view("box_head.layers.4.bias"))
         box6d = b3.view(N, BOX_OUT_PAD)[:, :6]
         S.update(feat=feat, d1=d1, e1=e1, bnpd1=bnpd1, d2=d2, e2=e2, bnpd2=bnpd2, logits=logits, m0=m0, b1=b1, b2=b2)
         self.saved = S if tr else None
@@ -438,20 +439,16 @@ class HybridNet:
             dout, blocks, part = S.pop("_dout"), S.pop("_blocks_left"), S.pop("_dout_part")
             return self._backward_trunk(S, dout, blocks, part)
         # ---- box head (f32)
-        g3 = torch.zeros((N, 1, 1, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
-        g3.view(N, BOX_OUT_PAD)[:, :6].copy_(g_box6d)
-        K.conv2d_wgrad(S["b2"], g3, 1, 1, 1, 0, out=gv("box_head.layers.4.weight"))
-        K.col_sum(g3, gv("box_head.layers.4.bias"))
-        w4t = p.view("box_head.layers.4.weight").permute(3, 1, 2, 0).contiguous()
-        gb2 = K.relu_bwd(K.conv2d_dgrad(g3, w4t, (1, 1), 1, 0), S["b2"])
-        K.conv2d_wgrad(S["b1"], gb2, 1, 1, 1, 0, out=gv("box_head.layers.2.weight"))
-        K.col_sum(gb2, gv("box_head.layers.2.bias"))
-        w2t = p.view("box_head.layers.2.weight").permute(3, 1, 2, 0).contiguous()
-        gb1 = K.relu_bwd(K.conv2d_dgrad(gb2, w2t, (1, 1), 1, 0), S["b1"])
-        K.conv2d_wgrad(S["m0"], gb1, 1, 1, 1, 0, out=gv("box_head.layers.0.weight"))
-        K.col_sum(gb1, gv("box_head.layers.0.bias"))
-        w0t = p.view("box_head.layers.0.weight").permute(3, 1, 2, 0).contiguous()
-        g_mean = K.conv2d_dgrad(gb1, w0t, (1, 1), 1, 0).view(N, 512)
+        g3 = torch.zeros((N, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
+        g3[:, :6].copy_(g_box6d)
+        lw = lambda n: p.view(n).view(p.entries[n].kshape[0], -1)      # noqa: E731
+        lg = lambda n: gv(n).view(p.entries[n].kshape[0], -1)          # noqa: E731
+        K.linear_wgrad(g3, S["b2"], lg("box_head.layers.4.weight"), gv("box_head.layers.4.bias"))
+        gb2 = K.linear_dgrad(g3, lw("box_head.layers.4.weight"), act_out=S["b2"])
+        K.linear_wgrad(gb2, S["b1"], lg("box_head.layers.2.weight"), gv("box_head.layers.2.bias"))
+        gb1 = K.linear_dgrad(gb2, lw("box_head.layers.2.weight"), act_out=S["b1"])
+        K.linear_wgrad(gb1, S["m0"], lg("box_head.layers.0.weight"), gv("box_head.layers.0.bias"))
+        g_mean = K.linear_dgrad(gb1, lw("box_head.layers.0.weight"))
         # ---- head
         e2, e1, feat = S["e2"], S["e1"], S["feat"]
         self._wgrad_side(K.conv2d_wgrad, e2, dlogits, 1, 1, 1, 0, out=gv("hybrid_head.final_layer.weight"))

@@ -242,6 +242,34 @@ def transpose_oki(src_f32_oki, dst):
     return dst
 
 
+def linear_fwd(x, w, bias=None, relu=False):
+    """fp32 x [M,K] @ w[N,K]^T (+bias) (+ReLU) -> [M,N]   (ab_linear_fwd; the box-rotation MLP)."""
+    M, Kd = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    L.check(L.lib().ab_linear_fwd(L.ptr(x), L.ptr(w), L.ptr(bias), L.i(M), L.i(N), L.i(Kd), L.i(1 if relu else 0), L.ptr(y),
+                                  L.stream()), "ab_linear_fwd")
+    return y
+
+
+def linear_dgrad(g, w, act_out=None):
+    """fp32 g [M,N] @ w[N,K] -> [M,K], zeroed where act_out <= 0 (the ReLU that produced this layer's input)."""
+    M, N = g.shape
+    Kd = w.shape[1]
+    gx = torch.empty((M, Kd), dtype=torch.float32, device=g.device)
+    L.check(L.lib().ab_linear_dgrad(L.ptr(g), L.ptr(w), L.ptr(act_out), L.i(M), L.i(N), L.i(Kd), L.ptr(gx), L.stream()),
+            "ab_linear_dgrad")
+    return gx
+
+
+def linear_wgrad(g, x, dw, db=None):
+    """dw[N,K] = g[M,N]^T @ x[M,K], db[N] = sum_m g (written in place into the flat gradient views)."""
+    M, N = g.shape
+    Kd = x.shape[1]
+    L.check(L.lib().ab_linear_wgrad(L.ptr(g), L.ptr(x), L.i(M), L.i(N), L.i(Kd), L.ptr(dw), L.ptr(db), L.stream()),
+            "ab_linear_wgrad")
+
+
 def transpose_plan(pairs):
     """pairs: [(src f32 [O,K,I], dst [I,K,O])] -> (device descriptor table, n, total_tiles, dtype code) for
     transpose_oki_batch; None when a shape does not fit the 16-byte vector tiles."""

@@ -293,3 +293,28 @@ def test_dgrad_with_fused_bn_backward_reduction(case, monkeypatch):
     np.testing.assert_allclose(dg1.cpu().numpy(), dg0.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(dg0.abs().max()))
     np.testing.assert_allclose(db1.cpu().numpy(), db0.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(db0.abs().max()))
     np.testing.assert_allclose(d1.float().cpu().numpy(), d0.float().cpu().numpy(), rtol=2e-2, atol=2e-2 * float(d0.float().abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 256, 512), (64, 64, 128), (3, 6, 8), (70, 5, 36)])
+def test_small_batch_linear_kernels(M, N, K):
+    """ab_linear_fwd / dgrad / wgrad (the fp32 box-rotation MLP) vs torch on CPU in float64."""
+    from artiboost_amd import kernels as K_
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn((M, K), generator=g); w = 0.1 * torch.randn((N, K), generator=g); b = torch.randn(N, generator=g)
+    gy = torch.randn((M, N), generator=g)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    y = torch.relu(xd @ wd.t() + bd)
+    y.backward(gy.double())
+    yo = K_.linear_fwd(x.cuda(), w.cuda(), b.cuda(), relu=True)
+    np.testing.assert_allclose(yo.cpu().numpy(), y.detach().numpy(), rtol=1e-5, atol=1e-5)
+    gz = (gy * (y.detach() > 0)).float()                          # gradient after the ReLU mask
+    gx = K_.linear_dgrad(gz.cuda(), w.cuda())
+    np.testing.assert_allclose(gx.cpu().numpy(), xd.grad.numpy(), rtol=1e-5, atol=1e-5)
+    # masked variant: mask by the activation that fed the layer
+    act = torch.relu(x)
+    gxm = K_.linear_dgrad(gz.cuda(), w.cuda(), act_out=act.cuda())
+    np.testing.assert_allclose(gxm.cpu().numpy(), (xd.grad * (act > 0)).numpy(), rtol=1e-5, atol=1e-5)
+    dw = torch.empty((N, K), device="cuda"); db = torch.empty(N, device="cuda")
+    K_.linear_wgrad(gz.cuda(), x.cuda(), dw, db)
+    np.testing.assert_allclose(dw.cpu().numpy(), wd.grad.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), bd.grad.numpy(), rtol=1e-5, atol=1e-5)
