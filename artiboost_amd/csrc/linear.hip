@@ -2,66 +2,80 @@
 // rows (64) is far too small for the tiled conv kernels (a 1x1 conv GEMM with a 32-step K loop costs ~14 us of pure
 // latency per layer here).  Plain FMA kernels, exact fp32, one launch per product:
 //   fwd   y[m][n]  = act( sum_k x[m][k] * W[n][k] + b[n] )
-//   dgrad gx[m][k] = ( sum_n g[m][n] * W[n][k] ) * (act_out[m][k] > 0 if masked)
+//   dgrad gx[m][k] = ( sum_n g[m][n] * Wt[k][n] ) * (act_out[m][k] > 0 if masked)      (Wt = W transposed, [K][N])
 //   wgrad dW[n][k] = sum_m g[m][n] * x[m][k],   db[n] = sum_m g[m][n]
-// W is [N][K] row-major (the OHWI layout of a 1x1 conv).  K % 4 == 0.
+// W is [N][K] row-major (the OHWI layout of a 1x1 conv).  Reduction lengths are multiples of 4.
 #include "common.h"
 
-// grid (ceil(N/4), ceil(M/64)); block 256: lane -> row (64 rows), wave -> one of 4 output columns.  W[n][k..k+3] is a
-// wave-uniform (broadcast) load, x rows are L1-resident after the first touch of each 128-byte line.
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                         const float* __restrict__ bias, int M, int N, int K, int relu,
-                                                         float* __restrict__ y) {
-    const int m = blockIdx.y * 64 + (threadIdx.x & 63), n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M || n >= N) return;
-    const float4* xr = (const float4*)(x + (long)m * K);
-    const float4* wr = (const float4*)(W + (long)n * K);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int k = 0; k < K / 4; ++k) {
-        float4 xv = xr[k], wv = wr[k];
-        a0 += xv.x * wv.x; a1 += xv.y * wv.y; a2 += xv.z * wv.z; a3 += xv.w * wv.w;
+// C[i][j] = epilogue( sum_r A[i][r] * B[j][r] ), both operands reduction-contiguous.  One wave per 4 x 4 micro-tile: the
+// lanes split the reduction (float4 slices, fully coalesced 1-KiB row loads, all 16+ loads of a lane independent), sixteen
+// wave reductions finish it.  Block = 4 waves = 4 rows x 16 columns; grid (ceil(J/16), ceil(I/4)).  Epilogue: + bias[j],
+// ReLU, or zero where mask[i][j] <= 0.
+__global__ __launch_bounds__(256) void linear_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                        const float* __restrict__ bias, const float* __restrict__ mask,
+                                                        int I, int J, int R, int relu, float* __restrict__ C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = blockIdx.y * 4, j0 = (blockIdx.x * 4 + wave) * 4;
+    if (j0 >= J) return;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int q = lane * 4; q < R; q += 256) {
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) av[a] = *(const float4*)(A + (long)min(i0 + a, I - 1) * R + q);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bv[b] = *(const float4*)(B + (long)min(j0 + b, J - 1) * R + q);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[a][b] += (av[a].x * bv[b].x + av[a].y * bv[b].y) + (av[a].z * bv[b].z + av[a].w * bv[b].w);
     }
-    float v = (a0 + a1) + (a2 + a3) + (bias ? bias[n] : 0.f);
-    if (relu) v = fmaxf(v, 0.f);
-    y[(long)m * N + n] = v;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = wave_sum(acc[a][b]);
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = i0 + a, j = j0 + b;
+                if (i >= I || j >= J) continue;
+                float v = acc[a][b] + (bias ? bias[j] : 0.f);
+                if (relu) v = fmaxf(v, 0.f);
+                if (mask && !(mask[(long)i * J + j] > 0.f)) v = 0.f;
+                C[(long)i * J + j] = v;
+            }
+    }
 }
 
-// grid (ceil(K/256), M); block 64 lanes x 4 k each: W rows read coalesced along k, g[m][n] broadcast
-__global__ __launch_bounds__(64) void linear_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ W,
-                                                          const float* __restrict__ act_out, int M, int N, int K,
-                                                          float* __restrict__ gx) {
-    const int m = blockIdx.y, k4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (k4 >= K) return;
-    const float* gr = g + (long)m * N;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int n = 0; n < N; ++n) {
-        const float gv = gr[n];
-        const float4 wv = *(const float4*)(W + (long)n * K + k4);
-        a.x += gv * wv.x; a.y += gv * wv.y; a.z += gv * wv.z; a.w += gv * wv.w;
-    }
-    if (act_out) {
-        const float4 o = *(const float4*)(act_out + (long)m * K + k4);
-        if (!(o.x > 0.f)) a.x = 0.f; if (!(o.y > 0.f)) a.y = 0.f; if (!(o.z > 0.f)) a.z = 0.f; if (!(o.w > 0.f)) a.w = 0.f;
-    }
-    *(float4*)(gx + (long)m * K + k4) = a;
-}
-
-// grid (ceil(K/256), N); block 64 lanes x 4 k each; rows summed in order (deterministic).  Lane 0 of block x == 0 also
-// writes db[n].
+// grid (ceil(K/256), N); block 64 lanes x 4 k each; the M rows are summed in order (deterministic), 16 rows of loads in
+// flight.  Lane 0 of block x == 0 also writes db[n].
 __global__ __launch_bounds__(64) void linear_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x, int M, int N,
                                                           int K, float* __restrict__ dW, float* __restrict__ db) {
     const int n = blockIdx.y, k4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     if (k4 < K) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int m = 0; m < M; ++m) {
-            const float gv = g[(long)m * N + n];
-            const float4 xv = *(const float4*)(x + (long)m * K + k4);
-            a.x += gv * xv.x; a.y += gv * xv.y; a.z += gv * xv.z; a.w += gv * xv.w;
+        for (int m0 = 0; m0 < M; m0 += 16) {          // 16 rows of loads issued before any is consumed
+            float gv[16]; float4 xv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int m = min(m0 + u, M - 1);
+                gv[u] = (m0 + u < M) ? g[(long)m * N + n] : 0.f;
+                xv[u] = *(const float4*)(x + (long)m * K + k4);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { a.x += gv[u] * xv[u].x; a.y += gv[u] * xv[u].y; a.z += gv[u] * xv[u].z; a.w += gv[u] * xv[u].w; }
         }
         *(float4*)(dW + (long)n * K + k4) = a;
     }
     if (db && blockIdx.x == 0 && threadIdx.x == 0) {
         float s = 0.f;
+#pragma unroll 16
         for (int m = 0; m < M; ++m) s += g[(long)m * N + n];
         db[n] = s;
     }
@@ -71,14 +85,14 @@ extern "C" int ab_linear_fwd(const float* x, const float* w, const float* bias, 
                              void* stream) {
     if (!x || !w || !y || M < 1 || N < 1 || K < 4) return AB_EINVAL;
     if (K % 4) return AB_ESHAPE;
-    linear_fwd_kernel<<<dim3((N + 3) / 4, (M + 63) / 64), 256, 0, as_stream(stream)>>>(x, w, bias, M, N, K, relu, y);
+    linear_nt_kernel<<<dim3((N + 15) / 16, (M + 3) / 4), 256, 0, as_stream(stream)>>>(x, w, bias, nullptr, M, N, K, relu, y);
     AB_LAUNCH_CHECK(); return 0;
 }
-extern "C" int ab_linear_dgrad(const float* g, const float* w, const float* act_out, int M, int N, int K, float* gx,
+extern "C" int ab_linear_dgrad(const float* g, const float* wt, const float* act_out, int M, int N, int K, float* gx,
                                void* stream) {
-    if (!g || !w || !gx || M < 1 || N < 1 || K < 4) return AB_EINVAL;
-    if (K % 4) return AB_ESHAPE;
-    linear_dgrad_kernel<<<dim3((K + 255) / 256, M), 64, 0, as_stream(stream)>>>(g, w, act_out, M, N, K, gx);
+    if (!g || !wt || !gx || M < 1 || N < 4 || K < 1) return AB_EINVAL;
+    if (N % 4) return AB_ESHAPE;
+    linear_nt_kernel<<<dim3((K + 15) / 16, (M + 3) / 4), 256, 0, as_stream(stream)>>>(g, wt, nullptr, act_out, M, K, N, 0, gx);
     AB_LAUNCH_CHECK(); return 0;
 }
 extern "C" int ab_linear_wgrad(const float* g, const float* x, int M, int N, int K, float* dw, float* db, void* stream) {

@@ -283,6 +283,19 @@ class HybridNet:
                 pairs.append((p.view(name).reshape(O, kh * kw, I), dst))
             self._tr_pairs = pairs                                   # the flat buffer and the copies are persistent
             self._tr_plan = K.transpose_plan(pairs) or False
+            # fp32 [in][out] copies of the box-head weights (its data gradients run as NT products too)
+            self.box_t, bpairs = {}, []
+            for name in ("box_head.layers.0.weight", "box_head.layers.2.weight", "box_head.layers.4.weight"):
+                O, _, _, I = p.entries[name].kshape
+                dst = self.box_t[name] = torch.empty((I, O), dtype=torch.float32, device=p.device)
+                bpairs.append((p.view(name).reshape(O, 1, I), dst.view(I, 1, O)))
+            self._box_pairs = bpairs
+            self._box_plan = K.transpose_plan(bpairs) or False
+        if self._box_plan:
+            K.transpose_oki_batch(self._box_plan)
+        else:
+            for src, dst in self._box_pairs:
+                dst.copy_(src.permute(2, 1, 0))
         if self._tr_plan:
             K.transpose_oki_batch(self._tr_plan)                     # one launch for all IHWO dgrad copies
         else:
@@ -444,11 +457,11 @@ class HybridNet:
         lw = lambda n: p.view(n).view(p.entries[n].kshape[0], -1)      # noqa: E731
         lg = lambda n: gv(n).view(p.entries[n].kshape[0], -1)          # noqa: E731
         K.linear_wgrad(g3, S["b2"], lg("box_head.layers.4.weight"), gv("box_head.layers.4.bias"))
-        gb2 = K.linear_dgrad(g3, lw("box_head.layers.4.weight"), act_out=S["b2"])
+        gb2 = K.linear_dgrad(g3, self.box_t["box_head.layers.4.weight"], act_out=S["b2"])
         K.linear_wgrad(gb2, S["b1"], lg("box_head.layers.2.weight"), gv("box_head.layers.2.bias"))
-        gb1 = K.linear_dgrad(gb2, lw("box_head.layers.2.weight"), act_out=S["b1"])
+        gb1 = K.linear_dgrad(gb2, self.box_t["box_head.layers.2.weight"], act_out=S["b1"])
         K.linear_wgrad(gb1, S["m0"], lg("box_head.layers.0.weight"), gv("box_head.layers.0.bias"))
-        g_mean = K.linear_dgrad(gb1, lw("box_head.layers.0.weight"))
+        g_mean = K.linear_dgrad(gb1, self.box_t["box_head.layers.0.weight"])
         # ---- head
         e2, e1, feat = S["e2"], S["e1"], S["feat"]
         self._wgrad_side(K.conv2d_wgrad, e2, dlogits, 1, 1, 1, 0, out=gv("hybrid_head.final_layer.weight"))

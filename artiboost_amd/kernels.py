@@ -252,12 +252,12 @@ def linear_fwd(x, w, bias=None, relu=False):
     return y
 
 
-def linear_dgrad(g, w, act_out=None):
-    """fp32 g [M,N] @ w[N,K] -> [M,K], zeroed where act_out <= 0 (the ReLU that produced this layer's input)."""
+def linear_dgrad(g, wt, act_out=None):
+    """fp32 g [M,N] @ W[N,K] -> [M,K] given wt = W^T [K,N]; zeroed where act_out <= 0 (the ReLU that fed this layer)."""
     M, N = g.shape
-    Kd = w.shape[1]
+    Kd = wt.shape[0]
     gx = torch.empty((M, Kd), dtype=torch.float32, device=g.device)
-    L.check(L.lib().ab_linear_dgrad(L.ptr(g), L.ptr(w), L.ptr(act_out), L.i(M), L.i(N), L.i(Kd), L.ptr(gx), L.stream()),
+    L.check(L.lib().ab_linear_dgrad(L.ptr(g), L.ptr(wt), L.ptr(act_out), L.i(M), L.i(N), L.i(Kd), L.ptr(gx), L.stream()),
             "ab_linear_dgrad")
     return gx
 

@@ -187,10 +187,10 @@ int ab_render_batch(const ab_scene* scene_host, const void* samples, const float
                     void* stream);
 /* Small-batch fp32 linear layers (the box-rotation MLP, anakin/models/mlp.py:11-25; nn.Linear weights [N][K]):
  *   fwd   y[M][N]  = act(x[M][K] W^T + bias)            (relu != 0: ReLU)
- *   dgrad gx[M][K] = (g[M][N] W) masked by act_out > 0   (act_out NULL: no mask)
- *   wgrad dw[N][K] = g^T x, db[N] = column sums of g     (db may be NULL)              K % 4 == 0.                  */
+ *   dgrad gx[M][K] = (g[M][N] W) masked by act_out > 0   (act_out NULL: no mask); takes wt = W transposed, [K][N]
+ *   wgrad dw[N][K] = g^T x, db[N] = column sums of g     (db may be NULL)      reduction lengths % 4 == 0.          */
 int ab_linear_fwd(const float* x, const float* w, const float* bias, int M, int N, int K, int relu, float* y, void* stream);
-int ab_linear_dgrad(const float* g, const float* w, const float* act_out, int M, int N, int K, float* gx, void* stream);
+int ab_linear_dgrad(const float* g, const float* wt, const float* act_out, int M, int N, int K, float* gx, void* stream);
 int ab_linear_wgrad(const float* g, const float* x, int M, int N, int K, float* dw, float* db, void* stream);
 /* The colour-jitter chain of ab_render_batch on its own (anakin/utils/img_augment.py:6-80 on a PIL image): B RGBX images of
  * npix pixels, order int32 [B][4] (0 brightness, 1 saturation, 2 hue, 3 contrast), factor float [B][4]; out (RGBX, X =

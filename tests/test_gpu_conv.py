@@ -295,7 +295,7 @@ def test_dgrad_with_fused_bn_backward_reduction(case, monkeypatch):
     np.testing.assert_allclose(d1.float().cpu().numpy(), d0.float().cpu().numpy(), rtol=2e-2, atol=2e-2 * float(d0.float().abs().max()))
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 256, 512), (64, 64, 128), (3, 6, 8), (70, 5, 36)])
+@pytest.mark.parametrize("M,N,K", [(64, 256, 512), (64, 64, 128), (3, 8, 8), (70, 12, 36)])
 def test_small_batch_linear_kernels(M, N, K):
     """ab_linear_fwd / dgrad / wgrad (the fp32 box-rotation MLP) vs torch on CPU in float64."""
     from artiboost_amd import kernels as K_
@@ -308,11 +308,12 @@ def test_small_batch_linear_kernels(M, N, K):
     yo = K_.linear_fwd(x.cuda(), w.cuda(), b.cuda(), relu=True)
     np.testing.assert_allclose(yo.cpu().numpy(), y.detach().numpy(), rtol=1e-5, atol=1e-5)
     gz = (gy * (y.detach() > 0)).float()                          # gradient after the ReLU mask
-    gx = K_.linear_dgrad(gz.cuda(), w.cuda())
+    wt = w.t().contiguous().cuda()
+    gx = K_.linear_dgrad(gz.cuda(), wt)
     np.testing.assert_allclose(gx.cpu().numpy(), xd.grad.numpy(), rtol=1e-5, atol=1e-5)
     # masked variant: mask by the activation that fed the layer
     act = torch.relu(x)
-    gxm = K_.linear_dgrad(gz.cuda(), w.cuda(), act_out=act.cuda())
+    gxm = K_.linear_dgrad(gz.cuda(), wt, act_out=act.cuda())
     np.testing.assert_allclose(gxm.cpu().numpy(), (xd.grad * (act > 0)).numpy(), rtol=1e-5, atol=1e-5)
     dw = torch.empty((N, K), device="cuda"); db = torch.empty(N, device="cuda")
     K_.linear_wgrad(gz.cuda(), x.cuda(), dw, db)
