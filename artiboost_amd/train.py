@@ -53,7 +53,8 @@ class TrainStep:
         # the next stage computes, so only the last 5 MB are exposed.  AB_DDP_SPLIT=1 forces the split on one GPU
         # (tests), =0 disables it.
         env = os.environ.get("AB_DDP_SPLIT", "")
-        self.split = bool(use_graph and fused_criterion and (self.world > 1 or env == "1") and env != "0")
+        self.split = bool(use_graph and fused_criterion and (self.world > 1 or env == "1") and env != "0")   # (cleared below
+        #                                                                                            if the criterion is not fusable)
         self.g_bwd_rest = []
         # Render/learn pipelining (the reference overlaps them through DataLoader worker processes,
         # artiboost_loader.py:195-260): the batch for step i+1 is rendered on a side stream while step i trains.
@@ -66,12 +67,17 @@ class TrainStep:
             self.rstatic = {k: v.clone() for k, v in self.static.items() if torch.is_tensor(v) and k.startswith("_") and not k.startswith("__flat_")}
             self.rstatic["image_nhwc4_padded"] = torch.zeros_like(self.static["image_nhwc4_padded"])
             self.render_stream = torch.cuda.Stream(device=self.dev)
-        if use_graph:
-            self.opt.use_device_hyper(self.dev)
         self.fused = None
         if fused_criterion:
             from .criterions import FusedPoseCriterion
-            self.fused = FusedPoseCriterion(criterion, self.hb.inp_res, self.hb.center_idx)
+            try:
+                self.fused = FusedPoseCriterion(criterion, self.hb.inp_res, self.hb.center_idx)
+            except NotImplementedError:       # a loss outside the fused kernel (e.g. SymCornerLoss): autograd criterion
+                self.fused = None
+                self.split = False
+                self.use_graph = False        # the registry losses index with host lists / move constants: not capturable
+        if self.use_graph:
+            self.opt.use_device_hyper(self.dev)
 
     # ------------------------------------------------------------------ pieces
     def _fwd_bwd(self):

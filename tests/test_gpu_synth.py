@@ -221,3 +221,43 @@ def test_two_rank_ddp_step_keeps_weights_identical():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "weights_identical_across_ranks=True" in r.stdout
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_train_step_with_symcorner_loss_falls_back_to_autograd_criterion(graph):
+    """A criterion list containing SymCornerLoss (DexYCB-style configs, symcornerloss.py:18-102) is not covered by the fused
+    pose/loss kernel: TrainStep must run it through the registry losses + autograd on top of the HIP forward/backward."""
+    import yaml, os
+    from artiboost_amd import registry as R
+    from artiboost_amd.criterions import Criterion
+    from artiboost_amd.models import Arch
+    from artiboost_amd.optim import FusedClipAdam
+    from artiboost_amd.train import TrainStep
+    assets, loader = _loader(torch.bfloat16, bs=8, n=16, size=224)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    nobj = 21
+    info = {str(i + 1): ({"symmetries_discrete": [[-1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]]} if i % 2 else
+                         {"symmetries_continuous": [{"axis": [0, 0, 1], "offset": [0, 0, 0]}]}) for i in range(nobj)}
+    cfg["CRITERION"] = cfg["CRITERION"] + [{"TYPE": "SymCornerLoss", "LAMBDA_SYM_CORNERS_3D": 1.0, "MODEL_INFO": info,
+                                            "MAX_SYM_DISC_STEP": 0.2}]
+    cfg["LAMBDAS"] = cfg["LAMBDAS"] + [0.3]
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16")
+    model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
+    crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+    hb = model.model_list[0]
+    opt = FusedClipAdam(model.models_params, lr=1e-3, max_norm=1.0, model=hb)
+    loader.prepare()
+    static = loader.new_static_batch()
+    loader.load_batch(static, 0)
+    model.train()
+    ts = TrainStep(model, crit, opt, static, use_graph=graph, renderer=loader)
+    ts.static = static
+    assert ts.fused is None and ts.use_graph is False      # autograd criterion => eager issue (documented limitation)
+    vals = []
+    for i in range(6):
+        loader.load_batch(static, 0)
+        _, total, losses = ts()
+        vals.append(float(total))
+        assert "sym_corners_3d_loss" in losses or any("sym" in k for k in losses)
+    assert np.isfinite(vals).all() and vals[-1] < vals[0], vals
