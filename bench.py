@@ -198,11 +198,19 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    ngpu = torch.cuda.device_count()
+    # one rank per GPU over RCCL; if there are fewer devices than ranks (dry runs of the multi-rank path on a 1-GPU box)
+    # the ranks share devices and the collectives go through gloo
+    shared = world > ngpu
+    local = local % max(ngpu, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if shared:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
     cfg, model, crit, opt, loader, ts, static = build_everything(args, rank, world, device)
