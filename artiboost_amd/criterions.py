@@ -46,10 +46,25 @@ class Criterion(TensorLoss):
         return self._loss_lambdas
 
     def draw(self, dev):
-        """Refresh the random draws of every loss (host RNG, reference order) into their device buffers."""
+        """Refresh the random draws of every loss (host RNG, reference order) into their device buffers.  On a GPU the
+        draws of all losses are packed into one pinned staging tensor and shipped with a single H2D copy."""
+        dev = torch.device(dev)
+        arena = None
+        if dev.type == "cuda":
+            arena = getattr(self, "_draw_arena", None)
+            if arena is None:
+                arena = self._draw_arena = _DrawArena()
+            arena.begin()
         for loss in self.loss_list:
             if hasattr(loss, "draw"):
+                if hasattr(loss, "draws"):
+                    loss.draws.arena = arena
                 loss.draw(dev)
+        if arena is not None:
+            arena.flush(dev)
+            for loss in self.loss_list:          # a loss called on its own (not through this method) copies directly
+                if hasattr(loss, "draws"):
+                    loss.draws.arena = None
 
     def freeze_draws(self, frozen=True):
         for loss in self.loss_list:
@@ -114,6 +129,40 @@ def _shuffled_third(n):
     return idx[: n // 3]
 
 
+class _DrawArena:
+    """One persistent device byte buffer for every per-step draw of a Criterion: `add` records (owner, name, cpu tensor) in
+    call order, `flush` packs them (16-byte aligned slots, layout fixed by the first step), pins the pack and issues ONE
+    async H2D copy; the owners' `bufs[name]` are typed views into the device buffer (stable addresses for hipGraphs)."""
+
+    def __init__(self):
+        self.items, self.layout, self.dev_buf = [], None, None
+
+    def begin(self):
+        self.items = []
+
+    def add(self, owner, name, cpu_tensor):
+        self.items.append((owner, name, cpu_tensor.contiguous()))
+
+    def flush(self, dev):
+        sig = tuple((id(o), n, tuple(t.shape), t.dtype) for o, n, t in self.items)
+        if self.layout is None or self.layout[0] != sig:
+            offs, off = [], 0
+            for _, _, t in self.items:
+                offs.append(off)
+                off += (t.numel() * t.element_size() + 15) // 16 * 16
+            self.layout = (sig, offs, off)
+            self.dev_buf = torch.empty(max(off, 16), dtype=torch.uint8, device=dev)
+            for (o, n, t), b in zip(self.items, offs):
+                nb = t.numel() * t.element_size()
+                o.bufs[n] = self.dev_buf[b:b + nb].view(t.dtype).view(t.shape)
+        _, offs, total = self.layout
+        pack = torch.empty(max(total, 16), dtype=torch.uint8)
+        for (_, _, t), b in zip(self.items, offs):
+            nb = t.numel() * t.element_size()
+            pack[b:b + nb] = t.reshape(-1).view(torch.uint8)
+        self.dev_buf.copy_(pack.pin_memory(), non_blocking=True)      # a fresh pinned block per step: no reuse hazard
+
+
 class _Draws:
     """Per-call random draws of the ordinal losses, kept in persistent device buffers so that the arithmetic can be
     captured in a hipGraph: `draw()` (host RNG, same order as the reference) refreshes the buffers with async H2D
@@ -123,8 +172,12 @@ class _Draws:
         self.dev = None
         self.bufs = {}
         self.frozen = False     # True while a captured graph owns the call: __call__ must not draw
+        self.arena = None       # set by Criterion.draw: pack all draws of the step into one H2D copy
 
     def put(self, name, cpu_tensor, dev):
+        if self.arena is not None:
+            self.arena.add(self, name, cpu_tensor)
+            return None
         b = self.bufs.get(name)
         if b is None or b.shape != cpu_tensor.shape:      # buffers are persistent: a captured hipGraph holds their addresses
             b = torch.empty(cpu_tensor.shape, dtype=cpu_tensor.dtype, device=dev)
