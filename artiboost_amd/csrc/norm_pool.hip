@@ -328,10 +328,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
                                                           int W, int C, T* __restrict__ out, uint8_t* __restrict__ idx) {
     constexpr int V = Vec<T>::N;
     const int Ho = H / 2, Wo = W / 2, vc = C / V;
-    long nvec = (long)N * Ho * Wo * vc;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-        int cv = (int)(i % vc); long pix = i / vc;
-        int wo = (int)(pix % Wo); long t = pix / Wo; int ho = (int)(t % Ho); int n = (int)(t / Ho);
+    // grid (ceil(Wo*vc / 256), Ho, N): one output row per (blockIdx.y, blockIdx.z) -- no 64-bit div/mod per vector (they dominated the
+    // flat-index version of this HBM-bound kernel)
+    const unsigned col = blockIdx.x * 256 + threadIdx.x;
+    if (col < (unsigned)(Wo * vc)) {
+        const int wo = (int)(col / (unsigned)vc), cv = (int)(col - (unsigned)wo * vc);
+        const int n = blockIdx.z, ho = blockIdx.y;
+        const long i = (((long)n * Ho + ho) * Wo + wo) * vc + cv;
         float m[V]; uint8_t am[V];
         float sc[V], sh[V];
         if (bnp) {
@@ -372,10 +375,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
                                                           int N, int H, int W, int C, T* __restrict__ dx) {
     constexpr int V = Vec<T>::N;
     const int Ho = H / 2, Wo = W / 2, vc = C / V;
-    long nvec = (long)N * H * W * vc;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-        int cv = (int)(i % vc); long pix = i / vc;
-        int w = (int)(pix % W); long t = pix / W; int h = (int)(t % H); int n = (int)(t / H);
+    // grid (ceil(W*vc / 256), H, N): one input row per (blockIdx.y, blockIdx.z), 32-bit index math only
+    const unsigned col = blockIdx.x * 256 + threadIdx.x;
+    if (col < (unsigned)(W * vc)) {
+        const int w = (int)(col / (unsigned)vc), cv = (int)(col - (unsigned)w * vc);
+        const int n = blockIdx.z, h = blockIdx.y;
+        const long i = (((long)n * H + h) * W + w) * vc + cv;
         float acc[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) acc[k] = 0.f;
@@ -645,8 +650,10 @@ extern "C" int ab_add(const void* a, const void* b, int dtype, long n, void* out
 extern "C" int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* idx, void* stream) {
     int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
     long nvec = (long)N * (H / 2) * (W / 2) * C / V;
-    DISPATCH(dtype, (maxpool_fwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)x, nullptr, N, H, W, C, (float*)out, (uint8_t*)idx)),
-             (maxpool_fwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)x, nullptr, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
+    dim3 pgrid((unsigned)(((long)(W / 2) * (C / V) + 255) / 256), (unsigned)(H / 2), (unsigned)N);
+    (void)nvec;
+    DISPATCH(dtype, (maxpool_fwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>((const float*)x, nullptr, N, H, W, C, (float*)out, (uint8_t*)idx)),
+             (maxpool_fwd_kernel<bf16_t><<<pgrid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, nullptr, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
     AB_LAUNCH_CHECK(); return 0;
 }
 extern "C" int ab_bn_relu_maxpool3x3s2_fwd(const void* y, const float* bnp, int dtype, int N, int H, int W, int C, void* out,
@@ -654,16 +661,20 @@ extern "C" int ab_bn_relu_maxpool3x3s2_fwd(const void* y, const float* bnp, int 
     if (!y || !bnp || !out) return AB_EINVAL;
     int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
     long nvec = (long)N * (H / 2) * (W / 2) * C / V;
-    DISPATCH(dtype, (maxpool_fwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const float*)y, bnp, N, H, W, C, (float*)out, (uint8_t*)idx)),
-             (maxpool_fwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const bf16_t*)y, bnp, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
+    dim3 pgrid((unsigned)(((long)(W / 2) * (C / V) + 255) / 256), (unsigned)(H / 2), (unsigned)N);
+    (void)nvec;
+    DISPATCH(dtype, (maxpool_fwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>((const float*)y, bnp, N, H, W, C, (float*)out, (uint8_t*)idx)),
+             (maxpool_fwd_kernel<bf16_t><<<pgrid, 256, 0, as_stream(stream)>>>((const bf16_t*)y, bnp, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
     AB_LAUNCH_CHECK(); return 0;
 }
 extern "C" int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx,
                                    void* stream) {
     int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
     long nvec = (long)N * H * W * C / V;
-    DISPATCH(dtype, (maxpool_bwd_kernel<float><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const uint8_t*)idx, (const float*)dout, N, H, W, C, (float*)dx)),
-             (maxpool_bwd_kernel<bf16_t><<<grid_for(nvec), 256, 0, as_stream(stream)>>>((const uint8_t*)idx, (const bf16_t*)dout, N, H, W, C, (bf16_t*)dx)));
+    dim3 pgrid((unsigned)(((long)W * (C / V) + 255) / 256), (unsigned)H, (unsigned)N);
+    (void)nvec;
+    DISPATCH(dtype, (maxpool_bwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>((const uint8_t*)idx, (const float*)dout, N, H, W, C, (float*)dx)),
+             (maxpool_bwd_kernel<bf16_t><<<pgrid, 256, 0, as_stream(stream)>>>((const uint8_t*)idx, (const bf16_t*)dout, N, H, W, C, (bf16_t*)dx)));
     AB_LAUNCH_CHECK(); return 0;
 }
 
