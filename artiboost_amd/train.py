@@ -14,6 +14,11 @@ import torch
 from .registry import Queries
 
 
+# hipGraph captures use thread-local error mode: with a process group alive, RCCL's watchdog / heartbeat threads query
+# events concurrently, which under the default global mode can invalidate a capture in progress on this thread
+CAPTURE_MODE = "thread_local"
+
+
 def allreduce_flat_(g, world, group=None, bucket_elems=8 << 20):
     """In-place average of the flat gradient over `world` ranks in fixed-size buckets (32 MiB of fp32 by default:
     large enough to run RCCL at link rate over xGMI, small enough that the first bucket is on the wire while the
@@ -160,21 +165,21 @@ class TrainStep:
         if self.split:
             self._capturing_split = True
             try:
-                with torch.cuda.graph(self.g_fwd_bwd):
+                with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode=CAPTURE_MODE):
                     self.out = self._fwd_bwd()                       # ... up to and including layer4's backward
                 self.g_bwd_rest = []
                 for st in range(1, self.hb.net.BWD_STAGES):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=self.g_fwd_bwd.pool()):
+                    with torch.cuda.graph(g, pool=self.g_fwd_bwd.pool(), capture_error_mode=CAPTURE_MODE):
                         self.hb.net.backward(stage=st)
                     self.g_bwd_rest.append(g)
             finally:
                 self._capturing_split = False
         else:
-            with torch.cuda.graph(self.g_fwd_bwd):
+            with torch.cuda.graph(self.g_fwd_bwd, capture_error_mode=CAPTURE_MODE):
                 self.out = self._fwd_bwd()
         self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt, pool=self.g_fwd_bwd.pool()):
+        with torch.cuda.graph(self.g_opt, pool=self.g_fwd_bwd.pool(), capture_error_mode=CAPTURE_MODE):
             self._optim()
         self.opt.graph_steps = 1            # the warm-up above performed one real update
 
