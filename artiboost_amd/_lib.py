@@ -80,3 +80,10 @@ def i(x):
 
 def l(x):
     return ctypes.c_long(int(x))
+
+
+class SymCorner(ctypes.Structure):
+    """struct ab_symcorner (include/artiboost_hip.h)."""
+    _fields_ = [("R", ctypes.c_void_p), ("t", ctypes.c_void_p), ("K", ctypes.c_int32), ("obj_idx", ctypes.c_void_p),
+                ("obj_transf", ctypes.c_void_p), ("lam", ctypes.c_float), ("weight", ctypes.c_float),
+                ("loss_out", ctypes.c_void_p)]

@@ -356,7 +356,9 @@ class FusedPoseCriterion:
         self.inp_res = inp_res
         self.center_idx = center_idx
         w = [0.0] * 8
-        self.hand = self.scene = None
+        self.hand = self.scene = self.sym = None
+        self.sym_weight = 0.0
+        self._sym_dev = None
         for loss in criterion.loss_list:
             lam = criterion.loss_lambdas[type(loss).__name__]
             if isinstance(loss, JointsLoss):
@@ -367,6 +369,9 @@ class FusedPoseCriterion:
             elif isinstance(loss, SceneOrdLoss):
                 w[4], w[7] = loss.lambda_scene_lev, float(lam)
                 self.scene = loss
+            elif isinstance(loss, SymCornerLoss):
+                self.sym = loss
+                self.sym_weight = float(lam)
             else:
                 raise NotImplementedError(f"{type(loss).__name__} is not part of the fused criterion")
         self.weights = (ctypes.c_float * 8)(*w)
@@ -378,7 +383,8 @@ class FusedPoseCriterion:
     def _alloc(self, B, dev):
         z = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)   # noqa: E731
         self.out = dict(joints_3d_abs=z(B, 21, 3), corners_3d_abs=z(B, 8, 3), box_rot_rotmat=z(B, 3, 3),
-                        uvd2d=z(B, 30, 3), sample_part=z(B, 8), losses=z(8), g_kp3d=z(B, 22, 3), g_box6d=z(B, 6))
+                        uvd2d=z(B, 30, 3), sample_part=z(B, 8), losses=z(8), g_kp3d=z(B, 22, 3), g_box6d=z(B, 6),
+                        sym_loss=torch.zeros(1, dtype=torch.float32, device=dev))
 
     def __call__(self, kp3d, box6d_buf, box_stride, targs, backward=True):
         """kp3d [B,22,3] f32; box6d_buf: f32 buffer whose rows (pitch box_stride) start with the 6-D rotation."""
@@ -392,17 +398,29 @@ class FusedPoseCriterion:
         nvh = hb["views"].shape[0] if hb else 0
         nvs = sb["views"].shape[0] if sb else 0
         t = lambda k: targs[k]   # noqa: E731
-        L.check(L.lib().ab_pose_loss(
+        symp = None
+        if self.sym is not None and self.sym.lambda_sym_corners_3d:
+            import ctypes
+            if self._sym_dev is None or self._sym_dev[0].device != dev:
+                self._sym_dev = (self.sym.R.to(dev).contiguous(), self.sym.t.to(dev).reshape(self.sym.t.shape[0], -1, 3).contiguous())
+            Rd, td = self._sym_dev
+            obj = t(Queries.OBJ_IDX)
+            if obj.dtype != torch.int64:
+                raise TypeError("obj_idx must be int64")
+            self._sym_struct = L.SymCorner(L.ptr(Rd), L.ptr(td), int(Rd.shape[1]), L.ptr(obj), L.ptr(t(Queries.OBJ_TRANSF)),
+                                           float(self.sym.lambda_sym_corners_3d), float(self.sym_weight), L.ptr(o["sym_loss"]))
+            symp = ctypes.byref(self._sym_struct)
+        L.check(L.lib().ab_pose_loss_sym(
             L.ptr(kp3d), L.ptr(box6d_buf), L.i(box_stride), L.ptr(t(Queries.ROOT_JOINT)), L.ptr(t(Queries.CAM_INTR)),
             L.ptr(t(Queries.CORNERS_CAN)), L.ptr(t(Queries.JOINTS_3D)), L.ptr(t(Queries.CORNERS_3D)),
             L.ptr(t(Queries.JOINTS_VIS)), L.ptr(t(Queries.CORNERS_VIS)),
             L.ptr(hb.get("views")), L.i(nvh), L.ptr(hb.get("j0")), L.ptr(hb.get("j1")), L.i(hb["j0"].numel() if hb else 0),
             L.ptr(hb.get("p0")), L.ptr(hb.get("p1")), L.i(hb["p0"].numel() if hb else 0),
             L.ptr(sb.get("views")), L.i(nvs), L.ptr(sb.get("i0")), L.ptr(sb.get("i1")), L.i(sb["i0"].numel() if sb else 0),
-            L.i(B), L.i(self.center_idx), L.f(self.inp_res[0]), L.f(self.inp_res[1]), self.weights,
+            L.i(B), L.i(self.center_idx), L.f(self.inp_res[0]), L.f(self.inp_res[1]), self.weights, symp,
             L.ptr(o["joints_3d_abs"]), L.ptr(o["corners_3d_abs"]), L.ptr(o["box_rot_rotmat"]), L.ptr(o["uvd2d"]),
             L.ptr(o["sample_part"]), L.ptr(o["losses"]), L.ptr(o["g_kp3d"] if backward else None),
-            L.ptr(o["g_box6d"] if backward else None), L.stream()), "ab_pose_loss")
+            L.ptr(o["g_box6d"] if backward else None), L.stream()), "ab_pose_loss_sym")
         return o
 
     LOSS_KEYS = ("joints_3d_loss", "corners_3d_loss", "joint_ord_loss", "part_ord_loss", "scene_ord_loss", "final_loss")
@@ -410,4 +428,7 @@ class FusedPoseCriterion:
     def losses_dict(self):
         """Host view of the loss scalars of the last call (synchronises)."""
         v = self.out["losses"].cpu()
-        return {k: v[i] for i, k in enumerate(self.LOSS_KEYS)}
+        d = {k: v[i] for i, k in enumerate(self.LOSS_KEYS)}
+        if self.sym is not None:
+            d["sym_corners_3d_loss"] = self.out["sym_loss"].cpu()[0]
+        return d

@@ -39,6 +39,14 @@ struct PoseLossArgs {
     float lam_joints, lam_corners;          // inside JointsLoss (1.0, 0.2)
     float lam_hand_joint, lam_hand_part, lam_scene;   // inside the ordinal losses (1,1,1)
     float w_jointsloss, w_handord, w_sceneord;        // Criterion LAMBDAS (0.5, 0.2, 0.1); 0 disables a loss
+    // SymCornerLoss (symcornerloss.py:49-102): min over the object's symmetry set of the vis-masked corner MSE
+    const float* sym_R;        // [nobj][symK][3][3]
+    const float* sym_t;        // [nobj][symK][3]  (metres)
+    const int64_t* obj_idx;    // [B] 1-based object index
+    const float* obj_transf;   // [B][4][4]
+    int symK;                  // 0: loss absent
+    float lam_sym, w_sym;      // LAMBDA_SYM_CORNERS_3D, Criterion LAMBDA of the loss
+    float* sym_loss;           // [1] output (mean over the batch)
     // outputs
     float* joints_abs;      // [B,21,3]
     float* corners_abs;     // [B,8,3]
@@ -207,6 +215,44 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
         }
         gsp[pi][0] = g[0]; gsp[pi][1] = g[1]; gsp[pi][2] = g[2];
     }
+    // ---- SymCornerLoss: lanes scan the symmetry set, wave arg-min (ties -> lowest k), gradient from the winner only
+    __shared__ float gsym[8][3];
+    if (lane < 24) gsym[lane / 3][lane % 3] = 0.f;
+    if (a.symK > 0) {
+        const long obj = (long)a.obj_idx[b] - 1;
+        const float* Tm = a.obj_transf + (long)b * 16;
+        auto sym_gt = [&](int k, int c, float* gt) {           // vis-masked transformed canonical corner c under symmetry k
+            const float* Rk = a.sym_R + (obj * a.symK + k) * 9;
+            const float* tk = a.sym_t + (obj * a.symK + k) * 3;
+            const float* can = a.corners_can + ((long)b * 8 + c) * 3;
+            float sc[3];
+            for (int i = 0; i < 3; ++i) sc[i] = (Rk[i * 3] * can[0] + Rk[i * 3 + 1] * can[1] + Rk[i * 3 + 2] * can[2]) + tk[i];
+            for (int i = 0; i < 3; ++i) gt[i] = ((Tm[i * 4] * sc[0] + Tm[i * 4 + 1] * sc[1] + Tm[i * 4 + 2] * sc[2]) + Tm[i * 4 + 3]) * vc[c];
+        };
+        float best = INFINITY; int bk = 0x7fffffff;
+        for (int k = lane; k < a.symK; k += 64) {
+            float e = 0.f;
+            for (int c = 0; c < 8; ++c) {
+                float gt[3]; sym_gt(k, c, gt);
+                float per = 0.f;
+                for (int i = 0; i < 3; ++i) { float d = gt[i] - mC[c][i]; per += d * d; }
+                e += per / 3.f;                                 // .mean(-1) over xyz, then .mean(-1) over corners
+            }
+            e /= 8.f;
+            if (e < best) { best = e; bk = k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o, 64); int ok = __shfl_xor(bk, o, 64);
+            if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+        }
+        if (lane == 0) a.sample_part[(long)b * 8 + 7] = best;
+        if (lane < 8 && a.g_kp3d) {
+            float gt[3]; sym_gt(bk, lane, gt);
+            const float wS = a.w_sym * a.lam_sym * 2.f / (24.f * B_);
+            for (int i = 0; i < 3; ++i) gsym[lane][i] = wS * (mC[lane][i] - gt[i]);
+        }
+    }
     for (int i = 0; i < 5; ++i) red[lane][i] = acc[i];
     __syncthreads();
     if (lane < 5) {
@@ -242,7 +288,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     }
     if (lane < 24) {
         int c = lane / 3, i = lane % 3;
-        float s = wC * (mC[c][i] - mTC[c][i]);
+        float s = wC * (mC[c][i] - mTC[c][i]) + gsym[c][i];
         for (int pi = 0; pi < a.nsp; ++pi) if ((int)is1[pi] == c) s -= gsp[pi][i];
         gC[c][i] = s * vc[c];
     }
@@ -300,13 +346,21 @@ __global__ void pose_loss_finalize(const float* __restrict__ sample_part, PoseLo
         losses[lane < 5 ? lane : lane + 1] = v;
     }
     __syncthreads();
-    if (lane == 0)
+    if (lane == 0) {
+        float symv = 0.f;
+        if (a.symK > 0) {
+            double s = 0.0;
+            for (int b = 0; b < a.B; ++b) s += sample_part[(long)b * 8 + 7];
+            symv = (float)(s / (double)a.B);
+            if (a.sym_loss) a.sym_loss[0] = symv;
+        }
         losses[5] = a.w_jointsloss * (a.lam_joints * losses[0] + a.lam_corners * losses[1]) +
                     a.w_handord * (a.lam_hand_joint * losses[2] + a.lam_hand_part * losses[3]) +
-                    a.w_sceneord * (a.lam_scene * losses[4]);
+                    a.w_sceneord * (a.lam_scene * losses[4]) + a.w_sym * (a.lam_sym * symv);
+    }
 }
 
-extern "C" int ab_pose_loss(const float* kp3d, const float* box6d, int box_stride, const float* root_joint,
+static int pose_loss_impl(const float* kp3d, const float* box6d, int box_stride, const float* root_joint,
                             const float* cam_intr, const float* corners_can, const float* joints_3d,
                             const float* corners_3d, const float* joints_vis, const float* corners_vis,
                             const float* hand_views, int nvh, const int64_t* j0, const int64_t* j1, int njp,
@@ -314,7 +368,7 @@ extern "C" int ab_pose_loss(const float* kp3d, const float* box6d, int box_strid
                             const int64_t* s0, const int64_t* s1, int nsp, int B, int center_idx, float res_w,
                             float res_h, const float* weights8_host, float* joints_abs, float* corners_abs, float* rotmat,
                             float* uvd2d, float* sample_part, float* losses, float* g_kp3d, float* g_box6d,
-                            void* stream) {
+                            void* stream, const ab_symcorner* sym) {
     if (!kp3d || !box6d || !root_joint || !cam_intr || !corners_can || !joints_3d || !corners_3d || !joints_vis ||
         !corners_vis || !weights8_host || !joints_abs || !corners_abs || !rotmat || !sample_part || !losses)
         return AB_EINVAL;
@@ -334,7 +388,11 @@ extern "C" int ab_pose_loss(const float* kp3d, const float* box6d, int box_strid
     a.lam_scene = weights8_host[4]; a.w_jointsloss = weights8_host[5]; a.w_handord = weights8_host[6]; a.w_sceneord = weights8_host[7];
     a.joints_abs = joints_abs; a.corners_abs = corners_abs; a.rotmat = rotmat; a.uvd2d = uvd2d;
     a.sample_part = sample_part; a.g_kp3d = g_kp3d; a.g_box6d = g_box6d;
-    if (a.njp == 0) a.njp = 0;
+    if (sym && sym->K > 0 && sym->weight != 0.f && sym->lambda != 0.f) {
+        if (!sym->R || !sym->t || !sym->obj_idx || !sym->obj_transf) return AB_EINVAL;
+        a.sym_R = sym->R; a.sym_t = sym->t; a.obj_idx = sym->obj_idx; a.obj_transf = sym->obj_transf;
+        a.symK = sym->K; a.lam_sym = sym->lambda; a.w_sym = sym->weight; a.sym_loss = sym->loss_out;
+    }
     pose_loss_kernel<<<B, 64, 0, as_stream(stream)>>>(a);
     AB_LAUNCH_CHECK();
     // guard the normalisers of disabled losses
@@ -344,4 +402,35 @@ extern "C" int ab_pose_loss(const float* kp3d, const float* box6d, int box_strid
     pose_loss_finalize<<<1, 64, 0, as_stream(stream)>>>(sample_part, f, losses);
     AB_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int ab_pose_loss(const float* kp3d, const float* box6d, int box_stride, const float* root_joint,
+                            const float* cam_intr, const float* corners_can, const float* joints_3d,
+                            const float* corners_3d, const float* joints_vis, const float* corners_vis,
+                            const float* hand_views, int nvh, const int64_t* j0, const int64_t* j1, int njp,
+                            const int64_t* p0, const int64_t* p1, int npp, const float* scene_views, int nvs,
+                            const int64_t* s0, const int64_t* s1, int nsp, int B, int center_idx, float res_w,
+                            float res_h, const float* weights8_host, float* joints_abs, float* corners_abs, float* rotmat,
+                            float* uvd2d, float* sample_part, float* losses, float* g_kp3d, float* g_box6d,
+                            void* stream) {
+    return pose_loss_impl(kp3d, box6d, box_stride, root_joint, cam_intr, corners_can, joints_3d, corners_3d, joints_vis,
+                          corners_vis, hand_views, nvh, j0, j1, njp, p0, p1, npp, scene_views, nvs, s0, s1, nsp, B, center_idx,
+                          res_w, res_h, weights8_host, joints_abs, corners_abs, rotmat, uvd2d, sample_part, losses, g_kp3d,
+                          g_box6d, stream, nullptr);
+}
+
+// ab_pose_loss + SymCornerLoss (sym may be NULL): the final loss (losses[5]) and the corner gradients include it
+extern "C" int ab_pose_loss_sym(const float* kp3d, const float* box6d, int box_stride, const float* root_joint,
+                                const float* cam_intr, const float* corners_can, const float* joints_3d,
+                                const float* corners_3d, const float* joints_vis, const float* corners_vis,
+                                const float* hand_views, int nvh, const int64_t* j0, const int64_t* j1, int njp,
+                                const int64_t* p0, const int64_t* p1, int npp, const float* scene_views, int nvs,
+                                const int64_t* s0, const int64_t* s1, int nsp, int B, int center_idx, float res_w,
+                                float res_h, const float* weights8_host, const ab_symcorner* sym, float* joints_abs,
+                                float* corners_abs, float* rotmat, float* uvd2d, float* sample_part, float* losses,
+                                float* g_kp3d, float* g_box6d, void* stream) {
+    return pose_loss_impl(kp3d, box6d, box_stride, root_joint, cam_intr, corners_can, joints_3d, corners_3d, joints_vis,
+                          corners_vis, hand_views, nvh, j0, j1, njp, p0, p1, npp, scene_views, nvs, s0, s1, nsp, B, center_idx,
+                          res_w, res_h, weights8_host, joints_abs, corners_abs, rotmat, uvd2d, sample_part, losses, g_kp3d,
+                          g_box6d, stream, sym);
 }

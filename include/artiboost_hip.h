@@ -159,6 +159,27 @@ int ab_pose_loss(const float* kp3d, const float* box6d, int box_stride, const fl
                  int center_idx, float res_w, float res_h, const float* weights8_host, float* joints_abs,
                  float* corners_abs, float* rotmat, float* uvd2d, float* sample_part, float* losses, float* g_kp3d,
                  float* g_box6d, void* stream);
+/* ab_pose_loss with SymCornerLoss (anakin/criterions/symcornerloss.py:49-102, use_ho3d_ycb = False) in the same kernel:
+ * loss = mean_b min_k mean((sym_k(corners_gt) - pred)^2) over the object's symmetry set, vis-masked; its value goes to
+ * loss_out[0], losses[5] (final) and the corner gradients include weight * lambda * loss.  sym == NULL or K == 0: absent. */
+typedef struct ab_symcorner {
+    const float* R;            /* device [nobj][K][3][3] (identity-padded)                       */
+    const float* t;            /* device [nobj][K][3], metres                                     */
+    int32_t K;
+    const int64_t* obj_idx;    /* device [B], 1-based                                             */
+    const float* obj_transf;   /* device [B][4][4]                                                */
+    float lambda;              /* LAMBDA_SYM_CORNERS_3D                                           */
+    float weight;              /* the Criterion LAMBDA of this loss                               */
+    float* loss_out;           /* device [1], may be NULL                                         */
+} ab_symcorner;
+int ab_pose_loss_sym(const float* kp3d, const float* box6d, int box_stride, const float* root_joint,
+                     const float* cam_intr, const float* corners_can, const float* joints_3d, const float* corners_3d,
+                     const float* joints_vis, const float* corners_vis, const float* hand_views, int nvh,
+                     const int64_t* j0, const int64_t* j1, int njp, const int64_t* p0, const int64_t* p1, int npp,
+                     const float* scene_views, int nvs, const int64_t* s0, const int64_t* s1, int nsp, int B,
+                     int center_idx, float res_w, float res_h, const float* weights8_host, const ab_symcorner* sym,
+                     float* joints_abs, float* corners_abs, float* rotmat, float* uvd2d, float* sample_part, float* losses,
+                     float* g_kp3d, float* g_box6d, void* stream);
 
 /* ---- R3/R4/R5: batched online synthesis (rasterise + z-buffer + shade + background + colour jitter + crop) --------
  * replaces: anakin/utils/renderer.py:101-136 (Renderer.__call__: pyrender/OpenGL draw, background putmask),

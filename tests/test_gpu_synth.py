@@ -226,9 +226,9 @@ def test_two_rank_ddp_step_keeps_weights_identical():
 
 
 @pytest.mark.parametrize("graph", [False, True])
-def test_train_step_with_symcorner_loss_falls_back_to_autograd_criterion(graph):
-    """A criterion list containing SymCornerLoss (DexYCB-style configs, symcornerloss.py:18-102) is not covered by the fused
-    pose/loss kernel: TrainStep must run it through the registry losses + autograd on top of the HIP forward/backward."""
+def test_train_step_with_symcorner_loss(graph):
+    """A criterion list containing SymCornerLoss (DexYCB-style configs, symcornerloss.py:18-102) runs through the fused
+    pose/loss kernel (ab_pose_loss_sym), eagerly and as replayed hipGraphs, and trains."""
     import yaml, os
     from artiboost_amd import registry as R
     from artiboost_amd.criterions import Criterion
@@ -255,11 +255,11 @@ def test_train_step_with_symcorner_loss_falls_back_to_autograd_criterion(graph):
     model.train()
     ts = TrainStep(model, crit, opt, static, use_graph=graph, renderer=loader)
     ts.static = static
-    assert ts.fused is None and ts.use_graph is False      # autograd criterion => eager issue (documented limitation)
-    vals = []
-    for i in range(6):
+    assert ts.fused is not None and ts.fused.sym is not None and ts.use_graph is graph
+    vals, syms = [], []
+    for i in range(8):
         loader.load_batch(static, 0)
-        _, total, losses = ts()
-        vals.append(float(total))
-        assert "sym_corners_3d_loss" in losses or any("sym" in k for k in losses)
-    assert np.isfinite(vals).all() and vals[-1] < vals[0], vals
+        _, losses, o = ts()
+        vals.append(float(losses[5])); syms.append(float(o["sym_loss"][0]))
+    assert np.isfinite(vals).all() and np.isfinite(syms).all() and syms[0] > 0
+    assert vals[-1] < vals[0], vals
