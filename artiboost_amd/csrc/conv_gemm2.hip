@@ -10,7 +10,10 @@
 //     branching, so the load stream is uniform;
 //   * workgroups are renumbered so that each XCD (block id mod 8) owns a contiguous range of M tiles: neighbouring
 //     tiles re-read each other's halo pixels and the 9 taps re-read the same rows from that XCD's L2;
-//   * two LDS buffers; the loads of step s+1 are issued before the 16*TM*TN/4 MFMAs of step s and drained at the barrier.
+//   * a ring of NBUF (3) LDS stages; the loads run two K-steps ahead of the MFMAs, issued from inline asm and retired
+//     with counted s_waitcnt vmcnt(N) + a raw s_barrier per step (see the loop);
+//   * 4 or 8 waves per workgroup (WM x WN): the L2->LDS fill rate scales with the number of waves issuing loads;
+//   * nclass > 1: the four output-parity classes of a stride-2 data gradient share one grid.
 #include "conv_common.h"
 
 __device__ uint4 ab_zero_page[2];    // zero-initialised device memory: source of every out-of-range chunk

@@ -9,6 +9,10 @@
 //
 // Each workgroup owns a BI x BJ tile of dW and one slice of the pixel range (split-R); slices are written to
 // separate slabs and summed in a fixed order by wgrad_reduce (deterministic, no atomics).
+//
+// This register-staged kernel is the f32 / odd-shape path (and the reference the full-size check compares against);
+// bf16 problems are routed to wgrad3x3.hip (3x3 / stride 1: all nine taps per workgroup) or wgrad_gemm2.hip (everything
+// else, LDS-DMA operands) by ab_conv2d_wgrad / ab_conv2d_stem_wgrad below.  wgrad_reduce serves all three.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

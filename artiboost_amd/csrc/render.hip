@@ -9,10 +9,12 @@
 // are DEFINED in oracle/render_oracle.c (the reference's rasteriser is the GL driver: parity unpinned); this file
 // must match that oracle bit for bit.  Float work uses the same operation order and no FMA contraction.
 //
-// Rasteriser: one workgroup per 32x32-pixel tile; the tile's z-buffer is 1024 u64 keys in LDS; each lane takes one
-// triangle record at a time (the meshes are 1-20 px per face at this camera distance, so lane-per-triangle keeps all
-// 64 lanes busy) and resolves visibility with ds_min_u64; tiles outside the sample's screen bounding box skip
-// straight to the background.  The HBM side is small (a 48-byte record per face, 4 bytes per pixel out).
+// Rasteriser: the setup kernel snaps / culls every triangle and bins it into the 32x32-pixel tiles its bounding box touches
+// (per-workgroup LDS counts, one global reservation per touched tile); one workgroup per tile then walks its own list:
+// the tile's z-buffer is 1024 u64 keys in LDS, each lane takes one triangle at a time (the meshes are 1-20 px per face
+// at this camera distance, so lane-per-triangle keeps the lanes busy), steps the edge functions and the depth numerator
+// incrementally and resolves visibility with ds_min_u64; tiles with an empty list go straight to the background.  The
+// HBM side is small (a 48-byte record per face, 4 bytes per pixel out).
 #include "common.h"
 
 #define HAND_FACES 1538
