@@ -60,7 +60,7 @@ def build_everything(args, rank, world, device):
     group = torch.distributed.group.WORLD if world > 1 else None
     model.train()
     ts = TrainStep(model, crit, opt, static, use_graph=not args.eager, dist_group=group, renderer=loader,
-                   pipeline_render=args.pipeline)
+                   pipeline_render=("opt" if args.pipeline_opt else args.pipeline))
     ts.static = static
     return cfg, model, crit, opt, loader, ts, static
 
@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="render batch i+1 on a side stream while step i learns (measured slower on one GPU: the conv "
                          "kernels already fill the chip, co-scheduling the rasteriser only evicts their workgroups)")
+    ap.add_argument("--pipeline-opt", action="store_true",
+                    help="render batch i+1 on a side stream while step i's all-reduce and clip+Adam run")
     ap.add_argument("--cpu-samples", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=6)
     ap.add_argument("--cpu-threads", type=int, default=32)

@@ -121,7 +121,8 @@ def test_end_to_end_train_steps_decrease_loss():
 
 
 @pytest.mark.gpu
-def test_pipelined_render_hands_over_next_batch():
+@pytest.mark.parametrize("mode", [True, "opt"])
+def test_pipelined_render_hands_over_next_batch(mode):
     """Pipelined TrainStep: step i learns from batch i while batch i+1 is rendered on the side stream; the image handed
     to the next step must be bit-identical to an inline render of that batch."""
     import yaml, os
@@ -142,7 +143,7 @@ def test_pipelined_render_hands_over_next_batch():
     static = loader.new_static_batch()
     loader.load_batch(static, 0)
     model.train()
-    ts = TrainStep(model, crit, opt, static, use_graph=True, renderer=loader, pipeline_render=True)
+    ts = TrainStep(model, crit, opt, static, use_graph=True, renderer=loader, pipeline_render=mode)
     ts.static = static
     ref = loader.new_static_batch()
 
