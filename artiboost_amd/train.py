@@ -51,7 +51,8 @@ class TrainStep:
         self.out = None
         self.g_fwd_bwd = None
         self.g_opt = None
-        self.comm_stream = torch.cuda.Stream(device=self.dev) if self.world > 1 else None
+        self._fake_comm = os.environ.get("AB_FAKE_COMM") == "1"     # timing probe: the DDP stream choreography without RCCL
+        self.comm_stream = torch.cuda.Stream(device=self.dev) if (self.world > 1 or self._fake_comm) else None
         self.steps = 0
         # DDP overlap: the backward is captured as three graphs (heads + layer4 | layer3 | layer2 .. stem).  The first
         # stage produces 68 % of the gradient bytes, the second 27 %; each range is all-reduced on the comm stream while
@@ -156,7 +157,10 @@ class TrainStep:
         on the compute stream."""
         self.comm_stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.comm_stream):
-            allreduce_flat_(self.hb.store.grad[lo:hi], self.world, self.group)
+            if self._fake_comm:
+                self.hb.store.grad[lo:hi].mul_(1.0)          # same bytes touched once, no communication
+            else:
+                allreduce_flat_(self.hb.store.grad[lo:hi], self.world, self.group)
 
     def _allreduce(self):
         """Average the flat gradient across ranks on the side stream (RCCL over xGMI), bucketed so the first buckets'
@@ -263,14 +267,15 @@ class TrainStep:
             self.g_fwd_bwd.replay()
             if self.split:
                 ranges = self.hb.net.grad_stage_ranges()
-                if self.world > 1:
+                comm = self.world > 1 or self._fake_comm
+                if comm:
                     self._allreduce_range(*ranges[0])
                 for g, rng in zip(self.g_bwd_rest, ranges[1:]):
                     g.replay()
-                    if self.world > 1:
+                    if comm:
                         self._allreduce_range(*rng)
                 self._launch_render_next()
-                if self.world > 1:
+                if comm:
                     torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
             else:
                 self._launch_render_next()
