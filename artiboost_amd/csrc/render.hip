@@ -24,6 +24,7 @@
 #define ZMAX 16777215.0f
 #define KD 0.0716f
 #define TILE 32
+#define RS_THREADS 256   // raster/shade workgroup: one pixel of the 32x32 tile per thread in the shading pass
 #define BIN_CAP 1024      // per-tile triangle list capacity (overflowing tiles fall back to scanning all records)
 
 struct SceneDev {    // mirrors ab_scene (host struct of device pointers)
@@ -252,7 +253,7 @@ __device__ __forceinline__ void shade_pixel(const SceneDev& sc, const SampleDev&
     o[3] = 255;
 }
 
-__global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const SampleDev* __restrict__ samples,
+__global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, const SampleDev* __restrict__ samples,
                                                            const float* __restrict__ hand_verts, int maxf,
                                                            const TriRec* __restrict__ tri, const int4* __restrict__ tails_g,
                                                            const int* __restrict__ bin_count, const int* __restrict__ bin_list,
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const Sa
     const int ty0 = (blockIdx.x / tiles_x) * TILE, tx0 = (blockIdx.x % tiles_x) * TILE;
     const SampleDev sm = samples[b];
     const float* hv = hand_verts + (size_t)b * HAND_VERTS * 3;
-    for (int i = threadIdx.x; i < TILE * TILE; i += 256) zb[i] = ~0ull;
+    for (int i = threadIdx.x; i < TILE * TILE; i += RS_THREADS) zb[i] = ~0ull;
     __syncthreads();
     const int ntile = tiles_x * (sc.H / TILE);
     const int nbin = bin_count[b * ntile + blockIdx.x];
@@ -317,31 +318,31 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const Sa
             }
         };
         if (nbin <= BIN_CAP) {
-            // the tile's own list (typically ~100 triangles: one round of the 256 lanes)
+            // the tile's own list (typically ~100 triangles: one round of the lanes)
             const int* lst = bin_list + ((size_t)b * ntile + blockIdx.x) * BIN_CAP;
-            for (int i = threadIdx.x; i < nbin; i += 256) { const int gid = lst[i]; raster_tri(gid, tl[gid]); }
+            for (int i = threadIdx.x; i < nbin; i += RS_THREADS) { const int gid = lst[i]; raster_tri(gid, tl[gid]); }
         } else {
             // overflowed list: scan every record; four tails per lane are fetched before any is examined
-            for (int gbase = threadIdx.x; gbase < nf; gbase += 1024) {
+            for (int gbase = threadIdx.x; gbase < nf; gbase += 4 * RS_THREADS) {
                 int4 tails[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int gq = gbase + u * 256; tails[u] = gq < nf ? tl[gq] : make_int4(0, 0, 0, 0); }
+                for (int u = 0; u < 4; ++u) { const int gq = gbase + u * RS_THREADS; tails[u] = gq < nf ? tl[gq] : make_int4(0, 0, 0, 0); }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) raster_tri(gbase + u * 256, tails[u]);
+                for (int u = 0; u < 4; ++u) raster_tri(gbase + u * RS_THREADS, tails[u]);
             }
         }
     }
     __syncthreads();
     if (!active) {
         // background-only tile (4 of 5 at the benchmark geometry): all four pixels' texel loads are issued before any store
-        constexpr int NP = TILE * TILE / 256;
+        constexpr int NP = TILE * TILE / RS_THREADS;
         const unsigned dx = 2u * (unsigned)sc.W, dy = 2u * (unsigned)sc.H;
         const int shx = (dx & (dx - 1)) ? -1 : __ffs(dx) - 1, shy = (dy & (dy - 1)) ? -1 : __ffs(dy) - 1;
         const uint8_t* bgimg = sc.bg + (size_t)sm.bg_id * sc.bgs * sc.bgs * 3;
         uint32_t px[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int i = threadIdx.x + j * 256;
+            const int i = threadIdx.x + j * RS_THREADS;
             const int y = ty0 + i / TILE, x = tx0 + i % TILE;
             const unsigned nx = (unsigned)(2 * x + 1) * (unsigned)sm.bg_w, ny = (unsigned)(2 * y + 1) * (unsigned)sm.bg_h;
             const int sx = sm.bg_x0 + (int)(shx < 0 ? nx / dx : nx >> shx), sy = sm.bg_y0 + (int)(shy < 0 ? ny / dy : ny >> shy);
@@ -350,14 +351,14 @@ __global__ __launch_bounds__(256) void raster_shade_kernel(SceneDev sc, const Sa
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            const int i = threadIdx.x + j * 256;
+            const int i = threadIdx.x + j * RS_THREADS;
             const size_t pix = ((size_t)b * sc.H + (ty0 + i / TILE)) * sc.W + (tx0 + i % TILE);
             *(uint32_t*)(rgbx + pix * 4) = px[j];
             if (keys_out) keys_out[pix] = ~0ull;
         }
         return;
     }
-    for (int i = threadIdx.x; i < TILE * TILE; i += 256) {
+    for (int i = threadIdx.x; i < TILE * TILE; i += RS_THREADS) {
         int y = ty0 + i / TILE, x = tx0 + i % TILE;
         uint64_t key = zb[i];
         uint8_t o[4];
@@ -573,7 +574,7 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
     raster_setup_kernel<<<dim3((max_faces + 255) / 256, B), 256, (size_t)ntile * 12, st>>>(sc, (const SampleDev*)samples, hand_verts,
                                                                            max_faces, tri, tails, bin_count, bin_list);
     AB_LAUNCH_CHECK();
-    raster_shade_kernel<<<dim3((sc.W / TILE) * (sc.H / TILE), B), 256, 0, st>>>(sc, (const SampleDev*)samples, hand_verts,
+    raster_shade_kernel<<<dim3((sc.W / TILE) * (sc.H / TILE), B), RS_THREADS, 0, st>>>(sc, (const SampleDev*)samples, hand_verts,
                                                                                  max_faces, tri, tails, bin_count, bin_list, rgbx,
                                                                                  (uint64_t*)keys_out);
     AB_LAUNCH_CHECK();
