@@ -175,19 +175,50 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(SceneDev sc, const Sa
 }
 
 // ------------------------------------------------------------------ kernel 2: tile raster + shade
-__device__ __forceinline__ void shade_pixel(const SceneDev& sc, const SampleDev& sm, const float* hv, uint64_t key, int x,
-                                            int y, uint8_t o[4]) {
-    if (key == ~(uint64_t)0) {
-        // (2x+1)*bg_w / (2W): operands are < 2^31 here (x < W <= 8192, crop side <= 2^16), so the unsigned 32-bit
-        // quotient equals the oracle's 64-bit one; power-of-two render sizes divide by a shift
-        const unsigned nx = (unsigned)(2 * x + 1) * (unsigned)sm.bg_w, ny = (unsigned)(2 * y + 1) * (unsigned)sm.bg_h;
-        const unsigned dx = 2u * (unsigned)sc.W, dy = 2u * (unsigned)sc.H;
-        int sx = sm.bg_x0 + (int)((dx & (dx - 1)) ? nx / dx : nx >> (__ffs(dx) - 1));
-        int sy = sm.bg_y0 + (int)((dy & (dy - 1)) ? ny / dy : ny >> (__ffs(dy) - 1));
-        const uint8_t* p = sc.bg + (((size_t)sm.bg_id * sc.bgs + sy) * sc.bgs + sx) * 3;
-        o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = 0;
-        return;
+// Background = the sample's random crop resized to the render size with cv2's INTER_LINEAR fixed-point arithmetic
+// (renderer.py:125-136; restated in oracle/render_oracle.c bg_pixel / lin_coef, which this must match bit for bit).
+// The two coefficients and the source index of a destination column / row depend only on that column / row: the
+// workgroup tabulates them for its 32 columns and 32 rows in LDS (bgc[0..31] columns, bgc[32..63] rows).
+struct BgCoef { int s0, s1, a0, a1; };
+__device__ __forceinline__ BgCoef bg_coef(int d, int dsize, int ssize) {
+    const double scale = 1.0 / ((double)dsize / (double)ssize);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    BgCoef c;
+    c.s0 = s; c.s1 = s + 1 < ssize ? s + 1 : ssize - 1;
+    c.a0 = (int)rintf((1.f - f) * 2048.f); c.a1 = (int)rintf(f * 2048.f);
+    return c;
+}
+__device__ __forceinline__ void bg_coef_fill(const SceneDev& sc, const SampleDev& sm, int tx0, int ty0, BgCoef* bgc) {
+    if (threadIdx.x < TILE) bgc[threadIdx.x] = bg_coef(tx0 + threadIdx.x, sc.W, sm.bg_w);
+    else if (threadIdx.x < 2 * TILE) bgc[threadIdx.x] = bg_coef(ty0 + threadIdx.x - TILE, sc.H, sm.bg_h);
+}
+__device__ __forceinline__ uint32_t bg_texels(const SceneDev& sc, const SampleDev& sm, const BgCoef& cx, const BgCoef& cy) {
+    const uint32_t* img = (const uint32_t*)sc.bg + (size_t)sm.bg_id * sc.bgs * sc.bgs;      // RGBX texels
+    const uint32_t* r0 = img + (size_t)(sm.bg_y0 + cy.s0) * sc.bgs + sm.bg_x0;
+    const uint32_t* r1 = img + (size_t)(sm.bg_y0 + cy.s1) * sc.bgs + sm.bg_x0;
+    const uint32_t p00 = r0[cx.s0], p01 = r0[cx.s1], p10 = r1[cx.s0], p11 = r1[cx.s1];
+    uint32_t out = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int S0 = (int)((p00 >> (8 * c)) & 255u) * cx.a0 + (int)((p01 >> (8 * c)) & 255u) * cx.a1;
+        const int S1 = (int)((p10 >> (8 * c)) & 255u) * cx.a0 + (int)((p11 >> (8 * c)) & 255u) * cx.a1;
+        const int v = (((cy.a0 * (S0 >> 4)) >> 16) + ((cy.a1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        out |= (uint32_t)(v & 255) << (8 * c);
     }
+    return out;
+}
+__device__ __forceinline__ void bg_sample(const SceneDev& sc, const SampleDev& sm, const BgCoef& cx, const BgCoef& cy, uint8_t o[4]) {
+    const uint32_t q = bg_texels(sc, sm, cx, cy);
+    o[0] = (uint8_t)q; o[1] = (uint8_t)(q >> 8); o[2] = (uint8_t)(q >> 16); o[3] = 0;
+}
+
+__device__ __forceinline__ void shade_pixel(const SceneDev& sc, const SampleDev& sm, const float* hv, uint64_t key, int x,
+                                            int y, const BgCoef* bgc, uint8_t o[4]) {
+    if (key == ~(uint64_t)0) { bg_sample(sc, sm, bgc[x & (TILE - 1)], bgc[TILE + (y & (TILE - 1))], o); return; }
     int gid = (int)(uint32_t)key;
     TriRec t; setup_tri(sc, sm, hv, gid, t);
     float P[3][3]; int vid[3];
@@ -259,12 +290,14 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
                                                            const int* __restrict__ bin_count, const int* __restrict__ bin_list,
                                                            uint8_t* __restrict__ rgbx, uint64_t* __restrict__ keys_out) {
     __shared__ unsigned long long zb[TILE * TILE];
+    __shared__ BgCoef bgc[2 * TILE];
     const int b = blockIdx.y;
     const int tiles_x = sc.W / TILE;
     const int ty0 = (blockIdx.x / tiles_x) * TILE, tx0 = (blockIdx.x % tiles_x) * TILE;
     const SampleDev sm = samples[b];
     const float* hv = hand_verts + (size_t)b * HAND_VERTS * 3;
     for (int i = threadIdx.x; i < TILE * TILE; i += RS_THREADS) zb[i] = ~0ull;
+    bg_coef_fill(sc, sm, tx0, ty0, bgc);
     __syncthreads();
     const int ntile = tiles_x * (sc.H / TILE);
     const int nbin = bin_count[b * ntile + blockIdx.x];
@@ -336,18 +369,11 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
     if (!active) {
         // background-only tile (4 of 5 at the benchmark geometry): all four pixels' texel loads are issued before any store
         constexpr int NP = TILE * TILE / RS_THREADS;
-        const unsigned dx = 2u * (unsigned)sc.W, dy = 2u * (unsigned)sc.H;
-        const int shx = (dx & (dx - 1)) ? -1 : __ffs(dx) - 1, shy = (dy & (dy - 1)) ? -1 : __ffs(dy) - 1;
-        const uint8_t* bgimg = sc.bg + (size_t)sm.bg_id * sc.bgs * sc.bgs * 3;
         uint32_t px[NP];
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int i = threadIdx.x + j * RS_THREADS;
-            const int y = ty0 + i / TILE, x = tx0 + i % TILE;
-            const unsigned nx = (unsigned)(2 * x + 1) * (unsigned)sm.bg_w, ny = (unsigned)(2 * y + 1) * (unsigned)sm.bg_h;
-            const int sx = sm.bg_x0 + (int)(shx < 0 ? nx / dx : nx >> shx), sy = sm.bg_y0 + (int)(shy < 0 ? ny / dy : ny >> shy);
-            const uint8_t* p = bgimg + ((size_t)sy * sc.bgs + sx) * 3;
-            px[j] = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+            px[j] = bg_texels(sc, sm, bgc[i % TILE], bgc[TILE + i / TILE]);
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -362,7 +388,7 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
         int y = ty0 + i / TILE, x = tx0 + i % TILE;
         uint64_t key = zb[i];
         uint8_t o[4];
-        shade_pixel(sc, sm, hv, key, x, y, o);
+        shade_pixel(sc, sm, hv, key, x, y, bgc, o);
         size_t pix = ((size_t)b * sc.H + y) * sc.W + x;
         *(uint32_t*)(rgbx + pix * 4) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
         if (keys_out) keys_out[pix] = key;
@@ -438,15 +464,107 @@ __device__ __forceinline__ void jitter_op(const HueLut& lut, int op, float f, in
     else { for (int c = 0; c < 3; ++c) px[c] = blend8(mean_gray, px[c], f); }
 }
 
+// ------------------------------------------------------------------ PIL GaussianBlur (rendered_dataset.py:257-258)
+// ImageFilter.GaussianBlur(radius) = libImaging/BoxBlur.c: three box-blur passes of fractional radius
+// _gaussian_blur_radius(radius, 3) along x, then three along y; for a box radius < 1 (Gaussian radius < 1.41; the
+// reference draws radius <= 0.1) one pass is  out = (c * ww + (left + right) * fw + 2^23) >> 24  with the neighbours
+// clamped to the line.  Restated (and pinned against the real Pillow) in oracle/render_oracle.c ro_gaussian_blur.
+// With ww = 2^24 - 2 fw - e (e = 0 | 1) a pass is the identity whenever 510 fw + 255 <= 2^23, i.e. for radius < ~0.077
+// (3 of 4 of the reference's draws): such samples are not touched and the later stages read the unblurred image.
+struct BlurPar { uint32_t ww, fw; int on; };
+__device__ __forceinline__ BlurPar blur_params(float radius) {
+    const float sigma2 = radius * radius / 3.0f;
+    const float L = (float)sqrt(12.0 * (double)sigma2 + 1.0);
+    const float l = (float)floor(((double)L - 1.0) / 2.0);
+    float a = (2 * l + 1) * (l * (l + 1) - 3 * sigma2);
+    a /= 6 * (sigma2 - (l + 1) * (l + 1));
+    const float fr = l + a;
+    BlurPar p; p.ww = 1u << 24; p.fw = 0; p.on = 0;
+    if (!(fr > 0.f)) return p;
+    p.ww = (uint32_t)((float)(1 << 24) / (fr * 2 + 1));
+    p.fw = ((1u << 24) - p.ww) / 2;
+    p.on = 510u * p.fw + 255u > (1u << 23);
+    return p;
+}
+__device__ __forceinline__ uint32_t box3(uint32_t l, uint32_t c, uint32_t r, uint32_t ww, uint32_t fw) {
+    uint32_t o = c & 0xff000000u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t cc = (c >> (8 * k)) & 255u, s = ((l >> (8 * k)) & 255u) + ((r >> (8 * k)) & 255u);
+        o |= ((__umul24(cc, ww) + __umul24(s, fw) + (1u << 23)) >> 24) << (8 * k);     // ww < 2^24 whenever the pass is not the identity
+    }
+    return o;
+}
+#define BL_HALO 3
+#define BL_P (TILE + 2 * BL_HALO)
+// One workgroup per 32x32 tile: the tile + a 3-pixel halo goes to LDS, the three horizontal passes shrink the valid
+// columns by one each, the three vertical passes the valid rows; positions outside the image are never read (the
+// neighbour index is clamped at the image border exactly as PIL clamps it at the line ends).
+__global__ __launch_bounds__(256) void gauss_blur_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H,
+                                                         const float* __restrict__ radius, int copy_identity) {
+    __shared__ uint32_t buf[2][BL_P * BL_P];
+    const int b = blockIdx.y;
+    const int tiles_x = W / TILE;
+    const int ty0 = (blockIdx.x / tiles_x) * TILE, tx0 = (blockIdx.x % tiles_x) * TILE;
+    const BlurPar bp = blur_params(radius[b]);
+    const uint32_t* src = (const uint32_t*)in + (size_t)b * W * H;
+    uint32_t* dst = (uint32_t*)out + (size_t)b * W * H;
+    if (!bp.on) {
+        if (copy_identity)
+            for (int i = threadIdx.x; i < TILE * TILE; i += 256) {
+                const size_t o = (size_t)(ty0 + i / TILE) * W + tx0 + i % TILE;
+                dst[o] = src[o];
+            }
+        return;
+    }
+    for (int i = threadIdx.x; i < BL_P * BL_P; i += 256) {
+        const int r = i / BL_P, c = i - r * BL_P;
+        const int gy = min(max(ty0 - BL_HALO + r, 0), H - 1), gx = min(max(tx0 - BL_HALO + c, 0), W - 1);
+        buf[0][i] = src[(size_t)gy * W + gx];
+    }
+    __syncthreads();
+    int cur = 0;
+#pragma unroll
+    for (int p = 1; p <= 3; ++p) {
+        const int ncol = BL_P - 2 * p;
+        for (int i = threadIdx.x; i < BL_P * ncol; i += 256) {
+            const int r = i / ncol, c = p + (i - r * ncol);
+            const int x = tx0 - BL_HALO + c;
+            const int cl = x == 0 ? c : c - 1, cr = x == W - 1 ? c : c + 1;
+            const uint32_t* row = buf[cur] + r * BL_P;
+            buf[cur ^ 1][r * BL_P + c] = box3(row[cl], row[c], row[cr], bp.ww, bp.fw);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int p = 1; p <= 3; ++p) {
+        const int nrow = BL_P - 2 * p;
+        for (int i = threadIdx.x; i < nrow * TILE; i += 256) {
+            const int r = p + i / TILE, c = BL_HALO + i % TILE;
+            const int y = ty0 - BL_HALO + r;
+            const int ru = y == 0 ? r : r - 1, rd = y == H - 1 ? r : r + 1;
+            const uint32_t v = box3(buf[cur][ru * BL_P + c], buf[cur][r * BL_P + c], buf[cur][rd * BL_P + c], bp.ww, bp.fw);
+            if (p == 3) dst[(size_t)y * W + tx0 + c - BL_HALO] = v;
+            else buf[cur ^ 1][r * BL_P + c] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // kernel 3: luma sum of the image as it is when the contrast op is reached (ops before it applied on the fly)
-__global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __restrict__ rgbx, int npix,
+__global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __restrict__ rgbx_plain, int npix,
                                                            const int32_t* __restrict__ order, const float* __restrict__ factor,
-                                                           unsigned long long* __restrict__ lsum) {
+                                                           unsigned long long* __restrict__ lsum,
+                                                           const uint8_t* __restrict__ rgbx_blur = nullptr,
+                                                           const float* __restrict__ radius = nullptr) {
     __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256];
     hue_lut_fill(l_sect, l_frac, l_sat);
     __syncthreads();
     const HueLut lut = {l_sect, l_frac, l_sat};
     const int b = blockIdx.y;
+    const uint8_t* rgbx = (radius && blur_params(radius[b]).on) ? rgbx_blur : rgbx_plain;     // blurred copy exists only where the blur acts
     const int32_t* ord = order + b * 4; const float* fac = factor + b * 4;
     int kc = 0;
     while (kc < 4 && ord[kc] != 3) ++kc;
@@ -465,16 +583,18 @@ __global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __rest
 
 // kernel 4: nearest-neighbour affine crop + full jitter chain + normalise; writes zero-bordered NHWC4 and/or CHW f32
 template <typename T>
-__global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restrict__ rgbx, int W, int H,
+__global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restrict__ rgbx_plain, int W, int H,
                                                           const int32_t* __restrict__ order, const float* __restrict__ factor,
                                                           const float* __restrict__ inv_affine,
                                                           const unsigned long long* __restrict__ lsum, int ow, int oh,
-                                                          T* __restrict__ out_pad, float* __restrict__ out_chw) {
+                                                          T* __restrict__ out_pad, float* __restrict__ out_chw,
+                                                          const uint8_t* __restrict__ rgbx_blur, const float* __restrict__ radius) {
     __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256];
     hue_lut_fill(l_sect, l_frac, l_sat);
     __syncthreads();
     const HueLut lut = {l_sect, l_frac, l_sat};
     const int b = blockIdx.y;
+    const uint8_t* rgbx = (radius && blur_params(radius[b]).on) ? rgbx_blur : rgbx_plain;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= ow * oh) return;
     const int y = i / ow, x = i - y * ow;
@@ -543,13 +663,15 @@ extern "C" long ab_render_workspace_bytes(int B, int W, int H, int max_faces) {
     // tri records + rgbx + lsum + sbox + compact (valid, bbox) tails + per-tile bin counts and lists, each 256-byte aligned
     auto al = [](long x) { return (x + 255) / 256 * 256; };
     return al((long)B * max_faces * 48) + al((long)B * W * H * 4) + al((long)B * 8) + al((long)B * 16) + al((long)B * max_faces * 16) +
-           al((long)B * (W / TILE) * (H / TILE) * 4) + al((long)B * (W / TILE) * (H / TILE) * BIN_CAP * 4);
+           al((long)B * (W / TILE) * (H / TILE) * 4) + al((long)B * (W / TILE) * (H / TILE) * BIN_CAP * 4) +
+           al((long)B * W * H * 4);        // last: the blurred copy of the samples the GaussianBlur acts on
 }
 
 extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, const float* hand_verts,
-                               const int32_t* order, const float* factor, const float* inv_affine, int B,
-                               int max_faces, int ow, int oh, int out_dtype, void* out_pad, float* out_chw,
-                               void* workspace, void* keys_out, void* rgbx_out, void* stream) {
+                               const int32_t* order, const float* factor, const float* inv_affine,
+                               const float* blur_radius, int B, int max_faces, int ow, int oh, int out_dtype,
+                               void* out_pad, float* out_chw, void* workspace, void* keys_out, void* rgbx_out,
+                               void* stream) {
     if (!scene_host || !samples || !hand_verts || !order || !factor || !inv_affine || !workspace) return AB_EINVAL;
     if (!out_pad && !out_chw) return AB_EINVAL;
     SceneDev sc = to_dev(scene_host);
@@ -565,7 +687,8 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
     int4* tails = (int4*)ws; ws += al((long)B * max_faces * 16);
     const long ntile = (long)(sc.W / TILE) * (sc.H / TILE);
     int* bin_count = (int*)ws; ws += al(B * ntile * 4);
-    int* bin_list = (int*)ws;
+    int* bin_list = (int*)ws; ws += al(B * ntile * BIN_CAP * 4);
+    uint8_t* rgbx_blur = (uint8_t*)ws;
     // zeroing by kernel, not hipMemsetAsync: under stream capture the 64 KiB memset node of bin_count faulted on replay
     // (ROCm 7.2), so neither buffer goes through a memset node
     zero_words_kernel<<<(unsigned)((B * 2 + 255) / 256), 256, 0, st>>>((unsigned*)lsum, (long)B * 2);
@@ -579,13 +702,17 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
                                                                                  (uint64_t*)keys_out);
     AB_LAUNCH_CHECK();
     int npix = sc.W * sc.H;
-    jitter_stats_kernel<<<dim3(64, B), 256, 0, st>>>(rgbx, npix, order, factor, lsum);
+    if (blur_radius) {
+        gauss_blur_kernel<<<dim3((unsigned)ntile, B), 256, 0, st>>>(rgbx, rgbx_blur, sc.W, sc.H, blur_radius, 0);
+        AB_LAUNCH_CHECK();
+    }
+    jitter_stats_kernel<<<dim3(64, B), 256, 0, st>>>(rgbx, npix, order, factor, lsum, rgbx_blur, blur_radius);
     AB_LAUNCH_CHECK();
     dim3 g((ow * oh + 255) / 256, B);
     if (out_dtype == AB_DT_F32)
-        warp_jitter_kernel<float><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (float*)out_pad, out_chw);
+        warp_jitter_kernel<float><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (float*)out_pad, out_chw, rgbx_blur, blur_radius);
     else if (out_dtype == AB_DT_BF16)
-        warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw);
+        warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw, rgbx_blur, blur_radius);
     else return AB_EINVAL;
     AB_LAUNCH_CHECK();
     return 0;
@@ -602,6 +729,15 @@ extern "C" int ab_color_jitter(const void* rgbx, int B, int npix, const int32_t*
     AB_LAUNCH_CHECK();
     jitter_apply_kernel<<<dim3(256, B), 256, 0, st>>>((const uint8_t*)rgbx, npix, order, factor,
                                                        (const unsigned long long*)lsum_ws, (uint8_t*)out);
+    AB_LAUNCH_CHECK();
+    return 0;
+}
+
+// PIL GaussianBlur alone on B RGBX images (radius float [B] on the device, each < 1.41; X byte copied); out must not alias rgbx.
+extern "C" int ab_gaussian_blur(const void* rgbx, int B, int W, int H, const float* radius, void* out, void* stream) {
+    if (!rgbx || !radius || !out || rgbx == out || B < 1) return AB_EINVAL;
+    if (W < TILE || H < TILE || W % TILE || H % TILE) return AB_ESHAPE;
+    gauss_blur_kernel<<<dim3((unsigned)((W / TILE) * (H / TILE)), B), 256, 0, as_stream(stream)>>>((const uint8_t*)rgbx, (uint8_t*)out, W, H, radius, 1);
     AB_LAUNCH_CHECK();
     return 0;
 }

@@ -30,6 +30,13 @@ def color_luts():
     return s2l, np.clip(np.floor(l2s * 255.0 + 0.5), 0, 255).astype(np.uint8)
 
 
+def _rgbx(rgb):
+    """uint8 [..., 3] -> [..., 4]: the background texels are fetched as aligned dwords."""
+    a = np.zeros(rgb.shape[:-1] + (4,), np.uint8)
+    a[..., :3] = rgb
+    return a
+
+
 class DeviceRenderer:
     """Renderer(width, height).setup(cam_intr, obj_meshes, hand_meshes, backgrounds) on the GPU; `render()` draws a
     whole batch (the reference's __call__ draws one image per Python call)."""
@@ -42,7 +49,7 @@ class DeviceRenderer:
         host = dict(hand_faces=np.ascontiguousarray(h["faces"], np.int32), hand_normals=h["normals"], hand_uv=h["uv"],
                     hand_tex=assets.hand_tex, obj_verts=assets.obj_verts, obj_normals=assets.obj_normals,
                     obj_uv=assets.obj_uv, obj_faces=assets.obj_faces, obj_vert_off=assets.obj_vert_off,
-                    obj_face_off=assets.obj_face_off, obj_tex=assets.obj_tex, bg=assets.backgrounds, srgb2lin=s2l,
+                    obj_face_off=assets.obj_face_off, obj_tex=assets.obj_tex, bg=_rgbx(assets.backgrounds), srgb2lin=s2l,
                     lin2srgb=l2s)
         self.t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(self.dev) for k, v in host.items()}
         sc = _Scene()
@@ -56,9 +63,10 @@ class DeviceRenderer:
         self._ws = None
 
     def render(self, samples_dev, hand_verts, order, factor, inv_affine, ow, oh, out_pad=None, out_chw=None,
-               want_keys=False, want_rgbx=False):
+               want_keys=False, want_rgbx=False, blur=None):
         """samples_dev: uint8 device tensor [B,96] (SAMPLE_DTYPE records); hand_verts [B,778,3] f32; order int32 [B,4];
-        factor f32 [B,4]; inv_affine f32 [B,6].  Returns dict(keys=..., rgbx=...) of the optional outputs."""
+        factor f32 [B,4]; inv_affine f32 [B,6]; blur: f32 [B] GaussianBlur radii (< 1.41) or None.
+        Returns dict(keys=..., rgbx=...) of the optional outputs (rgbx: the render before blur and jitter)."""
         B = hand_verts.shape[0]
         lib = L.lib()
         need = lib.ab_render_workspace_bytes(L.i(B), L.i(self.W), L.i(self.H), L.i(self.max_faces))
@@ -68,7 +76,7 @@ class DeviceRenderer:
         rgbx = torch.empty((B, self.H, self.W, 4), dtype=torch.uint8, device=self.dev) if want_rgbx else None
         dt = L.dt(out_pad) if out_pad is not None else 0
         L.check(lib.ab_render_batch(ctypes.byref(self.sc), L.ptr(samples_dev), L.ptr(hand_verts), L.ptr(order),
-                                    L.ptr(factor), L.ptr(inv_affine), L.i(B), L.i(self.max_faces), L.i(ow), L.i(oh),
+                                    L.ptr(factor), L.ptr(inv_affine), L.ptr(blur), L.i(B), L.i(self.max_faces), L.i(ow), L.i(oh),
                                     L.i(dt), L.ptr(out_pad), L.ptr(out_chw), L.ptr(self._ws), L.ptr(keys), L.ptr(rgbx),
                                     L.stream()), "ab_render_batch")
         return dict(keys=keys, rgbx=rgbx)

@@ -257,6 +257,7 @@ class ArtiBoostLoader:
         self.image_size = list(cfg_preset["IMAGE_SIZE"])
         self.center_idx = cfg_preset.get("CENTER_IDX", 0)
         self.bbox_expand = float(cfg_preset.get("BBOX_EXPAND_RATIO", 1.2))
+        self.blur_radius = 0.1        # RenderedDataset(aug=True): rendered_dataset.py:67 (hard-coded there; 0 when aug is off)
         self.sample_weight_map = torch.ones((self.n_obj, self.n_persp, self.n_grasp), dtype=torch.float32)
         self.occurence_map = torch.zeros((self.n_obj, self.n_persp, self.n_grasp), dtype=torch.bool)
         wu = cfg.get("WEIGHT_UPDATE", {"LOWER": 0.1, "UPPER": 10.0})
@@ -314,7 +315,8 @@ class ArtiBoostLoader:
                    bx=rng.uniform(0, 1, S_all), by=rng.uniform(0, 1, S_all),
                    order=np.stack([rng.permutation(4) for _ in range(S_all)]),
                    bright=rng.uniform(0.9, 1.1, S_all), contrast=rng.uniform(0.9, 1.1, S_all),
-                   sat=rng.uniform(0.9, 1.1, S_all), hue=rng.uniform(-0.075, 0.075, S_all))
+                   sat=rng.uniform(0.9, 1.1, S_all), hue=rng.uniform(-0.075, 0.075, S_all),
+                   blur=self.blur_radius * rng.uniform(0, 1, S_all))
         plan = {k: val[sl] for k, val in plan.items()}
         plan["aug"] = {k: val[sl] for k, val in aug.items()}
         plan.update(o=o[sl], v=v[sl], g=g[sl], global_index=np.arange(S_all)[sl])
@@ -387,6 +389,7 @@ class ArtiBoostLoader:
         ep["_order"] = torch.from_numpy(order).to(dev)
         ep["_factor"] = torch.from_numpy(factor).to(dev)
         ep["_inv_affine"] = torch.from_numpy(inv).to(dev)
+        ep["_blur"] = torch.from_numpy(a["blur"].astype(np.float32)).to(dev)
         self.epoch, self.epoch_len, self.cursor = ep, S, 0
         self._pack_batches()
 
@@ -452,7 +455,8 @@ class ArtiBoostLoader:
             if chw is None:
                 chw = static[Queries.IMAGE] = torch.empty((self.batch_size, 3, H, W), dtype=torch.float32, device=self.dev)
         self.renderer.render(static["_samples"], static["_hand_verts"], static["_order"], static["_factor"],
-                             static["_inv_affine"], W, H, out_pad=static["image_nhwc4_padded"], out_chw=chw)
+                             static["_inv_affine"], W, H, out_pad=static["image_nhwc4_padded"], out_chw=chw,
+                             blur=static["_blur"])
 
     def __iter__(self):
         """Reference-shaped iteration: yields batch dicts (device tensors, `image` as float CHW like the reference's

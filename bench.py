@@ -144,7 +144,8 @@ def cpu_baseline(args, cfg):
     sc = gen_scene.make_samples(assets, n, 1, out_res=(args.size, args.size))
     holder = ro.SceneHolder(assets)
     t0 = time.time()
-    img, _, _ = holder.render_batch(sc["samples"], sc["hand_verts"], sc["order"], sc["factor"], sc["inv_affine"], args.size, args.size)
+    img, _, _ = holder.render_batch(sc["samples"], sc["hand_verts"], sc["order"], sc["factor"], sc["inv_affine"], args.size, args.size,
+                                    blur=sc["blur"])
     t_render = time.time() - t0
     params = lo.fill_params(lo.param_shapes(22, 28), seed=1)
     leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in params.items()}

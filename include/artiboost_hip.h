@@ -189,8 +189,12 @@ int ab_pose_loss_sym(const float* kp3d, const float* box6d, int box_stride, cons
  * ab_scene: HOST struct of DEVICE pointers to the immutable assets (one packed table for all object meshes).
  * samples : device array of 96-byte records {int32 obj_id, hand_tex_id, bg_id, bg_x0, bg_y0, bg_w, bg_h; float light;
  *           float obj_pose[16] (row-major 4x4)}.  hand_verts: float [B,778,3] camera frame.
+ * The background is the record's crop rectangle resized to the render size with cv2.resize's INTER_LINEAR fixed-point
+ * arithmetic (renderer.py:136); ab_scene.bg holds RGBX texels, uint8 [nbg, bgs, bgs, 4].
  * order/factor: int32/float [B,4] colour-jitter op ids (0 brightness, 1 saturation, 2 hue, 3 contrast) and factors in
  * application order.  inv_affine: float [B,6] output-pixel-centre -> render-pixel map (PIL AFFINE data).
+ * blur_radius: float [B] (device) or NULL: PIL ImageFilter.GaussianBlur radius applied to the composited render before
+ * the jitter (rendered_dataset.py:257-258, radius = U(0,1) * 0.1); each radius must be < 1.41 (box radius < 1 px).
  * out_pad: zero-bordered NHWC4 [B, oh+6, ow+8, 4] in out_dtype (interior written; border must already be zero);
  * out_chw: optional float [B,3,oh,ow] (the reference's `image` tensor).  keys_out (optional) uint64 [B,H,W]:
  * depth24<<32 | face id, ~0 = background.  rgbx_out (optional) uint8 [B,H,W,4] pre-jitter render.                 */
@@ -203,9 +207,12 @@ typedef struct ab_scene {
 } ab_scene;
 long ab_render_workspace_bytes(int B, int W, int H, int max_faces);
 int ab_render_batch(const ab_scene* scene_host, const void* samples, const float* hand_verts, const int32_t* order,
-                    const float* factor, const float* inv_affine, int B, int max_faces, int ow, int oh,
-                    int out_dtype, void* out_pad, float* out_chw, void* workspace, void* keys_out, void* rgbx_out,
-                    void* stream);
+                    const float* factor, const float* inv_affine, const float* blur_radius, int B, int max_faces,
+                    int ow, int oh, int out_dtype, void* out_pad, float* out_chw, void* workspace, void* keys_out,
+                    void* rgbx_out, void* stream);
+/* The GaussianBlur stage of ab_render_batch on its own (PIL ImageFilter.GaussianBlur on the RGB bytes of B RGBX images,
+ * W and H multiples of 32): radius float [B] on the device, each < 1.41; out must not alias rgbx.                  */
+int ab_gaussian_blur(const void* rgbx, int B, int W, int H, const float* radius, void* out, void* stream);
 /* Small-batch fp32 linear layers (the box-rotation MLP, anakin/models/mlp.py:11-25; nn.Linear weights [N][K]):
  *   fwd   y[M][N]  = act(x[M][K] W^T + bias)            (relu != 0: ReLU)
  *   dgrad gx[M][K] = (g[M][N] W) masked by act_out > 0   (act_out NULL: no mask); takes wt = W transposed, [K][N]

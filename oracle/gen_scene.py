@@ -44,5 +44,7 @@ def make_samples(assets, B, seed, out_res=(256, 256), K=None, render=512):
                                    raw_size=[render, render])
         gts.append(gt)
         inv.append(np.linalg.inv(np.vstack([gt["affine"][:2], [0, 0, 1]]).astype(np.float64))[:2].reshape(-1))
+    blur = (0.1 * rng.uniform(0, 1, B)).astype(np.float32)          # rendered_dataset.py:257 (blur_radius 0.1, :67)
+    blur[::3] = np.float32(0.1) - blur[::3] * np.float32(0.2)        # keep radii > 0.077 (where the blur acts) in every batch
     return dict(samples=samples, hand_verts=verts.astype(np.float32), joints=joints, obj_pose=obj_pose, order=order,
-                factor=factor, inv_affine=np.asarray(inv, np.float32), gt=gts, obj_id=obj_id, persp=persp)
+                factor=factor, inv_affine=np.asarray(inv, np.float32), gt=gts, obj_id=obj_id, persp=persp, blur=blur)

@@ -18,9 +18,10 @@
  *   - shading: nearest texel, sRGB->linear by LUT, lin = base * (0.8 + KD * I * max(n.l,0) / d^2) (ambient 0.8 and one
  *     point light at the camera as in renderer.py:72-84,103-104; rest-pose ("stale") hand normals as in
  *     anakin/utils/frender_utils.py:36-46,139), linear->sRGB by 4096-entry LUT
- *   - background where no geometry (renderer.py:117-119,125-136), nearest-neighbour crop resize
- * The colour jitter + crop stage restates PIL (anakin/utils/img_augment.py:6-80, rendered_dataset.py:256-270) and IS
- * pinned against the real Pillow in tests/test_render_oracle.py.
+ *   - background where no geometry (renderer.py:117-119,125-136): the random crop resized with cv2's INTER_LINEAR
+ *     fixed-point arithmetic (restated at bg_pixel; cv2 is absent, so unpinned as well)
+ * The GaussianBlur + colour jitter + crop stage restates PIL (anakin/utils/img_augment.py:6-80,
+ * rendered_dataset.py:256-270) and IS pinned against the real Pillow in tests/test_render_oracle.py.
  */
 #include <math.h>
 #include <stdint.h>
@@ -176,11 +177,35 @@ void ro_rasterize(const ro_scene* sc, const ro_sample* sm, const float* hv, uint
     }
 }
 
+/* Background = cv2.resize(crop, (W, H)) with the default INTER_LINEAR (renderer.py:125-136).  PARITY UNPINNED: cv2
+ * (opencv-python-headless==4.5.1.48, requirements.txt:84) is not in this image.  Restated from the published algorithm
+ * of that version's 8-bit path (modules/imgproc/src/resize.cpp: resizeGeneric_ with HResizeLinear / VResizeLinear,
+ * INTER_RESIZE_COEF_BITS = 11): source coordinate f = (float)((d + 0.5) * scale - 0.5) with scale = 1 / ((double)dsize /
+ * ssize), s = floor(f), f -= s; s < 0 -> (0, f = 0); s >= ssize - 1 -> (ssize - 1, f = 0); coefficients
+ * cvRound((1 - f) * 2048), cvRound(f * 2048) (round half to even); rows: S = p[s] * a0 + p[s + 1] * a1; columns:
+ * (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.                                                     */
+static inline void lin_coef(int d, int dsize, int ssize, int* s0, int* s1, int* a0, int* a1) {
+    const double scale = 1.0 / ((double)dsize / (double)ssize);
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    *s0 = s; *s1 = s + 1 < ssize ? s + 1 : ssize - 1;
+    *a0 = (int)lrintf((1.f - f) * 2048.f); *a1 = (int)lrintf(f * 2048.f);
+}
 static inline void bg_pixel(const ro_scene* sc, const ro_sample* sm, int x, int y, uint8_t* rgb) {
-    int sx = sm->bg_x0 + (int)(((int64_t)(2 * x + 1) * sm->bg_w) / (2 * sc->W));
-    int sy = sm->bg_y0 + (int)(((int64_t)(2 * y + 1) * sm->bg_h) / (2 * sc->H));
-    const uint8_t* p = sc->bg + (((size_t)sm->bg_id * sc->bgs + sy) * sc->bgs + sx) * 3;
-    rgb[0] = p[0]; rgb[1] = p[1]; rgb[2] = p[2];
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    lin_coef(x, sc->W, sm->bg_w, &x0, &x1, &a0, &a1);
+    lin_coef(y, sc->H, sm->bg_h, &y0, &y1, &b0, &b1);
+    const uint8_t* img = sc->bg + (size_t)sm->bg_id * sc->bgs * sc->bgs * 3;
+    const uint8_t* r0 = img + ((size_t)(sm->bg_y0 + y0) * sc->bgs + sm->bg_x0) * 3;
+    const uint8_t* r1 = img + ((size_t)(sm->bg_y0 + y1) * sc->bgs + sm->bg_x0) * 3;
+    for (int c = 0; c < 3; ++c) {
+        int S0 = r0[x0 * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+        int S1 = r1[x0 * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+        rgb[c] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+    }
 }
 
 /* rgbx: uint8 [H*W*4]; X = 255 where geometry, 0 where background */
@@ -325,6 +350,54 @@ void ro_color_jitter(uint8_t* rgbx, int npix, const int32_t* order, const float*
     }
 }
 
+/* PIL ImageFilter.GaussianBlur(radius) on the RGB bands of an RGBX image, in place (rendered_dataset.py:257-258).
+ * Restates libImaging/BoxBlur.c: ImagingGaussianBlur = 3 passes of a box blur of fractional radius
+ * _gaussian_blur_radius(radius, 3) along x, then 3 along y; one pass (ImagingLineBoxBlur8/32) is
+ *   out[x] = (acc * ww + (in[x - r - 1] + in[x + r + 1]) * fw + 2^23) >> 24,   acc = sum in[x - r .. x + r],
+ * indices clamped to the line, r = (int)radius, ww = (UINT32)(2^24 / (radius * 2 + 1)) (float division),
+ * fw = (2^24 - (2r + 1) * ww) / 2.  Pinned against the real Pillow in tests/test_render_oracle.py.                   */
+float ro_gaussian_box_radius(float radius) {
+    const int passes = 3;
+    float sigma2 = radius * radius / passes;
+    float L = (float)sqrt(12.0 * sigma2 + 1.0);
+    float l = (float)floor((L - 1.0) / 2.0);
+    float a = (2 * l + 1) * (l * (l + 1) - 3 * sigma2);
+    a /= 6 * (sigma2 - (l + 1) * (l + 1));
+    return l + a;
+}
+static void box_line(const uint8_t* in, int n, int stride, int r, uint32_t ww, uint32_t fw, uint8_t* out) {
+    for (int x = 0; x < n; ++x) {
+        uint32_t acc = 0;
+        for (int k = x - r; k <= x + r; ++k) { int kk = k < 0 ? 0 : k > n - 1 ? n - 1 : k; acc += in[(size_t)kk * stride]; }
+        int lo = x - r - 1 < 0 ? 0 : x - r - 1, hi = x + r + 1 > n - 1 ? n - 1 : x + r + 1;
+        uint32_t bulk = acc * ww + ((uint32_t)in[(size_t)lo * stride] + in[(size_t)hi * stride]) * fw;
+        out[x] = (uint8_t)((bulk + (1u << 23)) >> 24);
+    }
+}
+void ro_gaussian_blur(uint8_t* rgbx, int W, int H, float radius) {
+    const float fr = ro_gaussian_box_radius(radius);
+    if (!(fr > 0.f)) return;                           /* ImagingBoxBlur skips a zero radius */
+    const int r = (int)fr;
+    const uint32_t ww = (uint32_t)((float)(1 << 24) / (fr * 2 + 1));
+    const uint32_t fw = ((1u << 24) - (uint32_t)(r * 2 + 1) * ww) / 2;
+    uint8_t* line = (uint8_t*)malloc((size_t)(W > H ? W : H));
+    for (int pass = 0; pass < 3; ++pass)
+        for (int y = 0; y < H; ++y)
+            for (int c = 0; c < 3; ++c) {
+                uint8_t* p = rgbx + (size_t)y * W * 4 + c;
+                box_line(p, W, 4, r, ww, fw, line);
+                for (int x = 0; x < W; ++x) p[(size_t)x * 4] = line[x];
+            }
+    for (int pass = 0; pass < 3; ++pass)
+        for (int x = 0; x < W; ++x)
+            for (int c = 0; c < 3; ++c) {
+                uint8_t* p = rgbx + (size_t)x * 4 + c;
+                box_line(p, H, W * 4, r, ww, fw, line);
+                for (int y = 0; y < H; ++y) p[(size_t)y * W * 4] = line[y];
+            }
+    free(line);
+}
+
 /* Nearest-neighbour affine crop (PIL Image.transform(AFFINE, NEAREST), img_augment.transform_img): inv = 2x3 matrix
  * mapping output pixel centres to source coordinates; out float [3][oh][ow] = px/255 - 0.5, 0 outside the source. */
 void ro_affine_crop(const uint8_t* rgbx, int W, int H, const float* inv, int ow, int oh, float* out_chw) {
@@ -343,8 +416,8 @@ void ro_affine_crop(const uint8_t* rgbx, int W, int H, const float* inv, int ow,
 
 /* Whole synthesis of one batch (used as the CPU baseline): OpenMP over samples when compiled with -fopenmp. */
 void ro_render_batch(const ro_scene* sc, const ro_sample* sm, const float* hand_verts, int B, const int32_t* order,
-                     const float* factor, const float* inv_affine, int ow, int oh, float* out_bchw,
-                     uint8_t* scratch_rgbx, uint64_t* scratch_keys) {
+                     const float* factor, const float* inv_affine, const float* blur_radius, int ow, int oh,
+                     float* out_bchw, uint8_t* scratch_rgbx, uint64_t* scratch_keys) {
 #pragma omp parallel for schedule(dynamic)
     for (int b = 0; b < B; ++b) {
         uint64_t* keys = scratch_keys + (size_t)b * sc->W * sc->H;
@@ -352,6 +425,7 @@ void ro_render_batch(const ro_scene* sc, const ro_sample* sm, const float* hand_
         const float* hv = hand_verts + (size_t)b * HAND_VERTS * 3;
         ro_rasterize(sc, sm + b, hv, keys);
         ro_shade(sc, sm + b, hv, keys, img);
+        if (blur_radius) ro_gaussian_blur(img, sc->W, sc->H, blur_radius[b]);
         ro_color_jitter(img, sc->W * sc->H, order + b * 4, factor + b * 4);
         ro_affine_crop(img, sc->W, sc->H, inv_affine + b * 6, ow, oh, out_bchw + (size_t)b * 3 * ow * oh);
     }

@@ -80,7 +80,7 @@ class SceneHolder:
                        np.ascontiguousarray(keys).ctypes.data_as(ctypes.c_void_p), img.ctypes.data_as(ctypes.c_void_p))
         return img
 
-    def render_batch(self, samples, hand_verts, order, factor, inv_affine, ow, oh):
+    def render_batch(self, samples, hand_verts, order, factor, inv_affine, ow, oh, blur=None):
         B = len(samples)
         out = np.empty((B, 3, oh, ow), np.float32)
         rgbx = np.empty((B, self.H, self.W, 4), np.uint8)
@@ -90,8 +90,9 @@ class SceneHolder:
         factor = np.ascontiguousarray(factor, np.float32)
         inv = np.ascontiguousarray(inv_affine, np.float32)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+        blur = None if blur is None else np.ascontiguousarray(blur, np.float32)
         lib().ro_render_batch(ctypes.byref(self.sc), p(samples), p(hv), ctypes.c_int(B), p(order), p(factor), p(inv),
-                              ctypes.c_int(ow), ctypes.c_int(oh), p(out), p(rgbx), p(keys))
+                              None if blur is None else p(blur), ctypes.c_int(ow), ctypes.c_int(oh), p(out), p(rgbx), p(keys))
         return out, rgbx, keys
 
 
@@ -112,3 +113,11 @@ def affine_crop(rgbx, inv, ow, oh):
                          inv.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(ow), ctypes.c_int(oh),
                          out.ctypes.data_as(ctypes.c_void_p))
     return out
+
+
+def gaussian_blur(rgbx, radius):
+    """PIL ImageFilter.GaussianBlur(radius) on the RGB bytes of an RGBX image (H, W, 4)."""
+    img = np.ascontiguousarray(rgbx, np.uint8).copy()
+    lib().ro_gaussian_blur(img.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(img.shape[1]), ctypes.c_int(img.shape[0]),
+                           ctypes.c_float(radius))
+    return img

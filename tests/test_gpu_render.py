@@ -10,7 +10,7 @@ import render_oracle as ro
 pytestmark = pytest.mark.gpu
 
 
-def _run(dataset, B, seed, res):
+def _run(dataset, B, seed, res, blur=True):
     from artiboost_amd.assets import SceneAssets
     from artiboost_amd.render import DeviceRenderer
     assets = SceneAssets(dataset)
@@ -18,7 +18,7 @@ def _run(dataset, B, seed, res):
     sc = gen_scene.make_samples(assets, B, seed, out_res=(res, res))
     holder = ro.SceneHolder(assets)
     out_ref, rgbx_ref, keys_ref = holder.render_batch(sc["samples"], sc["hand_verts"], sc["order"], sc["factor"],
-                                                      sc["inv_affine"], res, res)
+                                                      sc["inv_affine"], res, res, blur=sc["blur"] if blur else None)
     # un-jittered render for the bit-exact shading check
     rgbx_plain = np.stack([holder.shade(sc["samples"][b:b + 1], sc["hand_verts"][b], keys_ref[b]) for b in range(B)])
     r = DeviceRenderer(assets, K)
@@ -28,14 +28,16 @@ def _run(dataset, B, seed, res):
     out_chw = torch.empty((B, 3, res, res), dtype=torch.float32, device=dev)
     o = r.render(smp, torch.from_numpy(sc["hand_verts"]).to(dev), torch.from_numpy(sc["order"]).to(dev),
                  torch.from_numpy(sc["factor"]).to(dev), torch.from_numpy(sc["inv_affine"]).to(dev), res, res,
-                 out_pad=out_pad, out_chw=out_chw, want_keys=True, want_rgbx=True)
+                 out_pad=out_pad, out_chw=out_chw, want_keys=True, want_rgbx=True,
+                 blur=torch.from_numpy(sc["blur"]).to(dev) if blur else None)
     return sc, (out_ref, rgbx_plain, keys_ref), (out_chw.cpu().numpy(), out_pad.cpu().numpy(), o["rgbx"].cpu().numpy(),
                                                 o["keys"].cpu().numpy().view(np.uint64))
 
 
-@pytest.mark.parametrize("dataset,B,seed,res", [("HO3D", 3, 0, 224), ("DexYCB", 2, 1, 256), ("HO3D", 8, 2, 256)])
-def test_render_bit_exact_vs_oracle(dataset, B, seed, res):
-    sc, (out_ref, rgbx_ref, keys_ref), (out, out_pad, rgbx, keys) = _run(dataset, B, seed, res)
+@pytest.mark.parametrize("dataset,B,seed,res,blur", [("HO3D", 3, 0, 224, True), ("DexYCB", 2, 1, 256, True),
+                                                     ("HO3D", 8, 2, 256, True), ("HO3D", 3, 3, 256, False)])
+def test_render_bit_exact_vs_oracle(dataset, B, seed, res, blur):
+    sc, (out_ref, rgbx_ref, keys_ref), (out, out_pad, rgbx, keys) = _run(dataset, B, seed, res, blur)
     covered = keys_ref != np.uint64(0xFFFFFFFFFFFFFFFF)
     assert covered.mean() > 0.01, "scene should contain geometry"
     np.testing.assert_array_equal(keys, keys_ref)                      # depth24<<32 | face id, every pixel
@@ -57,6 +59,27 @@ def test_render_properties():
     Z = 1.0 / (20.0 + z * (0.01 - 20.0))
     assert Z.min() > 0.25 and Z.max() < 0.9
     assert np.isfinite(out).all() and out.min() >= -0.5 and out.max() <= 0.5
+
+
+def test_gaussian_blur_vs_oracle():
+    """ab_gaussian_blur == the CPU oracle (itself pinned against Pillow's ImageFilter.GaussianBlur) on noise images with
+    flat and striped regions (worst case for the rounding), for radii over the reference's range and beyond, including
+    the radii where every pass is the identity."""
+    from artiboost_amd import _lib as L
+    rng = np.random.default_rng(0)
+    radii = np.array([0.0, 1e-4, 0.05, 0.0765, 0.0767, 0.08, 0.0999, 0.1, 0.3, 0.7, 1.2, 1.4], np.float32)
+    B, H, W = len(radii), 96, 160
+    img = rng.integers(0, 256, (B, H, W, 4), dtype=np.uint8)
+    img[:, :8] = 0; img[:, 8:16:2] = 255; img[:, :, :4, :3] = 255; img[:, -3:] = 7
+    ref = np.stack([ro.gaussian_blur(img[b], float(radii[b])) for b in range(B)])
+    src = torch.from_numpy(img).cuda()
+    out = torch.empty_like(src)
+    rc = L.lib().ab_gaussian_blur(L.ptr(src), L.i(B), L.i(W), L.i(H), L.ptr(torch.from_numpy(radii).cuda()), L.ptr(out), L.stream())
+    assert rc == 0
+    got = out.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(got[b], ref[b], err_msg=f"radius {radii[b]}")
+    assert (ref[2] == img[2]).all() and (ref[7] != img[7]).any()      # 0.05: identity; 0.1: acts
 
 
 def test_color_jitter_all_rgb_values_vs_oracle():

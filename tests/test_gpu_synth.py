@@ -72,7 +72,8 @@ def test_loader_batches_match_oracle_render():
         s0 = bi * 4
         smp = ep["_samples"][s0:s0 + 4].cpu().numpy().view(ro.SAMPLE_DTYPE).reshape(-1)
         ref, _, keys = holder.render_batch(smp, ep["_hand_verts"][s0:s0 + 4].cpu().numpy(), ep["_order"][s0:s0 + 4].cpu().numpy(),
-                                           ep["_factor"][s0:s0 + 4].cpu().numpy(), ep["_inv_affine"][s0:s0 + 4].cpu().numpy(), 224, 224)
+                                           ep["_factor"][s0:s0 + 4].cpu().numpy(), ep["_inv_affine"][s0:s0 + 4].cpu().numpy(), 224, 224,
+                                           blur=ep["_blur"][s0:s0 + 4].cpu().numpy())
         np.testing.assert_array_equal(batch["image"].cpu().numpy(), ref)
         pad = batch["image_nhwc4_padded"].cpu().numpy()
         np.testing.assert_array_equal(pad[:, 3:-3, 3:-5, :3].transpose(0, 3, 1, 2), ref)

@@ -2,7 +2,7 @@
 reference calls: anakin/utils/img_augment.py:6-80, rendered_dataset.py:256-270)."""
 import numpy as np
 import pytest
-from PIL import Image, ImageEnhance
+from PIL import Image, ImageEnhance, ImageFilter
 
 import render_oracle as ro
 
@@ -77,3 +77,47 @@ def test_full_chain_and_crop_match_reference_flow(seed):
     got = ro.affine_crop(jit, inv[:2].reshape(-1), res[0], res[1])
     mism = np.abs(got - ref) > 1e-6
     assert mism.mean() < 2e-3, mism.mean()        # nearest-neighbour ties at exact .0 source coordinates only
+
+
+@pytest.mark.parametrize("radius", [0.0, 1e-4, 0.01, 0.05, 0.0765, 0.0767, 0.09, 0.1, 0.3, 0.9, 1.2, 1.4, 2.0, 3.7])
+def test_gaussian_blur_matches_pillow(radius):
+    """rendered_dataset.py:257-258: img.filter(ImageFilter.GaussianBlur(radius)), radius = U(0,1) * 0.1; the restatement
+    (three fractional box-blur passes per axis, libImaging/BoxBlur.c) is bit-exact also for larger radii."""
+    rng = np.random.default_rng(int(radius * 1e4))
+    a = rng.integers(0, 256, (70, 90, 3), dtype=np.uint8)
+    a[:8] = 0
+    a[8:16:2] = 255
+    a[:, :3] = 255
+    ref = np.asarray(Image.fromarray(a).filter(ImageFilter.GaussianBlur(radius)))
+    rgbx = np.concatenate([a, np.full(a.shape[:2] + (1,), 9, np.uint8)], 2)
+    got = ro.gaussian_blur(rgbx, radius)
+    assert (got[:, :, 3] == 9).all()
+    assert np.abs(got[:, :, :3].astype(int) - ref.astype(int)).max() == 0
+    if radius <= 0.0765:
+        assert (ref == a).all()          # below ~0.0766 every pass is the identity (used by the HIP path to skip samples)
+
+
+def test_background_resize_is_bilinear_within_one_lsb():
+    """renderer.py:125-136: the background is a random crop resized with cv2.resize (INTER_LINEAR).  cv2 is absent, so the
+    fixed-point restatement in the oracle is unpinned; this checks it against a float half-pixel-centre bilinear
+    interpolation (<= 1 LSB) and that an unscaled crop is copied bit for bit."""
+    from artiboost_amd.assets import SceneAssets
+    assets = SceneAssets("HO3D", seed=1)
+    holder = ro.SceneHolder(assets)
+    keys = np.full((512, 512), 0xFFFFFFFFFFFFFFFF, np.uint64)          # no geometry anywhere
+    hv = np.zeros((778, 3), np.float32)
+    for crop, x0, y0 in [(512, 100, 256), (768, 0, 0), (600, 168, 3), (513, 255, 255), (701, 11, 67)]:
+        smp = np.zeros(1, ro.SAMPLE_DTYPE)
+        smp["bg_id"], smp["bg_w"], smp["bg_h"], smp["bg_x0"], smp["bg_y0"], smp["light"] = 2, crop, crop, x0, y0, 1.0
+        smp["obj_pose"][0, [0, 5, 10, 15]] = 1.0
+        got = holder.shade(smp, hv, keys)[:, :, :3].astype(np.float64)
+        src = assets.backgrounds[2, y0:y0 + crop, x0:x0 + crop].astype(np.float64)
+        if crop == 512:
+            assert (got == src).all()
+            continue
+        f = (np.arange(512) + 0.5) * (crop / 512.0) - 0.5
+        s = np.clip(np.floor(f).astype(int), 0, crop - 2)
+        w = np.clip(f - s, 0.0, 1.0)
+        rows = src[s] * (1 - w)[:, None, None] + src[s + 1] * w[:, None, None]
+        ref = rows[:, s] * (1 - w)[None, :, None] + rows[:, s + 1] * w[None, :, None]
+        assert np.abs(got - ref).max() <= 1.0, (crop, np.abs(got - ref).max())
