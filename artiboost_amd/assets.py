@@ -225,3 +225,28 @@ class SceneAssets:
         self.obj_faces = np.concatenate([o["faces"] for o in self.objects])     # indices local to the object
         self.max_obj_faces = max(len(o["faces"]) for o in self.objects)
         self.max_obj_verts = max(len(o["verts"]) for o in self.objects)
+
+
+def _subdivide(verts, faces):
+    """One midpoint subdivision (each triangle -> 4, one new vertex per unique edge), as trimesh's Trimesh.subdivide()."""
+    e = np.sort(np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]), axis=1)
+    uniq, inv = np.unique(e, axis=0, return_inverse=True)
+    mid = 0.5 * (verts[uniq[:, 0]] + verts[uniq[:, 1]])
+    nf = len(faces)
+    m01, m12, m20 = (len(verts) + inv.reshape(-1)[k * nf:(k + 1) * nf] for k in range(3))
+    f = np.concatenate([np.stack([faces[:, 0], m01, m20], 1), np.stack([m01, faces[:, 1], m12], 1),
+                        np.stack([m20, m12, faces[:, 2]], 1), np.stack([m01, m12, m20], 1)])
+    return np.concatenate([verts, mid]), f
+
+
+def resample_objects(assets, n_points=10000, seed=7):
+    """HORefiner.resample_obj (anakin/artiboost/refiner.py:169-179) for every object: subdivide until the mesh has at
+    least n_points vertices, then keep n_points of them drawn without replacement.  -> float32 [n_obj, n_points, 3]."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for o in assets.objects:
+        v, f = np.asarray(o["verts"], np.float64), np.asarray(o["faces"], np.int64)
+        while len(v) < n_points:
+            v, f = _subdivide(v, f)
+        out.append(v[rng.choice(len(v), n_points, replace=False)])
+    return np.stack(out).astype(np.float32)

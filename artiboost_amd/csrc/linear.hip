@@ -10,10 +10,12 @@
 // C[i][j] = epilogue( sum_r A[i][r] * B[j][r] ), both operands reduction-contiguous.  One wave per 4 x 4 micro-tile: the
 // lanes split the reduction (float4 slices, fully coalesced 1-KiB row loads, all 16+ loads of a lane independent), sixteen
 // wave reductions finish it.  Block = 4 waves = 4 rows x 16 columns; grid (ceil(J/16), ceil(I/4)).  Epilogue: + bias[j],
-// ReLU, or zero where mask[i][j] <= 0.
+// per-column affine (an eval-mode BatchNorm1d), + residual[i][j], ReLU / leaky ReLU, or zero where mask[i][j] <= 0.
+struct LinEpi { const float* scale; const float* shift; const float* residual; int ldr; float slope; int ldc; };
 __global__ __launch_bounds__(256) void linear_nt_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                         const float* __restrict__ bias, const float* __restrict__ mask,
-                                                        int I, int J, int R, int relu, float* __restrict__ C) {
+                                                        int I, int J, int R, int relu, float* __restrict__ C,
+                                                        LinEpi ep = LinEpi{nullptr, nullptr, nullptr, 0, 0.f, 0}) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = blockIdx.y * 4, j0 = (blockIdx.x * 4 + wave) * 4;
     if (j0 >= J) return;
@@ -46,9 +48,12 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(const float* __restrict_
                 const int i = i0 + a, j = j0 + b;
                 if (i >= I || j >= J) continue;
                 float v = acc[a][b] + (bias ? bias[j] : 0.f);
-                if (relu) v = fmaxf(v, 0.f);
+                if (ep.scale) v = v * ep.scale[j] + ep.shift[j];
+                if (ep.residual) v += ep.residual[(long)i * ep.ldr + j];
+                if (relu == 1) v = fmaxf(v, 0.f);
+                else if (relu == 2) v = v > 0.f ? v : v * ep.slope;
                 if (mask && !(mask[(long)i * J + j] > 0.f)) v = 0.f;
-                C[(long)i * J + j] = v;
+                C[(long)i * (ep.ldc ? ep.ldc : J) + j] = v;
             }
     }
 }
@@ -99,5 +104,19 @@ extern "C" int ab_linear_wgrad(const float* g, const float* x, int M, int N, int
     if (!g || !x || !dw || M < 1 || N < 1 || K < 4) return AB_EINVAL;
     if (K % 4) return AB_ESHAPE;
     linear_wgrad_kernel<<<dim3((K + 255) / 256, N), 64, 0, as_stream(stream)>>>(g, x, M, N, K, dw, db);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+// y[m][n] = act(((x W^T + bias) * scale[n] + shift[n]) + residual[m][n]); act 0 none, 1 ReLU, 2 leaky ReLU(slope).
+// scale/shift (both or neither) and residual (row pitch ldr) may be NULL; ldy = row pitch of y (>= N), so a layer can
+// write a column block of a wider feature matrix.  The MLP of the grasp refiner (anakin/artiboost/refiner.py:227-319).
+extern "C" int ab_linear_fused(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                               const float* residual, int ldr, int M, int N, int K, int act, float slope, float* y, int ldy,
+                               void* stream) {
+    if (!x || !w || !y || M < 1 || N < 1 || K < 4 || ldy < N || act < 0 || act > 2) return AB_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr) || (residual && ldr < N)) return AB_EINVAL;
+    if (K % 4) return AB_ESHAPE;
+    LinEpi ep{scale, shift, residual, ldr, slope, ldy};
+    linear_nt_kernel<<<dim3((N + 15) / 16, (M + 3) / 4), 256, 0, as_stream(stream)>>>(x, w, bias, nullptr, M, N, K, act, y, ep);
     AB_LAUNCH_CHECK(); return 0;
 }

@@ -11,7 +11,8 @@ What changed structurally (MI355X-first):
     tensors; every training step renders its own batch on the training GPU's stream (render.DeviceRenderer);
   * CCV sampling, view / grasp lookup, GT geometry (bbox crop, jitter, affine, visibility) stay on the host exactly as
     in the reference (float64 numpy, integer truncations included) but vectorised over the epoch;
-  * the GrabNet refiner (refiner.py) is not part of this path (weights are a download).
+  * the GrabNet refiner (refiner.py) runs inside the pose generator when the manager config has a
+    REFINER block of TYPE "hand_obj" (artiboost_amd/refiner.py); its checkpoint is a download.
 """
 import math
 import random
@@ -95,11 +96,11 @@ class PoseGenerator:
     """PreProcessorPoseGenerator.forward (preprocessor.py:20-99) with the RandomScrambler (scrambler.py:65-81);
     batched device tensors in, (obj_pose [B,4,4], hand_verts [B,778,3], joints [B,21,3]) out."""
 
-    def __init__(self, mano: ManoLayerHIP, tsl_sigma=0.01, pose_sigma=0.1):
-        self.mano, self.tsl_sigma, self.pose_sigma = mano, tsl_sigma, pose_sigma
+    def __init__(self, mano: ManoLayerHIP, tsl_sigma=0.01, pose_sigma=0.1, refiner=None):
+        self.mano, self.tsl_sigma, self.pose_sigma, self.refiner = mano, tsl_sigma, pose_sigma, refiner
 
     def __call__(self, hand_pose, hand_shape, hand_tsl, persp_rotmat, camera_free_transf, z_offset, rand_pose_angle=None,
-                 rand_tsl=None):
+                 rand_tsl=None, obj_idx=None):
         B = hand_pose.shape[0]
         verts, joints, T = self.mano(hand_pose, hand_shape)
         joints = joints + hand_tsl[:, None]
@@ -123,8 +124,12 @@ class PoseGenerator:
             new_pose = (axis * (nrm[..., 0] + rand_pose_angle)[..., None]).reshape(B, 48)
         if rand_tsl is not None:
             new_tsl = new_tsl + rand_tsl
-        v2, j2, _ = self.mano(new_pose, hand_shape)
-        off = (new_tsl + cam_sys_offset)[:, None]
+        if self.refiner is not None:        # preprocessor.py:73-80: the refiner decodes (and refines) the scrambled grasp
+            res = self.refiner({"hand_pose": new_pose, "hand_tsl": new_tsl, "obj_rot": obj_pose[:, :3, :3]}, obj_idx)
+            v2, j2, off = res["hand_verts"], res["joints"], cam_sys_offset[:, None]
+        else:
+            v2, j2, _ = self.mano(new_pose, hand_shape)
+            off = (new_tsl + cam_sys_offset)[:, None]
         Rf = camera_free_transf[:, :3, :3]
         final_verts = torch.bmm(v2 + off, Rf.transpose(1, 2))
         final_joints = torch.bmm(j2 + off, Rf.transpose(1, 2))
@@ -277,7 +282,14 @@ class ArtiBoostLoader:
             self.renderer = DeviceRenderer(assets, self.K, self.render_size[0], self.render_size[1], device)
         else:       # host-only instance (epoch planning / CCV bookkeeping); prepare() needs the GPU
             self.mano = self.renderer = None
-        self.pose_generator = PoseGenerator(self.mano, sc["HAND_TSL_SIGMA"], sc["HAND_POSE_SIGMA"])
+        self.refiner = None
+        rcfg = cfg.get("REFINER")
+        if rcfg and rcfg.get("TYPE", "null") != "null" and self.mano is not None:      # preprocessor.py:73-80, refiner.py:151-224
+            from .assets import resample_objects
+            from .refiner import Refiner
+            self.refiner = Refiner.build(rcfg["TYPE"], rcfg, self.mano, device)
+            self.refiner.setup(resample_objects(assets, int(rcfg.get("N_SAMPLE_VERTS", 10000)), seed=random_seed + 6))
+        self.pose_generator = PoseGenerator(self.mano, sc["HAND_TSL_SIGMA"], sc["HAND_POSE_SIGMA"], refiner=self.refiner)
         self.epoch = None
         self.cursor = 0
 
@@ -350,7 +362,8 @@ class ArtiBoostLoader:
         for s0 in range(0, S, 256):
             s1 = min(S, s0 + 256)
             op, hv, jt = self.pose_generator(t(gp[o[s0:s1], g[s0:s1]]), t(gs[o[s0:s1], g[s0:s1]]), t(gt_[o[s0:s1], g[s0:s1]]),
-                                             t(Rp[s0:s1]), t(Tf[s0:s1]), t(z3[s0:s1]), t(pick(d_pose)[s0:s1]), t(pick(d_tsl)[s0:s1]))
+                                             t(Rp[s0:s1]), t(Tf[s0:s1]), t(z3[s0:s1]), t(pick(d_pose)[s0:s1]), t(pick(d_tsl)[s0:s1]),
+                                             obj_idx=torch.from_numpy(np.ascontiguousarray(o[s0:s1], np.int64)).to(dev))
             obj_pose.append(op); verts.append(hv); joints.append(jt)
         obj_pose_d, verts_d, joints_d = torch.cat(obj_pose), torch.cat(verts), torch.cat(joints)
         obj_pose_h, joints_h = obj_pose_d.cpu().numpy().astype(np.float64), joints_d.cpu().numpy().astype(np.float64)

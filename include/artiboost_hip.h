@@ -220,6 +220,22 @@ int ab_gaussian_blur(const void* rgbx, int B, int W, int H, const float* radius,
 int ab_linear_fwd(const float* x, const float* w, const float* bias, int M, int N, int K, int relu, float* y, void* stream);
 int ab_linear_dgrad(const float* g, const float* wt, const float* act_out, int M, int N, int K, float* gx, void* stream);
 int ab_linear_wgrad(const float* g, const float* x, int M, int N, int K, float* dw, float* db, void* stream);
+
+/* ---- grasp refiner (anakin/artiboost/refiner.py) ------------------------------------------------
+ * ab_nearest_dist replaces point2point_signed(hand_verts, verts_object) (refiner.py:21-83; nearest neighbour from the
+ * third-party chamfer_distance CUDA extension) together with the rotated-object temporary of refiner.py:196-199:
+ *   dist[b][i] = min_j || x[b][i] - rot[b] * y[j] ||   (+ per-vertex affine dist * scale[i] + shift[i], the eval-mode
+ *   BatchNorm1d(778) of refiner.py:267, when scale != NULL), idx_out[b][i] = arg min (first minimum; optional).
+ * x [B,P1,3]; ypts [nobj,P2,3] selected by obj_idx [B] (int64), or [B,P2,3] when obj_idx == NULL; rot [B,3,3] or NULL;
+ * dist has row pitch ld >= P1.
+ * ab_linear_fused: one layer of the RefineNet MLP (refiner.py:227-319, ResBlock :286-319), fp32:
+ *   y[m][n] = act(((x W^T + bias) * scale[n] + shift[n]) + residual[m][n]), act 0 none / 1 ReLU / 2 leaky(slope);
+ *   W [N][K], K % 4 == 0 (pad the features), scale/shift/residual/bias may be NULL, ldr / ldy = row pitches.        */
+int ab_nearest_dist(const float* x, const float* ypts, const int64_t* obj_idx, const float* rot, int B, int P1, int P2,
+                    const float* scale, const float* shift, float* dist, int ld, int32_t* idx_out, void* stream);
+int ab_linear_fused(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                    const float* residual, int ldr, int M, int N, int K, int act, float slope, float* y, int ldy,
+                    void* stream);
 /* The colour-jitter chain of ab_render_batch on its own (anakin/utils/img_augment.py:6-80 on a PIL image): B RGBX images of
  * npix pixels, order int32 [B][4] (0 brightness, 1 saturation, 2 hue, 3 contrast), factor float [B][4]; out (RGBX, X =
  * 255) may alias rgbx; lsum_ws: B x 8 bytes of device scratch.                                                        */

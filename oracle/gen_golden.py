@@ -181,9 +181,53 @@ def gen_misc(seed=5):
     print("wrote misc")
 
 
+def gen_refiner(B=3, seed=4, n_iters=3):
+    """HORefiner.forward of the real reference (refiner.py:181-224) on seeded grasps, weights from
+    refiner_oracle.fill_params, third-party stand-ins as documented in ref_import.load_refiner."""
+    import refiner_oracle as rfo
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from artiboost_amd.assets import SceneAssets, resample_objects
+    assets = SceneAssets("HO3D", seed=1)
+    R = ref_import.load_refiner(assets.hand)
+    net = R._RefineNet(n_iters=n_iters)
+    params = rfo.fill_params(seed)
+    sd = net.state_dict()
+    for k in sd:
+        sd[k] = params[k].clone()
+    net.load_state_dict(sd)
+    net.eval()
+    ref = R.HORefiner.__new__(R.HORefiner)               # __init__ would torch.load the GrabNet checkpoint (a download)
+    torch.nn.Module.__init__(ref)
+    ref.refine_net = net
+    pts = resample_objects(assets, 10000, seed=7)
+    ref.obj_idx = {f"obj{i}": i for i in range(assets.n_obj)}
+    ref.register_buffer("resampled_objs_buffer", torch.from_numpy(pts))
+    pose, tsl, rot, oi = rfo.make_inputs(assets, B, seed)
+    out = {"in.hand_pose": pose, "in.hand_tsl": tsl, "in.obj_rot": rot, "in.obj_idx": oi}
+    with torch.no_grad():
+        res = ref({"hand_pose": torch.from_numpy(pose), "hand_tsl": torch.from_numpy(tsl), "obj_rot": torch.from_numpy(rot)},
+                  [f"obj{i}" for i in oi])
+        # pieces: one ResBlock, CRot2rotmat, the first-iteration distances
+        x = torch.from_numpy(np.random.default_rng(seed).standard_normal((B, rfo.IN_SIZE)).astype(np.float32))
+        out["rb1.in"], out["rb1.out"] = x.numpy(), net.rb1(x).numpy().copy()
+        c6 = torch.from_numpy(np.random.default_rng(seed + 1).standard_normal((B * 16, 6)).astype(np.float32))
+        out["crot.in"], out["crot.out"] = c6.numpy(), R.CRot2rotmat(c6).numpy().copy()
+        verts = net.mano_layer(torch.from_numpy(pose)).verts + torch.from_numpy(tsl)[:, None]
+        vo = torch.transpose(torch.bmm(torch.from_numpy(rot), torch.transpose(torch.from_numpy(pts[oi]), -2, -1)), -2, -1)
+        out["h2o.first"] = R.point2point_signed(verts, vo).numpy().copy()
+    for k, v in res.items():
+        out["out." + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "refiner.npz"), **out)
+    print("wrote refiner", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if "--refiner" in sys.argv:
+        gen_refiner()
+        sys.exit(0)
     gen_head_only()
     gen_misc()
     gen_learner("g224", 224, 28, 28, B=2, seed=1)
     gen_learner("g256", 256, 32, 28, B=2, seed=2)
+    gen_refiner()

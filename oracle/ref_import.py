@@ -101,6 +101,56 @@ def load_control_plane():
     stub("manotorch.manolayer", ManoLayer=type("ManoLayer", (_B,), {}), MANOOutput=type("MANOOutput", (_B,), {}))
 
 
+def load_refiner(hand_model):
+    """anakin.artiboost.refiner of the reference, importable: its three absent third-party dependencies are bound to
+    stand-ins (documented in oracle/refiner_oracle.py; parity is unpinned at exactly these boundaries):
+      chamfer_distance.ChamferDistance -> brute-force nearest neighbour (fp32, first minimum),
+      manotorch.manolayer.ManoLayer    -> pose_oracle.mano_lbs on `hand_model` (flat_hand_mean, center_idx None, zero betas),
+      pytorch3d rotation conversions   -> pose_oracle.aa_to_rotmat / rotmat_to_aa.
+    Everything else that runs (HORefiner.forward, _RefineNet, ResBlock, CRot2rotmat, parms_decode, point2point_signed) is
+    the reference's own code."""
+    load_control_plane()
+    import numpy as np
+    import torch
+    import pose_oracle as po
+    import refiner_oracle as rfo
+
+    class ChamferDistance:
+        def __call__(self, x, y):
+            d_xy, i_xy = rfo.nearest_dist(x.numpy(), y.numpy())
+            d_yx, i_yx = rfo.nearest_dist(y.numpy(), x.numpy())
+            t = torch.from_numpy
+            return t(d_xy) ** 2, t(d_yx) ** 2, t(i_xy), t(i_yx)
+
+    class MANOOutput:
+        def __init__(self, verts, joints):
+            self.verts, self.joints = verts, joints
+
+    class ManoLayer(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+        def forward(self, pose_coeffs, betas=None):
+            b = np.zeros((pose_coeffs.shape[0], 10)) if betas is None else betas.double().numpy()
+            v, j, _ = po.mano_lbs(hand_model, pose_coeffs.detach().double().numpy(), b)
+            return MANOOutput(torch.from_numpy(v).float(), torch.from_numpy(j).float())
+
+    cd = types.ModuleType("chamfer_distance")
+    cd.ChamferDistance = ChamferDistance
+    sys.modules["chamfer_distance"] = cd
+    ml = types.ModuleType("manotorch.manolayer")
+    ml.ManoLayer, ml.MANOOutput = ManoLayer, MANOOutput
+    sys.modules["manotorch.manolayer"] = ml
+    import anakin.utils.transform as T
+    f64 = lambda fn: (lambda x: torch.from_numpy(fn(x.detach().double().numpy())).float())   # noqa: E731
+    T.axis_angle_to_matrix = f64(po.aa_to_rotmat)
+    T.matrix_to_quaternion = lambda m: m                       # rotmat_to_aa = Compose([matrix_to_quaternion, quaternion_to_axis_angle])
+    T.quaternion_to_axis_angle = f64(po.rotmat_to_aa)
+    sys.modules.pop("anakin.artiboost.refiner", None)
+    import anakin.artiboost.refiner as R
+    return R
+
+
 def build_reference_model_and_criterion(image_size=224, heatmap=28, depth=28, center_idx=0, seed=1):
     """Reference Arch(HybridBaseline) + Criterion from the reference's own training YAML
     (config/ho3dv2_clasbased_jlol_artiboost2.yaml), random init from `seed`."""
