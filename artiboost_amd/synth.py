@@ -15,6 +15,7 @@ What changed structurally (MI355X-first):
     REFINER block of TYPE "hand_obj" (artiboost_amd/refiner.py); its checkpoint is a download.
 """
 import math
+import os
 import random
 
 import numpy as np
@@ -161,6 +162,67 @@ def perspective_rotmat(persp_id, u_off, th_off, u_bins, theta_bins):
     return align_mat(np.array([s * np.cos(th), s * np.sin(th), u]))
 
 
+def perspective_rotmats(persp_id, u_off, th_off, u_bins, theta_bins):
+    """perspective_rotmat for arrays of views: [N] ids / offsets -> [N,3,3] (same arithmetic, vectorised)."""
+    persp_id = np.asarray(persp_id)
+    u_id, th_id = persp_id // theta_bins, persp_id % theta_bins
+    u_unit, th_unit = 2 / u_bins, (2 * np.pi) / theta_bins
+    u = np.clip((-1 + u_unit / 2) + u_id * u_unit + np.asarray(u_off) * u_unit, -1, 1)
+    th = np.clip(th_unit / 2 + th_id * th_unit + np.asarray(th_off) * th_unit, 0, 2 * np.pi)
+    s = np.sqrt(1 - u * u)
+    vec = np.stack([s * np.cos(th), s * np.sin(th), u], -1)
+    vec = vec / np.linalg.norm(vec, axis=-1, keepdims=True)
+    K = np.zeros(vec.shape[:-1] + (3, 3))
+    K[..., 0, 2], K[..., 2, 0] = vec[..., 0], -vec[..., 0]              # skew(z x vec), z x vec = (-vy, vx, 0)
+    K[..., 1, 2], K[..., 2, 1] = vec[..., 1], -vec[..., 1]
+    d = vec[..., 2]
+    safe = np.where(d == -1, 1.0, 1 + d)
+    R = np.eye(3) + K + (K @ K) / safe[..., None, None]
+    R = np.where((d == -1)[..., None, None], -np.eye(3), R)
+    return np.where((d == 1)[..., None, None], np.eye(3), R)
+
+
+def construct_blacklist_map(grasp_pose, u_bins, theta_bins, rng, filter_back_flag=True):
+    """ArtiBoostLoader._construct_blacklist_map (artiboost_loader.py:415-500): a CCV triplet is blacklisted when the back
+    of the hand faces the camera, th_sgn = (R_persp^T R_wrist [1, 0.2, 0]/|.|) . z < -0.8, with one jittered view drawn per
+    triplet (view_engine.get_view -> get_perspective_from_id).  grasp_pose [n_obj, n_grasp, 48] axis-angle (wrist first).
+    -> torch.bool [n_obj, n_persp, n_grasp].  (The reference's 57 600-iteration Python loop, here one vectorised pass.)"""
+    n_obj, n_grasp = grasp_pose.shape[:2]
+    n_persp = u_bins * theta_bins
+    out = torch.zeros((n_obj, n_persp, n_grasp), dtype=torch.bool)
+    if not filter_back_flag:
+        return out
+    u_off, th_off = rng.uniform(-0.5, 0.5, (n_obj, n_persp, n_grasp)), rng.uniform(-0.5, 0.5, (n_obj, n_persp, n_grasp))
+    ids = np.broadcast_to(np.arange(n_persp)[None, :, None], u_off.shape)
+    return back_facing(grasp_pose, perspective_rotmats(ids, u_off, th_off, u_bins, theta_bins))
+
+
+def back_facing(grasp_pose, persp_rotmat):
+    """The test of artiboost_loader.py:478-489 for every triplet: grasp_pose [n_obj, n_grasp, >=3], persp_rotmat
+    [n_obj, n_persp, n_grasp, 3, 3] -> torch.bool [n_obj, n_persp, n_grasp]."""
+    back = np.array([1.0, 0.2, 0.0])
+    back = back / np.linalg.norm(back)
+    wrist = aa_to_rotmat(torch.from_numpy(np.asarray(grasp_pose[..., :3], np.float64))).numpy() @ back        # [n_obj, n_grasp, 3]
+    # (R_persp^T R_wrist back) . z = (third column of R_persp) . (R_wrist back)
+    return torch.from_numpy(np.einsum("ovgk,ogk->ovg", np.asarray(persp_rotmat, np.float64)[..., :, 2], wrist) < -0.8)
+
+
+def blacklist_cache_path(cfg, n_obj, n_grasp, u_bins, theta_bins, filter_back_flag, root="common/cache/CCV_blacklist",
+                         obj_engine_type=None, grasp_engine_type=None):
+    """The reference's md5-keyed cache file of the blacklist (artiboost_loader.py:427-448): same identifier fields, same
+    JSON / md5 recipe, so a cache written by either side is found by the other."""
+    import hashlib
+    import json
+    origin = cfg.get("OBJ_ENGINE", {}).get("OBJ_ORIGIN_DATASET", "HO3D")
+    ident = {"obj_engine_type": obj_engine_type or f"{origin}ObjEngine", "sample_n_obj": n_obj,
+             "obj_names": sorted(cfg.get("OBJ_ENGINE", {}).get("OBJ", [])),
+             "grasp_engine_type": grasp_engine_type or f"{cfg.get('GRASP_ENGINE', {}).get('GRASP_ORIGIN_DATASET', origin)}GraspEngine",
+             "sample_n_grasp": n_grasp,
+             "view_engine_u_bins": u_bins, "view_engine_theta_bins": theta_bins, "filter_back_flag": filter_back_flag}
+    key = hashlib.md5(json.dumps(ident, sort_keys=True).encode("ascii")).hexdigest()
+    return os.path.join(root, f"{key}.pkl")
+
+
 def _affine_no_rot(center, scale, res):
     a = np.zeros((3, 3))
     ratio = float(res[0]) / float(res[1])
@@ -272,10 +334,15 @@ class ArtiBoostLoader:
         self.update_method_key = cfg.get("UPDATE_METHOD", "method_1")
         self.n_epochs = cfg.get("EPOCH", 100)
         self.use_synth = self.synth_len > 0
+        self._seed = random_seed
         self.rng = np.random.default_rng(random_seed)
         self.torch_gen = torch.Generator().manual_seed(random_seed)
         from .assets import make_grasps
         self.grasps = grasps if grasps is not None else make_grasps(self.n_obj, self.n_grasp, seed=random_seed + 5)
+        # blacklist of back-of-hand views (artiboost_loader.py:82,124-130): FILTER.BACK defaults to true in the reference
+        self.filter_back_flag = cfg["FILTER"].get("BACK", True) if "FILTER" in cfg else True
+        self.blacklist_map = self._blacklist(cfg.get("BLACKLIST_CACHE_ROOT"))
+        self.sample_weight_map[self.blacklist_map] = 0.0
         sc = cfg.get("SCRAMBLER", {"HAND_TSL_SIGMA": 0.01, "HAND_POSE_SIGMA": 0.1})
         if self.dev.type == "cuda":
             self.mano = ManoLayerHIP(assets.hand, device)
@@ -307,6 +374,27 @@ class ArtiBoostLoader:
         self.occurence_map |= occ
         return o.numpy(), v.numpy(), g.numpy()
 
+    def _blacklist(self, cache_root=None):
+        """_construct_blacklist_map incl. its pickle cache (only when BLACKLIST_CACHE_ROOT is configured: the reference
+        writes under ./common/cache unconditionally)."""
+        import pickle
+        path = None
+        if self.grasps[0] is None:          # planning-only instance without a grasp table
+            return torch.zeros((self.n_obj, self.n_persp, self.n_grasp), dtype=torch.bool)
+        if cache_root and self.filter_back_flag:
+            path = blacklist_cache_path(self.cfg, self.n_obj, self.n_grasp, self.u_bins, self.theta_bins, self.filter_back_flag, cache_root)
+            if os.path.exists(path):
+                with open(path, "rb") as f:
+                    cached = pickle.load(f)
+                if list(cached.shape) == [self.n_obj, self.n_persp, self.n_grasp]:
+                    return torch.as_tensor(cached, dtype=torch.bool)
+        bl = construct_blacklist_map(self.grasps[0], self.u_bins, self.theta_bins, np.random.default_rng(self._seed + 11), self.filter_back_flag)
+        if path:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "wb") as f:
+                pickle.dump(bl, f)
+        return bl
+
     # ------------------------------------------------------------------ epoch plan (host only; testable without a GPU)
     def plan_epoch(self):
         """Draw the epoch's CCV triplets and every per-sample random draw from the shared seed, then keep this rank's
@@ -335,21 +423,37 @@ class ArtiBoostLoader:
         return plan
 
     # ------------------------------------------------------------------ prepare(): per-epoch pose generation
-    def prepare(self):
+    def prepare(self, cache=None):
         """artiboost_loader.py:279-291,352-400: sample CCV triplets, generate poses (GPU, batches of 256), assemble GT
         (host), upload the epoch as device SoA tensors.  Under DDP every rank draws the same epoch (same seed) and
-        keeps its own slice idx[rank::world]."""
+        keeps its own slice idx[rank::world].
+        cache: an epoch of poses read back from the reference's on-disk format (ccv_cache.load_cache: one pickle per
+        sample as written by CacheRecorder, cache_recorder.py:22-45) -- used instead of generating poses."""
         if not self.use_synth:
             self.epoch = None
             return
         if self.mano is None:
             raise RuntimeError("ArtiBoostLoader.prepare() renders on the GPU: construct the loader with a cuda device")
         plan = self.plan_epoch()
-        o, v, g, aug = plan["o"], plan["v"], plan["g"], plan["aug"]
+        if cache is not None:
+            S = len(cache["obj_id"])
+            if S > len(plan["o"]):
+                raise ValueError(f"cache holds {S} samples, the epoch plan {len(plan['o'])}")
+            plan["aug"] = {k: val[:S] for k, val in plan["aug"].items()}
+            plan.update(o=np.asarray(cache["obj_id"], np.int64), v=np.asarray(cache["persp_id"], np.int64),
+                        g=np.asarray(cache["grasp_id"], np.int64), global_index=plan["global_index"][:S])
+            t32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.dev)   # noqa: E731
+            self._assemble_epoch(plan, t32(cache["obj_pose"]), t32(cache["hand_verts"]), t32(cache["hand_joints"]))
+        else:
+            self._assemble_epoch(plan, *self._generate_poses(plan))
+
+    def _generate_poses(self, plan):
+        """Pose generator over the epoch (preprocessor.py:20-99, batches of 256 as artiboost_loader.py:352-400)."""
+        o, v, g = plan["o"], plan["v"], plan["g"]
         u_off, th_off, free, zoff, d_pose, d_tsl = (plan[k] for k in ("u_off", "th_off", "free", "zoff", "d_pose", "d_tsl"))
         pick = lambda a: a   # noqa: E731  (plan_epoch already sliced to this rank)
         S = len(o)
-        Rp = np.stack([perspective_rotmat(int(p), a, b, self.u_bins, self.theta_bins) for p, a, b in zip(v, pick(u_off), pick(th_off))])
+        Rp = perspective_rotmats(v, pick(u_off), pick(th_off), self.u_bins, self.theta_bins)
         fr = pick(free)
         Tf = np.tile(np.eye(4), (S, 1, 1))
         Tf[:, 0, 0], Tf[:, 0, 1], Tf[:, 1, 0], Tf[:, 1, 1] = np.cos(fr), -np.sin(fr), np.sin(fr), np.cos(fr)
@@ -365,10 +469,18 @@ class ArtiBoostLoader:
                                              t(Rp[s0:s1]), t(Tf[s0:s1]), t(z3[s0:s1]), t(pick(d_pose)[s0:s1]), t(pick(d_tsl)[s0:s1]),
                                              obj_idx=torch.from_numpy(np.ascontiguousarray(o[s0:s1], np.int64)).to(dev))
             obj_pose.append(op); verts.append(hv); joints.append(jt)
-        obj_pose_d, verts_d, joints_d = torch.cat(obj_pose), torch.cat(verts), torch.cat(joints)
+        return torch.cat(obj_pose), torch.cat(verts), torch.cat(joints)
+
+    def _assemble_epoch(self, plan, obj_pose_d, verts_d, joints_d):
+        """RenderedDataset.__getitem__'s geometry for every sample (rendered_dataset.py:127-254) + the render records."""
+        o, v, g, a = plan["o"], plan["v"], plan["g"], plan["aug"]
+        S, dev = len(o), self.dev
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)   # noqa: E731
         obj_pose_h, joints_h = obj_pose_d.cpu().numpy().astype(np.float64), joints_d.cpu().numpy().astype(np.float64)
+        # what CacheRecorder would have pickled for this epoch (ccv_cache.export_epoch writes it in the reference's format)
+        self.epoch_poses = dict(index=plan["global_index"], obj_id=o, persp_id=v, grasp_id=g, obj_pose=obj_pose_d,
+                                hand_verts=verts_d, hand_joints=joints_d)
         # ---- host: GT assembly + render descriptors
-        a = aug
         samples = np.zeros(S, SAMPLE_DTYPE)
         samples["obj_id"], samples["hand_tex_id"], samples["bg_id"] = o, a["hid"], a["bid"]
         bgs = self.assets.backgrounds.shape[1]

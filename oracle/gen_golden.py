@@ -181,6 +181,83 @@ def gen_misc(seed=5):
     print("wrote misc")
 
 
+def gen_blacklist(seed=9):
+    """ArtiBoostLoader._construct_blacklist_map of the real reference (artiboost_loader.py:415-500) on a small CCV space,
+    called with a stand-in `self` that carries the real ViewEngine (jittered views from the seeded torch RNG) and a table
+    of grasps; the views it drew are recorded so that the restatement can be checked on exactly the same triplets."""
+    import types
+    ref_import.load_control_plane()
+    import pose_oracle as po
+    import anakin.utils.transform as T
+    T.axis_angle_to_matrix = lambda x: torch.from_numpy(po.aa_to_rotmat(x.detach().double().numpy())).float()   # pytorch3d stand-in
+    from anakin.artiboost.artiboost_loader import ArtiBoostLoader
+    from anakin.artiboost.view_engine import ViewEngine
+    n_obj, u_bins, th_bins, n_grasp = 2, 4, 6, 7
+    rng = np.random.default_rng(seed)
+    grasps = (1.5 * rng.standard_normal((n_obj, n_grasp, 48))).astype(np.float32)
+    ve = ViewEngine.__new__(ViewEngine)
+    ve.persp_u_bins, ve.persp_theta_bins = u_bins, th_bins
+    views = []
+
+    def get_view(vi):
+        R = ViewEngine.get_perspective_from_id(ve, torch.tensor(vi))
+        views.append(np.asarray(R, np.float64))
+        return R, np.eye(4), np.zeros(3)
+
+    fake = types.SimpleNamespace(
+        obj_engine=types.SimpleNamespace(obj_names=[f"obj{i}" for i in range(n_obj)]),
+        grasp_engine=types.SimpleNamespace(get_obj_grasp=lambda name, gi: (grasps[int(name[3:]), gi], None, None)),
+        view_engine=types.SimpleNamespace(persp_u_bins=u_bins, persp_theta_bins=th_bins, get_view=get_view))
+    cwd = os.getcwd()
+    import tempfile
+    os.chdir(tempfile.mkdtemp())                         # the method writes its pickle cache under ./common/cache
+    torch.manual_seed(seed)
+    try:
+        bl = ArtiBoostLoader._construct_blacklist_map(fake, n_obj, u_bins * th_bins, n_grasp, True)
+        cache = [os.path.join(r, f) for r, _, fs in os.walk("common") for f in fs]
+        assert len(cache) == 1
+        ident = os.path.basename(cache[0])
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(OUT, "blacklist.npz"), grasps=grasps, views=np.array(views).reshape(n_obj, u_bins * th_bins, n_grasp, 3, 3),
+                        blacklist=bl.numpy(), u_bins=u_bins, th_bins=th_bins, cache_name=ident)
+    print("wrote blacklist", bl.shape, float(bl.float().mean()), ident)
+
+
+def gen_state_files(seed=12):
+    """Files written by the reference's own writers -- CacheRecorder.__call__ (cache_recorder.py:22-45) and
+    Recorder.record_sample_weight / record_sample_occurence / record_shutdown (utils/recorder.py:182-202) -- on small seeded
+    inputs, committed as fixtures under tests/golden/ref_state/ for the readers in artiboost_amd/ccv_cache.py."""
+    import types
+    import shutil
+    ref_import.load_control_plane()
+    from anakin.artiboost.cache_recorder import CacheRecorder
+    git = types.ModuleType("git")
+    git.Repo = object
+    sys.modules.setdefault("git", git)
+    from anakin.utils.recorder import Recorder
+    Recorder = Recorder.__wrapped__                      # @singleton (utils/misc.py:41-50) keeps the class here
+    root = os.path.join(OUT, "ref_state")
+    shutil.rmtree(root, ignore_errors=True)
+    os.makedirs(os.path.join(root, "cache"))
+    g = torch.Generator().manual_seed(seed)
+    batch = {"index": torch.tensor([3, 17]), "obj_id": torch.tensor([1, 0]), "persp_id": torch.tensor([200, 5]),
+             "grasp_id": torch.tensor([49, 7]), "obj_name": ["021_bleach_cleanser", "010_potted_meat_can"],
+             "final_obj_pose": torch.randn(2, 4, 4, generator=g), "final_hand_verts": torch.randn(2, 778, 3, generator=g),
+             "final_joints": torch.randn(2, 21, 3, generator=g)}
+    CacheRecorder.__call__(types.SimpleNamespace(cache_root=os.path.join(root, "cache")), batch)
+    w = torch.rand(2, 6, 5, generator=g) * 3
+    occ = torch.rand(2, 6, 5, generator=g) > 0.5
+    fake = types.SimpleNamespace(dump_path=os.path.join(root, "dump"))
+    os.makedirs(os.path.join(root, "dump", "artiboost"))
+    Recorder.record_sample_weight(fake, w, 4)
+    Recorder.record_sample_occurence(fake, occ, 4)
+    Recorder.record_shutdown(fake, types.SimpleNamespace(use_synth=False))
+    np.savez_compressed(os.path.join(root, "expected.npz"), weight=w.numpy(), occ=occ.numpy(),
+                        **{k: v.numpy() for k, v in batch.items() if k != "obj_name"})
+    print("wrote ref_state", sorted(os.path.relpath(os.path.join(r, f), root) for r, _, fs in os.walk(root) for f in fs))
+
+
 def gen_refiner(B=3, seed=4, n_iters=3):
     """HORefiner.forward of the real reference (refiner.py:181-224) on seeded grasps, weights from
     refiner_oracle.fill_params, third-party stand-ins as documented in ref_import.load_refiner."""
@@ -226,8 +303,16 @@ if __name__ == "__main__":
     if "--refiner" in sys.argv:
         gen_refiner()
         sys.exit(0)
+    if "--blacklist" in sys.argv:
+        gen_blacklist()
+        sys.exit(0)
+    if "--state" in sys.argv:
+        gen_state_files()
+        sys.exit(0)
     gen_head_only()
     gen_misc()
     gen_learner("g224", 224, 28, 28, B=2, seed=1)
     gen_learner("g256", 256, 32, 28, B=2, seed=2)
     gen_refiner()
+    gen_blacklist()
+    gen_state_files()
