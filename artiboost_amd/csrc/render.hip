@@ -588,7 +588,8 @@ __global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restr
                                                           const float* __restrict__ inv_affine,
                                                           const unsigned long long* __restrict__ lsum, int ow, int oh,
                                                           T* __restrict__ out_pad, float* __restrict__ out_chw,
-                                                          const uint8_t* __restrict__ rgbx_blur, const float* __restrict__ radius) {
+                                                          const uint8_t* __restrict__ rgbx_blur, const float* __restrict__ radius,
+                                                          const uint8_t* __restrict__ flip = nullptr) {
     __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256];
     hue_lut_fill(l_sect, l_frac, l_sat);
     __syncthreads();
@@ -604,6 +605,9 @@ __global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restr
     int sx = (int)floorf(xin), sy = (int)floorf(yin);
     float v[3] = {0.f, 0.f, 0.f};
     if (sx >= 0 && sx < W && sy >= 0 && sy < H) {
+        // Image.FLIP_LEFT_RIGHT before the blur / jitter / warp (hodata.py:336-337) == the same chain on the unflipped
+        // image read at the mirrored column: the blur is symmetric and the jitter is per pixel (+ a global mean)
+        if (flip && flip[b]) sx = W - 1 - sx;
         uint32_t q = *(const uint32_t*)(rgbx + (((size_t)b * H + sy) * W + sx) * 4);
         uint8_t px[3] = {(uint8_t)q, (uint8_t)(q >> 8), (uint8_t)(q >> 16)};
         int mean = (int)((double)lsum[b] / (double)(W * H) + 0.5);
@@ -738,6 +742,37 @@ extern "C" int ab_gaussian_blur(const void* rgbx, int B, int W, int H, const flo
     if (!rgbx || !radius || !out || rgbx == out || B < 1) return AB_EINVAL;
     if (W < TILE || H < TILE || W % TILE || H % TILE) return AB_ESHAPE;
     gauss_blur_kernel<<<dim3((unsigned)((W / TILE) * (H / TILE)), B), 256, 0, as_stream(stream)>>>((const uint8_t*)rgbx, (uint8_t*)out, W, H, radius, 1);
+    AB_LAUNCH_CHECK();
+    return 0;
+}
+
+// The augmentation chain of a real frame (anakin/datasets/hodata.py:336-337,435-446: optional left-right flip, PIL
+// GaussianBlur, colour jitter in drawn order, inverse-affine nearest crop, to_tensor - 0.5) for B decoded RGBX images of
+// one size: the same kernels as the tail of ab_render_batch.  workspace: ab_augment_workspace_bytes(B, W, H).
+extern "C" long ab_augment_workspace_bytes(int B, int W, int H) {
+    auto al = [](long x) { return (x + 255) / 256 * 256; };
+    return al((long)B * 8) + al((long)B * W * H * 4);
+}
+extern "C" int ab_augment_batch(const void* rgbx_in, int B, int W, int H, const int32_t* order, const float* factor,
+                                const float* inv_affine, const float* blur_radius, const uint8_t* flip, int ow, int oh,
+                                int out_dtype, void* out_pad, float* out_chw, void* workspace, void* stream) {
+    if (!rgbx_in || !order || !factor || !inv_affine || !workspace || B < 1 || (!out_pad && !out_chw)) return AB_EINVAL;
+    if (blur_radius && (W < TILE || H < TILE || W % TILE || H % TILE)) return AB_ESHAPE;
+    hipStream_t st = as_stream(stream);
+    auto al = [](long x) { return (x + 255) / 256 * 256; };
+    const uint8_t* rgbx = (const uint8_t*)rgbx_in;
+    unsigned long long* lsum = (unsigned long long*)workspace;
+    uint8_t* rgbx_blur = (uint8_t*)workspace + al((long)B * 8);
+    zero_words_kernel<<<(unsigned)((B * 2 + 255) / 256), 256, 0, st>>>((unsigned*)lsum, (long)B * 2);
+    if (blur_radius) gauss_blur_kernel<<<dim3((unsigned)((W / TILE) * (H / TILE)), B), 256, 0, st>>>(rgbx, rgbx_blur, W, H, blur_radius, 0);
+    jitter_stats_kernel<<<dim3(64, B), 256, 0, st>>>(rgbx, W * H, order, factor, lsum, rgbx_blur, blur_radius);
+    AB_LAUNCH_CHECK();
+    dim3 g((ow * oh + 255) / 256, B);
+    if (out_dtype == AB_DT_F32)
+        warp_jitter_kernel<float><<<g, 256, 0, st>>>(rgbx, W, H, order, factor, inv_affine, lsum, ow, oh, (float*)out_pad, out_chw, rgbx_blur, blur_radius, flip);
+    else if (out_dtype == AB_DT_BF16)
+        warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, W, H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw, rgbx_blur, blur_radius, flip);
+    else return AB_EINVAL;
     AB_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,232 @@
+"""Real-data half of the training mix: anakin/datasets/hodata.py:315-450 (HOdata.__getitem__) and
+anakin/artiboost/mixed_dataset.py.
+
+The reference decodes a frame with PIL in a DataLoader worker, assembles the ground truth in numpy and runs the
+augmentation chain (flip, GaussianBlur, colour jitter, affine crop) in PIL on the CPU -- 62.5 % of every training batch.
+Here the decoded frames of a batch are uploaded once and the whole chain runs in `ab_augment_batch` (the same kernels as
+the tail of the synthetic render); the ground-truth geometry stays on the host in the reference's arithmetic.  The datasets
+themselves (HO3D / DexYCB) are downloads: a source only has to provide the getters of `HOdataSource`."""
+import numpy as np
+import torch
+
+from . import _lib as L
+from .registry import Queries, SynthQueries
+from .synth import get_affine_transform
+
+
+class HOdataSource:
+    """The per-sample getters HOdata subclasses implement (hodata.py:204-296), as used by __getitem__."""
+    raw_size = (640, 480)       # (W, H) of the frames (ho3d.py:40)
+    sides = "right"             # CONST.SIDE
+
+    def __len__(self):
+        raise NotImplementedError
+
+    def get_image(self, idx):
+        """uint8 [H, W, 3] RGB (Image.open(path).convert("RGB"), ho3d.py:228-231)."""
+        raise NotImplementedError
+
+    def get_annots(self, idx):
+        """dict: cam_intr (3,3), joints_3d (21,3), joints_2d (21,2), corners_3d (8,3), corners_2d (8,2), corners_can (8,3),
+        obj_transf (4,4), obj_idx int, side str, bbox_center (2,), bbox_scale float (get_center_scale_wrt_bbox)."""
+        raise NotImplementedError
+
+
+def annot_center_scale(pts2d):
+    """HOdata.get_annot_center / get_annot_scale (hodata.py:162-186): int-truncated centre, max span."""
+    mn, mx = pts2d.min(0), pts2d.max(0)
+    return np.asarray([int((mx[0] + mn[0]) / 2), int((mx[1] + mn[1]) / 2)]), max(mx[0] - mn[0], mx[1] - mn[1])
+
+
+def assemble_real_gt(ann, image_size, raw_size, draws, center_idx=0, bbox_expand=1.2, center_jit=0.1, scale_jit=0.1,
+                     sides="right", train_split=True):
+    """HOdata.__getitem__ geometry (hodata.py:315-433).  draws: None (no augmentation) or dict(center (2,) in U(-1,1),
+    scale ~ N(0, scale_jit/3), rot radians).  Returns the sample dict (+ "affine" 3x3 and "flip")."""
+    flip = ann["side"] != sides
+    center, scale = np.asarray(ann["bbox_center"]).copy(), float(ann["bbox_scale"]) * bbox_expand
+    K = np.asarray(ann["cam_intr"])
+    j3, j2 = np.asarray(ann["joints_3d"]), np.asarray(ann["joints_2d"])
+    c3, c2 = np.asarray(ann["corners_3d"]), np.asarray(ann["corners_2d"])
+    raw_j2, raw_c2 = j2, c2                                        # get_joints_vis / get_corners_vis re-read the raw annotation
+    if flip:                                                       # hodata.py:336-343
+        center[0] = raw_size[0] - center[0]
+        j3, c3 = j3 * np.array([-1, 1, 1]), c3 * np.array([-1, 1, 1])
+        j2, c2 = j2.copy(), c2.copy()
+        j2[:, 0] = raw_size[0] - j2[:, 0]
+        c2[:, 0] = raw_size[0] - c2[:, 0]
+    rot = 0.0
+    if draws is not None:                                          # hodata.py:346-359
+        center = center + (center_jit * scale * np.asarray(draws["center"])).astype(int)
+        scale = scale * np.clip(draws["scale"] + 1.0, 1 - scale_jit, 1 + scale_jit)
+        rot = draws["rot"]
+    rm = np.array([[np.cos(rot), -np.sin(rot), 0], [np.sin(rot), np.cos(rot), 0], [0, 0, 1]]).astype(np.float32)
+    aff, post = get_affine_transform(center, scale, [K[0, 2], K[1, 2]], image_size, rot)
+    out = {"affine": aff, "flip": bool(flip), Queries.CAM_INTR: post.dot(K).astype(np.float32)}
+    j3 = rm.dot(j3.transpose(1, 0)).transpose()
+    root = j3[center_idx]
+    c3 = rm.dot(c3.transpose(1, 0)).transpose()
+    out[Queries.ROOT_JOINT], out[Queries.JOINTS_3D], out[Queries.CORNERS_3D] = root, j3 - root, c3 - root
+    hom = lambda p: aff.dot(np.concatenate([p, np.ones((p.shape[0], 1))], 1).T).T[:, :2]   # noqa: E731  transform_coords
+    j2a, c2a = hom(j2).astype(np.float32), hom(c2).astype(np.float32)
+    out[Queries.JOINTS_2D], out[Queries.CORNERS_2D] = j2a, c2a
+
+    def vis(raw2d, aug2d, n):                                      # hodata.py:296-313,383-396,418-431
+        if not train_split:
+            return np.ones(n, np.float32)
+        v = (raw2d[:, 0] >= 0) & (raw2d[:, 0] < raw_size[0]) & (raw2d[:, 1] >= 0) & (raw2d[:, 1] < raw_size[1])
+        if v.sum() < n * 0.4:
+            return np.zeros(n, np.float32)
+        va = ((aug2d[:, 0] >= 0) & (aug2d[:, 0] < image_size[0]) & (aug2d[:, 1] >= 0) & (aug2d[:, 1] < image_size[1])).astype(np.float32)
+        return np.zeros(n, np.float32) if va.sum() < n * 0.4 else va
+
+    out[Queries.JOINTS_VIS], out[Queries.CORNERS_VIS] = vis(raw_j2, j2a, 21), vis(raw_c2, c2a, 8)
+    out[Queries.CORNERS_CAN] = np.asarray(ann["corners_can"])
+    out[Queries.OBJ_IDX] = int(ann["obj_idx"])
+    base = np.asarray(ann["obj_transf"]).astype(np.float32)
+    T = np.concatenate([np.concatenate([rm @ base[:3, :3], rm.dot(base[:3, 3:])], 1), np.array([[0.0, 0.0, 0.0, 1.0]])], 0)
+    out[Queries.OBJ_TRANSF] = T.astype(np.float32)
+    return out
+
+
+class RealBatcher:
+    """Batches of real samples on the device: host GT assembly + one upload of the decoded frames + ab_augment_batch."""
+    GT_KEYS = (Queries.CAM_INTR, Queries.ROOT_JOINT, Queries.JOINTS_3D, Queries.JOINTS_2D, Queries.JOINTS_VIS, Queries.CORNERS_3D,
+               Queries.CORNERS_2D, Queries.CORNERS_VIS, Queries.CORNERS_CAN, Queries.OBJ_TRANSF)
+
+    def __init__(self, source: HOdataSource, cfg_preset, aug=True, aug_param=None, device="cuda", compute_dtype=torch.bfloat16, seed=1):
+        self.src, self.dev, self.dtype, self.aug = source, torch.device(device), compute_dtype, aug
+        self.image_size = list(cfg_preset["IMAGE_SIZE"])
+        self.center_idx = int(cfg_preset.get("CENTER_IDX", 9))
+        self.bbox_expand = float(cfg_preset.get("BBOX_EXPAND_RATIO", 1.2))
+        ap = aug_param or {"SCALE_JIT": 0.1, "CENTER_JIT": 0.1, "MAX_ROT": 0.2}
+        self.scale_jit, self.center_jit, self.max_rot = ap["SCALE_JIT"], ap["CENTER_JIT"], ap["MAX_ROT"] * np.pi
+        self.rng = np.random.default_rng(seed)
+        self._ws = None
+
+    def draw(self, n):
+        """One set of augmentation draws per sample (hodata.py:346-359,435-442: ranges hard-coded at hodata.py:107-112)."""
+        r = self.rng
+        order = np.stack([r.permutation(4) for _ in range(n)]).astype(np.int32)
+        fac_of = np.stack([r.uniform(0.9, 1.1, n), r.uniform(0.9, 1.1, n), r.uniform(-0.075, 0.075, n), r.uniform(0.9, 1.1, n)], 1)
+        return dict(center=r.uniform(-1, 1, (n, 2)), scale=r.normal(0, self.scale_jit / 3.0, n), rot=r.uniform(-self.max_rot, self.max_rot, n),
+                    blur=(0.1 * r.uniform(0, 1, n)).astype(np.float32), order=order,
+                    factor=np.take_along_axis(fac_of, order, 1).astype(np.float32))
+
+    def assemble(self, idxs, draws=None):
+        """Host side of a batch: frames (uint8 RGBX), GT arrays, inverse affines, flips and jitter draws."""
+        n = len(idxs)
+        if draws is None and self.aug:
+            draws = self.draw(n)
+        W, H = self.src.raw_size
+        frames = np.zeros((n, H, W, 4), np.uint8)
+        gt = {k: [] for k in self.GT_KEYS}
+        inv, flip, obj_idx = np.zeros((n, 6), np.float32), np.zeros(n, np.uint8), np.zeros(n, np.int64)
+        for i, idx in enumerate(idxs):
+            frames[i, :, :, :3] = self.src.get_image(idx)
+            d = None if draws is None else dict(center=draws["center"][i], scale=draws["scale"][i], rot=draws["rot"][i])
+            r = assemble_real_gt(self.src.get_annots(idx), self.image_size, self.src.raw_size, d, self.center_idx, self.bbox_expand,
+                                 self.center_jit, self.scale_jit, self.src.sides)
+            for k in self.GT_KEYS:
+                gt[k].append(r[k])
+            inv[i] = np.linalg.inv(np.vstack([r["affine"][:2], [0, 0, 1]]).astype(np.float64))[:2].reshape(-1)
+            flip[i], obj_idx[i] = r["flip"], r[Queries.OBJ_IDX]
+        if draws is None:                                          # no augmentation: identity jitter, no blur (hodata.py:113-121)
+            order = np.tile(np.arange(4, dtype=np.int32), (n, 1))
+            factor = np.tile(np.array([1, 1, 0, 1], np.float32), (n, 1))
+            blur = None
+        else:
+            order, factor, blur = draws["order"], draws["factor"], draws["blur"]
+        return dict(frames=frames, gt={k: np.stack(v).astype(np.float32) for k, v in gt.items()}, inv=inv, flip=flip, obj_idx=obj_idx,
+                    order=order, factor=factor, blur=blur, idxs=np.asarray(idxs, np.int64))
+
+    def augment(self, host, out_pad=None, out_chw=None):
+        """Upload + ab_augment_batch.  out_pad: zero-bordered NHWC4 rows to fill (a slice of the training batch)."""
+        n = len(host["idxs"])
+        W, H = self.src.raw_size
+        ow, oh = self.image_size
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev, non_blocking=True)   # noqa: E731
+        lib = L.lib()
+        need = lib.ab_augment_workspace_bytes(L.i(n), L.i(W), L.i(H))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        if out_pad is None and out_chw is None:
+            out_chw = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=self.dev)
+        frames, order, factor, inv, flip = t(host["frames"]), t(host["order"]), t(host["factor"]), t(host["inv"]), t(host["flip"])
+        blur = t(host["blur"]) if host["blur"] is not None else None
+        dt = L.dt(out_pad) if out_pad is not None else 0
+        L.check(lib.ab_augment_batch(L.ptr(frames), L.i(n), L.i(W), L.i(H), L.ptr(order), L.ptr(factor), L.ptr(inv), L.ptr(blur),
+                                     L.ptr(flip), L.i(ow), L.i(oh), L.i(dt), _ptr(out_pad), L.ptr(out_chw), L.ptr(self._ws), L.stream()),
+                "ab_augment_batch")
+        return out_chw
+
+    def batch(self, idxs, draws=None, out_pad=None, want_chw=True):
+        """Device batch dict with the reference's keys (hodata.py:315-450; IS_SYNTH false, CCV ids -1)."""
+        host = self.assemble(idxs, draws)
+        n = len(idxs)
+        ow, oh = self.image_size
+        chw = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=self.dev) if want_chw else None
+        self.augment(host, out_pad=out_pad, out_chw=chw)
+        b = {k: torch.from_numpy(v).to(self.dev) for k, v in host["gt"].items()}
+        b[Queries.OBJ_IDX] = torch.from_numpy(host["obj_idx"]).to(self.dev)
+        b[Queries.SAMPLE_IDX] = torch.from_numpy(host["idxs"]).to(self.dev)
+        b[SynthQueries.IS_SYNTH] = torch.zeros(n, dtype=torch.bool, device=self.dev)
+        for k in (SynthQueries.OBJ_ID, SynthQueries.PERSP_ID, SynthQueries.GRASP_ID):
+            b[k] = torch.full((n,), -1, dtype=torch.int64, device=self.dev)
+        if chw is not None:
+            b[Queries.IMAGE] = chw
+        return b
+
+
+def _ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class MixedLoader:
+    """MixedDataset (mixed_dataset.py:5-37) + the shuffling DataLoader of train_artiboost.py, with a STATIC per-batch split:
+    every batch holds n_real = round(B * real_len / (real_len + synth_len)) real samples (a random permutation of the real
+    set over the epoch) followed by B - n_real synthetic ones (the epoch's CCV draws, already i.i.d.), instead of a
+    hypergeometric count per batch -- fixed shapes keep the step replayable as a hipGraph.  `remove_synth()` ==
+    ArtiBoostLoader.synth_shutdown: real samples only."""
+
+    def __init__(self, real: RealBatcher, synth_loader, batch_size, seed=1):
+        self.real, self.synth, self.B = real, synth_loader, batch_size
+        self.rng = np.random.default_rng(seed)
+        self.update()
+
+    def update(self):
+        self.real_len = len(self.real.src)
+        self.synth_len = self.synth.epoch_len if (self.synth is not None and self.synth.use_synth and self.synth.epoch is not None) else 0
+        tot = self.real_len + self.synth_len
+        self.n_real = self.B if self.synth_len == 0 else int(round(self.B * self.real_len / tot))
+        self.n_synth = self.B - self.n_real
+        assert self.synth is None or self.n_synth == 0 or self.synth.batch_size == self.n_synth, \
+            "construct the ArtiBoostLoader with batch_size == MixedLoader.n_synth_for(...)"
+
+    @staticmethod
+    def n_synth_for(batch_size, real_len, synth_len):
+        return batch_size - int(round(batch_size * real_len / (real_len + synth_len)))
+
+    def __len__(self):
+        n = self.real_len // self.n_real if self.n_real else 0
+        return min(n, len(self.synth)) if self.n_synth else n
+
+    def __iter__(self):
+        perm = self.rng.permutation(self.real_len)
+        W, H = self.real.image_size
+        static = self.synth.new_static_batch() if self.n_synth else None
+        for bi in range(len(self)):
+            pad = torch.zeros((self.B, H + 6, W + 8, 4), dtype=self.real.dtype, device=self.real.dev)
+            rb = self.real.batch(perm[bi * self.n_real:(bi + 1) * self.n_real], out_pad=pad[:self.n_real])
+            if not self.n_synth:
+                rb["image_nhwc4_padded"] = pad
+                yield rb
+                continue
+            self.synth.load_batch(static, bi)
+            self.synth.render_into(static, want_chw=True)
+            pad[self.n_real:] = static["image_nhwc4_padded"]
+            out = {"image_nhwc4_padded": pad}
+            for k, v in rb.items():
+                sv = static[k]
+                out[k] = torch.cat([v, sv.to(v.dtype) if sv.dtype != v.dtype else sv])
+            yield out

@@ -213,6 +213,15 @@ int ab_render_batch(const ab_scene* scene_host, const void* samples, const float
 /* The GaussianBlur stage of ab_render_batch on its own (PIL ImageFilter.GaussianBlur on the RGB bytes of B RGBX images,
  * W and H multiples of 32): radius float [B] on the device, each < 1.41; out must not alias rgbx.                  */
 int ab_gaussian_blur(const void* rgbx, int B, int W, int H, const float* radius, void* out, void* stream);
+/* SURVEY section 8f-3, the real-data half of MixedDataset: the augmentation chain of HOdata.__getitem__
+ * (anakin/datasets/hodata.py:336-337,435-446) for B decoded frames of one size, RGBX uint8 [B,H,W,4] on the device:
+ * optional Image.FLIP_LEFT_RIGHT (flip uint8 [B] or NULL), GaussianBlur (blur_radius [B] or NULL; needs W, H % 32 == 0),
+ * colour jitter (order / factor as ab_render_batch), inverse-affine nearest crop to ow x oh, to_tensor - 0.5.
+ * Outputs as ab_render_batch (zero-bordered NHWC4 in out_dtype and/or float CHW).                                   */
+long ab_augment_workspace_bytes(int B, int W, int H);
+int ab_augment_batch(const void* rgbx, int B, int W, int H, const int32_t* order, const float* factor,
+                     const float* inv_affine, const float* blur_radius, const uint8_t* flip, int ow, int oh,
+                     int out_dtype, void* out_pad, float* out_chw, void* workspace, void* stream);
 /* Small-batch fp32 linear layers (the box-rotation MLP, anakin/models/mlp.py:11-25; nn.Linear weights [N][K]):
  *   fwd   y[M][N]  = act(x[M][K] W^T + bias)            (relu != 0: ReLU)
  *   dgrad gx[M][K] = (g[M][N] W) masked by act_out > 0   (act_out NULL: no mask); takes wt = W transposed, [K][N]

@@ -258,6 +258,113 @@ def gen_state_files(seed=12):
     print("wrote ref_state", sorted(os.path.relpath(os.path.join(r, f), root) for r, _, fs in os.walk(root) for f in fs))
 
 
+def gen_real_sample(seed=21):
+    """HOdata.__getitem__ of the real reference (anakin/datasets/hodata.py:315-450) on a stand-in subclass that serves
+    seeded frames and annotations (the datasets are downloads): the full sample dict incl. the augmented image, plus the
+    augmentation draws, recovered by replaying the same RNG calls in the same order.  torchvision (absent) enters through
+    stand-ins for to_tensor / normalize only."""
+    import random
+    import types
+    from PIL import Image
+    ref_import.load_control_plane()
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tvf.to_tensor = lambda im: torch.from_numpy(np.asarray(im, np.uint8).copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+    tvf.normalize = lambda t, mean, std: (t - torch.tensor(mean)[:, None, None]) / torch.tensor(std)[:, None, None]
+    sys.modules["torchvision.transforms.functional"] = tvf
+    sys.modules["torchvision.transforms"].functional = tvf
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]      # `import a.b.c as x` walks attributes
+    sys.modules.pop("anakin.datasets.hodata", None)
+    from anakin.datasets.hodata import HOdata
+    from anakin.utils import img_augment
+
+    class _NP:                                    # NumPy < 2 semantics of np.uint8(negative float) (img_augment.py:187): C cast + wrap
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+        class uint8(np.uint8):
+            def __new__(cls, v=0):
+                return np.uint8(int(v) & 0xFF)
+    img_augment.np = _NP()
+    from torch.distributions.normal import Normal
+    from torch.distributions.uniform import Uniform
+    W, H, res = 192, 160, 64
+    rng = np.random.default_rng(seed)
+    n = 3
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = np.stack([np.stack([(xx * (3 + i) + yy * 2 + 40 * np.sin(xx / (5.0 + c) + i) + 30 * rng.standard_normal((H, W))) % 256
+                                 for c in range(3)], -1) for i in range(n)]).astype(np.uint8)
+    K = np.array([[150.0, 0, 96.0], [0, 150.0, 80.0], [0, 0, 1.0]], np.float32)
+    ann = []
+    for i in range(n):
+        j3 = (rng.uniform(-0.06, 0.06, (21, 3)) + [0.01 * i, 0.0, 0.5]).astype(np.float32)
+        T = np.eye(4, dtype=np.float32)
+        T[:3, :3] = po_aa(rng.standard_normal(3)); T[:3, 3] = [0.02, -0.01, 0.52]
+        can = (rng.uniform(0.03, 0.06, 3) * np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])).astype(np.float32)
+        c3 = (T[:3, :3] @ can.T).T + T[:3, 3]
+        ann.append(dict(j3=j3, c3=c3.astype(np.float32), can=can, T=T, side="left" if i == 1 else "right", obj_idx=3 + i))
+
+    class Fake(HOdata):
+        def __init__(self, **cfg):
+            super().__init__(**cfg)
+            self.raw_size = (W, H)
+        get_sample_idxs = lambda self: list(range(n))                                   # noqa: E731
+        get_image = lambda self, idx: Image.fromarray(frames[idx])                      # noqa: E731
+        get_cam_intr = lambda self, idx: K.copy()                                       # noqa: E731
+        get_joints_3d = lambda self, idx: ann[idx]["j3"].copy()                         # noqa: E731
+        get_joints_2d = lambda self, idx: HOdata.persp_project(ann[idx]["j3"], K)       # noqa: E731
+        get_corners_3d = lambda self, idx: ann[idx]["c3"].copy()                        # noqa: E731
+        get_corners_2d = lambda self, idx: HOdata.persp_project(ann[idx]["c3"], K)      # noqa: E731
+        get_corners_can = lambda self, idx: ann[idx]["can"].copy()                      # noqa: E731
+        get_obj_transf = lambda self, idx: ann[idx]["T"].copy()                         # noqa: E731
+        get_obj_idx = lambda self, idx: ann[idx]["obj_idx"]                             # noqa: E731
+        get_sides = lambda self, idx: ann[idx]["side"]                                  # noqa: E731
+
+        def get_center_scale_wrt_bbox(self, idx):                                       # CROP_MODEL root_obj, ho3d.py:318-324
+            all2d = np.concatenate([self.get_joints_2d(idx)[[0]], self.get_corners_2d(idx)], 0)
+            return HOdata.get_annot_center(all2d), HOdata.get_annot_scale(all2d)
+    for name in ("get_image_path get_hand_verts_3d get_hand_verts_2d get_hand_faces get_obj_faces get_obj_verts_transf "
+                 "get_obj_verts_2d get_obj_verts_can get_sample_identifier").split():
+        setattr(Fake, name, lambda self, idx: None)
+    Fake.__abstractmethods__ = frozenset()
+    cfg = dict(DATA_ROOT="", DATA_SPLIT="train", AUG=True, AUG_PARAM={"SCALE_JIT": 0.1, "CENTER_JIT": 0.1, "MAX_ROT": 0.2},
+               DATA_PRESET={"USE_CACHE": False, "FILTER_NO_CONTACT": False, "FILTER_THRESH": 0.0, "BBOX_EXPAND_RATIO": 1.2,
+                            "CROP_MODEL": "root_obj", "FULL_IMAGE": False, "IMAGE_SIZE": [res, res], "CENTER_IDX": 0})
+    ds = Fake(**cfg)
+    out = {"frames": frames, "K": K, "res": res}
+    for i in range(n):
+        for k, v in ann[i].items():
+            out[f"ann{i}.{k}"] = np.asarray(v)
+        out[f"ann{i}.j2"], out[f"ann{i}.c2"] = ds.get_joints_2d(i), ds.get_corners_2d(i)
+        c, s = ds.get_center_scale_wrt_bbox(i)
+        out[f"ann{i}.bbox_center"], out[f"ann{i}.bbox_scale"] = np.asarray(c), np.asarray(s)
+        torch.manual_seed(seed + i); random.seed(seed + i)
+        sample = ds[i]
+        # replay the draws (hodata.py:350-358,436-441; img_augment.py:6-46) from the same seeds
+        torch.manual_seed(seed + i); random.seed(seed + i)
+        cj = Uniform(low=-1, high=1).sample((2,)).numpy()
+        sj = Normal(0, 0.1 / 3.0).sample().item()
+        rot = Uniform(low=-0.2 * np.pi, high=0.2 * np.pi).sample().item()
+        blur = Uniform(low=0, high=1).sample().item() * 0.1
+        b_, c_, s_, h_ = (random.uniform(0.9, 1.1), random.uniform(0.9, 1.1), random.uniform(0.9, 1.1), random.uniform(-0.075, 0.075))
+        ops = [0, 1, 2, 3]                       # apply_jitter's list order: brightness, saturation, hue, contrast
+        random.shuffle(ops)
+        fac = {0: b_, 1: s_, 2: h_, 3: c_}
+        out[f"draw{i}.center"], out[f"draw{i}.scale"], out[f"draw{i}.rot"], out[f"draw{i}.blur"] = cj, np.array(sj), np.array(rot), np.array(blur)
+        out[f"draw{i}.order"], out[f"draw{i}.factor"] = np.array(ops, np.int32), np.array([fac[o] for o in ops], np.float32)
+        for k, v in sample.items():
+            v = v.numpy() if torch.is_tensor(v) else np.asarray(v)
+            if k == "image":
+                v = np.round((v + 0.5) * 255).astype(np.uint8)          # exact: the tensor is k/255 - 0.5
+            out[f"sample{i}.{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "real_sample.npz"), **out)
+    print("wrote real_sample", os.path.getsize(os.path.join(OUT, "real_sample.npz")), sorted(k for k in out if k.startswith("sample0")))
+
+
+def po_aa(aa):
+    import pose_oracle as po
+    return po.aa_to_rotmat(np.asarray(aa, np.float64)).astype(np.float32)
+
+
 def gen_refiner(B=3, seed=4, n_iters=3):
     """HORefiner.forward of the real reference (refiner.py:181-224) on seeded grasps, weights from
     refiner_oracle.fill_params, third-party stand-ins as documented in ref_import.load_refiner."""
@@ -309,6 +416,9 @@ if __name__ == "__main__":
     if "--state" in sys.argv:
         gen_state_files()
         sys.exit(0)
+    if "--real" in sys.argv:
+        gen_real_sample()
+        sys.exit(0)
     gen_head_only()
     gen_misc()
     gen_learner("g224", 224, 28, 28, B=2, seed=1)
@@ -316,3 +426,4 @@ if __name__ == "__main__":
     gen_refiner()
     gen_blacklist()
     gen_state_files()
+    gen_real_sample()

@@ -414,6 +414,22 @@ void ro_affine_crop(const uint8_t* rgbx, int W, int H, const float* inv, int ow,
         }
 }
 
+/* The augmentation chain of a real frame, HOdata.__getitem__ (anakin/datasets/hodata.py:336-337,435-446): optional
+ * Image.FLIP_LEFT_RIGHT, GaussianBlur, colour jitter, inverse-affine crop, to_tensor - 0.5; rgbx is modified in place. */
+void ro_augment(uint8_t* rgbx, int W, int H, int flip, float blur_radius, const int32_t* order, const float* factor,
+                const float* inv, int ow, int oh, float* out_chw) {
+    if (flip)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W / 2; ++x) {
+                uint32_t* a = (uint32_t*)rgbx + (size_t)y * W + x;
+                uint32_t* b = (uint32_t*)rgbx + (size_t)y * W + (W - 1 - x);
+                uint32_t t = *a; *a = *b; *b = t;
+            }
+    ro_gaussian_blur(rgbx, W, H, blur_radius);
+    ro_color_jitter(rgbx, W * H, order, factor);
+    ro_affine_crop(rgbx, W, H, inv, ow, oh, out_chw);
+}
+
 /* Whole synthesis of one batch (used as the CPU baseline): OpenMP over samples when compiled with -fopenmp. */
 void ro_render_batch(const ro_scene* sc, const ro_sample* sm, const float* hand_verts, int B, const int32_t* order,
                      const float* factor, const float* inv_affine, const float* blur_radius, int ow, int oh,

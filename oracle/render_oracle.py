@@ -121,3 +121,17 @@ def gaussian_blur(rgbx, radius):
     lib().ro_gaussian_blur(img.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(img.shape[1]), ctypes.c_int(img.shape[0]),
                            ctypes.c_float(radius))
     return img
+
+
+def augment(rgb, order, factor, inv, blur, flip, ow, oh):
+    """HOdata.__getitem__'s image chain (hodata.py:336-337,435-446) on one uint8 (H, W, 3) frame -> float32 [3, oh, ow]."""
+    rgb = np.asarray(rgb, np.uint8)
+    img = np.zeros(rgb.shape[:2] + (4,), np.uint8)
+    img[..., :3] = rgb
+    o = np.ascontiguousarray(order, np.int32); f = np.ascontiguousarray(factor, np.float32)
+    inv = np.ascontiguousarray(inv, np.float32)
+    out = np.empty((3, oh, ow), np.float32)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+    lib().ro_augment(p(img), ctypes.c_int(img.shape[1]), ctypes.c_int(img.shape[0]), ctypes.c_int(int(bool(flip))),
+                     ctypes.c_float(blur), p(o), p(f), p(inv), ctypes.c_int(ow), ctypes.c_int(oh), p(out))
+    return out

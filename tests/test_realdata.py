@@ -1,0 +1,129 @@
+"""Real-data half of the training mix (anakin/datasets/hodata.py:315-450, mixed_dataset.py).
+Golden: tests/golden/real_sample.npz = the sample dicts produced by the REAL HOdata.__getitem__ on a stand-in subclass
+serving seeded frames / annotations (oracle/gen_golden.py gen_real_sample), one of them a left hand (flip path)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import render_oracle as ro
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "real_sample.npz")
+GT = ("cam_intr", "root_joint", "joints_3d", "joints_2d", "joints_vis", "corners_3d", "corners_2d", "corners_vis", "corners_can", "obj_transf")
+
+
+class GoldenSource:
+    """HOdataSource over the golden frames (index modulo 3)."""
+    sides = "right"
+
+    def __init__(self):
+        self.g = np.load(GOLD)
+        self.raw_size = (self.g["frames"].shape[2], self.g["frames"].shape[1])
+        self.n = 12
+
+    def __len__(self):
+        return self.n
+
+    def get_image(self, idx):
+        return self.g["frames"][idx % 3]
+
+    def get_annots(self, idx):
+        g, i = self.g, idx % 3
+        return dict(cam_intr=g["K"], joints_3d=g[f"ann{i}.j3"], joints_2d=g[f"ann{i}.j2"], corners_3d=g[f"ann{i}.c3"],
+                    corners_2d=g[f"ann{i}.c2"], corners_can=g[f"ann{i}.can"], obj_transf=g[f"ann{i}.T"], obj_idx=int(g[f"ann{i}.obj_idx"]),
+                    side=str(g[f"ann{i}.side"]), bbox_center=g[f"ann{i}.bbox_center"], bbox_scale=float(g[f"ann{i}.bbox_scale"]))
+
+
+def _draws(g, i):
+    return dict(center=g[f"draw{i}.center"], scale=float(g[f"draw{i}.scale"]), rot=float(g[f"draw{i}.rot"]))
+
+
+def _image_close(got, ref_u8):
+    """got float [3,h,w] = k/255 - 0.5; ref uint8.  Exact up to nearest-neighbour ties at .0 source coordinates."""
+    k = np.round((got + 0.5) * 255).astype(np.int64)
+    assert np.abs((k / 255.0 - 0.5) - got).max() < 1e-6
+    return (k != ref_u8.astype(np.int64)).any(axis=0).mean()
+
+
+def test_gt_and_image_match_reference_getitem():
+    from artiboost_amd.realdata import assemble_real_gt
+    src = GoldenSource()
+    g = src.g
+    res = int(g["res"])
+    assert [str(g[f"ann{i}.side"]) for i in range(3)] == ["right", "left", "right"]
+    for i in range(3):
+        r = assemble_real_gt(src.get_annots(i), [res, res], src.raw_size, _draws(g, i), center_idx=0)
+        assert r["flip"] == (i == 1)
+        for k in GT:
+            np.testing.assert_allclose(r[k], g[f"sample{i}.{k}"], rtol=1e-5, atol=1e-5, err_msg=f"{i}.{k}")
+        assert r["obj_idx"] == int(g[f"sample{i}.obj_idx"])
+        inv = np.linalg.inv(np.vstack([r["affine"][:2], [0, 0, 1]]).astype(np.float64))[:2].reshape(-1)
+        img = ro.augment(src.get_image(i), g[f"draw{i}.order"], g[f"draw{i}.factor"], inv, float(g[f"draw{i}.blur"]), r["flip"], res, res)
+        assert _image_close(img, g[f"sample{i}.image"]) < 4e-3, i
+        assert not bool(g[f"sample{i}.is_synth"]) and int(g[f"sample{i}.obj_id"]) == -1
+
+
+@pytest.mark.gpu
+def test_real_batch_on_gpu_vs_oracle_and_reference():
+    from artiboost_amd.realdata import RealBatcher
+    src = GoldenSource()
+    g = src.g
+    res = int(g["res"])
+    rb = RealBatcher(src, {"IMAGE_SIZE": [res, res], "CENTER_IDX": 0, "BBOX_EXPAND_RATIO": 1.2}, compute_dtype=torch.float32)
+    draws = dict(center=np.stack([g[f"draw{i}.center"] for i in range(3)]), scale=np.array([float(g[f"draw{i}.scale"]) for i in range(3)]),
+                 rot=np.array([float(g[f"draw{i}.rot"]) for i in range(3)]), blur=np.array([float(g[f"draw{i}.blur"]) for i in range(3)], np.float32),
+                 order=np.stack([g[f"draw{i}.order"] for i in range(3)]), factor=np.stack([g[f"draw{i}.factor"] for i in range(3)]))
+    draws["blur"][2] = 0.0999            # make the blur act on one sample
+    pad = torch.zeros((3, res + 6, res + 8, 4), dtype=torch.float32, device="cuda")
+    b = rb.batch([0, 1, 2], draws, out_pad=pad)
+    host = rb.assemble([0, 1, 2], draws)
+    img = b["image"].cpu().numpy()
+    for i in range(3):
+        ref = ro.augment(src.get_image(i), draws["order"][i], draws["factor"][i], host["inv"][i], float(draws["blur"][i]), bool(host["flip"][i]), res, res)
+        np.testing.assert_array_equal(img[i], ref)                       # HIP == CPU oracle, bit for bit (incl. flip and blur)
+        if i < 2:
+            assert _image_close(img[i], g[f"sample{i}.image"]) < 4e-3    # == the reference's own output
+        for k in GT:
+            np.testing.assert_allclose(b[k][i].cpu().numpy(), g[f"sample{i}.{k}"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(pad[:, 3:-3, 3:-5, :3].permute(0, 3, 1, 2).cpu().numpy(), img)
+    assert not b["is_synth"].any() and (b["obj_id"] == -1).all() and b["obj_idx"].tolist() == [3, 4, 5]
+    # no augmentation: identity chain
+    rb0 = RealBatcher(src, {"IMAGE_SIZE": [res, res], "CENTER_IDX": 0}, aug=False, compute_dtype=torch.float32)
+    b0 = rb0.batch([0])
+    h0 = rb0.assemble([0])
+    ref0 = ro.augment(src.get_image(0), h0["order"][0], h0["factor"][0], h0["inv"][0], 0.0, False, res, res)
+    np.testing.assert_array_equal(b0["image"][0].cpu().numpy(), ref0)
+
+
+@pytest.mark.gpu
+def test_mixed_loader_batches():
+    """MixedDataset semantics with a static split: real rows first (is_synth False, CCV ids -1), synthetic rows after."""
+    import copy
+    from test_gpu_synth import _loader
+    from artiboost_amd.realdata import MixedLoader, RealBatcher
+    from artiboost_amd.synth import ArtiBoostLoader
+    src = GoldenSource()
+    assets, proto = _loader(size=64)
+    B = 8
+    n_synth = MixedLoader.n_synth_for(B, len(src), proto.synth_len)
+    synth = ArtiBoostLoader(assets, proto.cfg, proto.preset, n_synth, proto.synth_len, compute_dtype=torch.float32, random_seed=3)
+    synth.prepare()
+    real = RealBatcher(src, proto.preset, compute_dtype=torch.float32)
+    ml = MixedLoader(real, synth, B)
+    assert ml.n_real + ml.n_synth == B and ml.n_synth == n_synth and 0 < ml.n_real < B
+    seen_real = []
+    nb = 0
+    for batch in ml:
+        nb += 1
+        assert batch["image"].shape == (B, 3, 64, 64) and batch["image_nhwc4_padded"].shape == (B, 70, 72, 4)
+        assert batch["is_synth"].tolist() == [False] * ml.n_real + [True] * ml.n_synth
+        assert (batch["obj_id"][:ml.n_real] == -1).all() and (batch["obj_id"][ml.n_real:] >= 0).all()
+        assert batch["joints_3d"].shape == (B, 21, 3) and torch.isfinite(batch["image"]).all()
+        np.testing.assert_array_equal(batch["image_nhwc4_padded"][:, 3:-3, 3:-5, :3].permute(0, 3, 1, 2).cpu().numpy(), batch["image"].cpu().numpy())
+        seen_real += batch["sample_idx"][:ml.n_real].tolist()
+    assert nb == len(ml) and len(set(seen_real)) == len(seen_real)          # a permutation: no real sample twice per epoch
+    synth.synth_shutdown()
+    ml.update()
+    assert ml.n_real == B and ml.n_synth == 0
+    assert next(iter(ml))["is_synth"].sum() == 0
