@@ -151,3 +151,198 @@ class Evaluator:
 
     def __str__(self):
         return " | ".join(s for s in (str(m) for m in self._metrics_list) if s)
+
+
+# ============================================================================ eval / submit path
+@METRIC.register_module
+class Mean2DEPE(Mean3DEPE):
+    """anakin/metrics/meanepe.py:97-101: pixel errors, never scaled to millimetres."""
+
+    def __init__(self, **cfg):
+        super().__init__(**cfg)
+        self.to_millimeters = False
+
+
+class PCKMetric(Metric):
+    """anakin/metrics/pckmetric.py:12-143: per-keypoint Euclidean errors of the visible keypoints; mean EPE, PCK curve
+    over STEPS thresholds in [VAL_MIN, VAL_MAX], AUC by the trapezoid rule normalised by the area under 1."""
+    num_kp = 0
+    keys = ("", "", "")
+
+    def __init__(self, **cfg):
+        self.val_min, self.val_max, self.steps = cfg["VAL_MIN"], cfg["VAL_MAX"], cfg["STEPS"]
+        self.reset()
+
+    def reset(self):
+        self.data = [[] for _ in range(self.num_kp)]
+        self.count = 0
+
+    def feed(self, preds, targs, **kwargs):
+        kp, kt, kv = self.keys
+        p, t = preds[kp].detach(), targs[kt].to(preds[kp].device)
+        dist = torch.sqrt(torch.sum((p - t) ** 2, dim=-1)).cpu().numpy()           # (B, N)
+        vis = np.asarray(targs[kv].detach().cpu()).astype(bool)
+        assert dist.ndim == 2 and vis.shape == dist.shape
+        for i in range(self.num_kp):
+            self.data[i].extend(dist[vis[:, i], i].tolist())
+        self.count += dist.shape[0]
+
+    def _get_pck(self, kp_id, threshold):
+        if not self.data[kp_id]:
+            return None
+        return float(np.mean((np.array(self.data[kp_id]) <= threshold).astype("float")))
+
+    def get_pck_all(self, threshold):
+        vals = [v for v in (self._get_pck(i, threshold) for i in range(self.num_kp)) if v is not None]
+        return float(np.mean(np.array(vals))) if vals else float("nan")
+
+    def get_measures(self, **kwargs):
+        thresholds = np.array(np.linspace(self.val_min, self.val_max, self.steps))
+        area_under_one = np.trapezoid(np.ones_like(thresholds), thresholds)
+        epe, auc, curves = [], [], []
+        for i in range(self.num_kp):
+            if not self.data[i]:
+                continue
+            d = np.array(self.data[i])
+            epe.append(np.mean(d))
+            curve = np.array([np.mean((d <= t).astype("float")) for t in thresholds])
+            curves.append(curve)
+            auc.append(np.trapezoid(curve, thresholds) / area_under_one)
+        return {"epe_mean_per_kp": np.array(epe), "pck_curve_per_kp": np.array(curves), "auc_per_kp": np.array(auc),
+                "epe_mean_all": np.mean(np.array(epe)), "auc_all": np.mean(np.array(auc)), "thresholds": thresholds}
+
+
+def _pck(name, n, keys, label=None):
+    def __str__(self):
+        return f"{label}: {self.get_pck_all(0.02):6.4f}" if label else ""
+    return METRIC.register_module(type(name, (PCKMetric,), {"num_kp": n, "keys": keys, "__str__": __str__,
+                                                          "__doc__": "anakin/metrics/pckmetric.py:146-197"}))
+
+
+Hand3DPCKMetric = _pck("Hand3DPCKMetric", 21, ("joints_3d", "joints_3d", "joints_vis"), "hand3d pck")
+Hand2DPCKMetric = _pck("Hand2DPCKMetric", 21, ("joints_2d", "joints_2d", "joints_vis"))
+Obj3DPCKMetric = _pck("Obj3DPCKMetric", 8, ("corners_3d", "corners_3d", "corners_vis"), "obj3d pck")
+Obj2DPCKMetric = _pck("Obj2DPCKMetric", 8, ("corners_2d", "corners_2d", "corners_vis"))
+
+
+class _MSSDBase:
+    """Maximum symmetry-aware surface distance (anakin/metrics/bopAR.py:74-195, val_metric.py:235-327): per sample
+    min over the object's symmetry set of max over the model points of ||sym(gt) - pred||, batched per object class."""
+
+    def __init__(self, **cfg):
+        import json
+        from .criterions import get_symmetry_transformations
+        info = cfg.get("MODEL_INFO") or json.load(open(cfg["MODEL_INFO_PATH"], "r"))
+        step = cfg.get("MAX_SYM_DISC_STEP", 0.01)
+        self.n_obj = len(info)
+        self.mssd_use_corners = cfg.get("MSSD_USE_CORNERS", False)
+        self.use_ho3d_ycb = cfg.get("USE_HO3D_YCB", False)
+        self.center_idx = cfg["DATA_PRESET"]["CENTER_IDX"] if cfg.get("MSSD_USE_CENTER_IDX", False) else None
+        self.R, self.t = [], []
+        for i in range(1, self.n_obj + 1):
+            tr = get_symmetry_transformations(info[str(i)], step)
+            self.R.append(torch.Tensor(np.stack([x["R"] for x in tr])))
+            self.t.append(torch.Tensor(np.stack([x["t"] for x in tr])) / 1000.0)        # mm -> m
+
+    def per_object(self, preds, targs):
+        """Yields (obj_idx, mask, mssd [n] in metres)."""
+        dev = preds["box_rot_rotmat"].device
+        can_all = targs[Queries.CORNERS_CAN if self.mssd_use_corners else "obj_verts_can"].to(dev)
+        transf_all = targs[Queries.OBJ_TRANSF].to(dev)
+        obj_idx = targs[Queries.OBJ_IDX].to(dev)
+        for oi in range(1, self.n_obj + 1):
+            mask = obj_idx == oi
+            if not torch.any(mask):
+                continue
+            sym_R, sym_t = self.R[oi - 1].to(dev), self.t[oi - 1].to(dev)
+            can, transf = can_all[mask], transf_all[mask]
+            if not self.use_ho3d_ycb:
+                sym_can = (torch.einsum("kmn,bvn->bkmv", sym_R, can) + sym_t[None, :]).transpose(-2, -1)
+            else:
+                ext = torch.tensor([[1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0]], dtype=torch.float32, device=dev)
+                sym_can = (ext @ (torch.einsum("kmn,bnv->bkmv", sym_R, ext @ can.transpose(-2, -1)) + sym_t)).transpose(-2, -1)
+            sym_abs = (torch.einsum("bij,bklj->bkil", transf[:, :3, :3], sym_can) + transf[:, None, :3, 3:]).transpose(-2, -1)
+            if self.mssd_use_corners:
+                pred_abs = preds["corners_3d_abs"][mask]
+            else:
+                pred_abs = (preds["box_rot_rotmat"][mask] @ can.transpose(-2, -1)).transpose(-2, -1) + preds["boxroot_3d_abs"][mask]
+            if self.center_idx is None:
+                d = sym_abs - pred_abs.unsqueeze(1)
+            else:
+                d = ((sym_abs - targs[Queries.ROOT_JOINT].to(dev)[mask][:, None, None, :]) -
+                     (pred_abs - preds["joints_3d_abs"][mask][:, [self.center_idx]]).unsqueeze(1))
+            yield oi, mask, torch.norm(d, dim=-1).max(-1)[0].min(-1)[0].detach()
+
+
+@METRIC.register_module
+class AR(Metric):
+    """anakin/metrics/bopAR.py:15-61 with USE_MSSD (VSD / MSPD raise NotImplementedError in the reference too)."""
+
+    def __init__(self, **cfg):
+        if cfg.get("USE_VSD", False) or cfg.get("USE_MSPD", False):
+            raise NotImplementedError()
+        self.mssd = _MSSDBase(**cfg) if cfg.get("USE_MSSD", False) else None
+        self.reset()
+
+    def reset(self):
+        if self.mssd is not None:
+            self.objs_error = {i + 1: AverageMeter() for i in range(self.mssd.n_obj)}
+
+    def feed(self, preds, targs, **kwargs):
+        if self.mssd is None:
+            return
+        for oi, _, v in self.mssd.per_object(preds, targs):
+            self.objs_error[oi].update(v.sum().item(), n=v.numel())
+
+    @property
+    def avg(self):
+        s = sum(m.sum for m in self.objs_error.values())
+        c = sum(m.count for m in self.objs_error.values())
+        return s / c * 1000.0
+
+    def get_measures(self, **kwargs):
+        if self.mssd is None:
+            return {}
+        tag = ".corner" if self.mssd.mssd_use_corners else ""
+        out = {"MSSD": self.avg}
+        out.update({f"{i}{tag}.mssd": m.avg * 1000.0 for i, m in self.objs_error.items()})
+        return out
+
+    def __str__(self):
+        return f"mssd: {self.avg:6.4f}" if self.mssd is not None else ""
+
+
+@METRIC.register_module
+class ValMetricAR2(Metric):
+    """anakin/metrics/val_metric.py:145-222: per-(object, view, grasp) MSSD in mm of the synthetic samples (last write
+    wins), the second mining signal ArtiBoostLoader.get_evaluator_result accepts (artiboost_loader.py:301-327)."""
+
+    def __init__(self, **cfg):
+        if cfg.get("USE_VSD", False) or cfg.get("USE_MSPD", False):
+            raise NotImplementedError()
+        self.mssd = _MSSDBase(**cfg) if cfg.get("USE_MSSD", False) else None
+        self.reset()
+
+    def reset(self):
+        self.storage = {}
+
+    def feed(self, preds, targs, **kwargs):
+        if self.mssd is None:
+            return
+        synth = targs[SynthQueries.IS_SYNTH]
+        ids = torch.stack([targs[k] for k in (SynthQueries.OBJ_ID, SynthQueries.PERSP_ID, SynthQueries.GRASP_ID)], 1)
+        for _, mask, v in self.mssd.per_object(preds, targs):
+            mask = mask.cpu()
+            vals, flags, tid = (v * 1000.0).cpu().numpy(), np.asarray(synth[mask].cpu()).astype(bool), np.asarray(ids[mask].cpu())
+            for t, val, f in zip(tid, vals, flags):
+                if f:
+                    self.storage[tuple(int(x) for x in t)] = val
+
+    def get_measures(self, **kwargs):
+        return {"mssd": self.storage} if self.mssd is not None else {}
+
+    def get_measures_averaged(self, **kwargs):
+        return dict(self.storage)
+
+    def __str__(self):
+        return ""

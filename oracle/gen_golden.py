@@ -365,6 +365,80 @@ def po_aa(aa):
     return po.aa_to_rotmat(np.asarray(aa, np.float64)).astype(np.float32)
 
 
+def gen_eval_metrics(seed=31):
+    """Reference eval metrics on seeded predictions: PCK family (pckmetric.py), Mean2DEPE (meanepe.py), AR / MSSD (bopAR.py),
+    ValMetricAR2 (val_metric.py) and HOSubmitEpochPass.dump_json / get_order_idxs (hodata_submit_epoch_pass.py)."""
+    import json
+    import tempfile
+    ref_import.load_control_plane()
+    from anakin.metrics.pckmetric import Hand3DPCKMetric, Obj2DPCKMetric
+    from anakin.metrics.meanepe import Mean2DEPE
+    from anakin.metrics.bopAR import AR
+    from anakin.metrics.val_metric import ValMetricAR2
+    g = torch.Generator().manual_seed(seed)
+    B = 12
+    r = lambda *s: torch.randn(*s, generator=g)      # noqa: E731
+    targs = {"joints_3d": 0.05 * r(B, 21, 3), "joints_2d": 100 + 20 * r(B, 21, 2), "corners_3d": 0.05 * r(B, 8, 3),
+             "corners_2d": 100 + 20 * r(B, 8, 2), "joints_vis": (torch.rand(B, 21, generator=g) > 0.2).float(),
+             "corners_vis": (torch.rand(B, 8, generator=g) > 0.2).float(), "root_joint": 0.5 + 0.05 * r(B, 3),
+             "corners_can": 0.05 * r(B, 8, 3), "obj_idx": torch.randint(1, 4, (B,), generator=g),
+             "is_synth": torch.rand(B, generator=g) > 0.3, "obj_id": torch.randint(0, 3, (B,), generator=g),
+             "persp_id": torch.randint(0, 288, (B,), generator=g), "grasp_id": torch.randint(0, 50, (B,), generator=g)}
+    T = torch.eye(4).repeat(B, 1, 1)
+    T[:, :3, :3] = torch.from_numpy(po_aa(r(B, 3).numpy()))
+    T[:, :3, 3] = 0.5 + 0.05 * r(B, 3)
+    targs["obj_transf"] = T
+    preds = {"joints_3d": targs["joints_3d"] + 0.015 * r(B, 21, 3), "joints_2d": targs["joints_2d"] + 6 * r(B, 21, 2),
+             "corners_3d": targs["corners_3d"] + 0.015 * r(B, 8, 3), "corners_2d": targs["corners_2d"] + 6 * r(B, 8, 2),
+             "box_rot_rotmat": torch.from_numpy(po_aa(r(B, 3).numpy())), "boxroot_3d_abs": (T[:, :3, 3] + 0.01 * r(B, 3))[:, None],
+             "joints_3d_abs": targs["joints_3d"] + targs["root_joint"][:, None] + 0.01 * r(B, 21, 3)}
+    preds["corners_3d_abs"] = (T[:, :3, :3] @ targs["corners_can"].transpose(1, 2)).transpose(1, 2) + T[:, None, :3, 3] + 0.01 * r(B, 8, 3)
+    info = {"1": {}, "2": {"symmetries_discrete": [[-1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]]},
+            "3": {"symmetries_continuous": [{"axis": [0, 0, 1], "offset": [0, 0, 0]}]}}
+    out = {f"t.{k}": v.numpy() for k, v in targs.items()}
+    out.update({f"p.{k}": v.numpy() for k, v in preds.items()})
+    out["model_info"] = np.array(json.dumps(info))
+    pck_cfg = dict(VAL_MIN=0.0, VAL_MAX=0.05, STEPS=20)
+    for name, cls, cfg in (("hand3d", Hand3DPCKMetric, pck_cfg), ("obj2d", Obj2DPCKMetric, dict(VAL_MIN=0.0, VAL_MAX=30.0, STEPS=15))):
+        m = cls(**cfg)
+        m.feed(preds, targs); m.feed(preds, targs)
+        for k, v in m.get_measures().items():
+            out[f"{name}.{k}"] = np.asarray(v)
+        out[f"{name}.pck_all"] = np.asarray(m.get_pck_all(0.02 if name == "hand3d" else 10.0))
+    m = Mean2DEPE(VAL_KEYS=["joints_2d", "corners_2d"], MILLIMETERS=True)
+    m.feed(preds, targs)
+    out["mean2d"] = np.array([m.get_measures()[k] for k in ("joints_2d_mepe", "corners_2d_mepe")])
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(info, f)
+    ar_cfg = dict(USE_MSSD=True, MODEL_INFO_PATH=f.name, MAX_SYM_DISC_STEP=0.25, MSSD_USE_CORNERS=True, DATA_PRESET={"CENTER_IDX": 0})
+    for tag, extra in (("ar", {}), ("ar_center", {"MSSD_USE_CENTER_IDX": True}), ("ar_ycb", {"USE_HO3D_YCB": True})):
+        a = AR(**dict(ar_cfg, **extra))
+        a.feed(preds, targs)
+        meas = a.get_measures()
+        out[f"{tag}.keys"] = np.array(sorted(meas))
+        out[f"{tag}.vals"] = np.array([meas[k] for k in sorted(meas)])
+    v = ValMetricAR2(**ar_cfg)
+    v.feed(preds, targs)
+    avg = v.get_measures_averaged()
+    out["val_ar2.ids"] = np.array(sorted(avg))
+    out["val_ar2.vals"] = np.array([avg[k] for k in sorted(avg)])
+    # submission file
+    import types
+    sys.modules.setdefault("anakin.submit", types.ModuleType("anakin.submit")).__path__ = [f"{ref_import.REF_ROOT}/anakin/submit"]
+    try:
+        from anakin.submit.hodata_submit_epoch_pass import HOSubmitEpochPass
+        with tempfile.TemporaryDirectory() as d:
+            xyz = [x.numpy() for x in preds["joints_3d_abs"][:3]]
+            vts = [np.zeros((778, 3))] * 3
+            HOSubmitEpochPass.dump_json(None, os.path.join(d, "pred.json"), xyz, vts, codalab=False)
+            out["submit.json"] = np.array(open(os.path.join(d, "pred.json")).read())
+        out["submit.reorder"], out["submit.unorder"] = (np.asarray(x) for x in HOSubmitEpochPass.get_order_idxs())
+    except Exception as e:      # heavy import chain (fitting unit, viz): record why and keep the metric goldens
+        print("submit pass not importable:", repr(e)[:200])
+    np.savez_compressed(os.path.join(OUT, "eval_metrics.npz"), **out)
+    print("wrote eval_metrics", sorted(k for k in out if not k.startswith(("t.", "p."))))
+
+
 def gen_refiner(B=3, seed=4, n_iters=3):
     """HORefiner.forward of the real reference (refiner.py:181-224) on seeded grasps, weights from
     refiner_oracle.fill_params, third-party stand-ins as documented in ref_import.load_refiner."""
@@ -419,6 +493,9 @@ if __name__ == "__main__":
     if "--real" in sys.argv:
         gen_real_sample()
         sys.exit(0)
+    if "--eval" in sys.argv:
+        gen_eval_metrics()
+        sys.exit(0)
     gen_head_only()
     gen_misc()
     gen_learner("g224", 224, 28, 28, B=2, seed=1)
@@ -427,3 +504,4 @@ if __name__ == "__main__":
     gen_blacklist()
     gen_state_files()
     gen_real_sample()
+    gen_eval_metrics()
