@@ -361,11 +361,19 @@ class ArtiBoostLoader:
         self.cursor = 0
 
     # ------------------------------------------------------------------ CCV sampling (ovg_set.py:104-132,162-178)
-    def _sample_ccv(self):
-        # == torch.distributions.Categorical(w).sample((n,)) (ovg_set.py:113-114: multinomial with replacement over the
-        # normalised weights) but from the loader's own seeded generator, so every DDP rank draws the same epoch
-        w = self.sample_weight_map.reshape(-1)
-        idx = torch.multinomial(w / w.sum(), self.synth_len, replacement=True, generator=self.torch_gen)
+    def _sample_ccv(self, is_train=True):
+        # train: == torch.distributions.Categorical(w).sample((n,)) (ovg_set.py:113-114: multinomial with replacement over the
+        # normalised weights) but from the loader's own seeded generator, so every DDP rank draws the same epoch.
+        # val (OVGSet.val(), ovg_set.py:108-118): uniform over the non-blacklisted triplets WITHOUT replacement.
+        if is_train:
+            w = self.sample_weight_map.reshape(-1)
+            idx = torch.multinomial(w / w.sum(), self.synth_len, replacement=True, generator=self.torch_gen)
+        else:
+            w = torch.ones_like(self.sample_weight_map)
+            w[self.blacklist_map] = 0.0
+            if self.synth_len > int(w.sum()):
+                raise ValueError(f"val epoch of {self.synth_len} samples exceeds the {int(w.sum())} admissible CCV triplets")
+            idx = torch.multinomial(w.reshape(-1), self.synth_len, replacement=False, generator=self.torch_gen)
         o = torch.div(idx, self.n_persp * self.n_grasp, rounding_mode="floor")
         v = torch.div(idx, self.n_grasp, rounding_mode="floor") % self.n_persp
         g = idx % self.n_grasp
@@ -396,11 +404,11 @@ class ArtiBoostLoader:
         return bl
 
     # ------------------------------------------------------------------ epoch plan (host only; testable without a GPU)
-    def plan_epoch(self):
+    def plan_epoch(self, is_train=True):
         """Draw the epoch's CCV triplets and every per-sample random draw from the shared seed, then keep this rank's
         slice idx[rank::world] (SURVEY.md section 8e): all ranks consume identical RNG streams, so the union over ranks
         is exactly the single-process epoch and the slices are disjoint."""
-        o, v, g = self._sample_ccv()
+        o, v, g = self._sample_ccv(is_train)
         sl = slice(self.rank, None, self.world)
         rng = self.rng
         S_all = self.synth_len
@@ -423,7 +431,11 @@ class ArtiBoostLoader:
         return plan
 
     # ------------------------------------------------------------------ prepare(): per-epoch pose generation
-    def prepare(self, cache=None):
+    def generate_render_cache(self, is_train=True):
+        """artiboost_loader.py:352-400 under its own name: is_train=False draws the validation-mode epoch (OVGSet.val)."""
+        self.prepare(is_train=is_train)
+
+    def prepare(self, cache=None, is_train=True):
         """artiboost_loader.py:279-291,352-400: sample CCV triplets, generate poses (GPU, batches of 256), assemble GT
         (host), upload the epoch as device SoA tensors.  Under DDP every rank draws the same epoch (same seed) and
         keeps its own slice idx[rank::world].
@@ -434,7 +446,7 @@ class ArtiBoostLoader:
             return
         if self.mano is None:
             raise RuntimeError("ArtiBoostLoader.prepare() renders on the GPU: construct the loader with a cuda device")
-        plan = self.plan_epoch()
+        plan = self.plan_epoch(is_train)
         if cache is not None:
             S = len(cache["obj_id"])
             if S > len(plan["o"]):

@@ -53,6 +53,9 @@ def test_loader_masks_blacklisted_triplets(tmp_path):
     assert (ld.sample_weight_map[bl] == 0).all() and (ld.sample_weight_map[~bl] == 1).all()
     o, v, g = ld._sample_ccv()                                  # blacklisted triplets are never drawn
     assert not bl[o, v, g].any()
+    plan = ld.plan_epoch(is_train=False)                        # validation mode: without replacement, blacklist excluded
+    trip = list(zip(plan["o"].tolist(), plan["v"].tolist(), plan["g"].tolist()))
+    assert len(set(trip)) == len(trip) == 16 and not bl[plan["o"], plan["v"], plan["g"]].any()
     files = os.listdir(tmp_path / "CCV_blacklist")
     assert len(files) == 1
     # a second loader reads the cache instead of recomputing: plant a recognisable map
