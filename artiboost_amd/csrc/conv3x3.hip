@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if ((t == 1 || t == 2) && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB + LP) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // WAR on the ring stage restaged below: see conv_gemm2.hip
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (t + 2 < 9) issue_b(chunk, t + 2, (t + 2) % 3);

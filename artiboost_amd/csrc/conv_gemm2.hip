@@ -20,7 +20,10 @@ __device__ uint4 ab_zero_page[2];    // zero-initialised device memory: source o
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WM, int WN, int NBUF = 3>
+// STEM: A is the zero-bordered NHWC4 image; a K step covers TWO kernel rows (2 x 32 elements = 128 bytes per output pixel:
+// chunks 0..3 from image row 2p + 2s, chunks 4..7 from row 2p + 2s + 1, both starting at column 2q), four steps for the 7
+// rows + 1 row of padding; weight rows are [7][8][4] = 224 elements, the missing 32 are read from the zero page.
+template <int BM, int BN, int WM, int WN, int NBUF = 3, bool STEM = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g) {
     constexpr int NW = WM * WN, NT = 64 * NW;                // 4 or 8 waves: the LDS fill rate scales with the waves issuing loads
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;     // 32x32 MFMA tiles per wave
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         a_h[j] = p * g.a_sh; a_w[j] = q * g.a_sw;
         a_base[j] = (long)n * g.Ha * g.Wa;
         a_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;      // element offset of the logical chunk this lane fetches
+        if (STEM) { const int c = lslot ^ ((r >> 1) & 7); a_chunk[j] = ((c >> 2) << 16) | ((c & 3) * 8); }   // (row of the pair, offset)
         if (lslot == 0 && ii < IA) {
             int op = (n * g.Ho + p * g.out_sh + out_oh) * g.Wo + q * g.out_sw + out_ow;
             s_outpix[r] = a_ok[j] ? op : -1;
@@ -97,19 +101,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         b_off[j] = (long)(b_ok[j] ? col : 0) * g.ktot;
         b_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;
     }
-    const int nsteps = ntaps * g.cpt;
+    const int nsteps = STEM ? 4 : ntaps * g.cpt;
 
     auto issue = [&](int step, int buf) {
-        const int t = step / g.cpt, c0 = (step - t * g.cpt) * 64;
-        const int dh = s_tap[t], dw = s_tap[CG_MAXTAPS + t], ko = s_tap[2 * CG_MAXTAPS + t];
+        const int t = STEM ? 0 : step / g.cpt, c0 = STEM ? step * 64 : (step - t * g.cpt) * 64;
+        const int dh = STEM ? 0 : s_tap[t], dw = STEM ? 0 : s_tap[CG_MAXTAPS + t], ko = STEM ? 0 : s_tap[2 * CG_MAXTAPS + t];
         unsigned char* base = smem + buf * BUFSZ;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int ii = wave * NA + j;
             if (ii < IA) {
-                int hi = a_h[j] + dh, wi = a_w[j] + dw;
-                bool ok = a_ok[j] && (unsigned)hi < (unsigned)g.Ha && (unsigned)wi < (unsigned)g.Wa;
-                const bf16_t* src = ok ? (A + ((a_base[j] + (long)hi * g.Wa + wi) * g.Ca + c0 + a_chunk[j])) : zp;
+                const bf16_t* src;
+                if (STEM) {
+                    const int krow = 2 * step + (a_chunk[j] >> 16);                 // kernel row 0..7 (7 = padding)
+                    src = (a_ok[j] && krow < 7) ? A + ((a_base[j] + (long)(a_h[j] + krow) * g.Wa + a_w[j]) * 4 + (a_chunk[j] & 0xffff)) : zp;
+                } else {
+                    int hi = a_h[j] + dh, wi = a_w[j] + dw;
+                    bool ok = a_ok[j] && (unsigned)hi < (unsigned)g.Ha && (unsigned)wi < (unsigned)g.Wa;
+                    src = ok ? (A + ((a_base[j] + (long)hi * g.Wa + wi) * g.Ca + c0 + a_chunk[j])) : zp;
+                }
                 glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(base + ii * 1024)));
             }
         }
@@ -117,7 +127,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         for (int j = 0; j < NB; ++j) {
             const int ii = wave * NB + j;
             if (ii < IB) {
-                const bf16_t* src = b_ok[j] ? (Bw + (b_off[j] + ko + c0 + b_chunk[j])) : zp;
+                const bool ok = b_ok[j] && (!STEM || c0 + b_chunk[j] < g.ktot);
+                const bf16_t* src = ok ? (Bw + (b_off[j] + ko + c0 + b_chunk[j])) : zp;
                 glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(base + BM * 128 + ii * 1024)));
             }
         }
@@ -148,6 +159,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         else if (ahead == 2) wait_vm<(PD >= 3 ? 2 : 0) * L>();
         else if (ahead == 1) wait_vm<L>();
         else wait_vm<0>();
+        // WAR: the buffer restaged right after this barrier was read in the previous step; those ds_reads must have RETIRED
+        // (not merely issued) before any wave passes the barrier.  The compiler otherwise sinks the previous step's last MFMA
+        // -- and the lgkmcnt wait it needs -- below the barrier (seen in the ISA of the fully unrolled 4-step stem variant:
+        // sporadic wrong tiles, run-to-run different).  cdna_hip_programming.md: "raw s_barrier + lgkmcnt(0)".
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (step + PD < nsteps) { int nb = cur + PD; if (nb >= NBUF) nb -= NBUF; issue(step + PD, nb); }
@@ -284,6 +300,19 @@ static void pick_tile2(int M, int Cn, int nsteps, int* bm, int* bn) {
 int conv_gemm2_mtiles(int M, int Cn, int nsteps) {
     int bm, bn; pick_tile2(M, Cn, nsteps, &bm, &bn);
     return (M + bm - 1) / bm;
+}
+
+// bf16 stem (see the STEM note above the kernel): g as set up by ab_conv2d_stem_fwd (Ca = 4, a_sh = a_sw = 2, ktot = 224)
+int conv_gemm2_stem_mtiles(int M) { return (M + 127) / 128; }
+int conv_gemm2_stem_run(ConvGemmArgs& g, hipStream_t st) {
+    if (g.Cn != 64 || g.ktot != 224 || getenv("AB_STEM_V1")) return AB_ESHAPE;
+    g.nclass = 0; g.nmajor = 0; g.ntaps = 4; g.cpt = 1;
+    int tiles = (g.M + 127) / 128;
+    // two ring stages: the four K steps of a tile are latency-bound, and 49 KB of LDS lets three workgroups share a CU
+    // (110 us at B = 64, 256x256 vs 125 us with three stages and 130 us for the register-staged kernel)
+    conv_gemm2_kernel<128, 64, 4, 2, 2, true><<<tiles, 512, 0, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 int conv_gemm2_run(ConvGemmArgs& g, hipStream_t st) {

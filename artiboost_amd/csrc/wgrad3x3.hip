@@ -167,6 +167,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
     int buf = 0;
     for (int band = band_begin; band < band_end; ++band) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // WAR on the band buffer restaged below: see conv_gemm2.hip
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (band + 1 < band_end) issue_band(band + 1, buf ^ 1);
