@@ -22,6 +22,7 @@ import learner_oracle as lo  # noqa: E402
 OUT = os.path.join(HERE, "..", "tests", "golden")
 
 
+sys.path.insert(0, os.path.join(HERE, "..", "tests"))
 from gen_batch import make_batch  # noqa: E402
 
 

@@ -1,9 +1,10 @@
-"""Run the small end-to-end training twice per mode and report where losses start to differ (determinism check)."""
+"""TEST INFRASTRUCTURE (run by hand: python tests/det_check.py; BS=64 SIZE=256 for the benchmark geometry): the small
+end-to-end training of test_gpu_synth twice per mode, reporting where losses start to differ (determinism check)."""
 import os, sys, types
 import numpy as np, torch, pytest
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+HERE = os.path.dirname(os.path.abspath(__file__))
+for p in (HERE, os.path.join(HERE, ".."), os.path.join(HERE, "..", "oracle")):
+    sys.path.insert(0, p)
 import test_gpu_synth as T
 
 class MP:

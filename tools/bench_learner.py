@@ -7,7 +7,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))      # gen_batch: seeded inputs
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 
 ap = argparse.ArgumentParser()
