@@ -21,3 +21,43 @@ def test_ops_fail_loudly_without_device_tensors():
     from artiboost_amd.head import softargmax3d
     with pytest.raises(RuntimeError):
         softargmax3d(torch.zeros(1, 2, 2, 6), 2, 3)
+
+
+def test_only_tests_smoke_and_cpu_baseline_touch_the_oracle():
+    """oracle/ is test infrastructure: the package and the developer tools never import it; bench.py only inside its
+    cpu_baseline leg, __graft_entry__ only inside smoke()."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    oracle_modules = {os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(root, "oracle", "*.py"))}
+
+    def offenders(path, allowed_funcs=()):
+        tree = ast.parse(open(path).read())
+        bad = []
+        for node in ast.walk(tree):
+            for child in ast.iter_child_nodes(node):
+                child._parent = node
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name.split(".")[0] for a in node.names]
+            elif isinstance(node, ast.ImportFrom) and node.module:
+                names = [node.module.split(".")[0]]
+            if not (set(names) & oracle_modules):
+                continue
+            fn, cur = None, node
+            while hasattr(cur, "_parent"):
+                cur = cur._parent
+                if isinstance(cur, ast.FunctionDef):
+                    fn = cur.name
+            if fn not in allowed_funcs:
+                bad.append((os.path.relpath(path, root), node.lineno, names))
+        return bad
+
+    bad = []
+    for f in glob.glob(os.path.join(root, "artiboost_amd", "*.py")) + glob.glob(os.path.join(root, "tools", "*.py")):
+        bad += offenders(f)
+        assert "oracle" not in [p for p in open(f).read().split('"') if p.endswith("oracle")], f
+    bad += offenders(os.path.join(root, "bench.py"), allowed_funcs=("cpu_baseline",))
+    bad += offenders(os.path.join(root, "__graft_entry__.py"), allowed_funcs=("smoke",))
+    assert not bad, bad
