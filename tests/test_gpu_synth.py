@@ -265,3 +265,52 @@ def test_train_step_with_symcorner_loss(graph):
         vals.append(float(losses[5])); syms.append(float(o["sym_loss"][0]))
     assert np.isfinite(vals).all() and np.isfinite(syms).all() and syms[0] > 0
     assert vals[-1] < vals[0], vals
+
+
+def test_deferred_epoch_metrics_equal_per_step_feeding():
+    """DeferredEpochMetrics (one transfer per epoch) == evaluator.feed_all after every batch (train_artiboost.py:96-98)."""
+    import copy, os, yaml
+    from artiboost_amd import registry as R
+    from artiboost_amd.criterions import Criterion
+    from artiboost_amd.metrics import Evaluator
+    from artiboost_amd.models import Arch
+    from artiboost_amd.optim import FusedClipAdam
+    from artiboost_amd.train import DeferredEpochMetrics, TrainStep
+    assets, loader = _loader(torch.bfloat16, bs=8, n=32, size=64)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [64, 64], [8, 8]
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16")
+    model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
+    crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+    ev_a = Evaluator(cfg, R.build_evaluator_metric_list(cfg["EVALUATOR"], preset_cfg=cfg["DATA_PRESET"]))
+    ev_b = Evaluator(cfg, R.build_evaluator_metric_list(copy.deepcopy(cfg["EVALUATOR"]), preset_cfg=cfg["DATA_PRESET"]))
+    hb = model.model_list[0]
+    opt = FusedClipAdam(model.models_params, lr=1e-3, max_norm=1.0, model=hb)
+    loader.prepare()
+    static = loader.new_static_batch()
+    loader.load_batch(static, 0)
+    model.train()
+    ts = TrainStep(model, crit, opt, static, use_graph=True, renderer=loader)
+    rec = DeferredEpochMetrics(ts, 2 * len(loader))
+    for bi in list(range(len(loader))) * 2:          # every triplet twice: the later write must win in both evaluators
+        ts.stage(loader, bi)
+        preds, _, _ = ts()
+        ev_a.feed_all(preds, ts.static, ts.fused.losses_dict())
+        rec.collect()
+    rec.flush(ev_b)
+    ma, mb = ev_a.get_measures_all(), ev_b.get_measures_all()
+    assert set(ma) == set(mb)
+    for k in ma:
+        if isinstance(ma[k], dict):
+            assert set(ma[k]) == set(mb[k]) and len(ma[k]) > 0
+            for t in ma[k]:
+                np.testing.assert_allclose(mb[k][t], ma[k][t], rtol=2e-5)
+        else:
+            np.testing.assert_allclose(float(mb[k]), float(ma[k]), rtol=2e-5)
+    wa = copy.deepcopy(loader.sample_weight_map)
+    loader.step_eval(0, ev_a)
+    w1 = loader.sample_weight_map.clone()
+    loader.sample_weight_map = wa
+    loader.step_eval(0, ev_b)
+    np.testing.assert_allclose(loader.sample_weight_map.numpy(), w1.numpy(), rtol=1e-5)      # same mining update
