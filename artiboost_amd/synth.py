@@ -607,13 +607,18 @@ class ArtiBoostLoader:
             yield {k: v for k, v in static.items() if not k.startswith("_")}
 
     # ------------------------------------------------------------------ mining (artiboost_loader.py:292-340,503-598)
-    def step_eval(self, epoch_idx, evaluator):
-        from .metrics import ValMetricMean3DEPE2
-        res = [m.get_measures_averaged() for m in evaluator.metrics_list if isinstance(m, ValMetricMean3DEPE2)]
+    def get_evaluator_result(self, evaluator):
+        """artiboost_loader.py:301-327: average of the per-(object, view, grasp) measures of every validation metric."""
+        from .metrics import ValMetricAR2, ValMetricMean3DEPE2
+        res = [m.get_measures_averaged() for m in evaluator.metrics_list if isinstance(m, (ValMetricMean3DEPE2, ValMetricAR2))]
         if not res:
             raise ValueError("No validation metric have been found")
-        merged = {k: sum(r[k] for r in res) / len(res) for k in res[0]}
-        self.sample_reweight(merged, epoch_idx)
+        if not all(set(r) == set(res[0]) for r in res):
+            raise ValueError("some ccv space idx lost!")
+        return {k: sum(r[k] for r in res) / len(res) for k in res[0]}
+
+    def step_eval(self, epoch_idx, evaluator):
+        self.sample_reweight(self.get_evaluator_result(evaluator), epoch_idx)
 
     def sample_reweight(self, eval_res, epoch_idx):
         fn = {"method_1": self.update_method_1, "method_2": self.update_method_2, "method_3": self.update_method_3,
