@@ -188,3 +188,29 @@ def test_ddp_pieces_gloo_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True, True, True), (1, True, True, True)], res
+
+
+def test_assemble_gt_batch_equals_per_sample_assembly():
+    """The epoch-vectorised GT assembly == RenderedDataset.__getitem__'s per-sample arithmetic (assemble_gt, itself checked
+    against the reference golden above), including samples pushed out of the crop (visibility masks)."""
+    from artiboost_amd import synth
+    from artiboost_amd.registry import Queries
+    rng = np.random.default_rng(3)
+    S = 64
+    K = np.array([[435.0, 0, 256.0], [0, 435.0, 256.0], [0, 0, 1.0]])
+    joints = rng.uniform(-0.08, 0.08, (S, 21, 3)) + [0.0, 0.0, 0.5]
+    joints[::7, :, 0] += 0.5                                   # far off-centre: raw / cropped visibility rules kick in
+    pose = np.tile(np.eye(4), (S, 1, 1))
+    pose[:, :3, :3] = po.aa_to_rotmat(rng.standard_normal((S, 3)))
+    pose[:, :3, 3] = rng.uniform(-0.05, 0.05, (S, 3)) + [0.0, 0.0, 0.5]
+    pose[::5, 0, 3] += 0.6
+    can = rng.uniform(0.03, 0.08, (S, 1, 3)) * np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])[None]
+    cj, sj, rot = rng.uniform(-1, 1, (S, 2)), rng.normal(0, 0.1 / 3, S), rng.uniform(-0.2 * np.pi, 0.2 * np.pi, S)
+    got = synth.assemble_gt_batch(K, joints, pose, can, [256, 256], [512, 512], cj, sj, rot)
+    nz = 0
+    for i in range(S):
+        ref = synth.assemble_gt(K, joints[i], pose[i], can[i], [256, 256], [512, 512], cj[i], sj[i], rot[i])
+        for k, v in ref.items():
+            np.testing.assert_allclose(got[k][i], v, rtol=1e-6, atol=1e-5, err_msg=f"{i}.{k}")
+        nz += int(ref[Queries.JOINTS_VIS].sum() == 0) + int(ref[Queries.CORNERS_VIS].sum() == 0)
+    assert nz > 0                                              # the all-zero visibility branches were exercised
