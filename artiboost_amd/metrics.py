@@ -227,7 +227,9 @@ Obj2DPCKMetric = _pck("Obj2DPCKMetric", 8, ("corners_2d", "corners_2d", "corners
 
 class _MSSDBase:
     """Maximum symmetry-aware surface distance (anakin/metrics/bopAR.py:74-195, val_metric.py:235-327): per sample
-    min over the object's symmetry set of max over the model points of ||sym(gt) - pred||, batched per object class."""
+    min over the object's symmetry set of max over the model points of ||sym(gt) - pred||.  The reference loops over the
+    object classes with boolean masks (a device synchronisation per class); here the symmetry sets are padded to one
+    length with identities (the identity is in every set, so the minimum is unchanged) and the whole batch is one product."""
 
     def __init__(self, **cfg):
         import json
@@ -238,40 +240,41 @@ class _MSSDBase:
         self.mssd_use_corners = cfg.get("MSSD_USE_CORNERS", False)
         self.use_ho3d_ycb = cfg.get("USE_HO3D_YCB", False)
         self.center_idx = cfg["DATA_PRESET"]["CENTER_IDX"] if cfg.get("MSSD_USE_CENTER_IDX", False) else None
-        self.R, self.t = [], []
-        for i in range(1, self.n_obj + 1):
-            tr = get_symmetry_transformations(info[str(i)], step)
-            self.R.append(torch.Tensor(np.stack([x["R"] for x in tr])))
-            self.t.append(torch.Tensor(np.stack([x["t"] for x in tr])) / 1000.0)        # mm -> m
+        syms = [get_symmetry_transformations(info[str(i)], step) for i in range(1, self.n_obj + 1)]
+        kmax = max(len(x) for x in syms)
+        R = np.tile(np.eye(3), (self.n_obj, kmax, 1, 1))
+        t = np.zeros((self.n_obj, kmax, 3, 1))
+        for i, tr in enumerate(syms):
+            for k, x in enumerate(tr):
+                R[i, k], t[i, k] = x["R"], x["t"]
+        self.R, self.t = torch.Tensor(R), torch.Tensor(t) / 1000.0                 # mm -> m
+        self._dev = None
 
-    def per_object(self, preds, targs):
-        """Yields (obj_idx, mask, mssd [n] in metres)."""
+    def values(self, preds, targs):
+        """-> (obj_idx [B] int64 1-based, mssd [B] in metres), both on the predictions' device."""
         dev = preds["box_rot_rotmat"].device
-        can_all = targs[Queries.CORNERS_CAN if self.mssd_use_corners else "obj_verts_can"].to(dev)
-        transf_all = targs[Queries.OBJ_TRANSF].to(dev)
-        obj_idx = targs[Queries.OBJ_IDX].to(dev)
-        for oi in range(1, self.n_obj + 1):
-            mask = obj_idx == oi
-            if not torch.any(mask):
-                continue
-            sym_R, sym_t = self.R[oi - 1].to(dev), self.t[oi - 1].to(dev)
-            can, transf = can_all[mask], transf_all[mask]
-            if not self.use_ho3d_ycb:
-                sym_can = (torch.einsum("kmn,bvn->bkmv", sym_R, can) + sym_t[None, :]).transpose(-2, -1)
-            else:
-                ext = torch.tensor([[1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0]], dtype=torch.float32, device=dev)
-                sym_can = (ext @ (torch.einsum("kmn,bnv->bkmv", sym_R, ext @ can.transpose(-2, -1)) + sym_t)).transpose(-2, -1)
-            sym_abs = (torch.einsum("bij,bklj->bkil", transf[:, :3, :3], sym_can) + transf[:, None, :3, 3:]).transpose(-2, -1)
-            if self.mssd_use_corners:
-                pred_abs = preds["corners_3d_abs"][mask]
-            else:
-                pred_abs = (preds["box_rot_rotmat"][mask] @ can.transpose(-2, -1)).transpose(-2, -1) + preds["boxroot_3d_abs"][mask]
-            if self.center_idx is None:
-                d = sym_abs - pred_abs.unsqueeze(1)
-            else:
-                d = ((sym_abs - targs[Queries.ROOT_JOINT].to(dev)[mask][:, None, None, :]) -
-                     (pred_abs - preds["joints_3d_abs"][mask][:, [self.center_idx]]).unsqueeze(1))
-            yield oi, mask, torch.norm(d, dim=-1).max(-1)[0].min(-1)[0].detach()
+        if self._dev != dev:
+            self.R, self.t, self._dev = self.R.to(dev), self.t.to(dev), dev
+        can = targs[Queries.CORNERS_CAN if self.mssd_use_corners else "obj_verts_can"].to(dev)
+        transf = targs[Queries.OBJ_TRANSF].to(dev)
+        obj_idx = targs[Queries.OBJ_IDX].to(dev).long()
+        sym_R, sym_t = self.R[obj_idx - 1], self.t[obj_idx - 1]                      # [B,K,3,3], [B,K,3,1]
+        if not self.use_ho3d_ycb:
+            sym_can = (torch.einsum("bkmn,bvn->bkmv", sym_R, can) + sym_t).transpose(-2, -1)
+        else:
+            ext = torch.tensor([[1.0, 0.0, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0]], dtype=torch.float32, device=dev)
+            sym_can = (ext @ (torch.einsum("bkmn,bnv->bkmv", sym_R, ext @ can.transpose(-2, -1)) + sym_t)).transpose(-2, -1)
+        sym_abs = (torch.einsum("bij,bklj->bkil", transf[:, :3, :3], sym_can) + transf[:, None, :3, 3:]).transpose(-2, -1)
+        if self.mssd_use_corners:
+            pred_abs = preds["corners_3d_abs"]
+        else:
+            pred_abs = (preds["box_rot_rotmat"] @ can.transpose(-2, -1)).transpose(-2, -1) + preds["boxroot_3d_abs"]
+        if self.center_idx is None:
+            d = sym_abs - pred_abs.unsqueeze(1)
+        else:
+            d = ((sym_abs - targs[Queries.ROOT_JOINT].to(dev)[:, None, None, :]) -
+                 (pred_abs - preds["joints_3d_abs"][:, [self.center_idx]]).unsqueeze(1))
+        return obj_idx, torch.norm(d, dim=-1).max(-1)[0].min(-1)[0].detach()
 
 
 @METRIC.register_module
@@ -285,20 +288,33 @@ class AR(Metric):
         self.reset()
 
     def reset(self):
-        if self.mssd is not None:
-            self.objs_error = {i + 1: AverageMeter() for i in range(self.mssd.n_obj)}
+        self._sum = self._cnt = None
 
     def feed(self, preds, targs, **kwargs):
         if self.mssd is None:
             return
-        for oi, _, v in self.mssd.per_object(preds, targs):
-            self.objs_error[oi].update(v.sum().item(), n=v.numel())
+        obj_idx, v = self.mssd.values(preds, targs)
+        if self._sum is None:
+            self._sum = torch.zeros(self.mssd.n_obj, dtype=torch.float64, device=v.device)
+            self._cnt = torch.zeros(self.mssd.n_obj, dtype=torch.float64, device=v.device)
+        self._sum.index_add_(0, obj_idx - 1, v.double())                 # per-object sums stay on the device: no sync per step
+        self._cnt.index_add_(0, obj_idx - 1, torch.ones_like(v, dtype=torch.float64))
+
+    @property
+    def objs_error(self):
+        out = {i + 1: AverageMeter() for i in range(self.mssd.n_obj)}
+        if self._sum is not None:
+            for i, (s_, c_) in enumerate(zip(self._sum.cpu().tolist(), self._cnt.cpu().tolist())):
+                if c_:
+                    out[i + 1].update(s_, n=int(c_))
+        return out
 
     @property
     def avg(self):
-        s = sum(m.sum for m in self.objs_error.values())
-        c = sum(m.count for m in self.objs_error.values())
-        return s / c * 1000.0
+        if self._sum is None:
+            return float("nan")
+        c = float(self._cnt.sum())
+        return float(self._sum.sum()) / c * 1000.0 if c else float("nan")
 
     def get_measures(self, **kwargs):
         if self.mssd is None:
@@ -329,14 +345,14 @@ class ValMetricAR2(Metric):
     def feed(self, preds, targs, **kwargs):
         if self.mssd is None:
             return
-        synth = targs[SynthQueries.IS_SYNTH]
-        ids = torch.stack([targs[k] for k in (SynthQueries.OBJ_ID, SynthQueries.PERSP_ID, SynthQueries.GRASP_ID)], 1)
-        for _, mask, v in self.mssd.per_object(preds, targs):
-            mask = mask.cpu()
-            vals, flags, tid = (v * 1000.0).cpu().numpy(), np.asarray(synth[mask].cpu()).astype(bool), np.asarray(ids[mask].cpu())
-            for t, val, f in zip(tid, vals, flags):
-                if f:
-                    self.storage[tuple(int(x) for x in t)] = val
+        obj_idx, v = self.mssd.values(preds, targs)
+        order = torch.argsort(obj_idx, stable=True).cpu().numpy()        # the reference visits the object classes in order:
+        vals = (v * 1000.0).cpu().numpy()                                # later classes overwrite earlier ones on a repeated triplet
+        flags = np.asarray(targs[SynthQueries.IS_SYNTH].cpu()).astype(bool)
+        ids = np.stack([np.asarray(targs[k].cpu()) for k in (SynthQueries.OBJ_ID, SynthQueries.PERSP_ID, SynthQueries.GRASP_ID)], 1)
+        for i in order:
+            if flags[i]:
+                self.storage[tuple(int(x) for x in ids[i])] = vals[i]
 
     def get_measures(self, **kwargs):
         return {"mssd": self.storage} if self.mssd is not None else {}

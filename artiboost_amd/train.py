@@ -296,16 +296,27 @@ class DeferredEpochMetrics:
     of the epoch and replays the steps into the metrics in their original order, so Mean3DEPE, LossesMetric and
     ValMetricMean3DEPE2 (last write per CCV triplet wins) end up exactly as with per-step feeding."""
 
-    def __init__(self, ts: TrainStep, capacity: int):
+    def __init__(self, ts: TrainStep, capacity: int, evaluator=None):
         assert ts.fused is not None, "needs the fused criterion (per-sample EPE comes from ab_pose_loss)"
         self.ts, self.n = ts, 0
+        # metrics that need the full predictions (PCK, AR, ...) are still fed after every step
+        self.direct = [m for m in (evaluator.metrics_list if evaluator is not None else []) if not self._deferrable(m)]
         B, dev = ts.static[Queries.ROOT_JOINT].shape[0], ts.dev
         self.epe = torch.zeros((capacity, B, 2), dtype=torch.float32, device=dev)         # (joints, corners) mm
         self.losses = torch.zeros((capacity, 8), dtype=torch.float32, device=dev)
         self.ids = torch.zeros((capacity, B, 4), dtype=torch.int64, device=dev)           # obj, persp, grasp, is_synth
 
+    @staticmethod
+    def _deferrable(m):
+        from .metrics import LossesMetric, Mean3DEPE, ValMetricMean3DEPE2
+        if isinstance(m, (ValMetricMean3DEPE2, LossesMetric)):
+            return True
+        return type(m) is Mean3DEPE and m.to_millimeters and all(k in ("joints_3d_abs", "corners_3d_abs") for k in m.val_keys_list)
+
     def collect(self):
         o, st, i = self.ts.fused.out, self.ts.static, self.n
+        for m in self.direct:
+            m.feed(self.ts.out[0], st)
         self.epe[i].copy_(o["sample_part"][:, 5:7])
         self.losses[i].copy_(o["losses"])
         self.ids[i].copy_(torch.stack([st[SynthQueries.OBJ_ID], st[SynthQueries.PERSP_ID], st[SynthQueries.GRASP_ID],
@@ -319,13 +330,15 @@ class DeferredEpochMetrics:
         col = {"joints_3d_abs": 0, "corners_3d_abs": 1}
         keys = self.ts.fused.LOSS_KEYS
         for m in evaluator.metrics_list:
+            if m in self.direct:
+                continue
             if isinstance(m, ValMetricMean3DEPE2):
                 for key in m.val_keys_list:
                     for s in range(n):
                         for b in range(epe.shape[1]):
                             if ids[s, b, 3]:
                                 m.storage[key][tuple(int(x) for x in ids[s, b, :3])] = epe[s, b, col[key]]
-            elif isinstance(m, Mean3DEPE) and m.to_millimeters and all(k in col for k in m.val_keys_list):
+            elif isinstance(m, Mean3DEPE):
                 for key in m.val_keys_list:
                     for s in range(n):
                         m.avg_meters[key].update(float(epe[s, :, col[key]].sum()), n=epe.shape[1])

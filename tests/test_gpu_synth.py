@@ -292,7 +292,7 @@ def test_deferred_epoch_metrics_equal_per_step_feeding():
     loader.load_batch(static, 0)
     model.train()
     ts = TrainStep(model, crit, opt, static, use_graph=True, renderer=loader)
-    rec = DeferredEpochMetrics(ts, 2 * len(loader))
+    rec = DeferredEpochMetrics(ts, 2 * len(loader), ev_b)
     for bi in list(range(len(loader))) * 2:          # every triplet twice: the later write must win in both evaluators
         ts.stage(loader, bi)
         preds, _, _ = ts()

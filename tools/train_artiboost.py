@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--bs", type=int, default=64)
     ap.add_argument("--synth-len", type=int, default=1024, help="synthetic samples per epoch over all ranks (SYNTH_FACTOR x len(real) in the reference)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--dataset", default="", help="asset set: HO3D (4 objects) or DexYCB (21); default: from the config's OBJ_ORIGIN_DATASET")
     ap.add_argument("--dump", default="")
     ap.add_argument("--resume-epoch", type=int, default=0)
     ap.add_argument("--per-step-eval", action="store_true", help="feed the evaluator after every batch as the reference does "
@@ -57,7 +58,8 @@ def main():
     evaluator = Evaluator(cfg, R.build_evaluator_metric_list(cfg["EVALUATOR"], preset_cfg=cfg["DATA_PRESET"]))
     hb = model.model_list[0]
     opt = FusedClipAdam(model.models_params, lr=cfg["TRAIN"]["LR"], max_norm=cfg["TRAIN"]["GRAD_CLIP"], model=hb)
-    loader = ArtiBoostLoader(SceneAssets("HO3D", seed=1), dict(cfg["MANAGER"], EPOCH=args.epochs), cfg["DATA_PRESET"], args.bs,
+    dataset = args.dataset or cfg["MANAGER"].get("OBJ_ENGINE", {}).get("OBJ_ORIGIN_DATASET", "HO3D")
+    loader = ArtiBoostLoader(SceneAssets(dataset, seed=1), dict(cfg["MANAGER"], EPOCH=args.epochs), cfg["DATA_PRESET"], args.bs,
                              args.synth_len, device=dev, compute_dtype=hb.net.dtype, random_seed=cfg["TRAIN"]["MANUAL_SEED"],
                              rank=rank, world_size=world)
     if args.resume_epoch:
@@ -72,7 +74,7 @@ def main():
             loader.load_batch(static, 0)
             ts = TrainStep(model, crit, opt, static, use_graph=True, renderer=loader,
                            dist_group=torch.distributed.group.WORLD if world > 1 else None)
-            rec = None if args.per_step_eval else DeferredEpochMetrics(ts, len(loader))
+            rec = None if args.per_step_eval else DeferredEpochMetrics(ts, len(loader), evaluator)
         t0 = time.time()
         for bi in range(len(loader)):
             ts.stage(loader, bi)
