@@ -21,6 +21,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.hyper = None           # device float[3]; set by use_device_hyper() for hipGraph replay
         self._hyper_host = None
         self.graph_steps = 0
+        self._eager_hyper = None
 
     def use_device_hyper(self, device):
         self.hyper = torch.zeros(3, dtype=torch.float32, device=device)
@@ -29,12 +30,28 @@ class FusedClipAdam(torch.optim.Optimizer):
     def advance_hyper(self):
         """Host side of a replayed step: bump the step count and push {lr, bias corrections} to the device."""
         self.graph_steps += 1
+        for st in self.state.values():          # keep the eager step count in line (state_dict / a later eager step)
+            st["step"] = self.graph_steps
         g = self.param_groups[0]
         b1, b2 = g["betas"]
         self._hyper_host[0] = g["lr"]
         self._hyper_host[1] = 1.0 - b1 ** self.graph_steps
         self._hyper_host[2] = (1.0 - b2 ** self.graph_steps) ** 0.5
         self.hyper.copy_(self._hyper_host, non_blocking=True)
+
+    def state_dict(self):
+        """torch.optim state_dict (one flat parameter: exp_avg / exp_avg_sq are the flat Adam moments) + the replay step
+        count that drives the bias corrections under hipGraph replay."""
+        sd = super().state_dict()
+        sd["graph_steps"] = self.graph_steps
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        self.graph_steps = int(state_dict.pop("graph_steps", 0))
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            self.graph_steps = max(self.graph_steps, int(st.get("step", 0)))
 
     def grad_norm(self, grad):
         if self._part is None:
@@ -64,9 +81,15 @@ class FusedClipAdam(torch.optim.Optimizer):
                         self.model.net.lp = torch.empty(p.numel(), dtype=torch.bfloat16, device=p.device)
                     lp = self.model.net.lp
                 b1, b2 = group["betas"]
+                hyper = self.hyper
+                if hyper is None:        # eager step: the same host-computed {lr, bias corrections} a replayed step reads, so
+                    if self._eager_hyper is None or self._eager_hyper.device != p.device:      # both modes update identically
+                        self._eager_hyper = torch.zeros(3, dtype=torch.float32, device=p.device)
+                    hyper = self._eager_hyper
+                    hyper.copy_(torch.tensor([group["lr"], 1.0 - b1 ** st["step"], (1.0 - b2 ** st["step"]) ** 0.5], dtype=torch.float32))
                 L.check(L.lib().ab_clip_adam(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
                                              L.l(p.numel()), L.ptr(tn), L.f(self.max_norm or 0.0), L.f(group["lr"]),
-                                             L.f(b1), L.f(b2), L.f(group["eps"]), L.i(st["step"]), L.ptr(self.hyper),
+                                             L.f(b1), L.f(b2), L.f(group["eps"]), L.i(st["step"]), L.ptr(hyper),
                                              L.ptr(lp), L.stream()), "ab_clip_adam")
                 if self.model is not None and p is self.model.flat_param:
                     self.model.net.refresh_after_update(lp_fresh=lp is not None)

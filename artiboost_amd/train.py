@@ -173,7 +173,43 @@ class TrainStep:
         cur.wait_stream(self.comm_stream)
 
     # ------------------------------------------------------------------ capture
+    def _snapshot(self):
+        """Everything the capture warm-up step modifies: weights, BatchNorm running statistics, Adam moments and step counts,
+        and the host RNG streams the loss draws consume."""
+        import random
+        import numpy as np
+        store = self.hb.store
+        snap = dict(flat=store.flat.detach().clone(), stats=store.stats.clone(), nbt=store.num_batches_tracked,
+                    graph_steps=self.opt.graph_steps, rng=(random.getstate(), np.random.get_state(), torch.get_rng_state()), opt={})
+        for p, st in self.opt.state.items():
+            snap["opt"][p] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+        return snap
+
+    def _restore(self, snap):
+        import random
+        import numpy as np
+        store = self.hb.store
+        with torch.no_grad():
+            store.flat.copy_(snap["flat"])
+            store.stats.copy_(snap["stats"])
+        store.num_batches_tracked = snap["nbt"]
+        for p, st in self.opt.state.items():
+            old = snap["opt"].get(p)
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    v.copy_(old[k]) if old is not None else v.zero_()      # moments created by the warm-up start from zero
+                else:
+                    st[k] = old[k] if old is not None else 0
+        self.opt.graph_steps = snap["graph_steps"]
+        random.setstate(snap["rng"][0]); np.random.set_state(snap["rng"][1]); torch.set_rng_state(snap["rng"][2])
+        self.hb.net.pack_weights()                                         # compute-precision copies of the restored weights
+        torch.cuda.synchronize(self.dev)
+
     def _capture(self):
+        # The capture needs one real step first (allocator warm-up, lazily created optimizer state).  Its effects are undone
+        # afterwards, so a graph-replayed run is the same sequence of updates as the eager one, bit for bit, and a
+        # checkpoint can be loaded before the first step.
+        snap = self._snapshot()
         self.crit.draw(self.dev)
         self.opt.advance_hyper()
         self.opt.graph_steps = 0
@@ -212,7 +248,7 @@ class TrainStep:
             self.g_render = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_render, pool=self.g_fwd_bwd.pool(), capture_error_mode=CAPTURE_MODE):
                 self._render_next()
-        self.opt.graph_steps = 1            # the warm-up above performed one real update
+        self._restore(snap)
 
     # ------------------------------------------------------------------ public
     def stage(self, loader, batch_idx):

@@ -177,5 +177,5 @@ def test_graph_replayed_training_step_over_mixed_batches():
     assert np.isfinite(lg).all() and np.isfinite(le).all() and len(lg) >= 2
     np.testing.assert_array_equal(lg, lg2)            # replay is deterministic
     np.testing.assert_array_equal(wg, wg2)
-    # the capture warm-up takes optimizer steps of its own, so graph and eager runs see different weights; same scale though
-    assert 0.3 < lg[0, 5] / le[0, 5] < 3.0
+    np.testing.assert_array_equal(lg, le)             # the capture warm-up leaves no trace: graph == eager
+    np.testing.assert_array_equal(wg, we)

@@ -62,7 +62,10 @@ def main():
     loader = ArtiBoostLoader(SceneAssets(dataset, seed=1), dict(cfg["MANAGER"], EPOCH=args.epochs), cfg["DATA_PRESET"], args.bs,
                              args.synth_len, device=dev, compute_dtype=hb.net.dtype, random_seed=cfg["TRAIN"]["MANUAL_SEED"],
                              rank=rank, world_size=world)
-    if args.resume_epoch:
+    ckpt = os.path.join(args.dump, "checkpoints", "checkpoint") if args.dump else ""
+    if args.resume_epoch:        # utils/io_utils.py:19-44,73-93: <model type>.pth.tar + train_param.pth.tar, and the mining state
+        hb.load_state_dict(torch.load(os.path.join(ckpt, "HybridBaseline.pth.tar"), map_location=dev))
+        opt.load_state_dict(torch.load(os.path.join(ckpt, "train_param.pth.tar"), map_location=dev)["optimizer"])
         ccv_cache.resume_artiboost_loader(loader, args.resume_epoch, args.dump)
     model.train()
     ts = rec = None
@@ -94,6 +97,9 @@ def main():
                   f"weights min {float(w.min()):.2f} max {float(w.max()):.2f} | explored {float(loader.occurence_map.float().mean()):.3f}", flush=True)
             if args.dump:
                 ccv_cache.record_artiboost_loader(loader, epoch, args.dump)
+                os.makedirs(ckpt, exist_ok=True)
+                torch.save(hb.state_dict(), os.path.join(ckpt, "HybridBaseline.pth.tar"))          # the reference's keys and layouts
+                torch.save({"epoch": epoch + 1, "optimizer": opt.state_dict()}, os.path.join(ckpt, "train_param.pth.tar"))
     if world > 1:
         torch.distributed.destroy_process_group()
 
