@@ -570,6 +570,10 @@ class ArtiBoostLoader:
         # what CacheRecorder would have pickled for this epoch (ccv_cache.export_epoch writes it in the reference's format)
         self.epoch_poses = dict(index=plan["global_index"], obj_id=o, persp_id=v, grasp_id=g, obj_pose=obj_pose_d,
                                 hand_verts=verts_d, hand_joints=joints_d)
+        # last global sample index at which this rank sees each triplet (only whole batches are trained on): gather_ccv_results
+        n_used = (S // self.batch_size) * self.batch_size
+        self._last_seen = {(int(a_), int(b_), int(c_)): int(gi) for a_, b_, c_, gi in
+                           zip(o[:n_used], v[:n_used], g[:n_used], plan["global_index"][:n_used])}
         # ---- host: GT assembly + render descriptors
         samples = np.zeros(S, SAMPLE_DTYPE)
         samples["obj_id"], samples["hand_tex_id"], samples["bg_id"] = o, a["hid"], a["bid"]
@@ -691,7 +695,26 @@ class ArtiBoostLoader:
             raise ValueError("No validation metric have been found")
         if not all(set(r) == set(res[0]) for r in res):
             raise ValueError("some ccv space idx lost!")
-        return {k: sum(r[k] for r in res) / len(res) for k in res[0]}
+        merged = {k: sum(r[k] for r in res) / len(res) for k in res[0]}
+        return self.gather_ccv_results(merged)
+
+    def gather_ccv_results(self, local):
+        """SURVEY.md section 8e(3): under data parallelism every rank has measured only its slice idx[rank::world] of the epoch.
+        All ranks exchange their {(o, v, g): value} dicts (one all_gather_object per epoch, <= synth_len entries) and resolve a
+        triplet seen by several ranks as the single-process run would: the occurrence with the highest global sample index
+        wins ("last write wins", val_metric.py:50-51).  Every rank then applies the identical mining update."""
+        if self.world <= 1 or not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return local
+        last = getattr(self, "_last_seen", {})
+        payload = {k: (float(v), int(last.get(k, -1))) for k, v in local.items()}
+        gathered = [None] * self.world
+        torch.distributed.all_gather_object(gathered, payload)
+        out, best = {}, {}
+        for part in gathered:                       # rank order; ties cannot happen (global indices are unique)
+            for k, (v, gi) in part.items():
+                if k not in best or gi > best[k]:
+                    best[k], out[k] = gi, v
+        return out
 
     def step_eval(self, epoch_idx, evaluator):
         self.sample_reweight(self.get_evaluator_result(evaluator), epoch_idx)

@@ -172,7 +172,22 @@ def _worker(rank, world, port, q):
     gathered = [None] * world
     dist.all_gather_object(gathered, idx.tolist())
     ok3 = sorted(sum(gathered, [])) == list(range(40))
-    q.put((rank, bool(ok1), bool(ok2), bool(ok3)))
+    # (3) mining results: every rank ends with the single-process dict (highest global index wins on shared triplets)
+    o_, v_, g_ = full["o"], full["v"], full["g"]
+    o_[7], v_[7], g_[7] = o_[2], v_[2], g_[2]                 # a triplet seen by both ranks (global samples 2 and 7)
+    vals = np.arange(40, dtype=np.float64) + 0.5               # "error" of global sample i
+    single = {}
+    for i in range(40):
+        single[(int(o_[i]), int(v_[i]), int(g_[i]))] = vals[i]
+    local = {}
+    ld._last_seen = {}
+    for i in idx:
+        t = (int(o_[i]), int(v_[i]), int(g_[i]))
+        local[t] = vals[i]
+        ld._last_seen[t] = int(i)
+    merged = ld.gather_ccv_results(local)
+    ok4 = merged == single and ld1.gather_ccv_results(single) is single
+    q.put((rank, bool(ok1), bool(ok2), bool(ok3 and ok4)))
     dist.destroy_process_group()
 
 
