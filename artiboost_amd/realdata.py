@@ -186,11 +186,14 @@ class MixedLoader:
     """MixedDataset (mixed_dataset.py:5-37) + the shuffling DataLoader of train_artiboost.py, with a STATIC per-batch split:
     every batch holds n_real = round(B * real_len / (real_len + synth_len)) real samples (a random permutation of the real
     set over the epoch) followed by B - n_real synthetic ones (the epoch's CCV draws, already i.i.d.), instead of a
-    hypergeometric count per batch -- fixed shapes keep the step replayable as a hipGraph.  `remove_synth()` ==
-    ArtiBoostLoader.synth_shutdown: real samples only."""
+    hypergeometric count per batch -- fixed shapes keep the step replayable as a hipGraph.  After
+    ArtiBoostLoader.synth_shutdown() + update(): real samples only (MixedDataset.remove_synth).  Under data parallelism the
+    real set is sharded like a DistributedSampler (shared permutation, rank r takes perm[r::world]); the synthetic loader
+    shards its own epoch the same way."""
 
-    def __init__(self, real: RealBatcher, synth_loader, batch_size, seed=1):
+    def __init__(self, real: RealBatcher, synth_loader, batch_size, seed=1, rank=0, world_size=1):
         self.real, self.synth, self.B = real, synth_loader, batch_size
+        self.rank, self.world = rank, world_size      # DistributedSampler semantics: one shared permutation, rank r keeps perm[r::world]
         self.rng = np.random.default_rng(seed)
         self.update()
 
@@ -208,11 +211,11 @@ class MixedLoader:
         return batch_size - int(round(batch_size * real_len / (real_len + synth_len)))
 
     def __len__(self):
-        n = self.real_len // self.n_real if self.n_real else 0
+        n = len(range(self.rank, self.real_len, self.world)) // self.n_real if self.n_real else 0
         return min(n, len(self.synth)) if self.n_synth else n
 
     def __iter__(self):
-        perm = self.rng.permutation(self.real_len)
+        perm = self.rng.permutation(self.real_len)[self.rank::self.world]      # same seed on every rank -> disjoint slices
         W, H = self.real.image_size
         static = self.synth.new_static_batch() if self.n_synth else None
         for bi in range(len(self)):

@@ -123,6 +123,13 @@ def test_mixed_loader_batches():
         np.testing.assert_array_equal(batch["image_nhwc4_padded"][:, 3:-3, 3:-5, :3].permute(0, 3, 1, 2).cpu().numpy(), batch["image"].cpu().numpy())
         seen_real += batch["sample_idx"][:ml.n_real].tolist()
     assert nb == len(ml) and len(set(seen_real)) == len(seen_real)          # a permutation: no real sample twice per epoch
+    # data-parallel sharding of the real set: disjoint slices of one shared permutation
+    shards = []
+    for r in range(2):
+        mr = MixedLoader(real, synth, B, seed=7, rank=r, world_size=2)
+        shards.append(mr.rng.permutation(mr.real_len)[r::2].tolist())
+        assert len(mr) == min(len(shards[-1]) // mr.n_real, len(synth))
+    assert not set(shards[0]) & set(shards[1]) and sorted(shards[0] + shards[1]) == list(range(len(src)))
     synth.synth_shutdown()
     ml.update()
     assert ml.n_real == B and ml.n_synth == 0
