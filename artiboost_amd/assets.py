@@ -122,16 +122,37 @@ def make_hand_model(seed=1):
     Jreg /= Jreg.sum(1, keepdims=True)
     uv = np.stack([(np.arctan2(v_template[:, 2], v_template[:, 0]) / (2 * np.pi)) % 1.0,
                    np.clip((v_template[:, 1] + 0.06) / 0.2, 0, 0.999)], 1)
+    # UV seam: a triangle that straddles the u = 0/1 wrap would interpolate across the whole texture.  As in a textured
+    # mesh loaded through trimesh (FMesh.from_trimesh; renderer.py:17-28 get_mapping), the vertices on the low side of such
+    # triangles are DUPLICATED with u + 1: render vertices V_dup = 778 + duplicates, `map` takes a render vertex to the
+    # MANO vertex whose position it shares; uv / normals are per render vertex, faces index render vertices.
+    render_faces = fcs.copy()
+    vmap, dup_of = list(range(778)), {}
+    uv_list, nrm = [tuple(x) for x in uv], _vertex_normals(v_template, fcs)
+    for fi, face in enumerate(fcs):
+        us = uv[face, 0]
+        if us.max() - us.min() > 0.5:
+            for k, vtx in enumerate(face):
+                if uv[vtx, 0] < 0.5:
+                    if vtx not in dup_of:
+                        dup_of[vtx] = len(vmap)
+                        vmap.append(int(vtx))
+                        uv_list.append((uv[vtx, 0] + 1.0, uv[vtx, 1]))
+                    render_faces[fi, k] = dup_of[vtx]
+    vmap = np.asarray(vmap, np.int32)
+    uv = np.asarray(uv_list)
+    fcs_render = render_faces.astype(np.int32)
     return {
         "v_template": v_template.astype(np.float32),
         "shapedirs": (1e-3 * rng.standard_normal((778, 3, 10))).astype(np.float32),
         "posedirs": (1e-4 * rng.standard_normal((778, 3, 135))).astype(np.float32),
         "J_regressor": Jreg.astype(np.float32),
         "weights": w.astype(np.float32),
-        "faces": fcs,
+        "faces": fcs_render,                                               # [1538,3] indices into the V_dup render vertices
+        "map": vmap,                                                        # [V_dup] render vertex -> MANO vertex (hand_mapping)
         "hands_mean": np.zeros(45, dtype=np.float32),
-        "uv": uv.astype(np.float32),
-        "normals": _vertex_normals(v_template, fcs).astype(np.float32),    # rest-pose normals (frender_utils.py:139)
+        "uv": uv.astype(np.float32),                                        # [V_dup,2]
+        "normals": nrm[vmap].astype(np.float32),    # [V_dup,3] rest-pose normals (frender_utils.py:139)
     }
 
 

@@ -28,7 +28,7 @@
 #define BIN_CAP 1024      // per-tile triangle list capacity (overflowing tiles fall back to scanning all records)
 
 struct SceneDev {    // mirrors ab_scene (host struct of device pointers)
-    const int32_t* hand_faces; const float* hand_normals; const float* hand_uv; const uint8_t* hand_tex; int hts;
+    const int32_t* hand_faces; const float* hand_normals; const float* hand_uv; const int32_t* hand_map; const uint8_t* hand_tex; int hts;
     const float* obj_verts; const float* obj_normals; const float* obj_uv; const int32_t* obj_faces;
     const int32_t* obj_vert_off; const int32_t* obj_face_off; const uint8_t* obj_tex; int ots;
     const uint8_t* bg; int bgs; const float* srgb2lin; const uint8_t* lin2srgb;
@@ -55,8 +55,9 @@ __device__ __forceinline__ void face_verts(const SceneDev& sc, const SampleDev& 
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             int v = sc.hand_faces[gid * 3 + k];
-            vid[k] = v;
-            P[k][0] = hv[v * 3]; P[k][1] = hv[v * 3 + 1]; P[k][2] = hv[v * 3 + 2];
+            vid[k] = v;                                         // render vertex: uv / normal index
+            const int pv = sc.hand_map ? sc.hand_map[v] : v;    // MANO vertex sharing its position (UV-seam duplicates)
+            P[k][0] = hv[pv * 3]; P[k][1] = hv[pv * 3 + 1]; P[k][2] = hv[pv * 3 + 2];
         }
     } else {
         int o = sm.obj_id;
@@ -630,6 +631,7 @@ __global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restr
 static SceneDev to_dev(const ab_scene* s) {
     SceneDev d;
     d.hand_faces = (const int32_t*)s->hand_faces; d.hand_normals = (const float*)s->hand_normals; d.hand_uv = (const float*)s->hand_uv;
+    d.hand_map = (const int32_t*)s->hand_map;
     d.hand_tex = (const uint8_t*)s->hand_tex; d.hts = s->hts; d.obj_verts = (const float*)s->obj_verts;
     d.obj_normals = (const float*)s->obj_normals; d.obj_uv = (const float*)s->obj_uv; d.obj_faces = (const int32_t*)s->obj_faces;
     d.obj_vert_off = (const int32_t*)s->obj_vert_off; d.obj_face_off = (const int32_t*)s->obj_face_off;

@@ -14,7 +14,7 @@ SAMPLE_DTYPE = np.dtype([("obj_id", "<i4"), ("hand_tex_id", "<i4"), ("bg_id", "<
 
 class _Scene(ctypes.Structure):
     _fields_ = [("hand_faces", ctypes.c_void_p), ("hand_normals", ctypes.c_void_p), ("hand_uv", ctypes.c_void_p),
-                ("hand_tex", ctypes.c_void_p), ("hts", ctypes.c_int), ("obj_verts", ctypes.c_void_p),
+                ("hand_map", ctypes.c_void_p), ("hand_tex", ctypes.c_void_p), ("hts", ctypes.c_int), ("obj_verts", ctypes.c_void_p),
                 ("obj_normals", ctypes.c_void_p), ("obj_uv", ctypes.c_void_p), ("obj_faces", ctypes.c_void_p),
                 ("obj_vert_off", ctypes.c_void_p), ("obj_face_off", ctypes.c_void_p), ("obj_tex", ctypes.c_void_p),
                 ("ots", ctypes.c_int), ("bg", ctypes.c_void_p), ("bgs", ctypes.c_int), ("srgb2lin", ctypes.c_void_p),
@@ -47,6 +47,7 @@ class DeviceRenderer:
         h = assets.hand
         s2l, l2s = color_luts()
         host = dict(hand_faces=np.ascontiguousarray(h["faces"], np.int32), hand_normals=h["normals"], hand_uv=h["uv"],
+                    hand_map=np.ascontiguousarray(h["map"], np.int32),
                     hand_tex=assets.hand_tex, obj_verts=assets.obj_verts, obj_normals=assets.obj_normals,
                     obj_uv=assets.obj_uv, obj_faces=assets.obj_faces, obj_vert_off=assets.obj_vert_off,
                     obj_face_off=assets.obj_face_off, obj_tex=assets.obj_tex, bg=_rgbx(assets.backgrounds), srgb2lin=s2l,

@@ -187,6 +187,9 @@ int ab_pose_loss_sym(const float* kp3d, const float* box6d, int box_stride, cons
  *           anakin/artiboost/render_infra.py:14-59 (render server + two queue hops per image),
  *           anakin/artiboost/rendered_dataset.py:256-270 + anakin/utils/img_augment.py:6-80 (PIL jitter, affine, to_tensor)
  * ab_scene: HOST struct of DEVICE pointers to the immutable assets (one packed table for all object meshes).
+ *   The hand mesh has V_dup >= 778 render vertices (UV-seam duplicates, as a textured trimesh has): hand_faces int32 [1538,3]
+ *   index them, hand_uv [V_dup,2] / hand_normals [V_dup,3] are per render vertex, hand_map int32 [V_dup] gives the MANO
+ *   vertex whose position a render vertex takes (renderer.py:17-28 get_mapping, :107 update_verts); NULL = identity.
  * samples : device array of 96-byte records {int32 obj_id, hand_tex_id, bg_id, bg_x0, bg_y0, bg_w, bg_h; float light;
  *           float obj_pose[16] (row-major 4x4)}.  hand_verts: float [B,778,3] camera frame.
  * The background is the record's crop rectangle resized to the render size with cv2.resize's INTER_LINEAR fixed-point
@@ -199,7 +202,7 @@ int ab_pose_loss_sym(const float* kp3d, const float* box6d, int box_stride, cons
  * out_chw: optional float [B,3,oh,ow] (the reference's `image` tensor).  keys_out (optional) uint64 [B,H,W]:
  * depth24<<32 | face id, ~0 = background.  rgbx_out (optional) uint8 [B,H,W,4] pre-jitter render.                 */
 typedef struct ab_scene {
-    const void* hand_faces; const void* hand_normals; const void* hand_uv; const void* hand_tex; int hts;
+    const void* hand_faces; const void* hand_normals; const void* hand_uv; const void* hand_map; const void* hand_tex; int hts;
     const void* obj_verts; const void* obj_normals; const void* obj_uv; const void* obj_faces;
     const void* obj_vert_off; const void* obj_face_off; const void* obj_tex; int ots;
     const void* bg; int bgs; const void* srgb2lin; const void* lin2srgb;

@@ -37,9 +37,10 @@
 
 typedef struct {
     const float* hand_verts;   /* [B,778,3] camera frame */
-    const int32_t* hand_faces; /* [1538,3] */
-    const float* hand_normals; /* [778,3] rest pose */
-    const float* hand_uv;      /* [778,2] */
+    const int32_t* hand_faces; /* [1538,3] indices into the V_dup render vertices */
+    const float* hand_normals; /* [V_dup,3] rest pose */
+    const float* hand_uv;      /* [V_dup,2] */
+    const int32_t* hand_map;   /* [V_dup] render vertex -> MANO vertex (UV-seam duplicates; renderer.py:17-28,107) or NULL */
     const uint8_t* hand_tex;   /* [nht, hts, hts, 3] */
     int hts;
     const float* obj_verts;    /* [Vtot,3] */
@@ -81,8 +82,9 @@ static void face_verts(const ro_scene* sc, const ro_sample* sm, const float* hv,
     if (gid < HAND_FACES) {
         for (int k = 0; k < 3; ++k) {
             int v = sc->hand_faces[gid * 3 + k];
+            const int pv = sc->hand_map ? sc->hand_map[v] : v;     /* position from the MANO vertex, attributes from the render vertex */
             vid[k] = v;
-            P[k][0] = hv[v * 3]; P[k][1] = hv[v * 3 + 1]; P[k][2] = hv[v * 3 + 2];
+            P[k][0] = hv[pv * 3]; P[k][1] = hv[pv * 3 + 1]; P[k][2] = hv[pv * 3 + 2];
         }
     } else {
         int o = sm->obj_id;

@@ -11,7 +11,7 @@ SO = os.path.join(HERE, "_build", "librender_oracle.so")
 
 class Scene(ctypes.Structure):
     _fields_ = [("hand_verts", ctypes.c_void_p), ("hand_faces", ctypes.c_void_p), ("hand_normals", ctypes.c_void_p),
-                ("hand_uv", ctypes.c_void_p), ("hand_tex", ctypes.c_void_p), ("hts", ctypes.c_int),
+                ("hand_uv", ctypes.c_void_p), ("hand_map", ctypes.c_void_p), ("hand_tex", ctypes.c_void_p), ("hts", ctypes.c_int),
                 ("obj_verts", ctypes.c_void_p), ("obj_normals", ctypes.c_void_p), ("obj_uv", ctypes.c_void_p),
                 ("obj_faces", ctypes.c_void_p), ("obj_vert_off", ctypes.c_void_p), ("obj_face_off", ctypes.c_void_p),
                 ("obj_tex", ctypes.c_void_p), ("ots", ctypes.c_int), ("bg", ctypes.c_void_p), ("bgs", ctypes.c_int),
@@ -51,7 +51,8 @@ class SceneHolder:
         h = assets.hand
         self.arrs = dict(
             hand_faces=np.ascontiguousarray(h["faces"], np.int32), hand_normals=np.ascontiguousarray(h["normals"], np.float32),
-            hand_uv=np.ascontiguousarray(h["uv"], np.float32), hand_tex=np.ascontiguousarray(assets.hand_tex),
+            hand_uv=np.ascontiguousarray(h["uv"], np.float32), hand_map=np.ascontiguousarray(h["map"], np.int32),
+            hand_tex=np.ascontiguousarray(assets.hand_tex),
             obj_verts=np.ascontiguousarray(assets.obj_verts, np.float32), obj_normals=np.ascontiguousarray(assets.obj_normals, np.float32),
             obj_uv=np.ascontiguousarray(assets.obj_uv, np.float32), obj_faces=np.ascontiguousarray(assets.obj_faces, np.int32),
             obj_vert_off=np.ascontiguousarray(assets.obj_vert_off, np.int32), obj_face_off=np.ascontiguousarray(assets.obj_face_off, np.int32),
