@@ -11,7 +11,7 @@ import torch
 
 from . import _lib as L
 from .registry import Queries, SynthQueries
-from .synth import get_affine_transform
+from .synth import get_affine_transform, gt_core_batch
 
 
 class HOdataSource:
@@ -88,6 +88,32 @@ def assemble_real_gt(ann, image_size, raw_size, draws, center_idx=0, bbox_expand
     return out
 
 
+def assemble_real_gt_batch(anns, image_size, raw_size, draws, center_idx=0, bbox_expand=1.2, center_jit=0.1, scale_jit=0.1,
+                           sides="right", train_split=True):
+    """assemble_real_gt for a list of annotation dicts at once (numpy-vectorised; same arithmetic)."""
+    st = lambda k: np.stack([np.asarray(a[k], np.float64) for a in anns])      # noqa: E731
+    S = len(anns)
+    flip = np.array([a["side"] != sides for a in anns])
+    center, scale = st("bbox_center"), np.array([float(a["bbox_scale"]) for a in anns]) * bbox_expand
+    j3, j2, c3, c2 = st("joints_3d"), st("joints_2d"), st("corners_3d"), st("corners_2d")
+    raw_j2, raw_c2 = j2.copy(), c2.copy()
+    center[flip, 0] = raw_size[0] - center[flip, 0]                              # hodata.py:336-343
+    j3[flip, :, 0] *= -1
+    c3[flip, :, 0] *= -1
+    j2[flip, :, 0] = raw_size[0] - j2[flip, :, 0]
+    c2[flip, :, 0] = raw_size[0] - c2[flip, :, 0]
+    rot = np.zeros(S)
+    if draws is not None:                                                        # hodata.py:346-359
+        center = center + (center_jit * scale[:, None] * np.asarray(draws["center"])).astype(int)
+        scale = scale * np.clip(np.asarray(draws["scale"]) + 1.0, 1 - scale_jit, 1 + scale_jit)
+        rot = np.asarray(draws["rot"], np.float64)
+    out = gt_core_batch(st("cam_intr"), j3, j2, c3, c2, st("corners_can"), st("obj_transf"), center, scale, rot, image_size, raw_size,
+                        center_idx, raw_j2d=raw_j2, raw_c2d=raw_c2, train_split=train_split)
+    out["flip"] = flip
+    out[Queries.OBJ_IDX] = np.array([int(a["obj_idx"]) for a in anns], np.int64)
+    return out
+
+
 class RealBatcher:
     """Batches of real samples on the device: host GT assembly + one upload of the decoded frames + ab_augment_batch."""
     GT_KEYS = (Queries.CAM_INTR, Queries.ROOT_JOINT, Queries.JOINTS_3D, Queries.JOINTS_2D, Queries.JOINTS_VIS, Queries.CORNERS_3D,
@@ -119,24 +145,22 @@ class RealBatcher:
             draws = self.draw(n)
         W, H = self.src.raw_size
         frames = np.zeros((n, H, W, 4), np.uint8)
-        gt = {k: [] for k in self.GT_KEYS}
-        inv, flip, obj_idx = np.zeros((n, 6), np.float32), np.zeros(n, np.uint8), np.zeros(n, np.int64)
         for i, idx in enumerate(idxs):
             frames[i, :, :, :3] = self.src.get_image(idx)
-            d = None if draws is None else dict(center=draws["center"][i], scale=draws["scale"][i], rot=draws["rot"][i])
-            r = assemble_real_gt(self.src.get_annots(idx), self.image_size, self.src.raw_size, d, self.center_idx, self.bbox_expand,
-                                 self.center_jit, self.scale_jit, self.src.sides)
-            for k in self.GT_KEYS:
-                gt[k].append(r[k])
-            inv[i] = np.linalg.inv(np.vstack([r["affine"][:2], [0, 0, 1]]).astype(np.float64))[:2].reshape(-1)
-            flip[i], obj_idx[i] = r["flip"], r[Queries.OBJ_IDX]
+        r = assemble_real_gt_batch([self.src.get_annots(idx) for idx in idxs], self.image_size, self.src.raw_size, draws, self.center_idx,
+                                   self.bbox_expand, self.center_jit, self.scale_jit, self.src.sides)
+        gt = {k: r[k] for k in self.GT_KEYS}
+        full = np.tile(np.eye(3), (n, 1, 1))
+        full[:, :2] = r["affine"][:, :2].astype(np.float64)
+        inv = np.linalg.inv(full)[:, :2].reshape(n, 6).astype(np.float32)
+        flip, obj_idx = r["flip"].astype(np.uint8), r[Queries.OBJ_IDX]
         if draws is None:                                          # no augmentation: identity jitter, no blur (hodata.py:113-121)
             order = np.tile(np.arange(4, dtype=np.int32), (n, 1))
             factor = np.tile(np.array([1, 1, 0, 1], np.float32), (n, 1))
             blur = None
         else:
             order, factor, blur = draws["order"], draws["factor"], draws["blur"]
-        return dict(frames=frames, gt={k: np.stack(v).astype(np.float32) for k, v in gt.items()}, inv=inv, flip=flip, obj_idx=obj_idx,
+        return dict(frames=frames, gt={k: np.asarray(v, np.float32) for k, v in gt.items()}, inv=inv, flip=flip, obj_idx=obj_idx,
                     order=order, factor=factor, blur=blur, idxs=np.asarray(idxs, np.int64))
 
     def augment(self, host, out_pad=None, out_chw=None):

@@ -303,7 +303,6 @@ def assemble_gt_batch(K, joints, obj_pose, corners_can, image_size, raw_size, ce
     """assemble_gt for a whole epoch at once (same arithmetic, numpy-vectorised over the S samples; the per-sample Python
     loop costs 75 us per sample, 3 s for a 40 k-sample epoch -- as long as training on it).  joints [S,21,3], obj_pose
     [S,4,4], corners_can [S,8,3] float64; draws [S,2], [S], [S].  Returns the stacked sample dict + "affine" [S,3,3]."""
-    S = joints.shape[0]
     K = np.asarray(K, np.float64)
 
     def project(p):
@@ -319,13 +318,26 @@ def assemble_gt_batch(K, joints, obj_pose, corners_can, image_size, raw_size, ce
     scale = np.maximum(mx[:, 0] - mn[:, 0], mx[:, 1] - mn[:, 1]) * bbox_expand
     center = center + (center_jit * scale[:, None] * np.asarray(center_jit_draw)).astype(np.int64)
     scale = scale * np.clip(np.asarray(scale_draw) + 1.0, 1 - scale_jit, 1 + scale_jit)
-    rot = np.asarray(rot, np.float64)
+    return gt_core_batch(K, joints, j2d, c3d, c2d, corners_can, obj_pose, center, scale, rot, image_size, raw_size, center_idx)
+
+
+def gt_core_batch(K, j3d, j2d, c3d, c2d, corners_can, obj_transf, center, scale, rot, image_size, raw_size, center_idx=0,
+                  raw_j2d=None, raw_c2d=None, train_split=True):
+    """The part of RenderedDataset.__getitem__ / HOdata.__getitem__ after the crop centre and scale are fixed
+    (rendered_dataset.py:192-254, hodata.py:361-433), for S samples: affine, rotated 3-D ground truth, warped 2-D ground
+    truth, visibility masks, object transform.  K [3,3] or [S,3,3]; raw_* = the un-flipped 2-D annotations the raw-image
+    visibility test reads (default: j2d / c2d)."""
+    S = j3d.shape[0]
+    K = np.asarray(K, np.float64)
+    Ks = np.broadcast_to(K, (S, 3, 3))
+    rot = np.broadcast_to(np.asarray(rot, np.float64), (S,))
+    scale = np.asarray(scale, np.float64)
     cs, sn = np.cos(rot), np.sin(rot)
     rm = np.zeros((S, 3, 3), np.float32)
     rm[:, 0, 0], rm[:, 0, 1], rm[:, 1, 0], rm[:, 1, 1], rm[:, 2, 2] = cs, -sn, sn, cs, 1.0
     # get_affine_transform (anakin/utils/transform.py:434-482), component-wise
-    ox, oy = K[0, 2], K[1, 2]
-    cx, cy = center[:, 0].astype(np.float64), center[:, 1].astype(np.float64)
+    ox, oy = Ks[:, 0, 2], Ks[:, 1, 2]
+    cx, cy = np.asarray(center)[:, 0].astype(np.float64), np.asarray(center)[:, 1].astype(np.float64)
     res0, res1 = float(image_size[0]), float(image_size[1])
     ratio = res0 / res1
 
@@ -343,8 +355,8 @@ def assemble_gt_batch(K, joints, obj_pose, corners_can, image_size, raw_size, ce
     aff = (no_rot(cs * cx - sn * cy, sn * cx + cs * cy) @ rm64).astype(np.float32)
     dx, dy = cx - ox, cy - oy
     post = no_rot(cs * dx - sn * dy + ox, sn * dx + cs * dy + oy).astype(np.float32)
-    out = {"affine": aff, Queries.CAM_INTR: np.einsum("sij,jk->sik", post, K).astype(np.float32)}
-    j3 = np.einsum("sij,snj->sni", rm, joints.astype(np.float32))
+    out = {"affine": aff, Queries.CAM_INTR: np.einsum("sij,sjk->sik", post, Ks).astype(np.float32)}
+    j3 = np.einsum("sij,snj->sni", rm, j3d.astype(np.float32))
     root = j3[:, center_idx]
     out[Queries.ROOT_JOINT] = root
     out[Queries.JOINTS_3D] = j3 - root[:, None]
@@ -354,6 +366,8 @@ def assemble_gt_batch(K, joints, obj_pose, corners_can, image_size, raw_size, ce
         return np.einsum("sij,snj->sni", aff.astype(np.float64), ph)[..., :2]
 
     def vis(raw2d, aug2d, n):
+        if not train_split:
+            return np.ones((S, n), np.float32)
         v = (raw2d[..., 0] >= 0) & (raw2d[..., 0] < raw_size[0]) & (raw2d[..., 1] >= 0) & (raw2d[..., 1] < raw_size[1])
         va = ((aug2d[..., 0] >= 0) & (aug2d[..., 0] < image_size[0]) & (aug2d[..., 1] >= 0) & (aug2d[..., 1] < image_size[1])).astype(np.float32)
         dead = (v.sum(1) < n * 0.4) | (va.sum(1) < n * 0.4)
@@ -362,16 +376,16 @@ def assemble_gt_batch(K, joints, obj_pose, corners_can, image_size, raw_size, ce
 
     j2a = hom(j2d).astype(np.float32)
     out[Queries.JOINTS_2D] = j2a
-    out[Queries.JOINTS_VIS] = vis(j2d, j2a, 21)
+    out[Queries.JOINTS_VIS] = vis(j2d if raw_j2d is None else raw_j2d, j2a, j2d.shape[1])
     c3 = np.einsum("sij,snj->sni", rm, c3d.astype(np.float32))
     out[Queries.CORNERS_3D] = c3 - root[:, None]
     c2a = hom(c2d)
     out[Queries.CORNERS_2D] = c2a.astype(np.float32)
-    out[Queries.CORNERS_VIS] = vis(c2d, c2a, 8)
-    out[Queries.CORNERS_CAN] = corners_can.astype(np.float32)
+    out[Queries.CORNERS_VIS] = vis(c2d if raw_c2d is None else raw_c2d, c2a, c2d.shape[1])
+    out[Queries.CORNERS_CAN] = np.asarray(corners_can).astype(np.float32)
     T = np.tile(np.eye(4, dtype=np.float32), (S, 1, 1))
-    T[:, :3, :3] = rm @ obj_pose[:, :3, :3].astype(np.float32)
-    T[:, :3, 3] = np.einsum("sij,sj->si", rm, obj_pose[:, :3, 3].astype(np.float32))
+    T[:, :3, :3] = rm @ obj_transf[:, :3, :3].astype(np.float32)
+    T[:, :3, 3] = np.einsum("sij,sj->si", rm, obj_transf[:, :3, 3].astype(np.float32))
     out[Queries.OBJ_TRANSF] = T
     return out
 

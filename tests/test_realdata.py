@@ -64,6 +64,26 @@ def test_gt_and_image_match_reference_getitem():
         assert not bool(g[f"sample{i}.is_synth"]) and int(g[f"sample{i}.obj_id"]) == -1
 
 
+def test_batched_real_gt_equals_per_sample_and_reference():
+    from artiboost_amd.realdata import assemble_real_gt, assemble_real_gt_batch
+    src = GoldenSource()
+    g = src.g
+    res = int(g["res"])
+    idxs = [0, 1, 2, 1, 0]
+    draws = dict(center=np.stack([g[f"draw{i}.center"] for i in idxs]), scale=np.array([float(g[f"draw{i}.scale"]) for i in idxs]),
+                 rot=np.array([float(g[f"draw{i}.rot"]) for i in idxs]))
+    out = assemble_real_gt_batch([src.get_annots(i) for i in idxs], [res, res], src.raw_size, draws, center_idx=0)
+    assert out["flip"].tolist() == [False, True, False, True, False]
+    for n, i in enumerate(idxs):
+        ref = assemble_real_gt(src.get_annots(i), [res, res], src.raw_size, _draws(g, i), center_idx=0)
+        for k in GT + ("affine",):
+            np.testing.assert_allclose(out[k][n], ref[k], rtol=1e-6, atol=1e-5, err_msg=f"{n}.{k}")
+            if k != "affine":
+                np.testing.assert_allclose(out[k][n], g[f"sample{i}.{k}"], rtol=1e-5, atol=1e-5)
+    plain = assemble_real_gt_batch([src.get_annots(i) for i in idxs], [res, res], src.raw_size, None, center_idx=0, train_split=False)
+    assert (plain["joints_vis"] == 1).all() and (plain["corners_vis"] == 1).all()
+
+
 @pytest.mark.gpu
 def test_real_batch_on_gpu_vs_oracle_and_reference():
     from artiboost_amd.realdata import RealBatcher
