@@ -128,6 +128,7 @@ class RealBatcher:
         self.scale_jit, self.center_jit, self.max_rot = ap["SCALE_JIT"], ap["CENTER_JIT"], ap["MAX_ROT"] * np.pi
         self.rng = np.random.default_rng(seed)
         self._ws = None
+        self._pin, self._pin_i = None, 0
 
     def draw(self, n):
         """One set of augmentation draws per sample (hodata.py:346-359,435-442: ranges hard-coded at hodata.py:107-112)."""
@@ -144,9 +145,16 @@ class RealBatcher:
         if draws is None and self.aug:
             draws = self.draw(n)
         W, H = self.src.raw_size
-        frames = np.zeros((n, H, W, 4), np.uint8)
+        # decoded frames go, RGB and contiguous, into one of two pinned staging buffers (a strided RGB -> RGBX scatter on the
+        # host costs 1 ms per 640x480 frame; the X byte is added on the device) and are uploaded with one asynchronous copy
+        if self._pin is None or self._pin[0].shape[0] < n or tuple(self._pin[0].shape[1:3]) != (H, W):
+            self._pin = [torch.empty((n, H, W, 3), dtype=torch.uint8).pin_memory() if torch.cuda.is_available()
+                         else torch.empty((n, H, W, 3), dtype=torch.uint8) for _ in range(2)]
+        self._pin_i ^= 1
+        stage = self._pin[self._pin_i][:n]
+        frames = stage.numpy()
         for i, idx in enumerate(idxs):
-            frames[i, :, :, :3] = self.src.get_image(idx)
+            frames[i] = self.src.get_image(idx)
         r = assemble_real_gt_batch([self.src.get_annots(idx) for idx in idxs], self.image_size, self.src.raw_size, draws, self.center_idx,
                                    self.bbox_expand, self.center_jit, self.scale_jit, self.src.sides)
         gt = {k: r[k] for k in self.GT_KEYS}
@@ -160,7 +168,7 @@ class RealBatcher:
             blur = None
         else:
             order, factor, blur = draws["order"], draws["factor"], draws["blur"]
-        return dict(frames=frames, gt={k: np.asarray(v, np.float32) for k, v in gt.items()}, inv=inv, flip=flip, obj_idx=obj_idx,
+        return dict(frames=stage, gt={k: np.asarray(v, np.float32) for k, v in gt.items()}, inv=inv, flip=flip, obj_idx=obj_idx,
                     order=order, factor=factor, blur=blur, idxs=np.asarray(idxs, np.int64))
 
     def augment(self, host, out_pad=None, out_chw=None):
@@ -175,7 +183,10 @@ class RealBatcher:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         if out_pad is None and out_chw is None:
             out_chw = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=self.dev)
-        frames, order, factor, inv, flip = t(host["frames"]), t(host["order"]), t(host["factor"]), t(host["inv"]), t(host["flip"])
+        rgb = host["frames"].to(self.dev, non_blocking=True)
+        frames = torch.zeros(rgb.shape[:3] + (4,), dtype=torch.uint8, device=self.dev)
+        frames[..., :3].copy_(rgb)                                  # RGBX: the kernels fetch a pixel as one aligned dword
+        order, factor, inv, flip = t(host["order"]), t(host["factor"]), t(host["inv"]), t(host["flip"])
         blur = t(host["blur"]) if host["blur"] is not None else None
         dt = L.dt(out_pad) if out_pad is not None else 0
         L.check(lib.ab_augment_batch(L.ptr(frames), L.i(n), L.i(W), L.i(H), L.ptr(order), L.ptr(factor), L.ptr(inv), L.ptr(blur),
