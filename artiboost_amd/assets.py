@@ -98,10 +98,7 @@ def make_hand_model(seed=1):
             J.append(base[f] + direc[f] * length[f] * (kk / 3.0))
     J = np.stack(J)
     # move the designated MANO tip ids onto the finger ends (swap vertex positions so tips are meaningful)
-    tip_of_finger = {1: 0, 2: 1, 4: 2, 3: 3, 0: 4}   # finger index -> position in MANO_TIPS (thumb,index,middle,ring,pinky ids)
     perm = np.arange(778)
-    for fidx, tvid in zip([0, 1, 2, 3, 4], tips):   # fingers in geometric order thumb..pinky? (base order: index.. see below)
-        pass
     # geometric fingers f=0..4 are (index-ish left to right); map: f=4 thumb, f=0 index, f=1 middle, f=2 ring, f=3 pinky
     geo2tip = {4: MANO_TIPS[0], 0: MANO_TIPS[1], 1: MANO_TIPS[2], 2: MANO_TIPS[3], 3: MANO_TIPS[4]}
     for f, cur in enumerate(tips):
@@ -110,7 +107,7 @@ def make_hand_model(seed=1):
         perm[i], perm[j] = perm[j], perm[i]
     inv = np.empty(778, dtype=np.int64)
     inv[perm] = np.arange(778)
-    v_template = v_template[np.argsort(inv)] if False else v_template[inv.argsort()]
+    v_template = v_template[inv.argsort()]
     remap = inv.argsort().argsort()
     fcs = remap[fcs].astype(np.int32)
     d = np.linalg.norm(v_template[:, None] - J[None], axis=2)
