@@ -154,7 +154,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         const unsigned pbase = (chunk & 1) * PATCH_BYTES;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            constexpr int dummy = 0; (void)dummy;
             // loads issued after B(step): B(step+1) [+ P(chunk+1) for t == 1, 2]
             const bool last = !more && t == 8;
             if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -261,11 +260,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
                     const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const int sh16 = (k & 1) ? 0 : 16;
                         const float gv = __uint_as_float((k & 1) ? (vw[k >> 1] & 0xffff0000u) : (vw[k >> 1] << 16));
                         const float yf = __uint_as_float((k & 1) ? (yw[k >> 1] & 0xffff0000u) : (yw[k >> 1] << 16));
                         const float of = __uint_as_float((k & 1) ? (ow[k >> 1] & 0xffff0000u) : (ow[k >> 1] << 16));
-                        (void)sh16;
                         const bool dead = BnOut ? !(of > 0.f) : !(yf * bsc[k] + bsh[k] > 0.f);
                         const float dz = dead ? 0.f : gv;
                         bs[k] += dz; bq[k] += dz * ((yf - bmean[k]) * bistd[k]);

@@ -649,9 +649,7 @@ extern "C" int ab_add(const void* a, const void* b, int dtype, long n, void* out
 
 extern "C" int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* idx, void* stream) {
     int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
-    long nvec = (long)N * (H / 2) * (W / 2) * C / V;
     dim3 pgrid((unsigned)(((long)(W / 2) * (C / V) + 255) / 256), (unsigned)(H / 2), (unsigned)N);
-    (void)nvec;
     DISPATCH(dtype, (maxpool_fwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>((const float*)x, nullptr, N, H, W, C, (float*)out, (uint8_t*)idx)),
              (maxpool_fwd_kernel<bf16_t><<<pgrid, 256, 0, as_stream(stream)>>>((const bf16_t*)x, nullptr, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
     AB_LAUNCH_CHECK(); return 0;
@@ -660,9 +658,7 @@ extern "C" int ab_bn_relu_maxpool3x3s2_fwd(const void* y, const float* bnp, int 
                                            void* idx, void* stream) {
     if (!y || !bnp || !out) return AB_EINVAL;
     int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
-    long nvec = (long)N * (H / 2) * (W / 2) * C / V;
     dim3 pgrid((unsigned)(((long)(W / 2) * (C / V) + 255) / 256), (unsigned)(H / 2), (unsigned)N);
-    (void)nvec;
     DISPATCH(dtype, (maxpool_fwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>((const float*)y, bnp, N, H, W, C, (float*)out, (uint8_t*)idx)),
              (maxpool_fwd_kernel<bf16_t><<<pgrid, 256, 0, as_stream(stream)>>>((const bf16_t*)y, bnp, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
     AB_LAUNCH_CHECK(); return 0;
@@ -670,9 +666,7 @@ extern "C" int ab_bn_relu_maxpool3x3s2_fwd(const void* y, const float* bnp, int 
 extern "C" int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx,
                                    void* stream) {
     int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
-    long nvec = (long)N * H * W * C / V;
     dim3 pgrid((unsigned)(((long)W * (C / V) + 255) / 256), (unsigned)H, (unsigned)N);
-    (void)nvec;
     DISPATCH(dtype, (maxpool_bwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>((const uint8_t*)idx, (const float*)dout, N, H, W, C, (float*)dx)),
              (maxpool_bwd_kernel<bf16_t><<<pgrid, 256, 0, as_stream(stream)>>>((const uint8_t*)idx, (const bf16_t*)dout, N, H, W, C, (bf16_t*)dx)));
     AB_LAUNCH_CHECK(); return 0;

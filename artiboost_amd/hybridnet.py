@@ -256,7 +256,7 @@ class HybridNet:
     def _dgrad_names(self):
         names = []
         for name, e in self.p.entries.items():
-            if e.kind in ("conv", "deconv", "final_w") and name != "backbone.layer1.0.conv1.weight_never":
+            if e.kind in ("conv", "deconv", "final_w"):
                 names.append(name)
         return names
 
