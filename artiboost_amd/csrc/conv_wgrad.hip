@@ -276,7 +276,7 @@ static int run_wgrad(WgradArgs& g, int dtype, float* dw, int dst_j, int accumula
     g.nslices = ns; g.rows_per_slice = rows;
     int rc = dtype == AB_DT_BF16 ? launch_wgrad<bf16_t>(g, bi, bj, st) : dtype == AB_DT_F32 ? launch_wgrad<float>(g, bi, bj, st) : AB_EINVAL;
     if (rc) return rc;
-    long slab = (long)g.Cout * g.jtot, total = (long)g.Cout * dst_j;
+    long slab = (long)g.Cout * g.jtot;
     return launch_reduce(g.slabs, ns, slab, g.jtot, dst_j, dw, accumulate, stem_mask, st);
 }
 
