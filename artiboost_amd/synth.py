@@ -14,9 +14,7 @@ What changed structurally (MI355X-first):
   * the GrabNet refiner (refiner.py) runs inside the pose generator when the manager config has a
     REFINER block of TYPE "hand_obj" (artiboost_amd/refiner.py); its checkpoint is a download.
 """
-import math
 import os
-import random
 
 import numpy as np
 import torch

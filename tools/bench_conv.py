@@ -1,5 +1,5 @@
 """Per-shape timing of the conv kernels (fwd / dgrad / wgrad) at the benchmark geometry (B=64, 256x256)."""
-import os, sys, time
+import os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from artiboost_amd import kernels as K
