@@ -215,6 +215,12 @@ static void pick_tile(int M, int Cn, int* bm, int* bn) {
 int conv_gemm2_mtiles(int M, int Cn, int nsteps);
 int conv_gemm2_stem_mtiles(int M);
 int conv_gemm2_stem_run(ConvGemmArgs& g, hipStream_t st);
+int stem_halo_tiles(int N, int H, int W);
+int stem_halo_run(const void* xpad, const void* w, void* y, int N, int H, int W, int Cout, float* stats, hipStream_t st);
+static bool use_stem_halo(int dtype, int Cout) {
+    const char* e = getenv("AB_STEM_HALO");
+    return !(e && atoi(e) == 0) && dtype == AB_DT_BF16 && Cout == 64 && !getenv("AB_STEM_V1") && !getenv("AB_CONV_V1");
+}
 static bool use_stem2(int dtype, int Cout) { return dtype == AB_DT_BF16 && Cout == 64 && !getenv("AB_STEM_V1") && !getenv("AB_CONV_V1"); }
 int conv3x3_tiles(int N, int H, int W, int C, int Cn);
 int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, int C, int Cn, int flip,
@@ -232,6 +238,7 @@ extern "C" int ab_conv2d_stat_rows(int dtype, int N, int H, int W, int Cin, int 
     const int Ho = stem ? H / 2 : (H + 2 * pad - kh) / stride + 1, Wo = stem ? W / 2 : (W + 2 * pad - kw) / stride + 1;
     const int M = N * Ho * Wo;
     if (!stem && use_c3(dtype, kh, kw, stride, pad)) { int t = conv3x3_tiles(N, H, W, Cin, Cout); if (t) return t; }
+    if (stem && use_stem_halo(dtype, Cout)) { int t = stem_halo_tiles(N, H, W); if (t) return t; }
     if (stem && use_stem2(dtype, Cout)) return conv_gemm2_stem_mtiles(M);
     if (use_v2(dtype, stem != 0, stem ? 0 : Cin)) return conv_gemm2_mtiles(M, Cout, kh * kw * (Cin / 64));
     int bm, bn; pick_tile(M, Cout, &bm, &bn);
@@ -286,6 +293,10 @@ extern "C" int ab_conv2d_stem_fwd(const void* xpad, const void* w, void* y, int 
     const int bk = dtype == AB_DT_BF16 ? 32 : 16, per = 32 / bk;     // K-steps per kh row (1 for bf16, 2 for f32)
     g.ntaps = 7 * per; g.cpt = 1; g.ktot = 7 * 32; g.M = N * g.P * g.Q;
     if (g.ntaps > CG_MAXTAPS) return AB_ESHAPE;
+    if (use_stem_halo(dtype, Cout)) {
+        int rc = stem_halo_run(xpad, w, y, N, H, W, Cout, stats, as_stream(stream));
+        if (rc != AB_ESHAPE) return rc;
+    }
     if (use_stem2(dtype, Cout)) {
         ConvGemmArgs g2 = g;
         int rc = conv_gemm2_stem_run(g2, as_stream(stream));

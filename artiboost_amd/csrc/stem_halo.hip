@@ -1,0 +1,150 @@
+// Stem convolution (7x7 / stride 2 / pad 3, 3 -> 64 channels; anakin/models/resnet.py:154) with an LDS-resident input halo.
+//
+// The tap-table kernel (conv_gemm2.hip, STEM) fills 96 KB of LDS per 128 output pixels -- every input pixel is fetched ~10x
+// (7 kernel rows x overlapping 8-pixel runs) and the 28 KB of weights once per tile -- and is bound by that fill.  Here a
+// persistent workgroup keeps its weight fragments in registers (each wave's 32 output channels x 224 = 14 B fragments, 56
+// VGPRs, loaded once) and owns TH x TW = 8 x 16 output pixels at a time: their input
+// patch (21 rows x 40 pixels of the zero-bordered NHWC4 image, 6.7 KB) is DMA'd once, double-buffered against the MFMAs of
+// the previous tile, and every A fragment is a 16-byte LDS read straight from a patch row: output pixel (p, q), kernel row
+// kh, K elements [j*16 + half*8, +8) are the bytes  (2p + kh) * 320 + 16 q + 32 j + 16 half  of the patch (pixel pitch
+// 8 bytes, so consecutive q are consecutive 16-byte slots: conflict-free).  K = 7 x 32 = 224 = 14 MFMA k-slices.
+// One barrier per tile: the staging tile and the BN partial buffer are double-buffered like the patch, so the 16-byte output
+// stores of tile t retire under the MFMAs of tile t + 1 (on gfx9 a wave's vmcnt also counts its stores: waiting for the
+// next patch right after issuing the stores would serialise every tile on the store acknowledgements).
+// What is left is the 134 MB output write of the launch.
+#include "conv_common.h"
+
+#define SH_TH 8
+#define SH_TW 16
+#define SH_PROW 320                 // patch row pitch: 40 pixels x 8 bytes
+#define SH_PSLOTS 420               // 21 rows x 20 sixteen-byte slots
+#define SH_PATCH 7168               // 7 wave instructions of 1 KiB
+#define SH_SPITCH 144               // staging row pitch (64 channels x 2 bytes + 16)
+#define SH_STAGE (128 * SH_SPITCH)  // 18432
+#define SH_STAT (4 * 64 * 2 * 4)    // 2048: [wave_m][channel][sum, sumsq]
+#define SH_OFF_P 0
+#define SH_OFF_S (2 * SH_PATCH)                         // 14336
+#define SH_OFF_T (SH_OFF_S + 2 * SH_STAGE)              // 51200
+#define SH_LDS (SH_OFF_T + 2 * SH_STAT)                 // 55296
+
+struct StemArgs {
+    const void* X; const void* Wt; void* Out; float* stats;
+    int Ha, Wa, Ho, Wo, tiles_x, tiles_per_img, ntiles;
+};
+
+__global__ __launch_bounds__(512) void stem_halo_kernel(StemArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int l32 = lane & 31, fhalf = lane >> 5;
+    const bf16_t* __restrict__ X = (const bf16_t*)g.X;
+    const bf16_t* __restrict__ Wt = (const bf16_t*)g.Wt;
+    bf16_t* __restrict__ Out = (bf16_t*)g.Out;
+    const unsigned lds0 = lds_addr_of(smem);
+
+    // B fragments of this wave's 32 output channels, all 14 k-slices, resident in registers for the life of the workgroup
+    uint4 fb[14];
+#pragma unroll
+    for (int kk = 0; kk < 14; ++kk) fb[kk] = *(const uint4*)(Wt + (wave_n * 32 + l32) * 224 + kk * 16 + fhalf * 8);
+
+    auto issue_patch = [&](int tile, int buf) {          // 420 sixteen-byte slots: waves 0..6, one instruction each
+        if (wave < 7) {
+            const int s = wave * 64 + lane;
+            if (s < SH_PSLOTS) {
+                const int img = tile / g.tiles_per_img, rem = tile - img * g.tiles_per_img;
+                const int ty0 = (rem / g.tiles_x) * SH_TH, tx0 = (rem % g.tiles_x) * SH_TW;
+                const int row = s / 20, c16 = s - row * 20;
+                const bf16_t* src = X + ((((long)img * g.Ha + 2 * ty0 + row) * g.Wa + 2 * tx0 + c16 * 2) * 4);
+                glds16(src, __builtin_amdgcn_readfirstlane(lds0 + SH_OFF_P + buf * SH_PATCH + wave * 1024));
+            }
+        }
+    };
+
+    // this lane's fragment bases: MFMA row m = l32 is output pixel (p, q) = (wave_m * 2 + m / 16, m % 16) of the tile
+    const int pq = l32 & 15, pp = wave_m * 2 + (l32 >> 4);
+    const unsigned a_off = (unsigned)(2 * pp * SH_PROW + pq * 16 + fhalf * 16);
+
+    int tile = blockIdx.x, buf = 0;
+    if (tile < g.ntiles) issue_patch(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (; tile < g.ntiles; tile += gridDim.x) {
+        // buffer parity `buf` of patch, staging and stat buffers belongs to this tile; the other parity's readers (MFMAs and
+        // output stores of the previous tile) all passed the previous barrier with lgkmcnt(0)
+        const int next = tile + gridDim.x;
+        if (next < g.ntiles) issue_patch(next, buf ^ 1);
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const unsigned char* pa = smem + SH_OFF_P + buf * SH_PATCH + a_off;
+#pragma unroll
+        for (int kk = 0; kk < 14; ++kk) {
+            const uint4 fa = *(const uint4*)(pa + (kk >> 1) * SH_PROW + (kk & 1) * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb[kk]), acc, 0, 0, 0);
+        }
+
+        // ---- epilogue: bf16 tile through LDS -> 16-byte stores; BN partial sums of this tile
+        const int cl = wave_n * 32 + l32;
+        unsigned char* stg = smem + SH_OFF_S + buf * SH_STAGE;
+        float* s_stat = (float*)(smem + SH_OFF_T + buf * SH_STAT);
+        float csum = 0.f, csq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+            const float v = acc[r];
+            *(bf16_t*)(stg + row * SH_SPITCH + cl * 2) = f32_to_bf16(v);
+            csum += v; csq += v * v;
+        }
+        if (g.stats) {
+            const float s = csum + __shfl_xor(csum, 32, 64), q = csq + __shfl_xor(csq, 32, 64);
+            if (lane < 32) { s_stat[(wave_m * 64 + cl) * 2] = s; s_stat[(wave_m * 64 + cl) * 2 + 1] = q; }
+        }
+        // the one barrier of the tile: staging + partials visible, next patch landed (the older output stores of the previous
+        // tile retired long ago), and every LDS read of this tile's patch has returned (WAR against the DMA after next)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int img = tile / g.tiles_per_img, rem = tile - img * g.tiles_per_img;
+        const int ty0 = (rem / g.tiles_x) * SH_TH, tx0 = (rem % g.tiles_x) * SH_TW;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int id = tid + u * 512;                  // 128 rows x 8 sixteen-byte chunks
+            const int row = id >> 3, c8 = id & 7;
+            const int p = row >> 4, q = row & 15;
+            const uint4 v = *(const uint4*)(stg + row * SH_SPITCH + c8 * 16);
+            uint4* dst = (uint4*)(Out + ((((long)img * g.Ho + ty0 + p) * g.Wo + tx0 + q) * 64 + c8 * 8));
+            *dst = v;
+        }
+        if (g.stats && tid < 64) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int wm = 0; wm < 4; ++wm) { s += s_stat[(wm * 64 + tid) * 2]; q += s_stat[(wm * 64 + tid) * 2 + 1]; }
+            g.stats[((long)tile * 64 + tid) * 2] = s;
+            g.stats[((long)tile * 64 + tid) * 2 + 1] = q;
+        }
+        buf ^= 1;
+    }
+}
+
+// bf16 stem forward; H, W = image size (output H/2 x W/2).  Returns AB_ESHAPE when the tiling does not fit (caller falls back).
+int stem_halo_tiles(int N, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    if (Ho % SH_TH || Wo % SH_TW) return 0;
+    return N * (Ho / SH_TH) * (Wo / SH_TW);
+}
+int stem_halo_run(const void* xpad, const void* w, void* y, int N, int H, int W, int Cout, float* stats, hipStream_t st) {
+    const int ntiles = stem_halo_tiles(N, H, W);
+    if (!ntiles || Cout != 64) return AB_ESHAPE;
+    StemArgs g;
+    g.X = xpad; g.Wt = w; g.Out = y; g.stats = stats;
+    g.Ha = H + 6; g.Wa = W + 8; g.Ho = H / 2; g.Wo = W / 2;
+    g.tiles_x = g.Wo / SH_TW; g.tiles_per_img = g.tiles_x * (g.Ho / SH_TH); g.ntiles = ntiles;
+    static const int per_cu = getenv("AB_STEM_HALO_WGS") ? atoi(getenv("AB_STEM_HALO_WGS")) : 2;
+    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    stem_halo_kernel<<<grid, 512, SH_LDS, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

@@ -321,9 +321,11 @@ def test_small_batch_linear_kernels(M, N, K):
     np.testing.assert_allclose(db.cpu().numpy(), bd.grad.numpy(), rtol=1e-5, atol=1e-5)
 
 
-def test_stem_fast_path_repeatable_at_full_size(monkeypatch):
-    """The bf16 stem on the LDS-DMA kernel (fully unrolled 4-step ring) at B=64: 12 runs bit-identical to each other and
-    equal to the register-staged kernel.  Before the lgkmcnt(0)-before-barrier fix this produced ~15 wrong tiles per run."""
+@pytest.mark.parametrize("halo", [1, 0])
+def test_stem_fast_path_repeatable_at_full_size(monkeypatch, halo):
+    """The bf16 stem at B=64 on the LDS-resident halo kernel (halo=1) and on the LDS-DMA tap kernel (halo=0, fully unrolled
+    4-step ring): 12 runs bit-identical to each other and equal to the register-staged kernel.  Before the
+    lgkmcnt(0)-before-barrier fix the tap kernel produced ~15 wrong tiles per run."""
     from artiboost_amd import kernels as K
     torch.manual_seed(0)
     xpad = K.image_pad_nhwc4(torch.rand(64, 3, 256, 256, device="cuda") - 0.5, torch.bfloat16)
@@ -333,6 +335,7 @@ def test_stem_fast_path_repeatable_at_full_size(monkeypatch):
     monkeypatch.setenv("AB_STEM_V1", "1")
     ref = K.conv2d_stem_fwd(xpad, w, 256, 256).clone()
     monkeypatch.delenv("AB_STEM_V1")
+    monkeypatch.setenv("AB_STEM_HALO", str(halo))
     first = None
     for _ in range(12):
         junk = torch.randn(32 * 1024 * 1024, device="cuda")

@@ -11,7 +11,7 @@ import sys
 import tempfile
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-FILES = ["conv_gemm2.hip", "conv3x3.hip", "wgrad3x3.hip", "wgrad_gemm2.hip"]
+FILES = ["conv_gemm2.hip", "conv3x3.hip", "wgrad3x3.hip", "wgrad_gemm2.hip", "stem_halo.hip"]
 
 
 def scan(asm):
