@@ -65,8 +65,15 @@ __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0
 
 __constant__ int c_parents[21] = {0, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 0, 13, 14, 15, 0, 17, 18, 19};
 
-__global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+// One workgroup of sixteen waves per sample.  The short assembly phases run on wave 0 (`lane` is out of range on the other
+// waves, so every `lane < N` guard excludes them).  The three ordinal losses run side by side on disjoint wave ranges with
+// the views of a pair spread over 4 (hand) or 8 (scene) adjacent lanes, whose gradient partials are combined by a fixed
+// butterfly; the deterministic gradient gathers split each pair list in sixteen fixed ranges, summed in wave order.  As a
+// single wave the kernel was a 75 us chain of dependent LDS / transcendental latencies (~800 cycles per view).
+#define PL_WAVES 16
+__global__ __launch_bounds__(PL_WAVES * 64) void pose_loss_kernel(PoseLossArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, l64 = tid & 63;
+    const int lane = wave == 0 ? tid : 1 << 20;
     __shared__ float P[22][3];        // predicted abs positions (21 joints + boxroot)
     __shared__ float C[8][3];         // predicted abs corners
     __shared__ float mP[21][3], mT[21][3], mC[8][3], mTC[8][3];   // vis-masked pred / target
@@ -80,26 +87,65 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     __shared__ float gsp[PL_MAXPAIR][3];                 // gradient wrt (mP_a - mC_c) per scene pair
     __shared__ float gpart[20][3];
     __shared__ float gP[22][3], gC[8][3];
-    __shared__ float red[64][5];
-    __shared__ float fx, fy, cx, cy, rootz;
-    // pair index tables staged once: the gradient-gather loops below walk them per lane (70 + 63 + 56 entries, twice),
-    // which as global loads was the latency chain of this kernel
+    __shared__ float red[PL_WAVES][5];
+    __shared__ float gpart_w[PL_WAVES][20][3], gP_w[PL_WAVES][21][3], gC_w[PL_WAVES][8][3];   // per-wave partial gathers
+    // Every global input of the sample is requested in this first phase -- pair tables, view vectors, predictions and
+    // targets -- with static (predicated) trip counts so the loads issue back to back and their latencies overlap: the kernel
+    // is one wave per sample, and as ~30 dependent load -> wait -> use rounds it was a 75 us latency chain.
     __shared__ uint8_t ij0[PL_MAXPAIR], ij1[PL_MAXPAIR], ip0[PL_MAXPAIR], ip1[PL_MAXPAIR], is0[PL_MAXPAIR], is1[PL_MAXPAIR];
-    for (int i = lane; i < a.njp; i += 64) { ij0[i] = (uint8_t)a.j0[i]; ij1[i] = (uint8_t)a.j1[i]; }
-    for (int i = lane; i < a.npp; i += 64) { ip0[i] = (uint8_t)a.p0[i]; ip1[i] = (uint8_t)a.p1[i]; }
-    for (int i = lane; i < a.nsp; i += 64) { is0[i] = (uint8_t)a.s0[i]; is1[i] = (uint8_t)a.s1[i]; }
-
-    const float* kp = a.kp3d + (long)b * 66;
-    if (lane == 0) {
-        const float* K = a.cam_intr + (long)b * 9;
-        fx = K[0]; fy = K[4]; cx = K[2]; cy = K[5]; rootz = a.root_joint[b * 3 + 2];
+    __shared__ float kp[66], Kc[9], CAN[8][3], J3[63], C3[24], RJ[3];
+    // unconditional loads (index clamped, absent tables redirected to a valid address), conditional LDS writes: branches
+    // around the loads would put each one in its own basic block with its own s_waitcnt
+    if (wave == 0) {
+    const void* any = a.kp3d;
+    auto ld = [&](auto* p, int i, int n) { p = n > 0 ? p : (decltype(p))any; return p[i < n ? i : 0]; };
+    int64_t rj0[2], rj1[2], rp0[2], rp1[2], rs0[2], rs1[2];
+    float rhv[3], rsv[3];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = lane + it * 64;
+        rj0[it] = ld(a.j0, i, a.njp); rj1[it] = ld(a.j1, i, a.njp);
+        rp0[it] = ld(a.p0, i, a.npp); rp1[it] = ld(a.p1, i, a.npp);
+        rs0[it] = ld(a.s0, i, a.nsp); rs1[it] = ld(a.s1, i, a.nsp);
     }
-    for (int i = lane; i < a.nvh * 3; i += 64) hv[i / 3][i % 3] = a.hand_views[i];
-    for (int i = lane; i < a.nvs * 3; i += 64) sv[i / 3][i % 3] = a.scene_views[i];
-    if (lane < 21) vj[lane] = a.joints_vis[b * 21 + lane];
-    if (lane < 8) vc[lane] = a.corners_vis[b * 8 + lane];
-    if (lane < 3) { avec[lane] = a.box6d[(long)b * a.box_stride + lane]; bvec[lane] = a.box6d[(long)b * a.box_stride + 3 + lane]; }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int i = lane + it * 64;
+        rhv[it] = ld(a.hand_views, i, a.nvh * 3); rsv[it] = ld(a.scene_views, i, a.nvs * 3);
+    }
+    const float r_kp = a.kp3d[(long)b * 66 + lane], r_kp2 = a.kp3d[(long)b * 66 + 64 + (lane & 1)];
+    const float r_K = a.cam_intr[(long)b * 9 + (lane < 9 ? lane : 0)];
+    const int l24 = lane < 24 ? lane : 0;
+    const float r_can = a.corners_can[(long)b * 24 + l24], r_c3 = a.corners_3d[(long)b * 24 + l24];
+    const float r_j3 = a.joints_3d[(long)b * 63 + (lane < 63 ? lane : 0)];
+    const float r_rj = a.root_joint[b * 3 + (lane < 3 ? lane : 0)];
+    const float r_vj = a.joints_vis[b * 21 + (lane < 21 ? lane : 0)], r_vc = a.corners_vis[b * 8 + (lane & 7)];
+    const float r_box = a.box6d[(long)b * a.box_stride + (lane < 6 ? lane : 0)];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = lane + it * 64;
+        if (i < a.njp) { ij0[i] = (uint8_t)rj0[it]; ij1[i] = (uint8_t)rj1[it]; }
+        if (i < a.npp) { ip0[i] = (uint8_t)rp0[it]; ip1[i] = (uint8_t)rp1[it]; }
+        if (i < a.nsp) { is0[i] = (uint8_t)rs0[it]; is1[i] = (uint8_t)rs1[it]; }
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int i = lane + it * 64;
+        if (i < a.nvh * 3) (&hv[0][0])[i] = rhv[it];
+        if (i < a.nvs * 3) (&sv[0][0])[i] = rsv[it];
+    }
+    kp[lane] = r_kp;
+    if (lane < 2) kp[64 + lane] = r_kp2;
+    if (lane < 9) Kc[lane] = r_K;
+    if (lane < 24) { (&CAN[0][0])[lane] = r_can; C3[lane] = r_c3; }
+    if (lane < 63) J3[lane] = r_j3;
+    if (lane < 3) { RJ[lane] = r_rj; avec[lane] = r_box; }
+    else if (lane < 6) bvec[lane - 3] = r_box;
+    if (lane < 21) vj[lane] = r_vj;
+    if (lane < 8) vc[lane] = r_vc;
+    }
     __syncthreads();
+    const float fx = Kc[0], fy = Kc[4], cx = Kc[2], cy = Kc[5], rootz = RJ[2];
     // ---- uvd -> xyz (transform.py:512-546)
     if (lane < 22) {
         float u = kp[lane * 3], v = kp[lane * 3 + 1], d = kp[lane * 3 + 2];
@@ -121,18 +167,18 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     __syncthreads();
     if (lane < 24) {
         int c = lane / 3, i = lane % 3;
-        const float* can = a.corners_can + ((long)b * 8 + c) * 3;
+        const float* can = CAN[c];
         C[c][i] = R[i][0] * can[0] + R[i][1] * can[1] + R[i][2] * can[2] + P[21][i];
     }
     if (lane < 63) {
         int k = lane / 3, i = lane % 3;
-        float t = a.joints_3d[((long)b * 21 + k) * 3 + i] + a.root_joint[b * 3 + i];
+        float t = J3[k * 3 + i] + RJ[i];
         T[k][i] = t; mT[k][i] = t * vj[k]; mP[k][i] = P[k][i] * vj[k];
     }
     __syncthreads();
     if (lane < 24) {
         int c = lane / 3, i = lane % 3;
-        float t = a.corners_3d[((long)b * 8 + c) * 3 + i] + a.root_joint[b * 3 + i];
+        float t = C3[c * 3 + i] + RJ[i];
         TC[c][i] = t; mTC[c][i] = t * vc[c]; mC[c][i] = C[c][i] * vc[c];
     }
     if (lane < 60) {
@@ -149,7 +195,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
         float* o = a.uvd2d + (long)b * 90;
         if (lane < 21) { o[lane * 3] = kp[lane * 3]; o[lane * 3 + 1] = kp[lane * 3 + 1]; o[lane * 3 + 2] = kp[lane * 3 + 2]; }
         if (lane < 8) {
-            const float* K = a.cam_intr + (long)b * 9;
+            const float* K = Kc;
             float X = C[lane][0], Y = C[lane][1], Z = C[lane][2];
             float hx = K[0] * X + K[1] * Y + K[2] * Z, hy = K[3] * X + K[4] * Y + K[5] * Z, hz = K[6] * X + K[7] * Y + K[8] * Z;
             o[(21 + lane) * 3] = hx / hz / a.res_w; o[(21 + lane) * 3 + 1] = hy / hz / a.res_h; o[(21 + lane) * 3 + 2] = 0.f;
@@ -163,57 +209,73 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     const float nJO = B_ * a.njp * a.nvh, nPO = B_ * a.npp * a.nvh, nSO = B_ * a.nsp * a.nvs;
     if (lane < 63) { float d = mP[lane / 3][lane % 3] - mT[lane / 3][lane % 3]; acc[0] = d * d; }
     if (lane < 24) { float d = mC[lane / 3][lane % 3] - mTC[lane / 3][lane % 3]; acc[1] = d * d; }
-    // joint-level ordinal: one pair per lane-iteration, loop over views
+    // wave ranges of the three losses: 16 joint / part pairs or 8 scene pairs per wave when that fits, else a fixed split
+    int wj = (a.njp + 15) / 16, wp = (a.npp + 15) / 16, ws = (a.nsp + 7) / 8;
+    if (wj + wp + ws > PL_WAVES) { wj = 5; wp = 4; ws = PL_WAVES - 9; }
     const float wjo = a.w_handord * a.lam_hand_joint / nJO;
-    for (int pi = lane; pi < a.njp; pi += 64) {
-        int i0 = (int)ij0[pi], i1 = (int)ij1[pi];
-        float dt[3], dp[3], g[3] = {0.f, 0.f, 0.f};
-        for (int i = 0; i < 3; ++i) { dt[i] = mT[i0][i] - mT[i1][i]; dp[i] = mP[i0][i] - mP[i1][i]; }
-        for (int v = 0; v < a.nvh; ++v) {
-            float s = sgn(dot3(dt, hv[v])), t = -s * dot3(dp, hv[v]);
-            if (t > 0.f) {
-                acc[2] += log1pf(t);
-                float c = wjo * (-s) / (1.f + t);
-                g[0] += c * hv[v][0]; g[1] += c * hv[v][1]; g[2] += c * hv[v][2];
-            }
-        }
-        gjp[pi][0] = g[0]; gjp[pi][1] = g[1]; gjp[pi][2] = g[2];
-    }
-    // part-level ordinal
     const float wpo = a.w_handord * a.lam_hand_part / nPO;
-    for (int pi = lane; pi < a.npp; pi += 64) {
-        int i0 = (int)ip0[pi], i1 = (int)ip1[pi];
-        float ct[3], cp[3], gp[3] = {0.f, 0.f, 0.f}, gq[3] = {0.f, 0.f, 0.f};
-        cross3(part_t[i0], part_t[i1], ct);
-        cross3(part_p[i0], part_p[i1], cp);
-        for (int v = 0; v < a.nvh; ++v) {
-            float s = sgn(dot3(ct, hv[v])), t = -s * dot3(cp, hv[v]);
-            if (t > 0.f) {
-                acc[3] += t;
-                float c = wpo * (-s);
-                float qn[3], np_[3];
-                cross3(part_p[i1], hv[v], qn);       // d((p x q).n)/dp = q x n
-                cross3(hv[v], part_p[i0], np_);      // d((p x q).n)/dq = n x p
-                for (int i = 0; i < 3; ++i) { gp[i] += c * qn[i]; gq[i] += c * np_[i]; }
-            }
-        }
-        for (int i = 0; i < 3; ++i) { gpp[pi][i] = gp[i]; gpq[pi][i] = gq[i]; }
-    }
-    // scene ordinal
     const float wso = a.w_sceneord * a.lam_scene / nSO;
-    for (int pi = lane; pi < a.nsp; pi += 64) {
-        int i0 = (int)is0[pi], i1 = (int)is1[pi];
-        float dt[3], dp[3], g[3] = {0.f, 0.f, 0.f};
-        for (int i = 0; i < 3; ++i) { dt[i] = mT[i0][i] - mTC[i1][i]; dp[i] = mP[i0][i] - mC[i1][i]; }
-        for (int v = 0; v < a.nvs; ++v) {
-            float s = sgn(dot3(dt, sv[v])), t = -s * dot3(dp, sv[v]);
-            if (t > 0.f) {
-                acc[4] += log1pf(t);
-                float c = wso * (-s) / (1.f + t);
-                g[0] += c * sv[v][0]; g[1] += c * sv[v][1]; g[2] += c * sv[v][2];
+    if (wave < wj) {                                    // joint-level ordinal: 4 lanes per pair
+        const int sub = tid & 3;
+        for (int pi = tid >> 2; pi < a.njp; pi += wj * 16) {
+            int i0 = (int)ij0[pi], i1 = (int)ij1[pi];
+            float dt[3], dp[3], g[3] = {0.f, 0.f, 0.f};
+            for (int i = 0; i < 3; ++i) { dt[i] = mT[i0][i] - mT[i1][i]; dp[i] = mP[i0][i] - mP[i1][i]; }
+            for (int v = sub; v < a.nvh; v += 4) {
+                float s = sgn(dot3(dt, hv[v])), t = -s * dot3(dp, hv[v]);
+                if (t > 0.f) {
+                    acc[2] += log1pf(t);
+                    float c = wjo * (-s) / (1.f + t);
+                    g[0] += c * hv[v][0]; g[1] += c * hv[v][1]; g[2] += c * hv[v][2];
+                }
             }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { g[i] += __shfl_xor(g[i], 1, 64); g[i] += __shfl_xor(g[i], 2, 64); }
+            if (sub == 0) { gjp[pi][0] = g[0]; gjp[pi][1] = g[1]; gjp[pi][2] = g[2]; }
         }
-        gsp[pi][0] = g[0]; gsp[pi][1] = g[1]; gsp[pi][2] = g[2];
+    } else if (wave < wj + wp) {                        // part-level ordinal: 4 lanes per pair
+        const int t0 = tid - wj * 64, sub = t0 & 3;
+        for (int pi = t0 >> 2; pi < a.npp; pi += wp * 16) {
+            int i0 = (int)ip0[pi], i1 = (int)ip1[pi];
+            float ct[3], cp[3], gp[3] = {0.f, 0.f, 0.f}, gq[3] = {0.f, 0.f, 0.f};
+            cross3(part_t[i0], part_t[i1], ct);
+            cross3(part_p[i0], part_p[i1], cp);
+            for (int v = sub; v < a.nvh; v += 4) {
+                float s = sgn(dot3(ct, hv[v])), t = -s * dot3(cp, hv[v]);
+                if (t > 0.f) {
+                    acc[3] += t;
+                    float c = wpo * (-s);
+                    float qn[3], np_[3];
+                    cross3(part_p[i1], hv[v], qn);       // d((p x q).n)/dp = q x n
+                    cross3(hv[v], part_p[i0], np_);      // d((p x q).n)/dq = n x p
+                    for (int i = 0; i < 3; ++i) { gp[i] += c * qn[i]; gq[i] += c * np_[i]; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                gp[i] += __shfl_xor(gp[i], 1, 64); gp[i] += __shfl_xor(gp[i], 2, 64);
+                gq[i] += __shfl_xor(gq[i], 1, 64); gq[i] += __shfl_xor(gq[i], 2, 64);
+            }
+            if (sub == 0) for (int i = 0; i < 3; ++i) { gpp[pi][i] = gp[i]; gpq[pi][i] = gq[i]; }
+        }
+    } else if (wave < wj + wp + ws) {                   // scene ordinal: 8 lanes per pair
+        const int t0 = tid - (wj + wp) * 64, sub = t0 & 7;
+        for (int pi = t0 >> 3; pi < a.nsp; pi += ws * 8) {
+            int i0 = (int)is0[pi], i1 = (int)is1[pi];
+            float dt[3], dp[3], g[3] = {0.f, 0.f, 0.f};
+            for (int i = 0; i < 3; ++i) { dt[i] = mT[i0][i] - mTC[i1][i]; dp[i] = mP[i0][i] - mC[i1][i]; }
+            for (int v = sub; v < a.nvs; v += 8) {
+                float s = sgn(dot3(dt, sv[v])), t = -s * dot3(dp, sv[v]);
+                if (t > 0.f) {
+                    acc[4] += log1pf(t);
+                    float c = wso * (-s) / (1.f + t);
+                    g[0] += c * sv[v][0]; g[1] += c * sv[v][1]; g[2] += c * sv[v][2];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { g[i] += __shfl_xor(g[i], 1, 64); g[i] += __shfl_xor(g[i], 2, 64); g[i] += __shfl_xor(g[i], 4, 64); }
+            if (sub == 0) { gsp[pi][0] = g[0]; gsp[pi][1] = g[1]; gsp[pi][2] = g[2]; }
+        }
     }
     // ---- SymCornerLoss: lanes scan the symmetry set, wave arg-min (ties -> lowest k), gradient from the winner only
     __shared__ float gsym[8][3];
@@ -224,7 +286,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
         auto sym_gt = [&](int k, int c, float* gt) {           // vis-masked transformed canonical corner c under symmetry k
             const float* Rk = a.sym_R + (obj * a.symK + k) * 9;
             const float* tk = a.sym_t + (obj * a.symK + k) * 3;
-            const float* can = a.corners_can + ((long)b * 8 + c) * 3;
+            const float* can = CAN[c];
             float sc[3];
             for (int i = 0; i < 3; ++i) sc[i] = (Rk[i * 3] * can[0] + Rk[i * 3 + 1] * can[1] + Rk[i * 3 + 2] * can[2]) + tk[i];
             for (int i = 0; i < 3; ++i) gt[i] = ((Tm[i * 4] * sc[0] + Tm[i * 4 + 1] * sc[1] + Tm[i * 4 + 2] * sc[2]) + Tm[i * 4 + 3]) * vc[c];
@@ -232,6 +294,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
         float best = INFINITY; int bk = 0x7fffffff;
         for (int k = lane; k < a.symK; k += 64) {
             float e = 0.f;
+#pragma unroll 1
             for (int c = 0; c < 8; ++c) {
                 float gt[3]; sym_gt(k, c, gt);
                 float per = 0.f;
@@ -253,11 +316,18 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
             for (int i = 0; i < 3; ++i) gsym[lane][i] = wS * (mC[lane][i] - gt[i]);
         }
     }
-    for (int i = 0; i < 5; ++i) red[lane][i] = acc[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (l64 == 0) red[wave][i] = v;
+    }
     __syncthreads();
     if (lane < 5) {
         float s = 0.f;
-        for (int l = 0; l < 64; ++l) s += red[l][lane];
+#pragma unroll
+        for (int w = 0; w < PL_WAVES; ++w) s += red[w][lane];
         a.sample_part[(long)b * 8 + lane] = s;
     }
     if (lane == 5 || lane == 6) {     // per-sample EPE in mm (unmasked, absolute), val_metric.py:96-104
@@ -268,28 +338,60 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
     }
     if (!a.g_kp3d) return;
     // ---- backward, deterministic gather
-    // part gradients: gpart[k] = sum over part pairs containing k
+    // every wave scans its sixteenth of each pair list, branch-free (selects, so the LDS loads pipeline); partials are summed
+    // in wave order
+    const int qpp = (a.npp + PL_WAVES - 1) / PL_WAVES, qjp = (a.njp + PL_WAVES - 1) / PL_WAVES, qsp = (a.nsp + PL_WAVES - 1) / PL_WAVES;
+    if (l64 < 60) {      // part gradients: gpart[k] = sum over part pairs containing k
+        int k = l64 / 3, i = l64 % 3;
+        float s = 0.f;
+        for (int pi = wave * qpp; pi < min((wave + 1) * qpp, a.npp); ++pi) {
+            const float u = gpp[pi][i], w = gpq[pi][i];
+            s += ((int)ip0[pi] == k ? u : 0.f) + ((int)ip1[pi] == k ? w : 0.f);
+        }
+        gpart_w[wave][k][i] = s;
+    }
+    if (l64 < 63) {
+        int k = l64 / 3, i = l64 % 3;
+        float s = 0.f;
+        for (int pi = wave * qjp; pi < min((wave + 1) * qjp, a.njp); ++pi) {
+            const float u = gjp[pi][i];
+            s += ((int)ij0[pi] == k ? u : 0.f) - ((int)ij1[pi] == k ? u : 0.f);
+        }
+        for (int pi = wave * qsp; pi < min((wave + 1) * qsp, a.nsp); ++pi) s += ((int)is0[pi] == k ? gsp[pi][i] : 0.f);
+        gP_w[wave][k][i] = s;
+    }
+    if (l64 < 24) {
+        int c = l64 / 3, i = l64 % 3;
+        float s = 0.f;
+        for (int pi = wave * qsp; pi < min((wave + 1) * qsp, a.nsp); ++pi) s -= ((int)is1[pi] == c ? gsp[pi][i] : 0.f);
+        gC_w[wave][c][i] = s;
+    }
+    __syncthreads();
     if (lane < 60) {
         int k = lane / 3, i = lane % 3;
         float s = 0.f;
-        for (int pi = 0; pi < a.npp; ++pi) { if ((int)ip0[pi] == k) s += gpp[pi][i]; if ((int)ip1[pi] == k) s += gpq[pi][i]; }
+#pragma unroll
+        for (int w = 0; w < PL_WAVES; ++w) s += gpart_w[w][k][i];
         gpart[k][i] = s;
     }
     __syncthreads();
     const float wJ = a.w_jointsloss * a.lam_joints * 2.f / nJ, wC = a.w_jointsloss * a.lam_corners * 2.f / nC;
     if (lane < 63) {      // gradient wrt masked joint mP[k][i], then * vis
         int k = lane / 3, i = lane % 3;
-        float s = wJ * (mP[k][i] - mT[k][i]);
-        for (int pi = 0; pi < a.njp; ++pi) { if ((int)ij0[pi] == k) s += gjp[pi][i]; if ((int)ij1[pi] == k) s -= gjp[pi][i]; }
-        for (int pi = 0; pi < a.nsp; ++pi) if ((int)is0[pi] == k) s += gsp[pi][i];
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < PL_WAVES; ++w) s += gP_w[w][k][i];
+        s += wJ * (mP[k][i] - mT[k][i]);
         if (k >= 1) s += gpart[k - 1][i];
         for (int c = 1; c < 21; ++c) if (c_parents[c] == k) s -= gpart[c - 1][i];
         gP[k][i] = s * vj[k];
     }
     if (lane < 24) {
         int c = lane / 3, i = lane % 3;
-        float s = wC * (mC[c][i] - mTC[c][i]) + gsym[c][i];
-        for (int pi = 0; pi < a.nsp; ++pi) if ((int)is1[pi] == c) s -= gsp[pi][i];
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < PL_WAVES; ++w) s += gC_w[w][c][i];
+        s += wC * (mC[c][i] - mTC[c][i]) + gsym[c][i];
         gC[c][i] = s * vc[c];
     }
     __syncthreads();
@@ -312,7 +414,7 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
         float GR[3][3];
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
             float s = 0.f;
-            for (int c = 0; c < 8; ++c) s += gC[c][i] * a.corners_can[((long)b * 8 + c) * 3 + j];
+            for (int c = 0; c < 8; ++c) s += gC[c][i] * CAN[c][j];
             GR[i][j] = s;
         }
         float gx[3] = {GR[0][0], GR[1][0], GR[2][0]}, gy[3] = {GR[0][1], GR[1][1], GR[2][1]}, gz[3] = {GR[0][2], GR[1][2], GR[2][2]};
@@ -331,33 +433,38 @@ __global__ __launch_bounds__(64) void pose_loss_kernel(PoseLossArgs a) {
 }
 
 // losses[8]: joints_3d_loss, corners_3d_loss, joint_ord_loss, part_ord_loss, scene_ord_loss, final_loss, mean epe_j, mean epe_c
-__global__ void pose_loss_finalize(const float* __restrict__ sample_part, PoseLossArgs a, float* __restrict__ losses) {
+__global__ __launch_bounds__(64) void pose_loss_finalize(const float* __restrict__ sample_part, PoseLossArgs a, float* __restrict__ losses) {
     const int lane = threadIdx.x;
-    if (lane < 7) {
+    // column sums over the batch in double: lane-strided partials (independent loads), then a butterfly in fixed order
+    double col[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
         double s = 0.0;
-        for (int b = 0; b < a.B; ++b) s += sample_part[(long)b * 8 + lane];
-        float B_ = (float)a.B, v = 0.f;
-        if (lane == 0) v = (float)(s / (B_ * 63.f));
-        if (lane == 1) v = (float)(s / (B_ * 24.f));
-        if (lane == 2) v = (float)(s / (B_ * a.njp * a.nvh));
-        if (lane == 3) v = (float)(s / (B_ * a.npp * a.nvh));
-        if (lane == 4) v = (float)(s / (B_ * a.nsp * a.nvs));
-        if (lane >= 5) v = (float)(s / B_);
-        losses[lane < 5 ? lane : lane + 1] = v;
+        for (int b = lane; b < a.B; b += 64) s += (double)sample_part[(long)b * 8 + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        col[c] = s;
     }
-    __syncthreads();
-    if (lane == 0) {
-        float symv = 0.f;
-        if (a.symK > 0) {
-            double s = 0.0;
-            for (int b = 0; b < a.B; ++b) s += sample_part[(long)b * 8 + 7];
-            symv = (float)(s / (double)a.B);
-            if (a.sym_loss) a.sym_loss[0] = symv;
-        }
-        losses[5] = a.w_jointsloss * (a.lam_joints * losses[0] + a.lam_corners * losses[1]) +
-                    a.w_handord * (a.lam_hand_joint * losses[2] + a.lam_hand_part * losses[3]) +
-                    a.w_sceneord * (a.lam_scene * losses[4]) + a.w_sym * (a.lam_sym * symv);
+    if (lane != 0) return;
+    const float B_ = (float)a.B;
+    float v[7];
+    v[0] = (float)(col[0] / (B_ * 63.f));
+    v[1] = (float)(col[1] / (B_ * 24.f));
+    v[2] = (float)(col[2] / (B_ * a.njp * a.nvh));
+    v[3] = (float)(col[3] / (B_ * a.npp * a.nvh));
+    v[4] = (float)(col[4] / (B_ * a.nsp * a.nvs));
+    v[5] = (float)(col[5] / B_);
+    v[6] = (float)(col[6] / B_);
+    float symv = 0.f;
+    if (a.symK > 0) {
+        symv = (float)(col[7] / (double)a.B);
+        if (a.sym_loss) a.sym_loss[0] = symv;
     }
+    for (int i = 0; i < 5; ++i) losses[i] = v[i];
+    losses[6] = v[5]; losses[7] = v[6];
+    losses[5] = a.w_jointsloss * (a.lam_joints * v[0] + a.lam_corners * v[1]) +
+                a.w_handord * (a.lam_hand_joint * v[2] + a.lam_hand_part * v[3]) +
+                a.w_sceneord * (a.lam_scene * v[4]) + a.w_sym * (a.lam_sym * symv);
 }
 
 static int pose_loss_impl(const float* kp3d, const float* box6d, int box_stride, const float* root_joint,
@@ -393,7 +500,7 @@ static int pose_loss_impl(const float* kp3d, const float* box6d, int box_stride,
         a.sym_R = sym->R; a.sym_t = sym->t; a.obj_idx = sym->obj_idx; a.obj_transf = sym->obj_transf;
         a.symK = sym->K; a.lam_sym = sym->lambda; a.w_sym = sym->weight; a.sym_loss = sym->loss_out;
     }
-    pose_loss_kernel<<<B, 64, 0, as_stream(stream)>>>(a);
+    pose_loss_kernel<<<B, PL_WAVES * 64, 0, as_stream(stream)>>>(a);
     AB_LAUNCH_CHECK();
     // guard the normalisers of disabled losses
     PoseLossArgs f = a;
