@@ -66,56 +66,69 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x,
     }
 }
 
-// Fixed-order reduction of per-workgroup partials part[nparts][C][2] for 8 channels per workgroup of 1024 threads
-// (8 channel lanes x 128 partial lanes; four independent double accumulators per lane keep the loads in flight).
-// Returns the totals in (s, q) for threads with pl == 0.
+// Fixed-order reduction of per-workgroup partials part[nparts][C][2] for CPW channels per workgroup of 1024 threads
+// (CPW channel lanes x 1024/CPW partial lanes; eight independent loads per lane in flight, double accumulators).  Fewer
+// channels per workgroup = more workgroups and fewer dependent load rounds per lane: these launches sit on the step's
+// dependency chain, their latency -- not their bandwidth -- is what counts.  Returns the totals in (s, q) for pl == 0.
+template <int CPW>
 __device__ __forceinline__ void reduce_parts_1024(const float* __restrict__ part, int nparts, int C, int c, double& s, double& q,
-                                                  double (*sm)[8][2]) {
-    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                                                  double* sm /* [1024][2] */) {
+    constexpr int NPL = 1024 / CPW;
+    const int cl = threadIdx.x % CPW, pl = threadIdx.x / CPW;
+    double sa[4] = {0, 0, 0, 0}, qa[4] = {0, 0, 0, 0};
     if (c < C) {
         int k = pl;
-        for (; k + 384 < nparts; k += 512) {
-            float2 a = *(const float2*)(part + ((long)k * C + c) * 2);
-            float2 b = *(const float2*)(part + ((long)(k + 128) * C + c) * 2);
-            float2 d = *(const float2*)(part + ((long)(k + 256) * C + c) * 2);
-            float2 e = *(const float2*)(part + ((long)(k + 384) * C + c) * 2);
-            s0 += a.x; q0 += a.y; s1 += b.x; q1 += b.y; s2 += d.x; q2 += d.y; s3 += e.x; q3 += e.y;
+        for (; k + 7 * NPL < nparts; k += 8 * NPL) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const float2*)(part + ((long)(k + u * NPL) * C + c) * 2);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { sa[u & 3] += v[u].x; qa[u & 3] += v[u].y; }
         }
-        for (; k < nparts; k += 128) { float2 a = *(const float2*)(part + ((long)k * C + c) * 2); s0 += a.x; q0 += a.y; }
+        for (; k + NPL < nparts; k += 2 * NPL) {
+            float2 a = *(const float2*)(part + ((long)k * C + c) * 2), b = *(const float2*)(part + ((long)(k + NPL) * C + c) * 2);
+            sa[0] += a.x; qa[0] += a.y; sa[1] += b.x; qa[1] += b.y;
+        }
+        for (; k < nparts; k += NPL) { float2 a = *(const float2*)(part + ((long)k * C + c) * 2); sa[0] += a.x; qa[0] += a.y; }
     }
-    sm[pl][cl][0] = (s0 + s1) + (s2 + s3); sm[pl][cl][1] = (q0 + q1) + (q2 + q3);
+    sm[(pl * CPW + cl) * 2] = (sa[0] + sa[1]) + (sa[2] + sa[3]); sm[(pl * CPW + cl) * 2 + 1] = (qa[0] + qa[1]) + (qa[2] + qa[3]);
     __syncthreads();
-    double a = 0, b = 0;                            // 128 -> 8
-    if (pl < 8) for (int k = pl; k < 128; k += 8) { a += sm[k][cl][0]; b += sm[k][cl][1]; }
+    double a = 0, b = 0;                            // NPL -> 16
+    if (pl < 16) for (int k = pl; k < NPL; k += 16) { a += sm[(k * CPW + cl) * 2]; b += sm[(k * CPW + cl) * 2 + 1]; }
     __syncthreads();
-    if (pl < 8) { sm[pl][cl][0] = a; sm[pl][cl][1] = b; }
+    if (pl < 16) { sm[(pl * CPW + cl) * 2] = a; sm[(pl * CPW + cl) * 2 + 1] = b; }
     __syncthreads();
     s = 0; q = 0;
-    if (pl == 0) for (int k = 0; k < 8; ++k) { s += sm[k][cl][0]; q += sm[k][cl][1]; }
+    if (pl == 0) for (int k = 0; k < 16; ++k) { s += sm[(k * CPW + cl) * 2]; q += sm[(k * CPW + cl) * 2 + 1]; }
 }
+static inline int finalize_cpw(int C) { return C <= 64 ? 2 : (C <= 128 ? 4 : 8); }
 
 // ---------------------------------------------------------------- BN finalize: partials -> scale/shift, saved stats
 // bnp: float [4][C] = scale (gamma*invstd), shift, mean, invstd.  running stats updated in place when non-null.
-// block = 8 channels x 128 part-lanes, grid = ceil(C/8)
+// block = CPW channels x 1024/CPW part-lanes, grid = ceil(C/CPW)
+template <int CPW>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, long count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* __restrict__ running_mean,
                                                           float* __restrict__ running_var, float* __restrict__ bnp) {
-    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
-    __shared__ double sm[128][8][2];
-    double s, q; reduce_parts_1024(part, nparts, C, c, s, q, sm);
-    if (pl == 0 && c < C) {
+    const int cl = threadIdx.x % CPW, pl = threadIdx.x / CPW;
+    const int c = blockIdx.x * CPW + cl;
+    __shared__ double sm[1024 * 2];
+    // the finishing thread's parameters are requested before the reduction so their latency hides under it
+    float g = 0.f, bt = 0.f, rm = 0.f, rv = 0.f;
+    const bool fin = pl == 0 && c < C;
+    if (fin) { g = gamma[c]; bt = beta[c]; if (running_mean) { rm = running_mean[c]; rv = running_var[c]; } }
+    double s, q; reduce_parts_1024<CPW>(part, nparts, C, c, s, q, sm);
+    if (fin) {
         double mean = s / (double)count;
         double var = q / (double)count - mean * mean; if (var < 0) var = 0;
         float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        float sc = gamma[c] * invstd;
-        bnp[c] = sc; bnp[C + c] = beta[c] - (float)mean * sc; bnp[2 * C + c] = (float)mean; bnp[3 * C + c] = invstd;
+        float sc = g * invstd;
+        bnp[c] = sc; bnp[C + c] = bt - (float)mean * sc; bnp[2 * C + c] = (float)mean; bnp[3 * C + c] = invstd;
         if (running_mean) {
             double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            running_mean[c] = (1.f - momentum) * rm + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * rv + momentum * (float)unb;
         }
     }
 }
@@ -250,13 +263,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 }
 
 // reduce partials -> dgamma, dbeta (written to the flat grad buffer) and bwdp[2][C] = (sum dz, sum dz*xhat)
+template <int CPW>
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ bwdp) {
-    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    const int c = blockIdx.x * 8 + cl;
-    __shared__ double sm[128][8][2];
-    double s, q; reduce_parts_1024(part, nparts, C, c, s, q, sm);
+    const int cl = threadIdx.x % CPW, pl = threadIdx.x / CPW;
+    const int c = blockIdx.x * CPW + cl;
+    __shared__ double sm[1024 * 2];
+    double s, q; reduce_parts_1024<CPW>(part, nparts, C, c, s, q, sm);
     if (pl == 0 && c < C) {
         dbeta[c] = (float)s; dgamma[c] = (float)q;
         bwdp[c] = (float)s; bwdp[C + c] = (float)q;
@@ -571,8 +585,12 @@ extern "C" int ab_bn_finalize(const float* part, int nparts, int C, long count, 
                               float eps, float momentum, float* running_mean, float* running_var, float* bnp,
                               void* stream) {
     if (!part || !gamma || !beta || !bnp) return AB_EINVAL;
-    bn_finalize_kernel<<<(C + 7) / 8, 1024, 0, as_stream(stream)>>>(part, nparts, C, count, gamma, beta, eps, momentum,
-                                                                    running_mean, running_var, bnp);
+    hipStream_t st = as_stream(stream);
+    switch (finalize_cpw(C)) {
+    case 2: bn_finalize_kernel<2><<<(C + 1) / 2, 1024, 0, st>>>(part, nparts, C, count, gamma, beta, eps, momentum, running_mean, running_var, bnp); break;
+    case 4: bn_finalize_kernel<4><<<(C + 3) / 4, 1024, 0, st>>>(part, nparts, C, count, gamma, beta, eps, momentum, running_mean, running_var, bnp); break;
+    default: bn_finalize_kernel<8><<<(C + 7) / 8, 1024, 0, st>>>(part, nparts, C, count, gamma, beta, eps, momentum, running_mean, running_var, bnp); break;
+    }
     AB_LAUNCH_CHECK(); return 0;
 }
 
@@ -593,6 +611,14 @@ extern "C" int ab_bn_apply(const void* y, const void* res, const float* bnp, int
     AB_LAUNCH_CHECK(); return 0;
 }
 
+static void launch_bn_bwd_finalize(const float* part, int np, int C, float* dgamma, float* dbeta, float* bwdp, hipStream_t st) {
+    switch (finalize_cpw(C)) {
+    case 2: bn_bwd_finalize_kernel<2><<<(C + 1) / 2, 1024, 0, st>>>(part, np, C, dgamma, dbeta, bwdp); break;
+    case 4: bn_bwd_finalize_kernel<4><<<(C + 3) / 4, 1024, 0, st>>>(part, np, C, dgamma, dbeta, bwdp); break;
+    default: bn_bwd_finalize_kernel<8><<<(C + 7) / 8, 1024, 0, st>>>(part, np, C, dgamma, dbeta, bwdp); break;
+    }
+}
+
 static int bn_bwd_impl(const void* dout, const void* out, const void* y, const float* bnp, int dtype, long M, int C,
                        int relu, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out,
                        const uint8_t* pool_idx, int pH, int pW, hipStream_t st, int given_parts = 0) {
@@ -603,7 +629,7 @@ static int bn_bwd_impl(const void* dout, const void* out, const void* y, const f
     DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, red_rows(M), part, pool_idx, pH, pW)),
              (bn_bwd_reduce_kernel<bf16_t><<<np, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, red_rows(M), part, pool_idx, pH, pW)));
     AB_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<(C + 7) / 8, 1024, 0, st>>>(part, np, C, dgamma, dbeta, bwdp);
+    launch_bn_bwd_finalize(part, np, C, dgamma, dbeta, bwdp, st);
     AB_LAUNCH_CHECK();
     long nvec = M * C / V;
     DISPATCH(dtype, (bn_bwd_apply_kernel<float><<<grid_for(nvec), 256, 0, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, bwdp, nvec, C, M, relu, (float*)dy, (float*)dz_out, pool_idx, pH, pW)),

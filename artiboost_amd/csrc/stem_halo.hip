@@ -64,6 +64,7 @@ __global__ __launch_bounds__(512) void stem_halo_kernel(StemArgs g) {
     const int pq = l32 & 15, pp = wave_m * 2 + (l32 >> 4);
     const unsigned a_off = (unsigned)(2 * pp * SH_PROW + pq * 16 + fhalf * 16);
 
+    float wg_sum = 0.f, wg_sq = 0.f;                     // threads 0..63: this workgroup's BN partial of channel tid
     int tile = blockIdx.x, buf = 0;
     if (tile < g.ntiles) issue_patch(tile, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -122,28 +123,37 @@ __global__ __launch_bounds__(512) void stem_halo_kernel(StemArgs g) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int wm = 0; wm < 4; ++wm) { s += s_stat[(wm * 64 + tid) * 2]; q += s_stat[(wm * 64 + tid) * 2 + 1]; }
-            g.stats[((long)tile * 64 + tid) * 2] = s;
-            g.stats[((long)tile * 64 + tid) * 2 + 1] = q;
+            wg_sum += s; wg_sq += q;
         }
         buf ^= 1;
+    }
+    // one partial row per workgroup (its tiles in launch order): 16x fewer rows for the finalize launch to reduce
+    if (g.stats && tid < 64) {
+        g.stats[((long)blockIdx.x * 64 + tid) * 2] = wg_sum;
+        g.stats[((long)blockIdx.x * 64 + tid) * 2 + 1] = wg_sq;
     }
 }
 
 // bf16 stem forward; H, W = image size (output H/2 x W/2).  Returns AB_ESHAPE when the tiling does not fit (caller falls back).
-int stem_halo_tiles(int N, int H, int W) {
+static int stem_halo_ntiles(int N, int H, int W) {
     const int Ho = H / 2, Wo = W / 2;
     if (Ho % SH_TH || Wo % SH_TW) return 0;
     return N * (Ho / SH_TH) * (Wo / SH_TW);
 }
+static int stem_halo_grid(int ntiles) {
+    static const int per_cu = getenv("AB_STEM_HALO_WGS") ? atoi(getenv("AB_STEM_HALO_WGS")) : 2;
+    return ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+}
+// number of BN-partial rows the launch writes (one per workgroup); 0 = shape not handled
+int stem_halo_tiles(int N, int H, int W) { return stem_halo_grid(stem_halo_ntiles(N, H, W)); }
 int stem_halo_run(const void* xpad, const void* w, void* y, int N, int H, int W, int Cout, float* stats, hipStream_t st) {
-    const int ntiles = stem_halo_tiles(N, H, W);
+    const int ntiles = stem_halo_ntiles(N, H, W);
     if (!ntiles || Cout != 64) return AB_ESHAPE;
     StemArgs g;
     g.X = xpad; g.Wt = w; g.Out = y; g.stats = stats;
     g.Ha = H + 6; g.Wa = W + 8; g.Ho = H / 2; g.Wo = W / 2;
     g.tiles_x = g.Wo / SH_TW; g.tiles_per_img = g.tiles_x * (g.Ho / SH_TH); g.ntiles = ntiles;
-    static const int per_cu = getenv("AB_STEM_HALO_WGS") ? atoi(getenv("AB_STEM_HALO_WGS")) : 2;
-    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
+    const int grid = stem_halo_grid(ntiles);
     stem_halo_kernel<<<grid, 512, SH_LDS, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
