@@ -82,6 +82,12 @@ def l(x):
     return ctypes.c_long(int(x))
 
 
+class WgradReduceDesc(ctypes.Structure):
+    """struct ab_wgrad_reduce_desc (include/artiboost_hip.h)."""
+    _fields_ = [("slabs", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("slab_elems", ctypes.c_long), ("nslices", ctypes.c_int),
+                ("src_j", ctypes.c_int), ("dst_j", ctypes.c_int), ("accumulate", ctypes.c_int), ("stem_mask", ctypes.c_int)]
+
+
 class SymCorner(ctypes.Structure):
     """struct ab_symcorner (include/artiboost_hip.h)."""
     _fields_ = [("R", ctypes.c_void_p), ("t", ctypes.c_void_p), ("K", ctypes.c_int32), ("obj_idx", ctypes.c_void_p),

@@ -217,8 +217,91 @@ __global__ __launch_bounds__(256) void wgrad_reduce(const float* __restrict__ sl
     }
 }
 
+// ---- deferred slab reductions: ab_conv2d_wgrad_deferred / ab_conv2d_stem_wgrad_deferred record the reduction they would
+// launch, ab_wgrad_reduce_batch runs up to AB_WGRAD_BATCH_MAX recorded reductions in ONE launch (descriptor table in the
+// kernel arguments).  39 reductions per step of 4-10 us each cost more as graph nodes than as bandwidth.
+static thread_local ab_wgrad_reduce_desc* g_reduce_sink = nullptr;
+
+struct ReduceBatch {
+    ab_wgrad_reduce_desc d[AB_WGRAD_BATCH_MAX];
+    int block0[AB_WGRAD_BATCH_MAX + 1];          // first workgroup of descriptor i
+    int n;
+};
+static inline int reduce_ky(int ns) { return ns <= 8 ? 4 : 16; }
+static inline long reduce_blocks(const ab_wgrad_reduce_desc& d) {
+    const long total = (d.slab_elems / d.src_j) * d.dst_j;
+    const int qx = 256 / reduce_ky(d.nslices);
+    return (total / 4 + qx - 1) / qx;
+}
+
+// same arithmetic, in the same order, as wgrad_reduce<KY> of the descriptor's slice count: bit-identical results
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch b) {
+    __shared__ float4 part[16 * 17 + 4];
+    int di = 0;
+    while (di + 1 < b.n && (int)blockIdx.x >= b.block0[di + 1]) ++di;
+    const ab_wgrad_reduce_desc& d = b.d[di];
+    const int KY = d.nslices <= 8 ? 4 : 16, QX = 256 / KY;
+    const int qx = threadIdx.x % QX, ky = threadIdx.x / QX;
+    const long quad = (long)((int)blockIdx.x - b.block0[di]) * QX + qx;
+    const long total = (d.slab_elems / d.src_j) * d.dst_j;
+    const long e = quad * 4;
+    const bool live = e < total;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int col = 0;
+    if (live) {
+        const long row = e / d.dst_j; col = (int)(e - row * d.dst_j);
+        const float* src = d.slabs + row * d.src_j + col;
+        for (int k = ky; k < d.nslices; k += KY) {
+            float4 v = *(const float4*)(src + (long)k * d.slab_elems);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    part[ky * (QX + 1) + qx] = s;
+    __syncthreads();
+    if (ky == 0 && live) {
+        float4 t = part[qx];
+        for (int k = 1; k < KY; ++k) { float4 v = part[k * (QX + 1) + qx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        if (d.stem_mask) {
+            if ((col & 31) >= 28) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            t.w = 0.f;
+        }
+        float4* o = (float4*)(d.dst + e);
+        if (d.accumulate) { float4 v = *o; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *o = t;
+    }
+}
+
+extern "C" int ab_wgrad_reduce_batch(const ab_wgrad_reduce_desc* desc, int n, void* stream) {
+    if (!desc || n < 0) return AB_EINVAL;
+    for (int i0 = 0; i0 < n; i0 += AB_WGRAD_BATCH_MAX) {
+        ReduceBatch b;
+        long blocks = 0;
+        b.n = 0;
+        for (int i = i0; i < n && b.n < AB_WGRAD_BATCH_MAX; ++i) {
+            const ab_wgrad_reduce_desc& d = desc[i];
+            if (d.nslices <= 0) continue;
+            if (!d.slabs || !d.dst || d.src_j <= 0 || d.dst_j <= 0 || d.dst_j % 4 || d.src_j % 4) return AB_EINVAL;
+            b.d[b.n] = d; b.block0[b.n] = (int)blocks; ++b.n;
+            blocks += reduce_blocks(d);
+            if (blocks > 0x7fffffffL) return AB_ESHAPE;
+        }
+        if (!b.n) continue;
+        b.block0[b.n] = (int)blocks;
+        wgrad_reduce_batch_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
 static int launch_reduce(const float* slabs, int ns, long slab_elems, int src_j, int dst_j, float* dst, int accumulate,
                          int stem_mask, hipStream_t st) {
+    if (g_reduce_sink) {
+        ab_wgrad_reduce_desc* d = g_reduce_sink;
+        d->slabs = slabs; d->dst = dst; d->slab_elems = slab_elems; d->nslices = ns; d->src_j = src_j; d->dst_j = dst_j;
+        d->accumulate = accumulate; d->stem_mask = stem_mask;
+        return 0;
+    }
     const long total = (slab_elems / src_j) * dst_j;
     if (ns <= 8) wgrad_reduce<4><<<(unsigned)((total / 4 + 63) / 64), 256, 0, st>>>(slabs, ns, slab_elems, src_j, dst_j, dst, accumulate, stem_mask);
     else wgrad_reduce<16><<<(unsigned)((total / 4 + 15) / 16), 256, 0, st>>>(slabs, ns, slab_elems, src_j, dst_j, dst, accumulate, stem_mask);
@@ -340,4 +423,27 @@ extern "C" long ab_conv2d_stem_wgrad_workspace(int N, int H, int W, int Cout) {
     long a = ab_conv2d_wgrad_workspace(N * (H / 2) * (W / 2), Cout, 256);
     long b = (long)(wgrad_gemm2_stem_slices(N, H, W, Cout) + 1) * Cout * 256 * 4;
     return a > b ? a : b;
+}
+
+// As ab_conv2d_wgrad / ab_conv2d_stem_wgrad, but the final slab reduction is recorded in *pending instead of launched
+// (pending->nslices == 0 if the path had nothing to reduce).  `workspace` must stay untouched until ab_wgrad_reduce_batch
+// has consumed the descriptor -- one workspace per deferred call.
+extern "C" int ab_conv2d_wgrad_deferred(const void* x, const void* dy, float* dw, int dtype, int N, int H, int W, int Cin,
+                                        int Cout, int kh, int kw, int stride, int pad, void* workspace, int accumulate,
+                                        ab_wgrad_reduce_desc* pending, void* stream) {
+    if (!pending) return AB_EINVAL;
+    *pending = ab_wgrad_reduce_desc{};
+    g_reduce_sink = pending;
+    int rc = ab_conv2d_wgrad(x, dy, dw, dtype, N, H, W, Cin, Cout, kh, kw, stride, pad, workspace, accumulate, stream);
+    g_reduce_sink = nullptr;
+    return rc;
+}
+extern "C" int ab_conv2d_stem_wgrad_deferred(const void* xpad, const void* dy, float* dw, int dtype, int N, int H, int W,
+                                             int Cout, void* workspace, ab_wgrad_reduce_desc* pending, void* stream) {
+    if (!pending) return AB_EINVAL;
+    *pending = ab_wgrad_reduce_desc{};
+    g_reduce_sink = pending;
+    int rc = ab_conv2d_stem_wgrad(xpad, dy, dw, dtype, N, H, W, Cout, workspace, stream);
+    g_reduce_sink = nullptr;
+    return rc;
 }

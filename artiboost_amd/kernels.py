@@ -1,5 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/artiboost_hip.h).  No autograd here: every function launches HIP
 kernels on the current stream and returns device tensors.  Layouts: activations NHWC, weights OHWI / IHWO."""
+import ctypes
+
 import torch
 
 from . import _lib as L
@@ -84,26 +86,62 @@ def _workspace(nbytes, device):
     return w
 
 
-def conv2d_wgrad(x, dy, kh, kw, stride, pad, out=None, accumulate=False):
-    """x [N,H,W,Cin], dy [N,Ho,Wo,Cout] -> dw float32 [Cout,kh,kw,Cin]."""
+class PendingReductions:
+    """Slab reductions recorded by deferred weight-gradient calls (`defer=`), run in one launch by flush().  Each deferred
+    call gets its own slab workspace, kept alive here until the batched reduction has been enqueued."""
+
+    def __init__(self):
+        self.descs, self.keep = [], []
+
+    def new(self, nbytes, device):
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        d = L.WgradReduceDesc()
+        self.keep.append(ws)
+        self.descs.append(d)
+        return ws, d
+
+    def flush(self):
+        live = [d for d in self.descs if d.nslices > 0]
+        if live:
+            arr = (L.WgradReduceDesc * len(live))(*live)
+            L.check(L.lib().ab_wgrad_reduce_batch(arr, L.i(len(live)), L.stream()), "ab_wgrad_reduce_batch")
+        self.descs, self.keep = [], []
+
+
+def conv2d_wgrad(x, dy, kh, kw, stride, pad, out=None, accumulate=False, defer=None):
+    """x [N,H,W,Cin], dy [N,Ho,Wo,Cout] -> dw float32 [Cout,kh,kw,Cin].  defer: a PendingReductions that receives the final
+    slab reduction instead of it being launched here (dw is complete only after defer.flush())."""
     N, H, W, Cin = x.shape
     Cout = dy.shape[3]
     lib = L.lib()
     M = dy.shape[0] * dy.shape[1] * dy.shape[2]
-    ws = _workspace(lib.ab_conv2d_wgrad_workspace(L.i(M), L.i(Cout), L.i(kh * kw * Cin)), x.device)
+    nbytes = lib.ab_conv2d_wgrad_workspace(L.i(M), L.i(Cout), L.i(kh * kw * Cin))
     dw = out if out is not None else torch.empty((Cout, kh, kw, Cin), dtype=torch.float32, device=x.device)
+    if defer is not None:
+        ws, d = defer.new(nbytes, x.device)
+        L.check(lib.ab_conv2d_wgrad_deferred(L.ptr(x), L.ptr(dy), L.ptr(dw), L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                             L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(ws),
+                                             L.i(1 if accumulate else 0), ctypes.byref(d), L.stream()), "ab_conv2d_wgrad_deferred")
+        return dw
+    ws = _workspace(nbytes, x.device)
     L.check(lib.ab_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), L.i(L.dt(x)), L.i(N), L.i(H), L.i(W), L.i(Cin),
                                 L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(ws),
                                 L.i(1 if accumulate else 0), L.stream()), "ab_conv2d_wgrad")
     return dw
 
 
-def conv2d_stem_wgrad(xpad, dy, H, W, out=None):
+def conv2d_stem_wgrad(xpad, dy, H, W, out=None, defer=None):
     N = xpad.shape[0]
     Cout = dy.shape[3]
     lib = L.lib()
-    ws = _workspace(lib.ab_conv2d_stem_wgrad_workspace(L.i(N), L.i(H), L.i(W), L.i(Cout)), xpad.device)
+    nbytes = lib.ab_conv2d_stem_wgrad_workspace(L.i(N), L.i(H), L.i(W), L.i(Cout))
     dw = out if out is not None else torch.empty((Cout, 7, 8, 4), dtype=torch.float32, device=xpad.device)
+    if defer is not None:
+        ws, d = defer.new(nbytes, xpad.device)
+        L.check(lib.ab_conv2d_stem_wgrad_deferred(L.ptr(xpad), L.ptr(dy), L.ptr(dw), L.i(L.dt(xpad)), L.i(N), L.i(H), L.i(W),
+                                                  L.i(Cout), L.ptr(ws), ctypes.byref(d), L.stream()), "ab_conv2d_stem_wgrad_deferred")
+        return dw
+    ws = _workspace(nbytes, xpad.device)
     L.check(lib.ab_conv2d_stem_wgrad(L.ptr(xpad), L.ptr(dy), L.ptr(dw), L.i(L.dt(xpad)), L.i(N), L.i(H), L.i(W),
                                      L.i(Cout), L.ptr(ws), L.stream()), "ab_conv2d_stem_wgrad")
     return dw

@@ -69,6 +69,24 @@ int ab_conv2d_dgrad(const void* dy, const void* wt, void* dx, int dtype, int N, 
 long ab_conv2d_wgrad_workspace(int M, int Cout, int jtot);
 int ab_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int N, int H, int W, int Cin, int Cout,
                     int kh, int kw, int stride, int pad, void* workspace, int accumulate, void* stream);
+/* Deferred slab reduction: the *_deferred variants run the slab kernel and record the fixed-order reduction they would
+ * launch; ab_wgrad_reduce_batch runs the recorded reductions of many layers in one launch (bit-identical results).  The
+ * workspace of a deferred call must stay untouched until its descriptor has been consumed.                          */
+#define AB_WGRAD_BATCH_MAX 48
+typedef struct ab_wgrad_reduce_desc {
+    const float* slabs;    /* [nslices][slab_elems] partial weight gradients */
+    float* dst;            /* dW */
+    long slab_elems;
+    int nslices;           /* 0: nothing pending */
+    int src_j, dst_j;      /* row lengths of a slab row and of the destination row (padded taps dropped) */
+    int accumulate, stem_mask;
+} ab_wgrad_reduce_desc;
+int ab_conv2d_wgrad_deferred(const void* x, const void* dy, float* dw, int dtype, int N, int H, int W, int Cin, int Cout,
+                             int kh, int kw, int stride, int pad, void* workspace, int accumulate,
+                             ab_wgrad_reduce_desc* pending, void* stream);
+int ab_conv2d_stem_wgrad_deferred(const void* xpad, const void* dy, float* dw, int dtype, int N, int H, int W, int Cout,
+                                  void* workspace, ab_wgrad_reduce_desc* pending, void* stream);
+int ab_wgrad_reduce_batch(const ab_wgrad_reduce_desc* desc, int n, void* stream);
 long ab_conv2d_stem_wgrad_workspace(int N, int H, int W, int Cout);
 int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw, int dtype, int N, int H, int W, int Cout,
                          void* workspace, void* stream);

@@ -355,3 +355,30 @@ def test_fast_conv_paths_at_benchmark_shapes():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fullsize_check.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_deferred_wgrad_reductions_are_bit_identical():
+    """ab_conv2d_wgrad_deferred / ab_conv2d_stem_wgrad_deferred + ONE ab_wgrad_reduce_batch launch for several layers (3x3
+    halo path, strided 3x3, 1x1, 4x4 transpose-conv shape, stem) == the per-layer launches, bit for bit."""
+    from artiboost_amd import kernels as K
+    torch.manual_seed(3)
+    dt = torch.bfloat16
+    cases = [(8, 32, 32, 64, 64, 3, 1, 1), (8, 32, 32, 64, 128, 3, 2, 1), (8, 16, 16, 128, 256, 1, 2, 0), (4, 16, 16, 256, 256, 3, 1, 1),
+             (8, 16, 16, 256, 704, 1, 1, 0)]
+    pend = K.PendingReductions()
+    got, ref = [], []
+    for N, H, W, Cin, Cout, k, s, p in cases:
+        x = (torch.randn(N, H, W, Cin, device="cuda") * 0.5).to(dt)
+        Ho = (H + 2 * p - k) // s + 1
+        dy = (torch.randn(N, Ho, Ho, Cout, device="cuda") * 0.5).to(dt)
+        ref.append(K.conv2d_wgrad(x, dy, k, k, s, p).clone())
+        got.append(K.conv2d_wgrad(x, dy, k, k, s, p, out=torch.full((Cout, k, k, Cin), float("nan"), device="cuda"), defer=pend))
+    xpad = K.image_pad_nhwc4(torch.rand(8, 3, 64, 64, device="cuda") - 0.5, dt)
+    dy0 = (torch.randn(8, 32, 32, 64, device="cuda") * 0.5).to(dt)
+    ref.append(K.conv2d_stem_wgrad(xpad, dy0, 64, 64).clone())
+    got.append(K.conv2d_stem_wgrad(xpad, dy0, 64, 64, out=torch.full((64, 7, 8, 4), float("nan"), device="cuda"), defer=pend))
+    assert len(pend.descs) == len(cases) + 1 and any(d.nslices > 0 for d in pend.descs)
+    pend.flush()
+    assert not pend.descs and not pend.keep
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
