@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x,
 // dependency chain, their latency -- not their bandwidth -- is what counts.  Returns the totals in (s, q) for pl == 0.
 template <int CPW>
 __device__ __forceinline__ void reduce_parts_1024(const float* __restrict__ part, int nparts, int C, int c, double& s, double& q,
-                                                  double* sm /* [1024][2] */) {
+                                                  double* sm /* [16][CPW][2] */) {
     constexpr int NPL = 1024 / CPW;
     const int cl = threadIdx.x % CPW, pl = threadIdx.x / CPW;
     double sa[4] = {0, 0, 0, 0}, qa[4] = {0, 0, 0, 0};
@@ -91,12 +91,12 @@ __device__ __forceinline__ void reduce_parts_1024(const float* __restrict__ part
         }
         for (; k < nparts; k += NPL) { float2 a = *(const float2*)(part + ((long)k * C + c) * 2); sa[0] += a.x; qa[0] += a.y; }
     }
-    sm[(pl * CPW + cl) * 2] = (sa[0] + sa[1]) + (sa[2] + sa[3]); sm[(pl * CPW + cl) * 2 + 1] = (qa[0] + qa[1]) + (qa[2] + qa[3]);
-    __syncthreads();
-    double a = 0, b = 0;                            // NPL -> 16
-    if (pl < 16) for (int k = pl; k < NPL; k += 16) { a += sm[(k * CPW + cl) * 2]; b += sm[(k * CPW + cl) * 2 + 1]; }
-    __syncthreads();
-    if (pl < 16) { sm[(pl * CPW + cl) * 2] = a; sm[(pl * CPW + cl) * 2 + 1] = b; }
+    // part-lanes of a wave by butterfly (lane = pl * CPW + cl: xor offsets CPW .. 32), the 16 waves through LDS in wave order
+    double a = (sa[0] + sa[1]) + (sa[2] + sa[3]), b = (qa[0] + qa[1]) + (qa[2] + qa[3]);
+#pragma unroll
+    for (int o = 32; o >= CPW; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < CPW) { sm[(wave * CPW + cl) * 2] = a; sm[(wave * CPW + cl) * 2 + 1] = b; }
     __syncthreads();
     s = 0; q = 0;
     if (pl == 0) for (int k = 0; k < 16; ++k) { s += sm[(k * CPW + cl) * 2]; q += sm[(k * CPW + cl) * 2 + 1]; }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                           float* __restrict__ running_var, float* __restrict__ bnp) {
     const int cl = threadIdx.x % CPW, pl = threadIdx.x / CPW;
     const int c = blockIdx.x * CPW + cl;
-    __shared__ double sm[1024 * 2];
+    __shared__ double sm[16 * CPW * 2];
     // the finishing thread's parameters are requested before the reduction so their latency hides under it
     float g = 0.f, bt = 0.f, rm = 0.f, rv = 0.f;
     const bool fin = pl == 0 && c < C;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                               float* __restrict__ bwdp) {
     const int cl = threadIdx.x % CPW, pl = threadIdx.x / CPW;
     const int c = blockIdx.x * CPW + cl;
-    __shared__ double sm[1024 * 2];
+    __shared__ double sm[16 * CPW * 2];
     double s, q; reduce_parts_1024<CPW>(part, nparts, C, c, s, q, sm);
     if (pl == 0 && c < C) {
         dbeta[c] = (float)s; dgamma[c] = (float)q;

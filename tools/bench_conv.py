@@ -37,7 +37,10 @@ def timeit(fn, n=20):
 
 
 tot = [0.0, 0.0, 0.0]
+only = sys.argv[1] if len(sys.argv) > 1 else ""          # substring filter on the shape name
 for name, H, W, Ci, Co, k, s, p, cnt in SHAPES:
+    if only not in name:
+        continue
     x = torch.randn(B, H, W, Ci, device="cuda").to(dt)
     w = torch.randn(Co, k, k, Ci, device="cuda").to(dt) * 0.05
     wt = w.permute(3, 1, 2, 0).contiguous()
