@@ -10,12 +10,9 @@ typedef uint16_t bf16_t;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even, NaN preserved (same as torch's float->bfloat16)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even; on gfx950 the conversion is one v_cvt_pk_bf16_f32 (the bit-twiddled form is 7 VALU ops, which made
+// the fused BN + ReLU + max-pool kernel VALU-bound)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 template <typename T> __device__ __forceinline__ float ld_f32(const T* p);
 template <> __device__ __forceinline__ float ld_f32<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld_f32<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
