@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
                     for (int k = 0; k < 4; ++k) {
                         float lo = __uint_as_float(vw[k] << 16) + __uint_as_float(aw[k] << 16);
                         float hi = __uint_as_float(vw[k] & 0xffff0000u) + __uint_as_float(aw[k] & 0xffff0000u);
-                        vw[k] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+                        vw[k] = pack_bf16x2(lo, hi);
                     }
                     v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                 }

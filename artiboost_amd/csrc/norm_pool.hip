@@ -24,7 +24,7 @@ template <> __device__ __forceinline__ void vstore<float>(float* p, const float*
 template <> __device__ __forceinline__ void vstore<bf16_t>(bf16_t* p, const float* f) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(f[2 * i]) | ((uint32_t)f32_to_bf16(f[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
     *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
 }
 

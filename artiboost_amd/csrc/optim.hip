@@ -61,8 +61,8 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __restric
         ((float4*)v)[i] = make_float4(vvv[0], vvv[1], vvv[2], vvv[3]);
         if (lp) {
             uint2 o;
-            o.x = (uint32_t)f32_to_bf16(pp[0]) | ((uint32_t)f32_to_bf16(pp[1]) << 16);
-            o.y = (uint32_t)f32_to_bf16(pp[2]) | ((uint32_t)f32_to_bf16(pp[3]) << 16);
+            o.x = pack_bf16x2(pp[0], pp[1]);
+            o.y = pack_bf16x2(pp[2], pp[3]);
             ((uint2*)lp)[i] = o;
         }
     }

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void sam_bwd_scalar(const T* __restrict__ logi
 template <typename T> __device__ __forceinline__ void st_pair(T* p, float a, float b);
 template <> __device__ __forceinline__ void st_pair<float>(float* p, float a, float b) { *(float2*)p = make_float2(a, b); }
 template <> __device__ __forceinline__ void st_pair<bf16_t>(bf16_t* p, float a, float b) {
-    *(uint32_t*)p = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    *(uint32_t*)p = pack_bf16x2(a, b);
 }
 
 #define SAM_BWD_PIX 16      // pixels per workgroup (4 per wave)
