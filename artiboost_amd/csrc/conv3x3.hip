@@ -187,33 +187,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kk & 1][i]),
-                                                                           __builtin_bit_cast(bf16x8, fb[kk & 1][j]), acc[i][j], 0, 0, 0);
+                        // weights as the first operand: the accumulator is the TRANSPOSED tile (see the epilogue)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[kk & 1][j]),
+                                                                           __builtin_bit_cast(bf16x8, fa[kk & 1][i]), acc[i][j], 0, 0, 0);
             }
         }
     }
     __syncthreads();
 
-    // ---- epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  The tile is transposed through
-    // LDS (free after the K loop) so that HBM sees whole 16-byte vectors / full lines instead of 2-byte scatters.
+    // ---- epilogue.  The MFMAs computed the transposed tile (weights x pixels), so in the C/D layout a lane owns ONE pixel
+    // (lane&31) and, per register quad, four consecutive output channels (r&3) + 8*(r>>2) + 4*(lane>>5): a quad is one packed
+    // 8-byte LDS store into the pixel-major staging tile (4 ds_write_b64 per 32x32 block instead of 16 ds_write_b16), from
+    // which HBM sees whole 16-byte vectors / full lines.
     bf16_t* __restrict__ Out = (bf16_t*)g.Out;
     const bf16_t* __restrict__ Add = (const bf16_t*)g.addend;
     constexpr int SPITCH = BN * 2 + 16;                   // staging row pitch (bytes): +16 spreads rows over banks
-    float csum[TN], csq[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int row = (wave_m * TM + i) * 32 + l32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = (wave_m * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int cl = (wave_n * TN + j) * 32 + l32;
-                float v = acc[i][j][r];
-                *(bf16_t*)(smem + row * SPITCH + cl * 2) = f32_to_bf16(v);
-                int yy = ty0 + row / TW, xx = tx0 + row % TW;
-                if (yy < g.H && xx < g.W && n0 + cl < g.Cn) { csum[j] += v; csq[j] += v * v; }
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int cl = (wave_n * TN + j) * 32 + 8 * q4 + 4 * fhalf;
+                uint2 w;
+                w.x = pack_bf16x2(acc[i][j][q4 * 4], acc[i][j][q4 * 4 + 1]);
+                w.y = pack_bf16x2(acc[i][j][q4 * 4 + 2], acc[i][j][q4 * 4 + 3]);
+                *(uint2*)(smem + row * SPITCH + cl * 2) = w;
             }
         }
     }
@@ -225,7 +225,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
     // sum(dz * xhat) with dz = masked gradient (mask from the stored activation bn_out, or recomputed from bn_y).
     const bf16_t* __restrict__ BnY = (const bf16_t*)g.bn_y;
     const bf16_t* __restrict__ BnOut = (const bf16_t*)g.bn_out;
+    // Forward launches (g.stats): BatchNorm partial sums of the tile AS STORED (bf16-rounded), accumulated by the same
+    // thread-owns-a-channel-group scheme and combined through the same LDS partial buffer.
     float bs[8], bq[8], bmean[8], bistd[8], bsc[8], bsh[8];
+    if (g.stats) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { bs[k] = 0.f; bq[k] = 0.f; }
+    }
     if (BnY) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -253,6 +259,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
                     v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                 }
                 *(uint4*)(Out + o) = v;
+                if (g.stats) {
+                    const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = __uint_as_float(vw[k] << 16), hi = __uint_as_float(vw[k] & 0xffff0000u);
+                        bs[2 * k] += lo; bq[2 * k] += lo * lo; bs[2 * k + 1] += hi; bq[2 * k + 1] += hi * hi;
+                    }
+                }
                 if (BnY) {
                     const uint4 yv = *(const uint4*)(BnY + o);
                     uint4 ov = make_uint4(0, 0, 0, 0);
@@ -272,7 +286,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         }
     }
     __syncthreads();
-    if (BnY) {
+    if (BnY || g.stats) {
+        float* part_out = BnY ? g.bn_part : g.stats;
         constexpr int PART_OFF = (BM * SPITCH + 15) / 16 * 16;
         float* sp = (float*)(smem + PART_OFF);             // [NT / CPR][BN][2]
         const int rg = tid / CPR, cb = (tid % CPR) * 8;
@@ -284,31 +299,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             if (col < g.Cn) {
                 float s = 0.f, q = 0.f;
                 for (int r = 0; r < NT / CPR; ++r) { s += sp[(r * BN + c) * 2]; q += sp[(r * BN + c) * 2 + 1]; }
-                g.bn_part[((long)tile_sp * g.Cn + col) * 2] = s;
-                g.bn_part[((long)tile_sp * g.Cn + col) * 2 + 1] = q;
-            }
-        }
-    }
-    if (g.stats) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s = csum[j] + __shfl_xor(csum[j], 32, 64);
-            float q = csq[j] + __shfl_xor(csq[j], 32, 64);
-            if (lane < 32) {
-                int cl = (wave_n * TN + j) * 32 + lane;
-                s_stat[(wave_m * BN + cl) * 2] = s;
-                s_stat[(wave_m * BN + cl) * 2 + 1] = q;
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < BN; c += NT) {
-            int col = n0 + c;
-            if (col < g.Cn) {
-                float s = 0.f, q = 0.f;
-#pragma unroll
-                for (int wm = 0; wm < WM; ++wm) { s += s_stat[(wm * BN + c) * 2]; q += s_stat[(wm * BN + c) * 2 + 1]; }
-                g.stats[((long)tile_sp * g.Cn + col) * 2] = s;
-                g.stats[((long)tile_sp * g.Cn + col) * 2 + 1] = q;
+                part_out[((long)tile_sp * g.Cn + col) * 2] = s;
+                part_out[((long)tile_sp * g.Cn + col) * 2 + 1] = q;
             }
         }
     }
@@ -380,6 +372,7 @@ int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, i
                 float* bn_part) {
     int cfg = c3_config(N, H, W, C, Cn);
     if (!cfg) return AB_ESHAPE;
+    if (stats && bn_y) return AB_EINVAL;          // the two partial-sum outputs share the epilogue's accumulators
     Conv3Args g = {};
     g.X = x; g.Wt = wt; g.Out = out; g.addend = addend; g.stats = stats;
     g.N = N; g.H = H; g.W = W; g.C = C; g.Cn = Cn; g.ktot = 9 * C;
