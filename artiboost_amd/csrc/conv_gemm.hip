@@ -308,6 +308,18 @@ extern "C" int ab_conv2d_stem_fwd(const void* xpad, const void* w, void* y, int 
     return run(g, dtype, as_stream(stream), true);
 }
 
+// rows of BN partials ab_conv2d_dgrad writes into `stats` for this problem; 0 = not supported (stats must be NULL)
+extern "C" int ab_conv2d_dgrad_stat_rows(int dtype, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+    if (stride != 2 || kh > 4 || kw > 4 || (H & 1) || (W & 1) || Cout % 64 || !use_v2(dtype, false, Cout)) return 0;
+    int maxt = 0;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+        int nt = 0;
+        for (int i = 0; i < kh; ++i) for (int j = 0; j < kw; ++j) if (!((a + pad - i) % 2) && !((b + pad - j) % 2)) ++nt;
+        if (nt > maxt) maxt = nt;
+    }
+    return 4 * conv_gemm2_mtiles(N * (H / 2) * (W / 2), Cin, maxt * (Cout / 64));
+}
+
 // Data gradient of conv2d(x, w, stride, pad): dx[N,H,W,Cin] from dy[N,Ho,Wo,Cout] and wt = [Cin][kh][kw][Cout].
 // Also == ConvTranspose2d forward (x:=dy).  stride 1 or 2; for stride 2 one launch per output parity class.
 // addend (same shape as dx, may be NULL) is added in the epilogue (residual-branch gradient).
@@ -318,7 +330,11 @@ extern "C" int ab_conv2d_dgrad(const void* dy, const void* wt, void* dx, int dty
     if (Cout % bk_of(dtype) || (stride != 1 && stride != 2)) return AB_ESHAPE;
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (stride == 2 && ((H & 1) || (W & 1))) return AB_ESHAPE;
-    if (stats) return AB_ESHAPE;                  // BN partials of a data-gradient output: use ab_col_stats
+    // BN partials of the output (sum, sum of squares per channel; a transposed convolution's forward IS this data gradient):
+    // only on the one-grid stride-2 path and without an addend -- ab_conv2d_dgrad_stat_rows() says how many rows, 0 = use
+    // ab_col_stats on the result instead
+    if (stats && !ab_conv2d_dgrad_stat_rows(dtype, N, H, W, Cin, Cout, kh, kw, stride, pad)) return AB_ESHAPE;
+    if (stats && addend) return AB_ESHAPE;
     if (use_c3(dtype, kh, kw, stride, pad)) {
         int rc = conv3x3_run(dy, wt, dx, N, H, W, Cout, Cin, 1, addend, nullptr, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
@@ -326,7 +342,7 @@ extern "C" int ab_conv2d_dgrad(const void* dy, const void* wt, void* dx, int dty
     if (stride == 2 && kh <= 4 && kw <= 4 && use_v2(dtype, false, Cout)) {
         // all four output-parity classes in one grid (each alone fills half the chip or less)
         ConvGemmArgs g = {};
-        g.A = dy; g.Bw = wt; g.Out = dx; g.addend = addend;
+        g.A = dy; g.Bw = wt; g.Out = dx; g.addend = addend; g.stats = stats;
         g.N = N; g.Ha = Ho; g.Wa = Wo; g.Ca = Cout;
         g.Ho = H; g.Wo = W; g.Cn = Cin;
         g.P = H / 2; g.Q = W / 2; g.out_sh = g.out_sw = 2;
@@ -351,6 +367,7 @@ extern "C" int ab_conv2d_dgrad(const void* dy, const void* wt, void* dx, int dty
         int rc = conv_gemm2_run(g, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
+    if (stats) return AB_ESHAPE;
     for (int a = 0; a < stride; ++a) for (int b = 0; b < stride; ++b) {
         ConvGemmArgs g = {};
         g.A = dy; g.Bw = wt; g.Out = dx; g.addend = addend; g.stats = stats;

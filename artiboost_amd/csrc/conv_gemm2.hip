@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
     int tile_m, tile_n;
     if (g.nmajor) { tile_n = logical / tiles_m; tile_m = logical - tile_n * tiles_m; }
     else { tile_m = logical / tiles_n; tile_n = logical - tile_m * tiles_n; }
+    const int stat_row = tile_m;                             // BN-partial row: unique over (parity class, M tile)
     int ntaps = g.ntaps, out_oh = g.out_oh, out_ow = g.out_ow, tap0 = 0;
     if (g.nclass > 1) {
         const int cls = tile_m / tiles_mc;
@@ -278,8 +279,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
                 float s = 0.f, q = 0.f;
 #pragma unroll
                 for (int wm = 0; wm < WM; ++wm) { s += s_stat[(wm * BN + c) * 2]; q += s_stat[(wm * BN + c) * 2 + 1]; }
-                g.stats[((long)tile_m * g.Cn + col) * 2] = s;
-                g.stats[((long)tile_m * g.Cn + col) * 2 + 1] = q;
+                g.stats[((long)stat_row * g.Cn + col) * 2] = s;
+                g.stats[((long)stat_row * g.Cn + col) * 2 + 1] = q;
             }
         }
     }

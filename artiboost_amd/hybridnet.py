@@ -368,10 +368,20 @@ class HybridNet:
         fmean = K.avgpool_fwd(feat)                      # res_layer4_mean [N,512] f32 (resnet.py:219)
         h4, w4 = feat.shape[1], feat.shape[2]
         # ---- IntegralDeconvHead: ConvT == data-gradient of the mirrored stride-2 conv
-        d1 = K.conv2d_dgrad(feat, self.tr["hybrid_head.deconv_layers.0.weight"], (2 * h4, 2 * w4), 2, 1)
-        e1, bnpd1 = self._bn("hybrid_head.deconv_layers.1", d1, K.col_stats(d1) if tr else None, N * 4 * h4 * w4)
-        d2 = K.conv2d_dgrad(e1, self.tr["hybrid_head.deconv_layers.3.weight"], (4 * h4, 4 * w4), 2, 1)
-        e2, bnpd2 = self._bn("hybrid_head.deconv_layers.4", d2, K.col_stats(d2) if tr else None, N * 16 * h4 * w4)
+        # transposed convs: the data-gradient kernel of the mirrored conv, BatchNorm partials from its epilogue
+        # (AB_DECONV_STATS=0: separate col_stats passes)
+        fused = os.environ.get("AB_DECONV_STATS", "1") != "0"
+
+        def deconv(x, name, hw):
+            if tr and fused:
+                return K.conv2d_dgrad(x, self.tr[name], hw, 2, 1, want_stats=True)
+            d = K.conv2d_dgrad(x, self.tr[name], hw, 2, 1)
+            return d, (K.col_stats(d) if tr else None)
+
+        d1, st1 = deconv(feat, "hybrid_head.deconv_layers.0.weight", (2 * h4, 2 * w4))
+        e1, bnpd1 = self._bn("hybrid_head.deconv_layers.1", d1, st1, N * 4 * h4 * w4)
+        d2, st2 = deconv(e1, "hybrid_head.deconv_layers.3.weight", (4 * h4, 4 * w4))
+        e2, bnpd2 = self._bn("hybrid_head.deconv_layers.4", d2, st2, N * 16 * h4 * w4)
         logits = K.conv2d_fwd(e2, self.w("hybrid_head.final_layer.weight"), 1, 0,
                               bias=p.view("hybrid_head.final_layer.bias"))
         # ---- MLP_O box head, always f32 (tiny; keeps the 6-D rotation at full precision)

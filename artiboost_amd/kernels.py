@@ -47,8 +47,10 @@ def conv2d_stem_fwd(xpad, w_stem, H, W, want_stats=False):
     return (y, stats) if want_stats else y
 
 
-def conv2d_dgrad(dy, w_ihwo, in_hw, stride, pad, addend=None, bn=None):
+def conv2d_dgrad(dy, w_ihwo, in_hw, stride, pad, addend=None, bn=None, want_stats=False):
     """dy [N,Ho,Wo,Cout], w [Cin,kh,kw,Cout] -> dx [N,H,W,Cin]  (== ConvTranspose2d forward when x:=dy).
+    want_stats (transposed-conv forward): returns (dx, part) with the BatchNorm partial sums [rows, Cin, 2] of dx written by
+    the kernel's epilogue, or by a col_stats pass where the shape has no fused path.
     bn=(bn_y, bn_out_or_None, bnp): also try to fuse the BatchNorm-backward reduction of the layer that produced this
     conv's input into the epilogue (ab_conv2d_dgrad_bnstats); returns (dx, part) with part=None when the shape has no
     fused path."""
@@ -68,9 +70,17 @@ def conv2d_dgrad(dy, w_ihwo, in_hw, stride, pad, addend=None, bn=None):
                                                 L.ptr(bn_y), L.ptr(bn_out), L.ptr(bnp), L.ptr(part), L.stream()),
                     "ab_conv2d_dgrad_bnstats")
             return dx, part
+    part = None
+    if want_stats and addend is None:
+        rows = L.lib().ab_conv2d_dgrad_stat_rows(L.i(L.dt(dy)), L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw),
+                                                 L.i(stride), L.i(pad))
+        if rows > 0:
+            part = torch.empty((rows, Cin, 2), dtype=torch.float32, device=dy.device)
     L.check(L.lib().ab_conv2d_dgrad(L.ptr(dy), L.ptr(w_ihwo), L.ptr(dx), L.i(L.dt(dy)), L.i(N), L.i(H), L.i(W), L.i(Cin),
-                                    L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(addend), L.ptr(None),
+                                    L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(addend), L.ptr(part),
                                     L.stream()), "ab_conv2d_dgrad")
+    if want_stats:
+        return dx, (part if part is not None else col_stats(dx))
     return (dx, None) if bn is not None else dx
 
 

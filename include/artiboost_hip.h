@@ -63,6 +63,9 @@ int ab_conv2d_stem_fwd(const void* xpad, const void* w, void* y, int dtype, int 
                        float* stats, void* stream);
 /* dx of conv2d(x,w,stride,pad) (also == ConvTranspose2d forward).  H,W,Cin describe dx.  addend (optional, dx-shaped)
  * is added in the epilogue.  stats must be NULL.                                                                 */
+/* rows of BatchNorm partials [rows][Cin][2] ab_conv2d_dgrad writes when `stats` is given (the forward of a transposed
+ * convolution is this data gradient: simplebaseline.py:95-101); 0: not available for the shape, pass stats = NULL. */
+int ab_conv2d_dgrad_stat_rows(int dtype, int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 int ab_conv2d_dgrad(const void* dy, const void* wt, void* dx, int dtype, int N, int H, int W, int Cin, int Cout,
                     int kh, int kw, int stride, int pad, const void* addend, float* stats, void* stream);
 /* dw (float, OHWI) of conv2d; workspace of ab_conv2d_wgrad_workspace(N*Ho*Wo, Cout, kh*kw*Cin) bytes           */

@@ -382,3 +382,22 @@ def test_deferred_wgrad_reductions_are_bit_identical():
     assert not pend.descs and not pend.keep
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(8, 8, 8, 512, 256), (4, 16, 16, 256, 256), (2, 6, 10, 128, 64)])
+def test_transposed_conv_forward_with_fused_bn_partials(shape):
+    """ConvTranspose2d(4, 2, 1) forward = ab_conv2d_dgrad of the mirrored conv; with `stats` the epilogue also writes the
+    BatchNorm partial sums of the output (one row per parity class and M tile): same tensor, sums == a col_stats pass."""
+    from artiboost_amd import kernels as K
+    N, h, w, Ct, Co = shape
+    torch.manual_seed(N + Ct)
+    x = (torch.randn(N, h, w, Ct, device="cuda") * 0.5).to(torch.bfloat16)
+    wt = (torch.randn(Co, 4, 4, Ct, device="cuda") * 0.05).to(torch.bfloat16)     # [Cin of the mirrored conv][kh][kw][Cout]
+    ref = K.conv2d_dgrad(x, wt, (2 * h, 2 * w), 2, 1)
+    got, part = K.conv2d_dgrad(x, wt, (2 * h, 2 * w), 2, 1, want_stats=True)
+    assert torch.equal(got, ref)
+    want = K.col_stats(ref).double().sum(0).cpu()
+    have = part.double().sum(0).cpu()
+    yy = ref.double().reshape(-1, Co)
+    np.testing.assert_allclose(have[:, 0].numpy(), want[:, 0].numpy(), rtol=2e-3, atol=2e-3 * float(yy.abs().sum(0).max()))
+    np.testing.assert_allclose(have[:, 1].numpy(), want[:, 1].numpy(), rtol=2e-2)
