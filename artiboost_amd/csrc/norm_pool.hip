@@ -101,7 +101,13 @@ __device__ __forceinline__ void reduce_parts_1024(const float* __restrict__ part
     s = 0; q = 0;
     if (pl == 0) for (int k = 0; k < 16; ++k) { s += sm[(k * CPW + cl) * 2]; q += sm[(k * CPW + cl) * 2 + 1]; }
 }
-static inline int finalize_cpw(int C) { return C <= 64 ? 2 : (C <= 128 ? 4 : 8); }
+static inline int finalize_cpw(int C) {
+    // channels per workgroup of the finalize launches: 2, 4 and 8 measure the same end to end (6.25-6.28 ms/step; the
+    // launches sit at their ~5 us launch + cross-XCD read latency floor whatever their shape) -- 8 unless AB_BNFIN_CPW says so
+    static const int force = getenv("AB_BNFIN_CPW") ? atoi(getenv("AB_BNFIN_CPW")) : 0;
+    (void)C;
+    return (force == 2 || force == 4) ? force : 8;
+}
 
 // ---------------------------------------------------------------- BN finalize: partials -> scale/shift, saved stats
 // bnp: float [4][C] = scale (gamma*invstd), shift, mean, invstd.  running stats updated in place when non-null.
