@@ -20,6 +20,7 @@ static __device__ uint4 c3_zero_page[2];     // zero-initialised: source of ever
 
 struct Conv3Args {
     const void* X; const void* Wt; void* Out; const void* addend; float* stats;
+    const void* X_lo; unsigned wlo_delta;   // X3 (split-bf16) launches: low-order plane of X; byte distance Wt_lo - Wt
     int N, H, W, C;          // input  [N,H,W,C]  (C % 64 == 0)
     int Cn;                  // output [N,H,W,Cn]
     int ktot;                // weight row length (9*C)
@@ -37,8 +38,15 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsig
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 
-template <int BM, int TW, int BN, int WM, int WN, int FLIP>
+// X3 = 1: split-bf16 operands ("bf16x3").  Every fp32 value v is held as two bf16 planes hi = bf16(v), lo = bf16(v - hi)
+// (v = hi + lo to 2^-17 relative) and the product is hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation:
+// fp32-grade convolutions (the reference trains in fp32, train_artiboost.py:39-41) at a third of the bf16 matrix peak
+// instead of the 1/16 the f32-input MFMA gives.  LDS geometry is unchanged: a 128-byte row now carries a 32-channel
+// chunk as [hi: 4 x 16 B][lo: 4 x 16 B], so logical slots 0..3 are the hi k-slices and 4..7 the lo ones; only the fill
+// source (plane select per lane) and the MFMA sequence differ.  Output, addend and BN partials are fp32.
+template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
+    constexpr int CK = X3 ? 32 : 64;                   // channels per K chunk
     // NW = WM*WN waves (4 or 8).  Measured (tools/probe_fill.hip): a wave pulls ~10 GB/s of L2-resident data into LDS
     // whatever its queue depth, and a CU's fill rate scales with the number of waves issuing loads (4 waves 10 TB/s
     // chip-wide, 8 waves 20, 16 waves 30) -- so the same tile is worked by 8 waves where the fill is the limit.
@@ -57,7 +65,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
     constexpr int NRING = 3;
     constexpr int PATCH0 = NRING * BBYTES;             // LDS: [weight ring x3][patch 0][patch 1][stats]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* s_stat = (float*)(smem + PATCH0 + (g.C > 64 ? 2 : 1) * PATCH_BYTES);      // [WM][BN][2]; one patch buffer if one chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WN, wave_n = wave % WN;
@@ -71,9 +78,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
     const int ty0 = (trem / g.tiles_x) * TH, tx0 = (trem % g.tiles_x) * TW;
     const int n0 = tile_n * BN;
     const bf16_t* __restrict__ X = (const bf16_t*)g.X;
+    const bf16_t* __restrict__ Xlo = (const bf16_t*)g.X_lo;
     const bf16_t* __restrict__ Wt = (const bf16_t*)g.Wt;
     const bf16_t* zp = (const bf16_t*)c3_zero_page;
-    const int nchunks = g.C / 64;
+    const int nchunks = g.C / CK;
     const unsigned lds0 = lds_addr_of(smem);
 
     // ---- per-lane load assignment
@@ -87,7 +95,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         int y = ty0 + py - 1, x = tx0 + px - 1;
         p_ok[j] = (ii < PI) && (pp < NPIX) && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
         int c = (lane & 7) ^ ((px >> 1) & 7);
-        p_src[j] = p_ok[j] ? X + ((((long)img * g.H + y) * g.W + x) * g.C + c * 8) : zp;
+        const bf16_t* plane = (X3 && (c & 4)) ? Xlo : X;
+        if (X3) c &= 3;
+        p_src[j] = p_ok[j] ? plane + ((((long)img * g.H + y) * g.W + x) * g.C + c * 8) : zp;
     }
     unsigned b_voff[LB];                               // byte offset of this lane's weight-row chunk from the step's base
 #pragma unroll
@@ -95,7 +105,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         int ii = wave * LB + j;
         int r = ii * 8 + (lane >> 3);
         int col = min(n0 + r, g.Cn - 1);               // rows past Cn are loaded from a valid row and never stored
-        b_voff[j] = (unsigned)(((long)col * g.ktot + (((lane & 7) ^ ((r >> 1) & 7)) * 8)) * 2);
+        int c = (lane & 7) ^ ((r >> 1) & 7);
+        const unsigned pl = (X3 && (c & 4)) ? g.wlo_delta : 0u;
+        if (X3) c &= 3;
+        b_voff[j] = (unsigned)(((long)col * g.ktot + c * 8) * 2) + pl;
     }
     // ---- per-lane fragment addresses (LDS byte offsets)
     const int l32 = lane & 31, fhalf = lane >> 5;
@@ -123,12 +136,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
 #pragma unroll
         for (int j = 0; j < LP; ++j) {
             const int ii = wave * LP + j;
-            glds16(p_ok[j] ? (const void*)(p_src[j] + chunk * 64) : (const void*)zp,
+            glds16(p_ok[j] ? (const void*)(p_src[j] + chunk * CK) : (const void*)zp,
                    __builtin_amdgcn_readfirstlane(lds0 + PATCH0 + pbuf * PATCH_BYTES + ii * 1024));
         }
     };
     auto issue_b = [&](int chunk, int tap, int ring) {  // weights of (chunk, tap) into ring slot `ring`
-        const bf16_t* base = Wt + ((long)tap * g.C + chunk * 64);
+        const bf16_t* base = Wt + ((long)tap * g.C + chunk * CK);
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
             const int ii = wave * LB + j;
@@ -143,6 +156,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // X3: the two cross products run on a second accumulator chain (more independent MFMA chains per SIMD, and the small
+    // terms are summed among themselves before they meet the large one)
+    f32x16 accx[X3 ? TM : 1][X3 ? TN : 1];
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accx[i][j][r] = 0.f;
+    }
 
     // ---- software pipeline.  Issue order: P(0) B(0,0) B(0,1) | per step s after its barrier: B(s+2), and at tap 0
     // of chunk c also P(c+1).  All loads are inline asm (invisible to hipcc's wait counting): the waits below are exact.
@@ -168,6 +192,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             const int t3 = t / 3, tr = t % 3;
             const int dh = FLIP ? 2 - t3 : t3, dw = FLIP ? 2 - tr : tr;     // compile-time per unrolled tap
             const unsigned aoff = pbase + dh * PW * 128;
+            if constexpr (X3) {
+                // slots kk = 0,1: hi k-slices (16 channels each), kk = 2,3: the lo planes of the same channels
+                u32x4 fa[4][TM], fb[4][TN];
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) fa[k2 + 2 * h][i] = *(const lds_u32x4*)(a_rel[i][dw][k2 + 2 * h] + aoff);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) fb[k2 + 2 * h][j] = *(const lds_u32x4*)(b_rel[j][k2 + 2 * h] + (t % 3) * BBYTES);
+                    }
+                }
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[k2][j]), bl = __builtin_bit_cast(bf16x8, fb[k2 + 2][j]);
+                            const bf16x8 ah = __builtin_bit_cast(bf16x8, fa[k2][i]), al = __builtin_bit_cast(bf16x8, fa[k2 + 2][i]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[i][j], 0, 0, 0);
+                            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, accx[i][j], 0, 0, 0);
+                            accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, accx[i][j], 0, 0, 0);
+                        }
+                }
+            } else {
             u32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[0][i] = *(const lds_u32x4*)(a_rel[i][dw][0] + aoff);
@@ -191,9 +242,67 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[kk & 1][j]),
                                                                            __builtin_bit_cast(bf16x8, fa[kk & 1][i]), acc[i][j], 0, 0, 0);
             }
+            }
         }
     }
     __syncthreads();
+
+    if constexpr (X3) {
+        // ---- fp32 epilogue of the split-bf16 launches: a lane owns ONE pixel (lane&31) and per register quad four
+        // consecutive channels = one 16-byte LDS store into the pixel-major fp32 staging tile; rows leave as 16-byte vectors.
+        float* __restrict__ OutF = (float*)g.Out;
+        const float* __restrict__ AddF = (const float*)g.addend;
+        constexpr int SPF = BN * 4 + 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wave_m * TM + i) * 32 + l32;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int cl = (wave_n * TN + j) * 32 + 8 * q4 + 4 * fhalf;
+                    float4 w;
+                    w.x = acc[i][j][q4 * 4] + accx[i][j][q4 * 4]; w.y = acc[i][j][q4 * 4 + 1] + accx[i][j][q4 * 4 + 1];
+                    w.z = acc[i][j][q4 * 4 + 2] + accx[i][j][q4 * 4 + 2]; w.w = acc[i][j][q4 * 4 + 3] + accx[i][j][q4 * 4 + 3];
+                    *(float4*)(smem + row * SPF + cl * 4) = w;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int CPRF = BN / 4;                          // 16-byte chunks (4 channels) per tile row
+        static_assert(NT % CPRF == 0, "a thread keeps one channel group over all its rows");
+        float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int id = tid; id < BM * CPRF; id += NT) {
+            const int row = id / CPRF, c4 = id - row * CPRF;
+            const int yy = ty0 + row / TW, xx = tx0 + row % TW, col = n0 + c4 * 4;
+            if (yy < g.H && xx < g.W && col < g.Cn) {
+                float4 v = *(const float4*)(smem + row * SPF + c4 * 16);
+                const long o = (((long)img * g.H + yy) * g.W + xx) * g.Cn + col;
+                if (AddF) { const float4 a = *(const float4*)(AddF + o); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+                *(float4*)(OutF + o) = v;
+                fs[0] += v.x; fq[0] += v.x * v.x; fs[1] += v.y; fq[1] += v.y * v.y;
+                fs[2] += v.z; fq[2] += v.z * v.z; fs[3] += v.w; fq[3] += v.w * v.w;
+            }
+        }
+        __syncthreads();
+        if (g.stats) {
+            float* sp = (float*)smem;                          // [NT / CPRF][BN][2], over the consumed staging tile
+            const int rg = tid / CPRF, cb = (tid % CPRF) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sp[(rg * BN + cb + k) * 2] = fs[k]; sp[(rg * BN + cb + k) * 2 + 1] = fq[k]; }
+            __syncthreads();
+            for (int c = tid; c < BN; c += NT) {
+                const int col = n0 + c;
+                if (col < g.Cn) {
+                    float s2 = 0.f, q2 = 0.f;
+                    for (int r = 0; r < NT / CPRF; ++r) { s2 += sp[(r * BN + c) * 2]; q2 += sp[(r * BN + c) * 2 + 1]; }
+                    g.stats[((long)tile_sp * g.Cn + col) * 2] = s2;
+                    g.stats[((long)tile_sp * g.Cn + col) * 2 + 1] = q2;
+                }
+            }
+        }
+        return;
+    }
 
     // ---- epilogue.  The MFMAs computed the transposed tile (weights x pixels), so in the C/D layout a lane owns ONE pixel
     // (lane&31) and, per register quad, four consecutive output channels (r&3) + 8*(r>>2) + 4*(lane>>5): a quad is one packed
@@ -306,13 +415,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
     }
 }
 
-template <int BM, int TW, int BN, int WM, int WN>
+template <int BM, int TW, int BN, int WM, int WN, int X3 = 0>
 static size_t c3_lds(int nchunks) {
     constexpr int NW = WM * WN;
     constexpr int TH = BM / TW, NPIX = (TH + 2) * ((TW == 8) ? TW + 3 : TW + 2), PI = (NPIX + 7) / 8, LP = (PI + NW - 1) / NW;
     size_t need = (size_t)(nchunks > 1 ? 2 : 1) * LP * NW * 1024 + 3 * BN * 128 + WM * BN * 8;
     size_t stage = ((size_t)BM * (BN * 2 + 16) + 15) / 16 * 16;      // epilogue staging tile
     stage += (size_t)(64 * NW / (BN / 8)) * BN * 8;                    // + fused BN-backward partials [NT/CPR][BN][2]
+    if (X3) {                                                          // fp32 staging tile; the partials reuse it
+        stage = (size_t)BM * (BN * 4 + 16);
+        const size_t part = (size_t)(64 * NW / (BN / 4)) * BN * 8;
+        if (part > stage) stage = part;
+    }
     return need > stage ? need : stage;
 }
 
@@ -347,20 +461,20 @@ int conv3x3_tiles(int N, int H, int W, int C, int Cn) {
     return N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
 }
 
-template <int BM, int TW, int BN, int WM, int WN, int FLIP>
+template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0>
 static int c3_launch(Conv3Args& g, hipStream_t st) {
     constexpr int TH = BM / TW;
     g.tiles_x = (g.W + TW - 1) / TW; g.tiles_y = (g.H + TH - 1) / TH;
     int blocks = g.N * g.tiles_x * g.tiles_y * ((g.Cn + BN - 1) / BN);
-    size_t lds = c3_lds<BM, TW, BN, WM, WN>(g.C / 64);
+    size_t lds = c3_lds<BM, TW, BN, WM, WN, X3>(g.C / (X3 ? 32 : 64));
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<BM, TW, BN, WM, WN, FLIP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)c3_lds<BM, TW, BN, WM, WN>(2));
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<BM, TW, BN, WM, WN, FLIP, X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)c3_lds<BM, TW, BN, WM, WN, X3>(2));
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv3x3_kernel<BM, TW, BN, WM, WN, FLIP><<<blocks, 64 * WM * WN, lds, st>>>(g);
+    conv3x3_kernel<BM, TW, BN, WM, WN, FLIP, X3><<<blocks, 64 * WM * WN, lds, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -404,4 +518,35 @@ int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, i
     if (flip) C3_GO(1);
     C3_GO(0);
 #undef C3_GO
+}
+
+// ---- split-bf16 ("bf16x3") launches: x / wt given as (hi, lo) bf16 planes, out / addend / stats fp32.
+// Tile shapes are those of the bf16 path, always on 8 waves (the accumulators of both chains need the registers).
+int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn) {
+    if (C % 32) return 0;
+    return conv3x3_tiles(N, H, W, (C + 63) / 64 * 64, Cn);
+}
+
+int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W,
+                   int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st) {
+    if (C % 32) return AB_ESHAPE;
+    int cfg = c3_config(N, H, W, (C + 63) / 64 * 64, Cn);
+    if (!cfg || Cn % 4) return AB_ESHAPE;
+    const long delta = (const char*)wt_lo - (const char*)wt_hi;
+    if (delta < 0 || delta >= (1L << 31)) return AB_EINVAL;       // the lo plane is addressed as a 32-bit offset from the hi plane
+    Conv3Args g = {};
+    g.X = x_hi; g.X_lo = x_lo; g.Wt = wt_hi; g.wlo_delta = (unsigned)delta; g.Out = out; g.addend = addend; g.stats = stats;
+    g.N = N; g.H = H; g.W = W; g.C = C; g.Cn = Cn; g.ktot = 9 * C; g.flip = flip;
+#define C3X_GO(FL) \
+    do { \
+        if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, FL, 1>(g, st); \
+        if (cfg == 2) return c3_launch<256, 32, 128, 4, 2, FL, 1>(g, st); \
+        if (cfg == 3) return c3_launch<128, 16, 128, 4, 2, FL, 1>(g, st); \
+        if (cfg == 5) return c3_launch<64, 8, 128, 2, 4, FL, 1>(g, st); \
+        if (cfg == 6) return c3_launch<256, 16, 64, 4, 2, FL, 1>(g, st); \
+        return c3_launch<128, 16, 64, 4, 2, FL, 1>(g, st); \
+    } while (0)
+    if (flip) C3X_GO(1);
+    C3X_GO(0);
+#undef C3X_GO
 }

@@ -6,6 +6,7 @@
 
 struct ConvGemmArgs {
     const void* A; const void* Bw; void* Out;
+    const void* A_lo; const void* Bw_lo;        // split-bf16 (X3) launches of conv_gemm2: the low-order planes of A and Bw
     const float* bias; const void* addend; float* stats;   // stats: [gridM][Cn][2]
     int N, Ha, Wa, Ca;          // A tensor dims (Ca = channel pitch in elements)
     int P, Q;                   // output sub-grid

@@ -23,8 +23,11 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // STEM: A is the zero-bordered NHWC4 image; a K step covers TWO kernel rows (2 x 32 elements = 128 bytes per output pixel:
 // chunks 0..3 from image row 2p + 2s, chunks 4..7 from row 2p + 2s + 1, both starting at column 2q), four steps for the 7
 // rows + 1 row of padding; weight rows are [7][8][4] = 224 elements, the missing 32 are read from the zero page.
-template <int BM, int BN, int WM, int WN, int NBUF = 3, bool STEM = false>
+// X3 = 1: split-bf16 operands (see conv3x3.hip): a 128-byte LDS row carries a 32-channel chunk as [hi 64 B][lo 64 B];
+// g.cpt counts 32-channel chunks; Out / addend are fp32.
+template <int BM, int BN, int WM, int WN, int NBUF = 3, bool STEM = false, int X3 = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g) {
+    constexpr int CK = X3 ? 32 : 64;                          // channels per K step
     constexpr int NW = WM * WN, NT = 64 * NW;                // 4 or 8 waves: the LDS fill rate scales with the waves issuing loads
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;     // 32x32 MFMA tiles per wave
     constexpr int IA = BM / 8, IB = BN / 8;                 // 1-KiB load instructions (8 rows each) for the A / B tile
@@ -66,6 +69,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16_t* __restrict__ A = (const bf16_t*)g.A;
     const bf16_t* __restrict__ Bw = (const bf16_t*)g.Bw;
+    const bf16_t* __restrict__ Alo = (const bf16_t*)g.A_lo;
+    const bf16_t* __restrict__ Bwlo = (const bf16_t*)g.Bw_lo;
     const int PQ = g.P * g.Q;
     const bf16_t* zp = (const bf16_t*)ab_zero_page;
 
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
     const int lrow = lane >> 3, lslot = lane & 7;
     constexpr int NA = IA / NW, NB = IB / NW;               // per wave
     static_assert(IA % NW == 0 && IB % NW == 0, "tile rows must split evenly over the waves");
-    int a_h[NA], a_w[NA], a_chunk[NA]; long a_base[NA]; bool a_ok[NA];
+    int a_h[NA], a_w[NA], a_chunk[NA]; long a_base[NA]; bool a_ok[NA]; bool a_lo[NA], b_lo[NB];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         int ii = wave * NA + j;
@@ -86,6 +91,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         a_h[j] = p * g.a_sh; a_w[j] = q * g.a_sw;
         a_base[j] = (long)n * g.Ha * g.Wa;
         a_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;      // element offset of the logical chunk this lane fetches
+        a_lo[j] = false;
+        if (X3) { const int c = lslot ^ ((r >> 1) & 7); a_lo[j] = (c & 4) != 0; a_chunk[j] = (c & 3) * 8; }
         if (STEM) { const int c = lslot ^ ((r >> 1) & 7); a_chunk[j] = ((c >> 2) << 16) | ((c & 3) * 8); }   // (row of the pair, offset)
         if (lslot == 0 && ii < IA) {
             int op = (n * g.Ho + p * g.out_sh + out_oh) * g.Wo + q * g.out_sw + out_ow;
@@ -101,11 +108,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         b_ok[j] = (ii < IB) && (col < g.Cn);
         b_off[j] = (long)(b_ok[j] ? col : 0) * g.ktot;
         b_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;
+        b_lo[j] = false;
+        if (X3) { const int c = lslot ^ ((r >> 1) & 7); b_lo[j] = (c & 4) != 0; b_chunk[j] = (c & 3) * 8; }
     }
     const int nsteps = STEM ? 4 : ntaps * g.cpt;
 
     auto issue = [&](int step, int buf) {
-        const int t = STEM ? 0 : step / g.cpt, c0 = STEM ? step * 64 : (step - t * g.cpt) * 64;
+        const int t = STEM ? 0 : step / g.cpt, c0 = STEM ? step * 64 : (step - t * g.cpt) * CK;
         const int dh = STEM ? 0 : s_tap[t], dw = STEM ? 0 : s_tap[CG_MAXTAPS + t], ko = STEM ? 0 : s_tap[2 * CG_MAXTAPS + t];
         unsigned char* base = smem + buf * BUFSZ;
 #pragma unroll
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
                 } else {
                     int hi = a_h[j] + dh, wi = a_w[j] + dw;
                     bool ok = a_ok[j] && (unsigned)hi < (unsigned)g.Ha && (unsigned)wi < (unsigned)g.Wa;
-                    src = ok ? (A + ((a_base[j] + (long)hi * g.Wa + wi) * g.Ca + c0 + a_chunk[j])) : zp;
+                    src = ok ? (((X3 && a_lo[j]) ? Alo : A) + ((a_base[j] + (long)hi * g.Wa + wi) * g.Ca + c0 + a_chunk[j])) : zp;
                 }
                 glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(base + ii * 1024)));
             }
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
             const int ii = wave * NB + j;
             if (ii < IB) {
                 const bool ok = b_ok[j] && (!STEM || c0 + b_chunk[j] < g.ktot);
-                const bf16_t* src = ok ? (Bw + (b_off[j] + ko + c0 + b_chunk[j])) : zp;
+                const bf16_t* src = ok ? (((X3 && b_lo[j]) ? Bwlo : Bw) + (b_off[j] + ko + c0 + b_chunk[j])) : zp;
                 glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(base + BM * 128 + ii * 1024)));
             }
         }
@@ -142,6 +151,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x16 accx[X3 ? TM : 1][X3 ? TN : 1];                  // X3: the two cross products hi*lo + lo*hi (second chain)
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accx[i][j][r] = 0.f;
+    }
 
     // ring with counted waits (raw s_barrier: __syncthreads() would drain vmcnt to 0 and kill the overlap):
     //   step s:  wait until only the loads of steps s+1 .. s+PD-1 are in flight -> barrier (step-s tile visible to all
@@ -182,6 +200,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
                 fb[j] = *(const uint4*)(sb + r * 128 + (((kk * 2 + fhalf) ^ ((r >> 1) & 7)) << 4));
             }
         };
+        if constexpr (X3) {
+            // slots 0,1: hi k-slices (16 channels each); slots 2,3: the lo planes of the same channels
+            uint4 fa[4][TM], fb[4][TN];
+            read_frags(0, fa[0], fb[0]); read_frags(2, fa[2], fb[2]);
+            read_frags(1, fa[1], fb[1]); read_frags(3, fa[3], fb[3]);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, fa[k2][i]), al = __builtin_bit_cast(bf16x8, fa[k2 + 2][i]);
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[k2][j]), bl = __builtin_bit_cast(bf16x8, fb[k2 + 2][j]);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, accx[i][j], 0, 0, 0);
+                        accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, accx[i][j], 0, 0, 0);
+                    }
+        } else {
         // software-pipelined fragments: the ds_reads of k-slice kk+1 are in flight while the MFMAs of kk issue
         uint4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
         read_frags(0, fa0, fb0);
@@ -196,9 +232,83 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]),
                                                                        __builtin_bit_cast(bf16x8, fb[j]), acc[i][j], 0, 0, 0);
         }
+        }
         if (++cur == NBUF) cur = 0;
     }
     __syncthreads();
+
+    if constexpr (X3) {
+        // ---- fp32 epilogue of the split-bf16 launches (same flow as below, 4-byte elements, 16-byte row vectors)
+        float* __restrict__ OutF = (float*)g.Out;
+        const float* __restrict__ AddF = (const float*)g.addend;
+        constexpr int SPF = BN * 4 + 16;
+        static_assert(BM * SPF <= NBUF * BUFSZ, "fp32 staging tile must fit in the K-loop buffers");
+        float csum[TN], csq[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cl = (wave_n * TN + j) * 32 + (lane & 31);
+            const int col = n0 + cl;
+            const bool cok = col < g.Cn;
+            const float bj = (g.bias && cok) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wave_m * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+                    float v = (acc[i][j][r] + accx[i][j][r]) + bj;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    *(float*)(smem + row * SPF + cl * 4) = v;
+                    if (cok && s_outpix[row] >= 0) { csum[j] += v; csq[j] += v * v; }
+                }
+            }
+        }
+        __syncthreads();
+        {
+            constexpr int CPRF = BN / 4;
+            const bool vec_ok = (g.Cn & 3) == 0;
+            for (int id = tid; id < BM * CPRF; id += NT) {
+                const int row = id / CPRF, c4 = id - row * CPRF;
+                const int op = s_outpix[row], col = n0 + c4 * 4;
+                if (op < 0 || col >= g.Cn) continue;
+                const long o = (long)op * g.Cn + col;
+                float4 v = *(const float4*)(smem + row * SPF + c4 * 16);
+                if (vec_ok) {
+                    if (AddF) { const float4 a = *(const float4*)(AddF + o); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+                    *(float4*)(OutF + o) = v;
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                    for (int k = 0; k < 4 && col + k < g.Cn; ++k) OutF[o + k] = vv[k] + (AddF ? AddF[o + k] : 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        if (g.stats) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float s2 = csum[j] + __shfl_xor(csum[j], 32, 64);
+                float q2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+                if (lane < 32) {
+                    int cl = (wave_n * TN + j) * 32 + lane;
+                    s_stat[(wave_m * BN + cl) * 2] = s2;
+                    s_stat[(wave_m * BN + cl) * 2 + 1] = q2;
+                }
+            }
+            __syncthreads();
+            for (int c = tid; c < BN; c += NT) {
+                int col = n0 + c;
+                if (col < g.Cn) {
+                    float s2 = 0.f, q2 = 0.f;
+#pragma unroll
+                    for (int wm = 0; wm < WM; ++wm) { s2 += s_stat[(wm * BN + c) * 2]; q2 += s_stat[(wm * BN + c) * 2 + 1]; }
+                    g.stats[((long)stat_row * g.Cn + col) * 2] = s2;
+                    g.stats[((long)stat_row * g.Cn + col) * 2 + 1] = q2;
+                }
+            }
+        }
+        return;
+    }
 
     // ---- epilogue: bias / ReLU / BN partials from the f32 accumulators, then the bf16 tile is transposed through LDS
     // (free after the K loop) and written with 16-byte vectors (the residual-gradient addend is folded in there).
@@ -344,6 +454,27 @@ int conv_gemm2_run(ConvGemmArgs& g, hipStream_t st) {
         if (deep) conv_gemm2_kernel<64, 64, 2, 2, 5><<<tiles, 256, 0, st>>>(g);
         else conv_gemm2_kernel<64, 64, 2, 2><<<tiles, 256, 0, st>>>(g);
     }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// ---- split-bf16 ("bf16x3") launches: g.A / g.A_lo and g.Bw / g.Bw_lo are the bf16 planes, g.cpt counts 32-channel
+// chunks, Out / addend / stats are fp32.  Tile choice follows the bf16 path (2x the K steps of the same shape).
+int conv_gemm2_x3_mtiles(int M, int Cn, int nsteps) {
+    int bm, bn; pick_tile2(M, Cn, nsteps, &bm, &bn);
+    return (M + bm - 1) / bm;
+}
+
+int conv_gemm2_x3_run(ConvGemmArgs& g, hipStream_t st) {
+    if (g.Ca % 32 || !g.A_lo || !g.Bw_lo) return AB_ESHAPE;
+    int bm, bn; pick_tile2(g.M, g.Cn, g.ntaps * g.cpt, &bm, &bn);
+    int tiles = ((g.M + bm - 1) / bm) * ((g.Cn + bn - 1) / bn) * (g.nclass > 1 ? g.nclass : 1);
+    const long wbytes = (long)g.Cn * g.ktot * 4, abytes = (long)g.N * g.Ha * g.Wa * g.Ca * 4;
+    g.nmajor = (wbytes > (3L << 20) && abytes <= (8L << 20) && g.Cn > bn);
+    if (bm == 128 && bn == 128) conv_gemm2_kernel<128, 128, 4, 2, 3, false, 1><<<tiles, 512, 0, st>>>(g);
+    else if (bm == 128 && bn == 64) conv_gemm2_kernel<128, 64, 4, 2, 3, false, 1><<<tiles, 512, 0, st>>>(g);
+    else if (bm == 64 && bn == 128) conv_gemm2_kernel<64, 128, 2, 4, 3, false, 1><<<tiles, 512, 0, st>>>(g);
+    else conv_gemm2_kernel<64, 64, 2, 2, 3, false, 1><<<tiles, 256, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

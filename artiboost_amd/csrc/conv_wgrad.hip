@@ -309,6 +309,12 @@ static int launch_reduce(const float* slabs, int ns, long slab_elems, int src_j,
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// the fixed-order slab reduction for the weight-gradient kernels of other translation units (conv_x3.hip)
+int wgrad_launch_reduce(const float* slabs, int ns, long slab_elems, int src_j, int dst_j, float* dst, int accumulate,
+                        int stem_mask, hipStream_t st) {
+    return launch_reduce(slabs, ns, slab_elems, src_j, dst_j, dst, accumulate, stem_mask, st);
+}
+
 static void pick_wgrad(int M, int Cout, int jtot, int* bi, int* bj, int* nslices, int* rows) {
     *bi = (Cout % 128 == 0) ? 128 : 64;
     *bj = (jtot % 128 == 0) ? 128 : 64;

@@ -1,0 +1,165 @@
+// C ABI of the split-bf16 ("bf16x3") convolution path: fp32-grade convolutions on the bf16 matrix cores.
+//
+// The reference trains in fp32 (train/train_artiboost.py:39-41,91-96: no autocast anywhere); the f32-input MFMA of
+// gfx950 runs at 1/16 of the bf16 rate (157 vs 2500 TFLOP/s).  Here every fp32 operand v is carried as two bf16 planes
+//     hi = bf16(v),  lo = bf16(v - hi)          (v = hi + lo up to 2^-17 |v|)
+// and a product a*b is evaluated as  a.hi*b.hi + a.hi*b.lo + a.lo*b.hi  on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation (the dropped lo*lo term is 2^-18 relative): three MFMA passes, i.e. a 833 TFLOP/s roof, with outputs,
+// residual addends, BatchNorm partials and weight-gradient slabs in fp32.  The kernels are the X3 instantiations of
+// conv3x3.hip / conv_gemm2.hip (forward, data gradient) and wgrad3x3.hip / wgrad_gemm2.hip (weight gradient).
+#include "conv_common.h"
+
+int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn);
+int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W,
+                   int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st);
+int conv_gemm2_x3_mtiles(int M, int Cn, int nsteps);
+int conv_gemm2_x3_run(ConvGemmArgs& g, hipStream_t st);
+int wgrad3x3_x3_slices(int N, int H, int W, int Cin, int Cout);
+int wgrad3x3_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N, int H, int W,
+                    int Cin, int Cout, hipStream_t st);
+int wgrad_gemm2_x3_slices(int M, int Cout, int Cin, int ntaps);
+int wgrad_gemm2_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N, int H, int W,
+                       int Cin, int Cout, int kh, int kw, int stride, int pad, hipStream_t st);
+int wgrad_launch_reduce(const float* slabs, int ns, long slab_elems, int src_j, int dst_j, float* dst, int accumulate,
+                           int stem_mask, hipStream_t st);      // conv_wgrad.hip
+
+// ---------------------------------------------------------------- fp32 -> (hi, lo) bf16 planes
+__global__ __launch_bounds__(256) void split_f32_kernel(const float* __restrict__ src, long nvec, bf16_t* __restrict__ hi,
+                                                        bf16_t* __restrict__ lo) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const float4 a = *(const float4*)(src + i * 8), b = *(const float4*)(src + i * 8 + 4);
+        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            h[k] = pack_bf16x2(f[2 * k], f[2 * k + 1]);
+            const float r0 = f[2 * k] - __uint_as_float(h[k] << 16), r1 = f[2 * k + 1] - __uint_as_float(h[k] & 0xffff0000u);
+            l[k] = pack_bf16x2(r0, r1);
+        }
+        *(uint4*)(hi + i * 8) = make_uint4(h[0], h[1], h[2], h[3]);
+        *(uint4*)(lo + i * 8) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
+extern "C" int ab_split_f32(const float* src, long n, void* hi, void* lo, void* stream) {
+    if (!src || !hi || !lo) return AB_EINVAL;
+    if (n % 8) return AB_ESHAPE;
+    const long nvec = n / 8;
+    long b = (nvec + 255) / 256; if (b > 8192) b = 8192; if (b < 1) b = 1;
+    split_f32_kernel<<<(int)b, 256, 0, as_stream(stream)>>>(src, nvec, (bf16_t*)hi, (bf16_t*)lo);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+// ---------------------------------------------------------------- forward
+static bool x3_is_c3(int kh, int kw, int stride, int pad) { return kh == 3 && kw == 3 && stride == 1 && pad == 1; }
+
+extern "C" int ab_conv2d_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (x3_is_c3(kh, kw, stride, pad)) { int t = conv3x3_x3_tiles(N, H, W, Cin, Cout); if (t) return t; }
+    return conv_gemm2_x3_mtiles(N * Ho * Wo, Cout, kh * kw * (Cin / 32));
+}
+
+extern "C" int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* y, int N, int H,
+                                int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* bias, float* stats,
+                                int relu, void* stream) {
+    if (!x_hi || !x_lo || !w_hi || !w_lo || !y) return AB_EINVAL;
+    if (kh * kw > CG_MAXTAPS || Cin % 32) return AB_ESHAPE;
+    if (x3_is_c3(kh, kw, stride, pad) && !bias && !relu) {
+        int rc = conv3x3_x3_run(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, 0, nullptr, stats, as_stream(stream));
+        if (rc != AB_ESHAPE) return rc;
+    }
+    ConvGemmArgs g = {};
+    g.A = x_hi; g.A_lo = x_lo; g.Bw = w_hi; g.Bw_lo = w_lo; g.Out = y; g.bias = bias; g.stats = stats; g.relu = relu;
+    g.N = N; g.Ha = H; g.Wa = W; g.Ca = Cin;
+    g.Ho = (H + 2 * pad - kh) / stride + 1; g.Wo = (W + 2 * pad - kw) / stride + 1; g.Cn = Cout;
+    g.P = g.Ho; g.Q = g.Wo; g.out_sh = g.out_sw = 1; g.a_sh = g.a_sw = stride;
+    g.ntaps = kh * kw; g.cpt = Cin / 32; g.ktot = kh * kw * Cin; g.M = N * g.P * g.Q;
+    for (int i = 0; i < kh; ++i) for (int j = 0; j < kw; ++j) {
+        g.dh[i * kw + j] = (int8_t)(i - pad); g.dw[i * kw + j] = (int8_t)(j - pad); g.koff[i * kw + j] = (i * kw + j) * Cin;
+    }
+    return conv_gemm2_x3_run(g, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- data gradient (== transposed-convolution forward)
+extern "C" int ab_conv2d_dgrad_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+    if (stride != 2 || kh > 4 || kw > 4 || (H & 1) || (W & 1) || Cout % 32) return 0;
+    int maxt = 0;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+        int nt = 0;
+        for (int i = 0; i < kh; ++i) for (int j = 0; j < kw; ++j) if (!((a + pad - i) % 2) && !((b + pad - j) % 2)) ++nt;
+        if (nt > maxt) maxt = nt;
+    }
+    return 4 * conv_gemm2_x3_mtiles(N * (H / 2) * (W / 2), Cin, maxt * (Cout / 32));
+}
+
+extern "C" int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N,
+                                  int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend,
+                                  float* stats, void* stream) {
+    if (!dy_hi || !dy_lo || !wt_hi || !wt_lo || !dx) return AB_EINVAL;
+    if (Cout % 32 || (stride != 1 && stride != 2)) return AB_ESHAPE;
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    if (stride == 2 && ((H & 1) || (W & 1) || kh > 4 || kw > 4)) return AB_ESHAPE;
+    if (stats && (addend || !ab_conv2d_dgrad_x3_stat_rows(N, H, W, Cin, Cout, kh, kw, stride, pad))) return AB_ESHAPE;
+    if (x3_is_c3(kh, kw, stride, pad)) {
+        int rc = conv3x3_x3_run(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cout, Cin, 1, addend, nullptr, as_stream(stream));
+        if (rc != AB_ESHAPE) return rc;
+    }
+    ConvGemmArgs g = {};
+    g.A = dy_hi; g.A_lo = dy_lo; g.Bw = wt_hi; g.Bw_lo = wt_lo; g.Out = dx; g.addend = addend; g.stats = stats;
+    g.N = N; g.Ha = Ho; g.Wa = Wo; g.Ca = Cout;
+    g.Ho = H; g.Wo = W; g.Cn = Cin;
+    g.a_sh = g.a_sw = 1; g.cpt = Cout / 32; g.ktot = kh * kw * Cout;
+    if (stride == 2) {      // the four output-parity classes in one grid (conv_gemm2.hip, nclass)
+        g.P = H / 2; g.Q = W / 2; g.out_sh = g.out_sw = 2; g.M = N * g.P * g.Q;
+        g.nclass = 4;
+        int maxt = 0;
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+            const int c = a * 2 + b;
+            int nt = 0;
+            for (int i = 0; i < kh; ++i) {
+                if ((a + pad - i) % 2) continue;
+                for (int j = 0; j < kw; ++j) {
+                    if ((b + pad - j) % 2) continue;
+                    g.dh[c * 4 + nt] = (int8_t)((a + pad - i) / 2); g.dw[c * 4 + nt] = (int8_t)((b + pad - j) / 2);
+                    g.koff[c * 4 + nt] = (i * kw + j) * Cout; ++nt;
+                }
+            }
+            g.cls_ntaps[c] = nt; g.cls_oh[c] = a; g.cls_ow[c] = b;
+            if (nt > maxt) maxt = nt;
+        }
+        g.ntaps = maxt;
+        return conv_gemm2_x3_run(g, as_stream(stream));
+    }
+    if (kh * kw > CG_MAXTAPS) return AB_ESHAPE;
+    g.P = H; g.Q = W; g.out_sh = g.out_sw = 1; g.M = N * H * W;
+    int nt = 0;
+    for (int i = 0; i < kh; ++i) for (int j = 0; j < kw; ++j) {
+        g.dh[nt] = (int8_t)(pad - i); g.dw[nt] = (int8_t)(pad - j); g.koff[nt] = (i * kw + j) * Cout; ++nt;
+    }
+    g.ntaps = nt;
+    return conv_gemm2_x3_run(g, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- weight gradient
+extern "C" int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N,
+                                  int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace,
+                                  int accumulate, void* stream) {
+    if (!x_hi || !x_lo || !dy_hi || !dy_lo || !dw || !workspace) return AB_EINVAL;
+    if (kh * kw > 16 || Cin % 64 || Cout % 64) return AB_ESHAPE;
+    hipStream_t st = as_stream(stream);
+    const long slab = (long)Cout * kh * kw * Cin;
+    if (x3_is_c3(kh, kw, stride, pad)) {
+        int ns = wgrad3x3_x3_slices(N, H, W, Cin, Cout);
+        if (ns > 0) {
+            int rc = wgrad3x3_x3_run(x_hi, x_lo, dy_hi, dy_lo, (float*)workspace, N, H, W, Cin, Cout, st);
+            if (rc) return rc;
+            return wgrad_launch_reduce((float*)workspace, ns, slab, 9 * Cin, 9 * Cin, dw, accumulate, 0, st);
+        }
+    }
+    const int M = N * ((H + 2 * pad - kh) / stride + 1) * ((W + 2 * pad - kw) / stride + 1);
+    int ns = wgrad_gemm2_x3_slices(M, Cout, Cin, kh * kw);
+    if (ns <= 0) return AB_ESHAPE;
+    int rc = wgrad_gemm2_x3_run(x_hi, x_lo, dy_hi, dy_lo, (float*)workspace, N, H, W, Cin, Cout, kh, kw, stride, pad, st);
+    if (rc) return rc;
+    return wgrad_launch_reduce((float*)workspace, ns, slab, kh * kw * Cin, kh * kw * Cin, dw, accumulate, 0, st);
+}

@@ -26,6 +26,7 @@ static __device__ uint4 wg3_zero_page[2];
 
 struct Wg3Args {
     const void* X; const void* DY; float* slabs;
+    const void* X_lo; const void* DY_lo;         // split-bf16 (X3) launches: low-order planes
     int N, H, Cin, Cout;
     int bands_per_slice, nbands;
 };
@@ -40,7 +41,9 @@ __device__ __forceinline__ uint4 tr_pair(unsigned addr_lo, unsigned addr_hi) {
 // NW = 4: every wave (2 co-halves x 2 ci-halves) accumulates all nine taps.  NW = 8: the taps are split 5 + 4 over two
 // groups of four waves -- twice the waves issue the band / patch DMA (the L2->LDS fill rate scales with the number of
 // issuing waves, tools/probe_fill.hip) and each holds 80 instead of 144 accumulators.
-template <int W, int TH, int NW = 4>
+// X3 = 1: split-bf16 operands (conv3x3.hip): the band and the patch are staged once per plane ([dy hi][dy lo][x hi][x lo],
+// bands of 64 pixels so that two stages still fit) and every (dy, x) fragment pair feeds hi*hi + hi*lo + lo*hi.
+template <int W, int TH, int NW = 4, int X3 = 0>
 __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
     constexpr int BP = TH * W;                       // band pixels (multiple of 16)
     constexpr int KS = BP / 16;                      // k-slices per band
@@ -50,7 +53,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
     constexpr int IX = (NPIX + 7) / 8, LX = (IX + NW - 1) / NW;
     constexpr int ABYTES = LA * NW * 1024, XBYTES = LX * NW * 1024;
     constexpr int NACC = NW == 8 ? 5 : 9;
-    constexpr int BUF = ABYTES + XBYTES;
+    constexpr int NPL = X3 ? 2 : 1;                  // operand planes
+    constexpr int BUF = NPL * (ABYTES + XBYTES);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned lds0 = lds_addr_of(smem);
 
@@ -66,6 +70,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
     const int bands_per_img = g.H / TH;
     const bf16_t* __restrict__ X = (const bf16_t*)g.X;
     const bf16_t* __restrict__ DY = (const bf16_t*)g.DY;
+    const bf16_t* __restrict__ Xl = (const bf16_t*)g.X_lo;
+    const bf16_t* __restrict__ DYl = (const bf16_t*)g.DY_lo;
     const bf16_t* zp = (const bf16_t*)wg3_zero_page;
 
     // ---- per-lane fill assignment
@@ -95,14 +101,19 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
             const int ii = wave * LA + j;
             glds16(a_ok[j] ? (const void*)(DY + pix0 * g.Cout + a_off[j]) : (const void*)zp,
                    __builtin_amdgcn_readfirstlane(lds0 + buf * BUF + ii * 1024));
+            if constexpr (X3)
+                glds16(a_ok[j] ? (const void*)(DYl + pix0 * g.Cout + a_off[j]) : (const void*)zp,
+                       __builtin_amdgcn_readfirstlane(lds0 + buf * BUF + ABYTES + ii * 1024));
         }
 #pragma unroll
         for (int j = 0; j < LX; ++j) {
             const int ii = wave * LX + j;
             int y = y0 + x_pr[j] - 1;
             bool ok = x_in[j] && (unsigned)y < (unsigned)g.H;
-            const bf16_t* src = ok ? X + ((((long)img * g.H + y) * W + (x_pc[j] - 1)) * g.Cin + ci0 + x_c[j]) : zp;
-            glds16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * BUF + ABYTES + ii * 1024));
+            const long xo = (((long)img * g.H + y) * W + (x_pc[j] - 1)) * g.Cin + ci0 + x_c[j];
+            glds16(ok ? X + xo : zp, __builtin_amdgcn_readfirstlane(lds0 + buf * BUF + NPL * ABYTES + ii * 1024));
+            if constexpr (X3)
+                glds16(ok ? Xl + xo : zp, __builtin_amdgcn_readfirstlane(lds0 + buf * BUF + NPL * ABYTES + XBYTES + ii * 1024));
         }
     };
 
@@ -151,6 +162,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
             // handled by ty_l/tx_l in x_base, so only the slice origin (row/col of pixel p0) is added here
             const int p0 = 16 * s;
             uint4 fa = tr_pair(a_cur[0] + p0 * 128, a_cur[1] + p0 * 128);
+            uint4 fal;
+            if constexpr (X3) fal = tr_pair(a_cur[0] + ABYTES + p0 * 128, a_cur[1] + ABYTES + p0 * 128);
 #pragma unroll
             for (int tt = 0; tt < NTP; ++tt) {
                 const int kh = (T0 + tt) / 3, kw = (T0 + tt) % 3;
@@ -159,6 +172,13 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
                 uint4 fb = tr_pair(x_cur[kw][0] + disp, x_cur[kw][1] + disp);
                 acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
                                                                   acc[tt], 0, 0, 0);
+                if constexpr (X3) {
+                    uint4 fbl = tr_pair(x_cur[kw][0] + XBYTES + disp, x_cur[kw][1] + XBYTES + disp);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fbl),
+                                                                      acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fal), __builtin_bit_cast(bf16x8, fb),
+                                                                      acc[tt], 0, 0, 0);
+                }
             }
         }
     };
@@ -171,7 +191,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (band + 1 < band_end) issue_band(band + 1, buf ^ 1);
-        const unsigned ab = lds0 + buf * BUF, xb = ab + ABYTES;
+        const unsigned ab = lds0 + buf * BUF, xb = ab + NPL * ABYTES;
         if constexpr (NW == 8) {
             if (tg == 0) band_compute(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, ab, xb);
             else band_compute(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{}, ab, xb);
@@ -195,23 +215,23 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
     }
 }
 
-template <int W, int TH, int NW>
+template <int W, int TH, int NW, int X3 = 0>
 static size_t wg3_lds() {
     constexpr int BP = TH * W, NPIX = (TH + 2) * (W + 4);
     constexpr int LA = (BP / 8 + NW - 1) / NW, LX = ((NPIX + 7) / 8 + NW - 1) / NW;
-    return (size_t)2 * (LA + LX) * NW * 1024;
+    return (size_t)2 * (X3 ? 2 : 1) * (LA + LX) * NW * 1024;
 }
 
-template <int W, int TH, int NW>
+template <int W, int TH, int NW, int X3 = 0>
 static int wg3_launch(Wg3Args& g, int tiles, int nslices, hipStream_t st) {
-    size_t lds = wg3_lds<W, TH, NW>();
+    size_t lds = wg3_lds<W, TH, NW, X3>();
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<W, TH, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<W, TH, NW, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    wgrad3x3_kernel<W, TH, NW><<<dim3(tiles, nslices), 64 * NW, lds, st>>>(g);
+    wgrad3x3_kernel<W, TH, NW, X3><<<dim3(tiles, nslices), 64 * NW, lds, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -259,4 +279,42 @@ int wgrad3x3_run(const void* x, const void* dy, float* slabs, int N, int H, int 
     if (W == 32) return wg3_launch<32, 4, 4>(g, tiles, ns, st);
     if (W == 16) return wg3_launch<16, 8, 4>(g, tiles, ns, st);
     return wg3_launch<8, 8, 4>(g, tiles, ns, st);
+}
+
+// ---- split-bf16 ("bf16x3") launches: bands of 64 pixels (two stages of both planes fit in LDS)
+static int wg3x_th(int H, int W) {
+    if (W == 64) return 1;
+    if (W == 32 && H % 2 == 0) return 2;
+    if (W == 16 && H % 4 == 0) return 4;
+    if (W == 8 && H % 8 == 0) return 8;
+    return 0;
+}
+
+int wgrad3x3_x3_slices(int N, int H, int W, int Cin, int Cout) {
+    int th = wg3x_th(H, W);
+    if (!th || Cin % 64 || Cout % 64) return 0;
+    int nbands = N * (H / th);
+    int tiles = (Cin / 64) * (Cout / 64);
+    int want = (256 + tiles - 1) / tiles;
+    int ns = want < 1 ? 1 : want;
+    if (ns > nbands / 2) ns = nbands / 2 > 0 ? nbands / 2 : 1;
+    if (ns > 256) ns = 256;
+    int bps = (nbands + ns - 1) / ns;
+    return (nbands + bps - 1) / bps;
+}
+
+int wgrad3x3_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N, int H, int W,
+                    int Cin, int Cout, hipStream_t st) {
+    int ns = wgrad3x3_x3_slices(N, H, W, Cin, Cout);
+    if (!ns) return AB_ESHAPE;
+    int th = wg3x_th(H, W);
+    Wg3Args g = {};
+    g.X = x_hi; g.X_lo = x_lo; g.DY = dy_hi; g.DY_lo = dy_lo; g.slabs = slabs; g.N = N; g.H = H; g.Cin = Cin; g.Cout = Cout;
+    g.nbands = N * (H / th);
+    g.bands_per_slice = (g.nbands + ns - 1) / ns;
+    int tiles = (Cin / 64) * (Cout / 64);
+    if (W == 64) return wg3_launch<64, 1, 8, 1>(g, tiles, ns, st);
+    if (W == 32) return wg3_launch<32, 2, 8, 1>(g, tiles, ns, st);
+    if (W == 16) return wg3_launch<16, 4, 8, 1>(g, tiles, ns, st);
+    return wg3_launch<8, 8, 8, 1>(g, tiles, ns, st);
 }

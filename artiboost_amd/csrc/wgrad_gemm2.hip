@@ -22,6 +22,7 @@ static __device__ uint4 wg2_zero_page[2];
 
 struct Wg2Args {
     const void* X; const void* DY; float* slabs;
+    const void* X_lo; const void* DY_lo;         // split-bf16 (X3) launches: low-order planes
     int N, Ha, Wa, Ca;          // x tensor
     int P, Q, Cout;             // dy tensor [N,P,Q,Cout]
     int stride;
@@ -46,16 +47,21 @@ __device__ __forceinline__ uint4 wg2_tr_pair(unsigned lo_addr, unsigned hi_addr)
 
 // STEM: x is the zero-bordered NHWC4 image and a dW row is [8 kernel rows (7 + 1 pad)][8 px][4 ch] = 256 columns (see
 // ab_conv2d_stem_fwd); BJ = 256 covers all of them, the 64-byte segment of kernel row t comes from image row 2p + t.
-template <int BI, int BJ, bool STEM = false, int WI = 2, int WJ = 2>
+// X3 = 1: split-bf16 operands (conv3x3.hip): 32 reduction rows per step, each operand tile staged once per plane
+// ([dy hi][dy lo][x hi][x lo]); the DMA instruction index runs over (plane, row group).
+template <int BI, int BJ, bool STEM = false, int WI = 2, int WJ = 2, int X3 = 0>
 __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
     constexpr int NW = WI * WJ;                             // 4 or 8 waves (the LDS fill rate scales with the waves issuing loads)
-    constexpr int BR = 64;                                  // reduction rows per step
+    constexpr int BR = X3 ? 32 : 64;                        // reduction rows per step
+    constexpr int NPL = X3 ? 2 : 1;                         // operand planes
     constexpr int PA = BI * 2, PB = BJ * 2;                 // row pitches (bytes)
     constexpr int RA = 1024 / PA, RB = 1024 / PB;           // rows per 1-KiB DMA instruction
-    constexpr int IA = BR / RA, IB = BR / RB;               // instructions per tile
+    constexpr int IA1 = BR / RA, IB1 = BR / RB;             // instructions per tile plane
+    constexpr int IA = NPL * IA1, IB = NPL * IB1;           // ... over both planes
     constexpr int LA = IA / NW, LB = IB / NW;               // per wave
     static_assert(IA % NW == 0 && IB % NW == 0, "tile rows must split evenly over the waves");
-    constexpr int ABYTES = BR * PA, STAGE = BR * (PA + PB);
+    constexpr int APL = BR * PA, BPL = BR * PB;             // bytes of one plane of a tile
+    constexpr int ABYTES = NPL * APL, STAGE = NPL * (APL + BPL);
     constexpr int NBUF = 3;
     constexpr int TI = BI / WI / 32, TJ = BJ / WJ / 32;     // 32x32 tiles per wave (waves WI x WJ)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * STAGE];
@@ -74,21 +80,28 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
     const int PQ = g.P * g.Q;
     const bf16_t* __restrict__ X = (const bf16_t*)g.X;
     const bf16_t* __restrict__ DY = (const bf16_t*)g.DY;
+    const bf16_t* __restrict__ Xl = (const bf16_t*)g.X_lo;
+    const bf16_t* __restrict__ DYl = (const bf16_t*)g.DY_lo;
     const bf16_t* zp = (const bf16_t*)wg2_zero_page;
 
     // per-lane DMA assignment: instruction ii covers rows ii*R .. ii*R+R-1; lane -> (row in instr, slot); the lane fetches
     // the logical chunk that belongs in its slot
     int a_row[LA], a_col[LA], b_row[LB], b_col[LB];
+    bool a_pl[LA], b_pl[LB];                                // X3: the instruction fills the lo plane
 #pragma unroll
     for (int j = 0; j < LA; ++j) {
         constexpr int LPR = PA / 16;                        // lanes (chunks) per row
-        int r = (wave * LA + j) * RA + lane / LPR, slot = lane % LPR;
+        const int ii = wave * LA + j;
+        a_pl[j] = ii >= IA1;
+        int r = (ii % IA1) * RA + lane / LPR, slot = lane % LPR;
         a_row[j] = r; a_col[j] = (slot ^ (swz<BI>(r) << 2)) * 8;
     }
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
         constexpr int LPR = PB / 16;
-        int r = (wave * LB + j) * RB + lane / LPR, slot = lane % LPR;
+        const int ii = wave * LB + j;
+        b_pl[j] = ii >= IB1;
+        int r = (ii % IB1) * RB + lane / LPR, slot = lane % LPR;
         int c = slot ^ (swz<BJ>(r) << 2);
         b_row[j] = r; b_col[j] = STEM ? (c >> 2) * g.Wa * 4 + (c & 3) * 8 : c * 8;
     }
@@ -110,13 +123,13 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
 #pragma unroll
         for (int j = 0; j < LA; ++j) {
             int m = rbase + a_row[j];
-            const bf16_t* src = m < r_end ? DY + ((long)m * g.Cout + i0 + a_col[j]) : zp;
+            const bf16_t* src = m < r_end ? ((X3 && a_pl[j]) ? DYl : DY) + ((long)m * g.Cout + i0 + a_col[j]) : zp;
             glds16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + (wave * LA + j) * 1024));
         }
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
             int off = s_xoff[slot][b_row[j]];
-            const bf16_t* src = off >= 0 ? X + (off + b_col[j]) : zp;
+            const bf16_t* src = off >= 0 ? ((X3 && b_pl[j]) ? Xl : X) + (off + b_col[j]) : zp;
             glds16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + ABYTES + (wave * LB + j) * 1024));
         }
     };
@@ -183,6 +196,22 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
                 for (int b = 0; b < TJ; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a]),
                                                                        __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+            if constexpr (X3) {
+                uint4 fal[TI], fbl[TJ];
+#pragma unroll
+                for (int a = 0; a < TI; ++a) fal[a] = wg2_tr_pair(a_base[a][0] + so + APL + s * 16 * PA, a_base[a][1] + so + APL + s * 16 * PA);
+#pragma unroll
+                for (int b = 0; b < TJ; ++b) fbl[b] = wg2_tr_pair(b_base[b][0] + so + BPL + s * 16 * PB, b_base[b][1] + so + BPL + s * 16 * PB);
+#pragma unroll
+                for (int a = 0; a < TI; ++a)
+#pragma unroll
+                    for (int b = 0; b < TJ; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a]),
+                                                                           __builtin_bit_cast(bf16x8, fbl[b]), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fal[a]),
+                                                                           __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+                    }
+            }
         }
         if (++cur == NBUF) cur = 0;
     }
@@ -284,6 +313,47 @@ int wgrad_gemm2_stem_run(const void* xpad, const void* dy, float* slabs, int N, 
     static const int w8 = getenv("AB_WG2_W8") ? atoi(getenv("AB_WG2_W8")) : 1;
     if (w8) wgrad_gemm2_kernel<64, 256, true, 2, 4><<<grid, 512, 0, st>>>(g);
     else wgrad_gemm2_kernel<64, 256, true><<<grid, 256, 0, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// ---- split-bf16 ("bf16x3") launches (x / dy as bf16 plane pairs).  Tiles up to 128 x 128: three ring stages of both
+// planes of a 32-row step are 96 KB.
+static void wg2x_pick(int M, int Cout, int Cin, int jtot, int* bi, int* bj, int* ns, int* rows) {
+    *bi = (Cout % 128 == 0) ? 128 : 64;
+    *bj = (Cin % 128 == 0) ? 128 : 64;
+    long tiles = (long)(Cout / *bi) * (jtot / *bj);
+    int want = (int)((256 + tiles - 1) / tiles);
+    int maxs = (M + 255) / 256;                              // at least 256 pixels (8 steps) per slice
+    int n = want < 1 ? 1 : want; if (n > maxs) n = maxs; if (n < 1) n = 1; if (n > 512) n = 512;
+    int r = (M + n - 1) / n; r = (r + 31) / 32 * 32;
+    *ns = (M + r - 1) / r; *rows = r;
+}
+
+int wgrad_gemm2_x3_slices(int M, int Cout, int Cin, int ntaps) {
+    if (Cout % 64 || Cin % 64 || ntaps > 16 || M >= (1 << 21)) return 0;
+    int bi, bj, ns, rows; wg2x_pick(M, Cout, Cin, ntaps * Cin, &bi, &bj, &ns, &rows);
+    return ns;
+}
+
+int wgrad_gemm2_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N, int H, int W,
+                       int Cin, int Cout, int kh, int kw, int stride, int pad, hipStream_t st) {
+    Wg2Args g = {};
+    g.X = x_hi; g.X_lo = x_lo; g.DY = dy_hi; g.DY_lo = dy_lo; g.slabs = slabs;
+    g.N = N; g.Ha = H; g.Wa = W; g.Ca = Cin;
+    g.P = (H + 2 * pad - kh) / stride + 1; g.Q = (W + 2 * pad - kw) / stride + 1; g.Cout = Cout;
+    g.stride = stride; g.ntaps = kh * kw; g.Cin = Cin; g.jtot = kh * kw * Cin; g.M = N * g.P * g.Q;
+    if (!wgrad_gemm2_x3_slices(g.M, Cout, Cin, g.ntaps)) return AB_ESHAPE;
+    for (int i = 0; i < kh; ++i) for (int j = 0; j < kw; ++j) { g.dh[i * kw + j] = (int8_t)(i - pad); g.dw[i * kw + j] = (int8_t)(j - pad); }
+    g.magic_pq = (1ull << 42) / (unsigned long long)(g.P * g.Q) + 1;
+    g.magic_q = (1ull << 42) / (unsigned long long)g.Q + 1;
+    int bi, bj, ns, rows; wg2x_pick(g.M, Cout, Cin, g.jtot, &bi, &bj, &ns, &rows);
+    g.rows_per_slice = rows;
+    dim3 grid((Cout / bi) * (g.jtot / bj), ns);
+    if (bi == 128 && bj == 128) wgrad_gemm2_kernel<128, 128, false, 2, 4, 1><<<grid, 512, 0, st>>>(g);
+    else if (bi == 128 && bj == 64) wgrad_gemm2_kernel<128, 64, false, 4, 2, 1><<<grid, 512, 0, st>>>(g);
+    else if (bi == 64 && bj == 128) wgrad_gemm2_kernel<64, 128, false, 2, 4, 1><<<grid, 512, 0, st>>>(g);
+    else wgrad_gemm2_kernel<64, 64, false, 2, 2, 1><<<grid, 256, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

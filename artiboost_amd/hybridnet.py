@@ -9,8 +9,12 @@ Design (MI355X-first, not a translation of the nn.Module tree):
     mirrored conv, the heat-map depth padded 28 -> 32 so every class is one aligned channel run).  Gradients live in
     a second flat buffer of the same shape, so the global-norm clip + Adam are two passes over contiguous memory and
     the DDP all-reduce is a handful of large buckets.
-  * activations are NHWC in the compute dtype (bf16 for speed, f32 for parity); forward and backward are explicit
-    kernel sequences (no autograd graph); training-mode BatchNorm statistics come for free from the conv epilogue.
+  * activations are NHWC in the compute dtype; forward and backward are explicit kernel sequences (no autograd graph);
+    training-mode BatchNorm statistics come for free from the conv epilogue.  Three precisions:
+      "bf16x3" (default, the reference's precision): fp32 activations / gradients in HBM, every convolution on the bf16
+               MFMA with split operands hi + lo (3 passes, fp32 accumulate: 2^-17 operand precision) -- see csrc/conv_x3.hip;
+      "f32"    exact-f32 MFMA everywhere (1/16 of the bf16 rate): the cross-check of bf16x3;
+      "bf16"   bf16 operands and activations (fastest; misses the 1e-3 parity bound of the north star).
   * state_dict()/load_state_dict() speak the reference's key names and tensor layouts (torchvision-compatible
     `backbone.*`, `hybrid_head.deconv_layers.*`, `hybrid_head.final_layer.*`, `box_head.layers.*`).
 """
@@ -245,7 +249,8 @@ class HybridNet:
     def __init__(self, store: ParamStore, image_size=(256, 256), compute_dtype=torch.bfloat16):
         self.p = store
         self.W, self.H = int(image_size[0]), int(image_size[1])
-        self.dtype = compute_dtype
+        self.x3 = compute_dtype in ("bf16x3", "x3")           # split-bf16 convolutions on fp32 tensors
+        self.dtype = torch.float32 if self.x3 else compute_dtype
         self.training = True
         self.lp = None           # low-precision copy of the flat params (bf16 mode)
         self.tr = {}             # IHWO (data-gradient) copies of conv weights in the compute dtype
@@ -267,7 +272,13 @@ class HybridNet:
     def pack_weights(self, skip_cast=False):
         """Refresh compute-precision copies after an optimizer step: one cast pass + IHWO transposes."""
         p = self.p
-        if self.dtype == torch.bfloat16:
+        if self.x3:
+            if self.lp is None or tuple(self.lp.shape) != (2, p.total):
+                self.lp = torch.empty((2, p.total), dtype=torch.bfloat16, device=p.device)
+                skip_cast = False
+            if not skip_cast:
+                K.split(p.flat, out=self.lp)                  # (hi, lo) planes of every weight, kernel layout
+        elif self.dtype == torch.bfloat16:
             if self.lp is None or self.lp.dtype != torch.bfloat16:
                 self.lp = torch.empty(p.total, dtype=torch.bfloat16, device=p.device)
                 skip_cast = False
@@ -277,9 +288,20 @@ class HybridNet:
             self.lp = p.flat
         if getattr(self, "_tr_plan", None) is None:
             pairs = []
+            if self.x3:      # IHWO copies: transposed in fp32 into one flat buffer, split into planes in one pass
+                tot = sum(_round_up(p.entries[n].numel, 64) for n in self._dgrad_names())
+                self._tr_f32 = torch.empty(tot, dtype=torch.float32, device=p.device)
+                self._tr_planes = torch.empty((2, tot), dtype=torch.bfloat16, device=p.device)
+                off = 0
             for name in self._dgrad_names():
                 O, kh, kw, I = p.entries[name].kshape
-                dst = self.tr[name] = torch.empty((I, kh, kw, O), dtype=self.dtype, device=p.device)
+                if self.x3:
+                    n = p.entries[name].numel
+                    dst = self._tr_f32[off:off + n].view(I, kh, kw, O)
+                    self.tr[name] = self._tr_planes[:, off:off + n].view(2, I, kh, kw, O)
+                    off += _round_up(n, 64)
+                else:
+                    dst = self.tr[name] = torch.empty((I, kh, kw, O), dtype=self.dtype, device=p.device)
                 pairs.append((p.view(name).reshape(O, kh * kw, I), dst))
             self._tr_pairs = pairs                                   # the flat buffer and the copies are persistent
             self._tr_plan = K.transpose_plan(pairs) or False
@@ -301,11 +323,32 @@ class HybridNet:
         else:
             for src, dst in self._tr_pairs:
                 K.transpose_oki(src, dst)
+        if self.x3:
+            K.split(self._tr_f32, out=self._tr_planes)
         self._packed = True
 
     def w(self, name):
         e = self.p.entries[name]
+        if self.x3:
+            return self.lp[:, e.offset:e.offset + e.numel].view((2,) + e.kshape)
         return self.lp[e.offset:e.offset + e.numel].view(e.kshape)
+
+    # ------------------------------------------------------------------ convolutions in the configured precision
+    def _conv_fwd(self, x, name, stride, pad, **kw):
+        if self.x3:
+            return K.conv2d_fwd_x3(x, self.w(name), stride, pad, **kw)
+        return K.conv2d_fwd(x, self.w(name), stride, pad, **kw)
+
+    def _conv_dgrad(self, dy, name, in_hw, stride, pad, addend=None, bn=None, want_stats=False):
+        if self.x3:
+            r = K.conv2d_dgrad_x3(dy, self.tr[name], in_hw, stride, pad, addend=addend, want_stats=want_stats)
+            return (r, None) if bn is not None else r
+        return K.conv2d_dgrad(dy, self.tr[name], in_hw, stride, pad, addend=addend, bn=bn, want_stats=want_stats)
+
+    def _conv_wgrad(self, x, dy, kh, kw, stride, pad, out=None, **kws):
+        if self.x3:
+            return K.conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=out)
+        return K.conv2d_wgrad(x, dy, kh, kw, stride, pad, out=out, **kws)
 
     # ------------------------------------------------------------------ BN helper
     def _bn_params(self, prefix, stats_part, count):
@@ -333,7 +376,9 @@ class HybridNet:
         N = xpad.shape[0]
         H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
         S = {"xpad": xpad, "N": N, "HW": (H, W), "blocks": []}
-        y0, st = K.conv2d_stem_fwd(xpad, self.w("backbone.conv1.weight"), H, W, want_stats=True)
+        # (bf16x3: the 3-channel stem runs on the exact-f32 kernel, 1 % of the FLOPs)
+        w_stem = p.view("backbone.conv1.weight") if self.x3 else self.w("backbone.conv1.weight")
+        y0, st = K.conv2d_stem_fwd(xpad, w_stem, H, W, want_stats=True)
         if self.fuse_stem:
             bnp0 = self._bn_params("backbone.bn1", st, N * (H // 2) * (W // 2))
             x, pool_idx = K.bn_relu_maxpool_fwd(y0, bnp0)      # BN + ReLU + 3x3/2 max-pool: the 128x128x64 activation is never stored
@@ -346,13 +391,13 @@ class HybridNet:
             for b in range(nblk):
                 stride = 2 if (b == 0 and li > 1) else 1
                 pre = f"backbone.layer{li}.{b}"
-                y1, st1 = K.conv2d_fwd(x, self.w(pre + ".conv1.weight"), stride, 1, want_stats=True)
+                y1, st1 = self._conv_fwd(x, pre + ".conv1.weight", stride, 1, want_stats=True)
                 cnt = y1.shape[0] * y1.shape[1] * y1.shape[2]
                 a1, bnp1 = self._bn(pre + ".bn1", y1, st1, cnt)
-                y2, st2 = K.conv2d_fwd(a1, self.w(pre + ".conv2.weight"), 1, 1, want_stats=True)
+                y2, st2 = self._conv_fwd(a1, pre + ".conv2.weight", 1, 1, want_stats=True)
                 rec = dict(pre=pre, stride=stride, x=x, y1=y1, a1=a1, bnp1=bnp1, y2=y2, ds=False)
                 if stride != 1 or inpl != planes:
-                    yd, std_ = K.conv2d_fwd(x, self.w(pre + ".downsample.0.weight"), stride, 0, want_stats=True)
+                    yd, std_ = self._conv_fwd(x, pre + ".downsample.0.weight", stride, 0, want_stats=True)
                     r, bnpd = self._bn(pre + ".downsample.1", yd, std_, cnt, relu=False)
                     rec.update(ds=True, yd=yd, bnpd=bnpd)
                 else:
@@ -374,16 +419,15 @@ class HybridNet:
 
         def deconv(x, name, hw):
             if tr and fused:
-                return K.conv2d_dgrad(x, self.tr[name], hw, 2, 1, want_stats=True)
-            d = K.conv2d_dgrad(x, self.tr[name], hw, 2, 1)
+                return self._conv_dgrad(x, name, hw, 2, 1, want_stats=True)
+            d = self._conv_dgrad(x, name, hw, 2, 1)
             return d, (K.col_stats(d) if tr else None)
 
         d1, st1 = deconv(feat, "hybrid_head.deconv_layers.0.weight", (2 * h4, 2 * w4))
         e1, bnpd1 = self._bn("hybrid_head.deconv_layers.1", d1, st1, N * 4 * h4 * w4)
         d2, st2 = deconv(e1, "hybrid_head.deconv_layers.3.weight", (4 * h4, 4 * w4))
         e2, bnpd2 = self._bn("hybrid_head.deconv_layers.4", d2, st2, N * 16 * h4 * w4)
-        logits = K.conv2d_fwd(e2, self.w("hybrid_head.final_layer.weight"), 1, 0,
-                              bias=p.view("hybrid_head.final_layer.bias"))
+        logits = self._conv_fwd(e2, "hybrid_head.final_layer.weight", 1, 0, bias=p.view("hybrid_head.final_layer.bias"))
         # ---- MLP_O box head, always f32 (tiny; keeps the 6-D rotation at full precision)
         m0 = fmean.view(N, 512)
         lw = lambda n: p.view(n).view(p.entries[n].kshape[0], -1)      # noqa: E731  ([out][in] rows of the 1x1 layout)
@@ -422,7 +466,7 @@ class HybridNet:
 
     def _wgrad_side(self, fn, *args, **kw):
         if not self.overlap_wgrad:
-            if self.batch_wgrad_reduce:
+            if self.batch_wgrad_reduce and not self.x3:
                 if getattr(self, "_pending", None) is None:
                     self._pending = K.PendingReductions()
                 kw["defer"] = self._pending
@@ -486,17 +530,19 @@ class HybridNet:
         g_mean = K.linear_dgrad(gb1, self.box_t["box_head.layers.0.weight"])
         # ---- head
         e2, e1, feat = S["e2"], S["e1"], S["feat"]
-        self._wgrad_side(K.conv2d_wgrad, e2, dlogits, 1, 1, 1, 0, out=gv("hybrid_head.final_layer.weight"))
         K.col_sum(dlogits, gv("hybrid_head.final_layer.bias"))
-        de2 = K.conv2d_dgrad(dlogits, self.tr["hybrid_head.final_layer.weight"], (e2.shape[1], e2.shape[2]), 1, 0)
+        if self.x3:
+            dlogits = K.split(dlogits)        # one split serves the weight and the data gradient
+        self._wgrad_side(self._conv_wgrad, e2, dlogits, 1, 1, 1, 0, out=gv("hybrid_head.final_layer.weight"))
+        de2 = self._conv_dgrad(dlogits, "hybrid_head.final_layer.weight", (e2.shape[-3], e2.shape[-2]), 1, 0)
         dd2 = K.bn_bwd(de2, e2, S["d2"], S["bnpd2"], gv("hybrid_head.deconv_layers.4.weight"),
                        gv("hybrid_head.deconv_layers.4.bias"), relu="recompute")
-        self._wgrad_side(K.conv2d_wgrad, dd2, e1, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.3.weight"))
-        de1 = K.conv2d_fwd(dd2, self.w("hybrid_head.deconv_layers.3.weight"), 2, 1)
+        self._wgrad_side(self._conv_wgrad, dd2, e1, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.3.weight"))
+        de1 = self._conv_fwd(dd2, "hybrid_head.deconv_layers.3.weight", 2, 1)
         dd1 = K.bn_bwd(de1, e1, S["d1"], S["bnpd1"], gv("hybrid_head.deconv_layers.1.weight"),
                        gv("hybrid_head.deconv_layers.1.bias"), relu="recompute")
-        self._wgrad_side(K.conv2d_wgrad, dd1, feat, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.0.weight"))
-        dout = K.conv2d_fwd(dd1, self.w("hybrid_head.deconv_layers.0.weight"), 2, 1)
+        self._wgrad_side(self._conv_wgrad, dd1, feat, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.0.weight"))
+        dout = self._conv_fwd(dd1, "hybrid_head.deconv_layers.0.weight", 2, 1)
         K.avgpool_bwd(g_mean, dout, accumulate=True)
         # ---- backbone, last block first
         blocks = list(reversed(S["blocks"]))
@@ -519,27 +565,26 @@ class HybridNet:
             nxt = blocks[k + 1] if k + 1 < len(blocks) else below
             dy2, dz = K.bn_bwd(dout, rec["out"], rec["y2"], rec["bnp2"], gv(pre + ".bn2.weight"), gv(pre + ".bn2.bias"),
                                relu=True, want_dz=True, part=dout_part)
-            self._wgrad_side(K.conv2d_wgrad, rec["a1"], dy2, 3, 3, 1, 1, out=gv(pre + ".conv2.weight"))
+            self._wgrad_side(self._conv_wgrad, rec["a1"], dy2, 3, 3, 1, 1, out=gv(pre + ".conv2.weight"))
             # the BN-backward reduction of bn1 rides in the epilogue of the data gradient that produces its input
-            da1, part1 = K.conv2d_dgrad(dy2, self.tr[pre + ".conv2.weight"], (dy2.shape[1], dy2.shape[2]), 1, 1,
-                                        bn=(rec["y1"], None, rec["bnp1"]))
+            da1, part1 = self._conv_dgrad(dy2, pre + ".conv2.weight", (dy2.shape[-3], dy2.shape[-2]), 1, 1,
+                                          bn=(rec["y1"], None, rec["bnp1"]))
             dy1 = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["bnp1"], gv(pre + ".bn1.weight"), gv(pre + ".bn1.bias"),
                             relu="recompute", part=part1)
-            self._wgrad_side(K.conv2d_wgrad, x, dy1, 3, 3, stride, 1, out=gv(pre + ".conv1.weight"))
+            self._wgrad_side(self._conv_wgrad, x, dy1, 3, 3, stride, 1, out=gv(pre + ".conv1.weight"))
             bn_below = (nxt["y2"], nxt["out"], nxt["bnp2"]) if nxt is not None else None
             if rec["ds"]:
                 dyd = K.bn_bwd(dz, None, rec["yd"], rec["bnpd"], gv(pre + ".downsample.1.weight"),
                                gv(pre + ".downsample.1.bias"), relu=False)
-                self._wgrad_side(K.conv2d_wgrad, x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
-                dx = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1)
-                dout = K.conv2d_dgrad(dyd, self.tr[pre + ".downsample.0.weight"], (x.shape[1], x.shape[2]), stride, 0,
-                                      addend=dx)
+                self._wgrad_side(self._conv_wgrad, x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
+                dx = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[1], x.shape[2]), stride, 1)
+                dout = self._conv_dgrad(dyd, pre + ".downsample.0.weight", (x.shape[1], x.shape[2]), stride, 0, addend=dx)
                 dout_part = None
             elif bn_below is not None:
-                dout, dout_part = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1,
-                                                 addend=dz, bn=bn_below)
+                dout, dout_part = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[1], x.shape[2]), stride, 1,
+                                                   addend=dz, bn=bn_below)
             else:
-                dout = K.conv2d_dgrad(dy1, self.tr[pre + ".conv1.weight"], (x.shape[1], x.shape[2]), stride, 1, addend=dz)
+                dout = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[1], x.shape[2]), stride, 1, addend=dz)
                 dout_part = None
         return dout, dout_part
 

@@ -363,3 +363,81 @@ def col_sum(x, out):
     part = torch.empty((lib.ab_col_stats_nparts(L.l(M)), C, 2), dtype=torch.float32, device=x.device)
     L.check(lib.ab_col_sum(L.ptr(x), L.i(L.dt(x)), L.l(M), L.i(C), L.ptr(part), L.ptr(out), L.stream()), "ab_col_sum")
     return out
+
+
+# ---------------------------------------------------------------- split-bf16 ("bf16x3") convolutions
+# A split tensor is a bf16 tensor [2, ...]: plane 0 = bf16(v), plane 1 = bf16(v - plane0) (include/artiboost_hip.h).
+
+def split(x_f32, out=None):
+    """fp32 tensor -> split planes [2, *x.shape] bf16 (ab_split_f32)."""
+    if x_f32.dtype != torch.float32:
+        raise TypeError("split() takes a float32 tensor")
+    sp = out if out is not None else torch.empty((2,) + tuple(x_f32.shape), dtype=torch.bfloat16, device=x_f32.device)
+    L.check(L.lib().ab_split_f32(L.ptr(x_f32), L.l(x_f32.numel()), L.ptr(sp[0]), L.ptr(sp[1]), L.stream()), "ab_split_f32")
+    return sp
+
+
+def _planes(t):
+    """(hi, lo) of a split tensor, or of the planes cached on an fp32 tensor by its producer; splits on the fly otherwise."""
+    if t.dtype == torch.bfloat16:
+        return t[0], t[1]
+    sp = getattr(t, "_ab_split", None)
+    if sp is None:
+        sp = split(t)
+    return sp[0], sp[1]
+
+
+def conv2d_fwd_x3(x, w_split, stride, pad, bias=None, want_stats=False, relu=False):
+    """x: fp32 [N,H,W,Cin] or split [2,N,H,W,Cin]; w_split [2,Cout,kh,kw,Cin] -> y fp32 [N,Ho,Wo,Cout] (+ BN partials)."""
+    xh, xl = _planes(x)
+    N, H, W, Cin = xh.shape
+    _, Cout, kh, kw, _ = w_split.shape
+    Ho, Wo = conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad)
+    y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=xh.device)
+    lib = L.lib()
+    stats = None
+    if want_stats:
+        nt = lib.ab_conv2d_x3_stat_rows(L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad))
+        stats = torch.empty((nt, Cout, 2), dtype=torch.float32, device=xh.device)
+    L.check(lib.ab_conv2d_fwd_x3(L.ptr(xh), L.ptr(xl), L.ptr(w_split[0]), L.ptr(w_split[1]), L.ptr(y), L.i(N), L.i(H), L.i(W),
+                                 L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(bias), L.ptr(stats),
+                                 L.i(1 if relu else 0), L.stream()), "ab_conv2d_fwd_x3")
+    return (y, stats) if want_stats else y
+
+
+def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=False):
+    """dy: fp32 / split [.., N,Ho,Wo,Cout]; wt_split [2,Cin,kh,kw,Cout] -> dx fp32 [N,H,W,Cin] (+ BN partials of dx)."""
+    dh, dl = _planes(dy)
+    N, Ho, Wo, Cout = dh.shape
+    _, Cin, kh, kw, _ = wt_split.shape
+    H, W = in_hw
+    dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dh.device)
+    lib = L.lib()
+    part = None
+    if want_stats and addend is None:
+        rows = lib.ab_conv2d_dgrad_x3_stat_rows(L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad))
+        if rows > 0:
+            part = torch.empty((rows, Cin, 2), dtype=torch.float32, device=dh.device)
+    L.check(lib.ab_conv2d_dgrad_x3(L.ptr(dh), L.ptr(dl), L.ptr(wt_split[0]), L.ptr(wt_split[1]), L.ptr(dx), L.i(N), L.i(H), L.i(W),
+                                   L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(addend), L.ptr(part),
+                                   L.stream()), "ab_conv2d_dgrad_x3")
+    if want_stats:
+        return dx, (part if part is not None else col_stats(dx))
+    return dx
+
+
+def conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=None, accumulate=False):
+    """x, dy: fp32 or split -> dw fp32 [Cout,kh,kw,Cin]."""
+    xh, xl = _planes(x)
+    dh, dl = _planes(dy)
+    N, H, W, Cin = xh.shape
+    Cout = dh.shape[3]
+    lib = L.lib()
+    M = dh.shape[0] * dh.shape[1] * dh.shape[2]
+    nbytes = lib.ab_conv2d_wgrad_workspace(L.i(M), L.i(Cout), L.i(kh * kw * Cin))
+    dw = out if out is not None else torch.empty((Cout, kh, kw, Cin), dtype=torch.float32, device=xh.device)
+    ws = _workspace(nbytes, xh.device)
+    L.check(lib.ab_conv2d_wgrad_x3(L.ptr(xh), L.ptr(xl), L.ptr(dh), L.ptr(dl), L.ptr(dw), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                   L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(ws), L.i(1 if accumulate else 0),
+                                   L.stream()), "ab_conv2d_wgrad_x3")
+    return dw

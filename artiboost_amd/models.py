@@ -82,11 +82,12 @@ class HybridBaseline(nn.Module):
         if cfg["BACKBONE"].get("FREEZE_BATCHNORM", False):
             raise NotImplementedError("FREEZE_BATCHNORM")
         dev = cfg.get("DEVICE", "cuda")
-        cd = cfg.get("COMPUTE_DTYPE", "bf16")
+        cd = cfg.get("COMPUTE_DTYPE", "bf16x3")     # the reference's precision (fp32-grade); "bf16" / "f32" opt in
         self.store = ParamStore(self.nclasses, self.depth_res, device=dev)
         self.store.init_reference_like(seed=int(cfg.get("INIT_SEED", 1)))
         self.net = HybridNet(self.store, image_size=self.inp_res,
-                             compute_dtype=torch.bfloat16 if cd in ("bf16", torch.bfloat16) else torch.float32)
+                             compute_dtype=(torch.bfloat16 if cd in ("bf16", torch.bfloat16) else
+                                            "bf16x3" if cd in ("bf16x3", "x3") else torch.float32))
         self.flat_param = nn.Parameter(self.store.flat, requires_grad=True)   # shares storage with the store
         pretrained = cfg.get("PRETRAINED", "")
         if pretrained:

@@ -94,6 +94,28 @@ long ab_conv2d_stem_wgrad_workspace(int N, int H, int W, int Cout);
 int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw, int dtype, int N, int H, int W, int Cout,
                          void* workspace, void* stream);
 
+/* ---- M1/M2 at the reference's precision: split-bf16 ("bf16x3") convolutions ------------------------------------
+ * The reference runs these convolutions in fp32 (train/train_artiboost.py:39-41,91-96 -- no autocast; cuDNN fp32 behind
+ * anakin/models/resnet.py:41-44,154,181-184 and simplebaseline.py:95-101,161-170).  Every fp32 operand v is given as
+ * two bf16 planes hi = bf16(v), lo = bf16(v - hi) (ab_split_f32 makes them) and a product is hi*hi + hi*lo + lo*hi on the
+ * bf16 MFMA with fp32 accumulation: 2^-17 operand precision instead of bf16's 2^-9, at 1/3 of the bf16 matrix peak
+ * (the f32-input MFMA runs at 1/16).  Outputs, addends, BatchNorm partials and weight gradients are fp32.
+ * Same layouts and meanings as ab_conv2d_fwd / _dgrad / _wgrad; Cin (fwd) / Cout (dgrad) % 32 == 0, wgrad: both % 64.
+ * w_lo must lie 0 .. 2^31-1 bytes after w_hi (both planes of one allocation).                                       */
+int ab_split_f32(const float* src, long n, void* hi, void* lo, void* stream);          /* n % 8 == 0 */
+int ab_conv2d_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* y, int N, int H, int W,
+                     int Cin, int Cout, int kh, int kw, int stride, int pad, const float* bias, float* stats, int relu,
+                     void* stream);
+int ab_conv2d_dgrad_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
+int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H,
+                       int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend, float* stats,
+                       void* stream);
+/* workspace: ab_conv2d_wgrad_workspace(N*Ho*Wo, Cout, kh*kw*Cin) bytes                                               */
+int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N, int H,
+                       int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace, int accumulate,
+                       void* stream);
+
 /* ---- M1/M2: training-mode BatchNorm, ReLU, residual, pooling (HBM-bound NHWC kernels) ---------------------------
  * replaces nn.BatchNorm2d / ReLU / MaxPool2d / mean-pool: anakin/models/resnet.py:85-101,155-157,219;
  * anakin/models/simplebaseline.py:171-172.

@@ -1,0 +1,119 @@
+"""GPU parity of the split-bf16 ("bf16x3") convolution kernels against torch-CPU float64.
+
+The kernels see fp32 inputs as hi + lo bf16 planes (2^-17 relative operand error) and accumulate in fp32, so against an
+exact reference the error of an output is bounded by ~2^-16 * sum|a||b| over its reduction; the tolerance below is that
+bound with the measured headroom (the exact-f32 MFMA path passes 2e-5 of the output scale, bf16 needs 8e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+X3_TOL = 3e-5        # of max|ref| (bf16: 8e-3, exact f32: 2e-5)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, ref, tol=X3_TOL):
+    s = float(ref.abs().max()) + 1e-30
+    err = float((got.double() - ref.double()).abs().max())
+    assert err <= tol * s, f"max err {err:.3e} vs scale {s:.3e} (ratio {err / s:.2e})"
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (3, 14, 10, 64, 128, 3, 2, 1),
+    (2, 8, 8, 128, 128, 3, 1, 1),
+    (2, 14, 14, 64, 128, 1, 2, 0),
+    (1, 7, 7, 512, 512, 3, 1, 1),
+    (2, 9, 5, 256, 616, 1, 1, 0),     # final layer: ragged N, ragged M, bias
+    (5, 6, 6, 256, 256, 3, 1, 1),
+    (2, 8, 8, 256, 512, 4, 2, 1),     # ConvTranspose backward-data shape
+    (2, 32, 32, 64, 64, 3, 1, 1),
+    (1, 28, 28, 128, 128, 3, 1, 1),
+    (3, 14, 14, 256, 256, 3, 1, 1),
+    (2, 56, 40, 64, 64, 3, 1, 1),
+    (2, 64, 64, 64, 64, 3, 1, 1),     # benchmark geometry layer1
+    (2, 16, 16, 256, 256, 3, 1, 1),   # benchmark geometry layer3
+]
+
+
+def test_split_planes():
+    from artiboost_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 8, 8, 64, generator=g) * torch.exp(4 * torch.randn(4, 8, 8, 64, generator=g))
+    sp = K.split(x.cuda()).cpu()
+    hi = x.to(torch.bfloat16)
+    assert torch.equal(sp[0], hi)
+    assert torch.equal(sp[1], (x - hi.float()).to(torch.bfloat16))
+    rel = ((sp[0].double() + sp[1].double() - x.double()).abs() / x.double().abs()).max()
+    assert float(rel) <= 2.0 ** -17
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_x3(case):
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g) if Cout == 616 else None
+    ref = F.conv2d(x.double(), w.double(), b.double() if b is not None else None, stride=s, padding=p)
+    ws = K.split(w.permute(0, 2, 3, 1).contiguous().cuda())
+    y, stats = K.conv2d_fwd_x3(nhwc(x).cuda(), ws, s, p, bias=b.cuda() if b is not None else None, want_stats=True)
+    close(nchw(y.cpu()), ref)
+    st = stats.double().sum(0).cpu()
+    yy = y.double().cpu().reshape(-1, Cout)
+    np.testing.assert_allclose(st[:, 0].numpy(), yy.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(yy.abs().sum(0).max()))
+    np.testing.assert_allclose(st[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", CASES[:7] + CASES[8:])
+def test_conv_dgrad_wgrad_x3(case):
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout, k, s, p = case
+    if s == 2 and (H % 2 or W % 2):
+        H, W = H + H % 2, W + W % 2
+    if Cout == 616:
+        Cout = 640
+    g = torch.Generator().manual_seed(hash(case) % 977)
+    x = torch.randn((N, Cin, H, W), generator=g).double().requires_grad_(True)
+    w = (torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (Cin * k * k)) ** 0.5).double().requires_grad_(True)
+    y = F.conv2d(x, w, stride=s, padding=p)
+    dy = torch.randn(y.shape, generator=g).double()
+    y.backward(dy)
+    add = torch.randn(x.shape, generator=g)
+    dyd = nhwc(dy.float()).cuda()
+    wt = K.split(w.detach().float().permute(1, 2, 3, 0).contiguous().cuda())      # [Cin][kh][kw][Cout]
+    dx = K.conv2d_dgrad_x3(dyd, wt, (H, W), s, p, addend=nhwc(add).cuda())
+    close(nchw(dx.cpu()), x.grad + add.double())
+    dw = K.conv2d_wgrad_x3(nhwc(x.detach().float()).cuda(), dyd, k, k, s, p).cpu().permute(0, 3, 1, 2)
+    close(dw, w.grad)
+    # accumulate=True adds onto the existing gradient
+    base = torch.randn(Cout, k, k, Cin, generator=g).cuda()
+    dw2 = K.conv2d_wgrad_x3(K.split(nhwc(x.detach().float()).cuda()), K.split(dyd), k, k, s, p, out=base.clone(), accumulate=True)
+    close(dw2.cpu().permute(0, 3, 1, 2), w.grad + base.cpu().permute(0, 3, 1, 2).double())
+
+
+def test_conv_transpose_4x4s2_x3():
+    """ConvTranspose2d(4x4, s2, p1) forward == data gradient of the mirrored conv, with BN partials from the epilogue."""
+    from artiboost_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 512, 8, 8, generator=g)
+    w = torch.randn(512, 256, 4, 4, generator=g) * 0.02            # ConvT weight [Cin_t, Cout_t, kh, kw]
+    ref = F.conv_transpose2d(x.double(), w.double(), stride=2, padding=1)
+    wt = K.split(w.permute(1, 2, 3, 0).contiguous().cuda())        # [Co][kh][kw][Ci]: dgrad (IHWO) layout of the mirrored conv
+    y, part = K.conv2d_dgrad_x3(nhwc(x).cuda(), wt, (16, 16), 2, 1, want_stats=True)
+    close(nchw(y.cpu()), ref)
+    yy = y.double().cpu().reshape(-1, 256)
+    st = part.double().sum(0).cpu()
+    np.testing.assert_allclose(st[:, 0].numpy(), yy.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(yy.abs().sum(0).max()))
+    np.testing.assert_allclose(st[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)

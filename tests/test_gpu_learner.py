@@ -40,26 +40,39 @@ def build(size, heat, dtype, seed):
     return model, crit, params
 
 
+# Prediction tolerances (absolute; metres for joints / corners, heat-map units for 2d_uvd).  "bf16x3" -- split-bf16 MFMA, the
+# benchmarked precision -- is held to the exact-f32 path's tolerances on the losses (3e-4) and gradient norms (1 %), and on
+# the predictions to a bound 7x below the north star's 1e-3.  Measured against the reference goldens on MI355X
+# (tools/parity_report.py): train-mode joints 2.7e-7 m / corners 5e-6 m (f32: 6e-8 / 2.6e-7); eval mode on this deliberately
+# ill-conditioned random-weight net (running statistics 0 / 1) joints 1.45e-4 m, 2d_uvd 3.6e-4 (f32: 2.2e-5 m, 5.6e-5;
+# bf16: 9.5e-2 m, 2.4e-1).
+PRED_TOL = {"f32": dict(eval=3e-5, train=3e-5, metres=3e-5), "bf16x3": dict(eval=5e-4, train=1e-4, metres=2e-4)}
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "f32"])
 @pytest.mark.parametrize("tag", ["g224", "g256"])
-def test_f32_path_matches_reference_golden(golden_dir, tag):
+def test_f32_path_matches_reference_golden(golden_dir, tag, dtype):
     g = np.load(os.path.join(golden_dir, f"learner_{tag}.npz"))
     size, heat, depth, B, seed = [int(x) for x in g["meta"]]
-    model, crit, params = build(size, heat, "f32", seed)
+    model, crit, params = build(size, heat, dtype, seed)
     hb = model.model_list[0]
     batch = make_batch(B, size, seed + 100)
     # ---- eval
     model.eval()
     with torch.no_grad():
         preds = model(batch)["HybridBaseline"]
+    T = PRED_TOL[dtype]
     for k in ("joints_3d_abs", "corners_3d_abs", "joints_3d", "corners_3d", "2d_uvd", "boxroot_3d_abs", "box_rot_rotmat"):
-        np.testing.assert_allclose(preds[k].cpu().numpy(), g[f"eval.pred.{k}"], rtol=1e-4, atol=3e-5, err_msg=k)
+        atol = T["metres"] if k.startswith(("joints", "corners", "boxroot")) else T["eval"]
+        np.testing.assert_allclose(preds[k].cpu().numpy(), g[f"eval.pred.{k}"], rtol=1e-4, atol=atol, err_msg=k)
     lg = hb.net.last["logits"].float().cpu().reshape(B, heat, heat, 22, 32)[..., :28].permute(0, 3, 4, 1, 2).reshape(B, 616, heat, heat)
     np.testing.assert_allclose(lg[:, ::37, ::5, ::5].numpy(), g["eval.logits.sample"], rtol=2e-3, atol=2e-4)
     # ---- train: forward, losses with the reference's RNG seeding, backward
     model.train()
     preds = model(batch)["HybridBaseline"]
     for k in ("joints_3d_abs", "corners_3d_abs", "2d_uvd", "box_rot_rotmat"):
-        np.testing.assert_allclose(preds[k].detach().cpu().numpy(), g[f"train.pred.{k}"], rtol=1e-4, atol=3e-5, err_msg=k)
+        atol = min(T["metres"], T["train"]) if k.startswith(("joints", "corners")) else T["train"]
+        np.testing.assert_allclose(preds[k].detach().cpu().numpy(), g[f"train.pred.{k}"], rtol=1e-4, atol=atol, err_msg=k)
     random.seed(seed + 7)
     torch.manual_seed(seed + 7)
     total, losses = crit.compute_losses(preds, batch)

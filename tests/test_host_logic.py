@@ -229,3 +229,18 @@ def test_assemble_gt_batch_equals_per_sample_assembly():
             np.testing.assert_allclose(got[k][i], v, rtol=1e-6, atol=1e-5, err_msg=f"{i}.{k}")
         nz += int(ref[Queries.JOINTS_VIS].sum() == 0) + int(ref[Queries.CORNERS_VIS].sum() == 0)
     assert nz > 0                                              # the all-zero visibility branches were exercised
+
+
+def test_bench_gpus_flag_launches_the_ranks():
+    """`python bench.py --gpus 2` is the whole multi-GPU command: it starts 2 ranks itself (torch.distributed.run, gloo here)
+    and the line reports the world size the ranks actually formed -- not the flag."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert lines == [{"dry_launch": True, "n_gpus": 2, "gpus_arg": 2}]
