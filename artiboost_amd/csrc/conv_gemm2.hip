@@ -35,8 +35,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
     // LDS ring of NBUF stages: loads run NBUF-1 K-steps ahead of the MFMAs.  The fill is latency-bound (bytes in flight
     // per CU / L2 latency), so grids that put a single workgroup on a CU use a deeper ring (5) than those that co-run 2-3.
     constexpr int PD = NBUF - 1;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUFSZ + BM * 4 + WM * BN * 8 + 3 * CG_MAXTAPS * 4];
-    int* s_outpix = (int*)(smem + NBUF * BUFSZ);
+    // (X3: the fp32 epilogue staging tile may exceed a two-stage ring)
+    constexpr int STAGE_X3 = X3 ? BM * (BN * 4 + 16) : 0;
+    constexpr int RINGSZ = NBUF * BUFSZ > STAGE_X3 ? NBUF * BUFSZ : STAGE_X3;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RINGSZ + BM * 4 + WM * BN * 8 + 3 * CG_MAXTAPS * 4];
+    int* s_outpix = (int*)(smem + RINGSZ);
     float* s_stat = (float*)(s_outpix + BM);                // [WM][BN][2]
     // tap tables copied to LDS: indexing the kernarg arrays with the runtime tap id compiles to VMEM loads inside the K
     // loop, and the vmcnt wait for those would drain the in-flight LDS-DMA prefetch
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         a_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;      // element offset of the logical chunk this lane fetches
         a_lo[j] = false;
         if (X3) { const int c = lslot ^ ((r >> 1) & 7); a_lo[j] = (c & 4) != 0; a_chunk[j] = (c & 3) * 8; }
-        if (STEM) { const int c = lslot ^ ((r >> 1) & 7); a_chunk[j] = ((c >> 2) << 16) | ((c & 3) * 8); }   // (row of the pair, offset)
+        if (STEM && !X3) { const int c = lslot ^ ((r >> 1) & 7); a_chunk[j] = ((c >> 2) << 16) | ((c & 3) * 8); }   // (row of the pair, offset)
         if (lslot == 0 && ii < IA) {
             int op = (n * g.Ho + p * g.out_sh + out_oh) * g.Wo + q * g.out_sw + out_ow;
             s_outpix[r] = a_ok[j] ? op : -1;
@@ -111,10 +114,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         b_lo[j] = false;
         if (X3) { const int c = lslot ^ ((r >> 1) & 7); b_lo[j] = (c & 4) != 0; b_chunk[j] = (c & 3) * 8; }
     }
-    const int nsteps = STEM ? 4 : ntaps * g.cpt;
+    const int nsteps = STEM ? (X3 ? 7 : 4) : ntaps * g.cpt;      // STEM + X3: one kernel row (32 elements, both planes) per step
 
     auto issue = [&](int step, int buf) {
-        const int t = STEM ? 0 : step / g.cpt, c0 = STEM ? step * 64 : (step - t * g.cpt) * CK;
+        const int t = STEM ? 0 : step / g.cpt, c0 = STEM ? step * CK : (step - t * g.cpt) * CK;
         const int dh = STEM ? 0 : s_tap[t], dw = STEM ? 0 : s_tap[CG_MAXTAPS + t], ko = STEM ? 0 : s_tap[2 * CG_MAXTAPS + t];
         unsigned char* base = smem + buf * BUFSZ;
 #pragma unroll
@@ -123,8 +126,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
             if (ii < IA) {
                 const bf16_t* src;
                 if (STEM) {
-                    const int krow = 2 * step + (a_chunk[j] >> 16);                 // kernel row 0..7 (7 = padding)
-                    src = (a_ok[j] && krow < 7) ? A + ((a_base[j] + (long)(a_h[j] + krow) * g.Wa + a_w[j]) * 4 + (a_chunk[j] & 0xffff)) : zp;
+                    const int krow = X3 ? step : 2 * step + (a_chunk[j] >> 16);     // kernel row 0..7 (7 = padding)
+                    src = (a_ok[j] && krow < 7) ? ((X3 && a_lo[j]) ? Alo : A) + ((a_base[j] + (long)(a_h[j] + krow) * g.Wa + a_w[j]) * 4 + (a_chunk[j] & 0xffff)) : zp;
                 } else {
                     int hi = a_h[j] + dh, wi = a_w[j] + dw;
                     bool ok = a_ok[j] && (unsigned)hi < (unsigned)g.Ha && (unsigned)wi < (unsigned)g.Wa;
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         float* __restrict__ OutF = (float*)g.Out;
         const float* __restrict__ AddF = (const float*)g.addend;
         constexpr int SPF = BN * 4 + 16;
-        static_assert(BM * SPF <= NBUF * BUFSZ, "fp32 staging tile must fit in the K-loop buffers");
+        static_assert(BM * SPF <= RINGSZ, "fp32 staging tile must fit in the K-loop buffers");
         float csum[TN], csq[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
@@ -460,21 +463,57 @@ int conv_gemm2_run(ConvGemmArgs& g, hipStream_t st) {
 
 // ---- split-bf16 ("bf16x3") launches: g.A / g.A_lo and g.Bw / g.Bw_lo are the bf16 planes, g.cpt counts 32-channel
 // chunks, Out / addend / stats are fp32.  Tile choice follows the bf16 path (2x the K steps of the same shape).
-int conv_gemm2_x3_mtiles(int M, int Cn, int nsteps) {
-    int bm, bn; pick_tile2(M, Cn, nsteps, &bm, &bn);
+// Tile choice of the split-bf16 launches.  A K step carries 3x the MFMA work of a bf16 step on the same bytes, so these
+// launches are bound by barriers / prologue / epilogue rather than by the fill: prefer the 128-pixel tile (twice the MFMAs per
+// barrier) whenever it still gives every CU two workgroups, counting all parity classes of a one-grid stride-2 data gradient.
+static void pick_tile2x(int M, int Cn, int nsteps, int nclass, int* bm, int* bn) {
+    static const int mode = getenv("AB_G2X_MODE") ? atoi(getenv("AB_G2X_MODE")) : 1;
+    if (mode == 0) { pick_tile2(M, Cn, nsteps, bm, bn); return; }
+    *bn = (Cn > 64) ? 128 : 64;
+    const long t128 = (long)((M + 127) / 128) * ((Cn + *bn - 1) / *bn) * (nclass > 1 ? nclass : 1);
+    *bm = t128 >= 512 ? 128 : 64;
+}
+
+int conv_gemm2_x3_mtiles(int M, int Cn, int nsteps, int nclass) {
+    int bm, bn; pick_tile2x(M, Cn, nsteps, nclass, &bm, &bn);
     return (M + bm - 1) / bm;
 }
 
 int conv_gemm2_x3_run(ConvGemmArgs& g, hipStream_t st) {
     if (g.Ca % 32 || !g.A_lo || !g.Bw_lo) return AB_ESHAPE;
-    int bm, bn; pick_tile2(g.M, g.Cn, g.ntaps * g.cpt, &bm, &bn);
+    const int nsteps = g.ntaps * g.cpt;
+    int bm, bn; pick_tile2x(g.M, g.Cn, nsteps, g.nclass, &bm, &bn);
     int tiles = ((g.M + bm - 1) / bm) * ((g.Cn + bn - 1) / bn) * (g.nclass > 1 ? g.nclass : 1);
     const long wbytes = (long)g.Cn * g.ktot * 4, abytes = (long)g.N * g.Ha * g.Wa * g.Ca * 4;
     g.nmajor = (wbytes > (3L << 20) && abytes <= (8L << 20) && g.Cn > bn);
-    if (bm == 128 && bn == 128) conv_gemm2_kernel<128, 128, 4, 2, 3, false, 1><<<tiles, 512, 0, st>>>(g);
-    else if (bm == 128 && bn == 64) conv_gemm2_kernel<128, 64, 4, 2, 3, false, 1><<<tiles, 512, 0, st>>>(g);
-    else if (bm == 64 && bn == 128) conv_gemm2_kernel<64, 128, 2, 4, 3, false, 1><<<tiles, 512, 0, st>>>(g);
-    else conv_gemm2_kernel<64, 64, 2, 2, 3, false, 1><<<tiles, 256, 0, st>>>(g);
+    // two ring stages for short K loops and for the 128x128 tile: 64 KB instead of 96, two workgroups per CU
+    static const int nb2 = getenv("AB_G2X_NBUF2") ? atoi(getenv("AB_G2X_NBUF2")) : 1;
+    const bool two = nb2 && (nsteps <= 16 || (bm == 128 && bn == 128));
+    if (bm == 128 && bn == 128) {
+        if (two) conv_gemm2_kernel<128, 128, 4, 2, 2, false, 1><<<tiles, 512, 0, st>>>(g);
+        else conv_gemm2_kernel<128, 128, 4, 2, 3, false, 1><<<tiles, 512, 0, st>>>(g);
+    } else if (bm == 128 && bn == 64) {
+        if (two) conv_gemm2_kernel<128, 64, 4, 2, 2, false, 1><<<tiles, 512, 0, st>>>(g);
+        else conv_gemm2_kernel<128, 64, 4, 2, 3, false, 1><<<tiles, 512, 0, st>>>(g);
+    } else if (bm == 64 && bn == 128) {
+        if (two) conv_gemm2_kernel<64, 128, 2, 4, 2, false, 1><<<tiles, 512, 0, st>>>(g);
+        else conv_gemm2_kernel<64, 128, 2, 4, 3, false, 1><<<tiles, 512, 0, st>>>(g);
+    } else {
+        if (two) conv_gemm2_kernel<64, 64, 2, 2, 2, false, 1><<<tiles, 256, 0, st>>>(g);
+        else conv_gemm2_kernel<64, 64, 2, 2, 3, false, 1><<<tiles, 256, 0, st>>>(g);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// split-bf16 stem (7x7/2 on the zero-bordered NHWC4 image planes; weights [Cout][7][8][4] planes): seven K steps of one
+// kernel row each
+int conv_gemm2_x3_stem_mtiles(int M) { return (M + 127) / 128; }
+int conv_gemm2_x3_stem_run(ConvGemmArgs& g, hipStream_t st) {
+    if (g.Cn != 64 || g.ktot != 224 || !g.A_lo || !g.Bw_lo) return AB_ESHAPE;
+    g.nclass = 0; g.nmajor = 0; g.ntaps = 7; g.cpt = 1;
+    int tiles = (g.M + 127) / 128;
+    conv_gemm2_kernel<128, 64, 4, 2, 2, true, 1><<<tiles, 512, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -12,7 +12,7 @@
 int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn);
 int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W,
                    int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st);
-int conv_gemm2_x3_mtiles(int M, int Cn, int nsteps);
+int conv_gemm2_x3_mtiles(int M, int Cn, int nsteps, int nclass);
 int conv_gemm2_x3_run(ConvGemmArgs& g, hipStream_t st);
 int wgrad3x3_x3_slices(int N, int H, int W, int Cin, int Cout);
 int wgrad3x3_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N, int H, int W,
@@ -20,6 +20,11 @@ int wgrad3x3_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, const
 int wgrad_gemm2_x3_slices(int M, int Cout, int Cin, int ntaps);
 int wgrad_gemm2_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N, int H, int W,
                        int Cin, int Cout, int kh, int kw, int stride, int pad, hipStream_t st);
+int conv_gemm2_x3_stem_mtiles(int M);
+int conv_gemm2_x3_stem_run(ConvGemmArgs& g, hipStream_t st);
+int wgrad_gemm2_stem_slices(int N, int H, int W, int Cout);
+int wgrad_gemm2_x3_stem_run(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N,
+                            int H, int W, int Cout, hipStream_t st);
 int wgrad_launch_reduce(const float* slabs, int ns, long slab_elems, int src_j, int dst_j, float* dst, int accumulate,
                            int stem_mask, hipStream_t st);      // conv_wgrad.hip
 
@@ -56,7 +61,7 @@ static bool x3_is_c3(int kh, int kw, int stride, int pad) { return kh == 3 && kw
 extern "C" int ab_conv2d_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (x3_is_c3(kh, kw, stride, pad)) { int t = conv3x3_x3_tiles(N, H, W, Cin, Cout); if (t) return t; }
-    return conv_gemm2_x3_mtiles(N * Ho * Wo, Cout, kh * kw * (Cin / 32));
+    return conv_gemm2_x3_mtiles(N * Ho * Wo, Cout, kh * kw * (Cin / 32), 0);
 }
 
 extern "C" int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* y, int N, int H,
@@ -89,7 +94,7 @@ extern "C" int ab_conv2d_dgrad_x3_stat_rows(int N, int H, int W, int Cin, int Co
         for (int i = 0; i < kh; ++i) for (int j = 0; j < kw; ++j) if (!((a + pad - i) % 2) && !((b + pad - j) % 2)) ++nt;
         if (nt > maxt) maxt = nt;
     }
-    return 4 * conv_gemm2_x3_mtiles(N * (H / 2) * (W / 2), Cin, maxt * (Cout / 32));
+    return 4 * conv_gemm2_x3_mtiles(N * (H / 2) * (W / 2), Cin, maxt * (Cout / 32), 4);
 }
 
 extern "C" int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N,
@@ -162,4 +167,32 @@ extern "C" int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void
     int rc = wgrad_gemm2_x3_run(x_hi, x_lo, dy_hi, dy_lo, (float*)workspace, N, H, W, Cin, Cout, kh, kw, stride, pad, st);
     if (rc) return rc;
     return wgrad_launch_reduce((float*)workspace, ns, slab, kh * kw * Cin, kh * kw * Cin, dw, accumulate, 0, st);
+}
+
+// ---------------------------------------------------------------- stem 7x7/2 (resnet.py:154) on split planes
+// xpad planes: zero-bordered NHWC4 image [N, H+6, W+8, 4]; w planes [64][7][8][4]; y fp32 [N, H/2, W/2, 64]
+extern "C" int ab_conv2d_stem_x3_stat_rows(int N, int H, int W) { return conv_gemm2_x3_stem_mtiles(N * (H / 2) * (W / 2)); }
+
+extern "C" int ab_conv2d_stem_fwd_x3(const void* xpad_hi, const void* xpad_lo, const void* w_hi, const void* w_lo, float* y, int N,
+                                     int H, int W, int Cout, float* stats, void* stream) {
+    if (!xpad_hi || !xpad_lo || !w_hi || !w_lo || !y) return AB_EINVAL;
+    if ((H & 1) || (W & 1) || Cout != 64) return AB_ESHAPE;
+    ConvGemmArgs g = {};
+    g.A = xpad_hi; g.A_lo = xpad_lo; g.Bw = w_hi; g.Bw_lo = w_lo; g.Out = y; g.stats = stats;
+    g.N = N; g.Ha = H + 6; g.Wa = W + 8; g.Ca = 4;
+    g.Ho = H / 2; g.Wo = W / 2; g.Cn = Cout; g.P = g.Ho; g.Q = g.Wo; g.out_sh = g.out_sw = 1; g.a_sh = g.a_sw = 2;
+    g.ktot = 7 * 32; g.M = N * g.P * g.Q;
+    return conv_gemm2_x3_stem_run(g, as_stream(stream));
+}
+
+/* dw fp32 [Cout][7][8][4]; workspace: ab_conv2d_stem_wgrad_workspace(N, H, W, Cout) bytes */
+extern "C" int ab_conv2d_stem_wgrad_x3(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo, float* dw,
+                                       int N, int H, int W, int Cout, void* workspace, void* stream) {
+    if (!xpad_hi || !xpad_lo || !dy_hi || !dy_lo || !dw || !workspace) return AB_EINVAL;
+    if ((H & 1) || (W & 1) || Cout % 64) return AB_ESHAPE;
+    int ns = wgrad_gemm2_stem_slices(N, H, W, Cout);
+    if (ns <= 0) return AB_ESHAPE;
+    int rc = wgrad_gemm2_x3_stem_run(xpad_hi, xpad_lo, dy_hi, dy_lo, (float*)workspace, N, H, W, Cout, as_stream(stream));
+    if (rc) return rc;
+    return wgrad_launch_reduce((float*)workspace, ns, (long)Cout * 256, 256, 7 * 32, dw, 0, 1, as_stream(stream));
 }

@@ -571,6 +571,97 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
     if (pl == 0 && c < C) { for (int k = 1; k < 32; ++k) s += sm[k][cl]; out[c] = (float)s; }
 }
 
+// ================================================================ split-bf16 ("bf16x3") producers
+// The fp32 elementwise passes that feed a convolution write its operand directly as (hi, lo) bf16 planes (conv_x3.hip):
+// same bytes as the fp32 tensor they replace, and no separate split pass.  8 channels per thread.
+__device__ __forceinline__ void store_split8(bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long e, const float* f) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h[k] = pack_bf16x2(f[2 * k], f[2 * k + 1]);
+        l[k] = pack_bf16x2(f[2 * k] - __uint_as_float(h[k] << 16), f[2 * k + 1] - __uint_as_float(h[k] & 0xffff0000u));
+    }
+    *(uint4*)(hi + e) = make_uint4(h[0], h[1], h[2], h[3]);
+    *(uint4*)(lo + e) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ void load8(const float* __restrict__ p, float* f) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void store8(float* __restrict__ p, const float* f) {
+    *(float4*)p = make_float4(f[0], f[1], f[2], f[3]); *(float4*)(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+// out = [relu]( y*scale + shift [+ res] ) -> fp32 `out` (optional) and split planes
+__global__ __launch_bounds__(256) void bn_apply_x3_kernel(const float* __restrict__ y, const float* __restrict__ res,
+                                                          const float* __restrict__ bnp, long nvec, int C, int relu,
+                                                          float* __restrict__ out, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+    const bool fixed = ((256 * 8) % C) == 0;
+    float sc[8], sh[8];
+    if (fixed) {
+        const int c = (int)(((long)threadIdx.x * 8) % C);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[k] = bnp[c + k]; sh[k] = bnp[C + c + k]; }
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const long e = i * 8;
+        if (!fixed) {
+            const int c = (int)(e % C);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sc[k] = bnp[c + k]; sh[k] = bnp[C + c + k]; }
+        }
+        float f[8], r[8];
+        load8(y + e, f);
+        if (res) load8(res + e, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = f[k] * sc[k] + sh[k];
+            if (res) v += r[k];
+            if (relu) v = fmaxf(v, 0.f);
+            f[k] = v;
+        }
+        if (out) store8(out + e, f);
+        store_split8(hi, lo, e, f);
+    }
+}
+
+// BatchNorm-backward pass 2 with dy written as split planes (its only consumers are the data- and weight-gradient convs)
+__global__ __launch_bounds__(256) void bn_bwd_apply_x3_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                              const float* __restrict__ y, const float* __restrict__ bnp,
+                                                              const float* __restrict__ bwdp, long nvec, int C, long M, int relu,
+                                                              bf16_t* __restrict__ dy_hi, bf16_t* __restrict__ dy_lo,
+                                                              float* __restrict__ dz_out) {
+    const float invM = 1.f / (float)M;
+    const bool fixed = ((256 * 8) % C) == 0;
+    float ga[8], sh[8], mu[8], is[8], k1[8], k2[8];
+    auto loadp = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ga[k] = bnp[c + k]; sh[k] = bnp[C + c + k]; mu[k] = bnp[2 * C + c + k]; is[k] = bnp[3 * C + c + k];
+            k1[k] = bwdp[c + k] * invM; k2[k] = bwdp[C + c + k] * invM;
+        }
+    };
+    if (fixed) loadp((int)(((long)threadIdx.x * 8) % C));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const long e = i * 8;
+        if (!fixed) loadp((int)(e % C));
+        float g[8], o[8], yy[8], d[8];
+        load8(dout + e, g);
+        load8(y + e, yy);
+        if (relu == 1) load8(out + e, o);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool dead = relu == 1 ? !(o[k] > 0.f) : relu == 2 ? !(yy[k] * ga[k] + sh[k] > 0.f) : false;
+            const float dz = dead ? 0.f : g[k];
+            const float xhat = (yy[k] - mu[k]) * is[k];
+            d[k] = ga[k] * (dz - k1[k] - xhat * k2[k]);
+            g[k] = dz;
+        }
+        store_split8(dy_hi, dy_lo, e, d);
+        if (dz_out) store8(dz_out + e, g);
+    }
+}
+
 // ================================================================ C ABI
 static inline int grid_for(long nvec) { long b = (nvec + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 #define DISPATCH(dtype, CALL_F, CALL_B) do { if ((dtype) == AB_DT_F32) { CALL_F; } else if ((dtype) == AB_DT_BF16) { CALL_B; } else return AB_EINVAL; } while (0)
@@ -755,5 +846,37 @@ extern "C" int ab_col_sum(const void* x, int dtype, long M, int C, float* part, 
     int rc = ab_col_stats(x, dtype, M, C, part, stream);
     if (rc) return rc;
     colsum_finalize_kernel<<<(C + 7) / 8, 256, 0, as_stream(stream)>>>(part, ab_col_stats_nparts(M), C, out);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+// ---- split-bf16 producers (fp32 in; see the kernels above).  out (bn_apply) / dz_out may be NULL.
+extern "C" int ab_bn_apply_x3(const float* y, const float* res, const float* bnp, long M, int C, int relu, float* out,
+                              void* out_hi, void* out_lo, void* stream) {
+    if (!y || !bnp || !out_hi || !out_lo) return AB_EINVAL;
+    if (C % 8) return AB_ESHAPE;
+    const long nvec = M * C / 8;
+    bn_apply_x3_kernel<<<grid_for(nvec), 256, 0, as_stream(stream)>>>(y, res, bnp, nvec, C, relu, out, (bf16_t*)out_hi, (bf16_t*)out_lo);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+// ab_bn_bwd / ab_bn_bwd_apply with dy as split planes: nparts_given = 0 runs the reduction pass into `part`
+// ([ab_col_stats_nparts(M)][C][2]); > 0 takes `part` as already reduced per-tile sums (see ab_bn_bwd_apply).
+extern "C" int ab_bn_bwd_x3(const float* dout, const float* out, const float* y, const float* bnp, long M, int C, int relu,
+                            float* part, int nparts_given, float* bwdp, float* dgamma, float* dbeta, void* dy_hi, void* dy_lo,
+                            float* dz_out, void* stream) {
+    if (!dout || !y || !bnp || !part || !bwdp || !dgamma || !dbeta || !dy_hi || !dy_lo || (relu == 1 && !out) || relu < 0 || relu > 2)
+        return AB_EINVAL;
+    if (C % 8 || C / 4 > 256) return AB_ESHAPE;
+    hipStream_t st = as_stream(stream);
+    int np = nparts_given > 0 ? nparts_given : ab_col_stats_nparts(M);
+    if (nparts_given <= 0) {
+        const int rl = 256 / (C / 4); const size_t sh = (size_t)rl * C * 2 * 4;
+        bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>(dout, out, y, bnp, M, C, relu, red_rows(M), part, nullptr, 0, 0);
+        AB_LAUNCH_CHECK();
+    }
+    launch_bn_bwd_finalize(part, np, C, dgamma, dbeta, bwdp, st);
+    AB_LAUNCH_CHECK();
+    const long nvec = M * C / 8;
+    bn_bwd_apply_x3_kernel<<<grid_for(nvec), 256, 0, st>>>(dout, out, y, bnp, bwdp, nvec, C, M, relu, (bf16_t*)dy_hi, (bf16_t*)dy_lo, dz_out);
     AB_LAUNCH_CHECK(); return 0;
 }

@@ -357,3 +357,22 @@ int wgrad_gemm2_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, co
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
+
+// split-bf16 stem weight gradient (image and dy as plane pairs); slabs as wgrad_gemm2_stem_run
+int wgrad_gemm2_x3_stem_run(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N,
+                            int H, int W, int Cout, hipStream_t st) {
+    int ns = wgrad_gemm2_stem_slices(N, H, W, Cout);
+    if (!ns) return AB_ESHAPE;
+    Wg2Args g = {};
+    g.X = xpad_hi; g.X_lo = xpad_lo; g.DY = dy_hi; g.DY_lo = dy_lo; g.slabs = slabs;
+    g.N = N; g.Ha = H + 6; g.Wa = W + 8; g.Ca = 4;
+    g.P = H / 2; g.Q = W / 2; g.Cout = Cout; g.stride = 2; g.ntaps = 8; g.Cin = 256; g.jtot = 256; g.M = N * g.P * g.Q;
+    g.magic_pq = (1ull << 42) / (unsigned long long)(g.P * g.Q) + 1;
+    g.magic_q = (1ull << 42) / (unsigned long long)g.Q + 1;
+    int r = (g.M + ns - 1) / ns; r = (r + 63) / 64 * 64;
+    g.rows_per_slice = r;
+    dim3 grid(Cout / 64, ns);
+    wgrad_gemm2_kernel<64, 256, true, 2, 4, 1><<<grid, 512, 0, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

@@ -359,10 +359,18 @@ class HybridNet:
         return K.bn_eval_params(p.view(prefix + ".weight"), p.view(prefix + ".bias"),
                                 p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
 
-    def _bn(self, prefix, y, stats_part, count, res=None, relu=True):
+    def _bn(self, prefix, y, stats_part, count, res=None, relu=True, feeds_conv=True, keep_f32=False):
+        """feeds_conv / keep_f32 (bf16x3 only): the activation feeds a convolution (it is written as split planes by this
+        pass) / is also needed in fp32 (residual input, ReLU mask of the backward, pooling)."""
         bnp = self._bn_params(prefix, stats_part, count)
+        if self.x3 and feeds_conv:
+            return K.bn_apply_x3(y, bnp, res=res, relu=relu, want_f32=keep_f32), bnp
         out = K.bn_apply(y, bnp, res=res, relu=relu)
         return out, bnp
+
+    def _bn_bwd(self, *a, **kw):
+        """BatchNorm backward; the gradient wrt the conv output goes to convolutions only: split planes under bf16x3."""
+        return (K.bn_bwd_x3 if self.x3 else K.bn_bwd)(*a, **kw)
 
     # ------------------------------------------------------------------ forward
     def forward(self, image=None, xpad=None):
@@ -376,9 +384,10 @@ class HybridNet:
         N = xpad.shape[0]
         H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
         S = {"xpad": xpad, "N": N, "HW": (H, W), "blocks": []}
-        # (bf16x3: the 3-channel stem runs on the exact-f32 kernel, 1 % of the FLOPs)
-        w_stem = p.view("backbone.conv1.weight") if self.x3 else self.w("backbone.conv1.weight")
-        y0, st = K.conv2d_stem_fwd(xpad, w_stem, H, W, want_stats=True)
+        if self.x3:
+            y0, st = K.conv2d_stem_fwd_x3(xpad, self.w("backbone.conv1.weight"), H, W, want_stats=True)
+        else:
+            y0, st = K.conv2d_stem_fwd(xpad, self.w("backbone.conv1.weight"), H, W, want_stats=True)
         if self.fuse_stem:
             bnp0 = self._bn_params("backbone.bn1", st, N * (H // 2) * (W // 2))
             x, pool_idx = K.bn_relu_maxpool_fwd(y0, bnp0)      # BN + ReLU + 3x3/2 max-pool: the 128x128x64 activation is never stored
@@ -398,11 +407,11 @@ class HybridNet:
                 rec = dict(pre=pre, stride=stride, x=x, y1=y1, a1=a1, bnp1=bnp1, y2=y2, ds=False)
                 if stride != 1 or inpl != planes:
                     yd, std_ = self._conv_fwd(x, pre + ".downsample.0.weight", stride, 0, want_stats=True)
-                    r, bnpd = self._bn(pre + ".downsample.1", yd, std_, cnt, relu=False)
+                    r, bnpd = self._bn(pre + ".downsample.1", yd, std_, cnt, relu=False, feeds_conv=False)
                     rec.update(ds=True, yd=yd, bnpd=bnpd)
                 else:
                     r = x
-                out, bnp2 = self._bn(pre + ".bn2", y2, st2, cnt, res=r, relu=True)
+                out, bnp2 = self._bn(pre + ".bn2", y2, st2, cnt, res=r, relu=True, keep_f32=True)
                 rec.update(bnp2=bnp2, out=out)
                 if not tr:
                     rec = dict(pre=pre)
@@ -535,11 +544,11 @@ class HybridNet:
             dlogits = K.split(dlogits)        # one split serves the weight and the data gradient
         self._wgrad_side(self._conv_wgrad, e2, dlogits, 1, 1, 1, 0, out=gv("hybrid_head.final_layer.weight"))
         de2 = self._conv_dgrad(dlogits, "hybrid_head.final_layer.weight", (e2.shape[-3], e2.shape[-2]), 1, 0)
-        dd2 = K.bn_bwd(de2, e2, S["d2"], S["bnpd2"], gv("hybrid_head.deconv_layers.4.weight"),
+        dd2 = self._bn_bwd(de2, e2, S["d2"], S["bnpd2"], gv("hybrid_head.deconv_layers.4.weight"),
                        gv("hybrid_head.deconv_layers.4.bias"), relu="recompute")
         self._wgrad_side(self._conv_wgrad, dd2, e1, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.3.weight"))
         de1 = self._conv_fwd(dd2, "hybrid_head.deconv_layers.3.weight", 2, 1)
-        dd1 = K.bn_bwd(de1, e1, S["d1"], S["bnpd1"], gv("hybrid_head.deconv_layers.1.weight"),
+        dd1 = self._bn_bwd(de1, e1, S["d1"], S["bnpd1"], gv("hybrid_head.deconv_layers.1.weight"),
                        gv("hybrid_head.deconv_layers.1.bias"), relu="recompute")
         self._wgrad_side(self._conv_wgrad, dd1, feat, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.0.weight"))
         dout = self._conv_fwd(dd1, "hybrid_head.deconv_layers.0.weight", 2, 1)
@@ -563,18 +572,18 @@ class HybridNet:
         for k, rec in enumerate(blocks):
             pre, stride, x = rec["pre"], rec["stride"], rec["x"]
             nxt = blocks[k + 1] if k + 1 < len(blocks) else below
-            dy2, dz = K.bn_bwd(dout, rec["out"], rec["y2"], rec["bnp2"], gv(pre + ".bn2.weight"), gv(pre + ".bn2.bias"),
+            dy2, dz = self._bn_bwd(dout, rec["out"], rec["y2"], rec["bnp2"], gv(pre + ".bn2.weight"), gv(pre + ".bn2.bias"),
                                relu=True, want_dz=True, part=dout_part)
             self._wgrad_side(self._conv_wgrad, rec["a1"], dy2, 3, 3, 1, 1, out=gv(pre + ".conv2.weight"))
             # the BN-backward reduction of bn1 rides in the epilogue of the data gradient that produces its input
             da1, part1 = self._conv_dgrad(dy2, pre + ".conv2.weight", (dy2.shape[-3], dy2.shape[-2]), 1, 1,
                                           bn=(rec["y1"], None, rec["bnp1"]))
-            dy1 = K.bn_bwd(da1, rec["a1"], rec["y1"], rec["bnp1"], gv(pre + ".bn1.weight"), gv(pre + ".bn1.bias"),
+            dy1 = self._bn_bwd(da1, rec["a1"], rec["y1"], rec["bnp1"], gv(pre + ".bn1.weight"), gv(pre + ".bn1.bias"),
                             relu="recompute", part=part1)
             self._wgrad_side(self._conv_wgrad, x, dy1, 3, 3, stride, 1, out=gv(pre + ".conv1.weight"))
             bn_below = (nxt["y2"], nxt["out"], nxt["bnp2"]) if nxt is not None else None
             if rec["ds"]:
-                dyd = K.bn_bwd(dz, None, rec["yd"], rec["bnpd"], gv(pre + ".downsample.1.weight"),
+                dyd = self._bn_bwd(dz, None, rec["yd"], rec["bnpd"], gv(pre + ".downsample.1.weight"),
                                gv(pre + ".downsample.1.bias"), relu=False)
                 self._wgrad_side(self._conv_wgrad, x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
                 dx = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[1], x.shape[2]), stride, 1)
@@ -597,8 +606,8 @@ class HybridNet:
         else:
             y0 = S["y0"]
             da0 = K.maxpool_bwd(S["pool_idx"], dout, (y0.shape[1], y0.shape[2]))
-            dy0 = K.bn_bwd(da0, None, y0, S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"), relu="recompute")
+            dy0 = self._bn_bwd(da0, None, y0, S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"), relu="recompute")
         H, W = S["HW"]
-        self._wgrad_side(K.conv2d_stem_wgrad, S["xpad"], dy0, H, W, out=gv("backbone.conv1.weight"))
+        self._wgrad_side(K.conv2d_stem_wgrad_x3 if self.x3 else K.conv2d_stem_wgrad, S["xpad"], dy0, H, W, out=gv("backbone.conv1.weight"))
         self._wgrad_join()
         self.saved = None

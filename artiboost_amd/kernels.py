@@ -383,7 +383,7 @@ def _planes(t):
         return t[0], t[1]
     sp = getattr(t, "_ab_split", None)
     if sp is None:
-        sp = split(t)
+        sp = t._ab_split = split(t)       # cached on the tensor object: its other consumers (weight gradient) reuse it
     return sp[0], sp[1]
 
 
@@ -440,4 +440,67 @@ def conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=None, accumulate=False):
     L.check(lib.ab_conv2d_wgrad_x3(L.ptr(xh), L.ptr(xl), L.ptr(dh), L.ptr(dl), L.ptr(dw), L.i(N), L.i(H), L.i(W), L.i(Cin),
                                    L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(ws), L.i(1 if accumulate else 0),
                                    L.stream()), "ab_conv2d_wgrad_x3")
+    return dw
+
+
+def bn_apply_x3(y, bnp, res=None, relu=True, want_f32=False):
+    """fp32 y -> split planes [2, *y.shape] of relu(bn(y) + res); want_f32: also the fp32 tensor (returned, with the planes
+    cached on it as `_ab_split`) -- needed where the activation is a residual input or a ReLU mask in the backward."""
+    C = y.shape[-1]
+    M = y.numel() // C
+    sp = torch.empty((2,) + tuple(y.shape), dtype=torch.bfloat16, device=y.device)
+    o = torch.empty_like(y) if want_f32 else None
+    L.check(L.lib().ab_bn_apply_x3(L.ptr(y), L.ptr(res), L.ptr(bnp), L.l(M), L.i(C), L.i(1 if relu else 0), L.ptr(o),
+                                   L.ptr(sp[0]), L.ptr(sp[1]), L.stream()), "ab_bn_apply_x3")
+    if o is None:
+        return sp
+    o._ab_split = sp
+    return o
+
+
+def bn_bwd_x3(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, part=None):
+    """As bn_bwd on fp32 tensors, with dy returned as split planes [2, *y.shape] (-> dy [, dz fp32])."""
+    C = y.shape[-1]
+    M = y.numel() // C
+    lib = L.lib()
+    bwdp = torch.empty((2, C), dtype=torch.float32, device=y.device)
+    dy = torch.empty((2,) + tuple(y.shape), dtype=torch.bfloat16, device=y.device)
+    dz = torch.empty_like(y) if want_dz else None
+    given = 0
+    if part is None:
+        part = torch.empty((lib.ab_col_stats_nparts(L.l(M)), C, 2), dtype=torch.float32, device=y.device)
+    else:
+        given = part.shape[0]
+    L.check(lib.ab_bn_bwd_x3(L.ptr(dout), L.ptr(out if relu is True else None), L.ptr(y), L.ptr(bnp), L.l(M), L.i(C),
+                             L.i(2 if relu == "recompute" else 1 if relu else 0), L.ptr(part), L.i(given), L.ptr(bwdp),
+                             L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy[0]), L.ptr(dy[1]), L.ptr(dz), L.stream()), "ab_bn_bwd_x3")
+    return (dy, dz) if want_dz else dy
+
+
+def conv2d_stem_fwd_x3(xpad, w_split, H, W, want_stats=False):
+    """xpad fp32 / split [.., N,H+6,W+8,4], w_split [2,64,7,8,4] -> y fp32 [N,H/2,W/2,64] (+ BN partials)."""
+    xh, xl = _planes(xpad)
+    N = xh.shape[0]
+    Cout = w_split.shape[1]
+    y = torch.empty((N, H // 2, W // 2, Cout), dtype=torch.float32, device=xh.device)
+    lib = L.lib()
+    stats = None
+    if want_stats:
+        stats = torch.empty((lib.ab_conv2d_stem_x3_stat_rows(L.i(N), L.i(H), L.i(W)), Cout, 2), dtype=torch.float32, device=xh.device)
+    L.check(lib.ab_conv2d_stem_fwd_x3(L.ptr(xh), L.ptr(xl), L.ptr(w_split[0]), L.ptr(w_split[1]), L.ptr(y), L.i(N), L.i(H), L.i(W),
+                                      L.i(Cout), L.ptr(stats), L.stream()), "ab_conv2d_stem_fwd_x3")
+    return (y, stats) if want_stats else y
+
+
+def conv2d_stem_wgrad_x3(xpad, dy, H, W, out=None):
+    xh, xl = _planes(xpad)
+    dh, dl = _planes(dy)
+    N = xh.shape[0]
+    Cout = dh.shape[3]
+    lib = L.lib()
+    nbytes = lib.ab_conv2d_stem_wgrad_workspace(L.i(N), L.i(H), L.i(W), L.i(Cout))
+    dw = out if out is not None else torch.empty((Cout, 7, 8, 4), dtype=torch.float32, device=xh.device)
+    ws = _workspace(nbytes, xh.device)
+    L.check(lib.ab_conv2d_stem_wgrad_x3(L.ptr(xh), L.ptr(xl), L.ptr(dh), L.ptr(dl), L.ptr(dw), L.i(N), L.i(H), L.i(W), L.i(Cout),
+                                        L.ptr(ws), L.stream()), "ab_conv2d_stem_wgrad_x3")
     return dw

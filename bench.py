@@ -76,7 +76,8 @@ def conv_kernel_time_ms(ts, loader, static, iters=3):
     durations of profiles/round1_*_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this same command)."""
     import torch
     from artiboost_amd import kernels as K
-    names = ["conv2d_fwd", "conv2d_stem_fwd", "conv2d_dgrad", "conv2d_wgrad", "conv2d_stem_wgrad"]
+    names = ["conv2d_fwd", "conv2d_stem_fwd", "conv2d_dgrad", "conv2d_wgrad", "conv2d_stem_wgrad",
+             "conv2d_fwd_x3", "conv2d_stem_fwd_x3", "conv2d_dgrad_x3", "conv2d_wgrad_x3", "conv2d_stem_wgrad_x3"]
     orig = {n: getattr(K, n) for n in names}
     spans = []
 

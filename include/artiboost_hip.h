@@ -116,6 +116,22 @@ int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void* dy_hi, co
                        int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace, int accumulate,
                        void* stream);
 
+/* stem 7x7/2 on split planes of the zero-bordered NHWC4 image (ab_conv2d_stem_fwd / _wgrad at bf16x3 precision)        */
+int ab_conv2d_stem_x3_stat_rows(int N, int H, int W);
+int ab_conv2d_stem_fwd_x3(const void* xpad_hi, const void* xpad_lo, const void* w_hi, const void* w_lo, float* y, int N, int H,
+                          int W, int Cout, float* stats, void* stream);
+int ab_conv2d_stem_wgrad_x3(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo, float* dw, int N,
+                            int H, int W, int Cout, void* workspace, void* stream);
+/* fp32 elementwise passes that write a convolution operand directly as split planes (no separate ab_split_f32 pass):
+ * ab_bn_apply_x3 = ab_bn_apply on fp32 with out (optional fp32 copy, may be NULL) + planes; ab_bn_bwd_x3 = ab_bn_bwd /
+ * ab_bn_bwd_apply on fp32 with dy as planes (nparts_given = 0: run the reduction into `part`; > 0: `part` holds that many
+ * already reduced rows).  resnet.py:85-101, simplebaseline.py:171-172.                                             */
+int ab_bn_apply_x3(const float* y, const float* res, const float* bnp, long M, int C, int relu, float* out, void* out_hi,
+                   void* out_lo, void* stream);
+int ab_bn_bwd_x3(const float* dout, const float* out, const float* y, const float* bnp, long M, int C, int relu, float* part,
+                 int nparts_given, float* bwdp, float* dgamma, float* dbeta, void* dy_hi, void* dy_lo, float* dz_out,
+                 void* stream);
+
 /* ---- M1/M2: training-mode BatchNorm, ReLU, residual, pooling (HBM-bound NHWC kernels) ---------------------------
  * replaces nn.BatchNorm2d / ReLU / MaxPool2d / mean-pool: anakin/models/resnet.py:85-101,155-157,219;
  * anakin/models/simplebaseline.py:171-172.

@@ -117,3 +117,52 @@ def test_conv_transpose_4x4s2_x3():
     st = part.double().sum(0).cpu()
     np.testing.assert_allclose(st[:, 0].numpy(), yy.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(yy.abs().sum(0).max()))
     np.testing.assert_allclose(st[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("nhw", [(2, 32, 32), (1, 224, 224), (3, 20, 12)])
+def test_stem_fwd_wgrad_x3(nhw):
+    from artiboost_amd import kernels as K
+    N, H, W = nhw
+    g = torch.Generator().manual_seed(N * H)
+    x = torch.rand((N, 3, H, W), generator=g) - 0.5
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), stride=2, padding=3)
+    xpad = K.image_pad_nhwc4(x.cuda(), torch.float32)
+    wst = torch.zeros(64, 7, 8, 4)
+    wst[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    y, stats = K.conv2d_stem_fwd_x3(xpad, K.split(wst.cuda()), H, W, want_stats=True)
+    close(nchw(y.cpu()), ref)
+    yy = y.double().cpu().reshape(-1, 64)
+    st = stats.double().sum(0).cpu()
+    np.testing.assert_allclose(st[:, 0].numpy(), yy.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(yy.abs().sum(0).max()))
+    np.testing.assert_allclose(st[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)
+    dy = torch.randn(ref.shape, generator=g)
+    wr = w.double().clone().requires_grad_(True)
+    F.conv2d(x.double(), wr, stride=2, padding=3).backward(dy.double())
+    dw = K.conv2d_stem_wgrad_x3(xpad, nhwc(dy).cuda(), H, W).cpu()
+    assert float(dw[:, :, 7, :].abs().max()) == 0.0 and float(dw[:, :, :, 3].abs().max()) == 0.0
+    close(dw[:, :, :7, :3].permute(0, 3, 1, 2), wr.grad)
+
+
+def test_bn_producers_write_split_planes():
+    """ab_bn_apply_x3 / ab_bn_bwd_x3 == the fp32 kernels followed by ab_split_f32, bit for bit."""
+    from artiboost_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    N, H, W, C = 3, 12, 10, 128
+    y = torch.randn(N, H, W, C, generator=g).cuda()
+    res = torch.randn(N, H, W, C, generator=g).cuda()
+    part = K.col_stats(y)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    bnp = K.bn_finalize(part, N * H * W, gamma, beta)
+    ref = K.bn_apply(y, bnp, res=res, relu=True)
+    got = K.bn_apply_x3(y, bnp, res=res, relu=True, want_f32=True)
+    assert torch.equal(got, ref) and torch.equal(got._ab_split, K.split(ref))
+    assert torch.equal(K.bn_apply_x3(y, bnp, relu=True), K.split(K.bn_apply(y, bnp, relu=True)))
+    dout = torch.randn(N, H, W, C, generator=g).cuda()
+    for relu in (True, "recompute", False):
+        dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dg2, db2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dy_ref, dz_ref = K.bn_bwd(dout, ref, y, bnp, dg, db, relu=relu, want_dz=True)
+        dy, dz = K.bn_bwd_x3(dout, ref, y, bnp, dg2, db2, relu=relu, want_dz=True)
+        assert torch.equal(dy, K.split(dy_ref)) and torch.equal(dz, dz_ref)
+        assert torch.equal(dg, dg2) and torch.equal(db, db2)
