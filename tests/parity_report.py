@@ -1,5 +1,5 @@
 """Deviation of each precision mode from the reference goldens (tests/golden/learner_*.npz): max abs error of the
-predictions, relative error of the losses, worst gradient-norm ratio.  Run on the GPU box:  python tools/parity_report.py"""
+predictions, relative error of the losses, worst gradient-norm ratio.  Run on the GPU box:  python tests/parity_report.py"""
 import os
 import random
 import sys
@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):   # test infrastructure: may use oracle/
     sys.path.insert(0, p)
 from test_gpu_learner import build          # noqa: E402
 from gen_batch import make_batch            # noqa: E402

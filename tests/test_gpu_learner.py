@@ -43,7 +43,7 @@ def build(size, heat, dtype, seed):
 # Prediction tolerances (absolute; metres for joints / corners, heat-map units for 2d_uvd).  "bf16x3" -- split-bf16 MFMA, the
 # benchmarked precision -- is held to the exact-f32 path's tolerance on the losses (3e-4), to 1.5 % on the gradient norms
 # (f32: 1 %) and on the predictions to a bound 5x below the north star's 1e-3.  Measured against the reference goldens on MI355X
-# (tools/parity_report.py): train-mode joints 2.7e-7 m / corners 5e-6 m (f32: 6e-8 / 2.6e-7); eval mode on this deliberately
+# (tests/parity_report.py): train-mode joints 2.7e-7 m / corners 5e-6 m (f32: 6e-8 / 2.6e-7); eval mode on this deliberately
 # ill-conditioned random-weight net (running statistics 0 / 1) joints 1.45e-4 m, 2d_uvd 3.6e-4 (f32: 2.2e-5 m, 5.6e-5;
 # bf16: 9.5e-2 m, 2.4e-1).
 # gsamp: element-wise check of sampled weight-gradient entries, as a fraction of the sample's largest entry (the gradient
