@@ -1,0 +1,1 @@
+from artiboost_amd.models import Arch, HybridBaseline  # noqa: F401  (registers the MODEL types; builder.py:82 imports them from here)

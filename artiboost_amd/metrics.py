@@ -149,6 +149,20 @@ class Evaluator:
             out.update(m.get_measures())
         return out
 
+    def get_measures_all_striped(self, return_losses=True):
+        """evaluator.py:58-74: {metric class name: {measure: float}} (scalars only) for the recorder / summarizer."""
+        out = {}
+        for m in self._metrics_list:
+            if not return_losses and isinstance(m, LossesMetric):
+                continue
+            out[type(m).__name__] = {k: float(v) for k, v in m.get_measures().items()
+                                     if isinstance(v, (float, int)) or (hasattr(v, "ndim") and getattr(v, "ndim") == 0)}
+        return out
+
+    def dump_images(self):
+        """evaluator.py:76-82 (the Vis* metrics draw with cv2 / matplotlib and are not part of this build)."""
+        return {}
+
     def __str__(self):
         return " | ".join(s for s in (str(m) for m in self._metrics_list) if s)
 

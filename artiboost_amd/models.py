@@ -89,6 +89,7 @@ class HybridBaseline(nn.Module):
                              compute_dtype=(torch.bfloat16 if cd in ("bf16", torch.bfloat16) else
                                             "bf16x3" if cd in ("bf16x3", "x3") else torch.float32))
         self.flat_param = nn.Parameter(self.store.flat, requires_grad=True)   # shares storage with the store
+        self.flat_param._ab_owner = self                                      # netutils.build_optimizer recognises it
         pretrained = cfg.get("PRETRAINED", "")
         if pretrained:
             self.load_pretrained(pretrained)

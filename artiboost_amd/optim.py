@@ -23,9 +23,17 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.graph_steps = 0
         self._eager_hyper = None
 
+    HYPER_SLOTS = 32
+
     def use_device_hyper(self, device):
+        """Device-side {lr, bias corrections} for hipGraph replay.  The host runs many replayed steps ahead of the device
+        (nothing in an epoch synchronises), so the pinned staging is a RING: slot k is rewritten only after the copy that
+        last read it has executed (its event) -- a single reused pinned tensor could be overwritten by step i+k's values
+        before step i's queued H2D copy ran."""
         self.hyper = torch.zeros(3, dtype=torch.float32, device=device)
-        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        self._hyper_host = torch.zeros((self.HYPER_SLOTS, 3), dtype=torch.float32).pin_memory()
+        self._hyper_events = [None] * self.HYPER_SLOTS
+        self._hyper_next = 0
 
     def advance_hyper(self):
         """Host side of a replayed step: bump the step count and push {lr, bias corrections} to the device."""
@@ -34,10 +42,18 @@ class FusedClipAdam(torch.optim.Optimizer):
             st["step"] = self.graph_steps
         g = self.param_groups[0]
         b1, b2 = g["betas"]
-        self._hyper_host[0] = g["lr"]
-        self._hyper_host[1] = 1.0 - b1 ** self.graph_steps
-        self._hyper_host[2] = (1.0 - b2 ** self.graph_steps) ** 0.5
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        k = self._hyper_next
+        self._hyper_next = (k + 1) % self.HYPER_SLOTS
+        if self._hyper_events[k] is not None:
+            self._hyper_events[k].synchronize()          # the copy that read this slot HYPER_SLOTS steps ago has run
+        slot = self._hyper_host[k]
+        slot[0] = g["lr"]
+        slot[1] = 1.0 - b1 ** self.graph_steps
+        slot[2] = (1.0 - b2 ** self.graph_steps) ** 0.5
+        self.hyper.copy_(slot, non_blocking=True)
+        ev = self._hyper_events[k] or torch.cuda.Event()
+        ev.record()
+        self._hyper_events[k] = ev
 
     def state_dict(self):
         """torch.optim state_dict (one flat parameter: exp_avg / exp_avg_sq are the flat Adam moments) + the replay step

@@ -390,13 +390,59 @@ def gt_core_batch(K, j3d, j2d, c3d, c2d, corners_can, obj_transf, center, scale,
 
 # --------------------------------------------------------------------------- the loader
 class ArtiBoostLoader:
-    """Synthetic half of the reference's ArtiBoostLoader (artiboost_loader.py:49-340): same public surface
-    (prepare / __iter__ / __len__ / step_eval / sample_weight_map / occurence_map / use_synth / update_method_*),
-    batches produced by the on-GPU renderer.  `real_train_set` mixing (MixedDataset) is out of scope here: the real
-    datasets are downloads."""
+    """The reference's ArtiBoostLoader (artiboost_loader.py:49-340) on the on-GPU renderer: same constructor keywords, same
+    public surface (prepare / __iter__ / __len__ / step_eval / sample_weight_map / occurence_map / use_synth /
+    update_method_*).  The OVG DataLoader, the pose cache on /dev/shm, the render-server processes and the DataLoader workers
+    behind the reference's constructor do not exist here (one in-process batched render per step), so `shuffle`,
+    `num_workers`, `pin_memory`, `collate_fn`, `time_f` and the `arg_extra` fields are accepted and unused."""
 
-    def __init__(self, assets, cfg, cfg_preset, batch_size, synth_len, device="cuda", compute_dtype=torch.bfloat16,
-                 random_seed=1, rank=0, world_size=1, grasps=None):
+    def __init__(self, real_train_set=None, arg=None, arg_extra=None, cfg=None, cfg_dataset=None, cfg_preset=None, time_f=None,
+                 batch_size=1, shuffle=False, num_workers=0, pin_memory=False, drop_last=False, collate_fn=None, random_seed=1,
+                 **kwargs):
+        """Reference call site: train/train_artiboost.py:175-190.  cfg = cfg["MANAGER"], cfg_dataset = cfg["DATASET"],
+        cfg_preset = cfg["DATA_PRESET"]; arg.device / arg.batch_size as parsed by anakin/opt.py.
+
+        real_train_set: the real training set.  synth_len = int(SYNTH_FACTOR * len(real_train_set)) as in the reference; an
+        empty / None set (HO3D and DexYCB are downloads) gives a synthetic-only epoch of cfg["SYNTH_LEN"] samples.
+        Iteration over this object yields the synthetic batches; the frames of a non-empty real set (a
+        `realdata.HOdataSource`) are mixed in by `realdata.MixedLoader(RealBatcher(real_train_set, ...), self_with_the_synthetic
+        share of the batch, batch_size)` -- the MixedDataset of the reference with a static per-batch split.
+        Extensions (keyword only): assets (SceneAssets; default: seeded stand-ins for cfg OBJ_ENGINE.OBJ_ORIGIN_DATASET),
+        synth_len, device, compute_dtype (torch.float32: what the bf16x3 / f32 model consumes), rank, world_size, grasps."""
+        if cfg is None or cfg_preset is None:
+            raise TypeError("ArtiBoostLoader needs cfg (the MANAGER block) and cfg_preset (the DATA_PRESET block)")
+        from .assets import SceneAssets
+        assets = kwargs.pop("assets", None)
+        if assets is None:
+            assets = SceneAssets(cfg.get("OBJ_ENGINE", {}).get("OBJ_ORIGIN_DATASET", "HO3D"), seed=1)
+        real_len = len(real_train_set) if real_train_set is not None else 0
+        synth_len = kwargs.pop("synth_len", None)
+        if synth_len is None:
+            synth_len = int(cfg.get("SYNTH_FACTOR", 0.0) * real_len) if real_len else int(cfg.get("SYNTH_LEN", 0))
+        device = kwargs.pop("device", None) or (getattr(arg, "device", None) if arg is not None else None) or "cuda"
+        if batch_size in (None, 1) and arg is not None and getattr(arg, "batch_size", None):
+            batch_size = arg.batch_size
+        self.real_train_set, self.real_len = real_train_set, real_len
+        self.shuffle, self.num_workers, self.pin_memory, self.drop_last, self.collat_fn = shuffle, num_workers, pin_memory, drop_last, collate_fn
+        self.cfg_dataset = cfg_dataset
+        self._setup(assets, cfg, cfg_preset, int(batch_size), synth_len, device=device,
+                    compute_dtype=kwargs.pop("compute_dtype", torch.float32), random_seed=random_seed,
+                    rank=kwargs.pop("rank", 0), world_size=kwargs.pop("world_size", 1), grasps=kwargs.pop("grasps", None))
+        self.epoch_len_total = self.real_len + self.synth_len        # the reference's epoch_len (real + synthetic samples)
+
+    @classmethod
+    def from_assets(cls, assets, cfg, cfg_preset, batch_size, synth_len, device="cuda", compute_dtype=torch.bfloat16,
+                    random_seed=1, rank=0, world_size=1, grasps=None):
+        """Direct construction from scene assets and an explicit epoch length (tests, bench.py)."""
+        self = cls.__new__(cls)
+        self.real_train_set, self.real_len, self.cfg_dataset = None, 0, None
+        self._setup(assets, cfg, cfg_preset, batch_size, synth_len, device=device, compute_dtype=compute_dtype,
+                    random_seed=random_seed, rank=rank, world_size=world_size, grasps=grasps)
+        self.epoch_len_total = self.synth_len
+        return self
+
+    def _setup(self, assets, cfg, cfg_preset, batch_size, synth_len, device="cuda", compute_dtype=torch.bfloat16,
+               random_seed=1, rank=0, world_size=1, grasps=None):
         self.assets, self.cfg, self.preset = assets, cfg, cfg_preset
         self.dev = torch.device(device)
         self.batch_size, self.synth_len = batch_size, int(synth_len)
@@ -499,9 +545,14 @@ class ArtiBoostLoader:
         slice idx[rank::world] (SURVEY.md section 8e): all ranks consume identical RNG streams, so the union over ranks
         is exactly the single-process epoch and the slices are disjoint."""
         o, v, g = self._sample_ccv(is_train)
-        sl = slice(self.rank, None, self.world)
         rng = self.rng
         S_all = self.synth_len
+        # every rank must run the same number of steps (a rank with one batch more would wait forever in the gradient
+        # all-reduce): under DDP the epoch is cut to a multiple of world * batch_size before slicing (drop_last)
+        S_use = S_all if self.world == 1 else (S_all // (self.world * self.batch_size)) * self.world * self.batch_size
+        if S_use == 0:
+            raise ValueError(f"synth_len {S_all} < world_size * batch_size = {self.world * self.batch_size}: no rank would get a batch")
+        sl = slice(self.rank, S_use, self.world)
         plan = dict(u_off=rng.uniform(-0.5, 0.5, S_all), th_off=rng.uniform(-0.5, 0.5, S_all),
                     free=rng.uniform(0, 2 * np.pi, S_all), zoff=rng.uniform(self.z_range[0], self.z_range[1], S_all),
                     d_pose=self.pose_generator.pose_sigma * rng.standard_normal((S_all, 16)),

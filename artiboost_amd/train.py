@@ -183,6 +183,8 @@ class TrainStep:
                     graph_steps=self.opt.graph_steps, rng=(random.getstate(), np.random.get_state(), torch.get_rng_state()), opt={})
         for p, st in self.opt.state.items():
             snap["opt"][p] = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+        if self.pipeline:       # the pipelined warm-up ends by handing the NEXT batch's image to the learn buffer: undo that too
+            snap["image"] = self.static["image_nhwc4_padded"].clone()
         return snap
 
     def _restore(self, snap):
@@ -192,6 +194,8 @@ class TrainStep:
         with torch.no_grad():
             store.flat.copy_(snap["flat"])
             store.stats.copy_(snap["stats"])
+            if "image" in snap:
+                self.static["image_nhwc4_padded"].copy_(snap["image"])
         store.num_batches_tracked = snap["nbt"]
         for p, st in self.opt.state.items():
             old = snap["opt"].get(p)

@@ -57,7 +57,7 @@ def build_everything(args, rank, world, device):
     assets = SceneAssets(args.dataset, seed=1)
     mgr = dict(cfg["MANAGER"], EPOCH=cfg["TRAIN"]["EPOCH"])
     synth_len = args.bs * world * max(args.steps + args.warmup + 2, 4)
-    loader = ArtiBoostLoader(assets, mgr, cfg["DATA_PRESET"], args.bs, synth_len, device=device,
+    loader = ArtiBoostLoader.from_assets(assets, mgr, cfg["DATA_PRESET"], args.bs, synth_len, device=device,
                              compute_dtype=hb.net.dtype, random_seed=cfg["TRAIN"]["MANUAL_SEED"], rank=rank, world_size=world)
     loader.prepare()
     static = loader.new_static_batch()

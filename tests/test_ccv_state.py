@@ -22,7 +22,7 @@ def _host_loader(cfg=None, **kw):
     from artiboost_amd.assets import SceneAssets
     from artiboost_amd.synth import ArtiBoostLoader
     cfg = cfg or _cfg()
-    return ArtiBoostLoader(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], 4, 16, device="cpu", random_seed=3, **kw)
+    return ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], 4, 16, device="cpu", random_seed=3, **kw)
 
 
 def test_blacklist_matches_reference_golden():

@@ -1,0 +1,109 @@
+"""The reference's training loop, constructed ONLY through the reference's import paths and keyword signatures
+(train/train_artiboost.py:9-22 imports, :108-190 construction, :46-105 epoch_pass, :205-237 epoch loop), running on the
+HIP path: `for batch in artiboost_loader` -> arch_model(batch) -> compute_losses -> feed_all -> zero_grad -> backward ->
+clip_grad_norm_ -> optimizer.step, two epochs with step_eval, then checkpoint + resume through the Recorder."""
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_reference_epoch_pass_sequence_two_epochs(tmp_path, monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["train_artiboost.py", "--cfg", os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml"),
+                                      "--batch_size", "8", "--gpu_render_id", "0", "--exp_id", "default"])
+    for m in [k for k in sys.modules if k == "anakin.opt" or k == "anakin.opt_extra"]:
+        del sys.modules[m]
+    from anakin.artiboost import ArtiBoostLoader
+    from anakin.criterions.criterion import Criterion
+    from anakin.datasets.hodata import ho_collate
+    from anakin.metrics.evaluator import Evaluator
+    from anakin.models.arch import Arch
+    from anakin.opt import arg, cfg
+    from anakin.opt_extra import data_generation_manager_parse
+    from anakin.utils import builder
+    from anakin.utils.misc import TrainMode
+    from anakin.utils.netutils import build_optimizer, build_scheduler
+    from anakin.utils.recorder import Recorder
+    from anakin.utils.summarizer import Summarizer
+
+    time_f = time.time()
+    cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [64, 64], [8, 8]      # small geometry: a test, not a benchmark
+    cfg["MANAGER"]["SYNTH_LEN"] = 32
+    cfg["TRAIN"]["EPOCH"] = 2
+    recorder = Recorder(arg.exp_id, cfg, root_path=str(tmp_path / "exp"), time_f=time_f)
+    summarizer = Summarizer(arg.exp_id, cfg, tensorboard_path=str(tmp_path / "runs"), time_f=time_f)
+    # ---- model / optimizer / scheduler (train_artiboost.py:127-137)
+    model_list = builder.build_arch_model_list(cfg["ARCH"], preset_cfg=cfg["DATA_PRESET"])
+    model = Arch(cfg, model_list=model_list)
+    recorder.record_arch_graph(model)
+    model = model.to(arg.device)
+    optimizer = build_optimizer(model.models_params, **cfg["TRAIN"])
+    scheduler = build_scheduler(optimizer, **cfg["TRAIN"])
+    grad_clip = cfg["TRAIN"].get("GRAD_CLIP")
+    # ---- criterion / evaluator (:148-160)
+    criterion = Criterion(cfg, loss_list=builder.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+    evaluator = Evaluator(cfg, metrics_list=builder.build_evaluator_metric_list(cfg["EVALUATOR"], preset_cfg=cfg["DATA_PRESET"]))
+    # ---- artiboost (:163-190)
+    cfg["MANAGER"].update({"VAL_FREQ": cfg["TRAIN"]["EVAL_FREQ"], "VAL_START_EPOCH": cfg["TRAIN"]["VAL_START_EPOCH"], "EPOCH": cfg["TRAIN"]["EPOCH"]})
+    train_data = builder.build_dataset(cfg["DATASET"]["TRAIN"], preset_cfg=cfg["DATA_PRESET"])
+    assert len(train_data) == 0            # ./data is a download: the real share of the mix is empty here
+    arg_extra = data_generation_manager_parse()
+    artiboost_loader = ArtiBoostLoader(train_data, arg=arg, arg_extra=arg_extra, cfg=cfg["MANAGER"], cfg_dataset=cfg["DATASET"],
+                                       cfg_preset=cfg["DATA_PRESET"], time_f=time_f, batch_size=arg.batch_size, shuffle=True,
+                                       num_workers=int(arg.workers), pin_memory=True, drop_last=arg.drop_last, collate_fn=ho_collate,
+                                       random_seed=cfg["TRAIN"]["MANUAL_SEED"])
+    w0 = artiboost_loader.sample_weight_map.clone()
+    first_losses = []
+    for epoch_idx in range(cfg["TRAIN"]["EPOCH"]):
+        artiboost_loader.prepare()
+        model.train()
+        evaluator.reset_all()
+        nb = 0
+        for batch_idx, batch in enumerate(artiboost_loader):
+            predict_arch_dict = model(batch)
+            predicts = {}
+            for key in predict_arch_dict.keys():
+                predicts.update(predict_arch_dict[key])
+            final_loss, losses = criterion.compute_losses(predicts, batch)
+            evaluator.feed_all(predicts, batch, losses)
+            summarizer.summarize_losses(losses)
+            optimizer.zero_grad()
+            final_loss.backward()
+            if grad_clip is not None:
+                total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
+                assert torch.isfinite(total_norm)
+            optimizer.step()
+            optimizer.zero_grad()
+            first_losses.append(float(final_loss))
+            nb += 1
+        assert nb == len(artiboost_loader) == 4
+        scheduler.step()
+        artiboost_loader.step_eval(epoch_idx=epoch_idx, evaluator=evaluator)
+        recorder.record_checkpoints(model, optimizer, scheduler, epoch_idx, arg.snapshot)
+        recorder.record_evaluator(evaluator, epoch_idx, TrainMode.TRAIN)
+        summarizer.summarize_evaluator(evaluator, epoch_idx, train_mode=TrainMode.TRAIN)
+        recorder.record_artiboost_loader(artiboost_loader, epoch_idx)
+    assert all(np.isfinite(first_losses)) and len(first_losses) == 8
+    assert not torch.equal(artiboost_loader.sample_weight_map, w0)          # mining re-weighted the visited CCV cells
+    assert type(optimizer).__name__ == "FusedClipAdam" and optimizer.max_norm is None
+    # ---- resume (train_artiboost.py:143-146,192-194) into fresh objects: identical weights, optimizer step, mining state
+    model2 = Arch(cfg, model_list=builder.build_arch_model_list(cfg["ARCH"], preset_cfg=cfg["DATA_PRESET"])).to(arg.device)
+    optimizer2 = build_optimizer(model2.models_params, **cfg["TRAIN"])
+    scheduler2 = build_scheduler(optimizer2, **cfg["TRAIN"])
+    epoch = recorder.resume_checkpoints(model2, optimizer2, scheduler2, recorder.dump_path)
+    assert epoch == 2
+    sd1, sd2 = model.model_list[0].state_dict(), model2.model_list[0].state_dict()
+    assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
+    loader2 = ArtiBoostLoader(train_data, arg=arg, arg_extra=arg_extra, cfg=cfg["MANAGER"], cfg_dataset=cfg["DATASET"],
+                              cfg_preset=cfg["DATA_PRESET"], time_f=time_f, batch_size=arg.batch_size, random_seed=cfg["TRAIN"]["MANUAL_SEED"])
+    recorder.resume_artiboost_loader(loader2, epoch, recorder.dump_path)
+    assert torch.equal(loader2.sample_weight_map, artiboost_loader.sample_weight_map)
+    assert torch.equal(loader2.occurence_map, artiboost_loader.occurence_map)
+    assert os.path.exists(os.path.join(recorder.dump_path, "checkpoints", "checkpoint", "random_state.pkl"))

@@ -59,7 +59,7 @@ def _loader(dtype=torch.float32, bs=4, n=8, size=224):
     cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
     cfg["DATA_PRESET"]["IMAGE_SIZE"] = [size, size]
     assets = SceneAssets("HO3D", seed=1)
-    return assets, ArtiBoostLoader(assets, cfg["MANAGER"], cfg["DATA_PRESET"], bs, n, compute_dtype=dtype, random_seed=3)
+    return assets, ArtiBoostLoader.from_assets(assets, cfg["MANAGER"], cfg["DATA_PRESET"], bs, n, compute_dtype=dtype, random_seed=3)
 
 
 def test_loader_batches_match_oracle_render():

@@ -160,10 +160,10 @@ def _worker(rank, world, port, q):
     assets = SceneAssets.__new__(SceneAssets)      # planning needs only a few fields; skip mesh generation
     assets.n_obj, assets.hand_tex, assets.backgrounds = 4, np.zeros((51, 1, 1, 3), np.uint8), np.zeros((16, 768, 1, 3), np.uint8)
     assets.hand = None
-    ld = ArtiBoostLoader(assets, cfg["MANAGER"], cfg["DATA_PRESET"], 4, 40, device="cpu", random_seed=7, rank=rank, world_size=world,
+    ld = ArtiBoostLoader.from_assets(assets, cfg["MANAGER"], cfg["DATA_PRESET"], 4, 40, device="cpu", random_seed=7, rank=rank, world_size=world,
                          grasps=(None, None, None))
     plan = ld.plan_epoch()
-    ld1 = ArtiBoostLoader(assets, cfg["MANAGER"], cfg["DATA_PRESET"], 4, 40, device="cpu", random_seed=7, rank=0, world_size=1,
+    ld1 = ArtiBoostLoader.from_assets(assets, cfg["MANAGER"], cfg["DATA_PRESET"], 4, 40, device="cpu", random_seed=7, rank=0, world_size=1,
                           grasps=(None, None, None))
     full = ld1.plan_epoch()
     idx = plan["global_index"]
@@ -244,3 +244,53 @@ def test_bench_gpus_flag_launches_the_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert lines == [{"dry_launch": True, "n_gpus": 2, "gpus_arg": 2}]
+
+
+def test_dropin_surface_matches_reference_signatures():
+    """The constructor keywords of train/train_artiboost.py:175-190 and the import paths of :9-22 exist (the alias package
+    `anakin` resolves them to artiboost_amd)."""
+    import inspect
+    import sys
+    from unittest import mock
+    with mock.patch.object(sys, "argv", ["x"]):
+        for m in [k for k in sys.modules if k in ("anakin.opt", "anakin.opt_extra")]:
+            del sys.modules[m]
+        from anakin.artiboost import ArtiBoostLoader
+        from anakin.criterions.criterion import Criterion  # noqa: F401
+        from anakin.datasets.hodata import ho_collate
+        from anakin.metrics.evaluator import Evaluator  # noqa: F401
+        from anakin.models.arch import Arch  # noqa: F401
+        from anakin.opt import arg, cfg  # noqa: F401
+        from anakin.opt_extra import data_generation_manager_parse
+        from anakin.utils import builder
+        from anakin.utils.etqdm import etqdm  # noqa: F401
+        from anakin.utils.logger import logger  # noqa: F401
+        from anakin.utils.misc import CONST, TrainMode  # noqa: F401
+        from anakin.utils.netutils import build_optimizer, build_scheduler
+        from anakin.utils.recorder import Recorder  # noqa: F401
+        from anakin.utils.summarizer import Summarizer  # noqa: F401
+        assert data_generation_manager_parse().ovg_batch_size == 256
+    names = list(inspect.signature(ArtiBoostLoader.__init__).parameters)[1:15]
+    assert names == ["real_train_set", "arg", "arg_extra", "cfg", "cfg_dataset", "cfg_preset", "time_f", "batch_size", "shuffle",
+                     "num_workers", "pin_memory", "drop_last", "collate_fn", "random_seed"]
+    # datasets: the reference YAML's TRAIN entry builds (empty: ./data is a download)
+    ds = builder.build_dataset({"TYPE": "HO3D", "DATA_SPLIT": "train", "DATA_ROOT": "/nonexistent", "AUG": True}, preset_cfg={})
+    assert len(ds) == 0
+    b = ho_collate([{"a": np.zeros((2, 3), np.float32), "i": 1}, {"a": np.ones((2, 3), np.float32), "i": 2}])
+    assert b["a"].shape == (2, 2, 3) and b["i"].tolist() == [1, 2]
+    # optimizer / scheduler builders with **cfg["TRAIN"]
+    p = torch.nn.Parameter(torch.zeros(4))
+    tr = dict(OPTIMIZER="adam", LR=5e-5, WEIGHT_DECAY=0, LR_DECAY_STEP=100, LR_DECAY_GAMMA=1.0, BATCH_SIZE=128)
+    opt = build_optimizer([{"params": [p]}], **tr)
+    assert isinstance(opt, torch.optim.Adam) and opt.param_groups[0]["lr"] == 5e-5
+    assert isinstance(build_scheduler(opt, **tr), torch.optim.lr_scheduler.StepLR)
+    assert isinstance(build_optimizer([{"params": [p]}], **dict(tr, OPTIMIZER="sgd", MOMENTUM=0.9)), torch.optim.SGD)
+    # a host-only loader through the reference keywords (no GPU): epoch length from SYNTH_LEN, mining maps in place
+    mcfg = yaml.safe_load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config",
+                                            "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    class A:  # noqa: E701
+        device, batch_size, workers = "cpu", 4, 0
+    ld = ArtiBoostLoader(ds, arg=A(), arg_extra=None, cfg=dict(mcfg["MANAGER"], SYNTH_LEN=40, EPOCH=2), cfg_dataset=mcfg["DATASET"],
+                         cfg_preset=mcfg["DATA_PRESET"], time_f=0.0, batch_size=4, shuffle=True, num_workers=0, pin_memory=True,
+                         drop_last=True, collate_fn=ho_collate, random_seed=1)
+    assert ld.synth_len == 40 and ld.use_synth and ld.sample_weight_map.shape == (4, 288, 50) and ld.batch_size == 4

@@ -127,7 +127,7 @@ def test_mixed_loader_batches():
     assets, proto = _loader(size=64)
     B = 8
     n_synth = MixedLoader.n_synth_for(B, len(src), proto.synth_len)
-    synth = ArtiBoostLoader(assets, proto.cfg, proto.preset, n_synth, proto.synth_len, compute_dtype=torch.float32, random_seed=3)
+    synth = ArtiBoostLoader.from_assets(assets, proto.cfg, proto.preset, n_synth, proto.synth_len, compute_dtype=torch.float32, random_seed=3)
     synth.prepare()
     real = RealBatcher(src, proto.preset, compute_dtype=torch.float32)
     ml = MixedLoader(real, synth, B)
@@ -180,7 +180,7 @@ def test_graph_replayed_training_step_over_mixed_batches():
         cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
         cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [size, size], [size // 8, size // 8]
         n_synth = MixedLoader.n_synth_for(B, len(src), proto.synth_len)
-        synth = ArtiBoostLoader(assets, proto.cfg, cfg["DATA_PRESET"], n_synth, proto.synth_len, compute_dtype=torch.bfloat16, random_seed=3)
+        synth = ArtiBoostLoader.from_assets(assets, proto.cfg, cfg["DATA_PRESET"], n_synth, proto.synth_len, compute_dtype=torch.bfloat16, random_seed=3)
         synth.prepare()
         ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.bfloat16, seed=2), synth, B, seed=4)
         arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16", INIT_SEED=3)

@@ -127,7 +127,7 @@ def test_loader_epoch_with_refiner():
     assets, plain = _loader()
     cfg = copy.deepcopy(plain.cfg)
     cfg["REFINER"] = {"TYPE": "hand_obj", "PRETRAINED": "", "ITERS": 3, "ALLOW_RANDOM_INIT": True}
-    refined = ArtiBoostLoader(assets, cfg, plain.preset, plain.batch_size, plain.synth_len, compute_dtype=plain.dtype, random_seed=3)
+    refined = ArtiBoostLoader.from_assets(assets, cfg, plain.preset, plain.batch_size, plain.synth_len, compute_dtype=plain.dtype, random_seed=3)
     refined.refiner.load_state_dict(rfo.fill_params(4))
     plain.prepare(); refined.prepare()
     a, b = plain.epoch["_hand_verts"], refined.epoch["_hand_verts"]

@@ -55,7 +55,7 @@ def main():
     B = 64
     synth_len = int(0.6 * len(src))
     n_synth = MixedLoader.n_synth_for(B, len(src), synth_len)
-    synth = ArtiBoostLoader(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], n_synth, synth_len, compute_dtype=torch.bfloat16)
+    synth = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], n_synth, synth_len, compute_dtype=torch.bfloat16)
     synth.prepare()
     real = RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.bfloat16)
     ml = MixedLoader(real, synth, B)

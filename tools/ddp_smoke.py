@@ -28,7 +28,7 @@ crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=c
 hb = model.model_list[0]
 opt = FusedClipAdam(model.models_params, lr=1e-3, max_norm=1.0, model=hb)
 assets = SceneAssets("HO3D", seed=1)
-loader = ArtiBoostLoader(assets, dict(cfg["MANAGER"], EPOCH=1), cfg["DATA_PRESET"], 8, 8 * world * 6, device=dev,
+loader = ArtiBoostLoader.from_assets(assets, dict(cfg["MANAGER"], EPOCH=1), cfg["DATA_PRESET"], 8, 8 * world * 6, device=dev,
                          compute_dtype=torch.bfloat16, random_seed=1, rank=rank, world_size=world)
 loader.prepare()
 static = loader.new_static_batch()

@@ -9,7 +9,7 @@ cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboo
 cfg["DATA_PRESET"]["IMAGE_SIZE"] = [256, 256]; cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [32, 32]
 assets = SceneAssets("HO3D", seed=1)
 mgr = dict(cfg["MANAGER"], EPOCH=1)
-loader = ArtiBoostLoader(assets, mgr, cfg["DATA_PRESET"], 64, 256, device="cuda", compute_dtype=torch.bfloat16, random_seed=1)
+loader = ArtiBoostLoader.from_assets(assets, mgr, cfg["DATA_PRESET"], 64, 256, device="cuda", compute_dtype=torch.bfloat16, random_seed=1)
 loader.prepare()
 st = loader.new_static_batch()
 for i in range(4):

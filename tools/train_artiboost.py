@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--dataset", default="", help="asset set: HO3D (4 objects) or DexYCB (21); default: from the config's OBJ_ORIGIN_DATASET")
     ap.add_argument("--dump", default="")
     ap.add_argument("--resume-epoch", type=int, default=0)
+    ap.add_argument("--dtype", default="bf16x3", choices=["bf16x3", "f32", "bf16"], help="bf16x3 = the reference's fp32-grade precision")
     ap.add_argument("--per-step-eval", action="store_true", help="feed the evaluator after every batch as the reference does "
                     "(a host synchronisation per step) instead of once per epoch from device-side records")
     args = ap.parse_args()
@@ -52,14 +53,14 @@ def main():
     cfg = yaml.safe_load(open(args.cfg))
     cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [args.size, args.size], [args.size // 8, args.size // 8]
     cfg["ARCH"]["BACKBONE"]["PRETRAINED"] = False
-    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16", DEVICE=dev, INIT_SEED=cfg["TRAIN"]["MANUAL_SEED"])
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE=args.dtype, DEVICE=dev, INIT_SEED=cfg["TRAIN"]["MANUAL_SEED"])
     model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
     crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
     evaluator = Evaluator(cfg, R.build_evaluator_metric_list(cfg["EVALUATOR"], preset_cfg=cfg["DATA_PRESET"]))
     hb = model.model_list[0]
     opt = FusedClipAdam(model.models_params, lr=cfg["TRAIN"]["LR"], max_norm=cfg["TRAIN"]["GRAD_CLIP"], model=hb)
     dataset = args.dataset or cfg["MANAGER"].get("OBJ_ENGINE", {}).get("OBJ_ORIGIN_DATASET", "HO3D")
-    loader = ArtiBoostLoader(SceneAssets(dataset, seed=1), dict(cfg["MANAGER"], EPOCH=args.epochs), cfg["DATA_PRESET"], args.bs,
+    loader = ArtiBoostLoader.from_assets(SceneAssets(dataset, seed=1), dict(cfg["MANAGER"], EPOCH=args.epochs), cfg["DATA_PRESET"], args.bs,
                              args.synth_len, device=dev, compute_dtype=hb.net.dtype, random_seed=cfg["TRAIN"]["MANUAL_SEED"],
                              rank=rank, world_size=world)
     ckpt = os.path.join(args.dump, "checkpoints", "checkpoint") if args.dump else ""
@@ -67,6 +68,16 @@ def main():
         hb.load_state_dict(torch.load(os.path.join(ckpt, "HybridBaseline.pth.tar"), map_location=dev))
         opt.load_state_dict(torch.load(os.path.join(ckpt, "train_param.pth.tar"), map_location=dev)["optimizer"])
         ccv_cache.resume_artiboost_loader(loader, args.resume_epoch, args.dump)
+        rng_file = os.path.join(ckpt, "loader_rng.pkl")      # the loader's generator states + the host RNG streams of the loss draws
+        if os.path.exists(rng_file):
+            import pickle
+            import random
+            import numpy as np
+            with open(rng_file, "rb") as f:
+                st = pickle.load(f)
+            loader.rng.bit_generator.state = st["numpy"]
+            loader.torch_gen.set_state(st["torch"])
+            random.setstate(st["py"]); np.random.set_state(st["np_global"]); torch.set_rng_state(st["torch_global"])
     model.train()
     ts = rec = None
     for epoch in range(args.resume_epoch, args.epochs):
@@ -99,7 +110,13 @@ def main():
                 ccv_cache.record_artiboost_loader(loader, epoch, args.dump)
                 os.makedirs(ckpt, exist_ok=True)
                 torch.save(hb.state_dict(), os.path.join(ckpt, "HybridBaseline.pth.tar"))          # the reference's keys and layouts
-                torch.save({"epoch": epoch + 1, "optimizer": opt.state_dict()}, os.path.join(ckpt, "train_param.pth.tar"))
+                torch.save({"epoch": epoch + 1, "optimizer": opt.state_dict(), "scheduler": {}}, os.path.join(ckpt, "train_param.pth.tar"))
+                import pickle
+                import random
+                import numpy as np
+                with open(os.path.join(ckpt, "loader_rng.pkl"), "wb") as f:      # without these a resumed run replays epoch 0's draws
+                    pickle.dump({"numpy": loader.rng.bit_generator.state, "torch": loader.torch_gen.get_state(), "py": random.getstate(),
+                                 "np_global": np.random.get_state(), "torch_global": torch.get_rng_state()}, f)
     if world > 1:
         torch.distributed.destroy_process_group()
 
