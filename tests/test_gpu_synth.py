@@ -1,5 +1,7 @@
 """GPU parity of the synthesis control/data plane: MANO LBS kernel and pose generator vs the numpy oracle, and the
 loader's rendered batches vs the CPU oracle renderer on the loader's own epoch records."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -25,6 +27,20 @@ def test_mano_lbs_vs_oracle():
     np.testing.assert_allclose(v.cpu().numpy(), v_ref, rtol=0, atol=2e-6)
     np.testing.assert_allclose(j.cpu().numpy(), j_ref, rtol=0, atol=2e-6)
     np.testing.assert_allclose(T.cpu().numpy(), T_ref, rtol=0, atol=2e-6)
+
+
+def test_mano_lbs_vs_reference_golden(golden_dir):
+    """R1 against the reference's own in-tree MANO forward (tests/golden/mano.npz, oracle/gen_mano_golden.py): fp32 kernel,
+    wrist-relative as that layer returns them."""
+    from artiboost_amd.assets import make_hand_model
+    from artiboost_amd.synth import ManoLayerHIP
+    g = np.load(os.path.join(golden_dir, "mano.npz"))
+    hm = make_hand_model(int(g["hand_model_seed"]))
+    layer = ManoLayerHIP(hm)
+    v, j, T = layer(torch.from_numpy(g["pose"].astype(np.float32)).cuda(), torch.from_numpy(g["betas"].astype(np.float32)).cuda())
+    v, j = v.cpu().numpy().astype(np.float64), j.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(v - j[:, :1], g["verts_rel_wrist"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(j - j[:, :1], g["joints_rel_wrist"], rtol=0, atol=3e-6)
 
 
 def test_pose_generator_vs_oracle():
