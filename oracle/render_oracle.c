@@ -15,9 +15,10 @@
  *     global face id; key = depth << 32 | face id
  *   - object faces are back-face culled with the camera-space geometric normal; the hand is double sided; triangles
  *     with a vertex at Z <= near are dropped
- *   - shading: nearest texel, sRGB->linear by LUT, lin = base * (0.8 + KD * I * max(n.l,0) / d^2) (ambient 0.8 and one
- *     point light at the camera as in renderer.py:72-84,103-104; rest-pose ("stale") hand normals as in
- *     anakin/utils/frender_utils.py:36-46,139), linear->sRGB by 4096-entry LUT
+ *   - shading: nearest texel, sRGB->linear by LUT, then pyrender's published fragment shader (mesh.frag: glTF
+ *     metallic-roughness BRDF, see ro_shade) with ambient 0.8 and one point light at the camera as in
+ *     renderer.py:72-84,103-104; rest-pose ("stale") hand normals as in anakin/utils/frender_utils.py:36-46,139;
+ *     linear->sRGB by 4096-entry LUT.  No MSAA resolve (pyrender renders 4x multisampled: edge pixels differ)
  *   - background where no geometry (renderer.py:117-119,125-136): the random crop resized with cv2's INTER_LINEAR
  *     fixed-point arithmetic (restated at bg_pixel; cv2 is absent, so unpinned as well)
  * The GaussianBlur + colour jitter + crop stage restates PIL (anakin/utils/img_augment.py:6-80,
@@ -31,7 +32,15 @@
 #define NEAR_INV 20.0f      /* 1 / 0.05 */
 #define FAR_INV 0.01f       /* 1 / 100  */
 #define ZMAX 16777215.0f
-#define KD 0.0716f
+/* pyrender's mesh.frag: glTF metallic-roughness BRDF.  Material factors: the only ones the reference states
+ * (frender_utils.py:153-157: metallicFactor 0.2, roughnessFactor 0.8); light colour 0.9 (artiboost_loader.py:194);
+ * ambient 0.8 (renderer.py:76).  The point light sits at the camera, so l = v = h and the Fresnel term is its r0. */
+#define PBR_METALLIC 0.2f
+#define PBR_ROUGHNESS 0.8f
+#define PBR_F0 0.04f
+#define PBR_LIGHT_COLOR 0.9f
+#define PBR_AMBIENT 0.8f
+#define PBR_INV_PI 0.31830987f
 #define HAND_FACES 1538
 #define HAND_VERTS 778
 
@@ -262,13 +271,29 @@ void ro_shade(const ro_scene* sc, const ro_sample* sm, const float* hv, const ui
             float ndl = -((n[0] * p[0] + n[1] * p[1]) + n[2] * p[2]) / (nl * dl);   /* light at the camera origin */
             if (gid < HAND_FACES) ndl = fabsf(ndl);                                  /* double-sided hand */
             if (ndl < 0.f) ndl = 0.f;
-            float shade = 0.8f + (KD * sm->light) * ndl / d2;
+            /* ---- pyrender mesh.frag, one point light at the camera (l = v = h; vh = 1 -> F = r0 = specular colour):
+             *   nl = clamp(n.l, 0.001, 1), nv = clamp(|n.v|, 0.001, 1), nh = clamp(n.h, 0, 1)
+             *   G = aL * aV, a? = 2 n? / (n? + sqrt(a2 + (1 - a2) n?^2)),  D = a2 / (pi ((nh a2 - nh) nh + 1)^2),  a2 = roughness^4
+             *   colour = nl * radiance * ((1 - F) diffuse / pi + F G D / (4 nl nv)) + base * ambient,  radiance = 0.9 I / d^2
+             *   diffuse = base (1 - f0)(1 - metallic),  F = mix(f0, base, metallic)                                         */
+            const float a2 = (PBR_ROUGHNESS * PBR_ROUGHNESS) * (PBR_ROUGHNESS * PBR_ROUGHNESS);
+            float nlc = ndl < 0.001f ? 0.001f : (ndl > 1.f ? 1.f : ndl);
+            float nhc = ndl > 1.f ? 1.f : ndl;
+            float att = (2.0f * nlc) / (nlc + sqrtf(a2 + (1.0f - a2) * (nlc * nlc)));
+            float ff = (nhc * a2 - nhc) * nhc + 1.0f;
+            float Dm = a2 / (3.14159274f * (ff * ff));
+            float gd4 = ((att * att) * Dm) / ((4.0f * nlc) * nlc);
+            float rad = (PBR_LIGHT_COLOR * sm->light) / d2;
+            float nlrad = nlc * rad;
             u = u - floorf(u); v = v - floorf(v);
             int tx = (int)(u * (float)ts), ty = (int)(v * (float)ts);
             if (tx > ts - 1) tx = ts - 1; if (ty > ts - 1) ty = ts - 1;
             const uint8_t* texel = tex + ((size_t)ty * ts + tx) * 3;
             for (int c = 0; c < 3; ++c) {
-                float lin = sc->srgb2lin[texel[c]] * shade;
+                float base = sc->srgb2lin[texel[c]];
+                float F = PBR_F0 * (1.0f - PBR_METALLIC) + PBR_METALLIC * base;
+                float dif = ((1.0f - F) * (((1.0f - PBR_F0) * (1.0f - PBR_METALLIC)) * base)) * PBR_INV_PI;
+                float lin = base * PBR_AMBIENT + nlrad * (dif + F * gd4);
                 if (lin < 0.f) lin = 0.f; if (lin > 1.f) lin = 1.f;
                 o[c] = sc->lin2srgb[(int)(lin * 4095.0f + 0.5f)];
             }
