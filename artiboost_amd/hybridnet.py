@@ -385,6 +385,8 @@ class HybridNet:
         H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
         S = {"xpad": xpad, "N": N, "HW": (H, W), "blocks": []}
         if self.x3:
+            xpad = K.split(xpad)      # planes of THIS step's image (forward and weight gradient of the stem read them)
+            S["xpad"] = xpad
             y0, st = K.conv2d_stem_fwd_x3(xpad, self.w("backbone.conv1.weight"), H, W, want_stats=True)
         else:
             y0, st = K.conv2d_stem_fwd(xpad, self.w("backbone.conv1.weight"), H, W, want_stats=True)
@@ -392,8 +394,10 @@ class HybridNet:
             bnp0 = self._bn_params("backbone.bn1", st, N * (H // 2) * (W // 2))
             x, pool_idx = K.bn_relu_maxpool_fwd(y0, bnp0)      # BN + ReLU + 3x3/2 max-pool: the 128x128x64 activation is never stored
         else:
-            a0, bnp0 = self._bn("backbone.bn1", y0, st, N * (H // 2) * (W // 2))
+            a0, bnp0 = self._bn("backbone.bn1", y0, st, N * (H // 2) * (W // 2), feeds_conv=False)
             x, pool_idx = K.maxpool_fwd(a0)
+        if self.x3:
+            x._ab_split = K.split(x)      # layer1.0 reads the pooled tensor three times (conv1, residual, conv1's weight gradient)
         S.update(y0=y0, bnp0=bnp0, pool_idx=pool_idx)
         inpl = 64
         for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET34_LAYERS), start=1):

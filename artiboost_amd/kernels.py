@@ -383,7 +383,10 @@ def _planes(t):
         return t[0], t[1]
     sp = getattr(t, "_ab_split", None)
     if sp is None:
-        sp = t._ab_split = split(t)       # cached on the tensor object: its other consumers (weight gradient) reuse it
+        # NOT cached on the tensor: a persistent buffer (the static image of a replayed step) changes its contents between
+        # calls, and a cached split would silently keep serving the first image.  Producers attach `_ab_split` to the FRESH
+        # tensors they allocate; whoever feeds the same fp32 tensor to two convolutions splits it once itself.
+        sp = split(t)
     return sp[0], sp[1]
 
 

@@ -185,7 +185,7 @@ def test_pipelined_render_hands_over_next_batch(mode):
                 assert torch.equal(static[k], v), k
 
 
-def _run_steps(monkeypatch, split, nsteps=6, bs=8, size=224):
+def _run_steps(monkeypatch, split, nsteps=6, bs=8, size=224, dtype="bf16"):
     import yaml, os, random
     from artiboost_amd import registry as R
     from artiboost_amd.criterions import Criterion
@@ -194,12 +194,12 @@ def _run_steps(monkeypatch, split, nsteps=6, bs=8, size=224):
     from artiboost_amd.train import TrainStep
     monkeypatch.setenv("AB_DDP_SPLIT", "1" if split else "0")
     random.seed(7); torch.manual_seed(7); np.random.seed(7)
-    assets, loader = _loader(torch.bfloat16, bs=bs, n=4 * bs, size=size)
+    assets, loader = _loader(torch.bfloat16 if dtype == "bf16" else torch.float32, bs=bs, n=4 * bs, size=size)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
     cfg["DATA_PRESET"]["IMAGE_SIZE"] = [size, size]
     cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [size // 8, size // 8]
-    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16", INIT_SEED=3)
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE=dtype, INIT_SEED=3)
     model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
     crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
     hb = model.model_list[0]
