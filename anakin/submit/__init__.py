@@ -1,1 +1,1 @@
-from artiboost_amd.submit import HOSubmitEpochPass  # noqa: F401  (anakin/submit/hodata_submit_epoch_pass.py:58)
+from artiboost_amd.submit import HOSubmitEpochPass, SubmitEpochPass  # noqa: F401  (anakin/submit/__init__.py)

@@ -594,13 +594,27 @@ __global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __rest
     int kc = 0;
     while (kc < 4 && ord[kc] != 3) ++kc;
     unsigned long long s = 0;
-    if (kc < 4)
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-            uint32_t q = *(const uint32_t*)(rgbx + ((size_t)b * npix + i) * 4);
+    if (kc < 4) {
+        // four pixels (one 16-byte load) per lane and iteration; the tail (npix % 4) one by one
+        const uint8_t* img = rgbx + (size_t)b * npix * 4;
+        const int nq = npix >> 2;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
+            const uint4 q4 = *(const uint4*)(img + (size_t)i * 16);
+            const uint32_t qq[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint8_t px[3] = {(uint8_t)qq[j], (uint8_t)(qq[j] >> 8), (uint8_t)(qq[j] >> 16)};
+                for (int k = 0; k < kc; ++k) jitter_op(lut, ord[k], fac[k], 0, px);
+                s += (unsigned long long)luma8(px[0], px[1], px[2]);
+            }
+        }
+        for (int i = nq * 4 + blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+            uint32_t q = *(const uint32_t*)(img + (size_t)i * 4);
             uint8_t px[3] = {(uint8_t)q, (uint8_t)(q >> 8), (uint8_t)(q >> 16)};
             for (int k = 0; k < kc; ++k) jitter_op(lut, ord[k], fac[k], 0, px);
             s += (unsigned long long)luma8(px[0], px[1], px[2]);
         }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(&lsum[b], s);     // integer: order-independent, exact

@@ -159,6 +159,36 @@ __global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ 
         }
     }
     __syncthreads();
+    if (D <= 32) {
+        // 32 lanes per class: lane d merges the four wave entries of channel (c, d), then a 5-step butterfly over the depth
+        // bins (fixed order).  The former one-thread-per-class loop was 4*D dependent merges on 22 lanes while the other
+        // 234 idled -- ~2 us at the end of each of the 8 workgroup rounds of a B = 64 launch.
+        const int d = threadIdx.x & 31;
+        const float invD = 1.f / D;
+        for (int c0 = 0; c0 < C; c0 += SAM_THREADS / 32) {
+            const int c = c0 + (threadIdx.x >> 5);
+            Acc r = {-INFINITY, 0.f, 0.f, 0.f, 0.f};
+            if (c < C && d < D) {
+                const int ch = c * DP + d;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) {
+                    Acc t = {sm[wv][ch][0], sm[wv][ch][1], sm[wv][ch][2], sm[wv][ch][3], 0.f};
+                    t.sd = t.s * (d * invD);
+                    acc_merge(r, t);
+                }
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                Acc t = {__shfl_xor(r.m, o, 64), __shfl_xor(r.s, o, 64), __shfl_xor(r.su, o, 64), __shfl_xor(r.sv, o, 64), __shfl_xor(r.sd, o, 64)};
+                acc_merge(r, t);
+            }
+            if (d == 0 && c < C) {
+                float* o = part + (((size_t)b * ntile + tile) * C + c) * 8;
+                o[0] = r.m; o[1] = r.s; o[2] = r.su; o[3] = r.sv; o[4] = r.sd;
+            }
+        }
+        return;
+    }
     // one thread per class
     for (int c = threadIdx.x; c < C; c += SAM_THREADS) {
         Acc r = {-INFINITY, 0.f, 0.f, 0.f, 0.f};

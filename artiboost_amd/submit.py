@@ -66,3 +66,14 @@ class HOSubmitEpochPass:
         if self.dump and dump_path:
             self.dump_json(dump_path, res_joints, res_verts, codalab=True)
         return res_joints
+
+
+class SubmitEpochPass:
+    """anakin/submit/submit_epoch_pass.py: `SubmitEpochPass.build(arg.submit_dataset, cfg=None)` (train/submit_reload.py:38)."""
+    _types = {"hodata": HOSubmitEpochPass}
+
+    @classmethod
+    def build(cls, type, cfg=None):
+        if type not in cls._types:
+            raise NotImplementedError(f"SubmitEpochPass of type {type} is not implemented")
+        return cls._types[type](cfg)
