@@ -64,8 +64,12 @@ def build_everything(args, rank, world, device):
     loader.load_batch(static, 0)
     group = torch.distributed.group.WORLD if world > 1 else None
     model.train()
+    # N > 1: the north-star schedule -- batch t+1 is rendered on a second stream while step t's last gradient range is
+    # all-reduced and its clip + Adam runs (on one GPU that concurrency measured slower than the single queue, so it stays off)
+    overlap = args.pipeline_opt or (world > 1 and not args.no_render_overlap)
     ts = TrainStep(model, crit, opt, static, use_graph=not args.eager, dist_group=group, renderer=loader,
-                   pipeline_render=("opt" if args.pipeline_opt else args.pipeline))
+                   pipeline_render=("opt" if overlap else args.pipeline))
+    args.render_overlap = bool(overlap)
     ts.static = static
     return cfg, model, crit, opt, loader, ts, static
 
@@ -205,6 +209,9 @@ def main():
                          "kernels already fill the chip, co-scheduling the rasteriser only evicts their workgroups)")
     ap.add_argument("--pipeline-opt", action="store_true",
                     help="render batch i+1 on a side stream while step i's all-reduce and clip+Adam run")
+    ap.add_argument("--no-render-overlap", action="store_true",
+                    help="N > 1 only: keep the render of the next batch on the compute stream instead of overlapping it with the "
+                         "gradient all-reduce and the optimizer")
     ap.add_argument("--cpu-samples", type=int, default=64)
     ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--dry-launch", action="store_true",
@@ -322,7 +329,8 @@ def main():
                "config": {"workload": f"train_artiboost HO3Dv2-clasbased (HybridBaseline/ResNet-34, 22x28x{args.size // 8}x{args.size // 8} heat-map) "
                                       f"+ online CCV render 512->{args.size}, per-GPU batch {args.bs}, {args.dataset}-like objects",
                           "global_batch": args.bs * world, "image": args.size, "parallelism": f"dp{world}",
-                          "graph": not args.eager, "shared_devices": bool(shared)},
+                          "graph": not args.eager, "shared_devices": bool(shared),
+                          "render_overlap": bool(getattr(args, "render_overlap", False))},
                "final_loss": losses[5] if losses else None,
                "roofline": roof, "cpu_baseline": base}
         print(json.dumps(out), flush=True)

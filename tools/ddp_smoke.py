@@ -1,6 +1,8 @@
 """Two-rank smoke of the DDP step on whatever devices are visible (both ranks may share one GPU when the backend is gloo):
    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/ddp_smoke.py
-Checks: the split-graph + side-stream all-reduce path runs, losses are finite, and the ranks hold identical weights."""
+Checks: the split-graph + side-stream all-reduce path runs -- by default with the north-star schedule (the render of batch
+t+1 on a second stream under the last all-reduce range and the optimizer; AB_DDP_OVERLAP=0 turns it off) in the benchmarked
+precision (AB_DDP_DTYPE, default bf16x3) -- losses are finite, and the ranks hold identical weights."""
 import os, sys
 import torch
 import torch.distributed as dist
@@ -22,21 +24,25 @@ backend = "nccl" if ngpu >= world else "gloo"
 dist.init_process_group(backend)
 root = os.path.join(os.path.dirname(__file__), "..")
 cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
-arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16", DEVICE=dev, INIT_SEED=1)
+dtype = os.environ.get("AB_DDP_DTYPE", "bf16x3")
+overlap = os.environ.get("AB_DDP_OVERLAP", "1") != "0"
+arch = dict(cfg["ARCH"], COMPUTE_DTYPE=dtype, DEVICE=dev, INIT_SEED=1)
 model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
 crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
 hb = model.model_list[0]
 opt = FusedClipAdam(model.models_params, lr=1e-3, max_norm=1.0, model=hb)
 assets = SceneAssets("HO3D", seed=1)
 loader = ArtiBoostLoader.from_assets(assets, dict(cfg["MANAGER"], EPOCH=1), cfg["DATA_PRESET"], 8, 8 * world * 6, device=dev,
-                         compute_dtype=torch.bfloat16, random_seed=1, rank=rank, world_size=world)
+                         compute_dtype=hb.net.dtype, random_seed=1, rank=rank, world_size=world)
 loader.prepare()
 static = loader.new_static_batch()
 loader.load_batch(static, 0)
 model.train()
-ts = TrainStep(model, crit, opt, static, use_graph=True, dist_group=dist.group.WORLD, renderer=loader)
+ts = TrainStep(model, crit, opt, static, use_graph=True, dist_group=dist.group.WORLD, renderer=loader,
+               pipeline_render="opt" if overlap else False)
 ts.static = static
 assert ts.split, "world_size > 1 must take the split-graph path"
+ts.prime(loader, 0)
 for i in range(5):
     ts.stage(loader, i % len(loader))
     _, losses, _ = ts()
@@ -47,6 +53,6 @@ ws = [torch.empty_like(w) for _ in range(world)]
 dist.all_gather(ws, w)
 same = all(torch.equal(ws[0], x) for x in ws)
 if rank == 0:
-    print(f"backend={backend} world={world} final_loss={float(losses[5]):.5f} weights_identical_across_ranks={same}")
+    print(f"backend={backend} world={world} dtype={dtype} render_overlap={overlap} final_loss={float(losses[5]):.5f} weights_identical_across_ranks={same}")
 assert same
 dist.destroy_process_group()
