@@ -43,8 +43,8 @@ def test_reference_epoch_pass_sequence_two_epochs(tmp_path, monkeypatch):
     model_list = builder.build_arch_model_list(cfg["ARCH"], preset_cfg=cfg["DATA_PRESET"])
     model = Arch(cfg, model_list=model_list)
     recorder.record_arch_graph(model)
-    model = model.to(arg.device)
-    optimizer = build_optimizer(model.models_params, **cfg["TRAIN"])
+    model = torch.nn.DataParallel(model).to(arg.device)                       # train_artiboost.py:131, as written there
+    optimizer = build_optimizer(model.module.models_params if hasattr(model, "module") else model.models_params, **cfg["TRAIN"])
     scheduler = build_scheduler(optimizer, **cfg["TRAIN"])
     grad_clip = cfg["TRAIN"].get("GRAD_CLIP")
     # ---- criterion / evaluator (:148-160)
@@ -99,7 +99,7 @@ def test_reference_epoch_pass_sequence_two_epochs(tmp_path, monkeypatch):
     scheduler2 = build_scheduler(optimizer2, **cfg["TRAIN"])
     epoch = recorder.resume_checkpoints(model2, optimizer2, scheduler2, recorder.dump_path)
     assert epoch == 2
-    sd1, sd2 = model.model_list[0].state_dict(), model2.model_list[0].state_dict()
+    sd1, sd2 = model.module.model_list[0].state_dict(), model2.model_list[0].state_dict()
     assert all(torch.equal(sd1[k], sd2[k]) for k in sd1)
     loader2 = ArtiBoostLoader(train_data, arg=arg, arg_extra=arg_extra, cfg=cfg["MANAGER"], cfg_dataset=cfg["DATASET"],
                               cfg_preset=cfg["DATA_PRESET"], time_f=time_f, batch_size=arg.batch_size, random_seed=cfg["TRAIN"]["MANUAL_SEED"])
