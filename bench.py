@@ -310,7 +310,8 @@ def main():
             ach = flops / (conv_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4), "traffic": pmc_traffic(args),
-                    "traffic_unit": "HBM bytes per step over the conv-stack launches (PMC, profiles/round1_pmc_hbm_traffic.*)",
+                    "traffic_unit": f"HBM bytes per step over the conv-stack launches (PMC passes of this precision: profiles/{PMC_FILE[args.dtype]}; "
+                                    "algorithmic bytes of the stack in the same file)",
                     "kernel": "implicit-GEMM conv stack: conv3x3_kernel / conv_gemm2_kernel / conv_gemm_kernel (fwd, dgrad) + "
                               "wgrad3x3_kernel / wgrad_gemm2_kernel / wgrad_reduce (weight grad)",
                     "conv_ms_per_step": round(conv_ms, 3), "conv_launches_per_step": nlaunch}
