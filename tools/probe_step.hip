@@ -1,0 +1,112 @@
+// What the inner step of the split-bf16 3x3 kernel can reach, without anything else around it: a workgroup of NW waves
+// loops over steps of [optional s_barrier] -> NRD ds_read_b128 of conflict-free fragments -> NMF MFMAs that consume them
+// (main + cross accumulator chains).  Variants: reads issued up front (as the kernel does) or interleaved one pair ahead
+// of the MFMAs that use them.  Compare the MFMA rate with the nominal 2.5 PFLOP/s.
+//   hipcc --offload-arch=gfx950 -O3 tools/probe_step.hip -o tools/probe_step && tools/probe_step
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+// TM x TN wave tile as in conv3x3 X3: per step 4*(TM+TN) fragment reads, 6*TM*TN MFMAs
+template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE>
+__global__ __launch_bounds__(64 * NW) void step_loop(int iters, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 96 * 1024 / 4; i += 64 * NW) ((unsigned*)smem)[i] = 0x3f803f80u + (i & 255);
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(const __attribute__((address_space(3))) void*)smem;
+    // conflict-free b128 pattern of the kernel: row r at r*128, slot (kk*2+half) ^ ((r>>1)&7)
+    const int l32 = lane & 31, fh = lane >> 5;
+    unsigned a_rel[TM][4], b_rel[TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { int r = ((wave % 4) * TM + i) * 32 + l32; a_rel[i][k] = lds0 + 49152 + r * 128 + ((((k * 2 + fh)) ^ ((r >> 1) & 7)) << 4); }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { int r = ((wave / 4) * TN + j) * 32 + l32; b_rel[j][k] = lds0 + r * 128 + ((((k * 2 + fh)) ^ ((r >> 1) & 7)) << 4); }
+    f32x16 acc[TM][TN], accx[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+    for (int it = 0; it < iters; ++it) {
+        if (BARRIER) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+        const unsigned off = (it % 3) * 16384;
+        u32x4 fa[4][TM], fb[4][TN];
+        if (!INTERLEAVE) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[k][i] = *(const lds_u32x4*)(a_rel[i][k] + (off >> 1));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[k][j] = *(const lds_u32x4*)(b_rel[j][k] + off);
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            if (INTERLEAVE) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[k2 + 2 * h][i] = *(const lds_u32x4*)(a_rel[i][k2 + 2 * h] + (off >> 1));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[k2 + 2 * h][j] = *(const lds_u32x4*)(b_rel[j][k2 + 2 * h] + off);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[k2][j]), bl = __builtin_bit_cast(bf16x8, fb[k2 + 2][j]);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, fa[k2][i]), al = __builtin_bit_cast(bf16x8, fa[k2 + 2][i]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah, acc[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, accx[i][j], 0, 0, 0);
+                }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) s += acc[i][j][0] + accx[i][j][5];
+    if (s == 12345.678f) sink[0] = s;
+}
+
+template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE>
+static void run(float* sink, const char* tag) {
+    const int iters = 4000, blocks = 256;
+    auto k = step_loop<NW, TM, TN, BARRIER, INTERLEAVE>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    k<<<blocks, 64 * NW, 96 * 1024>>>(iters / 10, sink); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0)); k<<<blocks, 64 * NW, 96 * 1024>>>(iters, sink); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double flops = (double)blocks * NW * iters * (6.0 * TM * TN) * 32768.0;
+    printf("%-44s waves %2d tile %dx%d barrier %d interleave %d : %7.1f TFLOP/s MFMA  (%.0f ns/step)\n", tag, NW, TM, TN, BARRIER, INTERLEAVE,
+           flops / ms / 1e9, ms * 1e6 / iters);
+}
+
+int main() {
+    float* sink; CK(hipMalloc(&sink, 64));
+    run<8, 1, 2, 1, 0>(sink, "l3 shape (128x128 tile, 8 waves)");
+    run<8, 1, 2, 0, 0>(sink, "  no barrier");
+    run<8, 1, 2, 1, 1>(sink, "  reads per k-slice");
+    run<8, 2, 2, 1, 0>(sink, "l2 shape (256x128 tile, 8 waves)");
+    run<8, 2, 2, 0, 0>(sink, "  no barrier");
+    run<8, 1, 1, 1, 0>(sink, "l1/l4 shape (1x1 per wave, 8 waves)");
+    run<4, 2, 2, 1, 0>(sink, "4 waves, 2x2 per wave");
+    run<4, 2, 2, 0, 0>(sink, "  no barrier");
+    run<4, 2, 4, 1, 0>(sink, "4 waves, 2x4 per wave");
+    run<16, 1, 1, 1, 0>(sink, "16 waves, 1x1 per wave");
+    return 0;
+}
