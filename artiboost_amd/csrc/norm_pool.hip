@@ -225,7 +225,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                             const T* __restrict__ y, const float* __restrict__ bnp,
                                                             long M, int C, int relu, int rows_per_block, float* __restrict__ part,
-                                                            const uint8_t* __restrict__ pool_idx = nullptr, int pH = 0, int pW = 0) {
+                                                            const uint8_t* __restrict__ pool_idx = nullptr, int pH = 0, int pW = 0,
+                                                            const bf16_t* __restrict__ out_hi = nullptr) {
     constexpr int V = Vec<T>::N;
     const int vc = C / V, rl = 256 / vc;
     const int cv = threadIdx.x % vc, rr = threadIdx.x / vc;
@@ -246,7 +247,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 pool_gather<T>(pool_idx, dout, n, h, w, pH, pW, C, cv, g);
             } else vload<T>(dout + e, g);
             vload<T>(y + e, yy);
-            if (relu == 1) vload<T>(out + e, o);
+            if (relu == 1) {
+                // out_hi (fp32 tensors only, V == 4): the ReLU mask from the hi plane of the split activation (same sign,
+                // half the bytes of the fp32 copy)
+                if (out_hi) {
+                    const uint2 h = *(const uint2*)(out_hi + e);
+                    o[0] = __uint_as_float(h.x << 16); o[1] = __uint_as_float(h.x & 0xffff0000u);
+                    if constexpr (V >= 4) { o[2] = __uint_as_float(h.y << 16); o[3] = __uint_as_float(h.y & 0xffff0000u); }
+                } else vload<T>(out + e, o);
+            }
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 // relu == 2: the mask is recomputed from y with bn_apply's own expression (same f32 value that was
@@ -491,8 +500,9 @@ __global__ void transpose_oki_kernel(const float* __restrict__ src, int O, int K
 }
 // All dgrad weight copies in one launch: tensor t = desc[t] (see ab_transpose_desc), a workgroup moves one 64(o) x 64(i)
 // tile of one tap k through LDS: 256-byte coalesced row reads of src [O][K][I], 16-byte stores into dst [I][K][O].
+// LO_OFF != 0 (T = bf16 only): also write the lo plane bf16(v - hi) at dst + lo_off elements (split-bf16 IHWO copies)
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_oki_batch_kernel(const ab_transpose_desc* __restrict__ desc, int ntensors) {
+__global__ __launch_bounds__(256) void transpose_oki_batch_kernel(const ab_transpose_desc* __restrict__ desc, int ntensors, long lo_off = 0) {
     __shared__ float sm[64][65];
     int t = 0;
     while (t + 1 < ntensors && (long)blockIdx.x >= desc[t + 1].tile_begin) ++t;
@@ -529,6 +539,11 @@ __global__ __launch_bounds__(256) void transpose_oki_batch_kernel(const ab_trans
 #pragma unroll
                 for (int q = 0; q < V; ++q) f[q] = sm[cv + q][il];
                 vstore<T>(dst + ((long)i * K + k) * O + o, f);
+                if (lo_off) {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) f[q] -= round_to<T>(f[q]);
+                    vstore<T>(dst + lo_off + ((long)i * K + k) * O + o, f);
+                }
             }
         }
     }
@@ -630,7 +645,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_x3_kernel(const float* __res
                                                               const float* __restrict__ y, const float* __restrict__ bnp,
                                                               const float* __restrict__ bwdp, long nvec, int C, long M, int relu,
                                                               bf16_t* __restrict__ dy_hi, bf16_t* __restrict__ dy_lo,
-                                                              float* __restrict__ dz_out) {
+                                                              float* __restrict__ dz_out, const bf16_t* __restrict__ out_hi) {
     const float invM = 1.f / (float)M;
     const bool fixed = ((256 * 8) % C) == 0;
     float ga[8], sh[8], mu[8], is[8], k1[8], k2[8];
@@ -648,7 +663,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_x3_kernel(const float* __res
         float g[8], o[8], yy[8], d[8];
         load8(dout + e, g);
         load8(y + e, yy);
-        if (relu == 1) load8(out + e, o);
+        if (relu == 1) {
+            if (out_hi) {
+                const uint4 h = *(const uint4*)(out_hi + e);
+                const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { o[2 * k] = __uint_as_float(hw[k] << 16); o[2 * k + 1] = __uint_as_float(hw[k] & 0xffff0000u); }
+            } else load8(out + e, o);
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const bool dead = relu == 1 ? !(o[k] > 0.f) : relu == 2 ? !(yy[k] * ga[k] + sh[k] > 0.f) : false;
@@ -659,6 +681,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_x3_kernel(const float* __res
         }
         store_split8(dy_hi, dy_lo, e, d);
         if (dz_out) store8(dz_out + e, g);
+    }
+}
+
+// column sums of a split tensor (hi + lo): the bias gradient of the final layer from the dlogits planes
+__global__ __launch_bounds__(256) void col_stats_x3_kernel(const bf16_t* __restrict__ hi, const bf16_t* __restrict__ lo, long M, int C,
+                                                          int rows_per_block, float* __restrict__ part) {
+    const int vc = C / 8, rl = 256 / vc;
+    const int cv = threadIdx.x % vc, rr = threadIdx.x / vc;
+    long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    float s[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s[i] = 0.f; q[i] = 0.f; }
+    if (rr < rl)
+        for (long r = r0 + rr; r < r1; r += rl) {
+            float a[8], b[8];
+            vload<bf16_t>(hi + r * C + cv * 8, a);
+            vload<bf16_t>(lo + r * C + cv * 8, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float v = a[i] + b[i]; s[i] += v; q[i] += v * v; }
+        }
+    extern __shared__ float sm[];
+    if (rr < rl)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sm[(rr * C + cv * 8 + i) * 2] = s[i]; sm[(rr * C + cv * 8 + i) * 2 + 1] = q[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < rl; ++k) { a += sm[(k * C + c) * 2]; b += sm[(k * C + c) * 2 + 1]; }
+        part[((long)blockIdx.x * C + c) * 2] = a; part[((long)blockIdx.x * C + c) * 2 + 1] = b;
     }
 }
 
@@ -861,22 +913,43 @@ extern "C" int ab_bn_apply_x3(const float* y, const float* res, const float* bnp
 
 // ab_bn_bwd / ab_bn_bwd_apply with dy as split planes: nparts_given = 0 runs the reduction pass into `part`
 // ([ab_col_stats_nparts(M)][C][2]); > 0 takes `part` as already reduced per-tile sums (see ab_bn_bwd_apply).
-extern "C" int ab_bn_bwd_x3(const float* dout, const float* out, const float* y, const float* bnp, long M, int C, int relu,
-                            float* part, int nparts_given, float* bwdp, float* dgamma, float* dbeta, void* dy_hi, void* dy_lo,
-                            float* dz_out, void* stream) {
+extern "C" int ab_bn_bwd_x3(const float* dout, const void* out, int out_is_hi_plane, const float* y, const float* bnp, long M, int C,
+                            int relu, float* part, int nparts_given, float* bwdp, float* dgamma, float* dbeta, void* dy_hi,
+                            void* dy_lo, float* dz_out, void* stream) {
     if (!dout || !y || !bnp || !part || !bwdp || !dgamma || !dbeta || !dy_hi || !dy_lo || (relu == 1 && !out) || relu < 0 || relu > 2)
         return AB_EINVAL;
+    const float* out_f = out_is_hi_plane ? nullptr : (const float*)out;
+    const bf16_t* out_h = out_is_hi_plane ? (const bf16_t*)out : nullptr;
     if (C % 8 || C / 4 > 256) return AB_ESHAPE;
     hipStream_t st = as_stream(stream);
     int np = nparts_given > 0 ? nparts_given : ab_col_stats_nparts(M);
     if (nparts_given <= 0) {
         const int rl = 256 / (C / 4); const size_t sh = (size_t)rl * C * 2 * 4;
-        bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>(dout, out, y, bnp, M, C, relu, red_rows(M), part, nullptr, 0, 0);
+        bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>(dout, out_f, y, bnp, M, C, relu, red_rows(M), part, nullptr, 0, 0, out_h);
         AB_LAUNCH_CHECK();
     }
     launch_bn_bwd_finalize(part, np, C, dgamma, dbeta, bwdp, st);
     AB_LAUNCH_CHECK();
     const long nvec = M * C / 8;
-    bn_bwd_apply_x3_kernel<<<grid_for(nvec), 256, 0, st>>>(dout, out, y, bnp, bwdp, nvec, C, M, relu, (bf16_t*)dy_hi, (bf16_t*)dy_lo, dz_out);
+    bn_bwd_apply_x3_kernel<<<grid_for(nvec), 256, 0, st>>>(dout, out_f, y, bnp, bwdp, nvec, C, M, relu, (bf16_t*)dy_hi, (bf16_t*)dy_lo, dz_out, out_h);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+// ab_transpose_oki_batch with bf16 outputs as split planes: hi at desc.dst, lo at desc.dst + lo_offset_elems
+extern "C" int ab_transpose_oki_batch_x3(const ab_transpose_desc* desc_dev, int ntensors, long total_tiles, long lo_offset_elems,
+                                         void* stream) {
+    if (!desc_dev || ntensors < 1 || total_tiles < 1 || total_tiles > 0x7fffffffL || lo_offset_elems <= 0) return AB_EINVAL;
+    transpose_oki_batch_kernel<bf16_t><<<(unsigned)total_tiles, 256, 0, as_stream(stream)>>>(desc_dev, ntensors, lo_offset_elems);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+// ab_col_sum over a split tensor (planes hi, lo: bf16 [M][C]); part as in ab_col_sum
+extern "C" int ab_col_sum_x3(const void* hi, const void* lo, long M, int C, float* part, float* out, void* stream) {
+    if (!hi || !lo || !part || !out) return AB_EINVAL;
+    if (C % 8 || C / 8 > 256) return AB_ESHAPE;
+    const int np = ab_col_stats_nparts(M), rl = 256 / (C / 8);
+    col_stats_x3_kernel<<<np, 256, (size_t)rl * C * 2 * 4, as_stream(stream)>>>((const bf16_t*)hi, (const bf16_t*)lo, M, C, red_rows(M), part);
+    AB_LAUNCH_CHECK();
+    colsum_finalize_kernel<<<(C + 7) / 8, 256, 0, as_stream(stream)>>>(part, np, C, out);
     AB_LAUNCH_CHECK(); return 0;
 }

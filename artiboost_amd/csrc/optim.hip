@@ -38,7 +38,7 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __restric
                                                                 const float* __restrict__ total_norm, float max_norm,
                                                                 float lr, float b1, float b2, float eps, float bc1,
                                                                 float bc2_sqrt, const float* __restrict__ hyper,
-                                                                bf16_t* __restrict__ lp) {
+                                                                bf16_t* __restrict__ lp, bf16_t* __restrict__ lp_lo = nullptr) {
     if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }   // device-side step state (hipGraph replay)
     float coef = 1.f;
     if (max_norm > 0.f) { coef = max_norm / (total_norm[0] + 1e-6f); coef = coef > 1.f ? 1.f : coef; }
@@ -64,6 +64,12 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_adam_kernel(float* __restric
             o.x = pack_bf16x2(pp[0], pp[1]);
             o.y = pack_bf16x2(pp[2], pp[3]);
             ((uint2*)lp)[i] = o;
+            if (lp_lo) {      // split-bf16 weights: lo = bf16(p - hi) (conv_x3.hip)
+                uint2 l;
+                l.x = pack_bf16x2(pp[0] - __uint_as_float(o.x << 16), pp[1] - __uint_as_float(o.x & 0xffff0000u));
+                l.y = pack_bf16x2(pp[2] - __uint_as_float(o.y << 16), pp[3] - __uint_as_float(o.y & 0xffff0000u));
+                ((uint2*)lp_lo)[i] = l;
+            }
         }
     }
 }
@@ -84,16 +90,32 @@ extern "C" int ab_grad_norm(const float* grad, long n, float* part, float* total
 // step: 1-based.  max_norm <= 0 disables clipping.  lp (optional): bf16 copy of the updated params.
 // hyper (optional, device float[3] = {lr, 1-beta1^step, sqrt(1-beta2^step)}) overrides lr/step so that a captured
 // hipGraph can be replayed with per-step values.
+static int clip_adam_impl(float* param, const float* grad, float* m, float* v, long n, const float* total_norm, float max_norm, float lr,
+                          float beta1, float beta2, float eps, int step, const float* hyper, void* lp, void* lp_lo, void* stream);
+
 extern "C" int ab_clip_adam(float* param, const float* grad, float* m, float* v, long n, const float* total_norm,
                             float max_norm, float lr, float beta1, float beta2, float eps, int step,
                             const float* hyper, void* lp, void* stream) {
+    return clip_adam_impl(param, grad, m, v, n, total_norm, max_norm, lr, beta1, beta2, eps, step, hyper, lp, nullptr, stream);
+}
+
+// as ab_clip_adam, refreshing the split-bf16 weight planes (hi, lo) of the updated parameters in the same pass
+extern "C" int ab_clip_adam_x3(float* param, const float* grad, float* m, float* v, long n, const float* total_norm,
+                               float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                               const float* hyper, void* lp_hi, void* lp_lo, void* stream) {
+    if (!lp_hi || !lp_lo) return AB_EINVAL;
+    return clip_adam_impl(param, grad, m, v, n, total_norm, max_norm, lr, beta1, beta2, eps, step, hyper, lp_hi, lp_lo, stream);
+}
+
+static int clip_adam_impl(float* param, const float* grad, float* m, float* v, long n, const float* total_norm, float max_norm, float lr,
+                          float beta1, float beta2, float eps, int step, const float* hyper, void* lp, void* lp_lo, void* stream) {
     if (!param || !grad || !m || !v || (max_norm > 0.f && !total_norm)) return AB_EINVAL;
     if (n % 4 || step < 1) return AB_ESHAPE;
     double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     long b = (n / 4 + OPT_THREADS - 1) / OPT_THREADS;
     int nb = (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
     clip_adam_kernel<<<nb, OPT_THREADS, 0, as_stream(stream)>>>(param, grad, m, v, n, total_norm, max_norm, lr, beta1,
-                                                                beta2, eps, (float)bc1, (float)sqrt(bc2), hyper, (bf16_t*)lp);
+                                                                beta2, eps, (float)bc1, (float)sqrt(bc2), hyper, (bf16_t*)lp, (bf16_t*)lp_lo);
     AB_LAUNCH_CHECK();
     return 0;
 }

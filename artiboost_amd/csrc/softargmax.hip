@@ -284,11 +284,14 @@ template <> __device__ __forceinline__ void st_pair<bf16_t>(bf16_t* p, float a, 
 // d logits = p * (g_u*(cu-u) + g_v*(cv-v) + g_d*(d/D-dd)) / z  [+ g_conf * conf * ([x == max] - p)],  p = exp(x-m)/s.
 // Everything that depends only on (b, channel) is folded into per-lane constants once per workgroup:
 //   out = exp(x - m) * (A*cu + Bv*cv + K),  A = g_u/(s z), Bv = g_v/(s z), K = (g_d*(d/D-dd) - g_u*u - g_v*v)/(s z)
-template <typename T>
+// SPLIT (T = float): dlogits leaves as the split-bf16 planes the final layer's data / weight gradients consume
+// (dl_hi, dl_lo: bf16 [B, H, W, C*DP]) instead of fp32 -- no separate split pass over the largest activation of the net.
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                const float* __restrict__ uvd, const float* __restrict__ conf,
                                                const float* __restrict__ stat, const float* __restrict__ g_uvd,
-                                               const float* __restrict__ g_conf, T* __restrict__ dlogits) {
+                                               const float* __restrict__ g_conf, T* __restrict__ dlogits,
+                                               bf16_t* __restrict__ dl_hi = nullptr, bf16_t* __restrict__ dl_lo = nullptr) {
     const int CD = C * DP, npix = H * W;      // CD even
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int KP = SAM_MAXCH / 128, NCH = 2 * KP;
@@ -327,7 +330,8 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
         const int h = p / W, w = p - h * W;
         const float cu = (float)w / W, cv = (float)h / H;
         const T* row = logits + ((size_t)b * npix + p) * CD;
-        T* drow = dlogits + ((size_t)b * npix + p) * CD;
+        T* drow = SPLIT ? nullptr : dlogits + ((size_t)b * npix + p) * CD;
+        const size_t prow = ((size_t)b * npix + p) * CD;
         float x[NCH];
 #pragma unroll
         for (int k = 0; k < KP; ++k) ld_pair<T>(row + min(2 * (lane + 64 * k), CD - 2), x[2 * k], x[2 * k + 1]);
@@ -343,7 +347,13 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
                 if (g_conf) out += cst[5][ch + t] * ((x[kk] == cm[kk] ? 1.f : 0.f) - e * cst[4][ch + t]);
                 o[t] = out;
             }
-            if (ch < CD) st_pair<T>(drow + ch, o[0], o[1]);
+            if (ch < CD) {
+                if constexpr (SPLIT) {
+                    const uint32_t hw = pack_bf16x2(o[0], o[1]);
+                    *(uint32_t*)(dl_hi + prow + ch) = hw;
+                    *(uint32_t*)(dl_lo + prow + ch) = pack_bf16x2(o[0] - __uint_as_float(hw << 16), o[1] - __uint_as_float(hw & 0xffff0000u));
+                } else st_pair<T>(drow + ch, o[0], o[1]);
+            }
         }
     }
 }
@@ -392,4 +402,17 @@ extern "C" int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, 
     return 0;
 }
 
-extern "C" int ab_abi_version(void) { return 1; }
+// fp32 logits in, dlogits out as split-bf16 planes (C * DP even)
+extern "C" int ab_softargmax3d_bwd_x3(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
+                                      const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
+                                      void* dl_hi, void* dl_lo, void* stream) {
+    if (!logits || !uvd || !conf || !stat || !g_uvd || !dl_hi || !dl_lo) return AB_EINVAL;
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH || ((C * DP) & 1)) return AB_ESHAPE;
+    dim3 grid((H * W + SAM_BWD_PIX - 1) / SAM_BWD_PIX, B);
+    sam_bwd<float, true><<<grid, 256, 0, as_stream(stream)>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
+                                                              (bf16_t*)dl_hi, (bf16_t*)dl_lo);
+    AB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ab_abi_version(void) { return 2; }

@@ -34,6 +34,18 @@ def softargmax3d_bwd(logits, C, D, DP, uvd, conf, stat, g_uvd, g_conf=None, inpl
     return dl
 
 
+def softargmax3d_bwd_x3(logits, C, D, DP, uvd, conf, stat, g_uvd, g_conf=None):
+    """fp32 logits -> dlogits as split-bf16 planes [2, B, H, W, C*DP] (ab_softargmax3d_bwd_x3)."""
+    B, H, W, _ = logits.shape
+    g_uvd = g_uvd.contiguous().float()
+    gc = g_conf.contiguous().float() if g_conf is not None else None
+    dl = torch.empty((2,) + tuple(logits.shape), dtype=torch.bfloat16, device=logits.device)
+    L.check(L.lib().ab_softargmax3d_bwd_x3(L.ptr(logits), L.i(B), L.i(C), L.i(D), L.i(DP), L.i(H), L.i(W), L.ptr(uvd), L.ptr(conf),
+                                           L.ptr(stat), L.ptr(g_uvd), L.ptr(gc), L.ptr(dl[0]), L.ptr(dl[1]), L.stream()),
+            "ab_softargmax3d_bwd_x3")
+    return dl
+
+
 class _SoftArgmax3D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, C, D, DP):

@@ -25,7 +25,7 @@ import os
 import torch
 
 from . import kernels as K
-from .head import softargmax3d_fwd, softargmax3d_bwd
+from .head import softargmax3d_fwd, softargmax3d_bwd, softargmax3d_bwd_x3
 
 RESNET34_LAYERS = [3, 4, 6, 3]
 DEPTH_PITCH = 32
@@ -288,16 +288,16 @@ class HybridNet:
             self.lp = p.flat
         if getattr(self, "_tr_plan", None) is None:
             pairs = []
-            if self.x3:      # IHWO copies: transposed in fp32 into one flat buffer, split into planes in one pass
+            if self.x3:      # IHWO copies as split planes [2][tot]: written by the transpose launch itself
                 tot = sum(_round_up(p.entries[n].numel, 64) for n in self._dgrad_names())
-                self._tr_f32 = torch.empty(tot, dtype=torch.float32, device=p.device)
-                self._tr_planes = torch.empty((2, tot), dtype=torch.bfloat16, device=p.device)
+                self._tr_planes = torch.zeros((2, tot), dtype=torch.bfloat16, device=p.device)
+                self._tr_lo_off = tot
                 off = 0
             for name in self._dgrad_names():
                 O, kh, kw, I = p.entries[name].kshape
                 if self.x3:
                     n = p.entries[name].numel
-                    dst = self._tr_f32[off:off + n].view(I, kh, kw, O)
+                    dst = self._tr_planes[0, off:off + n].view(I, kh, kw, O)         # hi plane; lo at + tot elements
                     self.tr[name] = self._tr_planes[:, off:off + n].view(2, I, kh, kw, O)
                     off += _round_up(n, 64)
                 else:
@@ -318,13 +318,15 @@ class HybridNet:
         else:
             for src, dst in self._box_pairs:
                 dst.copy_(src.permute(2, 1, 0))
-        if self._tr_plan:
+        if self.x3:
+            if not self._tr_plan:
+                raise RuntimeError("bf16x3 needs the batched transpose plan (channel counts multiples of 8 / 4)")
+            K.transpose_oki_batch_x3(self._tr_plan, self._tr_lo_off)
+        elif self._tr_plan:
             K.transpose_oki_batch(self._tr_plan)                     # one launch for all IHWO dgrad copies
         else:
             for src, dst in self._tr_pairs:
                 K.transpose_oki(src, dst)
-        if self.x3:
-            K.split(self._tr_f32, out=self._tr_planes)
         self._packed = True
 
     def w(self, name):
@@ -458,7 +460,9 @@ class HybridNet:
         return softargmax3d_fwd(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH)
 
     def head_bwd(self, logits, kp3d, conf, stat, g_kp3d, g_conf=None):
-        """dlogits, written in place over the logits buffer (they are not needed again)."""
+        """dlogits, written in place over the logits buffer (they are not needed again); bf16x3: as split planes."""
+        if self.x3:
+            return softargmax3d_bwd_x3(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf)
         return softargmax3d_bwd(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf,
                                 inplace=True)
 
@@ -543,9 +547,12 @@ class HybridNet:
         g_mean = K.linear_dgrad(gb1, self.box_t["box_head.layers.0.weight"])
         # ---- head
         e2, e1, feat = S["e2"], S["e1"], S["feat"]
-        K.col_sum(dlogits, gv("hybrid_head.final_layer.bias"))
-        if self.x3:
-            dlogits = K.split(dlogits)        # one split serves the weight and the data gradient
+        if self.x3 and dlogits.dtype == torch.bfloat16:       # planes straight from the soft-argmax backward
+            K.col_sum_x3(dlogits, gv("hybrid_head.final_layer.bias"))
+        else:
+            K.col_sum(dlogits, gv("hybrid_head.final_layer.bias"))
+            if self.x3:
+                dlogits = K.split(dlogits)        # one split serves the weight and the data gradient
         self._wgrad_side(self._conv_wgrad, e2, dlogits, 1, 1, 1, 0, out=gv("hybrid_head.final_layer.weight"))
         de2 = self._conv_dgrad(dlogits, "hybrid_head.final_layer.weight", (e2.shape[-3], e2.shape[-2]), 1, 0)
         dd2 = self._bn_bwd(de2, e2, S["d2"], S["bnpd2"], gv("hybrid_head.deconv_layers.4.weight"),

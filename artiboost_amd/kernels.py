@@ -340,6 +340,13 @@ def transpose_oki_batch(plan):
     L.check(L.lib().ab_transpose_oki_batch(L.ptr(dev), L.i(n), L.l(tiles), L.i(dt), L.stream()), "ab_transpose_oki_batch")
 
 
+def transpose_oki_batch_x3(plan, lo_offset_elems):
+    """transpose_oki_batch with bf16 destinations written as split planes (lo plane `lo_offset_elems` behind the hi plane)."""
+    dev, n, tiles, dt = plan
+    assert dt == L.DT_BF16
+    L.check(L.lib().ab_transpose_oki_batch_x3(L.ptr(dev), L.i(n), L.l(tiles), L.l(lo_offset_elems), L.stream()), "ab_transpose_oki_batch_x3")
+
+
 def image_pad_nhwc4(img_nchw_f32, dtype):
     N, C, H, W = img_nchw_f32.shape
     assert C == 3
@@ -474,7 +481,10 @@ def bn_bwd_x3(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, part=N
         part = torch.empty((lib.ab_col_stats_nparts(L.l(M)), C, 2), dtype=torch.float32, device=y.device)
     else:
         given = part.shape[0]
-    L.check(lib.ab_bn_bwd_x3(L.ptr(dout), L.ptr(out if relu is True else None), L.ptr(y), L.ptr(bnp), L.l(M), L.i(C),
+    mask, is_hi = (out if relu is True else None), 0
+    if mask is not None and getattr(mask, "_ab_split", None) is not None:
+        mask, is_hi = mask._ab_split[0], 1          # sign of the hi plane == sign of the activation; half the bytes
+    L.check(lib.ab_bn_bwd_x3(L.ptr(dout), L.ptr(mask), L.i(is_hi), L.ptr(y), L.ptr(bnp), L.l(M), L.i(C),
                              L.i(2 if relu == "recompute" else 1 if relu else 0), L.ptr(part), L.i(given), L.ptr(bwdp),
                              L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy[0]), L.ptr(dy[1]), L.ptr(dz), L.stream()), "ab_bn_bwd_x3")
     return (dy, dz) if want_dz else dy
@@ -507,3 +517,13 @@ def conv2d_stem_wgrad_x3(xpad, dy, H, W, out=None):
     L.check(lib.ab_conv2d_stem_wgrad_x3(L.ptr(xh), L.ptr(xl), L.ptr(dh), L.ptr(dl), L.ptr(dw), L.i(N), L.i(H), L.i(W), L.i(Cout),
                                         L.ptr(ws), L.stream()), "ab_conv2d_stem_wgrad_x3")
     return dw
+
+
+def col_sum_x3(x_split, out):
+    """Column sums of a split tensor [2, ..., C] (hi + lo) -> out fp32 [C]."""
+    C = x_split.shape[-1]
+    M = x_split[0].numel() // C
+    lib = L.lib()
+    part = torch.empty((lib.ab_col_stats_nparts(L.l(M)), C, 2), dtype=torch.float32, device=x_split.device)
+    L.check(lib.ab_col_sum_x3(L.ptr(x_split[0]), L.ptr(x_split[1]), L.l(M), L.i(C), L.ptr(part), L.ptr(out), L.stream()), "ab_col_sum_x3")
+    return out

@@ -91,11 +91,16 @@ class FusedClipAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 g = p.grad
                 tn = self.grad_norm(g) if self.max_norm else None
-                lp = None
-                if self.model is not None and self.model.net.dtype == torch.bfloat16 and p is self.model.flat_param:
-                    if self.model.net.lp is None or self.model.net.lp.dtype != torch.bfloat16:
-                        self.model.net.lp = torch.empty(p.numel(), dtype=torch.bfloat16, device=p.device)
-                    lp = self.model.net.lp
+                lp = lp_planes = None
+                net = self.model.net if (self.model is not None and p is self.model.flat_param) else None
+                if net is not None and getattr(net, "x3", False):
+                    if net.lp is None or tuple(net.lp.shape) != (2, p.numel()):
+                        net.lp = torch.empty((2, p.numel()), dtype=torch.bfloat16, device=p.device)
+                    lp_planes = net.lp               # split-bf16 weight planes, refreshed by the Adam pass itself
+                elif net is not None and net.dtype == torch.bfloat16:
+                    if net.lp is None or net.lp.dtype != torch.bfloat16:
+                        net.lp = torch.empty(p.numel(), dtype=torch.bfloat16, device=p.device)
+                    lp = net.lp
                 b1, b2 = group["betas"]
                 hyper = self.hyper
                 if hyper is None:        # eager step: the same host-computed {lr, bias corrections} a replayed step reads, so
@@ -103,10 +108,16 @@ class FusedClipAdam(torch.optim.Optimizer):
                         self._eager_hyper = torch.zeros(3, dtype=torch.float32, device=p.device)
                     hyper = self._eager_hyper
                     hyper.copy_(torch.tensor([group["lr"], 1.0 - b1 ** st["step"], (1.0 - b2 ** st["step"]) ** 0.5], dtype=torch.float32))
-                L.check(L.lib().ab_clip_adam(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
-                                             L.l(p.numel()), L.ptr(tn), L.f(self.max_norm or 0.0), L.f(group["lr"]),
-                                             L.f(b1), L.f(b2), L.f(group["eps"]), L.i(st["step"]), L.ptr(hyper),
-                                             L.ptr(lp), L.stream()), "ab_clip_adam")
-                if self.model is not None and p is self.model.flat_param:
-                    self.model.net.refresh_after_update(lp_fresh=lp is not None)
+                if lp_planes is not None:
+                    L.check(L.lib().ab_clip_adam_x3(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                                                    L.l(p.numel()), L.ptr(tn), L.f(self.max_norm or 0.0), L.f(group["lr"]),
+                                                    L.f(b1), L.f(b2), L.f(group["eps"]), L.i(st["step"]), L.ptr(hyper),
+                                                    L.ptr(lp_planes[0]), L.ptr(lp_planes[1]), L.stream()), "ab_clip_adam_x3")
+                else:
+                    L.check(L.lib().ab_clip_adam(L.ptr(p), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]),
+                                                 L.l(p.numel()), L.ptr(tn), L.f(self.max_norm or 0.0), L.f(group["lr"]),
+                                                 L.f(b1), L.f(b2), L.f(group["eps"]), L.i(st["step"]), L.ptr(hyper),
+                                                 L.ptr(lp), L.stream()), "ab_clip_adam")
+                if net is not None:
+                    net.refresh_after_update(lp_fresh=lp is not None or lp_planes is not None)
         return None

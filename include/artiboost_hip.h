@@ -45,6 +45,10 @@ int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, int D, int 
 int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W,
                         const float* uvd, const float* conf, const float* stat,
                         const float* g_uvd, const float* g_conf, void* dlogits, void* stream);
+/* fp32 logits in, dlogits out as split-bf16 planes (what the final layer's bf16x3 data / weight gradients consume)      */
+int ab_softargmax3d_bwd_x3(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
+                           const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
+                           void* dl_hi, void* dl_lo, void* stream);
 
 /* ---- M1/M2: convolution stack (implicit GEMM on MFMA) ----------------------------------------------------------
  * replaces cuDNN behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear:
@@ -128,9 +132,11 @@ int ab_conv2d_stem_wgrad_x3(const void* xpad_hi, const void* xpad_lo, const void
  * already reduced rows).  resnet.py:85-101, simplebaseline.py:171-172.                                             */
 int ab_bn_apply_x3(const float* y, const float* res, const float* bnp, long M, int C, int relu, float* out, void* out_hi,
                    void* out_lo, void* stream);
-int ab_bn_bwd_x3(const float* dout, const float* out, const float* y, const float* bnp, long M, int C, int relu, float* part,
-                 int nparts_given, float* bwdp, float* dgamma, float* dbeta, void* dy_hi, void* dy_lo, float* dz_out,
-                 void* stream);
+/* out (relu == 1): the stored activation as fp32, or -- out_is_hi_plane != 0 -- the hi plane (bf16) of its split form: the
+ * ReLU mask only needs the sign, and the plane is half the bytes                                                     */
+int ab_bn_bwd_x3(const float* dout, const void* out, int out_is_hi_plane, const float* y, const float* bnp, long M, int C,
+                 int relu, float* part, int nparts_given, float* bwdp, float* dgamma, float* dbeta, void* dy_hi, void* dy_lo,
+                 float* dz_out, void* stream);
 
 /* ---- M1/M2: training-mode BatchNorm, ReLU, residual, pooling (HBM-bound NHWC kernels) ---------------------------
  * replaces nn.BatchNorm2d / ReLU / MaxPool2d / mean-pool: anakin/models/resnet.py:85-101,155-157,219;
@@ -151,6 +157,7 @@ int ab_bn_bwd(const void* dout, const void* out, const void* y, const float* bnp
               float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out, void* stream);
 int ab_relu_bwd(const void* dout, const void* out, int dtype, long n, void* dz, void* stream);
 int ab_col_sum(const void* x, int dtype, long M, int C, float* part, float* out, void* stream);
+int ab_col_sum_x3(const void* hi, const void* lo, long M, int C, float* part, float* out, void* stream);   /* of hi + lo */
 int ab_add(const void* a, const void* b, int dtype, long n, void* out, void* stream);
 /* idx: uint8 [N,H/2,W/2,C] winning tap (0..8, first maximum in row-major order); H,W describe the pool INPUT          */
 int ab_maxpool3x3s2_fwd(const void* x, int dtype, int N, int H, int W, int C, void* out, void* idx, void* stream);
@@ -189,6 +196,9 @@ typedef struct ab_transpose_desc {
     int32_t tile_begin;
 } ab_transpose_desc;
 int ab_transpose_oki_batch(const ab_transpose_desc* desc_dev, int ntensors, long total_tiles, int dtype, void* stream);
+/* bf16 outputs as split planes (hi at desc.dst, lo = bf16(v - hi) at desc.dst + lo_offset_elems): the IHWO weight copies of
+ * the bf16x3 data gradients */
+int ab_transpose_oki_batch_x3(const ab_transpose_desc* desc_dev, int ntensors, long total_tiles, long lo_offset_elems, void* stream);
 int ab_image_pad_nhwc4(const float* img_nchw, int dtype, int N, int H, int W, void* out, void* stream);
 
 /* ---- T1: global-norm clip + Adam on the flat parameter buffer ---------------------------------------------------
@@ -199,6 +209,10 @@ int ab_grad_norm(const float* grad, long n, float* part, float* total_norm, void
 int ab_clip_adam(float* param, const float* grad, float* m, float* v, long n, const float* total_norm,
                  float max_norm, float lr, float beta1, float beta2, float eps, int step, const float* hyper,
                  void* lp, void* stream);
+/* ab_clip_adam that also refreshes the split-bf16 weight planes (hi = bf16(p), lo = bf16(p - hi)) in the same pass */
+int ab_clip_adam_x3(float* param, const float* grad, float* m, float* v, long n, const float* total_norm,
+                    float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                    const float* hyper, void* lp_hi, void* lp_lo, void* stream);
 
 /* ---- M4 + L1-L3 + V1: fused pose assembly + criterion, forward and backward --------------------------------------
  * replaces (one wave per sample, deterministic): anakin/models/hybridbaseline.py:49-96 (uvd->xyz, 6D->R, corners),

@@ -166,3 +166,36 @@ def test_bn_producers_write_split_planes():
         dy, dz = K.bn_bwd_x3(dout, ref, y, bnp, dg2, db2, relu=relu, want_dz=True)
         assert torch.equal(dy, K.split(dy_ref)) and torch.equal(dz, dz_ref)
         assert torch.equal(dg, dg2) and torch.equal(db, db2)
+
+
+def test_plane_producers_match_split_of_fp32_results():
+    """The passes that write split planes themselves (soft-argmax backward, Adam weight refresh, IHWO transposes) == their
+    fp32 counterparts followed by ab_split_f32, bit for bit; column sums of planes == column sums of hi + lo."""
+    from artiboost_amd import _lib as L
+    from artiboost_amd import kernels as K
+    from artiboost_amd.head import softargmax3d_bwd, softargmax3d_bwd_x3, softargmax3d_fwd
+    g = torch.Generator().manual_seed(9)
+    B, H, W, C, D, DP = 3, 8, 8, 22, 28, 32
+    logits = (3 * torch.randn(B, H, W, C * DP, generator=g)).cuda()
+    uvd, conf, stat = softargmax3d_fwd(logits, C, D, DP)
+    gu = torch.randn(B, C, 3, generator=g).cuda()
+    ref = softargmax3d_bwd(logits, C, D, DP, uvd, conf, stat, gu)
+    got = softargmax3d_bwd_x3(logits, C, D, DP, uvd, conf, stat, gu)
+    assert torch.equal(got, K.split(ref))
+    out = torch.empty(C * DP, device="cuda")
+    K.col_sum_x3(got, out)
+    np.testing.assert_allclose(out.cpu().numpy(), (got[0].float() + got[1].float()).sum((0, 1, 2)).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # Adam: the planes written by ab_clip_adam_x3 are the split of the updated parameters
+    n = 4096
+    p = torch.randn(n, generator=g).cuda()
+    gr, m, v = torch.randn(n, generator=g).cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    planes = torch.empty((2, n), dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().ab_clip_adam_x3(L.ptr(p), L.ptr(gr), L.ptr(m), L.ptr(v), L.l(n), L.ptr(None), L.f(0.0), L.f(1e-2), L.f(0.9), L.f(0.999),
+                                    L.f(1e-8), L.i(1), L.ptr(None), L.ptr(planes[0]), L.ptr(planes[1]), L.stream()), "ab_clip_adam_x3")
+    assert torch.equal(planes, K.split(p))
+    # IHWO weight copies as planes
+    w = torch.randn(64, 9, 32, generator=g).cuda()                      # [O][K][I]
+    dst = torch.zeros((2, 32 * 9 * 64), dtype=torch.bfloat16, device="cuda")
+    plan = K.transpose_plan([(w, dst[0].view(32, 9, 64))])
+    K.transpose_oki_batch_x3(plan, dst.shape[1])
+    assert torch.equal(dst.view(2, 32, 9, 64), K.split(w.permute(2, 1, 0).contiguous()))
