@@ -4,6 +4,7 @@
 The ordinal losses draw from the same global RNGs in the same order as the reference (torch.rand for the virtual
 view vectors, random.shuffle for the pair subsets), so seeding `random` and `torch` identically reproduces the
 reference's loss values.  Tensors here are tiny ((B,21,3)-sized); the arithmetic runs as device torch ops."""
+import os
 import random
 from itertools import combinations, product
 from typing import Dict, List, Tuple
@@ -36,6 +37,9 @@ class Criterion(TensorLoss):
         self._loss_list = loss_list
         lambdas = list(cfg["LAMBDAS"])
         self._loss_lambdas = {type(l).__name__: lambdas[i] for i, l in enumerate(loss_list)}
+        # predictions that come straight from the HIP model carry a link to its raw outputs; with it compute_losses runs
+        # the fused pose/loss kernel instead of the registry losses' torch ops.  FUSED_CRITERION: false / AB_FUSED_CRITERION=0: off
+        self.fused_route = bool(cfg.get("FUSED_CRITERION", os.environ.get("AB_FUSED_CRITERION", "1") != "0"))
 
     @property
     def loss_list(self):
@@ -71,7 +75,60 @@ class Criterion(TensorLoss):
             if hasattr(loss, "draws"):
                 loss.draws.frozen = frozen
 
+    # ---- the fused route of the reference-shaped loop ----------------------------------------------------------------
+    _FUSED_TARGETS = (Queries.ROOT_JOINT, Queries.CAM_INTR, Queries.CORNERS_CAN, Queries.JOINTS_3D, Queries.CORNERS_3D,
+                      Queries.JOINTS_VIS, Queries.CORNERS_VIS)
+
+    def _fused_for(self, link):
+        """FusedPoseCriterion of this loss list for the model geometry in `link`, or None when a loss is outside the kernel."""
+        key = (tuple(link["inp_res"]), link["center_idx"])
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        if key not in cache:
+            try:
+                f = FusedPoseCriterion(self, link["inp_res"], link["center_idx"])
+                cache[key] = None if f.sym is not None else f      # SymCornerLoss needs obj_idx / obj_transf: registry path
+            except NotImplementedError:
+                cache[key] = None
+        return cache[key]
+
+    def _compute_losses_fused(self, link, targs):
+        """One HIP kernel (csrc/pose_loss.hip) for pose assembly + all losses + their gradients, behind `compute_losses`:
+        the ~350 small torch kernels per step of the registry losses and of their autograd backward disappear, and the
+        update becomes deterministic (the autograd backward of index_select accumulates with float atomics)."""
+        fused = self._fused_for(link)
+        if fused is None:
+            return None
+        kp3d, box6d = link["kp3d"], link["box6d"]
+        dev = kp3d.device
+        t = {}
+        for k in self._FUSED_TARGETS:
+            v = targs[k]
+            if not torch.is_tensor(v):
+                return None
+            t[k] = v.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+        if not all(l.draws.frozen for l in self.loss_list if hasattr(l, "draws")):
+            self.draw(dev)                                   # reference RNG order: the losses' draws in list order
+        total, vals = _FusedLossFn.apply(kp3d, box6d, fused, t)
+        out = {}
+        for loss in self.loss_list:                          # the entries each registry class reports
+            if isinstance(loss, JointsLoss):
+                out["joints_3d_loss"] = vals[0] if loss.lambda_joints_3d else None
+                out["corners_3d_loss"] = vals[1] if loss.lambda_corners_3d else None
+                out[loss.output_key] = loss.lambda_joints_3d * vals[0] + loss.lambda_corners_3d * vals[1]
+            elif isinstance(loss, HandOrdLoss):
+                out["joint_ord_loss"], out["part_ord_loss"] = vals[2], vals[3]
+                out[loss.output_key] = loss.lambda_joint_lev * vals[2] + loss.lambda_part_lev * vals[3]
+            elif isinstance(loss, SceneOrdLoss):
+                out["scene_ord_loss"] = vals[4]
+        out["final_loss"] = total
+        return total, out
+
     def compute_losses(self, preds: Dict, targs: Dict, **kwargs):
+        link = getattr(preds.get("joints_3d_abs"), "_ab_fuse", None) if self.fused_route else None
+        if link is not None and torch.is_grad_enabled():
+            r = self._compute_losses_fused(link, targs)
+            if r is not None:
+                return r
         total, out = super().__call__(preds, targs, **kwargs)
         for loss in self.loss_list:
             fl, d = loss(preds, targs, **kwargs)
@@ -343,6 +400,23 @@ class SymCornerLoss(TensorLoss):
         losses["sym_corners_3d_loss"] = loss
         losses[self.output_key] = final_loss
         return final_loss, losses
+
+
+class _FusedLossFn(torch.autograd.Function):
+    """final_loss as a function of the network's raw outputs; the kernel has already produced its gradient."""
+
+    @staticmethod
+    def forward(ctx, kp3d, box6d, fused, targs):
+        o = fused(kp3d.detach().contiguous(), box6d.detach().contiguous(), box6d.shape[-1], targs, backward=True)
+        vals = o["losses"].clone()
+        ctx.save_for_backward(o["g_kp3d"].clone(), o["g_box6d"].clone())
+        ctx.mark_non_differentiable(vals)
+        return vals[5].clone(), vals
+
+    @staticmethod
+    def backward(ctx, g_total, g_vals):
+        gk, gb = ctx.saved_tensors
+        return gk * g_total, gb * g_total, None, None
 
 
 class FusedPoseCriterion:

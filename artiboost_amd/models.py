@@ -4,6 +4,7 @@ anakin/models/hybridbaseline.py:18-129) on top of the HIP executor (hybridnet.Hy
 `Arch(cfg, model_list)(batch) -> {TYPE: preds}`; `preds` carries the 7 keys of hybridbaseline.py:86-96.
 `final_loss.backward()` on anything computed from `preds` runs the hand-written backward kernels and leaves the
 gradient in `model.flat_param.grad` (one flat tensor -> clip_grad_norm_ / Adam see one parameter)."""
+import os
 from collections import OrderedDict
 from typing import Dict
 
@@ -36,18 +37,88 @@ def batch_uvd2xyz(uvd, root_joint, intr, inp_res, depth_range=0.4):
     return torch.cat([xy, z[..., None]], -1)
 
 
+class _NetSegment:
+    """The network half of an EAGER step as two replayed hipGraphs (forward + soft-argmax | backward) for one input shape.
+
+    The reference-shaped loop (train/train_artiboost.py:66-96) calls `arch_model(batch)`, the criterion, `backward()` and the
+    optimizer one after the other from Python; issued kernel by kernel that is ~600 launches (18-25 ms of host time) per step
+    for 11 ms of device work.  The first call with a given shape runs eagerly (lazy state, allocator); the second captures
+    the same call sequence into a graph whose inputs / outputs / saved activations live at fixed addresses, and every later
+    call is one input copy + one replay.  The criterion, the evaluator and the optimizer stay ordinary eager code.
+    AB_SEGMENT_GRAPHS=0 disables it."""
+    MAX_SHAPES = 4
+
+    def __init__(self):
+        self.calls = 0
+        self.pending = False          # a grad-mode forward whose backward has not run yet owns the saved activations
+        self.fwd = self.bwd = None
+        self.x = self.out = self.saved = self.last = self.gk = self.gb = None
+
+    def forward(self, net, image, xpad, grad):
+        """-> (logits, kp3d, conf, stat, box6d) at fixed addresses, or None (run eagerly this time)."""
+        src = xpad if xpad is not None else image
+        self.calls += 1
+        if self.pending:
+            return None
+        if self.fwd is None:
+            if self.calls < 2 or torch.cuda.is_current_stream_capturing():
+                return None
+            self.x = src.detach().clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                logits, box6d = net.forward(image=None if xpad is not None else self.x, xpad=self.x if xpad is not None else None)
+                kp3d, conf, stat = net.head_fwd(logits)
+                box = box6d.contiguous()
+            self.fwd, self.out, self.saved, self.last = g, (logits, kp3d, conf, stat, box), net.saved, net.last
+        elif torch.cuda.is_current_stream_capturing():
+            return None
+        else:
+            self.x.copy_(src, non_blocking=True)
+        self.fwd.replay()
+        net.saved, net.last = self.saved, self.last
+        self.pending = bool(grad)
+        return self.out
+
+    def backward(self, net, g_kp3d, g_box6d):
+        logits, kp3d, conf, stat, _ = self.out
+        net.saved, net.last = self.saved, self.last
+        self.pending = False
+        if torch.cuda.is_current_stream_capturing():
+            net.backward(net.head_bwd(logits, kp3d, conf, stat, g_kp3d), g_box6d)
+            return
+        if self.bwd is None:
+            self.gk, self.gb = g_kp3d.detach().clone(), g_box6d.detach().clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.fwd.pool(), capture_error_mode="thread_local"):
+                net.backward(net.head_bwd(logits, kp3d, conf, stat, self.gk), self.gb)
+            self.bwd = g
+        else:
+            self.gk.copy_(g_kp3d, non_blocking=True)
+            self.gb.copy_(g_box6d, non_blocking=True)
+        self.bwd.replay()
+
+
 class _NetBridge(torch.autograd.Function):
     """Autograd boundary: forward = HIP forward + fused soft-argmax; backward = HIP backward into the flat grad."""
 
     @staticmethod
-    def forward(ctx, flat_param, owner, image, xpad):
+    def forward(ctx, flat_param, owner, image, xpad, seg):
         net = owner.net
-        logits, box6d = net.forward(image=image, xpad=xpad)
-        kp3d, conf, stat = net.head_fwd(logits)
+        res = seg.forward(net, image, xpad, True) if seg is not None else None
+        if res is not None:
+            logits, kp3d, conf, stat, box = res
+            ctx.seg = seg
+            ctx.pack = (logits, kp3d, conf, stat)
+            kp3d, conf, box = kp3d.clone(), conf.clone(), box.clone()      # the caller's tensors outlive the next replay
+        else:
+            logits, box6d = net.forward(image=image, xpad=xpad)
+            kp3d, conf, stat = net.head_fwd(logits)
+            ctx.seg = None
+            ctx.pack = (logits, kp3d, conf, stat)
+            box = box6d.contiguous()
         ctx.owner = owner
-        ctx.pack = (logits, kp3d, conf, stat)
         ctx.mark_non_differentiable(conf)
-        return kp3d, conf, box6d.contiguous()
+        return kp3d, conf, box
 
     @staticmethod
     def backward(ctx, g_kp3d, g_conf, g_box6d):
@@ -58,10 +129,14 @@ class _NetBridge(torch.autograd.Function):
             g_kp3d = torch.zeros_like(kp3d)
         if g_box6d is None:
             g_box6d = torch.zeros((kp3d.shape[0], 6), dtype=torch.float32, device=kp3d.device)
-        dlogits = net.head_bwd(logits, kp3d, conf, stat, g_kp3d)
-        net.backward(dlogits, g_box6d.contiguous().float())
+        g_kp3d, g_box6d = g_kp3d.contiguous().float(), g_box6d.contiguous().float()
+        if ctx.seg is not None:
+            ctx.seg.backward(net, g_kp3d, g_box6d)
+        else:
+            dlogits = net.head_bwd(logits, kp3d, conf, stat, g_kp3d)
+            net.backward(dlogits, g_box6d)
         owner.flat_param.grad = owner.store.grad      # the kernels wrote it; no copy, no accumulation
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 @MODEL.register_module
@@ -90,6 +165,8 @@ class HybridBaseline(nn.Module):
                                             "bf16x3" if cd in ("bf16x3", "x3") else torch.float32))
         self.flat_param = nn.Parameter(self.store.flat, requires_grad=True)   # shares storage with the store
         self.flat_param._ab_owner = self                                      # netutils.build_optimizer recognises it
+        self.segment_graphs = bool(cfg.get("SEGMENT_GRAPHS", os.environ.get("AB_SEGMENT_GRAPHS", "1") != "0"))
+        self._segments = {}
         pretrained = cfg.get("PRETRAINED", "")
         if pretrained:
             self.load_pretrained(pretrained)
@@ -113,6 +190,19 @@ class HybridBaseline(nn.Module):
         self.net.training = mode
         return self
 
+    def _segment(self, image, xpad):
+        """The graph pair for this call's (mode, input shape), or None when segment graphs do not apply."""
+        src = xpad if xpad is not None else image
+        if not self.segment_graphs or src is None or not src.is_cuda:
+            return None
+        key = (self.training, torch.is_grad_enabled(), xpad is not None, tuple(src.shape), src.dtype)
+        seg = self._segments.get(key)
+        if seg is None:
+            if len(self._segments) >= _NetSegment.MAX_SHAPES:
+                return None
+            seg = self._segments[key] = _NetSegment()
+        return seg
+
     def params_updated(self):
         """Call after the optimizer changed flat_param (refreshes the compute-precision weight copies)."""
         self.net._packed = False
@@ -130,11 +220,16 @@ class HybridBaseline(nn.Module):
             self.net.pack_weights()      # torch-side update (e.g. torch.optim.Adam); the fused optimizer repacks itself
             self._seen_version = self.flat_param._version
         if self.training and torch.is_grad_enabled():
-            kp3d, conf, box6d = _NetBridge.apply(self.flat_param, self, image, xpad)
+            kp3d, conf, box6d = _NetBridge.apply(self.flat_param, self, image, xpad, self._segment(image, xpad))
         else:
             with torch.no_grad():
-                logits, box6d = self.net.forward(image=image, xpad=xpad)
-                kp3d, conf, _ = self.net.head_fwd(logits)
+                seg = self._segment(image, xpad)
+                res = seg.forward(self.net, image, xpad, False) if seg is not None else None
+                if res is not None:
+                    kp3d, conf, box6d = res[1].clone(), res[2].clone(), res[4].clone()
+                else:
+                    logits, box6d = self.net.forward(image=image, xpad=xpad)
+                    kp3d, conf, _ = self.net.head_fwd(logits)
         root_in = inputs[Queries.ROOT_JOINT].to(dev)
         intr = inputs[Queries.CAM_INTR].to(dev)
         pose_3d_abs = batch_uvd2xyz(kp3d, root_in, intr, self.inp_res)
@@ -149,6 +244,8 @@ class HybridBaseline(nn.Module):
         corners_2d = torch.stack([corners_2d[:, :, 0] / W, corners_2d[:, :, 1] / H], dim=2)
         corners_2d_uvd = torch.cat((corners_2d, torch.zeros_like(corners_2d[:, :, 0:1])), dim=2)
         final_2d_uvd = torch.cat((kp3d[:, 0:21, :], corners_2d_uvd, kp3d[:, 21:22, :]), dim=1)
+        if kp3d.requires_grad:      # lets Criterion.compute_losses run the fused pose/loss kernel on the raw outputs
+            joints_3d_abs._ab_fuse = dict(kp3d=kp3d, box6d=box6d, inp_res=self.inp_res, center_idx=self.center_idx)
         return {
             "joints_3d_abs": joints_3d_abs,
             "corners_3d_abs": corners_3d_abs,

@@ -23,13 +23,13 @@ REF_YAML_ARCH = {
 }
 
 
-def build(size, heat, dtype, seed):
+def build(size, heat, dtype, seed, **arch_extra):
     from artiboost_amd import registry as R
     from artiboost_amd.models import Arch
     from artiboost_amd.criterions import Criterion
     import artiboost_amd.criterions  # noqa: F401 (registers losses)
     preset = {"IMAGE_SIZE": [size, size], "HEATMAP_SIZE": [heat, heat], "CENTER_IDX": 0}
-    arch_cfg = dict(REF_YAML_ARCH, COMPUTE_DTYPE=dtype)
+    arch_cfg = dict(REF_YAML_ARCH, COMPUTE_DTYPE=dtype, **arch_extra)
     cfg = {"ARCH": arch_cfg, "LAMBDAS": [0.5, 0.2, 0.1],
            "CRITERION": [{"TYPE": "JointsLoss", "LAMBDA_JOINTS_3D": 1.0, "LAMBDA_CORNERS_3D": 0.2},
                          {"TYPE": "HandOrdLoss"}, {"TYPE": "SceneOrdLoss"}]}
@@ -54,12 +54,16 @@ PRED_TOL = {"f32": dict(eval=3e-5, train=3e-5, metres=3e-5, logits=2e-4, gsamp=3
             "bf16x3": dict(eval=5e-4, train=1e-4, metres=2e-4, logits=3e-3, gsamp=6e-2, gnorm=1.5e-2)}
 
 
+@pytest.mark.parametrize("route", ["fused", "registry"])
 @pytest.mark.parametrize("dtype", ["bf16x3", "f32"])
 @pytest.mark.parametrize("tag", ["g224", "g256"])
-def test_f32_path_matches_reference_golden(golden_dir, tag, dtype):
+def test_f32_path_matches_reference_golden(golden_dir, tag, dtype, route):
+    """route: `Criterion.compute_losses` through the fused pose/loss kernel (the default when the predictions come from the
+    HIP model) or through the registry losses' torch ops + autograd."""
     g = np.load(os.path.join(golden_dir, f"learner_{tag}.npz"))
     size, heat, depth, B, seed = [int(x) for x in g["meta"]]
     model, crit, params = build(size, heat, dtype, seed)
+    crit.fused_route = route == "fused"
     hb = model.model_list[0]
     batch = make_batch(B, size, seed + 100)
     # ---- eval
@@ -81,6 +85,7 @@ def test_f32_path_matches_reference_golden(golden_dir, tag, dtype):
     random.seed(seed + 7)
     torch.manual_seed(seed + 7)
     total, losses = crit.compute_losses(preds, batch)
+    assert (type(total.grad_fn).__name__ == "_FusedLossFnBackward") == (route == "fused")
     for k in ("joints_3d_loss", "corners_3d_loss", "joint_ord_loss", "part_ord_loss", "scene_ord_loss", "final_loss"):
         np.testing.assert_allclose(losses[k].detach().cpu().numpy().reshape(-1), g[f"loss.{k}"].reshape(-1),
                                    rtol=3e-4, atol=1e-7, err_msg=k)
@@ -135,3 +140,52 @@ def test_bf16_path_tolerance(golden_dir):
     ref = dict(zip([str(n) for n in g["grad.names"]], g["grad.norms"]))
     bad = [(n, float(grads[n].norm()), r) for n, r in ref.items() if abs(float(grads[n].norm()) - r) > 0.35 * r + 1e-9]
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
+def test_segment_graphs_equal_eager_loop(dtype):
+    """The reference-shaped loop (model(batch) -> compute_losses -> backward -> clip_grad_norm_ -> optimizer.step) with the
+    network halves replayed as hipGraphs (models._NetSegment, the default) is the same sequence of updates, bit for bit, as
+    the kernel-by-kernel eager loop; eval-mode forwards in between do not disturb it.  (torch's deterministic algorithms
+    are switched on for the comparison: the autograd backward of the registry losses otherwise accumulates with float atomics
+    and two EAGER runs already differ in the last bits.)"""
+    from artiboost_amd.netutils import build_optimizer
+    size, heat, B, seed, steps = 64, 8, 4, 11, 5
+    runs = {}
+    det = torch.are_deterministic_algorithms_enabled()
+    torch.use_deterministic_algorithms(True)
+    try:
+        _segment_runs(runs, size, heat, B, seed, steps, dtype, build_optimizer)
+    finally:
+        torch.use_deterministic_algorithms(det)
+    assert runs[False][0] == runs[True][0]
+    assert all(torch.equal(a, b) for a, b in zip(runs[False][1], runs[True][1]))
+    assert torch.equal(runs[False][2], runs[True][2]) and torch.equal(runs[False][3], runs[True][3])
+
+
+def _segment_runs(runs, size, heat, B, seed, steps, dtype, build_optimizer):
+    for seg in (False, True):
+        model, crit, _ = build(size, heat, dtype, seed, SEGMENT_GRAPHS=seg)
+        hb = model.model_list[0]
+        assert hb.segment_graphs is seg
+        opt = build_optimizer(model.models_params, OPTIMIZER="adam", LR=1e-4, WEIGHT_DECAY=0)
+        losses, evals = [], []
+        for it in range(steps):
+            batch = make_batch(B, size, seed + 100 + it)
+            model.train()
+            preds = model(batch)["HybridBaseline"]
+            random.seed(seed + it)
+            torch.manual_seed(seed + it)
+            total, _ = crit.compute_losses(preds, batch)
+            opt.zero_grad()
+            total.backward()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.001)
+            opt.step()
+            losses.append(float(total))
+            model.eval()
+            with torch.no_grad():
+                evals.append(model(make_batch(B, size, seed + 500 + it))["HybridBaseline"]["joints_3d_abs"].cpu())
+        if seg:
+            segs = list(hb._segments.values())
+            assert len(segs) == 2 and all(s.fwd is not None for s in segs) and any(s.bwd is not None for s in segs)
+        runs[seg] = (losses, evals, hb.store.flat.detach().cpu().clone(), hb.store.stats.cpu().clone())
