@@ -44,8 +44,15 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsig
 // instead of the 1/16 the f32-input MFMA gives.  LDS geometry is unchanged: a 128-byte row now carries a 32-channel
 // chunk as [hi: 4 x 16 B][lo: 4 x 16 B], so logical slots 0..3 are the hi k-slices and 4..7 the lo ones; only the fill
 // source (plane select per lane) and the MFMA sequence differ.  Output, addend and BN partials are fp32.
+//
+// X3 = 2: X3 data-gradient launch whose output is the gradient arriving at  relu(bn(bn_y) [+ residual]):  the epilogue masks
+// it (dz), stores dz instead of the raw gradient and leaves the BatchNorm-backward partial sums (sum dz, sum dz*xhat) per
+// tile in bn_part -- the standalone reduction pass over (dout, y, mask) disappears.  The tile of bn_y (and of the mask
+// plane / the addend) this thread will need is requested at kernel entry and sits in registers while the K loop runs,
+// so the epilogue adds arithmetic only (exposed reads at the end of a workgroup were what made the bf16 variant lose).
 template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
+    constexpr bool BNR = X3 == 2;
     constexpr int CK = X3 ? 32 : 64;                   // channels per K chunk
     // NW = WM*WN waves (4 or 8).  Measured (tools/probe_fill.hip): a wave pulls ~10 GB/s of L2-resident data into LDS
     // whatever its queue depth, and a CU's fill rate scales with the number of waves issuing loads (4 waves 10 TB/s
@@ -83,6 +90,37 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
     const bf16_t* zp = (const bf16_t*)c3_zero_page;
     const int nchunks = g.C / CK;
     const unsigned lds0 = lds_addr_of(smem);
+
+    // ---- X3 = 2: this thread's share of the BatchNorm operands of the epilogue (rows er0 + k*ERS, channels ec4*4 .. +3)
+    constexpr int ECPR = BN / 4, ERS = NT / ECPR, ER = BNR ? BM / ERS : 1;
+    constexpr bool EPRE = BNR && ER <= 8;               // held in registers from here on (the 256-pixel tile has none to spare)
+    const int ec4 = tid % ECPR, er0 = tid / ECPR;
+    float4 e_y[EPRE ? ER : 1], e_add[EPRE ? ER : 1];
+    uint2 e_m[EPRE ? ER : 1];
+    float e_mean[4], e_istd[4], e_sc[4], e_sh[4];
+    if constexpr (BNR) {
+        const int col = n0 + ec4 * 4;
+        const bool cok = col < g.Cn;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            e_sc[k] = cok ? g.bnp[col + k] : 0.f; e_sh[k] = cok ? g.bnp[g.Cn + col + k] : 0.f;
+            e_mean[k] = cok ? g.bnp[2 * g.Cn + col + k] : 0.f; e_istd[k] = cok ? g.bnp[3 * g.Cn + col + k] : 0.f;
+        }
+        if constexpr (EPRE) {
+#pragma unroll
+            for (int k = 0; k < ER; ++k) {
+                const int row = er0 + k * ERS;
+                const int yy = ty0 + row / TW, xx = tx0 + row % TW;
+                e_y[k] = make_float4(0.f, 0.f, 0.f, 0.f); e_add[k] = e_y[k]; e_m[k] = make_uint2(0u, 0u);
+                if (yy < g.H && xx < g.W && cok) {
+                    const long o = (((long)img * g.H + yy) * g.W + xx) * g.Cn + col;
+                    e_y[k] = *(const float4*)((const float*)g.bn_y + o);
+                    if (g.bn_out) e_m[k] = *(const uint2*)((const bf16_t*)g.bn_out + o);
+                    if (g.addend) e_add[k] = *(const float4*)((const float*)g.addend + o);
+                }
+            }
+        }
+    }
 
     // ---- per-lane load assignment
     const bf16_t* p_src[LP];                           // chunk-0 source of this lane's patch fills (zero page when outside)
@@ -272,6 +310,39 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         constexpr int CPRF = BN / 4;                          // 16-byte chunks (4 channels) per tile row
         static_assert(NT % CPRF == 0, "a thread keeps one channel group over all its rows");
         float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (BNR) {
+            const float* __restrict__ BnY = (const float*)g.bn_y;
+            const bf16_t* __restrict__ BnM = (const bf16_t*)g.bn_out;
+            const int col = n0 + ec4 * 4;
+#pragma unroll
+            for (int k = 0; k < ER; ++k) {
+                const int row = er0 + k * ERS;
+                const int yy = ty0 + row / TW, xx = tx0 + row % TW;
+                if (yy < g.H && xx < g.W && col < g.Cn) {
+                    const float4 v4 = *(const float4*)(smem + row * SPF + ec4 * 16);
+                    const long o = (((long)img * g.H + yy) * g.W + xx) * g.Cn + col;
+                    float4 y4, a4; uint2 m2;
+                    if constexpr (EPRE) { y4 = e_y[k]; a4 = e_add[k]; m2 = e_m[k]; }
+                    else {
+                        y4 = *(const float4*)(BnY + o);
+                        a4 = AddF ? *(const float4*)(AddF + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        m2 = BnM ? *(const uint2*)(BnM + o) : make_uint2(0u, 0u);
+                    }
+                    float v[4] = {v4.x + a4.x, v4.y + a4.y, v4.z + a4.z, v4.w + a4.w};
+                    const float y[4] = {y4.x, y4.y, y4.z, y4.w};
+                    const float m[4] = {__uint_as_float(m2.x << 16), __uint_as_float(m2.x & 0xffff0000u),
+                                        __uint_as_float(m2.y << 16), __uint_as_float(m2.y & 0xffff0000u)};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // mask: the stored activation's hi plane, or bn_apply's own expression on y (no residual was added)
+                        const bool dead = BnM ? !(m[i] > 0.f) : !(y[i] * e_sc[i] + e_sh[i] > 0.f);
+                        v[i] = dead ? 0.f : v[i];
+                        fs[i] += v[i]; fq[i] += v[i] * ((y[i] - e_mean[i]) * e_istd[i]);
+                    }
+                    *(float4*)(OutF + o) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        } else
         for (int id = tid; id < BM * CPRF; id += NT) {
             const int row = id / CPRF, c4 = id - row * CPRF;
             const int yy = ty0 + row / TW, xx = tx0 + row % TW, col = n0 + c4 * 4;
@@ -285,7 +356,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             }
         }
         __syncthreads();
-        if (g.stats) {
+        float* part_out = BNR ? g.bn_part : g.stats;
+        if (part_out) {
             float* sp = (float*)smem;                          // [NT / CPRF][BN][2], over the consumed staging tile
             const int rg = tid / CPRF, cb = (tid % CPRF) * 4;
 #pragma unroll
@@ -296,8 +368,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
                 if (col < g.Cn) {
                     float s2 = 0.f, q2 = 0.f;
                     for (int r = 0; r < NT / CPRF; ++r) { s2 += sp[(r * BN + c) * 2]; q2 += sp[(r * BN + c) * 2 + 1]; }
-                    g.stats[((long)tile_sp * g.Cn + col) * 2] = s2;
-                    g.stats[((long)tile_sp * g.Cn + col) * 2 + 1] = q2;
+                    part_out[((long)tile_sp * g.Cn + col) * 2] = s2;
+                    part_out[((long)tile_sp * g.Cn + col) * 2 + 1] = q2;
                 }
             }
         }
@@ -528,8 +600,10 @@ int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn) {
 }
 
 int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W,
-                   int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st) {
+                   int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st, const float* bn_y,
+                   const void* bn_out_hi, const float* bnp, float* bn_part) {
     if (C % 32) return AB_ESHAPE;
+    if (bn_y && (!flip || stats || !bnp || !bn_part)) return AB_EINVAL;
     int cfg = c3_config(N, H, W, (C + 63) / 64 * 64, Cn);
     if (!cfg || Cn % 4) return AB_ESHAPE;
     const long delta = (const char*)wt_lo - (const char*)wt_hi;
@@ -537,6 +611,15 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
     Conv3Args g = {};
     g.X = x_hi; g.X_lo = x_lo; g.Wt = wt_hi; g.wlo_delta = (unsigned)delta; g.Out = out; g.addend = addend; g.stats = stats;
     g.N = N; g.H = H; g.W = W; g.C = C; g.Cn = Cn; g.ktot = 9 * C; g.flip = flip;
+    g.bn_y = bn_y; g.bn_out = bn_out_hi; g.bnp = bnp; g.bn_part = bn_part;
+    if (bn_y) {      // masked gradient + BatchNorm-backward partials from the epilogue
+        if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, 1, 2>(g, st);
+        if (cfg == 2) return c3_launch<256, 32, 128, 4, 2, 1, 2>(g, st);
+        if (cfg == 3) return c3_launch<128, 16, 128, 4, 2, 1, 2>(g, st);
+        if (cfg == 5) return c3_launch<64, 8, 128, 2, 4, 1, 2>(g, st);
+        if (cfg == 6) return c3_launch<256, 16, 64, 4, 2, 1, 2>(g, st);
+        return c3_launch<128, 16, 64, 4, 2, 1, 2>(g, st);
+    }
 #define C3X_GO(FL) \
     do { \
         if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, FL, 1>(g, st); \

@@ -11,7 +11,8 @@
 
 int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn);
 int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W,
-                   int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st);
+                   int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st, const float* bn_y = nullptr,
+                   const void* bn_out_hi = nullptr, const float* bnp = nullptr, float* bn_part = nullptr);
 int conv_gemm2_x3_mtiles(int M, int Cn, int nsteps, int nclass);
 int conv_gemm2_x3_run(ConvGemmArgs& g, hipStream_t st);
 int wgrad3x3_x3_slices(int N, int H, int W, int Cin, int Cout);
@@ -143,6 +144,24 @@ extern "C" int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const vo
     }
     g.ntaps = nt;
     return conv_gemm2_x3_run(g, as_stream(stream));
+}
+
+// Data gradient whose result is the gradient arriving at  relu(bn(bn_y) [+ residual])  (resnet.py:85-101 backwards): dx receives
+// the MASKED gradient dz (mask from bn_out_hi, the hi plane of the stored activation, or recomputed from bn_y when NULL) and
+// bn_part [rows][Cin][2] the per-tile sums (sum dz, sum dz*xhat) that ab_bn_bwd_x3 takes as `part` -- the reduction pass
+// of that BatchNorm backward is gone.  rows = ab_conv2d_dgrad_x3_bn_rows(...); 0: shape not handled (use ab_conv2d_dgrad_x3).
+extern "C" int ab_conv2d_dgrad_x3_bn_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+    if (!x3_is_c3(kh, kw, stride, pad) || getenv("AB_X3_BNFUSE_OFF")) return 0;
+    return conv3x3_x3_tiles(N, H, W, Cout, Cin);
+}
+
+extern "C" int ab_conv2d_dgrad_x3_bn(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dz, int N,
+                                     int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend,
+                                     const float* bn_y, const void* bn_out_hi, const float* bnp, float* bn_part, void* stream) {
+    if (!dy_hi || !dy_lo || !wt_hi || !wt_lo || !dz || !bn_y || !bnp || !bn_part) return AB_EINVAL;
+    if (!ab_conv2d_dgrad_x3_bn_rows(N, H, W, Cin, Cout, kh, kw, stride, pad)) return AB_ESHAPE;
+    return conv3x3_x3_run(dy_hi, dy_lo, wt_hi, wt_lo, dz, N, H, W, Cout, Cin, 1, addend, nullptr, as_stream(stream), bn_y,
+                          bn_out_hi, bnp, bn_part);
 }
 
 // ---------------------------------------------------------------- weight gradient

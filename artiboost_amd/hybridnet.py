@@ -343,8 +343,7 @@ class HybridNet:
 
     def _conv_dgrad(self, dy, name, in_hw, stride, pad, addend=None, bn=None, want_stats=False):
         if self.x3:
-            r = K.conv2d_dgrad_x3(dy, self.tr[name], in_hw, stride, pad, addend=addend, want_stats=want_stats)
-            return (r, None) if bn is not None else r
+            return K.conv2d_dgrad_x3(dy, self.tr[name], in_hw, stride, pad, addend=addend, want_stats=want_stats, bn=bn)
         return K.conv2d_dgrad(dy, self.tr[name], in_hw, stride, pad, addend=addend, bn=bn, want_stats=want_stats)
 
     def _conv_wgrad(self, x, dy, kh, kw, stride, pad, out=None, **kws):
@@ -371,8 +370,11 @@ class HybridNet:
         return out, bnp
 
     def _bn_bwd(self, *a, **kw):
-        """BatchNorm backward; the gradient wrt the conv output goes to convolutions only: split planes under bf16x3."""
-        return (K.bn_bwd_x3 if self.x3 else K.bn_bwd)(*a, **kw)
+        """BatchNorm backward; the gradient wrt the conv output goes to convolutions only: split planes under bf16x3.
+        bf16x3 with `part`: the data gradient that produced the input already masked and reduced it (conv3x3.hip, X3 = 2)."""
+        if self.x3:
+            return K.bn_bwd_x3(*a, premasked=kw.get("part") is not None, **kw)
+        return K.bn_bwd(*a, **kw)
 
     # ------------------------------------------------------------------ forward
     def forward(self, image=None, xpad=None):

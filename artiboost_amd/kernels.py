@@ -415,8 +415,12 @@ def conv2d_fwd_x3(x, w_split, stride, pad, bias=None, want_stats=False, relu=Fal
     return (y, stats) if want_stats else y
 
 
-def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=False):
-    """dy: fp32 / split [.., N,Ho,Wo,Cout]; wt_split [2,Cin,kh,kw,Cout] -> dx fp32 [N,H,W,Cin] (+ BN partials of dx)."""
+def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=False, bn=None):
+    """dy: fp32 / split [.., N,Ho,Wo,Cout]; wt_split [2,Cin,kh,kw,Cout] -> dx fp32 [N,H,W,Cin] (+ BN partials of dx).
+
+    bn=(bn_y, bn_out_or_None, bnp): dx is the gradient arriving at relu(bn(bn_y) [+ residual]).  Returns (dx, part): where the
+    kernel can, dx is already MASKED (dz) and `part` holds the BatchNorm-backward partial sums of its epilogue (pass it to
+    bn_bwd_x3(part=..., premasked=True)); otherwise part is None and dx the raw gradient."""
     dh, dl = _planes(dy)
     N, Ho, Wo, Cout = dh.shape
     _, Cin, kh, kw, _ = wt_split.shape
@@ -424,6 +428,23 @@ def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=Fa
     dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dh.device)
     lib = L.lib()
     part = None
+    if bn is not None:
+        bn_y, bn_out, bnp = bn
+        rows = lib.ab_conv2d_dgrad_x3_bn_rows(L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad))
+        mask = None
+        if bn_out is not None:
+            sp = getattr(bn_out, "_ab_split", None)
+            if sp is None:
+                rows = 0                   # the mask is read from the hi plane of the stored activation
+            else:
+                mask = sp[0]
+        if rows > 0:
+            part = torch.empty((rows, Cin, 2), dtype=torch.float32, device=dh.device)
+            L.check(lib.ab_conv2d_dgrad_x3_bn(L.ptr(dh), L.ptr(dl), L.ptr(wt_split[0]), L.ptr(wt_split[1]), L.ptr(dx), L.i(N),
+                                              L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad),
+                                              L.ptr(addend), L.ptr(bn_y), L.ptr(mask), L.ptr(bnp), L.ptr(part), L.stream()),
+                    "ab_conv2d_dgrad_x3_bn")
+            return dx, part
     if want_stats and addend is None:
         rows = lib.ab_conv2d_dgrad_x3_stat_rows(L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad))
         if rows > 0:
@@ -433,7 +454,7 @@ def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=Fa
                                    L.stream()), "ab_conv2d_dgrad_x3")
     if want_stats:
         return dx, (part if part is not None else col_stats(dx))
-    return dx
+    return (dx, None) if bn is not None else dx
 
 
 def conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=None, accumulate=False):
@@ -468,8 +489,13 @@ def bn_apply_x3(y, bnp, res=None, relu=True, want_f32=False):
     return o
 
 
-def bn_bwd_x3(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, part=None):
-    """As bn_bwd on fp32 tensors, with dy returned as split planes [2, *y.shape] (-> dy [, dz fp32])."""
+def bn_bwd_x3(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, part=None, premasked=False):
+    """As bn_bwd on fp32 tensors, with dy returned as split planes [2, *y.shape] (-> dy [, dz fp32]).
+    premasked (with part): `dout` is already the masked gradient dz and `part` its reduction (conv2d_dgrad_x3(bn=...))."""
+    if premasked:
+        assert part is not None
+        dy = bn_bwd_x3(dout, None, y, bnp, dgamma, dbeta, relu=False, part=part)
+        return (dy, dout) if want_dz else dy
     C = y.shape[-1]
     M = y.numel() // C
     lib = L.lib()

@@ -199,3 +199,51 @@ def test_plane_producers_match_split_of_fp32_results():
     plan = K.transpose_plan([(w, dst[0].view(32, 9, 64))])
     K.transpose_oki_batch_x3(plan, dst.shape[1])
     assert torch.equal(dst.view(2, 32, 9, 64), K.split(w.permute(2, 1, 0).contiguous()))
+
+
+BN_CASES = [(2, 16, 16, 64, 64), (1, 7, 7, 512, 512), (5, 6, 6, 256, 256), (2, 32, 32, 64, 64), (1, 28, 28, 128, 128),
+            (3, 14, 14, 256, 256), (2, 56, 40, 64, 64), (2, 64, 64, 128, 128), (2, 16, 16, 256, 256), (2, 8, 8, 512, 512)]
+
+
+@pytest.mark.parametrize("mask_src", ["recompute", "hi_plane"])
+@pytest.mark.parametrize("case", BN_CASES)
+def test_conv_dgrad_x3_bn_fused(case, mask_src):
+    """ab_conv2d_dgrad_x3_bn: the data gradient of a 3x3 conv, masked by the ReLU of the BatchNorm it arrives at, with that
+    BatchNorm's backward partial sums from the epilogue -- against float64 torch, and the BatchNorm backward built on the
+    partials against the one that runs its own reduction pass."""
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(hash(case) % 991)
+    w = (torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (Cin * 9)) ** 0.5).double()
+    dy = torch.randn((N, Cout, H, W), generator=g).double()
+    add = torch.randn((N, Cin, H, W), generator=g)
+    ref_dx = F.conv_transpose2d(dy, w, stride=1, padding=1) + add.double()             # data gradient + skip gradient
+    ybn = torch.randn((N, H, W, Cin), generator=g) * 2 + 0.3                              # the conv output the BatchNorm saw
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    stats = K.col_stats(ybn.cuda())
+    bnp = K.bn_finalize(stats, N * H * W, gamma.cuda(), beta.cuda(), torch.zeros(Cin).cuda(), torch.ones(Cin).cuda())
+    res = torch.randn((N, H, W, Cin), generator=g) if mask_src == "hi_plane" else None
+    out = K.bn_apply_x3(ybn.cuda(), bnp, res=res.cuda() if res is not None else None, relu=True, want_f32=True)
+    wt = K.split(w.float().permute(1, 2, 3, 0).contiguous().cuda())
+    dyd = nhwc(dy.float()).cuda()
+    dz, part = K.conv2d_dgrad_x3(dyd, wt, (H, W), 1, 1, addend=nhwc(add).cuda(), bn=(ybn.cuda(), out if res is not None else None, bnp))
+    assert part is not None
+    mask = (out.cpu() > 0).double()
+    ref_dz = nhwc(ref_dx) * mask
+    close(dz.cpu(), ref_dz)
+    mean, istd = bnp[2].double().cpu(), bnp[3].double().cpu()
+    xhat = (ybn.double() - mean) * istd
+    sums = part.double().sum(0).cpu()
+    scale = float(ref_dz.abs().sum((0, 1, 2)).max())
+    np.testing.assert_allclose(sums[:, 0].numpy(), ref_dz.sum((0, 1, 2)).numpy(), rtol=1e-4, atol=3e-5 * scale)
+    np.testing.assert_allclose(sums[:, 1].numpy(), (ref_dz * xhat).sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-4 * scale)
+    # BatchNorm backward on (dz, part) == the standalone one on the raw gradient
+    dg1, db1, dg2, db2 = (torch.zeros(Cin).cuda() for _ in range(4))
+    dy1 = K.bn_bwd_x3(dz, None, ybn.cuda(), bnp, dg1, db1, part=part, premasked=True)
+    raw = K.conv2d_dgrad_x3(dyd, wt, (H, W), 1, 1, addend=nhwc(add).cuda())
+    dy2 = K.bn_bwd_x3(raw, out if res is not None else None, ybn.cuda(), bnp, dg2, db2, relu=True if res is not None else "recompute")
+    a = dy1[0].float() + dy1[1].float()
+    b = dy2[0].float() + dy2[1].float()
+    close(a.cpu(), b.double().cpu(), tol=2e-5)
+    np.testing.assert_allclose(dg1.cpu().numpy(), dg2.cpu().numpy(), rtol=2e-4, atol=1e-4 * float(dg2.abs().max()))
+    np.testing.assert_allclose(db1.cpu().numpy(), db2.cpu().numpy(), rtol=2e-4, atol=1e-4 * float(db2.abs().max()))
