@@ -506,7 +506,14 @@ static size_t c3_lds(int nchunks) {
 // 5 = <64,8,128,2,2>
 static int c3_config(int N, int H, int W, int C, int Cn) {
     if (C % 64 || Cn % 8 || getenv("AB_CONV3_OFF")) return 0;
-    if (W >= 24) return (Cn <= 64) ? 1 : 2;
+    if (W >= 24) {
+        // 64 output channels: a 256-pixel tile (64 x 32 per wave: 1 KB of fragment reads per MFMA instead of 1.33) where that
+        // still leaves every CU two workgroups -- layer 1 at B = 64: 10.66 -> 10.54 ms/step in bf16x3.  AB_C3_L1ALT=0: 128 pixels.
+        // (=2: whatever the tile count -- tests)
+        const int alt1 = getenv("AB_C3_L1ALT") ? atoi(getenv("AB_C3_L1ALT")) : 1;
+        if (alt1 && Cn <= 64 && (alt1 == 2 || (long)N * ((H + 7) / 8) * ((W + 31) / 32) >= 512)) return 7;
+        return (Cn <= 64) ? 1 : 2;
+    }
     if (W >= 12) {
         static const int alt = getenv("AB_C3_ALT16") ? atoi(getenv("AB_C3_ALT16")) : 0;
         if (alt && W <= 16 && H % 16 == 0 && Cn % 64 == 0) return 6;      // whole 16x16 image x 64 channels per workgroup
@@ -521,6 +528,7 @@ static void c3_geom(int cfg, int* bm, int* tw, int* bn) {
     else if (cfg == 3) { *bm = 128; *tw = 16; *bn = 128; }
     else if (cfg == 5) { *bm = 64; *tw = 8; *bn = 128; }
     else if (cfg == 6) { *bm = 256; *tw = 16; *bn = 64; }
+    else if (cfg == 7) { *bm = 256; *tw = 32; *bn = 64; }
     else { *bm = 128; *tw = 16; *bn = 64; }
 }
 
@@ -567,6 +575,7 @@ int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, i
     static const int w8 = getenv("AB_C3_W8") ? atoi(getenv("AB_C3_W8")) : 2;     // 0: 4 waves, 1: 8 waves, 2: 8 (16 for the 256-pixel tile)
 #define C3_GO(FL) \
     do { \
+        if (cfg == 7) return c3_launch<256, 32, 64, 4, 2, FL>(g, st); \
         if (w8 == 2) { \
             if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, FL>(g, st); \
             if (cfg == 2) return c3_launch<256, 32, 128, 4, 4, FL>(g, st); \
@@ -618,6 +627,7 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
         if (cfg == 3) return c3_launch<128, 16, 128, 4, 2, 1, 2>(g, st);
         if (cfg == 5) return c3_launch<64, 8, 128, 2, 4, 1, 2>(g, st);
         if (cfg == 6) return c3_launch<256, 16, 64, 4, 2, 1, 2>(g, st);
+        if (cfg == 7) return c3_launch<256, 32, 64, 4, 2, 1, 2>(g, st);
         return c3_launch<128, 16, 64, 4, 2, 1, 2>(g, st);
     }
 #define C3X_GO(FL) \
@@ -627,6 +637,7 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
         if (cfg == 3) return c3_launch<128, 16, 128, 4, 2, FL, 1>(g, st); \
         if (cfg == 5) return c3_launch<64, 8, 128, 2, 4, FL, 1>(g, st); \
         if (cfg == 6) return c3_launch<256, 16, 64, 4, 2, FL, 1>(g, st); \
+        if (cfg == 7) return c3_launch<256, 32, 64, 4, 2, FL, 1>(g, st); \
         return c3_launch<128, 16, 64, 4, 2, FL, 1>(g, st); \
     } while (0)
     if (flip) C3X_GO(1);

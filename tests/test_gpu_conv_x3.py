@@ -247,3 +247,34 @@ def test_conv_dgrad_x3_bn_fused(case, mask_src):
     close(a.cpu(), b.double().cpu(), tol=2e-5)
     np.testing.assert_allclose(dg1.cpu().numpy(), dg2.cpu().numpy(), rtol=2e-4, atol=1e-4 * float(dg2.abs().max()))
     np.testing.assert_allclose(db1.cpu().numpy(), db2.cpu().numpy(), rtol=2e-4, atol=1e-4 * float(db2.abs().max()))
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 64), (2, 56, 40, 64, 64), (3, 32, 32, 64, 64)])
+def test_conv3x3_x3_256x64_tile(case, monkeypatch):
+    """The 256-pixel x 64-channel tile of the 64-channel 3x3 layers (picked on its own only when the launch has >= 512 tiles,
+    i.e. at benchmark size) forced onto small shapes: forward + statistics, data gradient, fused BatchNorm-backward epilogue."""
+    from artiboost_amd import kernels as K
+    monkeypatch.setenv("AB_C3_L1ALT", "2")
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(hash(case) % 983)
+    x = torch.randn((N, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    y, stats = K.conv2d_fwd_x3(nhwc(x).cuda(), K.split(w.permute(0, 2, 3, 1).contiguous().cuda()), 1, 1, want_stats=True)
+    close(nchw(y.cpu()), ref)
+    assert stats.shape[0] == N * ((H + 7) // 8) * ((W + 31) // 32)          # one partial row per 8 x 32 tile: the new geometry ran
+    yy = y.double().cpu().reshape(-1, Cout)
+    np.testing.assert_allclose(stats.double().sum(0).cpu()[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)
+    dy = torch.randn((N, Cout, H, W), generator=g)
+    add = torch.randn((N, Cin, H, W), generator=g)
+    wt = K.split(w.permute(1, 2, 3, 0).contiguous().cuda())
+    ref_dx = F.conv_transpose2d(dy.double(), w.double(), padding=1) + add.double()
+    dx = K.conv2d_dgrad_x3(nhwc(dy).cuda(), wt, (H, W), 1, 1, addend=nhwc(add).cuda())
+    close(nchw(dx.cpu()), ref_dx)
+    ybn = torch.randn((N, H, W, Cin), generator=g)
+    bnp = K.bn_finalize(K.col_stats(ybn.cuda()), N * H * W, torch.ones(Cin).cuda(), torch.zeros(Cin).cuda(), torch.zeros(Cin).cuda(), torch.ones(Cin).cuda())
+    dz, part = K.conv2d_dgrad_x3(nhwc(dy).cuda(), wt, (H, W), 1, 1, addend=nhwc(add).cuda(), bn=(ybn.cuda(), None, bnp))
+    ref_dz = nhwc(ref_dx) * (((ybn - bnp[2].cpu()) * bnp[3].cpu()) > 0).double()
+    close(dz.cpu(), ref_dz)
+    np.testing.assert_allclose(part.double().sum(0).cpu()[:, 0].numpy(), ref_dz.sum((0, 1, 2)).numpy(), rtol=1e-4,
+                               atol=3e-5 * float(ref_dz.abs().sum((0, 1, 2)).max()))

