@@ -85,8 +85,7 @@ class Criterion(TensorLoss):
         cache = self.__dict__.setdefault("_fused_cache", {})
         if key not in cache:
             try:
-                f = FusedPoseCriterion(self, link["inp_res"], link["center_idx"])
-                cache[key] = None if f.sym is not None else f      # SymCornerLoss needs obj_idx / obj_transf: registry path
+                cache[key] = FusedPoseCriterion(self, link["inp_res"], link["center_idx"])
             except NotImplementedError:
                 cache[key] = None
         return cache[key]
@@ -106,9 +105,15 @@ class Criterion(TensorLoss):
             if not torch.is_tensor(v):
                 return None
             t[k] = v.to(device=dev, dtype=torch.float32, non_blocking=True).contiguous()
+        if fused.sym is not None:                            # SymCornerLoss: the object's class index and pose
+            for k, dt in ((Queries.OBJ_IDX, torch.int64), (Queries.OBJ_TRANSF, torch.float32)):
+                v = targs.get(k)
+                if not torch.is_tensor(v):
+                    return None
+                t[k] = v.to(device=dev, dtype=dt, non_blocking=True).contiguous()
         if not all(l.draws.frozen for l in self.loss_list if hasattr(l, "draws")):
             self.draw(dev)                                   # reference RNG order: the losses' draws in list order
-        total, vals = _FusedLossFn.apply(kp3d, box6d, fused, t)
+        total, vals, sym = _FusedLossFn.apply(kp3d, box6d, fused, t)
         out = {}
         for loss in self.loss_list:                          # the entries each registry class reports
             if isinstance(loss, JointsLoss):
@@ -120,6 +125,9 @@ class Criterion(TensorLoss):
                 out[loss.output_key] = loss.lambda_joint_lev * vals[2] + loss.lambda_part_lev * vals[3]
             elif isinstance(loss, SceneOrdLoss):
                 out["scene_ord_loss"] = vals[4]
+            elif isinstance(loss, SymCornerLoss):
+                out["sym_corners_3d_loss"] = sym[0] if loss.lambda_sym_corners_3d else None
+                out[loss.output_key] = loss.lambda_sym_corners_3d * sym[0]
         out["final_loss"] = total
         return total, out
 
@@ -209,9 +217,9 @@ class _DrawArena:
                 off += (t.numel() * t.element_size() + 15) // 16 * 16
             self.layout = (sig, offs, off)
             self.dev_buf = torch.empty(max(off, 16), dtype=torch.uint8, device=dev)
-            for (o, n, t), b in zip(self.items, offs):
-                nb = t.numel() * t.element_size()
-                o.bufs[n] = self.dev_buf[b:b + nb].view(t.dtype).view(t.shape)
+            self.views = [self.dev_buf[b:b + t.numel() * t.element_size()].view(t.dtype).view(t.shape) for (_, _, t), b in zip(self.items, offs)]
+        for (o, n, _), v in zip(self.items, self.views):      # (re)bind every step: a loss called on its own in between
+            o.bufs[n] = v                                       # (registry route) works on private buffers, see _Draws.put
         _, offs, total = self.layout
         pack = torch.empty(max(total, 16), dtype=torch.uint8)
         for (_, _, t), b in zip(self.items, offs):
@@ -236,7 +244,9 @@ class _Draws:
             self.arena.add(self, name, cpu_tensor)
             return None
         b = self.bufs.get(name)
-        if b is None or b.shape != cpu_tensor.shape:      # buffers are persistent: a captured hipGraph holds their addresses
+        # buffers are persistent (a captured hipGraph holds their addresses) -- but never a view of the arena here: the
+        # arena's views share one version counter, and an in-place refresh of one would invalidate what autograd saved of another
+        if b is None or b.shape != cpu_tensor.shape or b._base is not None:
             b = torch.empty(cpu_tensor.shape, dtype=cpu_tensor.dtype, device=dev)
             self.bufs[name] = b
         src = cpu_tensor.pin_memory() if dev.type == "cuda" else cpu_tensor
@@ -408,13 +418,13 @@ class _FusedLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kp3d, box6d, fused, targs):
         o = fused(kp3d.detach().contiguous(), box6d.detach().contiguous(), box6d.shape[-1], targs, backward=True)
-        vals = o["losses"].clone()
+        vals, sym = o["losses"].clone(), o["sym_loss"].clone()
         ctx.save_for_backward(o["g_kp3d"].clone(), o["g_box6d"].clone())
-        ctx.mark_non_differentiable(vals)
-        return vals[5].clone(), vals
+        ctx.mark_non_differentiable(vals, sym)
+        return vals[5].clone(), vals, sym
 
     @staticmethod
-    def backward(ctx, g_total, g_vals):
+    def backward(ctx, g_total, g_vals, g_sym):
         gk, gb = ctx.saved_tensors
         return gk * g_total, gb * g_total, None, None
 

@@ -145,3 +145,48 @@ def test_fused_symcorner_loss_vs_oracle(B, seed):
     np.testing.assert_allclose(o["g_kp3d"].cpu().numpy(), gk, rtol=2e-4, atol=2e-5 * np.abs(gk).max())
     gb = box6d.grad.numpy()
     np.testing.assert_allclose(o["g_box6d"].cpu().numpy(), gb, rtol=2e-4, atol=2e-5 * np.abs(gb).max())
+
+
+@pytest.mark.parametrize("with_sym", [False, True])
+def test_compute_losses_fused_route_equals_registry_route(with_sym):
+    """`Criterion.compute_losses` on predictions of the HIP model: the fused pose/loss kernel (default) and the registry
+    losses' torch ops + autograd give the same loss entries and the same gradient at the network's raw outputs."""
+    from artiboost_amd import registry as R_
+    from artiboost_amd.criterions import Criterion
+    from artiboost_amd.models import batch_uvd2xyz, ortho6d_to_rotmat
+    size, B, seed = 256, 16, 5
+    cfgc = [{"TYPE": "JointsLoss", "LAMBDA_JOINTS_3D": 1.0, "LAMBDA_CORNERS_3D": 0.2}, {"TYPE": "HandOrdLoss"}, {"TYPE": "SceneOrdLoss"}]
+    lambdas = [0.5, 0.2, 0.1]
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in make_batch(B, size, seed + 20).items()}
+    g = torch.Generator().manual_seed(seed)
+    if with_sym:
+        info = {str(i + 1): ({"symmetries_discrete": [[-1, 0, 0, 0, 0, -1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]]} if i % 3 == 1 else
+                             {"symmetries_continuous": [{"axis": [0, 0, 1], "offset": [0, 0, 0]}]} if i % 3 == 2 else {}) for i in range(21)}
+        cfgc = cfgc + [{"TYPE": "SymCornerLoss", "LAMBDA_SYM_CORNERS_3D": 0.7, "MODEL_INFO": info, "MAX_SYM_DISC_STEP": 0.05}]
+        lambdas = lambdas + [0.3]
+        batch["obj_idx"] = torch.randint(1, 22, (B,), generator=g).cuda()
+        T = torch.eye(4).repeat(B, 1, 1)
+        T[:, :3, :3] = lo.ortho6d_to_rotmat(torch.randn(B, 6, generator=g))
+        T[:, :3, 3] = batch["root_joint"].cpu() + 0.05 * torch.randn(B, 3, generator=g)
+        batch["obj_transf"] = T.cuda()
+    crit = Criterion({"LAMBDAS": lambdas}, R_.build_criterion_loss_list(cfgc, preset_cfg={}, LAMBDAS=lambdas))
+    kp0, box0 = torch.rand(B, 22, 3, generator=g), torch.randn(B, 6, generator=g)
+    res = {}
+    for route in ("fused", "registry"):
+        kp3d, box6d = kp0.clone().cuda().requires_grad_(True), box0.clone().cuda().requires_grad_(True)
+        pose = batch_uvd2xyz(kp3d, batch["root_joint"], batch["cam_intr"], [size, size])
+        corners = torch.matmul(ortho6d_to_rotmat(box6d), batch["corners_can"].permute(0, 2, 1)).permute(0, 2, 1) + pose[:, 21:22]
+        joints = pose[:, :21]
+        joints._ab_fuse = dict(kp3d=kp3d, box6d=box6d, inp_res=[size, size], center_idx=0)      # what HybridBaseline.forward attaches
+        crit.fused_route = route == "fused"
+        random.seed(seed + 3); torch.manual_seed(seed + 3)
+        total, losses = crit.compute_losses({"joints_3d_abs": joints, "corners_3d_abs": corners}, batch)
+        assert (type(total.grad_fn).__name__ == "_FusedLossFnBackward") == (route == "fused")
+        (2.0 * total).backward()
+        res[route] = ({k: float(v) for k, v in losses.items() if v is not None}, kp3d.grad.cpu().numpy(), box6d.grad.cpu().numpy())
+    a, b = res["fused"], res["registry"]
+    assert set(a[0]) == set(b[0])
+    for k in b[0]:
+        np.testing.assert_allclose(a[0][k], b[0][k], rtol=3e-5, atol=1e-9, err_msg=k)
+    np.testing.assert_allclose(a[1], b[1], rtol=3e-4, atol=3e-5 * np.abs(b[1]).max())
+    np.testing.assert_allclose(a[2], b[2], rtol=3e-4, atol=3e-5 * np.abs(b[2]).max())

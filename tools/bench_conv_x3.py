@@ -23,6 +23,9 @@ SHAPES = [  # name, H, W, Cin, Cout, k, stride, pad, calls per step
     ("deconv1-as-conv 4x4s2 256->512 @16", 16, 16, 256, 512, 4, 2, 1, 1),
     ("deconv2-as-conv 4x4s2 256->256 @32", 32, 32, 256, 256, 4, 2, 1, 1),
     ("final 1x1 256->704 @32", 32, 32, 256, 704, 1, 1, 0, 1),
+    # tile-shape probe: two 8x8 layer-4 images side by side as one 8x16 image (run with AB_C3_FORCE=4: 128 pixels x 64 channels
+    # per workgroup = the weight stream of a workgroup halved at the same 256-workgroup grid; timing only, not layer 4's maths)
+    ("probe l4 pair-tile 8x16 B32", 8, 16, 512, 512, 3, 1, 1, 0, 32),
 ]
 
 
@@ -43,9 +46,10 @@ only = sys.argv[1] if len(sys.argv) > 1 else ""
 what = sys.argv[2] if len(sys.argv) > 2 else "all"
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 tot = [0.0, 0.0, 0.0]
-for name, H, W, Ci, Co, k, s, p, cnt in SHAPES:
-    if only not in name:
+for name, H, W, Ci, Co, k, s, p, cnt, *rest in SHAPES:
+    if only not in name or (name.startswith("probe") and not only):
         continue
+    B = rest[0] if rest else 64
     x = K.split(torch.randn(B, H, W, Ci, device="cuda"))
     w = K.split(torch.randn(Co, k, k, Ci, device="cuda") * 0.05)
     wt = K.split((torch.randn(Ci, k, k, Co, device="cuda") * 0.05))
