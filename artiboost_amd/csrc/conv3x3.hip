@@ -507,6 +507,7 @@ static size_t c3_lds(int nchunks) {
 static int c3_config(int N, int H, int W, int C, int Cn) {
     if (C % 64 || Cn % 8 || getenv("AB_CONV3_OFF")) return 0;
     if (const char* f = getenv("AB_C3_FORCE")) return atoi(f);      // tile-shape probes (tools/bench_conv_x3.py)
+    if (const char* f = getenv("AB_C3_FORCE")) return atoi(f);      // tile-shape probes (tools/bench_conv_x3.py)
     if (W >= 24) {
         // 64 output channels: a 256-pixel tile (64 x 32 per wave: 1 KB of fragment reads per MFMA instead of 1.33) where that
         // still leaves every CU two workgroups -- layer 1 at B = 64: 10.66 -> 10.54 ms/step in bf16x3.  AB_C3_L1ALT=0: 128 pixels.
