@@ -13,7 +13,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 
 // TM x TN wave tile as in conv3x3 X3: per step 4*(TM+TN) fragment reads, 6*TM*TN MFMAs
-template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE>
+// AMODE 1: the pixel-side fragments are read from LDS on every third step only and derived by a DPP row shift (one v_mov_dpp
+// per dword) on the two steps in between -- what serving the three horizontal taps of a 3x3 window from ONE fragment read
+// would cost; AMODE 2: never re-read (upper bound: the weight-side reads alone).
+template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE, int AMODE = 0>
 __global__ __launch_bounds__(64 * NW) void step_loop(int iters, float* sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -38,15 +41,29 @@ __global__ __launch_bounds__(64 * NW) void step_loop(int iters, float* sink) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+    u32x4 fa[4][TM];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[k][i] = *(const lds_u32x4*)(a_rel[i][k]);
     for (int it = 0; it < iters; ++it) {
         if (BARRIER) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
         const unsigned off = (it % 3) * 16384;
-        u32x4 fa[4][TM], fb[4][TN];
+        u32x4 fb[4][TN];
         if (!INTERLEAVE) {
+            const bool rd = AMODE == 0 || ((AMODE == 1 || AMODE == 3) && it % 3 == 0);      // AMODE 3: re-read every third step, reuse as is
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                if (rd) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[k][i] = *(const lds_u32x4*)(a_rel[i][k] + (off >> 1));
+                    for (int i = 0; i < TM; ++i) fa[k][i] = *(const lds_u32x4*)(a_rel[i][k] + (off >> 1));
+                } else if (AMODE == 1) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            fa[k][i][c] = (unsigned)__builtin_amdgcn_update_dpp((int)fa[k][i][c], (int)fa[k][i][c], 0x111, 0xf, 0xf, false);
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[k][j] = *(const lds_u32x4*)(b_rel[j][k] + off);
             }
@@ -82,10 +99,10 @@ __global__ __launch_bounds__(64 * NW) void step_loop(int iters, float* sink) {
     if (s == 12345.678f) sink[0] = s;
 }
 
-template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE>
+template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE, int AMODE = 0>
 static void run(float* sink, const char* tag) {
     const int iters = 4000, blocks = 256;
-    auto k = step_loop<NW, TM, TN, BARRIER, INTERLEAVE>;
+    auto k = step_loop<NW, TM, TN, BARRIER, INTERLEAVE, AMODE>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     k<<<blocks, 64 * NW, 96 * 1024>>>(iters / 10, sink); CK(hipDeviceSynchronize());
@@ -108,5 +125,18 @@ int main() {
     run<4, 2, 2, 0, 0>(sink, "  no barrier");
     run<4, 2, 4, 1, 0>(sink, "4 waves, 2x4 per wave");
     run<16, 1, 1, 1, 0>(sink, "16 waves, 1x1 per wave");
+    run<8, 1, 2, 1, 0, 1>(sink, "l3 shape, pixel frags: 1 read + 2 DPP shifts");
+    run<8, 1, 2, 1, 0, 2>(sink, "l3 shape, pixel frags never re-read");
+    run<8, 2, 2, 1, 0, 1>(sink, "l2 shape, pixel frags: 1 read + 2 DPP shifts");
+    run<8, 2, 2, 1, 0, 2>(sink, "l2 shape, pixel frags never re-read");
+    run<8, 1, 1, 1, 0, 1>(sink, "l1/l4 shape, pixel frags: 1 read + 2 DPP shifts");
+    run<8, 1, 1, 1, 0, 2>(sink, "l1/l4 shape, pixel frags never re-read");
+    run<8, 1, 2, 1, 0, 3>(sink, "l3 shape, pixel frags read every 3rd step");
+    run<8, 2, 2, 1, 0, 3>(sink, "l2 shape, pixel frags read every 3rd step");
+    run<8, 1, 1, 1, 0, 3>(sink, "l1/l4 shape, pixel frags read every 3rd step");
+    run<4, 2, 2, 1, 0, 3>(sink, "4 waves 2x2, pixel frags read every 3rd step");
+    run<4, 2, 2, 1, 0, 2>(sink, "4 waves 2x2, pixel frags never re-read");
+    run<4, 1, 2, 1, 0, 3>(sink, "4 waves 1x2, pixel frags read every 3rd step");
+    run<4, 2, 1, 1, 0, 3>(sink, "4 waves 2x1, pixel frags read every 3rd step");
     return 0;
 }
