@@ -18,7 +18,12 @@
  *   - shading: nearest texel, sRGB->linear by LUT, then pyrender's published fragment shader (mesh.frag: glTF
  *     metallic-roughness BRDF, see ro_shade) with ambient 0.8 and one point light at the camera as in
  *     renderer.py:72-84,103-104; rest-pose ("stale") hand normals as in anakin/utils/frender_utils.py:36-46,139;
- *     linear->sRGB by 4096-entry LUT.  No MSAA resolve (pyrender renders 4x multisampled: edge pixels differ)
+ *     linear->sRGB by 4096-entry LUT.  No MSAA resolve: pyrender's offscreen target is 4x multisampled and cleared to the scene's
+ *     bg_color 0.5 (renderer.py:76), and the reference keeps the resolved colour wherever the resolved DEPTH is non-zero
+ *     (renderer.py:110-119: np.putmask(color, depth == 0, background)) -- so its silhouette pixels are a blend of shaded
+ *     samples and grey where the depth sample was covered and pure background where it was not.  Which sample a
+ *     multisample depth blit keeps is implementation-defined in GL, so that fringe cannot be restated from a published
+ *     rule; this oracle takes every pixel from its centre sample (interior pixels are unaffected)
  *   - background where no geometry (renderer.py:117-119,125-136): the random crop resized with cv2's INTER_LINEAR
  *     fixed-point arithmetic (restated at bg_pixel; cv2 is absent, so unpinned as well)
  * The GaussianBlur + colour jitter + crop stage restates PIL (anakin/utils/img_augment.py:6-80,
