@@ -16,7 +16,8 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 // AMODE 1: the pixel-side fragments are read from LDS on every third step only and derived by a DPP row shift (one v_mov_dpp
 // per dword) on the two steps in between -- what serving the three horizontal taps of a 3x3 window from ONE fragment read
 // would cost; AMODE 2: never re-read (upper bound: the weight-side reads alone).
-template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE, int AMODE = 0>
+// CH1: the three products of a tile go to ONE accumulator (interleaved over the TN tiles) instead of main + cross chains
+template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE, int AMODE = 0, int CH1 = 0>
 __global__ __launch_bounds__(64 * NW) void step_loop(int iters, float* sink) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -80,7 +81,17 @@ __global__ __launch_bounds__(64 * NW) void step_loop(int iters, float* sink) {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                if (CH1) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const bf16x8 b = __builtin_bit_cast(bf16x8, fb[p == 2 ? k2 + 2 : k2][j]);
+                            const bf16x8 a = __builtin_bit_cast(bf16x8, fa[p == 1 ? k2 + 2 : k2][i]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc[i][j], 0, 0, 0);
+                        }
+                } else
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[k2][j]), bl = __builtin_bit_cast(bf16x8, fb[k2 + 2][j]);
@@ -89,6 +100,7 @@ __global__ __launch_bounds__(64 * NW) void step_loop(int iters, float* sink) {
                     accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, al, accx[i][j], 0, 0, 0);
                     accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, accx[i][j], 0, 0, 0);
                 }
+            }
         }
     }
     float s = 0.f;
@@ -99,10 +111,10 @@ __global__ __launch_bounds__(64 * NW) void step_loop(int iters, float* sink) {
     if (s == 12345.678f) sink[0] = s;
 }
 
-template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE, int AMODE = 0>
+template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE, int AMODE = 0, int CH1 = 0>
 static void run(float* sink, const char* tag) {
     const int iters = 4000, blocks = 256;
-    auto k = step_loop<NW, TM, TN, BARRIER, INTERLEAVE, AMODE>;
+    auto k = step_loop<NW, TM, TN, BARRIER, INTERLEAVE, AMODE, CH1>;
     CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     k<<<blocks, 64 * NW, 96 * 1024>>>(iters / 10, sink); CK(hipDeviceSynchronize());
@@ -138,5 +150,7 @@ int main() {
     run<4, 2, 2, 1, 0, 2>(sink, "4 waves 2x2, pixel frags never re-read");
     run<4, 1, 2, 1, 0, 3>(sink, "4 waves 1x2, pixel frags read every 3rd step");
     run<4, 2, 1, 1, 0, 3>(sink, "4 waves 2x1, pixel frags read every 3rd step");
+    run<8, 1, 2, 1, 0, 3, 1>(sink, "l3 shape, every 3rd step, ONE accumulator chain");
+    run<8, 1, 2, 1, 0, 0, 1>(sink, "l3 shape, every step, ONE accumulator chain");
     return 0;
 }
