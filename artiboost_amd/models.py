@@ -203,6 +203,14 @@ class HybridBaseline(nn.Module):
             seg = self._segments[key] = _NetSegment()
         return seg
 
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel over several GPUs (train_artiboost.py:131 with more than one visible device) would clone this module
+        per device; its parameters, activations and hipGraphs live in ONE device's flat buffers.  Multi-GPU training here is
+        one process per GPU (bench.py --gpus N, tools/train_artiboost.py under torch.distributed.run: RCCL all-reduce)."""
+        raise RuntimeError("HybridBaseline (HIP) cannot be replicated by nn.DataParallel: run one process per GPU "
+                           "(python -m torch.distributed.run --nproc-per-node N tools/train_artiboost.py ...), or restrict "
+                           "DataParallel to one device (--gpu_id 0 / CUDA_VISIBLE_DEVICES=0)")
+
     def params_updated(self):
         """Call after the optimizer changed flat_param (refreshes the compute-precision weight copies)."""
         self.net._packed = False

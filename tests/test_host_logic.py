@@ -294,3 +294,11 @@ def test_dropin_surface_matches_reference_signatures():
                          cfg_preset=mcfg["DATA_PRESET"], time_f=0.0, batch_size=4, shuffle=True, num_workers=0, pin_memory=True,
                          drop_last=True, collate_fn=ho_collate, random_seed=1)
     assert ld.synth_len == 40 and ld.use_synth and ld.sample_weight_map.shape == (4, 288, 50) and ld.batch_size == 4
+
+
+def test_dataparallel_replication_is_refused_with_instructions():
+    """nn.DataParallel over > 1 device clones modules per device (torch/nn/parallel/replicate.py calls
+    `_replicate_for_data_parallel`); the HIP model owns one device's flat buffers and says what to do instead."""
+    from artiboost_amd.models import HybridBaseline
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        HybridBaseline._replicate_for_data_parallel(object.__new__(HybridBaseline))
