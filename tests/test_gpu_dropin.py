@@ -107,3 +107,26 @@ def test_reference_epoch_pass_sequence_two_epochs(tmp_path, monkeypatch):
     assert torch.equal(loader2.sample_weight_map, artiboost_loader.sample_weight_map)
     assert torch.equal(loader2.occurence_map, artiboost_loader.occurence_map)
     assert os.path.exists(os.path.join(recorder.dump_path, "checkpoints", "checkpoint", "random_state.pkl"))
+
+
+def test_train_script_with_the_reference_command_line(tmp_path):
+    """train/train_artiboost.py -- the reference's command line on the graph-replayed step: two epochs, checkpoint, resume."""
+    import subprocess
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["TRAIN"]["EPOCH"] = 2
+    y = tmp_path / "cfg.yaml"
+    y.write_text(yaml.dump(cfg))
+    cmd = [sys.executable, os.path.join(ROOT, "train", "train_artiboost.py"), "--cfg", str(y), "--gpu_id", "0", "--gpu_render_id", "0",
+           "--batch_size", "8", "--exp_id", "t", "--snapshot", "1", "--synth_len", "32", "--size", "64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("epoch ")]
+    assert len(lines) == 2 and "final_loss" in lines[-1]
+    exp = [d for d in os.listdir(tmp_path / "exp") if d.startswith("t_")]
+    assert len(exp) == 1
+    ck = tmp_path / "exp" / exp[0] / "checkpoints" / "checkpoint"
+    assert (ck / "HybridBaseline.pth.tar").exists() and (ck / "train_param.pth.tar").exists()
+    # resume: nothing left to train (epoch 2 of 2), but every piece must load
+    out = subprocess.run(cmd + ["--resume", str(tmp_path / "exp" / exp[0])], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]

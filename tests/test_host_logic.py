@@ -302,3 +302,18 @@ def test_dataparallel_replication_is_refused_with_instructions():
     from artiboost_amd.models import HybridBaseline
     with pytest.raises(RuntimeError, match="one process per GPU"):
         HybridBaseline._replicate_for_data_parallel(object.__new__(HybridBaseline))
+
+
+def test_train_script_launches_one_rank_per_listed_gpu():
+    """train/train_artiboost.py with the reference's `--gpu_id 0,1` starts two ranks under torch.distributed.run (the reference
+    wraps the model in nn.DataParallel instead, train_artiboost.py:131,249-257); --dry-launch reports the world size and exits."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "train", "train_artiboost.py"), "--cfg",
+                          os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml"), "--gpu_id", "0,1", "--gpu_render_id", "0,1",
+                          "--batch_size", "16", "--dry-launch"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"dry_launch": True, "n_gpus": 2, "gpu_id": ["0", "1"]}
