@@ -101,3 +101,24 @@ def test_configs0_submit_pass_on_cpu_bs8(tmp_path):
     assert out["joints_3d_abs"].shape == (bs, 21, 3) and out["corners_3d_abs"].shape == (bs, 8, 3)
     assert out["hand_verts_3d"].shape == (bs, 778, 3) and out["box_rot_rotmat"].shape == (bs, 3, 3)
     np.testing.assert_allclose(out["joints_3d"][:, cfg["DATA_PRESET"]["CENTER_IDX"]].detach().numpy(), 0.0, atol=1e-7)
+
+
+def test_submit_reload_script_with_the_reference_command_line(tmp_path):
+    """train/submit_reload.py (the reference's command line, submit_reload.py:26-79) on CPU, batch size 8: BASELINE configs[0] by
+    one command -- evaluator record, CodaLab JSON + zip."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "train", "submit_reload.py"), "--cfg",
+                          os.path.join(ROOT, "config", "eval_ho3dv2_regbased_artiboost_cpu.yaml"), "--batch_size", "8", "--submit_dump",
+                          "--random_frames", "12"], capture_output=True, text=True, timeout=600, cwd=str(tmp_path),
+                         env=dict(os.environ, CUDA_VISIBLE_DEVICES=""))
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("submit:")][-1]
+    assert "12 frames on cpu" in line and "joints_3d_abs_mepe" in line
+    exp = os.path.join(tmp_path, "exp", os.listdir(tmp_path / "exp")[0])
+    js = [f for f in os.listdir(exp) if f.endswith("_SUBMIT.json")]
+    assert len(js) == 1 and os.path.exists(os.path.join(exp, js[0].replace(".json", ".zip")))
+    xyz, verts = json.load(open(os.path.join(exp, js[0])))
+    assert len(xyz) == 12 and len(xyz[0]) == 21 and len(verts[0]) == 778
+    assert os.path.exists(os.path.join(exp, "evaluations", "test_eval.txt"))
