@@ -55,7 +55,8 @@ def test_only_tests_smoke_and_cpu_baseline_touch_the_oracle():
         return bad
 
     bad = []
-    for f in glob.glob(os.path.join(root, "artiboost_amd", "*.py")) + glob.glob(os.path.join(root, "tools", "*.py")):
+    for f in (glob.glob(os.path.join(root, "artiboost_amd", "*.py")) + glob.glob(os.path.join(root, "tools", "*.py")) +
+              glob.glob(os.path.join(root, "train", "*.py")) + glob.glob(os.path.join(root, "anakin", "**", "*.py"), recursive=True)):
         bad += offenders(f)
         assert "oracle" not in [p for p in open(f).read().split('"') if p.endswith("oracle")], f
     bad += offenders(os.path.join(root, "bench.py"), allowed_funcs=("cpu_baseline",))
