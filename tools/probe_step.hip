@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -206,8 +207,32 @@ static void run(float* sink, const char* tag) {
            flops / ms / 1e9, ms * 1e6 / iters);
 }
 
-int main() {
+template <int NW, int TM, int TN, int BARRIER, int INTERLEAVE, int AMODE = 0, int CH1 = 0>
+static void hold(float* sink, double seconds, const char* tag) {
+    auto k = step_loop<NW, TM, TN, BARRIER, INTERLEAVE, AMODE, CH1>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int iters = 20000; double total = 0; long n = 0;
+    while (total < seconds * 1e3) {
+        CK(hipEventRecord(e0)); k<<<256, 64 * NW, 96 * 1024>>>(iters, sink); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); total += ms; ++n;
+    }
+    double flops = (double)256 * NW * iters * n * (6.0 * TM * TN) * 32768.0;
+    printf("hold %-40s %.1f s : %7.1f TFLOP/s MFMA sustained\n", tag, total / 1e3, flops / total / 1e9);
+}
+
+int main(int argc, char** argv) {
     float* sink; CK(hipMalloc(&sink, 64));
+    if (argc >= 4 && !strcmp(argv[1], "hold")) {      // one variant in a closed loop for N seconds (watch rocm-smi next to it)
+        const int w = atoi(argv[2]); const double sec = atof(argv[3]);
+        if (w == 0) hold<8, 1, 2, 1, 0>(sink, sec, "l3 shape");
+        if (w == 1) hold<8, 1, 2, 0, 0>(sink, sec, "l3 shape, no barrier");
+        if (w == 2) hold<8, 1, 2, 1, 0, 2>(sink, sec, "l3 shape, pixel frags never re-read");
+        if (w == 3) hold<8, 2, 2, 1, 0>(sink, sec, "l2 shape");
+        if (w == 4) hold<4, 2, 4, 1, 0>(sink, sec, "4 waves 2x4");
+        if (w == 5) hold<8, 1, 2, 1, 0, 3>(sink, sec, "l3 shape, frags every 3rd step");
+        return 0;
+    }
     run<8, 1, 2, 1, 0>(sink, "l3 shape (128x128 tile, 8 waves)");
     run<8, 1, 2, 0, 0>(sink, "  no barrier");
     run<8, 1, 2, 1, 1>(sink, "  reads per k-slice");
