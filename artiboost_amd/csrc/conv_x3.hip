@@ -26,6 +26,9 @@ int conv_gemm2_x3_stem_run(ConvGemmArgs& g, hipStream_t st);
 int wgrad_gemm2_stem_slices(int N, int H, int W, int Cout);
 int wgrad_gemm2_x3_stem_run(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N,
                             int H, int W, int Cout, hipStream_t st);
+int stem_halo_x3_tiles(int N, int H, int W);                   // stem_halo.hip
+int stem_halo_x3_run(const void* xpad_hi, const void* xpad_lo, const void* w_hi, const void* w_lo, float* y, int N, int H, int W,
+                     int Cout, float* stats, hipStream_t st);
 int wgrad_launch_reduce(const float* slabs, int ns, long slab_elems, int src_j, int dst_j, float* dst, int accumulate,
                            int stem_mask, hipStream_t st);      // conv_wgrad.hip
 
@@ -190,12 +193,16 @@ extern "C" int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void
 
 // ---------------------------------------------------------------- stem 7x7/2 (resnet.py:154) on split planes
 // xpad planes: zero-bordered NHWC4 image [N, H+6, W+8, 4]; w planes [64][7][8][4]; y fp32 [N, H/2, W/2, 64]
-extern "C" int ab_conv2d_stem_x3_stat_rows(int N, int H, int W) { return conv_gemm2_x3_stem_mtiles(N * (H / 2) * (W / 2)); }
+extern "C" int ab_conv2d_stem_x3_stat_rows(int N, int H, int W) {
+    if (int t = stem_halo_x3_tiles(N, H, W)) return t;          // persistent halo kernel: one partial row per workgroup
+    return conv_gemm2_x3_stem_mtiles(N * (H / 2) * (W / 2));
+}
 
 extern "C" int ab_conv2d_stem_fwd_x3(const void* xpad_hi, const void* xpad_lo, const void* w_hi, const void* w_lo, float* y, int N,
                                      int H, int W, int Cout, float* stats, void* stream) {
     if (!xpad_hi || !xpad_lo || !w_hi || !w_lo || !y) return AB_EINVAL;
     if ((H & 1) || (W & 1) || Cout != 64) return AB_ESHAPE;
+    if (stem_halo_x3_tiles(N, H, W)) return stem_halo_x3_run(xpad_hi, xpad_lo, w_hi, w_lo, y, N, H, W, Cout, stats, as_stream(stream));
     ConvGemmArgs g = {};
     g.A = xpad_hi; g.A_lo = xpad_lo; g.Bw = w_hi; g.Bw_lo = w_lo; g.Out = y; g.stats = stats;
     g.N = N; g.Ha = H + 6; g.Wa = W + 8; g.Ca = 4;

@@ -158,3 +158,148 @@ int stem_halo_run(const void* xpad, const void* w, void* y, int N, int H, int W,
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") stem: image and weights as (hi, lo) bf16 planes, fp32 output and BN partials.  Same persistent-tile
+// structure; both planes of the patch are DMA'd per tile (2 x 6.7 KB), the weight fragments of both planes stay in registers
+// (28 B fragments = 112 VGPRs), a k-slice is three MFMAs (hi*hi on the main chain, hi*lo + lo*hi on the cross chain), the
+// staging tile is fp32 (two buffers of 34 KB: one workgroup per CU, the stores of tile t under the MFMAs of tile t + 1).
+#define SX_SPITCH 272               // 64 channels x 4 bytes + 16
+#define SX_STAGE (128 * SX_SPITCH)  // 34816
+#define SX_OFF_P 0                                      // [buf][plane] patches of SH_PATCH bytes
+#define SX_OFF_S (4 * SH_PATCH)                         // 28672
+#define SX_OFF_T (SX_OFF_S + 2 * SX_STAGE)              // 98304
+#define SX_LDS (SX_OFF_T + 2 * SH_STAT)                 // 102400
+
+struct StemArgsX3 {
+    const void* X; const void* Xlo; const void* Wt; const void* Wtlo; float* Out; float* stats;
+    int Ha, Wa, Ho, Wo, tiles_x, tiles_per_img, ntiles;
+};
+
+__global__ __launch_bounds__(512) void stem_halo_x3_kernel(StemArgsX3 g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int l32 = lane & 31, fhalf = lane >> 5;
+    const bf16_t* __restrict__ Xh = (const bf16_t*)g.X;
+    const bf16_t* __restrict__ Xl = (const bf16_t*)g.Xlo;
+    const bf16_t* __restrict__ Wh = (const bf16_t*)g.Wt;
+    const bf16_t* __restrict__ Wl = (const bf16_t*)g.Wtlo;
+    float* __restrict__ Out = g.Out;
+    const unsigned lds0 = lds_addr_of(smem);
+
+    uint4 fbh[14], fbl[14];
+#pragma unroll
+    for (int kk = 0; kk < 14; ++kk) {
+        fbh[kk] = *(const uint4*)(Wh + (wave_n * 32 + l32) * 224 + kk * 16 + fhalf * 8);
+        fbl[kk] = *(const uint4*)(Wl + (wave_n * 32 + l32) * 224 + kk * 16 + fhalf * 8);
+    }
+
+    auto issue_patch = [&](int tile, int buf) {          // per plane 420 sixteen-byte slots: waves 0..6 one instruction per plane
+        if (wave < 7) {
+            const int s = wave * 64 + lane;
+            if (s < SH_PSLOTS) {
+                const int img = tile / g.tiles_per_img, rem = tile - img * g.tiles_per_img;
+                const int ty0 = (rem / g.tiles_x) * SH_TH, tx0 = (rem % g.tiles_x) * SH_TW;
+                const int row = s / 20, c16 = s - row * 20;
+                const long e = (((long)img * g.Ha + 2 * ty0 + row) * g.Wa + 2 * tx0 + c16 * 2) * 4;
+                glds16(Xh + e, __builtin_amdgcn_readfirstlane(lds0 + SX_OFF_P + (buf * 2) * SH_PATCH + wave * 1024));
+                glds16(Xl + e, __builtin_amdgcn_readfirstlane(lds0 + SX_OFF_P + (buf * 2 + 1) * SH_PATCH + wave * 1024));
+            }
+        }
+    };
+
+    const int pq = l32 & 15, pp = wave_m * 2 + (l32 >> 4);
+    const unsigned a_off = (unsigned)(2 * pp * SH_PROW + pq * 16 + fhalf * 16);
+
+    float wg_sum = 0.f, wg_sq = 0.f;
+    int tile = blockIdx.x, buf = 0;
+    if (tile < g.ntiles) issue_patch(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (; tile < g.ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if (next < g.ntiles) issue_patch(next, buf ^ 1);
+
+        f32x16 acc, accx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accx[r] = 0.f; }
+        const unsigned char* pah = smem + SX_OFF_P + (buf * 2) * SH_PATCH + a_off;
+        const unsigned char* pal = pah + SH_PATCH;
+#pragma unroll
+        for (int kk = 0; kk < 14; ++kk) {
+            const uint4 fah = *(const uint4*)(pah + (kk >> 1) * SH_PROW + (kk & 1) * 32);
+            const uint4 fal = *(const uint4*)(pal + (kk >> 1) * SH_PROW + (kk & 1) * 32);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fah), __builtin_bit_cast(bf16x8, fbh[kk]), acc, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fah), __builtin_bit_cast(bf16x8, fbl[kk]), accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fal), __builtin_bit_cast(bf16x8, fbh[kk]), accx, 0, 0, 0);
+        }
+
+        const int cl = wave_n * 32 + l32;
+        unsigned char* stg = smem + SX_OFF_S + buf * SX_STAGE;
+        float* s_stat = (float*)(smem + SX_OFF_T + buf * SH_STAT);
+        float csum = 0.f, csq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+            const float v = acc[r] + accx[r];
+            *(float*)(stg + row * SX_SPITCH + cl * 4) = v;
+            csum += v; csq += v * v;
+        }
+        if (g.stats) {
+            const float s = csum + __shfl_xor(csum, 32, 64), q = csq + __shfl_xor(csq, 32, 64);
+            if (lane < 32) { s_stat[(wave_m * 64 + cl) * 2] = s; s_stat[(wave_m * 64 + cl) * 2 + 1] = q; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int img = tile / g.tiles_per_img, rem = tile - img * g.tiles_per_img;
+        const int ty0 = (rem / g.tiles_x) * SH_TH, tx0 = (rem % g.tiles_x) * SH_TW;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int id = tid + u * 512;                  // 128 rows x 16 sixteen-byte chunks (4 channels each)
+            const int row = id >> 4, c4 = id & 15;
+            const int p = row >> 4, q = row & 15;
+            const float4 v = *(const float4*)(stg + row * SX_SPITCH + c4 * 16);
+            *(float4*)(Out + ((((long)img * g.Ho + ty0 + p) * g.Wo + tx0 + q) * 64 + c4 * 4)) = v;
+        }
+        if (g.stats && tid < 64) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int wm = 0; wm < 4; ++wm) { s += s_stat[(wm * 64 + tid) * 2]; q += s_stat[(wm * 64 + tid) * 2 + 1]; }
+            wg_sum += s; wg_sq += q;
+        }
+        buf ^= 1;
+    }
+    if (g.stats && tid < 64) {
+        g.stats[((long)blockIdx.x * 64 + tid) * 2] = wg_sum;
+        g.stats[((long)blockIdx.x * 64 + tid) * 2 + 1] = wg_sq;
+    }
+}
+
+static int stem_halo_x3_grid(int ntiles) { return ntiles < 256 ? ntiles : 256; }      // 100 KB of LDS: one workgroup per CU
+int stem_halo_x3_tiles(int N, int H, int W) {
+    if (getenv("AB_STEM_HALO_X3") && !atoi(getenv("AB_STEM_HALO_X3"))) return 0;
+    return stem_halo_x3_grid(stem_halo_ntiles(N, H, W));
+}
+int stem_halo_x3_run(const void* xpad_hi, const void* xpad_lo, const void* w_hi, const void* w_lo, float* y, int N, int H, int W,
+                     int Cout, float* stats, hipStream_t st) {
+    const int ntiles = stem_halo_ntiles(N, H, W);
+    if (!ntiles || Cout != 64) return AB_ESHAPE;
+    StemArgsX3 g;
+    g.X = xpad_hi; g.Xlo = xpad_lo; g.Wt = w_hi; g.Wtlo = w_lo; g.Out = y; g.stats = stats;
+    g.Ha = H + 6; g.Wa = W + 8; g.Ho = H / 2; g.Wo = W / 2;
+    g.tiles_x = g.Wo / SH_TW; g.tiles_per_img = g.tiles_x * (g.Ho / SH_TH); g.ntiles = ntiles;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)stem_halo_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SX_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    stem_halo_x3_kernel<<<stem_halo_x3_grid(ntiles), 512, SX_LDS, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
