@@ -404,22 +404,24 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
                                                           int N, int H, int W, int C, T* __restrict__ dx) {
     constexpr int V = Vec<T>::N;
     const int Ho = H / 2, Wo = W / 2, vc = C / V;
-    // grid (ceil(W*vc / 256), H, N): one input row per (blockIdx.y, blockIdx.z), 32-bit index math only
+    // grid (ceil(W*vc / 256), H/2, N): a thread owns one channel vector of the input row PAIR (2p, 2p+1): row 2p lies in pooled
+    // row p only, row 2p+1 in p and p+1 -- the winners / gradients of pooled row p are loaded once for both (4 loads of each kind
+    // instead of 6, half the workgroups); 32-bit index math only
     const unsigned col = blockIdx.x * 256 + threadIdx.x;
     if (col < (unsigned)(W * vc)) {
         const int w = (int)(col / (unsigned)vc), cv = (int)(col - (unsigned)w * vc);
-        const int n = blockIdx.z, h = blockIdx.y;
-        const long i = (((long)n * H + h) * W + w) * vc + cv;
-        float acc[V];
+        const int n = blockIdx.z, p = blockIdx.y;
+        float acc0[V], acc1[V];
 #pragma unroll
-        for (int k = 0; k < V; ++k) acc[k] = 0.f;
-        for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
+        for (int k = 0; k < V; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
+#pragma unroll
+        for (int dp = 0; dp < 2; ++dp) {
+            const int ho = p + dp;
             if (ho >= Ho) continue;
-            int dh = h - (ho * 2 - 1);
             for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
                 if (wo >= Wo) continue;
-                int code = dh * 3 + (w - (wo * 2 - 1));
-                long o = (((long)n * Ho + ho) * Wo + wo) * C + cv * V;
+                const int cw = w - (wo * 2 - 1);
+                const long o = (((long)n * Ho + ho) * Wo + wo) * C + cv * V;
                 uint8_t am[V];
                 if constexpr (V == 8) {
                     uint2 q = *(const uint2*)(idx + o);
@@ -431,11 +433,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t* __restr
                     for (int k = 0; k < 4; ++k) am[k] = (q >> (8 * k)) & 0xff;
                 }
                 float g[V]; vload<T>(dout + o, g);
+                // window rows of pooled row ho: 2ho-1 .. 2ho+1.  dp = 0: input row 2p is its row 1, row 2p+1 its row 2;
+                // dp = 1: input row 2p+1 is row 0 of pooled row p+1
+                if (dp == 0) {
 #pragma unroll
-                for (int k = 0; k < V; ++k) if (am[k] == code) acc[k] += g[k];
+                    for (int k = 0; k < V; ++k) { if (am[k] == 3 + cw) acc0[k] += g[k]; if (am[k] == 6 + cw) acc1[k] += g[k]; }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < V; ++k) if (am[k] == cw) acc1[k] += g[k];
+                }
             }
         }
-        vstore<T>(dx + i * V, acc);
+        const long i = (((long)n * H + 2 * p) * W + w) * vc + cv;
+        vstore<T>(dx + i * V, acc0);
+        vstore<T>(dx + (i + (long)W * vc) * V, acc1);
     }
 }
 
@@ -841,7 +852,7 @@ extern "C" int ab_bn_relu_maxpool3x3s2_fwd(const void* y, const float* bnp, int 
 extern "C" int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx,
                                    void* stream) {
     int V = dtype == AB_DT_F32 ? 4 : 8; if (C % V || (H & 1) || (W & 1)) return AB_ESHAPE;
-    dim3 pgrid((unsigned)(((long)W * (C / V) + 255) / 256), (unsigned)H, (unsigned)N);
+    dim3 pgrid((unsigned)(((long)W * (C / V) + 255) / 256), (unsigned)(H / 2), (unsigned)N);
     DISPATCH(dtype, (maxpool_bwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>((const uint8_t*)idx, (const float*)dout, N, H, W, C, (float*)dx)),
              (maxpool_bwd_kernel<bf16_t><<<pgrid, 256, 0, as_stream(stream)>>>((const uint8_t*)idx, (const bf16_t*)dout, N, H, W, C, (bf16_t*)dx)));
     AB_LAUNCH_CHECK(); return 0;
