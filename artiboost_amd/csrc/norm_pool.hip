@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
 // it, is pooled instead (the activation tensor is never materialised).
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bnp, int N, int H,
-                                                          int W, int C, T* __restrict__ out, uint8_t* __restrict__ idx) {
+                                                          int W, int C, T* __restrict__ out, uint8_t* __restrict__ idx,
+                                                          bf16_t* __restrict__ out_hi = nullptr, bf16_t* __restrict__ out_lo = nullptr) {
     constexpr int V = Vec<T>::N;
     const int Ho = H / 2, Wo = W / 2, vc = C / V;
     // grid (ceil(Wo*vc / 256), Ho, N): one output row per (blockIdx.y, blockIdx.z) -- no 64-bit div/mod per vector (they dominated the
@@ -388,6 +389,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
             }
         }
         vstore<T>(out + i * V, m);
+        if constexpr (V == 4) {
+            if (out_hi) {        // fp32 path: the pooled tensor also as (hi, lo) planes for the split-bf16 convolutions that read it
+                const uint32_t h0 = pack_bf16x2(m[0], m[1]), h1 = pack_bf16x2(m[2], m[3]);
+                const uint32_t l0 = pack_bf16x2(m[0] - __uint_as_float(h0 << 16), m[1] - __uint_as_float(h0 & 0xffff0000u));
+                const uint32_t l1 = pack_bf16x2(m[2] - __uint_as_float(h1 << 16), m[3] - __uint_as_float(h1 & 0xffff0000u));
+                *(uint2*)(out_hi + i * 4) = make_uint2(h0, h1);
+                *(uint2*)(out_lo + i * 4) = make_uint2(l0, l1);
+            }
+        }
         if (idx) {
             if constexpr (V == 8) {
                 uint2 o; o.x = am[0] | (am[1] << 8) | (am[2] << 16) | ((uint32_t)am[3] << 24);
@@ -847,6 +857,16 @@ extern "C" int ab_bn_relu_maxpool3x3s2_fwd(const void* y, const float* bnp, int 
     dim3 pgrid((unsigned)(((long)(W / 2) * (C / V) + 255) / 256), (unsigned)(H / 2), (unsigned)N);
     DISPATCH(dtype, (maxpool_fwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>((const float*)y, bnp, N, H, W, C, (float*)out, (uint8_t*)idx)),
              (maxpool_fwd_kernel<bf16_t><<<pgrid, 256, 0, as_stream(stream)>>>((const bf16_t*)y, bnp, N, H, W, C, (bf16_t*)out, (uint8_t*)idx)));
+    AB_LAUNCH_CHECK(); return 0;
+}
+// fp32 in, fp32 + (hi, lo) bf16 planes out: the pooled tensor is read by three split-bf16 convolutions (layer1.0 conv1, its
+// weight gradient, the residual stays fp32)
+extern "C" int ab_bn_relu_maxpool3x3s2_fwd_x3(const float* y, const float* bnp, int N, int H, int W, int C, float* out, void* out_hi,
+                                              void* out_lo, void* idx, void* stream) {
+    if (!y || !bnp || !out || !out_hi || !out_lo) return AB_EINVAL;
+    if (C % 4 || (H & 1) || (W & 1)) return AB_ESHAPE;
+    dim3 pgrid((unsigned)(((long)(W / 2) * (C / 4) + 255) / 256), (unsigned)(H / 2), (unsigned)N);
+    maxpool_fwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>(y, bnp, N, H, W, C, out, (uint8_t*)idx, (bf16_t*)out_hi, (bf16_t*)out_lo);
     AB_LAUNCH_CHECK(); return 0;
 }
 extern "C" int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx,

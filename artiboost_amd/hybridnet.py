@@ -396,11 +396,12 @@ class HybridNet:
             y0, st = K.conv2d_stem_fwd(xpad, self.w("backbone.conv1.weight"), H, W, want_stats=True)
         if self.fuse_stem:
             bnp0 = self._bn_params("backbone.bn1", st, N * (H // 2) * (W // 2))
-            x, pool_idx = K.bn_relu_maxpool_fwd(y0, bnp0)      # BN + ReLU + 3x3/2 max-pool: the 128x128x64 activation is never stored
+            # BN + ReLU + 3x3/2 max-pool: the 128x128x64 activation is never stored (bf16x3: the pooled planes come from the same pass)
+            x, pool_idx = (K.bn_relu_maxpool_fwd_x3 if self.x3 else K.bn_relu_maxpool_fwd)(y0, bnp0)
         else:
             a0, bnp0 = self._bn("backbone.bn1", y0, st, N * (H // 2) * (W // 2), feeds_conv=False)
             x, pool_idx = K.maxpool_fwd(a0)
-        if self.x3:
+        if self.x3 and getattr(x, "_ab_split", None) is None:
             x._ab_split = K.split(x)      # layer1.0 reads the pooled tensor three times (conv1, residual, conv1's weight gradient)
         S.update(y0=y0, bnp0=bnp0, pool_idx=pool_idx)
         inpl = 64

@@ -240,6 +240,19 @@ def bn_relu_maxpool_fwd(y, bnp):
     return o, idx
 
 
+def bn_relu_maxpool_fwd_x3(y, bnp):
+    """bn_relu_maxpool_fwd on fp32 -> (pooled fp32 with its (hi, lo) planes as `_ab_split`, idx): the planes come from the
+    pooling pass itself instead of a separate split pass over the pooled tensor."""
+    N, H, W, C = y.shape
+    o = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=y.device)
+    pl = torch.empty((2, N, H // 2, W // 2, C), dtype=torch.bfloat16, device=y.device)
+    idx = torch.empty((N, H // 2, W // 2, C), dtype=torch.uint8, device=y.device)
+    L.check(L.lib().ab_bn_relu_maxpool3x3s2_fwd_x3(L.ptr(y), L.ptr(bnp), L.i(N), L.i(H), L.i(W), L.i(C), L.ptr(o), L.ptr(pl[0]),
+                                                   L.ptr(pl[1]), L.ptr(idx), L.stream()), "ab_bn_relu_maxpool3x3s2_fwd_x3")
+    o._ab_split = pl
+    return o, idx
+
+
 def bn_relu_maxpool_bwd(dpool, idx, y, bnp, dgamma, dbeta):
     """Backward of bn_relu_maxpool_fwd -> dy (gradient wrt the conv output y)."""
     N, H, W, C = y.shape

@@ -187,6 +187,8 @@ int ab_bn_bwd_apply(const void* dout, const void* out, const void* y, const floa
  * both BN passes (dpool: pooled gradient; part/bwdp as in ab_bn_bwd with M = N*H*W).                                 */
 int ab_bn_relu_maxpool3x3s2_fwd(const void* y, const float* bnp, int dtype, int N, int H, int W, int C, void* out,
                                 void* idx, void* stream);
+int ab_bn_relu_maxpool3x3s2_fwd_x3(const float* y, const float* bnp, int N, int H, int W, int C, float* out, void* out_hi,
+                                   void* out_lo, void* idx, void* stream);      /* fp32 + (hi, lo) bf16 planes of the pooled tensor */
 int ab_bn_relu_maxpool_bwd(const void* dpool, const void* idx, const void* y, const float* bnp, int dtype, int N, int H,
                            int W, int C, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* stream);
 int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx, void* stream);

@@ -258,6 +258,9 @@ def test_fused_stem_bn_relu_maxpool(shape, dtype):
     ref_dy = K.bn_bwd(da, None, y, bnp, dg0, db0, relu="recompute")
     dy = K.bn_relu_maxpool_bwd(dpool, idx, y, bnp, dg1, db1)
     assert torch.equal(dy, ref_dy) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    if dtype == torch.float32:      # the split-bf16 path's variant: same pooled tensor and winners, plus its (hi, lo) planes
+        o3, i3 = K.bn_relu_maxpool_fwd_x3(y, bnp)
+        assert torch.equal(o3, out) and torch.equal(i3, idx) and torch.equal(o3._ab_split, K.split(out))
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, False), (3, 32, 32, 64, 64, True), (2, 8, 8, 128, 192, True),
