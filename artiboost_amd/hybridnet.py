@@ -477,6 +477,7 @@ class HybridNet:
     overlap_wgrad = os.environ.get("AB_WGRAD_OVERLAP", "0") == "1"
     fuse_stem = os.environ.get("AB_STEM_FUSE", "1") != "0"       # stem BN+ReLU+max-pool as one pass (forward)
     fuse_stem_bwd = os.environ.get("AB_STEM_FUSE_BWD", "0") == "1"   # ... and the gather-based fused backward
+    stem_pool_reduce = os.environ.get("AB_STEM_POOL_REDUCE", "1") != "0"   # bf16x3: see _backward_trunk
 
     # AB_WGRAD_BATCH=1: the fixed-order slab reductions of a backward stage's weight gradients run as ONE launch at the end
     # of the stage instead of one per layer right behind its slab kernel.  Bit-identical, 38 graph nodes fewer -- and 2 %
@@ -615,7 +616,13 @@ class HybridNet:
         gv = self.p.gview
         dout, _ = self._backward_blocks(dout, blocks, dout_part)
         # ---- stem
-        if self.fuse_stem_bwd:
+        dy0 = None
+        if self.x3 and self.fuse_stem and self.stem_pool_reduce:
+            # the max-pool backward pass also masks and reduces for the stem BatchNorm (AB_STEM_POOL_REDUCE=0: separate passes)
+            dy0 = K.bn_relu_maxpool_bwd_x3(dout, S["pool_idx"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"))
+        if dy0 is not None:
+            pass
+        elif self.fuse_stem_bwd:
             dy0 = K.bn_relu_maxpool_bwd(dout, S["pool_idx"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"))
         else:
             y0 = S["y0"]

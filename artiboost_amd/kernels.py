@@ -266,6 +266,24 @@ def bn_relu_maxpool_bwd(dpool, idx, y, bnp, dgamma, dbeta):
     return dy
 
 
+def bn_relu_maxpool_bwd_x3(dpool, idx, y, bnp, dgamma, dbeta):
+    """Backward of bn_relu_maxpool_fwd on fp32 tensors -> dy as split planes [2, *y.shape], or None when the shape is not handled:
+    the max-pool backward pass also masks and reduces (no separate BatchNorm-backward reduction over the full-size tensors)."""
+    N, H, W, C = y.shape
+    lib = L.lib()
+    np_ = lib.ab_bn_relu_maxpool_bwd_x3_nparts(L.i(N), L.i(H), L.i(W), L.i(C))
+    if np_ <= 0:
+        return None
+    part = torch.empty((np_, C, 2), dtype=torch.float32, device=y.device)
+    bwdp = torch.empty((2, C), dtype=torch.float32, device=y.device)
+    dz = torch.empty_like(y)
+    dy = torch.empty((2,) + tuple(y.shape), dtype=torch.bfloat16, device=y.device)
+    L.check(lib.ab_bn_relu_maxpool_bwd_x3(L.ptr(dpool), L.ptr(idx), L.ptr(y), L.ptr(bnp), L.i(N), L.i(H), L.i(W), L.i(C),
+                                          L.ptr(part), L.ptr(bwdp), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dz), L.ptr(dy[0]),
+                                          L.ptr(dy[1]), L.stream()), "ab_bn_relu_maxpool_bwd_x3")
+    return dy
+
+
 def maxpool_bwd(idx, dout, in_hw):
     N, Ho, Wo, C = dout.shape
     H, W = in_hw

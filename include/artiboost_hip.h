@@ -191,6 +191,13 @@ int ab_bn_relu_maxpool3x3s2_fwd_x3(const float* y, const float* bnp, int N, int 
                                    void* out_lo, void* idx, void* stream);      /* fp32 + (hi, lo) bf16 planes of the pooled tensor */
 int ab_bn_relu_maxpool_bwd(const void* dpool, const void* idx, const void* y, const float* bnp, int dtype, int N, int H,
                            int W, int C, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* stream);
+/* ... for the split-bf16 path: ONE pass scatters the pooled gradient to full resolution, masks it with the recomputed ReLU and
+ * reduces it (dz: fp32 [N,H,W,C] scratch; part: [ab_bn_relu_maxpool_bwd_x3_nparts(N,H,W,C)][C][2]), then finalize + a mask-free
+ * apply pass that writes dy as planes.  nparts == 0: shape not handled (use ab_maxpool3x3s2_bwd + ab_bn_bwd_x3).               */
+int ab_bn_relu_maxpool_bwd_x3_nparts(int N, int H, int W, int C);
+int ab_bn_relu_maxpool_bwd_x3(const float* dpool, const void* idx, const float* y, const float* bnp, int N, int H, int W,
+                              int C, float* part, float* bwdp, float* dgamma, float* dbeta, float* dz, void* dy_hi,
+                              void* dy_lo, void* stream);
 int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx, void* stream);
 int ab_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, float* out, void* stream);
 int ab_avgpool_bwd(const float* g, int dtype, int N, int HW, int C, void* dx, int accumulate, void* stream);

@@ -261,6 +261,13 @@ def test_fused_stem_bn_relu_maxpool(shape, dtype):
     if dtype == torch.float32:      # the split-bf16 path's variant: same pooled tensor and winners, plus its (hi, lo) planes
         o3, i3 = K.bn_relu_maxpool_fwd_x3(y, bnp)
         assert torch.equal(o3, out) and torch.equal(i3, idx) and torch.equal(o3._ab_split, K.split(out))
+        dg3, db3 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        pl = K.bn_relu_maxpool_bwd_x3(dpool, idx, y, bnp, dg3, db3)      # pool backward + mask + reduction in one pass, planes out
+        assert pl is not None
+        got = pl[0].float() + pl[1].float()
+        assert float((got - ref_dy).abs().max()) <= 2e-5 * float(ref_dy.abs().max())
+        np.testing.assert_allclose(dg3.cpu().numpy(), dg0.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(dg0.abs().max()))
+        np.testing.assert_allclose(db3.cpu().numpy(), db0.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(db0.abs().max()))
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, False), (3, 32, 32, 64, 64, True), (2, 8, 8, 128, 192, True),
