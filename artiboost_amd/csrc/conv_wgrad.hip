@@ -444,6 +444,32 @@ extern "C" int ab_conv2d_wgrad_deferred(const void* x, const void* dy, float* dw
     g_reduce_sink = nullptr;
     return rc;
 }
+// ... and of the split-bf16 weight gradients (conv_x3.hip)
+extern "C" int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N,
+                                  int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace,
+                                  int accumulate, void* stream);
+extern "C" int ab_conv2d_stem_wgrad_x3(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo, float* dw,
+                                       int N, int H, int W, int Cout, void* workspace, void* stream);
+extern "C" int ab_conv2d_wgrad_x3_deferred(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N,
+                                           int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace,
+                                           int accumulate, ab_wgrad_reduce_desc* pending, void* stream) {
+    if (!pending) return AB_EINVAL;
+    *pending = ab_wgrad_reduce_desc{};
+    g_reduce_sink = pending;
+    int rc = ab_conv2d_wgrad_x3(x_hi, x_lo, dy_hi, dy_lo, dw, N, H, W, Cin, Cout, kh, kw, stride, pad, workspace, accumulate, stream);
+    g_reduce_sink = nullptr;
+    return rc;
+}
+extern "C" int ab_conv2d_stem_wgrad_x3_deferred(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo,
+                                                float* dw, int N, int H, int W, int Cout, void* workspace,
+                                                ab_wgrad_reduce_desc* pending, void* stream) {
+    if (!pending) return AB_EINVAL;
+    *pending = ab_wgrad_reduce_desc{};
+    g_reduce_sink = pending;
+    int rc = ab_conv2d_stem_wgrad_x3(xpad_hi, xpad_lo, dy_hi, dy_lo, dw, N, H, W, Cout, workspace, stream);
+    g_reduce_sink = nullptr;
+    return rc;
+}
 extern "C" int ab_conv2d_stem_wgrad_deferred(const void* xpad, const void* dy, float* dw, int dtype, int N, int H, int W,
                                              int Cout, void* workspace, ab_wgrad_reduce_desc* pending, void* stream) {
     if (!pending) return AB_EINVAL;

@@ -168,6 +168,19 @@ extern "C" int ab_conv2d_dgrad_x3_bn(const void* dy_hi, const void* dy_lo, const
 }
 
 // ---------------------------------------------------------------- weight gradient
+// bytes of slab workspace ab_conv2d_wgrad_x3 writes for this shape (its own slice counts: not those of the bf16 kernels)
+extern "C" long ab_conv2d_wgrad_x3_workspace(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+    if (kh * kw > 16 || Cin % 64 || Cout % 64) return 0;
+    const long slab = (long)Cout * kh * kw * Cin * 4;
+    if (x3_is_c3(kh, kw, stride, pad)) {
+        int ns = wgrad3x3_x3_slices(N, H, W, Cin, Cout);
+        if (ns > 0) return ns * slab;
+    }
+    const int M = N * ((H + 2 * pad - kh) / stride + 1) * ((W + 2 * pad - kw) / stride + 1);
+    int ns = wgrad_gemm2_x3_slices(M, Cout, Cin, kh * kw);
+    return ns > 0 ? ns * slab : 0;
+}
+
 extern "C" int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N,
                                   int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace,
                                   int accumulate, void* stream) {

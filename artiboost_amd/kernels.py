@@ -488,16 +488,23 @@ def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=Fa
     return (dx, None) if bn is not None else dx
 
 
-def conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=None, accumulate=False):
-    """x, dy: fp32 or split -> dw fp32 [Cout,kh,kw,Cin]."""
+def conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=None, accumulate=False, defer=None):
+    """x, dy: fp32 or split -> dw fp32 [Cout,kh,kw,Cin].  defer: see conv2d_wgrad."""
     xh, xl = _planes(x)
     dh, dl = _planes(dy)
     N, H, W, Cin = xh.shape
     Cout = dh.shape[3]
     lib = L.lib()
-    M = dh.shape[0] * dh.shape[1] * dh.shape[2]
-    nbytes = lib.ab_conv2d_wgrad_workspace(L.i(M), L.i(Cout), L.i(kh * kw * Cin))
+    nbytes = lib.ab_conv2d_wgrad_x3_workspace(L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad))
+    if nbytes <= 0:
+        raise RuntimeError(f"conv2d_wgrad_x3: shape not handled (Cin {Cin}, Cout {Cout}, {kh}x{kw})")
     dw = out if out is not None else torch.empty((Cout, kh, kw, Cin), dtype=torch.float32, device=xh.device)
+    if defer is not None:
+        ws, d = defer.new(nbytes, xh.device)
+        L.check(lib.ab_conv2d_wgrad_x3_deferred(L.ptr(xh), L.ptr(xl), L.ptr(dh), L.ptr(dl), L.ptr(dw), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                                L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(ws), L.i(1 if accumulate else 0),
+                                                ctypes.byref(d), L.stream()), "ab_conv2d_wgrad_x3_deferred")
+        return dw
     ws = _workspace(nbytes, xh.device)
     L.check(lib.ab_conv2d_wgrad_x3(L.ptr(xh), L.ptr(xl), L.ptr(dh), L.ptr(dl), L.ptr(dw), L.i(N), L.i(H), L.i(W), L.i(Cin),
                                    L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(ws), L.i(1 if accumulate else 0),
@@ -562,7 +569,7 @@ def conv2d_stem_fwd_x3(xpad, w_split, H, W, want_stats=False):
     return (y, stats) if want_stats else y
 
 
-def conv2d_stem_wgrad_x3(xpad, dy, H, W, out=None):
+def conv2d_stem_wgrad_x3(xpad, dy, H, W, out=None, defer=None):
     xh, xl = _planes(xpad)
     dh, dl = _planes(dy)
     N = xh.shape[0]
@@ -570,6 +577,11 @@ def conv2d_stem_wgrad_x3(xpad, dy, H, W, out=None):
     lib = L.lib()
     nbytes = lib.ab_conv2d_stem_wgrad_workspace(L.i(N), L.i(H), L.i(W), L.i(Cout))
     dw = out if out is not None else torch.empty((Cout, 7, 8, 4), dtype=torch.float32, device=xh.device)
+    if defer is not None:
+        ws, d = defer.new(nbytes, xh.device)
+        L.check(lib.ab_conv2d_stem_wgrad_x3_deferred(L.ptr(xh), L.ptr(xl), L.ptr(dh), L.ptr(dl), L.ptr(dw), L.i(N), L.i(H), L.i(W),
+                                                     L.i(Cout), L.ptr(ws), ctypes.byref(d), L.stream()), "ab_conv2d_stem_wgrad_x3_deferred")
+        return dw
     ws = _workspace(nbytes, xh.device)
     L.check(lib.ab_conv2d_stem_wgrad_x3(L.ptr(xh), L.ptr(xl), L.ptr(dh), L.ptr(dl), L.ptr(dw), L.i(N), L.i(H), L.i(W), L.i(Cout),
                                         L.ptr(ws), L.stream()), "ab_conv2d_stem_wgrad_x3")

@@ -93,6 +93,11 @@ int ab_conv2d_wgrad_deferred(const void* x, const void* dy, float* dw, int dtype
                              ab_wgrad_reduce_desc* pending, void* stream);
 int ab_conv2d_stem_wgrad_deferred(const void* xpad, const void* dy, float* dw, int dtype, int N, int H, int W, int Cout,
                                   void* workspace, ab_wgrad_reduce_desc* pending, void* stream);
+int ab_conv2d_wgrad_x3_deferred(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N, int H,
+                                int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace, int accumulate,
+                                ab_wgrad_reduce_desc* pending, void* stream);
+int ab_conv2d_stem_wgrad_x3_deferred(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo, float* dw,
+                                     int N, int H, int W, int Cout, void* workspace, ab_wgrad_reduce_desc* pending, void* stream);
 int ab_wgrad_reduce_batch(const ab_wgrad_reduce_desc* desc, int n, void* stream);
 long ab_conv2d_stem_wgrad_workspace(int N, int H, int W, int Cout);
 int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw, int dtype, int N, int H, int W, int Cout,
@@ -123,7 +128,8 @@ int ab_conv2d_dgrad_x3_bn_rows(int N, int H, int W, int Cin, int Cout, int kh, i
 int ab_conv2d_dgrad_x3_bn(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dz, int N, int H,
                           int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend,
                           const float* bn_y, const void* bn_out_hi, const float* bnp, float* bn_part, void* stream);
-/* workspace: ab_conv2d_wgrad_workspace(N*Ho*Wo, Cout, kh*kw*Cin) bytes                                               */
+/* workspace: ab_conv2d_wgrad_x3_workspace(...) bytes (the split-bf16 kernels slice the pixels differently from the bf16 ones) */
+long ab_conv2d_wgrad_x3_workspace(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N, int H,
                        int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace, int accumulate,
                        void* stream);

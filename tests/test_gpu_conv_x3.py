@@ -278,3 +278,25 @@ def test_conv3x3_x3_256x64_tile(case, monkeypatch):
     close(dz.cpu(), ref_dz)
     np.testing.assert_allclose(part.double().sum(0).cpu()[:, 0].numpy(), ref_dz.sum((0, 1, 2)).numpy(), rtol=1e-4,
                                atol=3e-5 * float(ref_dz.abs().sum((0, 1, 2)).max()))
+
+
+@pytest.mark.parametrize("case", [(64, 64, 64, 64, 128, 1, 2, 0), (8, 32, 32, 128, 256, 3, 2, 1), (4, 16, 16, 256, 256, 3, 1, 1),
+                                  (16, 32, 32, 256, 704, 1, 1, 0)])
+def test_wgrad_x3_deferred_reduction_with_exact_workspace(case):
+    """Deferred slab reductions (several weight gradients reduced by ONE launch) give the same bits as the immediate ones, each
+    on a workspace of exactly ab_conv2d_wgrad_x3_workspace bytes (the 1x1/s2 downsample shape at B = 64 slices its pixels 256
+    ways: twice what the bf16 kernels' workspace formula provides)."""
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = K.split(torch.randn((N, H, W, Cin), generator=g).cuda())
+    Ho, Wo = K.conv_out(H, k, s, p), K.conv_out(W, k, s, p)
+    dy = K.split(torch.randn((N, Ho, Wo, Cout), generator=g).cuda())
+    ref = K.conv2d_wgrad_x3(x, dy, k, k, s, p)
+    pend = K.PendingReductions()
+    a = K.conv2d_wgrad_x3(x, dy, k, k, s, p, defer=pend)
+    b = K.conv2d_wgrad_x3(x, dy, k, k, s, p, defer=pend)
+    assert len(pend.descs) == 2
+    pend.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref) and torch.equal(b, ref)
