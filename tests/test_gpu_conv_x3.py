@@ -300,3 +300,22 @@ def test_wgrad_x3_deferred_reduction_with_exact_workspace(case):
     pend.flush()
     torch.cuda.synchronize()
     assert torch.equal(a, ref) and torch.equal(b, ref)
+
+
+@pytest.mark.parametrize("case", [(64, 64, 64, 64, 128, 1, 2, 0), (8, 32, 32, 128, 256, 3, 2, 1), (4, 16, 16, 256, 256, 3, 1, 1),
+                                  (16, 32, 32, 256, 704, 1, 1, 0), (64, 8, 8, 512, 512, 3, 1, 1)])
+def test_wgrad_bf16_deferred_reduction_with_exact_workspace(case):
+    """The same exact-size-workspace check for the bf16 weight gradients (ab_conv2d_wgrad_workspace)."""
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = torch.randn((N, H, W, Cin), generator=g).to(torch.bfloat16).cuda()
+    Ho, Wo = K.conv_out(H, k, s, p), K.conv_out(W, k, s, p)
+    dy = torch.randn((N, Ho, Wo, Cout), generator=g).to(torch.bfloat16).cuda()
+    ref = K.conv2d_wgrad(x, dy, k, k, s, p)
+    pend = K.PendingReductions()
+    a = K.conv2d_wgrad(x, dy, k, k, s, p, defer=pend)
+    b = K.conv2d_wgrad(x, dy, k, k, s, p, defer=pend)
+    pend.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref) and torch.equal(b, ref)
