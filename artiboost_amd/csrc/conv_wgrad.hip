@@ -427,7 +427,9 @@ extern "C" int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw,
 
 extern "C" long ab_conv2d_stem_wgrad_workspace(int N, int H, int W, int Cout) {
     long a = ab_conv2d_wgrad_workspace(N * (H / 2) * (W / 2), Cout, 256);
-    long b = (long)(wgrad_gemm2_stem_slices(N, H, W, Cout) + 1) * Cout * 256 * 4;
+    int n = N;                                               // the split-bf16 stem splits batches beyond 2^21 output pixels in halves
+    while ((long)n * (H / 2) * (W / 2) >= (1L << 21) && n > 1) n -= n / 2;
+    long b = (long)(wgrad_gemm2_stem_slices(n, H, W, Cout) + 1) * Cout * 256 * 4;
     return a > b ? a : b;
 }
 

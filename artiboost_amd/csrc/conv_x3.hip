@@ -168,6 +168,7 @@ extern "C" int ab_conv2d_dgrad_x3_bn(const void* dy_hi, const void* dy_lo, const
 }
 
 // ---------------------------------------------------------------- weight gradient
+static const long X3_WGRAD_MAX_M_FWD = 1L << 21;
 // bytes of slab workspace ab_conv2d_wgrad_x3 writes for this shape (its own slice counts: not those of the bf16 kernels)
 extern "C" long ab_conv2d_wgrad_x3_workspace(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
     if (kh * kw > 16 || Cin % 64 || Cout % 64) return 0;
@@ -176,16 +177,33 @@ extern "C" long ab_conv2d_wgrad_x3_workspace(int N, int H, int W, int Cin, int C
         int ns = wgrad3x3_x3_slices(N, H, W, Cin, Cout);
         if (ns > 0) return ns * slab;
     }
-    const int M = N * ((H + 2 * pad - kh) / stride + 1) * ((W + 2 * pad - kw) / stride + 1);
-    int ns = wgrad_gemm2_x3_slices(M, Cout, Cin, kh * kw);
+    const long Mi = (long)((H + 2 * pad - kh) / stride + 1) * ((W + 2 * pad - kw) / stride + 1);
+    int n = N;
+    while ((long)n * Mi >= X3_WGRAD_MAX_M_FWD && n > 1) n = n - n / 2;       // the larger half of ab_conv2d_wgrad_x3's batch split
+    int ns = wgrad_gemm2_x3_slices((int)(n * Mi), Cout, Cin, kh * kw);
     return ns > 0 ? ns * slab : 0;
 }
+
+// The generic weight-gradient kernels index pixels with 21-bit magic divisions: larger launches (a stem at batch 128 x 256^2) run
+// as two half-batches, the second accumulating onto the first.
+static const long X3_WGRAD_MAX_M = 1L << 21;
 
 extern "C" int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* dw, int N,
                                   int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, void* workspace,
                                   int accumulate, void* stream) {
     if (!x_hi || !x_lo || !dy_hi || !dy_lo || !dw || !workspace) return AB_EINVAL;
     if (kh * kw > 16 || Cin % 64 || Cout % 64) return AB_ESHAPE;
+    {
+        const long Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+        if ((long)N * Ho * Wo >= X3_WGRAD_MAX_M && N > 1 && !x3_is_c3(kh, kw, stride, pad)) {
+            const int n1 = N / 2;
+            const long xo = (long)n1 * H * W * Cin, yo = (long)n1 * Ho * Wo * Cout;
+            int rc = ab_conv2d_wgrad_x3(x_hi, x_lo, dy_hi, dy_lo, dw, n1, H, W, Cin, Cout, kh, kw, stride, pad, workspace, accumulate, stream);
+            if (rc) return rc;
+            return ab_conv2d_wgrad_x3((const bf16_t*)x_hi + xo, (const bf16_t*)x_lo + xo, (const bf16_t*)dy_hi + yo, (const bf16_t*)dy_lo + yo,
+                                      dw, N - n1, H, W, Cin, Cout, kh, kw, stride, pad, workspace, 1, stream);
+        }
+    }
     hipStream_t st = as_stream(stream);
     const long slab = (long)Cout * kh * kw * Cin;
     if (x3_is_c3(kh, kw, stride, pad)) {
@@ -225,13 +243,26 @@ extern "C" int ab_conv2d_stem_fwd_x3(const void* xpad_hi, const void* xpad_lo, c
 }
 
 /* dw fp32 [Cout][7][8][4]; workspace: ab_conv2d_stem_wgrad_workspace(N, H, W, Cout) bytes */
+static int stem_wgrad_x3_impl(const bf16_t* xpad_hi, const bf16_t* xpad_lo, const bf16_t* dy_hi, const bf16_t* dy_lo, float* dw, int N,
+                              int H, int W, int Cout, void* workspace, int accumulate, hipStream_t st) {
+    if ((long)N * (H / 2) * (W / 2) >= X3_WGRAD_MAX_M && N > 1) {         // two half-batches (see X3_WGRAD_MAX_M)
+        const int n1 = N / 2;
+        const long xo = (long)n1 * (H + 6) * (W + 8) * 4, yo = (long)n1 * (H / 2) * (W / 2) * Cout;
+        int rc = stem_wgrad_x3_impl(xpad_hi, xpad_lo, dy_hi, dy_lo, dw, n1, H, W, Cout, workspace, accumulate, st);
+        if (rc) return rc;
+        return stem_wgrad_x3_impl(xpad_hi + xo, xpad_lo + xo, dy_hi + yo, dy_lo + yo, dw, N - n1, H, W, Cout, workspace, 1, st);
+    }
+    int ns = wgrad_gemm2_stem_slices(N, H, W, Cout);
+    if (ns <= 0) return AB_ESHAPE;
+    int rc = wgrad_gemm2_x3_stem_run(xpad_hi, xpad_lo, dy_hi, dy_lo, (float*)workspace, N, H, W, Cout, st);
+    if (rc) return rc;
+    return wgrad_launch_reduce((float*)workspace, ns, (long)Cout * 256, 256, 7 * 32, dw, accumulate, 1, st);
+}
+
 extern "C" int ab_conv2d_stem_wgrad_x3(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo, float* dw,
                                        int N, int H, int W, int Cout, void* workspace, void* stream) {
     if (!xpad_hi || !xpad_lo || !dy_hi || !dy_lo || !dw || !workspace) return AB_EINVAL;
     if ((H & 1) || (W & 1) || Cout % 64) return AB_ESHAPE;
-    int ns = wgrad_gemm2_stem_slices(N, H, W, Cout);
-    if (ns <= 0) return AB_ESHAPE;
-    int rc = wgrad_gemm2_x3_stem_run(xpad_hi, xpad_lo, dy_hi, dy_lo, (float*)workspace, N, H, W, Cout, as_stream(stream));
-    if (rc) return rc;
-    return wgrad_launch_reduce((float*)workspace, ns, (long)Cout * 256, 256, 7 * 32, dw, 0, 1, as_stream(stream));
+    return stem_wgrad_x3_impl((const bf16_t*)xpad_hi, (const bf16_t*)xpad_lo, (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, dw, N, H, W, Cout,
+                              workspace, 0, as_stream(stream));
 }

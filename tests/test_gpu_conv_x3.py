@@ -319,3 +319,20 @@ def test_wgrad_bf16_deferred_reduction_with_exact_workspace(case):
     pend.flush()
     torch.cuda.synchronize()
     assert torch.equal(a, ref) and torch.equal(b, ref)
+
+
+def test_stem_wgrad_x3_beyond_2p21_pixels():
+    """A stem weight gradient over more than 2^21 output pixels (batch 128 at 256 x 256 -- the reference YAML's TRAIN.BATCH_SIZE on
+    one GPU) runs as two half-batches; same result as the sum of the halves computed separately."""
+    from artiboost_amd import kernels as K
+    N, H, W = 130, 256, 256
+    g = torch.Generator().manual_seed(1)
+    xpad = K.split(K.image_pad_nhwc4((torch.rand((N, 3, H, W), generator=g) - 0.5).cuda(), torch.float32))
+    dy = K.split(torch.randn((N, H // 2, W // 2, 64), generator=g).cuda())
+    assert N * (H // 2) * (W // 2) >= 1 << 21
+    dw = K.conv2d_stem_wgrad_x3(xpad, dy, H, W)
+    h = N // 2
+    a = K.conv2d_stem_wgrad_x3(xpad[:, :h].contiguous(), dy[:, :h].contiguous(), H, W)
+    b = K.conv2d_stem_wgrad_x3(xpad[:, h:].contiguous(), dy[:, h:].contiguous(), H, W)
+    ref = a.double() + b.double()
+    assert float((dw.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
