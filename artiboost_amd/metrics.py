@@ -6,7 +6,7 @@ from typing import Dict, List
 import numpy as np
 import torch
 
-from .registry import METRIC, Queries, SynthQueries
+from .registry import CONST, METRIC, Queries, SynthQueries
 
 
 class AverageMeter:
@@ -146,6 +146,8 @@ class Evaluator:
     def get_measures_all(self):
         out = {}
         for m in self._metrics_list:
+            if isinstance(m, VisMetric):
+                continue
             out.update(m.get_measures())
         return out
 
@@ -153,18 +155,108 @@ class Evaluator:
         """evaluator.py:58-74: {metric class name: {measure: float}} (scalars only) for the recorder / summarizer."""
         out = {}
         for m in self._metrics_list:
-            if not return_losses and isinstance(m, LossesMetric):
+            if isinstance(m, VisMetric) or (not return_losses and isinstance(m, LossesMetric)):
                 continue
             out[type(m).__name__] = {k: float(v) for k, v in m.get_measures().items()
                                      if isinstance(v, (float, int)) or (hasattr(v, "ndim") and getattr(v, "ndim") == 0)}
         return out
 
     def dump_images(self):
-        """evaluator.py:76-82 (the Vis* metrics draw with cv2 / matplotlib and are not part of this build)."""
-        return {}
+        """evaluator.py:76-82: {metric class name: image} of the Vis* metrics."""
+        return {type(m).__name__: m.image for m in self._metrics_list if isinstance(m, VisMetric)}
 
     def __str__(self):
-        return " | ".join(s for s in (str(m) for m in self._metrics_list) if s)
+        return " | ".join(s for s in (str(m) for m in self._metrics_list if not isinstance(m, VisMetric)) if s)
+
+
+class VisMetric(Metric):
+    """anakin/metrics/vismetric.py:18-68: a metric whose product is an image (skipped by the evaluator's measure tables)."""
+
+    def __init__(self, **cfg):
+        self.image, self.count = None, 0
+
+    def reset(self):
+        self.count = 0
+
+    def get_measures(self, **kwargs):
+        raise NotImplementedError()
+
+    def __str__(self):
+        return ""
+
+
+@METRIC.register_module
+class Vis2DMetric(VisMetric):
+    """anakin/metrics/vismetric.py:71-200: the first batch fed after a reset is drawn as an NROW x NCOL grid of crops with the
+    hand skeleton, the object's box edges, the ground-truth root (star) and box corners 0 / 7 (triangles) -- predictions on the
+    left half, ground truth on the right.  `image`: uint8 BGR [H, 2W, 3] like the reference's.  Drawn with PIL (the reference
+    uses matplotlib); later batches of the epoch only count."""
+    FINGER_COLORS = [(255, 0, 0), (255, 0, 255), (0, 0, 255), (0, 255, 255), (0, 255, 0)]       # thumb .. little (RGB)
+    BOX_EDGES = [(0, 1), (1, 3), (3, 2), (2, 0), (4, 5), (5, 7), (7, 6), (6, 4), (1, 5), (2, 6), (3, 7), (0, 4)]
+
+    def __init__(self, **cfg):
+        super().__init__(**cfg)
+        self.inp_res = cfg["DATA_PRESET"]["IMAGE_SIZE"]
+        self.ncol, self.nrow = int(cfg.get("NCOL", 3)), int(cfg.get("NROW", 3))
+        self.corner_link_order = list(cfg.get("CORNER_LINK_ORDER", range(8)))
+
+    @staticmethod
+    def _images(targs):
+        img = targs.get(Queries.IMAGE)
+        if img is not None:
+            return (img.detach().float().cpu().permute(0, 2, 3, 1) + 0.5).clamp(0, 1).numpy()
+        pad = targs["image_nhwc4_padded"]                    # the HIP loader's batch: zero-bordered NHWC4 (fp32 / bf16 or its planes)
+        if pad.dim() == 5:
+            pad = pad[0].float() + pad[1].float()
+        pad = pad.detach().float().cpu()
+        return (pad[:, 3:-3, 3:-5, :3] + 0.5).clamp(0, 1).numpy()
+
+    def _draw(self, images, joints, corners, root, jvis, cvis):
+        from PIL import Image, ImageDraw
+        W, H = int(self.inp_res[0]), int(self.inp_res[1])
+        grid = Image.new("RGB", (self.ncol * W, self.nrow * H))
+        for i in range(min(self.ncol * self.nrow, images.shape[0])):
+            tile = Image.fromarray((images[i] * 255.0 + 0.5).astype(np.uint8)).resize((W, H))
+            d = ImageDraw.Draw(tile)
+            j, c = joints[i], corners[i]
+            for k in range(1, CONST.NUM_JOINTS):
+                par = CONST.JOINTS_IDX_PARENTS[k]
+                d.line([tuple(j[par]), tuple(j[k])], fill=self.FINGER_COLORS[(k - 1) // 4], width=2)
+            for k in range(CONST.NUM_JOINTS):
+                r = 2 if jvis is None or jvis[i][k] > 0 else 1
+                d.ellipse([j[k][0] - r, j[k][1] - r, j[k][0] + r, j[k][1] + r], outline=(255, 255, 255))
+            for a, b in self.BOX_EDGES:
+                a, b = self.corner_link_order[a], self.corner_link_order[b]
+                d.line([tuple(c[a]), tuple(c[b])], fill=(64, 224, 208), width=2)
+            d.regular_polygon((float(root[i][0]), float(root[i][1]), 5), 5, fill=(138, 43, 226))
+            d.regular_polygon((float(c[0][0]), float(c[0][1]), 4), 3, fill=(255, 0, 0))
+            d.regular_polygon((float(c[7][0]), float(c[7][1]), 4), 3, fill=(255, 255, 0))
+            grid.paste(tile, ((i % self.ncol) * W, (i // self.ncol) * H))
+        return np.asarray(grid)[:, :, ::-1]
+
+    def feed(self, preds, targs, **kwargs):
+        bs = int(targs[Queries.JOINTS_2D].shape[0])
+        if self.count > 0:
+            self.count += bs
+            return
+        res = np.asarray(self.inp_res, dtype=np.float32)
+        if "2d_uvd" in preds:
+            uvd = preds["2d_uvd"].detach().float().cpu().numpy()
+            pj, pc = uvd[:, :CONST.NUM_JOINTS, :2] * res, uvd[:, CONST.NUM_JOINTS:CONST.NUM_JOINTS + 8, :2] * res
+        else:
+            pj, pc = preds["joints_2d"].detach().float().cpu().numpy(), preds["corners_2d"].detach().float().cpu().numpy()
+        gj = targs[Queries.JOINTS_2D][:, :CONST.NUM_JOINTS].detach().float().cpu().numpy()
+        gc = targs[Queries.CORNERS_2D].detach().float().cpu().numpy()
+        jv = targs[Queries.JOINTS_VIS].detach().float().cpu().numpy() if Queries.JOINTS_VIS in targs else None
+        cv = targs[Queries.CORNERS_VIS].detach().float().cpu().numpy() if Queries.CORNERS_VIS in targs else None
+        images = self._images(targs)
+        self.image = np.concatenate([self._draw(images, pj, pc, gj[:, 0], jv, cv), self._draw(images, gj, gc, gj[:, 0], jv, cv)], axis=1)
+        self.count += bs
+
+
+@METRIC.register_module
+class VisHand2DMetric(Vis2DMetric):
+    """vismetric.py:361: the hand-only variant shares the drawing."""
 
 
 # ============================================================================ eval / submit path (SURVEY.md section 8f-4)

@@ -156,6 +156,12 @@ class HybridBaseline(nn.Module):
             raise NotImplementedError("IntegralDeconvHead: softmax norm + 1x1 final conv only")
         if cfg["BACKBONE"].get("FREEZE_BATCHNORM", False):
             raise NotImplementedError("FREEZE_BATCHNORM")
+        if cfg["BACKBONE"].get("PRETRAINED") is True:
+            # resnet.py:249-262 fetches torchvision's ImageNet weights (a download); here the backbone keeps its seeded
+            # initialisation unless ARCH.PRETRAINED names a checkpoint in the reference's state-dict layout
+            import warnings
+            warnings.warn("BACKBONE.PRETRAINED: true -- ImageNet weights are a torchvision download and are not fetched; "
+                          "pass a converted checkpoint through ARCH.PRETRAINED")
         dev = cfg.get("DEVICE", "cuda")
         cd = cfg.get("COMPUTE_DTYPE", "bf16x3")     # the reference's precision (fp32-grade); "bf16" / "f32" opt in
         self.store = ParamStore(self.nclasses, self.depth_res, device=dev)

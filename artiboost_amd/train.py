@@ -149,6 +149,20 @@ class TrainStep:
 
     _capturing_split = False
 
+    def predictions(self):
+        """The step's predictions under the NINE keys HybridBaseline.forward returns (hybridbaseline.py:86-96).  The fused path keeps
+        only what the criterion kernel writes; the root-relative and box-root entries the evaluator's PCK / visual metrics read are
+        derived here (a few small device ops, outside the graphs)."""
+        if self.fused is None:
+            return self.out[0]
+        o, st = self.fused.out, self.static
+        ja, ca, R = o["joints_3d_abs"], o["corners_3d_abs"], o["box_rot_rotmat"]
+        root = ja[:, self.hb.center_idx:self.hb.center_idx + 1]
+        can = st[Queries.CORNERS_CAN].to(ca.dtype)
+        boxroot = (ca - torch.matmul(R, can.permute(0, 2, 1)).permute(0, 2, 1)).mean(1, keepdim=True)
+        return {"joints_3d_abs": ja, "corners_3d_abs": ca, "joints_3d": ja - root, "corners_3d": ca - root, "2d_uvd": o["uvd2d"],
+                "boxroot_3d_abs": boxroot, "box_rot_rotmat": R, "kp3d": self.out[0]["kp3d"], "kp3d_confd": self.out[0]["kp3d_confd"]}
+
     def _optim(self):
         self.opt.step()
 
@@ -355,8 +369,10 @@ class DeferredEpochMetrics:
 
     def collect(self):
         o, st, i = self.ts.fused.out, self.ts.static, self.n
-        for m in self.direct:
-            m.feed(self.ts.out[0], st)
+        if self.direct:
+            full = self.ts.predictions()
+            for m in self.direct:
+                m.feed(full, st)
         self.epe[i].copy_(o["sample_part"][:, 5:7])
         self.losses[i].copy_(o["losses"])
         self.ids[i].copy_(torch.stack([st[SynthQueries.OBJ_ID], st[SynthQueries.PERSP_ID], st[SynthQueries.GRASP_ID],

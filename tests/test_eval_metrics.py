@@ -100,3 +100,34 @@ def test_submit_pass_prediction_file(tmp_path):
     with zipfile.ZipFile(str(tmp_path / "pred.zip")) as z:
         assert z.namelist() == ["pred.json"]
     assert ev.get_measures_all()["joints_3d_abs_mepe"] > 0
+
+
+def test_vis2d_metric_draws_first_batch_only():
+    """Vis2DMetric (the reference's shipped YAML lists it under EVALUATOR): an image metric -- first batch after a reset drawn as a
+    [prediction | ground truth] grid, skipped by the evaluator's measure tables, returned by dump_images()."""
+    import torch
+    from artiboost_amd import registry as R
+    from artiboost_amd.metrics import Evaluator, Vis2DMetric
+    preset = {"IMAGE_SIZE": [64, 48]}
+    mets = R.build_evaluator_metric_list([{"TYPE": "Vis2DMetric", "NCOL": 3, "NROW": 2},
+                                          {"TYPE": "Mean3DEPE", "VAL_KEYS": ["joints_3d_abs"], "MILLIMETERS": True}], preset_cfg=preset)
+    ev = Evaluator({}, mets)
+    g = torch.Generator().manual_seed(0)
+    B = 4
+    targs = {"image": torch.rand((B, 3, 48, 64), generator=g) - 0.5, "joints_2d": torch.rand((B, 21, 2), generator=g) * 40 + 4,
+             "corners_2d": torch.rand((B, 8, 2), generator=g) * 40 + 4, "joints_vis": torch.ones(B, 21), "corners_vis": torch.ones(B, 8),
+             "joints_3d": torch.zeros(B, 21, 3), "root_joint": torch.zeros(B, 3)}
+    preds = {"2d_uvd": torch.rand((B, 30, 3), generator=g), "joints_3d_abs": torch.zeros(B, 21, 3)}
+    ev.reset_all()
+    ev.feed_all(preds, targs, {})
+    vis = mets[0]
+    assert isinstance(vis, Vis2DMetric) and vis.count == B
+    img = vis.image
+    assert img.shape == (2 * 48, 2 * 3 * 64, 3) and img.dtype == np.uint8
+    assert img[:, :3 * 64].any() and not np.array_equal(img[:, :3 * 64], img[:, 3 * 64:])       # predictions drawn != ground truth drawn
+    assert not img[48:, 64:3 * 64].any()                                                          # tiles 5, 6 of the grid stay empty (B = 4)
+    first = img.copy()
+    ev.feed_all({"2d_uvd": torch.rand((B, 30, 3), generator=g), "joints_3d_abs": torch.zeros(B, 21, 3)}, targs, {})
+    assert vis.count == 2 * B and np.array_equal(vis.image, first)
+    assert "Vis2DMetric" not in ev.get_measures_all_striped() and list(ev.dump_images()) == ["Vis2DMetric"]
+    assert "Vis2DMetric" not in str(ev)

@@ -115,6 +115,10 @@ def test_train_script_with_the_reference_command_line(tmp_path):
     import yaml
     cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
     cfg["TRAIN"]["EPOCH"] = 2
+    # the metric list of the reference's shipped YAML (config/ho3dv2_clasbased_jlol_artiboost2.yaml): PCK and the 2-D visual metric
+    # are fed from TrainStep.predictions() after every step, the rest once per epoch from device-side records
+    cfg["EVALUATOR"] += [{"TYPE": "Hand3DPCKMetric", "VAL_MIN": 0.0, "VAL_MAX": 0.05, "STEPS": 20},
+                         {"TYPE": "Obj3DPCKMetric", "VAL_MIN": 0.0, "VAL_MAX": 0.05, "STEPS": 20}, {"TYPE": "Vis2DMetric", "NCOL": 2, "NROW": 2}]
     y = tmp_path / "cfg.yaml"
     y.write_text(yaml.dump(cfg))
     cmd = [sys.executable, os.path.join(ROOT, "train", "train_artiboost.py"), "--cfg", str(y), "--gpu_id", "0", "--gpu_render_id", "0",
@@ -122,7 +126,7 @@ def test_train_script_with_the_reference_command_line(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("epoch ")]
-    assert len(lines) == 2 and "final_loss" in lines[-1]
+    assert len(lines) == 2 and "final_loss" in lines[-1] and "hand3d pck" in lines[-1]
     exp = [d for d in os.listdir(tmp_path / "exp") if d.startswith("t_")]
     assert len(exp) == 1
     ck = tmp_path / "exp" / exp[0] / "checkpoints" / "checkpoint"

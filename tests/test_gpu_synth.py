@@ -330,3 +330,35 @@ def test_deferred_epoch_metrics_equal_per_step_feeding():
     loader.sample_weight_map = wa
     loader.step_eval(0, ev_b)
     np.testing.assert_allclose(loader.sample_weight_map.numpy(), w1.numpy(), rtol=1e-5)      # same mining update
+
+
+def test_train_step_predictions_match_the_model_forward():
+    """TrainStep.predictions(): the nine HybridBaseline keys rebuilt from the fused criterion kernel's outputs == the model's own
+    forward on the same batch (learning rate 0, so the weights the step just used are still in place)."""
+    import yaml, os
+    from artiboost_amd import registry as R
+    from artiboost_amd.criterions import Criterion
+    from artiboost_amd.models import Arch
+    from artiboost_amd.optim import FusedClipAdam
+    from artiboost_amd.train import TrainStep
+    assets, loader = _loader(torch.float32, bs=4, n=8, size=64)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [64, 64], [8, 8]
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16x3", SEGMENT_GRAPHS=False)
+    model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
+    crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+    opt = FusedClipAdam(model.models_params, lr=0.0, max_norm=1.0, model=model.model_list[0])
+    loader.prepare()
+    static = loader.new_static_batch()
+    loader.load_batch(static, 0)
+    model.train()
+    ts = TrainStep(model, crit, opt, static, use_graph=False, renderer=loader)
+    ts.static = static
+    ts()
+    got = {k: v.detach().clone() for k, v in ts.predictions().items()}
+    with torch.no_grad():
+        ref = model(static)["HybridBaseline"]
+    assert set(got) == set(ref)
+    for k in ref:
+        np.testing.assert_allclose(got[k].float().cpu().numpy(), ref[k].float().cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)

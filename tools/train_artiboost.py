@@ -96,7 +96,7 @@ def main():
             if rec is not None:
                 rec.collect()
             else:
-                evaluator.feed_all(preds, ts.static, ts.fused.losses_dict() if ts.fused is not None else losses)
+                evaluator.feed_all(ts.predictions(), ts.static, ts.fused.losses_dict() if ts.fused is not None else losses)
         if rec is not None:
             rec.flush(evaluator)
         torch.cuda.synchronize()

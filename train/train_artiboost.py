@@ -18,7 +18,8 @@ scheduler.step -> step_eval -> recorder); what differs is HOW a step is issued a
   flat gradient is averaged with RCCL while the backward is still running, every rank applies the same mining update.
   `--gpu_render_id` is accepted and unused: rendering is in-process on the training GPU.
 
-Extra flags: --dtype {bf16x3,f32,bf16}, --synth_len N (samples per epoch when the real set is absent), --size S (square image).
+Extra flags: --dtype {bf16x3,f32,bf16}, --synth_len N (samples per epoch when the real set is absent), --size S (square image),
+--no_refiner (drop the MANAGER.REFINER block: its GrabNet checkpoint is a download).
 --dry-launch: parse, start the ranks (gloo), report the world size and exit (the launcher test)."""
 import os
 import sys
@@ -53,6 +54,7 @@ def main():
     dtype = _pop_flag(argv, "--dtype", default="bf16x3")
     synth_len = _pop_flag(argv, "--synth_len")
     size = _pop_flag(argv, "--size")
+    no_refiner = _pop_flag(argv, "--no_refiner", has_value=False, default=False)
     shared = _pop_flag(argv, "--allow-shared-devices", has_value=False, default=False)      # ranks over gloo on one device: tests only
     gpus = _gpu_ids(argv)
     if len(gpus) > 1 and "WORLD_SIZE" not in os.environ:
@@ -130,6 +132,8 @@ def main():
         cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [int(size)] * 2, [int(size) // 8] * 2
     if synth_len:
         cfg["MANAGER"]["SYNTH_LEN"] = int(synth_len)
+    if no_refiner:
+        cfg["MANAGER"].pop("REFINER", None)      # the GrabNet checkpoint (assets/GrabNet/refinenet.pt) is a download
     arch = cfg["ARCH"] if isinstance(cfg["ARCH"], dict) else cfg["ARCH"][0]
     arch.update(COMPUTE_DTYPE=dtype, DEVICE=dev, INIT_SEED=seed)
 
@@ -179,7 +183,7 @@ def main():
             if rec is not None:
                 rec.collect()
             else:
-                evaluator.feed_all(preds, ts.static, losses)
+                evaluator.feed_all(ts.predictions(), ts.static, losses)
         if rec is not None:
             rec.flush(evaluator)
         torch.cuda.synchronize()
