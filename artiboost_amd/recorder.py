@@ -164,6 +164,16 @@ class Summarizer:
         for k, v in evaluator.get_measures_all_striped(return_losses=False).items():
             for k_, v_ in (v.items() if isinstance(v, dict) else [("", v)]):
                 self._scalar(f"{k}/{_PREFIX[train_mode]}/{k_}".rstrip("/"), v_, epoch)
+        # summarizer.py:41-47: the Vis* metrics' images (BGR arrays) -> TensorBoard, or PNG files next to the scalars
+        for k, img in (evaluator.dump_images() if hasattr(evaluator, "dump_images") else {}).items():
+            if img is None:
+                continue
+            if self.tb_writer is not None:
+                self.tb_writer.add_image(f"{k}/{_PREFIX[train_mode]}", img[:, :, ::-1].copy(), epoch, dataformats="HWC")
+            elif self._fallback is not None:
+                from PIL import Image
+                Image.fromarray(img[:, :, ::-1].copy()).save(os.path.join(os.path.dirname(self._fallback.name),
+                                                                            f"{k}_{_PREFIX[train_mode]}_{epoch}.png"))
 
     def summarize_losses(self, losses):
         if self.rank:
