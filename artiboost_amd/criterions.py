@@ -178,6 +178,39 @@ class JointsLoss(TensorLoss):
         return final_loss, losses
 
 
+@LOSS.register_module
+class ManoLoss(TensorLoss):
+    """anakin/criterions/honetloss.py:12-73: MANO shape / pose regularisers and (optional) joint / vertex supervision of the
+    regression-based model (config_eval/eval_ho3dv2_regbased_artiboost.yaml)."""
+
+    def __init__(self, **cfg):
+        super().__init__()
+        self.lambda_joints_3d = float(cfg["LAMBDA_JOINTS_3D"])
+        self.lambda_hand_verts_3d = float(cfg["LAMBDA_HAND_VERTS_3D"])
+        self.lambda_shape_reg = float(cfg["LAMBDA_SHAPE_REG"])
+        self.lambda_pose_reg = float(cfg["LAMBDA_POSE_REG"])
+
+    def __call__(self, preds, targs, **kwargs):
+        final_loss, losses = super().__call__(preds, targs, **kwargs)
+        shape_reg = pose_reg = lj = lv = None
+        if self.lambda_shape_reg:
+            shape_reg = preds["mano_shape"].pow(2).mean()
+            final_loss = final_loss + self.lambda_shape_reg * shape_reg
+        if self.lambda_pose_reg:
+            pose_reg = preds["mano_pca_pose"][:, 3:].pow(2).mean()            # the root rotation is not regularised
+            final_loss = final_loss + self.lambda_pose_reg * pose_reg
+        if self.lambda_joints_3d and Queries.JOINTS_3D in targs:
+            p = preds["joints_3d_abs"]
+            lj = F.mse_loss(p, targs[Queries.JOINTS_3D].to(p.device) + targs[Queries.ROOT_JOINT].to(p.device).unsqueeze(1))
+            final_loss = final_loss + self.lambda_joints_3d * lj
+        if self.lambda_hand_verts_3d and "hand_verts_3d" in targs:
+            p = preds["hand_verts_3d_abs"]
+            lv = F.mse_loss(p, targs["hand_verts_3d"].to(p.device) + targs[Queries.ROOT_JOINT].to(p.device).unsqueeze(1))
+            final_loss = final_loss + self.lambda_hand_verts_3d * lv
+        losses.update(mano_shape=shape_reg, mano_pca_pose=pose_reg, joints_3d_loss=lj, hand_verts_3d_loss=lv)
+        return final_loss, losses
+
+
 def sample_view_vectors(n_virtual_views=20):
     """ordinal.py:59-71 (CPU draws from the global torch RNG: rand(n) for theta, then rand(n) for u)."""
     cam_vec = torch.Tensor([0.0, 0.0, 1.0]).unsqueeze(0)

@@ -44,15 +44,19 @@ class _BasicBlock(nn.Module):
         return self.relu(out + (x if self.downsample is None else self.downsample(x)))
 
 
-@BACKBONE.register_module
-class ResNet18(nn.Module):
-    """resnet.py:142-236 with layers [2, 2, 2, 2]; `forward(image=...)` returns the res_layer1..4 / res_layer4_mean dict."""
+class _TorchResNet(nn.Module):
+    """resnet.py:142-236 (BasicBlock variants) in plain torch -- the backbone of the regression-based model, which runs where the
+    reference runs it (CPU in BASELINE configs[0], any torch device otherwise); `forward(image=...)` returns the res_layer1..4 /
+    res_layer4_mean dict.  BACKBONE.PRETRAINED: true (torchvision's ImageNet weights, resnet.py:194-197,249-262) is a download:
+    reported and skipped -- the eval configs load the whole model from ARCH.PRETRAINED right after."""
+    LAYERS = (2, 2, 2, 2)
 
     @enable_lower_param
     def __init__(self, **cfg):
         super().__init__()
         if cfg.get("PRETRAINED"):
-            raise FileNotFoundError("ResNet18 PRETRAINED: the ImageNet weights are a download (resnet.py:194-197)")
+            import warnings
+            warnings.warn(f"{type(self).__name__} PRETRAINED: the ImageNet weights are a torchvision download and are not fetched")
         if cfg.get("FREEZE_BATCHNORM"):
             raise NotImplementedError("FREEZE_BATCHNORM")
         self.inplanes = 64
@@ -60,10 +64,10 @@ class ResNet18(nn.Module):
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
-        self.layer1 = self._make_layer(64, 2)
-        self.layer2 = self._make_layer(128, 2, 2)
-        self.layer3 = self._make_layer(256, 2, 2)
-        self.layer4 = self._make_layer(512, 2, 2)
+        self.layer1 = self._make_layer(64, self.LAYERS[0])
+        self.layer2 = self._make_layer(128, self.LAYERS[1], 2)
+        self.layer3 = self._make_layer(256, self.LAYERS[2], 2)
+        self.layer4 = self._make_layer(512, self.LAYERS[3], 2)
         self.fc = nn.Linear(512, 1000)             # present in the reference's state_dict (resnet.py:164); unused
         self.features = self.output_channel = 512
         for m in self.modules():                   # resnet.py:170-176
@@ -90,6 +94,18 @@ class ResNet18(nn.Module):
             f[f"res_layer{i}"] = x
         f["res_layer4_mean"] = x.mean(3).mean(2).view(x.size(0), -1)
         return f
+
+
+@BACKBONE.register_module
+class ResNet18(_TorchResNet):
+    LAYERS = (2, 2, 2, 2)
+
+
+@BACKBONE.register_module
+class ResNet34(_TorchResNet):
+    """The backbone config_eval/eval_ho3dv2_regbased_artiboost.yaml names for HOPRegNet (the clasbased HybridBaseline runs its own
+    ResNet-34 on the HIP kernels, hybridnet.py)."""
+    LAYERS = (3, 4, 6, 3)
 
 
 # ------------------------------------------------------------------------------------------------ MANO layer (torch)

@@ -51,6 +51,10 @@ class Mean3DEPE(Metric):
         self.val_keys_list: List[str] = cfg["VAL_KEYS"]
         self.avg_meters = {k: AverageMeter() for k in self.val_keys_list}
         self.to_millimeters = cfg.get("MILLIMETERS", False)
+        # meanepe.py:28-31,62-66: --filter_unseen_obj_idxs (through builder.build_evaluator_metric_list(..., arg=arg)) drops the
+        # samples of those object classes from the CORNER errors (HO3D's unseen pitcher, README evaluation commands)
+        arg = cfg.get("arg", cfg.get("ARG"))
+        self.filter_unseen_obj_idxs = list(getattr(arg, "filter_unseen_obj_idxs", []) or []) if arg is not None else []
 
     def reset(self):
         for m in self.avg_meters.values():
@@ -59,6 +63,12 @@ class Mean3DEPE(Metric):
     def feed(self, preds, targs, **kwargs):
         for key in self.val_keys_list:
             d = _epe_mm(preds, targs, key, self.to_millimeters)
+            if "corners" in key and self.filter_unseen_obj_idxs:
+                oi = targs[Queries.OBJ_IDX].to(d.device)
+                keep = torch.ones_like(oi, dtype=torch.bool)
+                for idx in self.filter_unseen_obj_idxs:
+                    keep &= oi != idx
+                d = d[keep]
             self.avg_meters[key].update(float(d.sum()), n=d.shape[0])
 
     def get_measures(self, **kwargs):

@@ -317,3 +317,37 @@ def test_train_script_launches_one_rank_per_listed_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     assert json.loads(line) == {"dry_launch": True, "n_gpus": 2, "gpu_id": ["0", "1"]}
+
+
+def test_every_type_named_by_the_reference_yamls_is_registered():
+    """Every TYPE the reference's shipped YAMLs name (config/*.yaml, config_eval/*.yaml: models, backbones / heads of the
+    regression model, losses, metrics, datasets) resolves in this build's registries.  Reads the reference checkout when it is
+    there (the build container); skipped elsewhere."""
+    import glob
+    import yaml
+    files = sorted(glob.glob("/root/reference/config/*.yaml") + glob.glob("/root/reference/config_eval/*.yaml"))
+    if not files:
+        pytest.skip("no reference checkout")
+    from artiboost_amd import registry as R
+    import artiboost_amd.criterions, artiboost_amd.datasets, artiboost_amd.hpregnet, artiboost_amd.metrics, artiboost_amd.models  # noqa: F401,E401
+    missing = []
+    for f in files:
+        c = yaml.safe_load(open(f))
+        archs = c["ARCH"] if isinstance(c["ARCH"], list) else [c["ARCH"]]
+        for a in archs:
+            if R.MODEL.get(a["TYPE"]) is None:
+                missing.append((os.path.basename(f), "MODEL", a["TYPE"]))
+            if a["TYPE"] == "HOPRegNet":            # its backbone / head are registry-built torch modules
+                if R.BACKBONE.get(a["BACKBONE"]["TYPE"]) is None:
+                    missing.append((os.path.basename(f), "BACKBONE", a["BACKBONE"]["TYPE"]))
+                if R.HEAD.get(a["HEAD"]["TYPE"]) is None:
+                    missing.append((os.path.basename(f), "HEAD", a["HEAD"]["TYPE"]))
+        for key, reg in (("CRITERION", R.LOSS), ("EVALUATOR", R.METRIC)):
+            for e in c.get(key) or []:
+                if reg.get(e["TYPE"]) is None:
+                    missing.append((os.path.basename(f), key, e["TYPE"]))
+        for split in ("TRAIN", "TEST"):
+            d = (c.get("DATASET") or {}).get(split)
+            if d and R.DATASET.get(d["TYPE"]) is None:
+                missing.append((os.path.basename(f), "DATASET", d["TYPE"]))
+    assert not missing, missing

@@ -86,10 +86,17 @@ def test_configs0_submit_pass_on_cpu_bs8(tmp_path):
                         "cam_intr": torch.tensor([[617.0, 0, 112.0], [0, 617.0, 112.0], [0, 0, 1.0]]).repeat(bs, 1, 1),
                         "root_joint": root, "corners_can": 0.05 * (torch.rand((bs, 8, 3), generator=g) * 2 - 1),
                         "joints_3d": 0.05 * torch.randn((bs, 21, 3), generator=g), "corners_3d": 0.05 * torch.randn((bs, 8, 3), generator=g),
+                        "joints_2d": 224 * torch.rand((bs, 21, 2), generator=g), "corners_2d": 224 * torch.rand((bs, 8, 2), generator=g),
                         "joints_vis": torch.ones(bs, 21), "corners_vis": torch.ones(bs, 8),
                         "is_synth": torch.zeros(bs, dtype=torch.bool), "obj_idx": torch.ones(bs, dtype=torch.long)})
     dump = str(tmp_path / "pred_SUBMIT.json")
-    joints = HOSubmitEpochPass({"DUMP": True})(0, batches, model, criterion=None, evaluator=evaluator, rank=0, dump_path=dump)
+    from artiboost_amd.criterions import Criterion
+    crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+    assert [type(l).__name__ for l in crit.loss_list] == ["ManoLoss", "JointsLoss", "HandOrdLoss", "SceneOrdLoss"]
+    assert type(model.model_list[0].base_net if hasattr(model.model_list[0], "base_net") else model.model_list[0]).__name__
+    joints = HOSubmitEpochPass({"DUMP": True})(0, batches, model, criterion=crit, evaluator=evaluator, rank=0, dump_path=dump)
+    assert {"mano_shape", "mano_pca_pose", "scene_ord_loss", "final_loss"} <= set(evaluator.get_measures_all_striped()["LossesMetric"])
+    assert evaluator.dump_images()["Vis2DMetric"].shape == (6 * 224, 2 * 6 * 224, 3)
     assert len(joints) == bs * nb and joints[0].shape == (21, 3)
     xyz, verts = json.load(open(dump))
     assert len(xyz) == bs * nb and len(xyz[0]) == 21 and len(verts[0]) == 778

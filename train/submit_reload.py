@@ -8,8 +8,9 @@ SubmitEpochPass.build(arg.submit_dataset), builder.build_dataset(TEST), Arch, Cr
 feeds the evaluator and writes the HO3D CodaLab prediction file next to the evaluation record.
 
 The HO3D / DexYCB test sets are downloads: with `./data` absent the TEST dataset is empty and the pass writes an empty
-prediction file.  `--random_frames N` (this script's only extra flag) runs the same plumbing over N seeded stand-in frames
-instead -- BASELINE.json configs[0] (regbased HOPRegNet, CPU, batch size 8, forward only) end to end without data."""
+prediction file.  `--random_frames N` runs the same plumbing over N seeded stand-in frames instead, `--ignore_pretrained` clears
+ARCH.PRETRAINED (the eval YAMLs name downloaded checkpoints) -- with both, BASELINE.json configs[0] (regbased HOPRegNet, CPU, batch
+size 8, forward only; the reference's own config_eval/eval_ho3dv2_regbased_artiboost.yaml) runs end to end without data."""
 import os
 import sys
 import time
@@ -26,10 +27,15 @@ def _random_batches(n, bs, size, seed):
     for s in range(0, n, bs):
         b = min(bs, n - s)
         root = torch.tensor([0.0, 0.0, 0.6]) + 0.05 * torch.randn((b, 3), generator=g)
-        out.append({"image": torch.rand((b, 3, size[1], size[0]), generator=g) - 0.5,
-                    "cam_intr": torch.tensor([[617.0, 0, size[0] / 2], [0, 617.0, size[1] / 2], [0, 0, 1.0]]).repeat(b, 1, 1),
+        K = torch.tensor([[617.0, 0, size[0] / 2], [0, 617.0, size[1] / 2], [0, 0, 1.0]]).repeat(b, 1, 1)
+        j3, c3 = 0.05 * torch.randn((b, 21, 3), generator=g), 0.05 * torch.randn((b, 8, 3), generator=g)
+
+        def proj(p):        # pinhole projection of root-relative points
+            q = torch.matmul(K, (p + root[:, None]).permute(0, 2, 1)).permute(0, 2, 1)
+            return q[..., :2] / q[..., 2:3]
+        out.append({"image": torch.rand((b, 3, size[1], size[0]), generator=g) - 0.5, "cam_intr": K,
                     "root_joint": root, "corners_can": 0.05 * (torch.rand((b, 8, 3), generator=g) * 2 - 1),
-                    "joints_3d": 0.05 * torch.randn((b, 21, 3), generator=g), "corners_3d": 0.05 * torch.randn((b, 8, 3), generator=g),
+                    "joints_3d": j3, "corners_3d": c3, "joints_2d": proj(j3), "corners_2d": proj(c3),
                     "joints_vis": torch.ones(b, 21), "corners_vis": torch.ones(b, 8),
                     "is_synth": torch.zeros(b, dtype=torch.bool), "obj_idx": torch.ones(b, dtype=torch.long)})
     return out
@@ -42,6 +48,9 @@ def main():
         i = argv.index("--random_frames")
         nrand = int(argv[i + 1])
         del argv[i:i + 2]
+    ignore_pretrained = "--ignore_pretrained" in argv       # ARCH.PRETRAINED of the eval YAMLs names a downloaded checkpoint
+    if ignore_pretrained:
+        argv.remove("--ignore_pretrained")
     sys.argv = [sys.argv[0]] + argv
 
     import random
@@ -57,6 +66,9 @@ def main():
     from anakin.utils.misc import TrainMode
     from anakin.utils.recorder import Recorder
 
+    if ignore_pretrained:
+        for a in (cfg["ARCH"] if isinstance(cfg["ARCH"], list) else [cfg["ARCH"]]):
+            a["PRETRAINED"] = ""
     time_f = time.time()
     seed = cfg.get("TRAIN", {}).get("MANUAL_SEED", 1)
     random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
@@ -76,7 +88,7 @@ def main():
             path = os.path.join(arg.resume, "checkpoints", "checkpoint", f"{type(m).__name__}.pth.tar")
             m.load_state_dict(torch.load(path, map_location="cpu"))
     criterion = Criterion(cfg, loss_list=builder.build_criterion_loss_list(cfg.get("CRITERION", []), cfg["DATA_PRESET"], LAMBDAS=cfg.get("LAMBDAS", [])))
-    evaluator = Evaluator(cfg, metrics_list=builder.build_evaluator_metric_list(cfg["EVALUATOR"], cfg["DATA_PRESET"]))
+    evaluator = Evaluator(cfg, metrics_list=builder.build_evaluator_metric_list(cfg["EVALUATOR"], cfg["DATA_PRESET"], arg=arg))
     name = cfg_name + ("_trueroot" if arg.true_root else "") + "_SUBMIT" + (".json" if not arg.resume_epoch else f"_epoch{arg.resume_epoch}.json")
     dump_path = os.path.join(recorder.dump_path, name)
     t0 = time.time()
