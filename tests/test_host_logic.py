@@ -351,3 +351,23 @@ def test_every_type_named_by_the_reference_yamls_is_registered():
             if d and R.DATASET.get(d["TYPE"]) is None:
                 missing.append((os.path.basename(f), "DATASET", d["TYPE"]))
     assert not missing, missing
+
+
+def test_alias_leaf_modules_resolve():
+    """The deeper import paths of the reference (`from anakin.criterions.ordinal import HandOrdLoss`, ...) resolve to this build's
+    classes for everything that is implemented here."""
+    import importlib
+    want = {"anakin.artiboost.artiboost_loader": ["ArtiBoostLoader"], "anakin.artiboost.refiner": ["Refiner", "HORefiner"],
+            "anakin.criterions.jointloss": ["JointsLoss"], "anakin.criterions.ordinal": ["HandOrdLoss", "SceneOrdLoss"],
+            "anakin.criterions.symcornerloss": ["SymCornerLoss"], "anakin.criterions.honetloss": ["ManoLoss"],
+            "anakin.datasets.ho3d": ["HO3D", "HO3DV3"], "anakin.datasets.dexycb": ["DexYCB"], "anakin.metrics.metric": ["Metric", "AverageMeter"],
+            "anakin.metrics.meanepe": ["Mean3DEPE", "Mean2DEPE"], "anakin.metrics.pckmetric": ["Hand3DPCKMetric", "Obj3DPCKMetric"],
+            "anakin.metrics.val_metric": ["ValMetricMean3DEPE2", "ValMetricAR2"], "anakin.metrics.vismetric": ["Vis2DMetric", "VisMetric"],
+            "anakin.metrics.lossesmetric": ["LossesMetric"], "anakin.metrics.bopAR": ["AR"], "anakin.models.hybridbaseline": ["HybridBaseline"],
+            "anakin.models.hpregnet": ["HOPRegNet"], "anakin.models.mano": ["ManoBranch"], "anakin.models.resnet": ["ResNet18", "ResNet34"],
+            "anakin.submit.submit_epoch_pass": ["SubmitEpochPass"], "anakin.submit.hodata_submit_epoch_pass": ["HOSubmitEpochPass"],
+            "anakin.utils.transform": ["batch_uvd2xyz", "compute_rotation_matrix_from_ortho6d"]}
+    for mod, names in want.items():
+        m = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(m, n), (mod, n)
