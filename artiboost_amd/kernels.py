@@ -88,6 +88,12 @@ _ws = {}
 
 
 def _workspace(nbytes, device):
+    """Scratch for the slab-writing kernels.  Eager: one growing buffer per (device, stream) -- stream order makes the reuse safe.
+    Under hipGraph capture: a fresh allocation from the capturing graph's own pool every time.  A cached buffer would be shared by
+    every graph captured on torch's (global) capture stream, and replacing it when a later call needs more frees memory that
+    an EARLIER graph still replays into."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     w = _ws.get(key)
     if w is None or w.numel() < nbytes:
