@@ -134,3 +134,22 @@ def test_train_script_with_the_reference_command_line(tmp_path):
     # resume: nothing left to train (epoch 2 of 2), but every piece must load
     out = subprocess.run(cmd + ["--resume", str(tmp_path / "exp" / exp[0])], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
+
+
+def test_train_script_two_ranks_on_a_shared_device(tmp_path):
+    """`--gpu_id 0,0 --allow-shared-devices`: the script launches two ranks (gloo, one GPU) -- per-rank share of --batch_size, rank
+    slices of the epoch, averaged flat gradient with the staged backward, one mining update from all ranks' errors."""
+    import subprocess
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["TRAIN"]["EPOCH"] = 2
+    y = tmp_path / "cfg.yaml"
+    y.write_text(yaml.dump(cfg))
+    cmd = [sys.executable, os.path.join(ROOT, "train", "train_artiboost.py"), "--cfg", str(y), "--gpu_id", "0,0", "--allow-shared-devices",
+           "--batch_size", "16", "--exp_id", "two", "--synth_len", "64", "--size", "64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("epoch ")]
+    assert len(lines) == 2 and "on 2 GPU(s)" in lines[-1] and "final_loss" in lines[-1]
+    exp = [d for d in os.listdir(tmp_path / "exp") if d.startswith("two_")]
+    assert len(exp) == 1            # only rank 0 records
