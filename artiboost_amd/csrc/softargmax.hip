@@ -98,7 +98,9 @@ template <> __device__ __forceinline__ void ld_pair<bf16_t>(const bf16_t* p, flo
     uint32_t v = *(const uint32_t*)p; a = __uint_as_float(v << 16); b = __uint_as_float(v & 0xffff0000u);
 }
 
-template <typename T>
+// KP: channel-pair groups of 128 channels a lane walks (ceil(C*DP / 128) rounded up to an instantiated value): the launch of the
+// 22 x 32 head (704 channels) runs with 6 instead of the maximal 8 -- a quarter fewer loads and exps, 48 instead of 64 KB of LDS.
+template <typename T, int KP = SAM_MAXCH / 128>
 __global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                           int ntile, float* __restrict__ part) {
     // grid: (ntile, B).  4 waves; wave w handles pixels w, w+4, ... of the tile, four at a time (all their loads in flight,
@@ -109,7 +111,6 @@ __global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int npix = H * W;
     const int p0 = tile * SAM_TILE_PIX;
-    constexpr int KP = SAM_MAXCH / 128;
     constexpr int NCH = 2 * KP;
     constexpr float NEG = -3.0e38f;          // finite stand-in for -inf: exp(NEG - m) == 0 without inf - inf NaNs
     float am[NCH], as[NCH], asu[NCH], asv[NCH];
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ 
         }
     }
     // per-channel accumulators -> LDS [wave][ch], then reduce over waves and over the D channels of each class
-    __shared__ float sm[4][SAM_MAXCH][4];  // m, s, su, sv   (64 KiB)
+    __shared__ float sm[4][KP * 128][4];  // m, s, su, sv
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         int ch = 2 * (lane + 64 * (k >> 1)) + (k & 1);
@@ -369,10 +370,22 @@ extern "C" int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, 
     const bool pair = ((C * DP) & 1) == 0;
     hipStream_t st = as_stream(stream);
     if (dtype == AB_DT_F32) {
-        if (pair) sam_stage1<float><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
+        if (pair) {
+            const int kp = (C * DP + 127) / 128;
+            if (kp <= 2) sam_stage1<float, 2><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
+            else if (kp <= 4) sam_stage1<float, 4><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
+            else if (kp <= 6) sam_stage1<float, 6><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
+            else sam_stage1<float, 8><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
+        }
         else sam_stage1_scalar<float><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
     } else if (dtype == AB_DT_BF16) {
-        if (pair) sam_stage1<bf16_t><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
+        if (pair) {
+            const int kp = (C * DP + 127) / 128;
+            if (kp <= 2) sam_stage1<bf16_t, 2><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
+            else if (kp <= 4) sam_stage1<bf16_t, 4><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
+            else if (kp <= 6) sam_stage1<bf16_t, 6><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
+            else sam_stage1<bf16_t, 8><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
+        }
         else sam_stage1_scalar<bf16_t><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
     } else return AB_EINVAL;
     AB_LAUNCH_CHECK();
