@@ -98,6 +98,19 @@ class PoseGenerator:
     def __init__(self, mano: ManoLayerHIP, tsl_sigma=0.01, pose_sigma=0.1, refiner=None):
         self.mano, self.tsl_sigma, self.pose_sigma, self.refiner = mano, tsl_sigma, pose_sigma, refiner
 
+    @staticmethod
+    def scramble(hand_pose, hand_tsl, rand_pose_angle=None, rand_tsl=None):
+        """RandomScrambler.forward (scrambler.py:65-81) with its two Normal draws passed in: every joint's rotation keeps its axis
+        and gets `rand_pose_angle` [B,16] added to its angle (which may go negative), the translation gets `rand_tsl` [B,3]."""
+        if rand_pose_angle is not None:
+            hp = hand_pose.reshape(-1, 16, 3)
+            nrm = torch.norm(hp, dim=-1, keepdim=True)
+            axis = hp / torch.clamp(nrm, min=1e-7)
+            hand_pose = (axis * (nrm[..., 0] + rand_pose_angle)[..., None]).reshape(-1, 48)
+        if rand_tsl is not None:
+            hand_tsl = hand_tsl + rand_tsl
+        return hand_pose, hand_tsl
+
     def __call__(self, hand_pose, hand_shape, hand_tsl, persp_rotmat, camera_free_transf, z_offset, rand_pose_angle=None,
                  rand_tsl=None, obj_idx=None):
         B = hand_pose.shape[0]
@@ -116,13 +129,7 @@ class PoseGenerator:
         off0 = center - torch.bmm(aa_to_rotmat(hand_pose[:, :3]), center[..., None])[..., 0]
         off1 = center - torch.bmm(aa_to_rotmat(new_pose[:, :3]), center[..., None])[..., 0]
         new_tsl = torch.bmm(Rinv, (off0 + hand_tsl)[..., None])[..., 0] - off1
-        if rand_pose_angle is not None:
-            hp = new_pose.reshape(B, 16, 3)
-            nrm = torch.norm(hp, dim=-1, keepdim=True)
-            axis = hp / torch.clamp(nrm, min=1e-7)
-            new_pose = (axis * (nrm[..., 0] + rand_pose_angle)[..., None]).reshape(B, 48)
-        if rand_tsl is not None:
-            new_tsl = new_tsl + rand_tsl
+        new_pose, new_tsl = self.scramble(new_pose, new_tsl, rand_pose_angle, rand_tsl)
         if self.refiner is not None:        # preprocessor.py:73-80: the refiner decodes (and refines) the scrambled grasp
             res = self.refiner({"hand_pose": new_pose, "hand_tsl": new_tsl, "obj_rot": obj_pose[:, :3, :3]}, obj_idx)
             v2, j2, off = res["hand_verts"], res["joints"], cam_sys_offset[:, None]

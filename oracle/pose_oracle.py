@@ -256,6 +256,20 @@ def mano_lbs(model, pose, betas, dtype=np.float64):
 
 
 # --------------------------------------------------------------------------- R2: pose generator glue
+def scramble(hand_pose, hand_tsl, rand_pose_angle=None, rand_tsl=None):
+    """RandomScrambler.forward (artiboost/scrambler.py:65-81), draws passed in.  PINNED: tests/golden/scrambler.npz is the
+    reference class run in the build container (oracle/gen_scrambler_golden.py)."""
+    if rand_pose_angle is not None:
+        B = hand_pose.shape[0]
+        hp = hand_pose.reshape(B, 16, 3)
+        nrm = np.linalg.norm(hp, axis=-1, keepdims=True)
+        axis = hp / np.clip(nrm, 1e-7, None)
+        hand_pose = (axis * (nrm[..., 0] + rand_pose_angle)[..., None]).reshape(B, 48)
+    if rand_tsl is not None:
+        hand_tsl = hand_tsl + rand_tsl
+    return hand_pose, hand_tsl
+
+
 def pose_generator(model, hand_pose, hand_shape, hand_tsl, persp_rotmat, camera_free_transf, z_offset,
                    rand_pose_angle=None, rand_tsl=None):
     """PreProcessorPoseGenerator.forward (artiboost/preprocessor.py:20-99) + RandomScrambler
@@ -283,15 +297,7 @@ def pose_generator(model, hand_pose, hand_shape, hand_tsl, persp_rotmat, camera_
     new_root = aa_to_rotmat(new_pose[:, :3])
     off1 = center - np.einsum("bij,bj->bi", new_root, center)
     new_tsl = np.einsum("bij,bj->bi", Rinv, off0 + hand_tsl) - off1
-    # scrambler (scrambler.py:65-81)
-    if rand_pose_angle is not None:
-        hp = new_pose.reshape(B, 16, 3)
-        nrm = np.linalg.norm(hp, axis=-1, keepdims=True)
-        axis = hp / np.clip(nrm, 1e-7, None)
-        ang = nrm[..., 0] + rand_pose_angle
-        new_pose = (axis * ang[..., None]).reshape(B, 48)
-    if rand_tsl is not None:
-        new_tsl = new_tsl + rand_tsl
+    new_pose, new_tsl = scramble(new_pose, new_tsl, rand_pose_angle, rand_tsl)
     v2, j2, _ = mano_lbs(model, new_pose, hand_shape)
     v2 = v2 + new_tsl[:, None] + cam_sys_offset[:, None]
     j2 = j2 + new_tsl[:, None] + cam_sys_offset[:, None]

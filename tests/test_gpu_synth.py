@@ -362,3 +362,19 @@ def test_train_step_predictions_match_the_model_forward():
     assert set(got) == set(ref)
     for k in ref:
         np.testing.assert_allclose(got[k].float().cpu().numpy(), ref[k].float().cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_pose_generator_vs_reference_class_golden(golden_dir):
+    """synth.PoseGenerator (ab_mano_lbs + device glue) against the reference's PreProcessorPoseGenerator.forward + RandomScrambler
+    run with stand-ins for manotorch / pytorch3d / the refiner only (tests/golden/posegen.npz)."""
+    from artiboost_amd.assets import make_hand_model
+    from artiboost_amd.synth import ManoLayerHIP, PoseGenerator
+    g = np.load(os.path.join(golden_dir, "posegen.npz"))
+    hm = make_hand_model(int(g["hand_model_seed"]))
+    gen = PoseGenerator(ManoLayerHIP(hm, "cuda"))
+    t = lambda k: torch.from_numpy(g[k]).float().cuda()       # noqa: E731
+    op, hv, jt = gen(t("hand_pose"), t("hand_shape"), t("hand_tsl"), t("persp_rotmat"), t("camera_free_transf"), t("z_offset"),
+                     rand_pose_angle=t("rand_angle"), rand_tsl=t("rand_tsl"))
+    np.testing.assert_allclose(op.cpu().numpy(), g["final_obj_pose"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(hv.cpu().numpy(), g["final_hand_verts"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(jt.cpu().numpy(), g["final_joints"], rtol=1e-5, atol=2e-5)

@@ -123,3 +123,39 @@ def test_mano_lbs_oracle_matches_reference_in_tree_layer(golden_dir):
     vs = hm["v_template"][None] + np.einsum("vkl,bl->bvk", hm["shapedirs"], g["betas"])
     np.testing.assert_allclose(j[:, 0], np.einsum("v,bvk->bk", hm["J_regressor"][0], vs), rtol=0, atol=1e-12)
     np.testing.assert_allclose(T[:, 0, :3, 3], j[:, 0], rtol=0, atol=1e-12)
+
+
+def test_scrambler_oracle_and_product_match_reference_class(golden_dir):
+    """RandomScrambler (scrambler.py:65-81): the oracle's restatement and the product's torch implementation against the
+    reference class run with the same draws (tests/golden/scrambler.npz, oracle/gen_scrambler_golden.py)."""
+    import torch
+    import pose_oracle as po
+    from artiboost_amd.synth import PoseGenerator
+    g = np.load(os.path.join(golden_dir, "scrambler.npz"))
+    pose, tsl = g["in.hand_pose"], g["in.hand_tsl"]
+    for seed in (11, 12):
+        ra, rt = g[f"s{seed}.rand_angle"], g[f"s{seed}.rand_tsl"]
+        op, ot = po.scramble(pose.astype(np.float64), tsl.astype(np.float64), ra.astype(np.float64), rt.astype(np.float64))
+        np.testing.assert_allclose(op, g[f"s{seed}.hand_pose"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ot, g[f"s{seed}.hand_tsl"], rtol=1e-6, atol=1e-7)
+        pp, pt = PoseGenerator.scramble(torch.from_numpy(pose), torch.from_numpy(tsl), torch.from_numpy(ra), torch.from_numpy(rt))
+        np.testing.assert_allclose(pp.numpy(), g[f"s{seed}.hand_pose"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(pt.numpy(), g[f"s{seed}.hand_tsl"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(g["s11.hand_pose"][0, 3:6], 0.0)        # a zero rotation stays zero (axis 0 / clip)
+
+
+def test_pose_generator_oracle_matches_reference_class(golden_dir):
+    """pose_oracle.pose_generator against the reference's own PreProcessorPoseGenerator.forward + RandomScrambler, run with
+    stand-ins for manotorch / pytorch3d / the refiner only (tests/golden/posegen.npz, oracle/gen_posegen_golden.py): the frame
+    algebra, offsets and ordering of preprocessor.py:20-99."""
+    import pose_oracle as po
+    from artiboost_amd.assets import make_hand_model
+    g = np.load(os.path.join(golden_dir, "posegen.npz"))
+    hm = make_hand_model(int(g["hand_model_seed"]))
+    f64 = lambda k: g[k].astype(np.float64)      # noqa: E731
+    obj_pose, verts, joints = po.pose_generator(hm, f64("hand_pose"), f64("hand_shape"), f64("hand_tsl"), f64("persp_rotmat"),
+                                                f64("camera_free_transf"), f64("z_offset"), rand_pose_angle=f64("rand_angle"),
+                                                rand_tsl=f64("rand_tsl"))
+    np.testing.assert_allclose(obj_pose, g["final_obj_pose"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(verts, g["final_hand_verts"], rtol=1e-5, atol=5e-6)
+    np.testing.assert_allclose(joints, g["final_joints"], rtol=1e-5, atol=5e-6)
