@@ -29,6 +29,7 @@ struct Wg3Args {
     const void* X_lo; const void* DY_lo;         // split-bf16 (X3) launches: low-order planes
     int N, H, Cin, Cout;
     int bands_per_slice, nbands;
+    int xcd_map;                // workgroups renumbered slice-major per XCD (conv_common.h)
 };
 
 __device__ __forceinline__ uint4 tr_pair(unsigned addr_lo, unsigned addr_hi) {
@@ -60,12 +61,13 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_ci = g.Cin / 64;
-    const int tile_co = blockIdx.x / tiles_ci, tile_ci = blockIdx.x - tile_co * tiles_ci;
+    int bx, by; xcd_slice_major(g.xcd_map, bx, by);
+    const int tile_co = bx / tiles_ci, tile_ci = bx - tile_co * tiles_ci;
     const int co0 = tile_co * 64, ci0 = tile_ci * 64;
     const int wco = (wave & 1) * 32, wci = ((wave >> 1) & 1) * 32;
     const int tg = wave >> 2;                                // tap group (NW = 8): 0 -> taps 0..4, 1 -> taps 5..8
     const int t0 = (NW == 8 && tg) ? 5 : 0, ntap = NW == 8 ? (tg ? 4 : 5) : 9;
-    const int band_begin = blockIdx.y * g.bands_per_slice;
+    const int band_begin = by * g.bands_per_slice;
     const int band_end = min(g.nbands, band_begin + g.bands_per_slice);
     const int bands_per_img = g.H / TH;
     const bf16_t* __restrict__ X = (const bf16_t*)g.X;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
         buf ^= 1;
     }
     // ---- slab write: dW[co][tap][ci] (row length 9*Cin)
-    float* out = g.slabs + (long)blockIdx.y * g.Cout * 9 * g.Cin;
+    float* out = g.slabs + (long)by * g.Cout * 9 * g.Cin;
     const int jt = 9 * g.Cin;
 #pragma unroll
     for (int tt = 0; tt < NACC; ++tt) {
@@ -231,6 +233,8 @@ static int wg3_launch(Wg3Args& g, int tiles, int nslices, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
+    static const int xcd = getenv("AB_WG_XCD") ? atoi(getenv("AB_WG_XCD")) : 0;
+    g.xcd_map = xcd;
     wgrad3x3_kernel<W, TH, NW, X3><<<dim3(tiles, nslices), 64 * NW, lds, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

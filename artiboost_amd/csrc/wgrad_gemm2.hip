@@ -28,6 +28,7 @@ struct Wg2Args {
     int stride;
     int ntaps, Cin, jtot;
     int M, rows_per_slice;
+    int xcd_map;                // workgroups renumbered slice-major per XCD (conv_common.h)
     unsigned long long magic_pq, magic_q;     // floor(2^42 / d) + 1
     int8_t dh[16], dw[16];
 };
@@ -49,7 +50,8 @@ __device__ __forceinline__ uint4 wg2_tr_pair(unsigned lo_addr, unsigned hi_addr)
 // ab_conv2d_stem_fwd); BJ = 256 covers all of them, the 64-byte segment of kernel row t comes from image row 2p + t.
 // X3 = 1: split-bf16 operands (conv3x3.hip): 32 reduction rows per step, each operand tile staged once per plane
 // ([dy hi][dy lo][x hi][x lo]); the DMA instruction index runs over (plane, row group).
-template <int BI, int BJ, bool STEM = false, int WI = 2, int WJ = 2, int X3 = 0>
+// NBUF = 2 (the 256 x 256 split-bf16 tile: two 64 KB stages): one step in flight instead of two.
+template <int BI, int BJ, bool STEM = false, int WI = 2, int WJ = 2, int X3 = 0, int NBUF = 3>
 __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
     constexpr int NW = WI * WJ;                             // 4 or 8 waves (the LDS fill rate scales with the waves issuing loads)
     constexpr int BR = X3 ? 32 : 64;                        // reduction rows per step
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
     static_assert(IA % NW == 0 && IB % NW == 0, "tile rows must split evenly over the waves");
     constexpr int APL = BR * PA, BPL = BR * PB;             // bytes of one plane of a tile
     constexpr int ABYTES = NPL * APL, STAGE = NPL * (APL + BPL);
-    constexpr int NBUF = 3;
+    constexpr int PF = NBUF - 1;                            // steps in flight ahead of the one being multiplied
     constexpr int TI = BI / WI / 32, TJ = BJ / WJ / 32;     // 32x32 tiles per wave (waves WI x WJ)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * STAGE];
     __shared__ int s_xoff[2][BR];                           // element offset of each row's input pixel (-1: padding / past the end)
@@ -71,11 +73,12 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_i = wave / WJ, wave_j = wave % WJ;
     const int tiles_j = g.jtot / BJ;
-    const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x - tile_i * tiles_j;
+    int bx, by; xcd_slice_major(g.xcd_map, bx, by);
+    const int tile_i = bx / tiles_j, tile_j = bx - tile_i * tiles_j;
     const int i0 = tile_i * BI, j0 = tile_j * BJ;
     const int tap = STEM ? 0 : j0 / g.Cin, ci0 = STEM ? 0 : j0 - tap * g.Cin;
     const int dh = STEM ? 0 : g.dh[tap], dw = STEM ? 0 : g.dw[tap];   // read once, before any DMA is in flight
-    const int r_begin = blockIdx.y * g.rows_per_slice;
+    const int r_begin = by * g.rows_per_slice;
     const int r_end = min(g.M, r_begin + g.rows_per_slice);
     const int PQ = g.P * g.Q;
     const bf16_t* __restrict__ X = (const bf16_t*)g.X;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
 #pragma unroll
         for (int j = 0; j < LA; ++j) {
             int m = rbase + a_row[j];
-            const bf16_t* src = m < r_end ? ((X3 && a_pl[j]) ? DYl : DY) + ((long)m * g.Cout + i0 + a_col[j]) : zp;
+            const bf16_t* src = (m < r_end && i0 + a_col[j] < g.Cout) ? ((X3 && a_pl[j]) ? DYl : DY) + ((long)m * g.Cout + i0 + a_col[j]) : zp;
             glds16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + (wave * LA + j) * 1024));
         }
 #pragma unroll
@@ -164,24 +167,24 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
 
     constexpr int L = LA + LB;
     const int nsteps = (r_end - r_begin + BR - 1) / BR;
-    // tables: step s uses slot s & 1; the table of step s+3 is written during step s (its slot was last read at step s-1's
-    // issue, i.e. before this step's barrier) and read at step s+1's issue (after the next barrier)
+    // tables: step s uses slot s & 1; with PF steps in flight the table of step s+PF+1 is written during step s (its slot was
+    // last read at step s-1's issue, i.e. before this step's barrier) and read at step s+1's issue (after the next barrier)
     make_table(r_begin, 0);
     make_table(r_begin + BR, 1);
     __syncthreads();
     if (nsteps > 0) issue(r_begin, 0, 0);
-    if (nsteps > 1) issue(r_begin + BR, 1, 1);
-    __syncthreads();                                         // both tables consumed (s_waitcnt lgkmcnt is implied by use)
-    make_table(r_begin + 2 * BR, 0);
+    if (PF > 1 && nsteps > 1) issue(r_begin + BR, 1, 1);
+    __syncthreads();                                         // the issued tables are consumed (s_waitcnt lgkmcnt is implied by use)
+    if (PF > 1) make_table(r_begin + 2 * BR, 0);
     int cur = 0;
     for (int step = 0; step < nsteps; ++step) {
-        if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        if (PF > 1 && step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * L) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (step + 2 < nsteps) { int nb = cur + 2; if (nb >= NBUF) nb -= NBUF; issue(r_begin + (step + 2) * BR, nb, step & 1); }
-        make_table(r_begin + (step + 3) * BR, (step + 1) & 1);
+        if (step + PF < nsteps) { int nb = cur + PF; if (nb >= NBUF) nb -= NBUF; issue(r_begin + (step + PF) * BR, nb, (step + PF) & 1); }
+        make_table(r_begin + (step + PF + 1) * BR, (step + PF + 1) & 1);
         const unsigned so = cur * STAGE;
 #pragma unroll
         for (int s = 0; s < BR / 16; ++s) {
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
         }
         if (++cur == NBUF) cur = 0;
     }
-    float* out = g.slabs + (long)blockIdx.y * g.Cout * g.jtot;
+    float* out = g.slabs + (long)by * g.Cout * g.jtot;
 #pragma unroll
     for (int a = 0; a < TI; ++a)
 #pragma unroll
@@ -224,9 +227,11 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
             for (int r = 0; r < 16; ++r) {
                 int row = i0 + (wave_i * TI + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 int col = j0 + (wave_j * TJ + b) * 32 + (lane & 31);
-                out[(long)row * g.jtot + col] = acc[a][b][r];
+                if (row < g.Cout) out[(long)row * g.jtot + col] = acc[a][b][r];
             }
 }
+
+static int wg2_xcd_map() { static const int v = getenv("AB_WG_XCD") ? atoi(getenv("AB_WG_XCD")) : 0; return v; }
 
 static void wg2_pick(int M, int Cout, int Cin, int jtot, int* bi, int* bj, int* ns, int* rows) {
     *bi = (Cout % 128 == 0) ? 128 : 64;
@@ -263,6 +268,7 @@ int wgrad_gemm2_run(const void* x, const void* dy, float* slabs, int N, int H, i
     g.magic_q = (1ull << 42) / (unsigned long long)g.Q + 1;
     int bi, bj, ns, rows; wg2_pick(g.M, Cout, Cin, g.jtot, &bi, &bj, &ns, &rows);
     g.rows_per_slice = rows;
+    g.xcd_map = wg2_xcd_map();
     dim3 grid((Cout / bi) * (g.jtot / bj), ns);
     static const int w8 = getenv("AB_WG2_W8") ? atoi(getenv("AB_WG2_W8")) : 1;
     if (bi == 128 && bj == 256) { if (w8) wgrad_gemm2_kernel<128, 256, false, 2, 4><<<grid, 512, 0, st>>>(g); else wgrad_gemm2_kernel<128, 256><<<grid, 256, 0, st>>>(g); }
@@ -309,6 +315,7 @@ int wgrad_gemm2_stem_run(const void* xpad, const void* dy, float* slabs, int N, 
     g.magic_q = (1ull << 42) / (unsigned long long)g.Q + 1;
     int r = (g.M + ns - 1) / ns; r = (r + 63) / 64 * 64;
     g.rows_per_slice = r;
+    g.xcd_map = wg2_xcd_map();
     dim3 grid(Cout / 64, ns);
     static const int w8 = getenv("AB_WG2_W8") ? atoi(getenv("AB_WG2_W8")) : 1;
     if (w8) wgrad_gemm2_kernel<64, 256, true, 2, 4><<<grid, 512, 0, st>>>(g);
@@ -319,13 +326,31 @@ int wgrad_gemm2_stem_run(const void* xpad, const void* dy, float* slabs, int N, 
 
 // ---- split-bf16 ("bf16x3") launches (x / dy as bf16 plane pairs).  Tiles up to 128 x 128: three ring stages of both
 // planes of a 32-row step are 96 KB.
+static int wg2x_mode() { static const int v = getenv("AB_WG2X_MODE") ? atoi(getenv("AB_WG2X_MODE")) : 3; return v; }
+
 static void wg2x_pick(int M, int Cout, int Cin, int jtot, int* bi, int* bj, int* ns, int* rows) {
     *bi = (Cout % 128 == 0) ? 128 : 64;
     *bj = (Cin % 128 == 0) ? 128 : 64;
-    long tiles = (long)(Cout / *bi) * (jtot / *bj);
-    int want = (int)((256 + tiles - 1) / tiles);
+    if (wg2x_mode() >= 2 && Cout % 256 == 0 && *bj == 128) *bi = 256;
+    // 256 x 256 (two stages of 64 KB, one step in flight; the last channel tile may be partial) pays from 16k pixels up: the
+    // transposed 256->256 layer 114 -> 102 us, the final 1x1 layer 104 -> 93 us, but 4 096-pixel launches 44 -> 50 us
+    if (wg2x_mode() == 3 && Cout >= 256 && Cin % 256 == 0 && M >= 16384) { *bi = 256; *bj = 256; }
+    long tiles = (long)((Cout + *bi - 1) / *bi) * (jtot / *bj);
     int maxs = (M + 255) / 256;                              // at least 256 pixels (8 steps) per slice
-    int n = want < 1 ? 1 : want; if (n > maxs) n = maxs; if (n < 1) n = 1; if (n > 512) n = 512;
+    if (maxs > 512) maxs = 512;
+    // The chip retires workgroups 256 at a time (one per CU, or two side by side at half the rate each): tiles x slices just over
+    // a multiple of 256 costs a whole extra round (18 tiles x 15 slices = 270 workgroups ran as two rounds of 1 120 pixels where
+    // 14 slices run as one round of 1 184).  Pick the slice count with the fewest pixel rows on the busiest CU; WG_ROWS prices a
+    // workgroup's fixed part (ring fill, 64 KB slab store) in pixel rows.
+    static const int legacy = getenv("AB_WG2X_LEGACY") ? atoi(getenv("AB_WG2X_LEGACY")) : 0;
+    const long WG_ROWS = 96;
+    int n = 1; long best = -1;
+    if (legacy) { n = (int)((256 + tiles - 1) / tiles); if (n > maxs) n = maxs; if (n < 1) n = 1; }
+    else for (int c = 1; c <= maxs && tiles * c <= 2048; ++c) {
+        long r = ((M + c - 1) / c + 31) / 32 * 32, rounds = (tiles * c + 255) / 256;
+        long cost = rounds * (r + WG_ROWS);
+        if (best < 0 || cost * 100 < best * 98) { best = cost; n = c; }     // more slices only for 2 % or more
+    }
     int r = (M + n - 1) / n; r = (r + 31) / 32 * 32;
     *ns = (M + r - 1) / r; *rows = r;
 }
@@ -349,8 +374,12 @@ int wgrad_gemm2_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, co
     g.magic_q = (1ull << 42) / (unsigned long long)g.Q + 1;
     int bi, bj, ns, rows; wg2x_pick(g.M, Cout, Cin, g.jtot, &bi, &bj, &ns, &rows);
     g.rows_per_slice = rows;
-    dim3 grid((Cout / bi) * (g.jtot / bj), ns);
-    if (bi == 128 && bj == 128) wgrad_gemm2_kernel<128, 128, false, 2, 4, 1><<<grid, 512, 0, st>>>(g);
+    g.xcd_map = wg2_xcd_map();
+    dim3 grid(((Cout + bi - 1) / bi) * (g.jtot / bj), ns);
+    if (bi == 256 && bj == 256) wgrad_gemm2_kernel<256, 256, false, 4, 2, 1, 2><<<grid, 512, 0, st>>>(g);
+    else if (bi == 256 && bj == 128) wgrad_gemm2_kernel<256, 128, false, 4, 2, 1><<<grid, 512, 0, st>>>(g);
+    else if (bi == 128 && bj == 128 && wg2x_mode() == 1) wgrad_gemm2_kernel<128, 128, false, 2, 2, 1><<<grid, 256, 0, st>>>(g);
+    else if (bi == 128 && bj == 128) wgrad_gemm2_kernel<128, 128, false, 2, 4, 1><<<grid, 512, 0, st>>>(g);
     else if (bi == 128 && bj == 64) wgrad_gemm2_kernel<128, 64, false, 4, 2, 1><<<grid, 512, 0, st>>>(g);
     else if (bi == 64 && bj == 128) wgrad_gemm2_kernel<64, 128, false, 2, 4, 1><<<grid, 512, 0, st>>>(g);
     else wgrad_gemm2_kernel<64, 64, false, 2, 2, 1><<<grid, 256, 0, st>>>(g);
@@ -371,6 +400,7 @@ int wgrad_gemm2_x3_stem_run(const void* xpad_hi, const void* xpad_lo, const void
     g.magic_q = (1ull << 42) / (unsigned long long)g.Q + 1;
     int r = (g.M + ns - 1) / ns; r = (r + 63) / 64 * 64;
     g.rows_per_slice = r;
+    g.xcd_map = wg2_xcd_map();
     dim3 grid(Cout / 64, ns);
     wgrad_gemm2_kernel<64, 256, true, 2, 4, 1><<<grid, 512, 0, st>>>(g);
     hipError_t e = hipGetLastError();
