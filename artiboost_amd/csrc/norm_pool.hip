@@ -1095,10 +1095,10 @@ extern "C" int ab_bn_bwd_x3(const float* dout, const void* out, int out_is_hi_pl
 // the pooled gradient to the full resolution, masks it and reduces it (pool_bwd_bn_reduce_kernel, part rows =
 // ab_bn_relu_maxpool_bwd_x3_nparts); finalize; the apply pass repeats the gather and writes dy as planes (pool_bwd_bn_apply_x3_kernel;
 // AB_POOL_BWD_REGATHER=0: the reduce pass stores the masked gradient in the fp32 scratch `dz` and the generic apply pass reads it).
-#define PBR_RP 16
+static int pbr_rp() { static const int v = getenv("AB_PBR_RP") ? atoi(getenv("AB_PBR_RP")) : 16; return (v == 4 || v == 8) ? v : 16; }
 extern "C" int ab_bn_relu_maxpool_bwd_x3_nparts(int N, int H, int W, int C) {
     if ((H & 1) || (W & 1) || C % 8 || C / 4 > 256 || 256 % (C / 4)) return 0;
-    const int gx = (int)(((long)W * (C / 4) + 255) / 256), gy = (H / 2 + PBR_RP - 1) / PBR_RP;
+    const int gx = (int)(((long)W * (C / 4) + 255) / 256), gy = (H / 2 + pbr_rp() - 1) / pbr_rp();
     return gx * gy * N;
 }
 extern "C" int ab_bn_relu_maxpool_bwd_x3(const float* dpool, const void* idx, const float* y, const float* bnp, int N, int H, int W,
@@ -1108,11 +1108,14 @@ extern "C" int ab_bn_relu_maxpool_bwd_x3(const float* dpool, const void* idx, co
     const int np = ab_bn_relu_maxpool_bwd_x3_nparts(N, H, W, C);
     if (!np) return AB_ESHAPE;
     hipStream_t st = as_stream(stream);
-    dim3 grid((unsigned)(((long)W * (C / 4) + 255) / 256), (unsigned)((H / 2 + PBR_RP - 1) / PBR_RP), (unsigned)N);
+    dim3 grid((unsigned)(((long)W * (C / 4) + 255) / 256), (unsigned)((H / 2 + pbr_rp() - 1) / pbr_rp()), (unsigned)N);
     static const int regather = getenv("AB_POOL_BWD_REGATHER") ? atoi(getenv("AB_POOL_BWD_REGATHER")) : 1;
     const long M = (long)N * H * W, nvec = M * C / 8;
-    if (regather) pool_bwd_bn_reduce_kernel<PBR_RP, false><<<grid, 256, 256 * 8 * 4, st>>>((const uint8_t*)idx, dpool, y, bnp, N, H, W, C, dz, part);
-    else pool_bwd_bn_reduce_kernel<PBR_RP><<<grid, 256, 256 * 8 * 4, st>>>((const uint8_t*)idx, dpool, y, bnp, N, H, W, C, dz, part);
+#define PBR_LAUNCH(RP, WR) pool_bwd_bn_reduce_kernel<RP, WR><<<grid, 256, 256 * 8 * 4, st>>>((const uint8_t*)idx, dpool, y, bnp, N, H, W, C, dz, part)
+    const int rp = pbr_rp();
+    if (regather) { if (rp == 4) PBR_LAUNCH(4, false); else if (rp == 8) PBR_LAUNCH(8, false); else PBR_LAUNCH(16, false); }
+    else { if (rp == 4) PBR_LAUNCH(4, true); else if (rp == 8) PBR_LAUNCH(8, true); else PBR_LAUNCH(16, true); }
+#undef PBR_LAUNCH
     AB_LAUNCH_CHECK();
     launch_bn_bwd_finalize(part, np, C, dgamma, dbeta, bwdp, st);
     AB_LAUNCH_CHECK();

@@ -336,3 +336,22 @@ def test_stem_wgrad_x3_beyond_2p21_pixels():
     b = K.conv2d_stem_wgrad_x3(xpad[:, h:].contiguous(), dy[:, h:].contiguous(), H, W)
     ref = a.double() + b.double()
     assert float((dw.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("case", [(16, 32, 32, 256, 704, 1, 1, 0),     # 256 x 256 tiles, partial last channel tile (704 = 2.75 x 256)
+                                  (16, 32, 32, 256, 320, 1, 1, 0),     # ... a last tile of 64 channels
+                                  (64, 32, 32, 256, 256, 4, 2, 1),     # 256 x 256 tiles, 16 taps (the transposed 256->256 layer)
+                                  (8, 32, 32, 128, 256, 3, 2, 1),      # 256 x 128 tiles
+                                  (64, 16, 16, 256, 512, 3, 2, 1)])    # 256 x 128 tiles, 72 of them: the slice count follows rounds of 256
+def test_wgrad_x3_large_tiles_vs_fp64(case):
+    """The 256-channel weight-gradient tiles (two-stage ring for 256 x 256, guarded last channel tile) and the round-aware slice
+    count against a float64 weight gradient of the same operands."""
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + k)
+    x = torch.randn((N, H, W, Cin), generator=g).cuda()
+    Ho, Wo = K.conv_out(H, k, s, p), K.conv_out(W, k, s, p)
+    dy = torch.randn((N, Ho, Wo, Cout), generator=g).cuda()
+    ref = torch.nn.grad.conv2d_weight(nchw(x).double(), (Cout, Cin, k, k), nchw(dy).double(), stride=s, padding=p)
+    dw = K.conv2d_wgrad_x3(K.split(x), K.split(dy), k, k, s, p)
+    close(dw.permute(0, 3, 1, 2).cpu(), ref.cpu())
