@@ -20,7 +20,7 @@ import sys
 CONV = ("conv_gemm_kernel", "conv_gemm2_kernel", "conv3x3_kernel", "stem_halo_kernel", "stem_halo_x3_kernel", "wgrad_kernel", "wgrad3x3_kernel",
         "wgrad_gemm2_kernel", "wgrad_reduce")
 BN = ("bn_apply_kernel", "bn_apply_x3_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "bn_bwd_apply_x3_kernel", "bn_finalize_kernel",
-      "bn_bwd_finalize_kernel", "pool_bwd_bn_reduce_kernel", "col_stats_kernel", "col_stats_x3_kernel", "maxpool_fwd_kernel", "maxpool_bwd_kernel", "split_f32_kernel", "avgpool_fwd_kernel",
+      "bn_bwd_finalize_kernel", "pool_bwd_bn_reduce_kernel", "pool_bwd_bn_apply_x3_kernel", "col_stats_kernel", "col_stats_x3_kernel", "maxpool_fwd_kernel", "maxpool_bwd_kernel", "split_f32_kernel", "avgpool_fwd_kernel",
       "avgpool_bwd_kernel")
 HEAD = ("sam_stage1", "sam_stage2", "sam_bwd", "pose_loss_kernel", "pose_loss_finalize", "colsum_finalize_kernel", "linear_nt_kernel",
         "linear_wgrad_kernel")
