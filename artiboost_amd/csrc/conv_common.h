@@ -25,6 +25,11 @@ struct ConvGemmArgs {
     int cls_ntaps[4]; int cls_oh[4], cls_ow[4];
     int8_t dh[CG_MAXTAPS], dw[CG_MAXTAPS];
     int koff[CG_MAXTAPS];
+    // conv_gemm2 X3 only: tap `alt_tap1 - 1` (absolute index into dh/dw/koff; 0: none) reads a SECOND operand pair -- A2 / Bw2 with
+    // weight row length ktot2 -- instead of A / Bw: the 1x1/s2 downsample branch rides in the data gradient of the stride-2 3x3
+    // convolution next to it as one more tap of parity class (even, even).
+    const void* A2; const void* A2_lo; const void* Bw2; const void* Bw2_lo;
+    int alt_tap1, ktot2;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -74,6 +74,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
     const bf16_t* __restrict__ Bw = (const bf16_t*)g.Bw;
     const bf16_t* __restrict__ Alo = (const bf16_t*)g.A_lo;
     const bf16_t* __restrict__ Bwlo = (const bf16_t*)g.Bw_lo;
+    const bf16_t* __restrict__ A2 = (const bf16_t*)g.A2;
+    const bf16_t* __restrict__ A2lo = (const bf16_t*)g.A2_lo;
+    const bf16_t* __restrict__ Bw2 = (const bf16_t*)g.Bw2;
+    const bf16_t* __restrict__ Bw2lo = (const bf16_t*)g.Bw2_lo;
+    const int alt_t = X3 ? g.alt_tap1 - 1 - tap0 : -1;        // class-local index of the tap that reads the second operand pair
     const int PQ = g.P * g.Q;
     const bf16_t* zp = (const bf16_t*)ab_zero_page;
 
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
             s_outpix[r] = a_ok[j] ? op : -1;
         }
     }
-    long b_off[NB]; int b_chunk[NB]; bool b_ok[NB];
+    long b_off[NB]; long b_off2[X3 ? NB : 1]; int b_chunk[NB]; bool b_ok[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         int ii = wave * NB + j;
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         int col = n0 + r;
         b_ok[j] = (ii < IB) && (col < g.Cn);
         b_off[j] = (long)(b_ok[j] ? col : 0) * g.ktot;
+        if constexpr (X3) b_off2[j] = (long)(b_ok[j] ? col : 0) * g.ktot2;
         b_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;
         b_lo[j] = false;
         if (X3) { const int c = lslot ^ ((r >> 1) & 7); b_lo[j] = (c & 4) != 0; b_chunk[j] = (c & 3) * 8; }
@@ -119,6 +125,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
     auto issue = [&](int step, int buf) {
         const int t = STEM ? 0 : step / g.cpt, c0 = STEM ? step * CK : (step - t * g.cpt) * CK;
         const int dh = STEM ? 0 : s_tap[t], dw = STEM ? 0 : s_tap[CG_MAXTAPS + t], ko = STEM ? 0 : s_tap[2 * CG_MAXTAPS + t];
+        const bool alt = X3 && !STEM && t == alt_t;           // wave-uniform: this step's rows come from (A2, Bw2)
+        const bf16_t* Ah = alt ? A2 : A; const bf16_t* Al = alt ? A2lo : Alo;
+        const bf16_t* Bh = alt ? Bw2 : Bw; const bf16_t* Bl = alt ? Bw2lo : Bwlo;
         unsigned char* base = smem + buf * BUFSZ;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
                 } else {
                     int hi = a_h[j] + dh, wi = a_w[j] + dw;
                     bool ok = a_ok[j] && (unsigned)hi < (unsigned)g.Ha && (unsigned)wi < (unsigned)g.Wa;
-                    src = ok ? (((X3 && a_lo[j]) ? Alo : A) + ((a_base[j] + (long)hi * g.Wa + wi) * g.Ca + c0 + a_chunk[j])) : zp;
+                    src = ok ? (((X3 && a_lo[j]) ? Al : Ah) + ((a_base[j] + (long)hi * g.Wa + wi) * g.Ca + c0 + a_chunk[j])) : zp;
                 }
                 glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(base + ii * 1024)));
             }
@@ -141,7 +150,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
             const int ii = wave * NB + j;
             if (ii < IB) {
                 const bool ok = b_ok[j] && (!STEM || c0 + b_chunk[j] < g.ktot);
-                const bf16_t* src = ok ? (((X3 && b_lo[j]) ? Bwlo : Bw) + (b_off[j] + ko + c0 + b_chunk[j])) : zp;
+                long bo = b_off[j] + ko;
+                if constexpr (X3) { if (alt) bo = b_off2[j]; }
+                const bf16_t* src = ok ? (((X3 && b_lo[j]) ? Bl : Bh) + (bo + c0 + b_chunk[j])) : zp;
                 glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(base + BM * 128 + ii * 1024)));
             }
         }

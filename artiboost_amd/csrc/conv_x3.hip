@@ -101,9 +101,10 @@ extern "C" int ab_conv2d_dgrad_x3_stat_rows(int N, int H, int W, int Cin, int Co
     return 4 * conv_gemm2_x3_mtiles(N * (H / 2) * (W / 2), Cin, maxt * (Cout / 32), 4);
 }
 
-extern "C" int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N,
-                                  int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend,
-                                  float* stats, void* stream) {
+static int dgrad_x3_impl(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N,
+                         int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend,
+                         float* stats, void* stream, const void* dy2_hi = nullptr, const void* dy2_lo = nullptr,
+                         const void* wt2_hi = nullptr, const void* wt2_lo = nullptr) {
     if (!dy_hi || !dy_lo || !wt_hi || !wt_lo || !dx) return AB_EINVAL;
     if (Cout % 32 || (stride != 1 && stride != 2)) return AB_ESHAPE;
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
@@ -133,12 +134,19 @@ extern "C" int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const vo
                     g.koff[c * 4 + nt] = (i * kw + j) * Cout; ++nt;
                 }
             }
+            if (c == 0 && dy2_hi) {         // the 1x1/s2/pad-0 branch: input pixel (2p, 2q) <- dy2[p, q], one more tap of class (even, even)
+                if (nt >= 4) return AB_ESHAPE;
+                g.dh[nt] = 0; g.dw[nt] = 0; g.koff[nt] = 0;
+                g.A2 = dy2_hi; g.A2_lo = dy2_lo; g.Bw2 = wt2_hi; g.Bw2_lo = wt2_lo; g.alt_tap1 = nt + 1; g.ktot2 = Cout;
+                ++nt;
+            }
             g.cls_ntaps[c] = nt; g.cls_oh[c] = a; g.cls_ow[c] = b;
             if (nt > maxt) maxt = nt;
         }
         g.ntaps = maxt;
         return conv_gemm2_x3_run(g, as_stream(stream));
     }
+    if (dy2_hi) return AB_ESHAPE;
     if (kh * kw > CG_MAXTAPS) return AB_ESHAPE;
     g.P = H; g.Q = W; g.out_sh = g.out_sw = 1; g.M = N * H * W;
     int nt = 0;
@@ -147,6 +155,25 @@ extern "C" int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const vo
     }
     g.ntaps = nt;
     return conv_gemm2_x3_run(g, as_stream(stream));
+}
+
+extern "C" int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N,
+                                  int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend,
+                                  float* stats, void* stream) {
+    return dgrad_x3_impl(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cin, Cout, kh, kw, stride, pad, addend, stats, stream);
+}
+
+// dx = dgrad(dy, wt; kh x kw / stride 2) + dgrad(dy2, wt2; 1x1 / stride 2 / pad 0) [+ addend]: the two branches that leave a
+// down-sampling residual block's input (resnet.py:85-101 backwards: conv1 and downsample.0 read the same x) in ONE launch --
+// the 1x1 branch is one more tap of the (even, even) parity class, reading its own gradient / weight planes.  dy2: planes
+// [N,Ho,Wo,Cout] of the same geometry as dy, wt2 planes [Cin][1][1][Cout].
+extern "C" int ab_conv2d_dgrad_x3_pair(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, const void* dy2_hi,
+                                       const void* dy2_lo, const void* wt2_hi, const void* wt2_lo, float* dx, int N, int H, int W,
+                                       int Cin, int Cout, int kh, int kw, int pad, const float* addend, void* stream) {
+    if (!dy2_hi || !dy2_lo || !wt2_hi || !wt2_lo) return AB_EINVAL;
+    if (kh > 3 || kw > 3 || (H & 1) || (W & 1) || (H + 2 * pad - kh) / 2 + 1 != H / 2 || (W + 2 * pad - kw) / 2 + 1 != W / 2) return AB_ESHAPE;
+    return dgrad_x3_impl(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cin, Cout, kh, kw, 2, pad, addend, nullptr, stream, dy2_hi, dy2_lo,
+                         wt2_hi, wt2_lo);
 }
 
 // Data gradient whose result is the gradient arriving at  relu(bn(bn_y) [+ residual])  (resnet.py:85-101 backwards): dx receives

@@ -478,6 +478,7 @@ class HybridNet:
     fuse_stem = os.environ.get("AB_STEM_FUSE", "1") != "0"       # stem BN+ReLU+max-pool as one pass (forward)
     fuse_stem_bwd = os.environ.get("AB_STEM_FUSE_BWD", "0") == "1"   # ... and the gather-based fused backward
     stem_pool_reduce = os.environ.get("AB_STEM_POOL_REDUCE", "1") != "0"   # bf16x3: see _backward_trunk
+    pair_dgrad = os.environ.get("AB_PAIR_DGRAD", "1") != "0"      # bf16x3: conv1 + downsample data gradients of a block in one launch
 
     # AB_WGRAD_BATCH=1: the fixed-order slab reductions of a backward stage's weight gradients run as ONE launch at the end
     # of the stage instead of one per layer right behind its slab kernel.  Bit-identical, 38 graph nodes fewer -- and 2 %
@@ -611,8 +612,12 @@ class HybridNet:
                 dyd = self._bn_bwd(dz, None, rec["yd"], rec["bnpd"], gv(pre + ".downsample.1.weight"),
                                gv(pre + ".downsample.1.bias"), relu=False)
                 self._wgrad_side(self._conv_wgrad, x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
-                dx = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[1], x.shape[2]), stride, 1)
-                dout = self._conv_dgrad(dyd, pre + ".downsample.0.weight", (x.shape[1], x.shape[2]), stride, 0, addend=dx)
+                if self.x3 and stride == 2 and self.pair_dgrad:      # both branches in one launch (the 1x1 as a tap of the 3x3/s2)
+                    dout = K.conv2d_dgrad_x3_pair(dy1, self.tr[pre + ".conv1.weight"], dyd, self.tr[pre + ".downsample.0.weight"],
+                                                  (x.shape[1], x.shape[2]), 1)
+                else:
+                    dx = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[1], x.shape[2]), stride, 1)
+                    dout = self._conv_dgrad(dyd, pre + ".downsample.0.weight", (x.shape[1], x.shape[2]), stride, 0, addend=dx)
                 dout_part = None
             elif bn_below is not None:
                 dout, dout_part = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[1], x.shape[2]), stride, 1,

@@ -494,6 +494,23 @@ def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=Fa
     return (dx, None) if bn is not None else dx
 
 
+def conv2d_dgrad_x3_pair(dy, wt_split, dy2, wt2_split, in_hw, pad, addend=None):
+    """dx = dgrad(dy, wt; k x k / stride 2) + dgrad(dy2, wt2; 1x1 / stride 2 / pad 0) [+ addend] in one launch: the conv1 and
+    downsample branches of a down-sampling block (anakin/models/resnet.py:85-101 backwards)."""
+    dh, dl = _planes(dy)
+    eh, el = _planes(dy2)
+    N, Ho, Wo, Cout = dh.shape
+    _, Cin, kh, kw, _ = wt_split.shape
+    assert tuple(eh.shape) == tuple(dh.shape) and tuple(wt2_split.shape[1:]) == (Cin, 1, 1, Cout)
+    H, W = in_hw
+    dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dh.device)
+    L.check(L.lib().ab_conv2d_dgrad_x3_pair(L.ptr(dh), L.ptr(dl), L.ptr(wt_split[0]), L.ptr(wt_split[1]), L.ptr(eh), L.ptr(el),
+                                            L.ptr(wt2_split[0]), L.ptr(wt2_split[1]), L.ptr(dx), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                            L.i(Cout), L.i(kh), L.i(kw), L.i(pad), L.ptr(addend), L.stream()),
+            "ab_conv2d_dgrad_x3_pair")
+    return dx
+
+
 def conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=None, accumulate=False, defer=None):
     """x, dy: fp32 or split -> dw fp32 [Cout,kh,kw,Cin].  defer: see conv2d_wgrad."""
     xh, xl = _planes(x)

@@ -120,6 +120,12 @@ int ab_conv2d_dgrad_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh,
 int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H,
                        int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend, float* stats,
                        void* stream);
+/* The two data gradients that leave the input of a down-sampling BasicBlock (anakin/models/resnet.py:85-101 backwards: conv1 3x3/s2
+ * and downsample.0 1x1/s2 read the same x) in one launch: dx = dgrad(dy, wt; kh x kw / 2 / pad) + dgrad(dy2, wt2; 1x1 / 2 / 0)
+ * [+ addend].  dy2 planes [N,H/2,W/2,Cout], wt2 planes [Cin][1][1][Cout]; kh, kw <= 3, H, W even.                            */
+int ab_conv2d_dgrad_x3_pair(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, const void* dy2_hi,
+                            const void* dy2_lo, const void* wt2_hi, const void* wt2_lo, float* dx, int N, int H, int W, int Cin,
+                            int Cout, int kh, int kw, int pad, const float* addend, void* stream);
 /* Data gradient of a 3x3/s1 conv whose result arrives at relu(bn(bn_y) [+ residual]) (BasicBlock, anakin/models/resnet.py:85-101,
  * backwards): dz = the MASKED gradient (mask: sign of bn_out_hi, the hi bf16 plane of the stored activation, or recomputed from
  * bn_y and bnp when bn_out_hi is NULL), bn_part[rows][Cin][2] = per-tile (sum dz, sum dz*xhat) for ab_bn_bwd_x3(part, rows).

@@ -355,3 +355,28 @@ def test_wgrad_x3_large_tiles_vs_fp64(case):
     ref = torch.nn.grad.conv2d_weight(nchw(x).double(), (Cout, Cin, k, k), nchw(dy).double(), stride=s, padding=p)
     dw = K.conv2d_wgrad_x3(K.split(x), K.split(dy), k, k, s, p)
     close(dw.permute(0, 3, 1, 2).cpu(), ref.cpu())
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 128), (3, 12, 20, 128, 256), (2, 8, 8, 256, 512), (8, 64, 64, 64, 128)])
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_conv_dgrad_x3_pair_vs_fp64(case, with_addend):
+    """conv1 (3x3/s2) and downsample (1x1/s2) data gradients of a down-sampling block in one launch
+    (ab_conv2d_dgrad_x3_pair) against the float64 sum of the two transposed convolutions, and against the two-launch route."""
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    w1 = (torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (Cin * 9)) ** 0.5).cuda()
+    w2 = (torch.randn((Cout, Cin, 1, 1), generator=g) * (2.0 / Cin) ** 0.5).cuda()
+    dy1 = torch.randn((N, Cout, H // 2, W // 2), generator=g).cuda()
+    dy2 = torch.randn((N, Cout, H // 2, W // 2), generator=g).cuda()
+    add = torch.randn((N, H, W, Cin), generator=g).cuda() if with_addend else None
+    ref = (torch.nn.grad.conv2d_input((N, Cin, H, W), w1.double(), dy1.double(), stride=2, padding=1)
+           + torch.nn.grad.conv2d_input((N, Cin, H, W), w2.double(), dy2.double(), stride=2, padding=0))
+    if with_addend:
+        ref = ref + nchw(add).double()
+    wt1 = K.split(w1.permute(1, 2, 3, 0).contiguous())      # [Cin][kh][kw][Cout]
+    wt2 = K.split(w2.permute(1, 2, 3, 0).contiguous())
+    dx = K.conv2d_dgrad_x3_pair(K.split(nhwc(dy1)), wt1, K.split(nhwc(dy2)), wt2, (H, W), 1, addend=add)
+    close(nchw(dx).cpu(), ref.cpu())
+    two = K.conv2d_dgrad_x3(nhwc(dy2), wt2, (H, W), 2, 0, addend=K.conv2d_dgrad_x3(nhwc(dy1), wt1, (H, W), 2, 1, addend=add))
+    close(dx.cpu(), two.cpu().double(), tol=2e-6)
