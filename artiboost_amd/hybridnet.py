@@ -360,12 +360,13 @@ class HybridNet:
         return K.bn_eval_params(p.view(prefix + ".weight"), p.view(prefix + ".bias"),
                                 p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
 
-    def _bn(self, prefix, y, stats_part, count, res=None, relu=True, feeds_conv=True, keep_f32=False):
+    def _bn(self, prefix, y, stats_part, count, res=None, relu=True, feeds_conv=True, keep_f32=False, res_bnp=None):
         """feeds_conv / keep_f32 (bf16x3 only): the activation feeds a convolution (it is written as split planes by this
         pass) / is also needed in fp32 (residual input, ReLU mask of the backward, pooling)."""
         bnp = self._bn_params(prefix, stats_part, count)
         if self.x3 and feeds_conv:
-            return K.bn_apply_x3(y, bnp, res=res, relu=relu, want_f32=keep_f32), bnp
+            return K.bn_apply_x3(y, bnp, res=res, relu=relu, want_f32=keep_f32, res_bnp=res_bnp), bnp
+        assert res_bnp is None
         out = K.bn_apply(y, bnp, res=res, relu=relu)
         return out, bnp
 
@@ -416,11 +417,15 @@ class HybridNet:
                 rec = dict(pre=pre, stride=stride, x=x, y1=y1, a1=a1, bnp1=bnp1, y2=y2, ds=False)
                 if stride != 1 or inpl != planes:
                     yd, std_ = self._conv_fwd(x, pre + ".downsample.0.weight", stride, 0, want_stats=True)
-                    r, bnpd = self._bn(pre + ".downsample.1", yd, std_, cnt, relu=False, feeds_conv=False)
+                    if self.x3 and self.fuse_ds_bn:      # identity = bn_ds(yd) is applied inside bn2's pass, never stored
+                        r, bnpd = yd, self._bn_params(pre + ".downsample.1", std_, cnt)
+                    else:
+                        r, bnpd = self._bn(pre + ".downsample.1", yd, std_, cnt, relu=False, feeds_conv=False)
                     rec.update(ds=True, yd=yd, bnpd=bnpd)
                 else:
-                    r = x
-                out, bnp2 = self._bn(pre + ".bn2", y2, st2, cnt, res=r, relu=True, keep_f32=True)
+                    r, bnpd = x, None
+                out, bnp2 = self._bn(pre + ".bn2", y2, st2, cnt, res=r, relu=True, keep_f32=True,
+                                     res_bnp=bnpd if (self.x3 and self.fuse_ds_bn) else None)
                 rec.update(bnp2=bnp2, out=out)
                 if not tr:
                     rec = dict(pre=pre)
@@ -478,6 +483,7 @@ class HybridNet:
     fuse_stem = os.environ.get("AB_STEM_FUSE", "1") != "0"       # stem BN+ReLU+max-pool as one pass (forward)
     fuse_stem_bwd = os.environ.get("AB_STEM_FUSE_BWD", "0") == "1"   # ... and the gather-based fused backward
     stem_pool_reduce = os.environ.get("AB_STEM_POOL_REDUCE", "1") != "0"   # bf16x3: see _backward_trunk
+    fuse_ds_bn = os.environ.get("AB_FUSE_DS_BN", "1") != "0"      # bf16x3: the downsample BatchNorm inside bn2's apply pass
     pair_dgrad = os.environ.get("AB_PAIR_DGRAD", "1") != "0"      # bf16x3: conv1 + downsample data gradients of a block in one launch
 
     # AB_WGRAD_BATCH=1: the fixed-order slab reductions of a backward stage's weight gradients run as ONE launch at the end

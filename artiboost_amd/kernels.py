@@ -535,15 +535,20 @@ def conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=None, accumulate=False, defe
     return dw
 
 
-def bn_apply_x3(y, bnp, res=None, relu=True, want_f32=False):
+def bn_apply_x3(y, bnp, res=None, relu=True, want_f32=False, res_bnp=None):
     """fp32 y -> split planes [2, *y.shape] of relu(bn(y) + res); want_f32: also the fp32 tensor (returned, with the planes
-    cached on it as `_ab_split`) -- needed where the activation is a residual input or a ReLU mask in the backward."""
+    cached on it as `_ab_split`) -- needed where the activation is a residual input or a ReLU mask in the backward.
+    res_bnp: `res` is the raw output of the downsample conv and the residual is its BatchNorm (scale, shift) applied on the fly."""
     C = y.shape[-1]
     M = y.numel() // C
     sp = torch.empty((2,) + tuple(y.shape), dtype=torch.bfloat16, device=y.device)
     o = torch.empty_like(y) if want_f32 else None
-    L.check(L.lib().ab_bn_apply_x3(L.ptr(y), L.ptr(res), L.ptr(bnp), L.l(M), L.i(C), L.i(1 if relu else 0), L.ptr(o),
-                                   L.ptr(sp[0]), L.ptr(sp[1]), L.stream()), "ab_bn_apply_x3")
+    if res_bnp is not None:
+        L.check(L.lib().ab_bn_apply_x3_resbn(L.ptr(y), L.ptr(res), L.ptr(bnp), L.ptr(res_bnp), L.l(M), L.i(C), L.i(1 if relu else 0),
+                                             L.ptr(o), L.ptr(sp[0]), L.ptr(sp[1]), L.stream()), "ab_bn_apply_x3_resbn")
+    else:
+        L.check(L.lib().ab_bn_apply_x3(L.ptr(y), L.ptr(res), L.ptr(bnp), L.l(M), L.i(C), L.i(1 if relu else 0), L.ptr(o),
+                                       L.ptr(sp[0]), L.ptr(sp[1]), L.stream()), "ab_bn_apply_x3")
     if o is None:
         return sp
     o._ab_split = sp

@@ -152,6 +152,10 @@ int ab_conv2d_stem_wgrad_x3(const void* xpad_hi, const void* xpad_lo, const void
  * already reduced rows).  resnet.py:85-101, simplebaseline.py:171-172.                                             */
 int ab_bn_apply_x3(const float* y, const float* res, const float* bnp, long M, int C, int relu, float* out, void* out_hi,
                    void* out_lo, void* stream);
+/* ... the residual given as the raw output res_y of the block's downsample conv and ITS BatchNorm parameters res_bnp
+ * (anakin/models/resnet.py:95-99: identity = downsample(x)): out = [relu]( bn(y) + bn_ds(res_y) ), bn_ds(res_y) never stored. */
+int ab_bn_apply_x3_resbn(const float* y, const float* res_y, const float* bnp, const float* res_bnp, long M, int C, int relu,
+                         float* out, void* out_hi, void* out_lo, void* stream);
 /* out (relu == 1): the stored activation as fp32, or -- out_is_hi_plane != 0 -- the hi plane (bf16) of its split form: the
  * ReLU mask only needs the sign, and the plane is half the bytes                                                     */
 int ab_bn_bwd_x3(const float* dout, const void* out, int out_is_hi_plane, const float* y, const float* bnp, long M, int C,

@@ -380,3 +380,20 @@ def test_conv_dgrad_x3_pair_vs_fp64(case, with_addend):
     close(nchw(dx).cpu(), ref.cpu())
     two = K.conv2d_dgrad_x3(nhwc(dy2), wt2, (H, W), 2, 0, addend=K.conv2d_dgrad_x3(nhwc(dy1), wt1, (H, W), 2, 1, addend=add))
     close(dx.cpu(), two.cpu().double(), tol=2e-6)
+
+
+def test_bn_apply_x3_with_downsample_bn_residual():
+    """relu(bn2(y2) + bn_ds(yd)) in one pass (ab_bn_apply_x3_resbn) == the two-pass route that stores bn_ds(yd) first."""
+    from artiboost_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    y2 = torch.randn((3, 10, 12, 128), generator=g).cuda()
+    yd = torch.randn((3, 10, 12, 128), generator=g).cuda()
+    bnp2 = torch.randn((4, 128), generator=g).cuda()
+    bnpd = torch.randn((4, 128), generator=g).cuda()
+    r = K.bn_apply(yd, bnpd, res=None, relu=False)
+    ref = K.bn_apply_x3(y2, bnp2, res=r, relu=True, want_f32=True)
+    got = K.bn_apply_x3(y2, bnp2, res=yd, relu=True, want_f32=True, res_bnp=bnpd)
+    exact = torch.relu(y2.double() * bnp2[0].double() + bnp2[1].double() + yd.double() * bnpd[0].double() + bnpd[1].double())
+    close(got.cpu(), exact.cpu(), tol=1e-6)
+    close(got.cpu(), ref.cpu().double(), tol=1e-6)
+    assert torch.equal(got._ab_split.cpu(), K.split(got).cpu())
