@@ -287,12 +287,16 @@ template <> __device__ __forceinline__ void st_pair<bf16_t>(bf16_t* p, float a, 
 //   out = exp(x - m) * (A*cu + Bv*cv + K),  A = g_u/(s z), Bv = g_v/(s z), K = (g_d*(d/D-dd) - g_u*u - g_v*v)/(s z)
 // SPLIT (T = float): dlogits leaves as the split-bf16 planes the final layer's data / weight gradients consume
 // (dl_hi, dl_lo: bf16 [B, H, W, C*DP]) instead of fp32 -- no separate split pass over the largest activation of the net.
-template <typename T, bool SPLIT = false>
+// colpart != NULL (PIX pixels per workgroup): the workgroup also writes the column sums of its dlogits rows (fixed order: a
+// lane over its pixels, then the four waves), colpart[(b * gridDim.x + blockIdx.x)][CD] -- the final layer's bias gradient
+// without another pass over the planes.
+template <typename T, bool SPLIT = false, int PIX = SAM_BWD_PIX>
 __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                const float* __restrict__ uvd, const float* __restrict__ conf,
                                                const float* __restrict__ stat, const float* __restrict__ g_uvd,
                                                const float* __restrict__ g_conf, T* __restrict__ dlogits,
-                                               bf16_t* __restrict__ dl_hi = nullptr, bf16_t* __restrict__ dl_lo = nullptr) {
+                                               bf16_t* __restrict__ dl_hi = nullptr, bf16_t* __restrict__ dl_lo = nullptr,
+                                               float* __restrict__ colpart = nullptr) {
     const int CD = C * DP, npix = H * W;      // CD even
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int KP = SAM_MAXCH / 128, NCH = 2 * KP;
@@ -324,9 +328,12 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
         int ch = 2 * (lane + 64 * (k >> 1)) + (k & 1);
         cm[k] = cst[0][ch]; ca[k] = cst[1][ch]; cb[k] = cst[2][ch]; ck[k] = cst[3][ch];
     }
+    float csum[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) csum[k] = 0.f;
 #pragma unroll 1
-    for (int j = 0; j < SAM_BWD_PIX / 4; ++j) {
-        const int p = blockIdx.x * SAM_BWD_PIX + j * 4 + wave;
+    for (int j = 0; j < PIX / 4; ++j) {
+        const int p = blockIdx.x * PIX + j * 4 + wave;
         if (p >= npix) break;
         const int h = p / W, w = p - h * W;
         const float cu = (float)w / W, cv = (float)h / H;
@@ -347,6 +354,7 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
                 float out = e * ((ca[kk] * cu + cb[kk] * cv) + ck[kk]);
                 if (g_conf) out += cst[5][ch + t] * ((x[kk] == cm[kk] ? 1.f : 0.f) - e * cst[4][ch + t]);
                 o[t] = out;
+                csum[kk] += out;
             }
             if (ch < CD) {
                 if constexpr (SPLIT) {
@@ -357,6 +365,26 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
             }
         }
     }
+    if (colpart) {
+        __syncthreads();                                     // cst is free: rows 0..3 take the four waves' sums
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) cst[wave][2 * (lane + 64 * (k >> 1)) + (k & 1)] = csum[k];
+        __syncthreads();
+        float* dst = colpart + ((size_t)b * gridDim.x + blockIdx.x) * CD;
+        for (int ch = threadIdx.x; ch < CD; ch += 256) dst[ch] = ((cst[0][ch] + cst[1][ch]) + cst[2][ch]) + cst[3][ch];
+    }
+}
+
+// column sums of colpart [rows][CD] in fixed order -> out [CD] (8 channels x 32 row lanes per workgroup, as colsum_finalize_kernel)
+__global__ __launch_bounds__(256) void sam_bias_finalize(const float* __restrict__ part, int rows, int CD, float* __restrict__ out) {
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    double s = 0.0;
+    if (c < CD) for (int k = pl; k < rows; k += 32) s += part[(size_t)k * CD + c];
+    __shared__ double sm[32][8];
+    sm[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < CD) { for (int k = 1; k < 32; ++k) s += sm[k][cl]; out[c] = (float)s; }
 }
 
 extern "C" int ab_softargmax3d_ntiles(int H, int W) { return (H * W + SAM_TILE_PIX - 1) / SAM_TILE_PIX; }
@@ -424,6 +452,25 @@ extern "C" int ab_softargmax3d_bwd_x3(const float* logits, int B, int C, int D, 
     dim3 grid((H * W + SAM_BWD_PIX - 1) / SAM_BWD_PIX, B);
     sam_bwd<float, true><<<grid, 256, 0, as_stream(stream)>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
                                                               (bf16_t*)dl_hi, (bf16_t*)dl_lo);
+    AB_LAUNCH_CHECK();
+    return 0;
+}
+
+// ... and the column sums of dlogits over all B*H*W rows (the bias gradient of the layer that produced the logits) -> dbias [C*DP]
+// fp32.  colpart: scratch of ab_softargmax3d_bwd_x3_bias_rows(B, H, W) x C*DP floats.
+#define SAM_BWD_PIX_BIAS 64
+extern "C" int ab_softargmax3d_bwd_x3_bias_rows(int B, int H, int W) { return B * ((H * W + SAM_BWD_PIX_BIAS - 1) / SAM_BWD_PIX_BIAS); }
+extern "C" int ab_softargmax3d_bwd_x3_bias(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
+                                           const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
+                                           void* dl_hi, void* dl_lo, float* colpart, float* dbias, void* stream) {
+    if (!logits || !uvd || !conf || !stat || !g_uvd || !dl_hi || !dl_lo || !colpart || !dbias) return AB_EINVAL;
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH || ((C * DP) & 1)) return AB_ESHAPE;
+    dim3 grid((H * W + SAM_BWD_PIX_BIAS - 1) / SAM_BWD_PIX_BIAS, B);
+    hipStream_t st = as_stream(stream);
+    sam_bwd<float, true, SAM_BWD_PIX_BIAS><<<grid, 256, 0, st>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
+                                                                 (bf16_t*)dl_hi, (bf16_t*)dl_lo, colpart);
+    AB_LAUNCH_CHECK();
+    sam_bias_finalize<<<(C * DP + 7) / 8, 256, 0, st>>>(colpart, (int)(grid.x * grid.y), C * DP, dbias);
     AB_LAUNCH_CHECK();
     return 0;
 }

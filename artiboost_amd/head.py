@@ -34,12 +34,22 @@ def softargmax3d_bwd(logits, C, D, DP, uvd, conf, stat, g_uvd, g_conf=None, inpl
     return dl
 
 
-def softargmax3d_bwd_x3(logits, C, D, DP, uvd, conf, stat, g_uvd, g_conf=None):
-    """fp32 logits -> dlogits as split-bf16 planes [2, B, H, W, C*DP] (ab_softargmax3d_bwd_x3)."""
+def softargmax3d_bwd_x3(logits, C, D, DP, uvd, conf, stat, g_uvd, g_conf=None, dbias=None):
+    """fp32 logits -> dlogits as split-bf16 planes [2, B, H, W, C*DP] (ab_softargmax3d_bwd_x3).
+    dbias (fp32 [C*DP], written): the column sums of dlogits -- the bias gradient of the final layer -- from the same pass; the
+    returned planes then carry `_ab_bias_done`."""
     B, H, W, _ = logits.shape
     g_uvd = g_uvd.contiguous().float()
     gc = g_conf.contiguous().float() if g_conf is not None else None
     dl = torch.empty((2,) + tuple(logits.shape), dtype=torch.bfloat16, device=logits.device)
+    if dbias is not None:
+        lib = L.lib()
+        part = torch.empty((lib.ab_softargmax3d_bwd_x3_bias_rows(L.i(B), L.i(H), L.i(W)), C * DP), dtype=torch.float32, device=logits.device)
+        L.check(lib.ab_softargmax3d_bwd_x3_bias(L.ptr(logits), L.i(B), L.i(C), L.i(D), L.i(DP), L.i(H), L.i(W), L.ptr(uvd), L.ptr(conf),
+                                                L.ptr(stat), L.ptr(g_uvd), L.ptr(gc), L.ptr(dl[0]), L.ptr(dl[1]), L.ptr(part),
+                                                L.ptr(dbias), L.stream()), "ab_softargmax3d_bwd_x3_bias")
+        dl._ab_bias_done = True
+        return dl
     L.check(L.lib().ab_softargmax3d_bwd_x3(L.ptr(logits), L.i(B), L.i(C), L.i(D), L.i(DP), L.i(H), L.i(W), L.ptr(uvd), L.ptr(conf),
                                            L.ptr(stat), L.ptr(g_uvd), L.ptr(gc), L.ptr(dl[0]), L.ptr(dl[1]), L.stream()),
             "ab_softargmax3d_bwd_x3")

@@ -470,7 +470,9 @@ class HybridNet:
     def head_bwd(self, logits, kp3d, conf, stat, g_kp3d, g_conf=None):
         """dlogits, written in place over the logits buffer (they are not needed again); bf16x3: as split planes."""
         if self.x3:
-            return softargmax3d_bwd_x3(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf)
+            # (the final layer's bias gradient = column sums of dlogits comes out of the same pass; backward() sees the tag)
+            dbias = self.p.gview("hybrid_head.final_layer.bias") if (self.sam_bias and self.saved is not None) else None
+            return softargmax3d_bwd_x3(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf, dbias=dbias)
         return softargmax3d_bwd(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf,
                                 inplace=True)
 
@@ -483,6 +485,7 @@ class HybridNet:
     fuse_stem = os.environ.get("AB_STEM_FUSE", "1") != "0"       # stem BN+ReLU+max-pool as one pass (forward)
     fuse_stem_bwd = os.environ.get("AB_STEM_FUSE_BWD", "0") == "1"   # ... and the gather-based fused backward
     stem_pool_reduce = os.environ.get("AB_STEM_POOL_REDUCE", "1") != "0"   # bf16x3: see _backward_trunk
+    sam_bias = os.environ.get("AB_SAM_BIAS", "1") != "0"          # bf16x3: final-layer bias gradient out of the soft-argmax backward
     fuse_ds_bn = os.environ.get("AB_FUSE_DS_BN", "1") != "0"      # bf16x3: the downsample BatchNorm inside bn2's apply pass
     pair_dgrad = os.environ.get("AB_PAIR_DGRAD", "1") != "0"      # bf16x3: conv1 + downsample data gradients of a block in one launch
 
@@ -569,7 +572,8 @@ class HybridNet:
         # ---- head
         e2, e1, feat = S["e2"], S["e1"], S["feat"]
         if self.x3 and dlogits.dtype == torch.bfloat16:       # planes straight from the soft-argmax backward
-            K.col_sum_x3(dlogits, gv("hybrid_head.final_layer.bias"))
+            if not getattr(dlogits, "_ab_bias_done", False):
+                K.col_sum_x3(dlogits, gv("hybrid_head.final_layer.bias"))
         else:
             K.col_sum(dlogits, gv("hybrid_head.final_layer.bias"))
             if self.x3:

@@ -49,6 +49,13 @@ int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, int D, int 
 int ab_softargmax3d_bwd_x3(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
                            const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
                            void* dl_hi, void* dl_lo, void* stream);
+/* ... and dbias [C*DP] = column sums of dlogits over all B*H*W rows: the bias gradient of the final 1x1 layer that produced the
+ * logits (anakin/models/simplebaseline.py:148, final_layer), reduced in the same pass in fixed order.
+ * colpart: ab_softargmax3d_bwd_x3_bias_rows(B, H, W) x C*DP floats of scratch.                                              */
+int ab_softargmax3d_bwd_x3_bias_rows(int B, int H, int W);
+int ab_softargmax3d_bwd_x3_bias(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
+                                const float* conf, const float* stat, const float* g_uvd, const float* g_conf, void* dl_hi,
+                                void* dl_lo, float* colpart, float* dbias, void* stream);
 
 /* ---- M1/M2: convolution stack (implicit GEMM on MFMA) ----------------------------------------------------------
  * replaces cuDNN behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear:

@@ -78,3 +78,25 @@ def test_head_properties_full_size():
     up, cp = softargmax3d(peak.cuda(), C, D)
     np.testing.assert_allclose(up.cpu().numpy(), np.broadcast_to(np.array([9 / W, 5 / H, 3 / D], np.float32), (B, C, 3)), atol=1e-6)
     np.testing.assert_allclose(cp.cpu().numpy(), 1.0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(3, 22, 28, 32, 7, 5), (64, 22, 28, 32, 32, 32), (2, 5, 9, 10, 65, 3)])
+@pytest.mark.parametrize("with_conf", [False, True])
+def test_softargmax_bwd_x3_bias_sums(shape, with_conf):
+    """ab_softargmax3d_bwd_x3_bias: the same dlogits planes as ab_softargmax3d_bwd_x3, bit for bit, and dbias = their column sums
+    (the final layer's bias gradient, simplebaseline.py:148) against a float64 sum of the fp32 gradient."""
+    from artiboost_amd.head import softargmax3d_fwd, softargmax3d_bwd, softargmax3d_bwd_x3
+    B, C, D, DP, H, W = shape
+    gen = torch.Generator().manual_seed(B + 7 * H)
+    x = (3.0 * torch.randn(B, H, W, C * DP, generator=gen)).cuda()
+    uvd, conf, stat = softargmax3d_fwd(x, C, D, DP)
+    gu = torch.randn(uvd.shape, generator=gen).cuda()
+    gc = torch.randn(conf.shape, generator=gen).cuda() if with_conf else None
+    plain = softargmax3d_bwd_x3(x, C, D, DP, uvd, conf, stat, gu, gc)
+    dbias = torch.full((C * DP,), float("nan"), device="cuda")
+    fused = softargmax3d_bwd_x3(x, C, D, DP, uvd, conf, stat, gu, gc, dbias=dbias)
+    assert getattr(fused, "_ab_bias_done", False) and torch.equal(fused, plain)
+    full = softargmax3d_bwd(x, C, D, DP, uvd, conf, stat, gu, gc)          # fp32 gradient
+    ref = full.double().sum((0, 1, 2))
+    scale = float(full.abs().double().sum((0, 1, 2)).max()) + 1e-30
+    assert float((dbias.double() - ref).abs().max()) <= 2e-6 * scale
