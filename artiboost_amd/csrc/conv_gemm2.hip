@@ -25,7 +25,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // rows + 1 row of padding; weight rows are [7][8][4] = 224 elements, the missing 32 are read from the zero page.
 // X3 = 1: split-bf16 operands (see conv3x3.hip): a 128-byte LDS row carries a 32-channel chunk as [hi 64 B][lo 64 B];
 // g.cpt counts 32-channel chunks; Out / addend are fp32.
-template <int BM, int BN, int WM, int WN, int NBUF = 3, bool STEM = false, int X3 = 0>
+// ALT (X3 only): one tap reads the second operand pair (ConvGemmArgs::alt_tap1).  A template parameter, not a run-time test: the
+// extra pointer selects in the load issue cost the launches that do not use it 5-20 %.
+template <int BM, int BN, int WM, int WN, int NBUF = 3, bool STEM = false, int X3 = 0, bool ALT = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g) {
     constexpr int CK = X3 ? 32 : 64;                          // channels per K step
     constexpr int NW = WM * WN, NT = 64 * NW;                // 4 or 8 waves: the LDS fill rate scales with the waves issuing loads
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
     const bf16_t* __restrict__ A2lo = (const bf16_t*)g.A2_lo;
     const bf16_t* __restrict__ Bw2 = (const bf16_t*)g.Bw2;
     const bf16_t* __restrict__ Bw2lo = (const bf16_t*)g.Bw2_lo;
-    const int alt_t = X3 ? g.alt_tap1 - 1 - tap0 : -1;        // class-local index of the tap that reads the second operand pair
+    const int alt_t = ALT ? g.alt_tap1 - 1 - tap0 : -1;       // class-local index of the tap that reads the second operand pair
     const int PQ = g.P * g.Q;
     const bf16_t* zp = (const bf16_t*)ab_zero_page;
 
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
             s_outpix[r] = a_ok[j] ? op : -1;
         }
     }
-    long b_off[NB]; long b_off2[X3 ? NB : 1]; int b_chunk[NB]; bool b_ok[NB];
+    long b_off[NB]; long b_off2[ALT ? NB : 1]; int b_chunk[NB]; bool b_ok[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         int ii = wave * NB + j;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
         int col = n0 + r;
         b_ok[j] = (ii < IB) && (col < g.Cn);
         b_off[j] = (long)(b_ok[j] ? col : 0) * g.ktot;
-        if constexpr (X3) b_off2[j] = (long)(b_ok[j] ? col : 0) * g.ktot2;
+        if constexpr (ALT) b_off2[j] = (long)(b_ok[j] ? col : 0) * g.ktot2;
         b_chunk[j] = (lslot ^ ((r >> 1) & 7)) * 8;
         b_lo[j] = false;
         if (X3) { const int c = lslot ^ ((r >> 1) & 7); b_lo[j] = (c & 4) != 0; b_chunk[j] = (c & 3) * 8; }
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
     auto issue = [&](int step, int buf) {
         const int t = STEM ? 0 : step / g.cpt, c0 = STEM ? step * CK : (step - t * g.cpt) * CK;
         const int dh = STEM ? 0 : s_tap[t], dw = STEM ? 0 : s_tap[CG_MAXTAPS + t], ko = STEM ? 0 : s_tap[2 * CG_MAXTAPS + t];
-        const bool alt = X3 && !STEM && t == alt_t;           // wave-uniform: this step's rows come from (A2, Bw2)
+        const bool alt = ALT && t == alt_t;                   // wave-uniform: this step's rows come from (A2, Bw2)
         const bf16_t* Ah = alt ? A2 : A; const bf16_t* Al = alt ? A2lo : Alo;
         const bf16_t* Bh = alt ? Bw2 : Bw; const bf16_t* Bl = alt ? Bw2lo : Bwlo;
         unsigned char* base = smem + buf * BUFSZ;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
             if (ii < IB) {
                 const bool ok = b_ok[j] && (!STEM || c0 + b_chunk[j] < g.ktot);
                 long bo = b_off[j] + ko;
-                if constexpr (X3) { if (alt) bo = b_off2[j]; }
+                if constexpr (ALT) { if (alt) bo = b_off2[j]; }
                 const bf16_t* src = ok ? (((X3 && b_lo[j]) ? Bl : Bh) + (bo + c0 + b_chunk[j])) : zp;
                 glds16(src, __builtin_amdgcn_readfirstlane(lds_addr_of(base + BM * 128 + ii * 1024)));
             }
@@ -502,19 +504,23 @@ int conv_gemm2_x3_run(ConvGemmArgs& g, hipStream_t st) {
     // two ring stages for short K loops and for the 128x128 tile: 64 KB instead of 96, two workgroups per CU
     static const int nb2 = getenv("AB_G2X_NBUF2") ? atoi(getenv("AB_G2X_NBUF2")) : 1;
     const bool two = nb2 && (nsteps <= 16 || (bm == 128 && bn == 128));
-    if (bm == 128 && bn == 128) {
-        if (two) conv_gemm2_kernel<128, 128, 4, 2, 2, false, 1><<<tiles, 512, 0, st>>>(g);
-        else conv_gemm2_kernel<128, 128, 4, 2, 3, false, 1><<<tiles, 512, 0, st>>>(g);
-    } else if (bm == 128 && bn == 64) {
-        if (two) conv_gemm2_kernel<128, 64, 4, 2, 2, false, 1><<<tiles, 512, 0, st>>>(g);
-        else conv_gemm2_kernel<128, 64, 4, 2, 3, false, 1><<<tiles, 512, 0, st>>>(g);
-    } else if (bm == 64 && bn == 128) {
-        if (two) conv_gemm2_kernel<64, 128, 2, 4, 2, false, 1><<<tiles, 512, 0, st>>>(g);
-        else conv_gemm2_kernel<64, 128, 2, 4, 3, false, 1><<<tiles, 512, 0, st>>>(g);
-    } else {
-        if (two) conv_gemm2_kernel<64, 64, 2, 2, 2, false, 1><<<tiles, 256, 0, st>>>(g);
-        else conv_gemm2_kernel<64, 64, 2, 2, 3, false, 1><<<tiles, 256, 0, st>>>(g);
+#define G2X_LAUNCH(ALT_)                                                                                                     \
+    if (bm == 128 && bn == 128) {                                                                                            \
+        if (two) conv_gemm2_kernel<128, 128, 4, 2, 2, false, 1, ALT_><<<tiles, 512, 0, st>>>(g);                              \
+        else conv_gemm2_kernel<128, 128, 4, 2, 3, false, 1, ALT_><<<tiles, 512, 0, st>>>(g);                                  \
+    } else if (bm == 128 && bn == 64) {                                                                                      \
+        if (two) conv_gemm2_kernel<128, 64, 4, 2, 2, false, 1, ALT_><<<tiles, 512, 0, st>>>(g);                               \
+        else conv_gemm2_kernel<128, 64, 4, 2, 3, false, 1, ALT_><<<tiles, 512, 0, st>>>(g);                                   \
+    } else if (bm == 64 && bn == 128) {                                                                                      \
+        if (two) conv_gemm2_kernel<64, 128, 2, 4, 2, false, 1, ALT_><<<tiles, 512, 0, st>>>(g);                               \
+        else conv_gemm2_kernel<64, 128, 2, 4, 3, false, 1, ALT_><<<tiles, 512, 0, st>>>(g);                                   \
+    } else {                                                                                                                 \
+        if (two) conv_gemm2_kernel<64, 64, 2, 2, 2, false, 1, ALT_><<<tiles, 256, 0, st>>>(g);                                \
+        else conv_gemm2_kernel<64, 64, 2, 2, 3, false, 1, ALT_><<<tiles, 256, 0, st>>>(g);                                    \
     }
+    if (g.alt_tap1) { G2X_LAUNCH(true) }      // the paired data gradient of a down-sampling block (ab_conv2d_dgrad_x3_pair)
+    else { G2X_LAUNCH(false) }
+#undef G2X_LAUNCH
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -707,30 +707,42 @@ __device__ __forceinline__ void store8(float* __restrict__ p, const float* f) {
 // out = [relu]( y*scale + shift [+ res] ) -> fp32 `out` (optional) and split planes
 // res_bnp != NULL: `res` is itself a raw conv output and the residual is res*scale2 + shift2 (the downsample branch,
 // resnet.py:95-99: its BatchNorm output is never materialised)
+// (RESBN is a template parameter: as a run-time branch the second parameter set doubled the time of EVERY launch of this kernel,
+// 540 -> 1 005 us per step over its 34 launches)
+template <bool RESBN>
 __global__ __launch_bounds__(256) void bn_apply_x3_kernel(const float* __restrict__ y, const float* __restrict__ res,
                                                           const float* __restrict__ bnp, long nvec, int C, int relu,
                                                           float* __restrict__ out, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
                                                           const float* __restrict__ res_bnp = nullptr) {
     const bool fixed = ((256 * 8) % C) == 0;
-    float sc[8], sh[8], sc2[8], sh2[8];
-    auto loadp = [&](int c) {
+    float sc[8], sh[8], sc2[RESBN ? 8 : 1], sh2[RESBN ? 8 : 1];
+    if (fixed) {
+        const int c = (int)(((long)threadIdx.x * 8) % C);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            sc[k] = bnp[c + k]; sh[k] = bnp[C + c + k];
-            if (res_bnp) { sc2[k] = res_bnp[c + k]; sh2[k] = res_bnp[C + c + k]; }
+        for (int k = 0; k < 8; ++k) { sc[k] = bnp[c + k]; sh[k] = bnp[C + c + k]; }
+        if constexpr (RESBN) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sc2[k] = res_bnp[c + k]; sh2[k] = res_bnp[C + c + k]; }
         }
-    };
-    if (fixed) loadp((int)(((long)threadIdx.x * 8) % C));
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
         const long e = i * 8;
-        if (!fixed) loadp((int)(e % C));
+        if (!fixed) {
+            const int c = (int)(e % C);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sc[k] = bnp[c + k]; sh[k] = bnp[C + c + k]; }
+            if constexpr (RESBN) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { sc2[k] = res_bnp[c + k]; sh2[k] = res_bnp[C + c + k]; }
+            }
+        }
         float f[8], r[8];
         load8(y + e, f);
         if (res) load8(res + e, r);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float v = f[k] * sc[k] + sh[k];
-            if (res_bnp) r[k] = r[k] * sc2[k] + sh2[k];
+            if constexpr (RESBN) r[k] = r[k] * sc2[k] + sh2[k];
             if (res) v += r[k];
             if (relu) v = fmaxf(v, 0.f);
             f[k] = v;
@@ -1066,7 +1078,7 @@ extern "C" int ab_bn_apply_x3(const float* y, const float* res, const float* bnp
     if (!y || !bnp || !out_hi || !out_lo) return AB_EINVAL;
     if (C % 8) return AB_ESHAPE;
     const long nvec = M * C / 8;
-    bn_apply_x3_kernel<<<grid_for(nvec), 256, 0, as_stream(stream)>>>(y, res, bnp, nvec, C, relu, out, (bf16_t*)out_hi, (bf16_t*)out_lo);
+    bn_apply_x3_kernel<false><<<grid_for(nvec), 256, 0, as_stream(stream)>>>(y, res, bnp, nvec, C, relu, out, (bf16_t*)out_hi, (bf16_t*)out_lo);
     AB_LAUNCH_CHECK(); return 0;
 }
 
@@ -1076,7 +1088,7 @@ extern "C" int ab_bn_apply_x3_resbn(const float* y, const float* res_y, const fl
     if (!y || !res_y || !bnp || !res_bnp || !out_hi || !out_lo) return AB_EINVAL;
     if (C % 8) return AB_ESHAPE;
     const long nvec = M * C / 8;
-    bn_apply_x3_kernel<<<grid_for(nvec), 256, 0, as_stream(stream)>>>(y, res_y, bnp, nvec, C, relu, out, (bf16_t*)out_hi, (bf16_t*)out_lo, res_bnp);
+    bn_apply_x3_kernel<true><<<grid_for(nvec), 256, 0, as_stream(stream)>>>(y, res_y, bnp, nvec, C, relu, out, (bf16_t*)out_hi, (bf16_t*)out_lo, res_bnp);
     AB_LAUNCH_CHECK(); return 0;
 }
 

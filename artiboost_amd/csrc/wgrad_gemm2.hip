@@ -65,6 +65,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
     constexpr int APL = BR * PA, BPL = BR * PB;             // bytes of one plane of a tile
     constexpr int ABYTES = NPL * APL, STAGE = NPL * (APL + BPL);
     constexpr int PF = NBUF - 1;                            // steps in flight ahead of the one being multiplied
+    constexpr bool PARTIAL_I = BI == 256 && BJ == 256;      // only these launches may have a partial last channel tile (Cout = 704)
     constexpr int TI = BI / WI / 32, TJ = BJ / WJ / 32;     // 32x32 tiles per wave (waves WI x WJ)
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * STAGE];
     __shared__ int s_xoff[2][BR];                           // element offset of each row's input pixel (-1: padding / past the end)
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
 #pragma unroll
         for (int j = 0; j < LA; ++j) {
             int m = rbase + a_row[j];
-            const bf16_t* src = (m < r_end && i0 + a_col[j] < g.Cout) ? ((X3 && a_pl[j]) ? DYl : DY) + ((long)m * g.Cout + i0 + a_col[j]) : zp;
+            const bool in = m < r_end && (!PARTIAL_I || i0 + a_col[j] < g.Cout);
+            const bf16_t* src = in ? ((X3 && a_pl[j]) ? DYl : DY) + ((long)m * g.Cout + i0 + a_col[j]) : zp;
             glds16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + (wave * LA + j) * 1024));
         }
 #pragma unroll
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
             for (int r = 0; r < 16; ++r) {
                 int row = i0 + (wave_i * TI + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 int col = j0 + (wave_j * TJ + b) * 32 + (lane & 31);
-                if (row < g.Cout) out[(long)row * g.jtot + col] = acc[a][b][r];
+                if (!PARTIAL_I || row < g.Cout) out[(long)row * g.jtot + col] = acc[a][b][r];
             }
 }
 
