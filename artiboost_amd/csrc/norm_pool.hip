@@ -1120,7 +1120,9 @@ extern "C" int ab_bn_bwd_x3(const float* dout, const void* out, int out_is_hi_pl
 // the pooled gradient to the full resolution, masks it and reduces it (pool_bwd_bn_reduce_kernel, part rows =
 // ab_bn_relu_maxpool_bwd_x3_nparts); finalize; the apply pass repeats the gather and writes dy as planes (pool_bwd_bn_apply_x3_kernel;
 // AB_POOL_BWD_REGATHER=0: the reduce pass stores the masked gradient in the fp32 scratch `dz` and the generic apply pass reads it).
-static int pbr_rp() { static const int v = getenv("AB_PBR_RP") ? atoi(getenv("AB_PBR_RP")) : 16; return (v == 4 || v == 8) ? v : 16; }
+// row pairs per workgroup of the reduction: 4 / 8 / 16 -> 91 + 18 / 92 + 9 / 110 + 6 us for the pass + its finalize over 2 048 / 1 024 /
+// 512 partial rows
+static int pbr_rp() { static const int v = getenv("AB_PBR_RP") ? atoi(getenv("AB_PBR_RP")) : 8; return (v == 4 || v == 16) ? v : 8; }
 extern "C" int ab_bn_relu_maxpool_bwd_x3_nparts(int N, int H, int W, int C) {
     if ((H & 1) || (W & 1) || C % 8 || C / 4 > 256 || 256 % (C / 4)) return 0;
     const int gx = (int)(((long)W * (C / 4) + 255) / 256), gy = (H / 2 + pbr_rp() - 1) / pbr_rp();
