@@ -486,7 +486,8 @@ static void pick_tile2x(int M, int Cn, int nsteps, int nclass, int* bm, int* bn)
     const long t128 = (long)((M + 127) / 128) * ((Cn + *bn - 1) / *bn) * (nclass > 1 ? nclass : 1);
     *bm = t128 >= 512 ? 128 : 64;
     // (a 256 x 128 tile -- 64 x 64 wave tiles, 0.67 fragment reads per MFMA instead of 1 -- needs 140 KB of LDS for its fp32
-    // epilogue staging, i.e. one workgroup per CU, and measured slower: final 1x1 layer 113 -> 129 us, its data gradient 87 -> 92)
+    // epilogue staging, i.e. one workgroup per CU, and measured slower: final 1x1 layer 113 -> 129 us, its data gradient 87 -> 92;
+    // on a three-stage ring -- two steps in flight, 96 KB of loads per CU instead of 2 x 32 KB -- 119 -> 137 and 90 -> 97)
 }
 
 int conv_gemm2_x3_mtiles(int M, int Cn, int nsteps, int nclass) {
