@@ -796,6 +796,67 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_x3_kernel(const float* __res
     }
 }
 
+// maxpool3x3/2(relu(bn(y))) forward of the split-bf16 path (the stem): maxpool_fwd_kernel<float>'s arithmetic and scan order with 8
+// channels per thread and PFX_ROWS output rows per thread: consecutive output rows share an input row (2ho+1 = 2(ho+1)-1), which the
+// one-row-per-workgroup version read twice (268 MB of input became ~400 MB of reads); here the bottom taps of a window are carried
+// in registers as the top taps of the next, already normalised -- six tap loads per output row instead of nine.
+#define PFX_ROWS 4
+__global__ __launch_bounds__(256) void maxpool_fwd_x3_kernel(const float* __restrict__ y, const float* __restrict__ bnp, int N, int H,
+                                                             int W, int C, float* __restrict__ out, uint8_t* __restrict__ idx,
+                                                             bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo) {
+    const int Ho = H / 2, Wo = W / 2, vc = C / 8;
+    const unsigned col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= (unsigned)(Wo * vc)) return;
+    const int wo = (int)(col / (unsigned)vc), cv = (int)(col - (unsigned)wo * vc);
+    const int n = blockIdx.z, ho0 = blockIdx.y * PFX_ROWS;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = bnp[cv * 8 + k]; sh[k] = bnp[C + cv * 8 + k]; }
+    const bool w0ok = wo > 0;                                // H, W even: only h = -1 / w = -1 can fall outside
+    auto load_row = [&](int h, float (*r)[8]) {              // relu(bn(.)) of the three taps of input row h
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) {
+            if (dw == 0 && !w0ok) continue;
+            load8(y + (((long)n * H + h) * W + (wo * 2 + dw - 1)) * C + cv * 8, r[dw]);
+        }
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) r[dw][k] = fmaxf(r[dw][k] * sc[k] + sh[k], 0.f);
+    };
+    float top[3][8], mid[3][8], bot[3][8];
+    if (ho0 > 0) load_row(ho0 * 2 - 1, top);
+#pragma unroll
+    for (int rr = 0; rr < PFX_ROWS; ++rr) {
+        const int ho = ho0 + rr;
+        if (ho >= Ho) break;
+        load_row(ho * 2, mid);
+        load_row(ho * 2 + 1, bot);
+        float m[8]; uint32_t am[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { m[k] = -INFINITY; am[k] = 0; }
+        auto scan = [&](const float (*r)[8], const int t0) {        // (inlined per row: the tap arrays stay in registers)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                if (dw == 0 && !w0ok) continue;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (r[dw][k] > m[k]) { m[k] = r[dw][k]; am[k] = t0 + dw; }
+            }
+        };
+        if (ho > 0) scan(top, 0);
+        scan(mid, 3);
+        scan(bot, 6);
+        const long e = ((((long)n * Ho + ho) * Wo + wo) * vc + cv) * 8;
+        store8(out + e, m);
+        *(uint2*)(idx + e) = make_uint2(am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24), am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24));
+        store_split8(out_hi, out_lo, e, m);
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) top[dw][k] = bot[dw][k];
+    }
+}
+
 // Second half of maxpool3x3/2(relu(bn(y))) backward (pool_bwd_bn_reduce_kernel) for the split-bf16 path without the fp32 dz round trip: the same gather and mask again (winners + pooled gradient are
 // a quarter of the map), then BatchNorm-backward pass 2 on the spot, dy written as planes.  Against (reduce writes dz, apply reads
 // dz): 0.27 GB less written and 0.27 GB less read at the benchmark size for 84 MB of winners / pooled gradient read twice.
@@ -1005,6 +1066,12 @@ extern "C" int ab_bn_relu_maxpool3x3s2_fwd_x3(const float* y, const float* bnp, 
                                               void* out_lo, void* idx, void* stream) {
     if (!y || !bnp || !out || !out_hi || !out_lo) return AB_EINVAL;
     if (C % 4 || (H & 1) || (W & 1)) return AB_ESHAPE;
+    static const int v8 = getenv("AB_POOL_FWD_V8") ? atoi(getenv("AB_POOL_FWD_V8")) : 1;
+    if (v8 && C % 8 == 0 && idx) {
+        dim3 g8((unsigned)(((long)(W / 2) * (C / 8) + 255) / 256), (unsigned)((H / 2 + PFX_ROWS - 1) / PFX_ROWS), (unsigned)N);
+        maxpool_fwd_x3_kernel<<<g8, 256, 0, as_stream(stream)>>>(y, bnp, N, H, W, C, out, (uint8_t*)idx, (bf16_t*)out_hi, (bf16_t*)out_lo);
+        AB_LAUNCH_CHECK(); return 0;
+    }
     dim3 pgrid((unsigned)(((long)(W / 2) * (C / 4) + 255) / 256), (unsigned)(H / 2), (unsigned)N);
     maxpool_fwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>(y, bnp, N, H, W, C, out, (uint8_t*)idx, (bf16_t*)out_hi, (bf16_t*)out_lo);
     AB_LAUNCH_CHECK(); return 0;
