@@ -799,11 +799,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_x3_kernel(const float* __res
 // maxpool3x3/2(relu(bn(y))) forward of the split-bf16 path (the stem): maxpool_fwd_kernel<float>'s arithmetic and scan order with 8
 // channels per thread and PFX_ROWS output rows per thread: consecutive output rows share an input row (2ho+1 = 2(ho+1)-1), which the
 // one-row-per-workgroup version read twice (268 MB of input became ~400 MB of reads); here the bottom taps of a window are carried
-// in registers as the top taps of the next, already normalised -- six tap loads per output row instead of nine.
+// in registers as the top taps of the next -- six tap loads per output row instead of nine.
 #define PFX_ROWS 4
 __global__ __launch_bounds__(256) void maxpool_fwd_x3_kernel(const float* __restrict__ y, const float* __restrict__ bnp, int N, int H,
                                                              int W, int C, float* __restrict__ out, uint8_t* __restrict__ idx,
-                                                             bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo) {
+                                                             bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                                             float* __restrict__ ywin) {
     const int Ho = H / 2, Wo = W / 2, vc = C / 8;
     const unsigned col = blockIdx.x * 256 + threadIdx.x;
     if (col >= (unsigned)(Wo * vc)) return;
@@ -813,17 +814,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_x3_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sc[k] = bnp[cv * 8 + k]; sh[k] = bnp[C + cv * 8 + k]; }
     const bool w0ok = wo > 0;                                // H, W even: only h = -1 / w = -1 can fall outside
-    auto load_row = [&](int h, float (*r)[8]) {              // relu(bn(.)) of the three taps of input row h
+    auto load_row = [&](int h, float (*r)[8]) {              // the three taps of input row h
 #pragma unroll
         for (int dw = 0; dw < 3; ++dw) {
             if (dw == 0 && !w0ok) continue;
             load8(y + (((long)n * H + h) * W + (wo * 2 + dw - 1)) * C + cv * 8, r[dw]);
         }
-#pragma unroll
-        for (int dw = 0; dw < 3; ++dw)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) r[dw][k] = fmaxf(r[dw][k] * sc[k] + sh[k], 0.f);
-    };
+    };      // (RAW values are kept: relu(bn(.)) is applied at the comparison, so the winner's raw value is at hand for `ywin`)
     float top[3][8], mid[3][8], bot[3][8];
     if (ho0 > 0) load_row(ho0 * 2 - 1, top);
 #pragma unroll
@@ -832,15 +829,18 @@ __global__ __launch_bounds__(256) void maxpool_fwd_x3_kernel(const float* __rest
         if (ho >= Ho) break;
         load_row(ho * 2, mid);
         load_row(ho * 2 + 1, bot);
-        float m[8]; uint32_t am[8];
+        float m[8], mraw[8]; uint32_t am[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { m[k] = -INFINITY; am[k] = 0; }
+        for (int k = 0; k < 8; ++k) { m[k] = -INFINITY; mraw[k] = 0.f; am[k] = 0; }
         auto scan = [&](const float (*r)[8], const int t0) {        // (inlined per row: the tap arrays stay in registers)
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
                 if (dw == 0 && !w0ok) continue;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) if (r[dw][k] > m[k]) { m[k] = r[dw][k]; am[k] = t0 + dw; }
+                for (int k = 0; k < 8; ++k) {
+                    const float v = fmaxf(r[dw][k] * sc[k] + sh[k], 0.f);
+                    if (v > m[k]) { m[k] = v; mraw[k] = r[dw][k]; am[k] = t0 + dw; }
+                }
             }
         };
         if (ho > 0) scan(top, 0);
@@ -850,6 +850,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_x3_kernel(const float* __rest
         store8(out + e, m);
         *(uint2*)(idx + e) = make_uint2(am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24), am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24));
         store_split8(out_hi, out_lo, e, m);
+        if (ywin) store8(ywin + e, mraw);      // the winner's RAW conv output: what the backward's reduction needs of y
 #pragma unroll
         for (int dw = 0; dw < 3; ++dw)
 #pragma unroll
@@ -923,6 +924,46 @@ __global__ __launch_bounds__(256) void col_stats_x3_kernel(const bf16_t* __restr
             vload<bf16_t>(lo + r * C + cv * 8, b);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { const float v = a[i] + b[i]; s[i] += v; q[i] += v * v; }
+        }
+    extern __shared__ float sm[];
+    if (rr < rl)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sm[(rr * C + cv * 8 + i) * 2] = s[i]; sm[(rr * C + cv * 8 + i) * 2 + 1] = q[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < rl; ++k) { a += sm[(k * C + c) * 2]; b += sm[(k * C + c) * 2 + 1]; }
+        part[((long)blockIdx.x * C + c) * 2] = a; part[((long)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+}
+
+// BatchNorm-backward reduction of  maxpool3x3/2(relu(bn(y)))  over the POOLED elements only: the masked gradient is non-zero at
+// window winners, so  sum dz = sum_w [relu'] dpool_w  and  sum dz*xhat = sum_w [relu'] dpool_w * xhat(ywin_w)  (an input position that
+// wins several windows contributes once per window: the sums are linear).  Reads 2 x [N,H/2,W/2,C] fp32 instead of the full-resolution
+// y + winners + pooled gradient; same mask expression as the forward.  part rows: ab_col_stats_nparts(N*H/2*W/2).
+__global__ __launch_bounds__(256) void pool_win_bn_reduce_kernel(const float* __restrict__ dpool, const float* __restrict__ ywin,
+                                                                  const float* __restrict__ bnp, long M, int C, int rows_per_block,
+                                                                  float* __restrict__ part) {
+    const int vc = C / 8, rl = 256 / vc;
+    const int cv = threadIdx.x % vc, rr = threadIdx.x / vc;
+    long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+    float s[8], q[8], sc[8], sh[8], mu[8], is[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s[i] = 0.f; q[i] = 0.f;
+        sc[i] = bnp[cv * 8 + i]; sh[i] = bnp[C + cv * 8 + i]; mu[i] = bnp[2 * C + cv * 8 + i]; is[i] = bnp[3 * C + cv * 8 + i];
+    }
+    if (rr < rl)
+        for (long r = r0 + rr; r < r1; r += rl) {
+            float g[8], yw[8];
+            load8(dpool + r * C + cv * 8, g);
+            load8(ywin + r * C + cv * 8, yw);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dz = (yw[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
+                s[i] += dz; q[i] += dz * ((yw[i] - mu[i]) * is[i]);
+            }
         }
     extern __shared__ float sm[];
     if (rr < rl)
@@ -1069,11 +1110,20 @@ extern "C" int ab_bn_relu_maxpool3x3s2_fwd_x3(const float* y, const float* bnp, 
     static const int v8 = getenv("AB_POOL_FWD_V8") ? atoi(getenv("AB_POOL_FWD_V8")) : 1;
     if (v8 && C % 8 == 0 && idx) {
         dim3 g8((unsigned)(((long)(W / 2) * (C / 8) + 255) / 256), (unsigned)((H / 2 + PFX_ROWS - 1) / PFX_ROWS), (unsigned)N);
-        maxpool_fwd_x3_kernel<<<g8, 256, 0, as_stream(stream)>>>(y, bnp, N, H, W, C, out, (uint8_t*)idx, (bf16_t*)out_hi, (bf16_t*)out_lo);
+        maxpool_fwd_x3_kernel<<<g8, 256, 0, as_stream(stream)>>>(y, bnp, N, H, W, C, out, (uint8_t*)idx, (bf16_t*)out_hi, (bf16_t*)out_lo, nullptr);
         AB_LAUNCH_CHECK(); return 0;
     }
     dim3 pgrid((unsigned)(((long)(W / 2) * (C / 4) + 255) / 256), (unsigned)(H / 2), (unsigned)N);
     maxpool_fwd_kernel<float><<<pgrid, 256, 0, as_stream(stream)>>>(y, bnp, N, H, W, C, out, (uint8_t*)idx, (bf16_t*)out_hi, (bf16_t*)out_lo);
+    AB_LAUNCH_CHECK(); return 0;
+}
+// ... also writing ywin [N,H/2,W/2,C] fp32: the RAW conv output at each window's winner, for ab_bn_relu_maxpool_bwd_x3w
+extern "C" int ab_bn_relu_maxpool3x3s2_fwd_x3w(const float* y, const float* bnp, int N, int H, int W, int C, float* out, void* out_hi,
+                                               void* out_lo, void* idx, float* ywin, void* stream) {
+    if (!y || !bnp || !out || !out_hi || !out_lo || !idx || !ywin) return AB_EINVAL;
+    if (C % 8 || (H & 1) || (W & 1)) return AB_ESHAPE;
+    dim3 g8((unsigned)(((long)(W / 2) * (C / 8) + 255) / 256), (unsigned)((H / 2 + PFX_ROWS - 1) / PFX_ROWS), (unsigned)N);
+    maxpool_fwd_x3_kernel<<<g8, 256, 0, as_stream(stream)>>>(y, bnp, N, H, W, C, out, (uint8_t*)idx, (bf16_t*)out_hi, (bf16_t*)out_lo, ywin);
     AB_LAUNCH_CHECK(); return 0;
 }
 extern "C" int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx,
@@ -1219,6 +1269,26 @@ extern "C" int ab_bn_relu_maxpool_bwd_x3(const float* dpool, const void* idx, co
                                                        (bf16_t*)dy_hi, (bf16_t*)dy_lo);
     } else
         bn_bwd_apply_x3_kernel<<<grid_for(nvec), 256, 0, st>>>(dz, nullptr, y, bnp, bwdp, nvec, C, M, 0, (bf16_t*)dy_hi, (bf16_t*)dy_lo, nullptr, nullptr);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+// ab_bn_relu_maxpool_bwd_x3 with the reduction over the pooled elements (pool_win_bn_reduce_kernel: dpool + ywin, 134 MB at the
+// benchmark size instead of 352); part: ab_col_stats_nparts(N*H/2*W/2) rows.
+extern "C" int ab_bn_relu_maxpool_bwd_x3w(const float* dpool, const void* idx, const float* ywin, const float* y, const float* bnp,
+                                          int N, int H, int W, int C, float* part, float* bwdp, float* dgamma, float* dbeta,
+                                          void* dy_hi, void* dy_lo, void* stream) {
+    if (!dpool || !idx || !ywin || !y || !bnp || !part || !bwdp || !dgamma || !dbeta || !dy_hi || !dy_lo) return AB_EINVAL;
+    if ((H & 1) || (W & 1) || C % 8 || C / 8 > 256) return AB_ESHAPE;
+    hipStream_t st = as_stream(stream);
+    const long Mp = (long)N * (H / 2) * (W / 2), M = (long)N * H * W;
+    const int np = ab_col_stats_nparts(Mp), rl = 256 / (C / 8);
+    pool_win_bn_reduce_kernel<<<np, 256, (size_t)rl * C * 2 * 4, st>>>(dpool, ywin, bnp, Mp, C, red_rows(Mp), part);
+    AB_LAUNCH_CHECK();
+    launch_bn_bwd_finalize(part, np, C, dgamma, dbeta, bwdp, st);
+    AB_LAUNCH_CHECK();
+    dim3 g2((unsigned)(((long)W * (C / 8) + 255) / 256), (unsigned)(H / 2), (unsigned)N);
+    pool_bwd_bn_apply_x3_kernel<<<g2, 256, 0, st>>>((const uint8_t*)idx, dpool, y, bnp, bwdp, N, H, W, C, 1.f / (float)M,
+                                                   (bf16_t*)dy_hi, (bf16_t*)dy_lo);
     AB_LAUNCH_CHECK(); return 0;
 }
 

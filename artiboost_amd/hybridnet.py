@@ -398,7 +398,12 @@ class HybridNet:
         if self.fuse_stem:
             bnp0 = self._bn_params("backbone.bn1", st, N * (H // 2) * (W // 2))
             # BN + ReLU + 3x3/2 max-pool: the 128x128x64 activation is never stored (bf16x3: the pooled planes come from the same pass)
-            x, pool_idx = (K.bn_relu_maxpool_fwd_x3 if self.x3 else K.bn_relu_maxpool_fwd)(y0, bnp0)
+            if self.x3:      # training: + the raw conv output at the winners, all the backward's reduction needs of y0
+                res = K.bn_relu_maxpool_fwd_x3(y0, bnp0, want_win=tr and self.pool_win)
+                x, pool_idx = res[0], res[1]
+                S["pool_ywin"] = res[2] if len(res) > 2 else None
+            else:
+                x, pool_idx = K.bn_relu_maxpool_fwd(y0, bnp0)
         else:
             a0, bnp0 = self._bn("backbone.bn1", y0, st, N * (H // 2) * (W // 2), feeds_conv=False)
             x, pool_idx = K.maxpool_fwd(a0)
@@ -485,6 +490,7 @@ class HybridNet:
     fuse_stem = os.environ.get("AB_STEM_FUSE", "1") != "0"       # stem BN+ReLU+max-pool as one pass (forward)
     fuse_stem_bwd = os.environ.get("AB_STEM_FUSE_BWD", "0") == "1"   # ... and the gather-based fused backward
     stem_pool_reduce = os.environ.get("AB_STEM_POOL_REDUCE", "1") != "0"   # bf16x3: see _backward_trunk
+    pool_win = os.environ.get("AB_POOL_WIN", "1") != "0"          # bf16x3: stem BatchNorm-backward reduction over the pooled elements
     sam_bias = os.environ.get("AB_SAM_BIAS", "1") != "0"          # bf16x3: final-layer bias gradient out of the soft-argmax backward
     fuse_ds_bn = os.environ.get("AB_FUSE_DS_BN", "1") != "0"      # bf16x3: the downsample BatchNorm inside bn2's apply pass
     pair_dgrad = os.environ.get("AB_PAIR_DGRAD", "1") != "0"      # bf16x3: conv1 + downsample data gradients of a block in one launch
@@ -644,7 +650,8 @@ class HybridNet:
         dy0 = None
         if self.x3 and self.fuse_stem and self.stem_pool_reduce:
             # the max-pool backward pass also masks and reduces for the stem BatchNorm (AB_STEM_POOL_REDUCE=0: separate passes)
-            dy0 = K.bn_relu_maxpool_bwd_x3(dout, S["pool_idx"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"))
+            dy0 = K.bn_relu_maxpool_bwd_x3(dout, S["pool_idx"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"),
+                                           ywin=S.get("pool_ywin"))
         if dy0 is not None:
             pass
         elif self.fuse_stem_bwd:

@@ -246,17 +246,24 @@ def bn_relu_maxpool_fwd(y, bnp):
     return o, idx
 
 
-def bn_relu_maxpool_fwd_x3(y, bnp):
+def bn_relu_maxpool_fwd_x3(y, bnp, want_win=False):
     """bn_relu_maxpool_fwd on fp32 -> (pooled fp32 with its (hi, lo) planes as `_ab_split`, idx): the planes come from the
-    pooling pass itself instead of a separate split pass over the pooled tensor."""
+    pooling pass itself instead of a separate split pass over the pooled tensor.  want_win: also the raw conv output at every
+    window's winner (-> (pooled, idx, ywin)), which bn_relu_maxpool_bwd_x3(ywin=...) reduces instead of the full-resolution y."""
     N, H, W, C = y.shape
     o = torch.empty((N, H // 2, W // 2, C), dtype=torch.float32, device=y.device)
     pl = torch.empty((2, N, H // 2, W // 2, C), dtype=torch.bfloat16, device=y.device)
     idx = torch.empty((N, H // 2, W // 2, C), dtype=torch.uint8, device=y.device)
+    if want_win and C % 8 == 0:
+        ywin = torch.empty_like(o)
+        L.check(L.lib().ab_bn_relu_maxpool3x3s2_fwd_x3w(L.ptr(y), L.ptr(bnp), L.i(N), L.i(H), L.i(W), L.i(C), L.ptr(o), L.ptr(pl[0]),
+                                                        L.ptr(pl[1]), L.ptr(idx), L.ptr(ywin), L.stream()), "ab_bn_relu_maxpool3x3s2_fwd_x3w")
+        o._ab_split = pl
+        return o, idx, ywin
     L.check(L.lib().ab_bn_relu_maxpool3x3s2_fwd_x3(L.ptr(y), L.ptr(bnp), L.i(N), L.i(H), L.i(W), L.i(C), L.ptr(o), L.ptr(pl[0]),
                                                    L.ptr(pl[1]), L.ptr(idx), L.stream()), "ab_bn_relu_maxpool3x3s2_fwd_x3")
     o._ab_split = pl
-    return o, idx
+    return (o, idx, None) if want_win else (o, idx)
 
 
 def bn_relu_maxpool_bwd(dpool, idx, y, bnp, dgamma, dbeta):
@@ -272,11 +279,20 @@ def bn_relu_maxpool_bwd(dpool, idx, y, bnp, dgamma, dbeta):
     return dy
 
 
-def bn_relu_maxpool_bwd_x3(dpool, idx, y, bnp, dgamma, dbeta):
+def bn_relu_maxpool_bwd_x3(dpool, idx, y, bnp, dgamma, dbeta, ywin=None):
     """Backward of bn_relu_maxpool_fwd on fp32 tensors -> dy as split planes [2, *y.shape], or None when the shape is not handled:
-    the max-pool backward pass also masks and reduces (no separate BatchNorm-backward reduction over the full-size tensors)."""
+    the max-pool backward pass also masks and reduces (no separate BatchNorm-backward reduction over the full-size tensors).
+    ywin (bn_relu_maxpool_fwd_x3(want_win=True)): the reduction runs over the pooled elements only."""
     N, H, W, C = y.shape
     lib = L.lib()
+    if ywin is not None:
+        part = torch.empty((lib.ab_col_stats_nparts(L.l(N * (H // 2) * (W // 2))), C, 2), dtype=torch.float32, device=y.device)
+        bwdp = torch.empty((2, C), dtype=torch.float32, device=y.device)
+        dy = torch.empty((2,) + tuple(y.shape), dtype=torch.bfloat16, device=y.device)
+        L.check(lib.ab_bn_relu_maxpool_bwd_x3w(L.ptr(dpool), L.ptr(idx), L.ptr(ywin), L.ptr(y), L.ptr(bnp), L.i(N), L.i(H), L.i(W),
+                                               L.i(C), L.ptr(part), L.ptr(bwdp), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy[0]),
+                                               L.ptr(dy[1]), L.stream()), "ab_bn_relu_maxpool_bwd_x3w")
+        return dy
     np_ = lib.ab_bn_relu_maxpool_bwd_x3_nparts(L.i(N), L.i(H), L.i(W), L.i(C))
     if np_ <= 0:
         return None

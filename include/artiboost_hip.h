@@ -221,6 +221,14 @@ int ab_bn_relu_maxpool_bwd_x3_nparts(int N, int H, int W, int C);
 int ab_bn_relu_maxpool_bwd_x3(const float* dpool, const void* idx, const float* y, const float* bnp, int N, int H, int W,
                               int C, float* part, float* bwdp, float* dgamma, float* dbeta, float* dz, void* dy_hi,
                               void* dy_lo, void* stream);
+/* The same pair with the backward's BatchNorm reduction run over the POOLED elements (the masked gradient is non-zero at window
+ * winners only): the forward also writes ywin [N,H/2,W/2,C] fp32, the raw conv output at each winner; the backward reduces
+ * (dpool, ywin) -- a quarter of the full-resolution tensors -- into part[ab_col_stats_nparts(N*H/2*W/2)][C][2].               */
+int ab_bn_relu_maxpool3x3s2_fwd_x3w(const float* y, const float* bnp, int N, int H, int W, int C, float* out, void* out_hi,
+                                    void* out_lo, void* idx, float* ywin, void* stream);
+int ab_bn_relu_maxpool_bwd_x3w(const float* dpool, const void* idx, const float* ywin, const float* y, const float* bnp, int N, int H,
+                               int W, int C, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy_hi, void* dy_lo,
+                               void* stream);
 int ab_maxpool3x3s2_bwd(const void* idx, const void* dout, int dtype, int N, int H, int W, int C, void* dx, void* stream);
 int ab_avgpool_fwd(const void* x, int dtype, int N, int HW, int C, float* out, void* stream);
 int ab_avgpool_bwd(const float* g, int dtype, int N, int HW, int C, void* dx, int accumulate, void* stream);

@@ -268,6 +268,16 @@ def test_fused_stem_bn_relu_maxpool(shape, dtype):
         assert float((got - ref_dy).abs().max()) <= 2e-5 * float(ref_dy.abs().max())
         np.testing.assert_allclose(dg3.cpu().numpy(), dg0.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(dg0.abs().max()))
         np.testing.assert_allclose(db3.cpu().numpy(), db0.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(db0.abs().max()))
+        # ... and with the reduction over the pooled elements: the forward also hands out the raw conv output at the winners
+        o4, i4, yw = K.bn_relu_maxpool_fwd_x3(y, bnp, want_win=True)
+        assert torch.equal(o4, out) and torch.equal(i4, idx) and torch.equal(o4._ab_split, o3._ab_split)
+        assert torch.equal(torch.relu(yw * bnp[0] + bnp[1]), out)           # bn + relu of the winner == the pooled activation
+        dg4, db4 = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        pw = K.bn_relu_maxpool_bwd_x3(dpool, idx, y, bnp, dg4, db4, ywin=yw)
+        got = pw[0].float() + pw[1].float()
+        assert float((got - ref_dy).abs().max()) <= 2e-5 * float(ref_dy.abs().max())
+        np.testing.assert_allclose(dg4.cpu().numpy(), dg0.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(dg0.abs().max()))
+        np.testing.assert_allclose(db4.cpu().numpy(), db0.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(db0.abs().max()))
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 128, False), (3, 32, 32, 64, 64, True), (2, 8, 8, 128, 192, True),
