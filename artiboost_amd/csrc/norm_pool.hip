@@ -709,11 +709,14 @@ __device__ __forceinline__ void store8(float* __restrict__ p, const float* f) {
 // resnet.py:95-99: its BatchNorm output is never materialised)
 // (RESBN is a template parameter: as a run-time branch the second parameter set doubled the time of EVERY launch of this kernel,
 // 540 -> 1 005 us per step over its 34 launches)
-template <bool RESBN>
+// RESPL: the residual arrives as its (hi, lo) planes (res_hi, res_lo; `res` unused) -- the block input need not exist in fp32.
+template <bool RESBN, bool RESPL = false>
 __global__ __launch_bounds__(256) void bn_apply_x3_kernel(const float* __restrict__ y, const float* __restrict__ res,
                                                           const float* __restrict__ bnp, long nvec, int C, int relu,
                                                           float* __restrict__ out, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
-                                                          const float* __restrict__ res_bnp = nullptr) {
+                                                          const float* __restrict__ res_bnp = nullptr,
+                                                          const bf16_t* __restrict__ res_hi = nullptr,
+                                                          const bf16_t* __restrict__ res_lo = nullptr) {
     const bool fixed = ((256 * 8) % C) == 0;
     float sc[8], sh[8], sc2[RESBN ? 8 : 1], sh2[RESBN ? 8 : 1];
     if (fixed) {
@@ -738,12 +741,20 @@ __global__ __launch_bounds__(256) void bn_apply_x3_kernel(const float* __restric
         }
         float f[8], r[8];
         load8(y + e, f);
-        if (res) load8(res + e, r);
+        if constexpr (RESPL) {
+            const uint4 h4 = *(const uint4*)(res_hi + e), l4 = *(const uint4*)(res_lo + e);
+            const uint32_t hw[4] = {h4.x, h4.y, h4.z, h4.w}, lw[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[2 * k] = __uint_as_float(hw[k] << 16) + __uint_as_float(lw[k] << 16);
+                r[2 * k + 1] = __uint_as_float(hw[k] & 0xffff0000u) + __uint_as_float(lw[k] & 0xffff0000u);
+            }
+        } else if (res) load8(res + e, r);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float v = f[k] * sc[k] + sh[k];
             if constexpr (RESBN) r[k] = r[k] * sc2[k] + sh2[k];
-            if (res) v += r[k];
+            if (RESPL || res) v += r[k];
             if (relu) v = fmaxf(v, 0.f);
             f[k] = v;
         }
@@ -847,7 +858,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_x3_kernel(const float* __rest
         scan(mid, 3);
         scan(bot, 6);
         const long e = ((((long)n * Ho + ho) * Wo + wo) * vc + cv) * 8;
-        store8(out + e, m);
+        if (out) store8(out + e, m);           // (NULL: the pooled tensor is wanted as planes only)
         *(uint2*)(idx + e) = make_uint2(am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24), am[4] | (am[5] << 8) | (am[6] << 16) | (am[7] << 24));
         store_split8(out_hi, out_lo, e, m);
         if (ywin) store8(ywin + e, mraw);      // the winner's RAW conv output: what the backward's reduction needs of y
@@ -1120,7 +1131,7 @@ extern "C" int ab_bn_relu_maxpool3x3s2_fwd_x3(const float* y, const float* bnp, 
 // ... also writing ywin [N,H/2,W/2,C] fp32: the RAW conv output at each window's winner, for ab_bn_relu_maxpool_bwd_x3w
 extern "C" int ab_bn_relu_maxpool3x3s2_fwd_x3w(const float* y, const float* bnp, int N, int H, int W, int C, float* out, void* out_hi,
                                                void* out_lo, void* idx, float* ywin, void* stream) {
-    if (!y || !bnp || !out || !out_hi || !out_lo || !idx || !ywin) return AB_EINVAL;
+    if (!y || !bnp || !out_hi || !out_lo || !idx || !ywin) return AB_EINVAL;          // out may be NULL: planes only
     if (C % 8 || (H & 1) || (W & 1)) return AB_ESHAPE;
     dim3 g8((unsigned)(((long)(W / 2) * (C / 8) + 255) / 256), (unsigned)((H / 2 + PFX_ROWS - 1) / PFX_ROWS), (unsigned)N);
     maxpool_fwd_x3_kernel<<<g8, 256, 0, as_stream(stream)>>>(y, bnp, N, H, W, C, out, (uint8_t*)idx, (bf16_t*)out_hi, (bf16_t*)out_lo, ywin);
@@ -1206,6 +1217,17 @@ extern "C" int ab_bn_apply_x3_resbn(const float* y, const float* res_y, const fl
     if (C % 8) return AB_ESHAPE;
     const long nvec = M * C / 8;
     bn_apply_x3_kernel<true><<<grid_for(nvec), 256, 0, as_stream(stream)>>>(y, res_y, bnp, nvec, C, relu, out, (bf16_t*)out_hi, (bf16_t*)out_lo, res_bnp);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+// ... with the residual given as its (hi, lo) planes
+extern "C" int ab_bn_apply_x3_respl(const float* y, const void* res_hi, const void* res_lo, const float* bnp, long M, int C, int relu,
+                                    float* out, void* out_hi, void* out_lo, void* stream) {
+    if (!y || !res_hi || !res_lo || !bnp || !out_hi || !out_lo) return AB_EINVAL;
+    if (C % 8) return AB_ESHAPE;
+    const long nvec = M * C / 8;
+    bn_apply_x3_kernel<false, true><<<grid_for(nvec), 256, 0, as_stream(stream)>>>(y, nullptr, bnp, nvec, C, relu, out, (bf16_t*)out_hi, (bf16_t*)out_lo,
+                                                                                 nullptr, (const bf16_t*)res_hi, (const bf16_t*)res_lo);
     AB_LAUNCH_CHECK(); return 0;
 }
 

@@ -399,7 +399,7 @@ class HybridNet:
             bnp0 = self._bn_params("backbone.bn1", st, N * (H // 2) * (W // 2))
             # BN + ReLU + 3x3/2 max-pool: the 128x128x64 activation is never stored (bf16x3: the pooled planes come from the same pass)
             if self.x3:      # training: + the raw conv output at the winners, all the backward's reduction needs of y0
-                res = K.bn_relu_maxpool_fwd_x3(y0, bnp0, want_win=tr and self.pool_win)
+                res = K.bn_relu_maxpool_fwd_x3(y0, bnp0, want_win=tr and self.pool_win, want_f32=not self.res_planes)
                 x, pool_idx = res[0], res[1]
                 S["pool_ywin"] = res[2] if len(res) > 2 else None
             else:
@@ -407,7 +407,7 @@ class HybridNet:
         else:
             a0, bnp0 = self._bn("backbone.bn1", y0, st, N * (H // 2) * (W // 2), feeds_conv=False)
             x, pool_idx = K.maxpool_fwd(a0)
-        if self.x3 and getattr(x, "_ab_split", None) is None:
+        if self.x3 and x.dtype != torch.bfloat16 and getattr(x, "_ab_split", None) is None:
             x._ab_split = K.split(x)      # layer1.0 reads the pooled tensor three times (conv1, residual, conv1's weight gradient)
         S.update(y0=y0, bnp0=bnp0, pool_idx=pool_idx)
         inpl = 64
@@ -429,7 +429,10 @@ class HybridNet:
                     rec.update(ds=True, yd=yd, bnpd=bnpd)
                 else:
                     r, bnpd = x, None
-                out, bnp2 = self._bn(pre + ".bn2", y2, st2, cnt, res=r, relu=True, keep_f32=True,
+                # bf16x3 + AB_RES_PLANES=1: block outputs exist only as their planes (the next block adds hi + lo as its residual);
+                # the last block's output is also kept in fp32 (global average pool, transposed conv head)
+                last = li == 4 and b == nblk - 1
+                out, bnp2 = self._bn(pre + ".bn2", y2, st2, cnt, res=r, relu=True, keep_f32=(not self.res_planes) or last or not self.x3,
                                      res_bnp=bnpd if (self.x3 and self.fuse_ds_bn) else None)
                 rec.update(bnp2=bnp2, out=out)
                 if not tr:
@@ -439,7 +442,7 @@ class HybridNet:
                 inpl = planes
         feat = x                                         # res_layer4 [N,h,w,512]
         fmean = K.avgpool_fwd(feat)                      # res_layer4_mean [N,512] f32 (resnet.py:219)
-        h4, w4 = feat.shape[1], feat.shape[2]
+        h4, w4 = feat.shape[-3], feat.shape[-2]
         # ---- IntegralDeconvHead: ConvT == data-gradient of the mirrored stride-2 conv
         # transposed convs: the data-gradient kernel of the mirrored conv, BatchNorm partials from its epilogue
         # (AB_DECONV_STATS=0: separate col_stats passes)
@@ -490,6 +493,7 @@ class HybridNet:
     fuse_stem = os.environ.get("AB_STEM_FUSE", "1") != "0"       # stem BN+ReLU+max-pool as one pass (forward)
     fuse_stem_bwd = os.environ.get("AB_STEM_FUSE_BWD", "0") == "1"   # ... and the gather-based fused backward
     stem_pool_reduce = os.environ.get("AB_STEM_POOL_REDUCE", "1") != "0"   # bf16x3: see _backward_trunk
+    res_planes = os.environ.get("AB_RES_PLANES", "1") != "0"     # bf16x3: block outputs only as (hi, lo) planes, no fp32 copy
     pool_win = os.environ.get("AB_POOL_WIN", "1") != "0"          # bf16x3: stem BatchNorm-backward reduction over the pooled elements
     sam_bias = os.environ.get("AB_SAM_BIAS", "1") != "0"          # bf16x3: final-layer bias gradient out of the soft-argmax backward
     fuse_ds_bn = os.environ.get("AB_FUSE_DS_BN", "1") != "0"      # bf16x3: the downsample BatchNorm inside bn2's apply pass
@@ -630,16 +634,16 @@ class HybridNet:
                 self._wgrad_side(self._conv_wgrad, x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
                 if self.x3 and stride == 2 and self.pair_dgrad:      # both branches in one launch (the 1x1 as a tap of the 3x3/s2)
                     dout = K.conv2d_dgrad_x3_pair(dy1, self.tr[pre + ".conv1.weight"], dyd, self.tr[pre + ".downsample.0.weight"],
-                                                  (x.shape[1], x.shape[2]), 1)
+                                                  (x.shape[-3], x.shape[-2]), 1)
                 else:
-                    dx = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[1], x.shape[2]), stride, 1)
-                    dout = self._conv_dgrad(dyd, pre + ".downsample.0.weight", (x.shape[1], x.shape[2]), stride, 0, addend=dx)
+                    dx = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[-3], x.shape[-2]), stride, 1)
+                    dout = self._conv_dgrad(dyd, pre + ".downsample.0.weight", (x.shape[-3], x.shape[-2]), stride, 0, addend=dx)
                 dout_part = None
             elif bn_below is not None:
-                dout, dout_part = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[1], x.shape[2]), stride, 1,
+                dout, dout_part = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[-3], x.shape[-2]), stride, 1,
                                                    addend=dz, bn=bn_below)
             else:
-                dout = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[1], x.shape[2]), stride, 1, addend=dz)
+                dout = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[-3], x.shape[-2]), stride, 1, addend=dz)
                 dout_part = None
         return dout, dout_part
 

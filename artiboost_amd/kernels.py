@@ -246,7 +246,7 @@ def bn_relu_maxpool_fwd(y, bnp):
     return o, idx
 
 
-def bn_relu_maxpool_fwd_x3(y, bnp, want_win=False):
+def bn_relu_maxpool_fwd_x3(y, bnp, want_win=False, want_f32=True):
     """bn_relu_maxpool_fwd on fp32 -> (pooled fp32 with its (hi, lo) planes as `_ab_split`, idx): the planes come from the
     pooling pass itself instead of a separate split pass over the pooled tensor.  want_win: also the raw conv output at every
     window's winner (-> (pooled, idx, ywin)), which bn_relu_maxpool_bwd_x3(ywin=...) reduces instead of the full-resolution y."""
@@ -256,8 +256,12 @@ def bn_relu_maxpool_fwd_x3(y, bnp, want_win=False):
     idx = torch.empty((N, H // 2, W // 2, C), dtype=torch.uint8, device=y.device)
     if want_win and C % 8 == 0:
         ywin = torch.empty_like(o)
+        if not want_f32:      # the pooled activation as planes only (its consumers read planes: conv1, the residual, the weight gradient)
+            o = None
         L.check(L.lib().ab_bn_relu_maxpool3x3s2_fwd_x3w(L.ptr(y), L.ptr(bnp), L.i(N), L.i(H), L.i(W), L.i(C), L.ptr(o), L.ptr(pl[0]),
                                                         L.ptr(pl[1]), L.ptr(idx), L.ptr(ywin), L.stream()), "ab_bn_relu_maxpool3x3s2_fwd_x3w")
+        if o is None:
+            return pl, idx, ywin
         o._ab_split = pl
         return o, idx, ywin
     L.check(L.lib().ab_bn_relu_maxpool3x3s2_fwd_x3(L.ptr(y), L.ptr(bnp), L.i(N), L.i(H), L.i(W), L.i(C), L.ptr(o), L.ptr(pl[0]),
@@ -486,7 +490,7 @@ def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=Fa
         rows = lib.ab_conv2d_dgrad_x3_bn_rows(L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad))
         mask = None
         if bn_out is not None:
-            sp = getattr(bn_out, "_ab_split", None)
+            sp = bn_out if bn_out.dtype == torch.bfloat16 else getattr(bn_out, "_ab_split", None)
             if sp is None:
                 rows = 0                   # the mask is read from the hi plane of the stored activation
             else:
@@ -559,7 +563,11 @@ def bn_apply_x3(y, bnp, res=None, relu=True, want_f32=False, res_bnp=None):
     M = y.numel() // C
     sp = torch.empty((2,) + tuple(y.shape), dtype=torch.bfloat16, device=y.device)
     o = torch.empty_like(y) if want_f32 else None
-    if res_bnp is not None:
+    if res is not None and res.dtype == torch.bfloat16:      # the residual as (hi, lo) planes
+        assert res_bnp is None
+        L.check(L.lib().ab_bn_apply_x3_respl(L.ptr(y), L.ptr(res[0]), L.ptr(res[1]), L.ptr(bnp), L.l(M), L.i(C), L.i(1 if relu else 0),
+                                             L.ptr(o), L.ptr(sp[0]), L.ptr(sp[1]), L.stream()), "ab_bn_apply_x3_respl")
+    elif res_bnp is not None:
         L.check(L.lib().ab_bn_apply_x3_resbn(L.ptr(y), L.ptr(res), L.ptr(bnp), L.ptr(res_bnp), L.l(M), L.i(C), L.i(1 if relu else 0),
                                              L.ptr(o), L.ptr(sp[0]), L.ptr(sp[1]), L.stream()), "ab_bn_apply_x3_resbn")
     else:
@@ -590,7 +598,9 @@ def bn_bwd_x3(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, part=N
     else:
         given = part.shape[0]
     mask, is_hi = (out if relu is True else None), 0
-    if mask is not None and getattr(mask, "_ab_split", None) is not None:
+    if mask is not None and mask.dtype == torch.bfloat16:
+        mask, is_hi = mask[0], 1                     # the activation exists only as planes
+    elif mask is not None and getattr(mask, "_ab_split", None) is not None:
         mask, is_hi = mask._ab_split[0], 1          # sign of the hi plane == sign of the activation; half the bytes
     L.check(lib.ab_bn_bwd_x3(L.ptr(dout), L.ptr(mask), L.i(is_hi), L.ptr(y), L.ptr(bnp), L.l(M), L.i(C),
                              L.i(2 if relu == "recompute" else 1 if relu else 0), L.ptr(part), L.i(given), L.ptr(bwdp),

@@ -25,7 +25,7 @@ GFLOP_FWD_BWD_PER_SAMPLE = {224: 24.336, 256: 31.785}
 # MI355X_MICROARCH.md (dense): bf16 MFMA 2.5 PFLOP/s, f32-input MFMA 157.3 TFLOP/s.  "bf16x3" (split-bf16, fp32-grade: the
 # reference's precision) spends three bf16 MFMA passes per product, so its roof for ALGORITHMIC flops is 2500 / 3.
 MFMA_PEAK_TFLOPS = {"bf16x3": 2500.0 / 3.0, "bf16": 2500.0, "f32": 157.3}
-DTYPE_NOTE = {"bf16x3": "fp32 activations/gradients/optimizer; convolutions as split-bf16 (hi+lo) x3 MFMA passes with fp32 accumulation "
+DTYPE_NOTE = {"bf16x3": "fp32 conv outputs/gradients/BatchNorm/optimizer; post-activation tensors held as the (hi+lo) bf16 pairs the convolutions read; convolutions as split-bf16 (hi+lo) x3 MFMA passes with fp32 accumulation "
                         "(2^-17 operand precision; meets the f32 tolerances of tests/test_gpu_learner.py against the reference goldens)",
               "f32": "exact f32 MFMA everywhere", "bf16": "bf16 operands and activations (misses the 1e-3 parity bound)"}
 

@@ -163,6 +163,9 @@ int ab_bn_apply_x3(const float* y, const float* res, const float* bnp, long M, i
  * (anakin/models/resnet.py:95-99: identity = downsample(x)): out = [relu]( bn(y) + bn_ds(res_y) ), bn_ds(res_y) never stored. */
 int ab_bn_apply_x3_resbn(const float* y, const float* res_y, const float* bnp, const float* res_bnp, long M, int C, int relu,
                          float* out, void* out_hi, void* out_lo, void* stream);
+/* ... the residual given as its (hi, lo) bf16 planes (a block input that exists only as the planes its producer wrote). */
+int ab_bn_apply_x3_respl(const float* y, const void* res_hi, const void* res_lo, const float* bnp, long M, int C, int relu,
+                         float* out, void* out_hi, void* out_lo, void* stream);
 /* out (relu == 1): the stored activation as fp32, or -- out_is_hi_plane != 0 -- the hi plane (bf16) of its split form: the
  * ReLU mask only needs the sign, and the plane is half the bytes                                                     */
 int ab_bn_bwd_x3(const float* dout, const void* out, int out_is_hi_plane, const float* y, const float* bnp, long M, int C,
@@ -223,7 +226,8 @@ int ab_bn_relu_maxpool_bwd_x3(const float* dpool, const void* idx, const float* 
                               void* dy_lo, void* stream);
 /* The same pair with the backward's BatchNorm reduction run over the POOLED elements (the masked gradient is non-zero at window
  * winners only): the forward also writes ywin [N,H/2,W/2,C] fp32, the raw conv output at each winner; the backward reduces
- * (dpool, ywin) -- a quarter of the full-resolution tensors -- into part[ab_col_stats_nparts(N*H/2*W/2)][C][2].               */
+ * (dpool, ywin) -- a quarter of the full-resolution tensors -- into part[ab_col_stats_nparts(N*H/2*W/2)][C][2].
+ * fwd: `out` may be NULL (the pooled activation as planes only).                                                            */
 int ab_bn_relu_maxpool3x3s2_fwd_x3w(const float* y, const float* bnp, int N, int H, int W, int C, float* out, void* out_hi,
                                     void* out_lo, void* idx, float* ywin, void* stream);
 int ab_bn_relu_maxpool_bwd_x3w(const float* dpool, const void* idx, const float* ywin, const float* y, const float* bnp, int N, int H,
