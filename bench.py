@@ -134,7 +134,7 @@ def pmc_traffic(args):
         return None
 
 
-PMC_FILE = {"bf16": "round1_pmc_hbm_traffic.json", "bf16x3": "round2_g_pmc_hbm_traffic.json", "f32": "none"}
+PMC_FILE = {"bf16": "round1_pmc_hbm_traffic.json", "bf16x3": "round2_h_pmc_hbm_traffic.json", "f32": "none"}
 
 
 def cpu_baseline(args, cfg):
