@@ -43,13 +43,13 @@ def build(size, heat, dtype, seed, **arch_extra):
 # Prediction tolerances (absolute; metres for joints / corners, heat-map units for 2d_uvd).  "bf16x3" -- split-bf16 MFMA, the
 # benchmarked precision -- is held to the exact-f32 path's tolerance on the losses (3e-4), to 1.5 % on the gradient norms
 # (f32: 1 %) and on the predictions to a bound 5x below the north star's 1e-3.  Measured against the reference goldens on MI355X
-# (tests/parity_report.py, final build of round 2): train-mode joints 3.6e-7 m / corners 1.0e-5 m (f32: 1.2e-7 / 2.6e-7); eval mode on this
-# deliberately ill-conditioned random-weight net (running statistics 0 / 1) joints 1.2e-4 m, 2d_uvd 3.1e-4 (f32: 2.2e-5 m, 5.6e-5;
-# bf16: 9.5e-2 m, 2.4e-1).
+# (tests/parity_report.py, final build of round 2 -- block outputs held as (hi, lo) planes): train-mode joints 3.6e-7 m / corners 7.5e-6 m
+# (f32: 1.2e-7 / 2.6e-7); eval mode on this deliberately ill-conditioned random-weight net (running statistics 0 / 1) joints 1.0e-4 m,
+# 2d_uvd 2.5e-4 (f32: 2.2e-5 m, 5.6e-5; bf16: 9.5e-2 m, 2.4e-1).  With fp32 copies of the block outputs (AB_RES_PLANES=0): 1.2e-4 m, 3.1e-4.
 # gsamp: element-wise check of sampled weight-gradient entries, as a fraction of the sample's largest entry (the gradient
 # of the stem passes through 33 BatchNorms at batch size 2: its small entries are the most rounding-sensitive numbers here)
 # gnorm: relative bound on every parameter tensor's gradient norm (110 tensors).  Measured worst case on MI355X: f32 0.47 %,
-# bf16x3 1.18 % (one BatchNorm bias of layer 1 in the batch-size-2 g224 golden; all others < 0.8 %), bf16 21 %.
+# bf16x3 0.75 % (1.18 % with AB_RES_PLANES=0: one BatchNorm bias of layer 1 in the batch-size-2 g224 golden), bf16 21 %.
 PRED_TOL = {"f32": dict(eval=3e-5, train=3e-5, metres=3e-5, logits=2e-4, gsamp=3e-2, gnorm=1e-2),
             "bf16x3": dict(eval=5e-4, train=1e-4, metres=2e-4, logits=3e-3, gsamp=6e-2, gnorm=1.5e-2)}
 
