@@ -397,3 +397,21 @@ def test_bn_apply_x3_with_downsample_bn_residual():
     close(got.cpu(), exact.cpu(), tol=1e-6)
     close(got.cpu(), ref.cpu().double(), tol=1e-6)
     assert torch.equal(got._ab_split.cpu(), K.split(got).cpu())
+
+
+def test_bn_apply_x3_with_residual_as_planes():
+    """relu(bn(y) + (res_hi + res_lo)) (ab_bn_apply_x3_respl) == ab_bn_apply_x3 fed the fp32 tensor hi + lo, bit for bit: a block
+    input that exists only as the planes its producer wrote adds exactly what those planes hold."""
+    from artiboost_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn((2, 9, 7, 256), generator=g).cuda()
+    res = torch.randn((2, 9, 7, 256), generator=g).cuda()
+    bnp = torch.randn((4, 256), generator=g).cuda()
+    pl = K.split(res)
+    held = pl[0].float() + pl[1].float()                  # what the planes hold (2^-17 of res)
+    assert float((held - res).abs().max()) <= 2.0 ** -16 * float(res.abs().max())
+    ref = K.bn_apply_x3(y, bnp, res=held, relu=True, want_f32=True)
+    got = K.bn_apply_x3(y, bnp, res=pl, relu=True, want_f32=True)
+    assert torch.equal(got, ref) and torch.equal(got._ab_split, ref._ab_split)
+    only = K.bn_apply_x3(y, bnp, res=pl, relu=True)       # planes only: no fp32 copy is written
+    assert only.dtype == torch.bfloat16 and torch.equal(only, ref._ab_split)
