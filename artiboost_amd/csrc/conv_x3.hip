@@ -220,17 +220,8 @@ extern "C" int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void
                                   int accumulate, void* stream) {
     if (!x_hi || !x_lo || !dy_hi || !dy_lo || !dw || !workspace) return AB_EINVAL;
     if (kh * kw > 16 || Cin % 64 || Cout % 64) return AB_ESHAPE;
-    {
-        const long Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
-        if ((long)N * Ho * Wo >= X3_WGRAD_MAX_M && N > 1 && !x3_is_c3(kh, kw, stride, pad)) {
-            const int n1 = N / 2;
-            const long xo = (long)n1 * H * W * Cin, yo = (long)n1 * Ho * Wo * Cout;
-            int rc = ab_conv2d_wgrad_x3(x_hi, x_lo, dy_hi, dy_lo, dw, n1, H, W, Cin, Cout, kh, kw, stride, pad, workspace, accumulate, stream);
-            if (rc) return rc;
-            return ab_conv2d_wgrad_x3((const bf16_t*)x_hi + xo, (const bf16_t*)x_lo + xo, (const bf16_t*)dy_hi + yo, (const bf16_t*)dy_lo + yo,
-                                      dw, N - n1, H, W, Cin, Cout, kh, kw, stride, pad, workspace, 1, stream);
-        }
-    }
+    // (same branch order as ab_conv2d_wgrad_x3_workspace: the all-taps 3x3 kernel where it applies, else the generic kernel --
+    // split into half-batches beyond 2^21 output pixels, 3x3/s1 shapes the all-taps kernel declined included)
     hipStream_t st = as_stream(stream);
     const long slab = (long)Cout * kh * kw * Cin;
     if (x3_is_c3(kh, kw, stride, pad)) {
@@ -239,6 +230,17 @@ extern "C" int ab_conv2d_wgrad_x3(const void* x_hi, const void* x_lo, const void
             int rc = wgrad3x3_x3_run(x_hi, x_lo, dy_hi, dy_lo, (float*)workspace, N, H, W, Cin, Cout, st);
             if (rc) return rc;
             return wgrad_launch_reduce((float*)workspace, ns, slab, 9 * Cin, 9 * Cin, dw, accumulate, 0, st);
+        }
+    }
+    {
+        const long Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+        if ((long)N * Ho * Wo >= X3_WGRAD_MAX_M && N > 1) {
+            const int n1 = N / 2;
+            const long xo = (long)n1 * H * W * Cin, yo = (long)n1 * Ho * Wo * Cout;
+            int rc = ab_conv2d_wgrad_x3(x_hi, x_lo, dy_hi, dy_lo, dw, n1, H, W, Cin, Cout, kh, kw, stride, pad, workspace, accumulate, stream);
+            if (rc) return rc;
+            return ab_conv2d_wgrad_x3((const bf16_t*)x_hi + xo, (const bf16_t*)x_lo + xo, (const bf16_t*)dy_hi + yo, (const bf16_t*)dy_lo + yo,
+                                      dw, N - n1, H, W, Cin, Cout, kh, kw, stride, pad, workspace, 1, stream);
         }
     }
     const int M = N * ((H + 2 * pad - kh) / stride + 1) * ((W + 2 * pad - kw) / stride + 1);

@@ -132,14 +132,17 @@ class ManoLayerTorch(nn.Module):
         super().__init__()
         self.ncomps, self.use_pca, self.center_idx = ncomps, use_pca, center_idx
         f = lambda k: torch.from_numpy(np.ascontiguousarray(hand_model[k], np.float32))      # noqa: E731
+        # MANO constants are assets, not learned state: non-persistent, so this layer adds NO keys to the state_dict.  The
+        # reference's checkpoints carry manotorch's own `mano_branch.mano_layer.th_*` buffers (mano.py:24,107 read
+        # `_buffers["th_J_regressor"]`, `th_faces`); HOPRegNet drops those keys on load, the constants come from the assets.
         for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "weights"):
-            self.register_buffer(k, f(k))
+            self.register_buffer(k, f(k), persistent=False)
         hm = np.zeros(45, np.float32) if flat_hand_mean else np.asarray(hand_model["hands_mean"], np.float32)
         comps = hand_model.get("hands_components")
         comps = np.eye(45, dtype=np.float32) if comps is None else np.asarray(comps, np.float32)
-        self.register_buffer("hands_mean", torch.from_numpy(hm))
-        self.register_buffer("comps", torch.from_numpy(comps[:ncomps] if use_pca else np.eye(45, dtype=np.float32)))
-        self.register_buffer("th_faces", torch.from_numpy(np.asarray(hand_model["faces"], np.int64)))
+        self.register_buffer("hands_mean", torch.from_numpy(hm), persistent=False)
+        self.register_buffer("comps", torch.from_numpy(comps[:ncomps] if use_pca else np.eye(45, dtype=np.float32)), persistent=False)
+        self.register_buffer("th_faces", torch.from_numpy(np.asarray(hand_model["faces"], np.int64)), persistent=False)
 
     def forward(self, pose_coeffs, betas=None):
         B = pose_coeffs.shape[0]
@@ -257,7 +260,20 @@ class HOPRegNet(nn.Module):
                 raise FileNotFoundError(f"=> No {type(self).__name__} checkpoints file found in {pretrained}")
             ck = torch.load(pretrained, map_location="cpu")
             sd = ck["state_dict"] if isinstance(ck, dict) and "state_dict" in ck else ck
-            self.load_state_dict({(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}, strict=True)
+            self.load_state_dict(self.clean_reference_state_dict(sd), strict=True)
+
+    MANO_LAYER_PREFIX = "mano_branch.mano_layer."
+
+    @classmethod
+    def clean_reference_state_dict(cls, sd):
+        """Reference checkpoint -> the keys this module owns: the DataParallel `module.` prefix goes, and so do the MANO asset
+        buffers manotorch's ManoLayer persists (`mano_branch.mano_layer.th_*`; hpregnet.py:59-64 loads strictly over them)."""
+        out = {}
+        for k, v in sd.items():
+            k = k[7:] if k.startswith("module.") else k
+            if not k.startswith(cls.MANO_LAYER_PREFIX):
+                out[k] = v
+        return out
 
     def recover_mano(self, feature, samples):
         from .models import ortho6d_to_rotmat  # noqa: F401  (same helper module; kept local to avoid an import cycle)

@@ -201,17 +201,25 @@ class ParamStore:
                 self.stat(name).copy_(clean[name].to(self.device).float())
             else:
                 missing.append(name)
+        # every BatchNorm of the network counts the same training forwards: one host counter stands for all <bn>.num_batches_tracked
+        nbt = [int(v) for k, v in clean.items() if k.endswith(".num_batches_tracked")]
+        if nbt:
+            self.num_batches_tracked = max(nbt)
         if strict and missing:
             raise KeyError(f"missing keys: {missing[:5]}... ({len(missing)})")
         return missing
 
     def reference_state_dict(self, grads=False):
+        """Reference-layout tensors under the reference's keys, in the order of its module tree (a BatchNorm contributes weight,
+        bias, running_mean, running_var, num_batches_tracked): what the reference's load_arch(strict=True) expects."""
         out = OrderedDict()
         for name, e in self.entries.items():
             out[name] = self._to_reference(e, self.view(name, self.grad if grads else None))
-        if not grads:
-            for name in self.buffers:
-                out[name] = self.stat(name).clone()
+            pre = name[:-len(".bias")] if name.endswith(".bias") else None
+            if not grads and pre is not None and pre + ".running_mean" in self.buffers:
+                out[pre + ".running_mean"] = self.stat(pre + ".running_mean").clone()
+                out[pre + ".running_var"] = self.stat(pre + ".running_var").clone()
+                out[pre + ".num_batches_tracked"] = torch.tensor(int(self.num_batches_tracked), dtype=torch.int64)
         return out
 
     def init_reference_like(self, seed=1):
@@ -386,6 +394,12 @@ class HybridNet:
         p, tr, dt = self.p, self.training, self.dtype
         if xpad is None:
             xpad = K.image_pad_nhwc4(image.contiguous().float(), dt)
+        if xpad.dtype != dt:
+            # the stem kernels take ONE dtype code for image and weights: a mismatch would read the weights as the image's type
+            raise TypeError(f"HybridNet({'bf16x3' if self.x3 else dt}) needs the padded image in {dt}, got {xpad.dtype} "
+                            f"(build the loader with compute_dtype=net.dtype)")
+        if tr and not torch.cuda.is_current_stream_capturing():
+            p.num_batches_tracked += 1      # nn.BatchNorm2d's counter (momentum is fixed, so only checkpoints read it); graph replays count themselves
         N = xpad.shape[0]
         H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
         S = {"xpad": xpad, "N": N, "HW": (H, W), "blocks": []}

@@ -75,6 +75,8 @@ class _NetSegment:
         else:
             self.x.copy_(src, non_blocking=True)
         self.fwd.replay()
+        if net.training:
+            net.p.num_batches_tracked += 1
         net.saved, net.last = self.saved, self.last
         self.pending = bool(grad)
         return self.out

@@ -427,8 +427,8 @@ class ArtiBoostLoader:
         if synth_len is None:
             synth_len = int(cfg.get("SYNTH_FACTOR", 0.0) * real_len) if real_len else int(cfg.get("SYNTH_LEN", 0))
         device = kwargs.pop("device", None) or (getattr(arg, "device", None) if arg is not None else None) or "cuda"
-        if batch_size in (None, 1) and arg is not None and getattr(arg, "batch_size", None):
-            batch_size = arg.batch_size
+        if batch_size is None and arg is not None and getattr(arg, "batch_size", None):
+            batch_size = arg.batch_size          # (an explicit batch_size -- 1 included: a rank's share under --batch_size N over N GPUs -- wins)
         self.real_train_set, self.real_len = real_train_set, real_len
         self.shuffle, self.num_workers, self.pin_memory, self.drop_last, self.collat_fn = shuffle, num_workers, pin_memory, drop_last, collate_fn
         self.cfg_dataset = cfg_dataset

@@ -319,6 +319,7 @@ class TrainStep:
             self.crit.draw(self.dev)
             self.opt.advance_hyper()
             self.g_fwd_bwd.replay()
+            self.hb.store.num_batches_tracked += 1           # the replayed forward is a training-mode BatchNorm forward
             if self.split:
                 ranges = self.hb.net.grad_stage_ranges()
                 comm = self.world > 1 or self._fake_comm
@@ -379,7 +380,9 @@ class DeferredEpochMetrics:
                                        st[SynthQueries.IS_SYNTH].to(torch.int64)], 1))
         self.n += 1
 
-    def flush(self, evaluator):
+    def flush(self, evaluator, summarizer=None):
+        """summarizer: also replay the per-step loss scalars into Summarizer.summarize_losses (epoch_pass does that after
+        every TRAIN batch, train_artiboost.py:101-103)."""
         from .metrics import LossesMetric, Mean3DEPE, ValMetricMean3DEPE2
         n = self.n
         epe, losses, ids = self.epe[:n].cpu().numpy(), self.losses[:n].cpu().numpy(), self.ids[:n].cpu().numpy()
@@ -401,4 +404,7 @@ class DeferredEpochMetrics:
             elif isinstance(m, LossesMetric):
                 for s in range(n):
                     m.feed(None, None, losses={k: losses[s, i] for i, k in enumerate(keys)})
+        if summarizer is not None:
+            for s in range(n):
+                summarizer.summarize_losses({k: losses[s, i] for i, k in enumerate(keys)})
         self.n = 0

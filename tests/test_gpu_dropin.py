@@ -122,18 +122,52 @@ def test_train_script_with_the_reference_command_line(tmp_path):
     y = tmp_path / "cfg.yaml"
     y.write_text(yaml.dump(cfg))
     cmd = [sys.executable, os.path.join(ROOT, "train", "train_artiboost.py"), "--cfg", str(y), "--gpu_id", "0", "--gpu_render_id", "0",
-           "--batch_size", "8", "--exp_id", "t", "--snapshot", "1", "--synth_len", "32", "--size", "64"]
+           "--batch_size", "8", "--exp_id", "t", "--snapshot", "1", "--synth_len", "32", "--size", "64", "--test_freq", "2"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("epoch ")]
     assert len(lines) == 2 and "final_loss" in lines[-1] and "hand3d pck" in lines[-1]
+    # the TEST pass of train_artiboost.py:224-240 ran after epoch 1 (--test_freq 2) and left its record
+    tests_ = [l for l in out.stdout.splitlines() if l.startswith("test ")]
+    assert len(tests_) == 1 and "final_loss" in tests_[0]
     exp = [d for d in os.listdir(tmp_path / "exp") if d.startswith("t_")]
     assert len(exp) == 1
+    assert (tmp_path / "exp" / exp[0] / "evaluations" / "test_eval.txt").exists()
     ck = tmp_path / "exp" / exp[0] / "checkpoints" / "checkpoint"
     assert (ck / "HybridBaseline.pth.tar").exists() and (ck / "train_param.pth.tar").exists()
     # resume: nothing left to train (epoch 2 of 2), but every piece must load
     out = subprocess.run(cmd + ["--resume", str(tmp_path / "exp" / exp[0])], capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
+    # --evaluate --resume: ONE test pass, no training, the checkpoint it read is left alone (train_artiboost.py:143-146,207,237-240)
+    before = (ck / "HybridBaseline.pth.tar").read_bytes()
+    out = subprocess.run(cmd + ["--resume", str(tmp_path / "exp" / exp[0]), "--evaluate", "--exp_id", "ev"], capture_output=True, text=True,
+                         timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("epoch ")]
+    assert len([l for l in out.stdout.splitlines() if l.startswith("test ")]) == 1
+    assert (ck / "HybridBaseline.pth.tar").read_bytes() == before
+
+
+def test_train_script_dtype_flag_reaches_the_loader(tmp_path):
+    """`--dtype bf16`: the loader's image buffer must be built in the network's dtype (a mismatch made the stem read bf16 weights
+    as fp32: finite garbage).  One epoch in bf16 trains to a loss in the range of the bf16x3 run on the same seeds."""
+    import re
+    import subprocess
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["TRAIN"]["EPOCH"] = 1
+    y = tmp_path / "cfg.yaml"
+    y.write_text(yaml.dump(cfg))
+    vals = {}
+    for dt in ("bf16x3", "bf16"):
+        cmd = [sys.executable, os.path.join(ROOT, "train", "train_artiboost.py"), "--cfg", str(y),
+               "--gpu_id", "0", "--batch_size", "8", "--exp_id", dt, "--synth_len", "32", "--size", "64", "--dtype", dt, "--no_refiner"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("epoch 0")][0]
+        vals[dt] = float(re.search(r"final_loss[^0-9]*([0-9.eE+-]+)", line).group(1))
+    assert np.isfinite(list(vals.values())).all()
+    assert abs(vals["bf16"] - vals["bf16x3"]) <= 0.05 * vals["bf16x3"], vals
 
 
 def test_train_script_two_ranks_on_a_shared_device(tmp_path):

@@ -14,10 +14,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_full_size_train_steps_match_cpu_oracle():
+@pytest.mark.parametrize("dataset,cfg_name", [("HO3D", "ho3dv2_clasbased_artiboost_mi355x.yaml"),
+                                              ("DexYCB", "dexycb_clasbased_sym_mi355x.yaml")])
+def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name):
     """Two graph-replayed bf16x3 steps of the benchmark workload (render -> forward -> fused criterion -> backward -> clip +
     Adam) vs learner_oracle (torch-CPU fp32 restatement pinned to the reference goldens) fed the images the GPU rendered:
-    every loss term of both steps within 3e-4 relative (step 2 sees step 1's update), the pre-clip gradient norm within 1 %."""
+    every loss term of both steps within 3e-4 relative (step 2 sees step 1's update), the pre-clip gradient norm within 1 %.
+    Two workloads: BASELINE configs[2] (HO3D-like objects, 3 losses) and configs[4] on one GPU (DexYCB-like: 21 objects at 16 k
+    faces, + SymCornerLoss from the DexYCB config, criterions/symcornerloss.py:18-102)."""
     from artiboost_amd import registry as R
     from artiboost_amd.assets import SceneAssets
     from artiboost_amd.criterions import Criterion
@@ -26,15 +30,18 @@ def test_full_size_train_steps_match_cpu_oracle():
     from artiboost_amd.synth import ArtiBoostLoader
     from artiboost_amd.train import TrainStep
     B, size, lr, clip = 64, 256, 5e-5, 0.001
-    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", cfg_name)))
     cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [size, size], [size // 8, size // 8]
     arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16x3", INIT_SEED=3)
     model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
     crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
     hb = model.model_list[0]
     opt = FusedClipAdam(model.models_params, lr=lr, max_norm=clip, model=hb)
-    loader = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], B, 2 * B, compute_dtype=torch.float32,
+    loader = ArtiBoostLoader.from_assets(SceneAssets(dataset, seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], B, 2 * B, compute_dtype=torch.float32,
                                          random_seed=3)
+    sym = next((l for l in crit.loss_list if type(l).__name__ == "SymCornerLoss"), None)
+    assert (sym is not None) == (dataset == "DexYCB")
+    lam = cfg["LAMBDAS"]
     loader.prepare()
     params0 = {k: v.clone() for k, v in hb.state_dict().items()}
     static = loader.new_static_batch()
@@ -42,6 +49,7 @@ def test_full_size_train_steps_match_cpu_oracle():
     model.train()
     ts = TrainStep(model, crit, opt, static, use_graph=True, renderer=loader)
     ts.static = static
+    assert (ts.fused.sym is not None) == (sym is not None)
     # ---- oracle state
     leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in params0.items()}
     names = ms = vs = None
@@ -54,14 +62,21 @@ def test_full_size_train_steps_match_cpu_oracle():
         # the batch the step just trained on, as the oracle's inputs
         xpad = static["image_nhwc4_padded"].float().cpu()
         batch = {"image": xpad[:, 3:3 + size, 3:3 + size, :3].permute(0, 3, 1, 2).contiguous()}
-        for k in ("root_joint", "cam_intr", "corners_can", "joints_3d", "corners_3d", "joints_vis", "corners_vis"):
+        for k in ("root_joint", "cam_intr", "corners_can", "joints_3d", "corners_3d", "joints_vis", "corners_vis", "obj_transf"):
             batch[k] = static[k].float().cpu()
+        batch["obj_idx"] = static["obj_idx"].cpu()
         for v in leaf.values():
             if getattr(v, "grad", None) is not None:
                 v.grad = None
         random.seed(100 + step); torch.manual_seed(100 + step)
         preds = lo.hybrid_forward(leaf, batch, [size, size], 22, 28, 0, training=True)
-        total, ref, _ = lo.criterion(preds, batch)
+        total, ref, _ = lo.criterion(preds, batch, lambdas=lam[:3])
+        if sym is not None:      # Criterion.compute_losses adds LAMBDAS[3] * (LAMBDA_SYM_CORNERS_3D * loss) (criterion.py:57-67)
+            sref = lo.sym_corner_loss(preds, batch, sym.R.cpu(), sym.t.cpu())
+            total = total + lam[3] * float(sym.lambda_sym_corners_3d) * sref
+            ref = dict(ref, final_loss=total)
+            got["sym_corners_3d_loss"] = float(ts.fused.losses_dict()["sym_corners_3d_loss"])
+            assert abs(got["sym_corners_3d_loss"] - float(sref)) <= 3e-4 * abs(float(sref)) + 1e-9, (step, got["sym_corners_3d_loss"], float(sref))
         total.backward()
         if names is None:
             names = [k for k, v in leaf.items() if v.dtype.is_floating_point and getattr(v, "grad", None) is not None]

@@ -66,8 +66,9 @@ def test_learner_step_matches_reference_golden(golden_dir):
     assert float(st.view("hybrid_head.final_layer.weight").reshape(22, 32, 256)[:, 28:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("graph", [False, True])
-def test_checkpoint_resume_is_bit_exact(graph, tmp_path):
+def test_checkpoint_resume_is_bit_exact(graph, dtype, tmp_path):
     """Model state_dict (the reference's keys) + optimizer state_dict saved after 3 steps and loaded into fresh objects:
     the following steps equal those of the uninterrupted run bit for bit (Adam moments, step count / bias corrections)."""
     import random
@@ -84,7 +85,7 @@ def test_checkpoint_resume_is_bit_exact(graph, tmp_path):
     batches = [{k: v.cuda() for k, v in make_batch(4, 64, 50 + i).items()} for i in range(6)]
 
     def fresh():
-        arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16", INIT_SEED=3)
+        arch = dict(cfg["ARCH"], COMPUTE_DTYPE=dtype, INIT_SEED=3)
         model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
         crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
         hb = model.model_list[0]
@@ -103,6 +104,8 @@ def test_checkpoint_resume_is_bit_exact(graph, tmp_path):
     model, crit, hb, opt = fresh()
     ts = TrainStep(model, crit, opt, {k: v.clone() for k, v in batches[0].items()}, use_graph=graph)
     run(ts, 0, 3)
+    # <bn>.num_batches_tracked counts training forwards, graph replays included (the capture warm-up is undone)
+    assert int(hb.state_dict()["backbone.layer3.2.bn1.num_batches_tracked"]) == 3
     torch.save({"model": hb.state_dict(), "optimizer": opt.state_dict()}, tmp_path / "ckpt.pth.tar")
     tail_ref = run(ts, 3, 6)
     w_ref = hb.store.flat.detach().cpu().numpy().copy()
@@ -116,7 +119,8 @@ def test_checkpoint_resume_is_bit_exact(graph, tmp_path):
     np.testing.assert_array_equal(hb2.store.flat.detach().cpu().numpy(), w_ref)
 
 
-def test_graph_replay_equals_eager_from_the_first_step():
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
+def test_graph_replay_equals_eager_from_the_first_step(dtype):
     """The capture warm-up is undone (weights, running stats, Adam state, RNG): graph and eager runs are the same updates."""
     import random
     import yaml
@@ -133,7 +137,7 @@ def test_graph_replay_equals_eager_from_the_first_step():
     res = []
     for graph in (False, True):
         random.seed(9); torch.manual_seed(9); np.random.seed(9)
-        arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16", INIT_SEED=3)
+        arch = dict(cfg["ARCH"], COMPUTE_DTYPE=dtype, INIT_SEED=3)
         model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
         crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
         hb = model.model_list[0]

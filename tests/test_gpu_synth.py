@@ -106,7 +106,15 @@ def test_loader_batches_match_oracle_render():
         np.testing.assert_allclose(uv, batch["joints_2d"].cpu().numpy(), atol=0.6)   # int-truncated crop centre -> sub-pixel slack
 
 
-def test_end_to_end_train_steps_decrease_loss():
+DTYPES = ["bf16x3", "bf16"]          # the benchmarked precision first; one reduced-precision case each
+
+
+def _ldt(dtype):
+    return torch.bfloat16 if dtype == "bf16" else torch.float32
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_end_to_end_train_steps_decrease_loss(dtype):
     """render -> forward -> fused loss -> backward -> clip/Adam for a few graph-replayed steps: finite, loss moves."""
     import yaml, os
     from artiboost_amd import registry as R
@@ -114,10 +122,10 @@ def test_end_to_end_train_steps_decrease_loss():
     from artiboost_amd.models import Arch
     from artiboost_amd.optim import FusedClipAdam
     from artiboost_amd.train import TrainStep
-    assets, loader = _loader(torch.bfloat16, bs=8, n=32, size=224)
+    assets, loader = _loader(_ldt(dtype), bs=8, n=32, size=224)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
-    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16")
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE=dtype)
     model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
     crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
     hb = model.model_list[0]
@@ -138,8 +146,9 @@ def test_end_to_end_train_steps_decrease_loss():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mode", [True, "opt"])
-def test_pipelined_render_hands_over_next_batch(mode):
+def test_pipelined_render_hands_over_next_batch(mode, dtype):
     """Pipelined TrainStep: step i learns from batch i while batch i+1 is rendered on the side stream; the image handed
     to the next step must be bit-identical to an inline render of that batch."""
     import yaml, os
@@ -148,10 +157,10 @@ def test_pipelined_render_hands_over_next_batch(mode):
     from artiboost_amd.models import Arch
     from artiboost_amd.optim import FusedClipAdam
     from artiboost_amd.train import TrainStep
-    assets, loader = _loader(torch.bfloat16, bs=8, n=32, size=224)
+    assets, loader = _loader(_ldt(dtype), bs=8, n=32, size=224)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
-    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16")
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE=dtype)
     model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
     crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
     hb = model.model_list[0]
@@ -243,8 +252,9 @@ def test_two_rank_ddp_step_keeps_weights_identical():
     assert "weights_identical_across_ranks=True" in r.stdout
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("graph", [False, True])
-def test_train_step_with_symcorner_loss(graph):
+def test_train_step_with_symcorner_loss(graph, dtype):
     """A criterion list containing SymCornerLoss (DexYCB-style configs, symcornerloss.py:18-102) runs through the fused
     pose/loss kernel (ab_pose_loss_sym), eagerly and as replayed hipGraphs, and trains."""
     import yaml, os
@@ -253,7 +263,7 @@ def test_train_step_with_symcorner_loss(graph):
     from artiboost_amd.models import Arch
     from artiboost_amd.optim import FusedClipAdam
     from artiboost_amd.train import TrainStep
-    assets, loader = _loader(torch.bfloat16, bs=8, n=16, size=224)
+    assets, loader = _loader(_ldt(dtype), bs=8, n=16, size=224)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
     nobj = 21
@@ -262,7 +272,7 @@ def test_train_step_with_symcorner_loss(graph):
     cfg["CRITERION"] = cfg["CRITERION"] + [{"TYPE": "SymCornerLoss", "LAMBDA_SYM_CORNERS_3D": 1.0, "MODEL_INFO": info,
                                             "MAX_SYM_DISC_STEP": 0.2}]
     cfg["LAMBDAS"] = cfg["LAMBDAS"] + [0.3]
-    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16")
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE=dtype)
     model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
     crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
     hb = model.model_list[0]
@@ -283,7 +293,8 @@ def test_train_step_with_symcorner_loss(graph):
     assert vals[-1] < vals[0], vals
 
 
-def test_deferred_epoch_metrics_equal_per_step_feeding():
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_deferred_epoch_metrics_equal_per_step_feeding(dtype):
     """DeferredEpochMetrics (one transfer per epoch) == evaluator.feed_all after every batch (train_artiboost.py:96-98)."""
     import copy, os, yaml
     from artiboost_amd import registry as R
@@ -292,11 +303,11 @@ def test_deferred_epoch_metrics_equal_per_step_feeding():
     from artiboost_amd.models import Arch
     from artiboost_amd.optim import FusedClipAdam
     from artiboost_amd.train import DeferredEpochMetrics, TrainStep
-    assets, loader = _loader(torch.bfloat16, bs=8, n=32, size=64)
+    assets, loader = _loader(_ldt(dtype), bs=8, n=32, size=64)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
     cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [64, 64], [8, 8]
-    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16")
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE=dtype)
     model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
     crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
     ev_a = Evaluator(cfg, R.build_evaluator_metric_list(cfg["EVALUATOR"], preset_cfg=cfg["DATA_PRESET"]))

@@ -55,8 +55,12 @@ def test_param_store_roundtrip_and_layouts():
     params = lo.fill_params(lo.param_shapes(22, 28), seed=3)
     st.load_reference_state_dict({"_model_list.0." + k: v for k, v in params.items()})
     back = st.reference_state_dict()
+    # the reference's resume is load_arch(strict=True): same keys in the same order, <bn>.num_batches_tracked (int64 scalars) included
+    assert list(back) == [k for k, _ in lo.param_shapes(22, 28)]
+    nbt = max(int(v) for k, v in params.items() if k.endswith("num_batches_tracked"))
     for k, v in params.items():
         if k.endswith("num_batches_tracked"):
+            assert back[k].dtype == torch.int64 and back[k].shape == () and int(back[k]) == nbt == st.num_batches_tracked
             continue
         np.testing.assert_array_equal(back[k].numpy(), v.numpy(), err_msg=k)
     # layout spot checks: OHWI, padded stem, padded depth, padded box head

@@ -129,3 +129,32 @@ def test_submit_reload_script_with_the_reference_command_line(tmp_path):
     xyz, verts = json.load(open(os.path.join(exp, js[0])))
     assert len(xyz) == 12 and len(xyz[0]) == 21 and len(verts[0]) == 778
     assert os.path.exists(os.path.join(exp, "evaluations", "test_eval.txt"))
+
+
+def test_reference_checkpoint_key_set_loads_strictly(tmp_path, golden_dir):
+    """The reference's regbased checkpoint is read with strict=True (hpregnet.py:59-64): HOPRegNet must own exactly the reference
+    module's keys (tests/golden/hpregnet_keys.json: state_dict names + shapes of the reference's own HOPRegNet, built by
+    oracle/gen_hpregnet_keys.py) apart from manotorch's persisted MANO asset buffers `mano_branch.mano_layer.th_*`, which are
+    dropped on load -- and a checkpoint carrying them (+ DataParallel's `module.` prefix) must load through ARCH.PRETRAINED."""
+    from artiboost_amd import hpregnet
+    keys = json.load(open(os.path.join(golden_dir, "hpregnet_keys.json")))
+    pre = hpregnet.HOPRegNet.MANO_LAYER_PREFIX
+    for bb in ("ResNet18", "ResNet34"):
+        cfg = {"TYPE": "HOPRegNet", "PRETRAINED": "", "BACKBONE": {"TYPE": bb, "PRETRAINED": False, "FREEZE_BATCHNORM": False},
+               "HEAD": {"TYPE": "ManoBranch", "INPUT_DIM": 512, "NCOMPS": 15, "USE_PCA": True, "USE_SHAPE": True, "MANO_ASSETS_ROOT": "assets/mano_v1_2"},
+               "DATA_PRESET": {"IMAGE_SIZE": [224, 224], "CENTER_IDX": 9}}
+        torch.manual_seed(0)
+        net = hpregnet.HOPRegNet(**cfg)
+        ours = {k: list(v.shape) for k, v in net.state_dict().items()}
+        ref = {k: s for k, s in keys[bb].items() if not k.startswith(pre)}
+        assert any(k.startswith(pre + "th_") for k in keys[bb])           # the reference checkpoint does carry them
+        assert ours == ref, (sorted(set(ours) ^ set(ref))[:8])
+        # a reference-shaped checkpoint: every reference key (MANO buffers included), `module.` prefix, seeded values
+        g = torch.Generator().manual_seed(1)
+        sd = {"module." + k: (torch.randn(s, generator=g) if "num_batches" not in k and "th_faces" not in k else torch.zeros(s, dtype=torch.long))
+              for k, s in keys[bb].items()}
+        path = str(tmp_path / f"{bb}.pth.tar")
+        torch.save({"state_dict": sd}, path)
+        net2 = hpregnet.HOPRegNet(**dict(cfg, PRETRAINED=path))
+        for k, v in net2.state_dict().items():
+            assert torch.equal(v, sd["module." + k]), k

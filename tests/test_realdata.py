@@ -157,7 +157,8 @@ def test_mixed_loader_batches():
 
 
 @pytest.mark.gpu
-def test_graph_replayed_training_step_over_mixed_batches():
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
+def test_graph_replayed_training_step_over_mixed_batches(dtype):
     """TrainStep (hipGraph replay, renderer=None) fed with MixedLoader batches: the same step as epoch_pass over the mixed
     loader (train_artiboost.py:66-96); replay is deterministic and the loss is finite on real + synthetic rows."""
     import random
@@ -173,6 +174,7 @@ def test_graph_replayed_training_step_over_mixed_batches():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = GoldenSource()
     B, size = 8, 64
+    cdt = torch.bfloat16 if dtype == "bf16" else torch.float32
 
     def run(use_graph):
         random.seed(5); torch.manual_seed(5); np.random.seed(5)
@@ -180,10 +182,10 @@ def test_graph_replayed_training_step_over_mixed_batches():
         cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
         cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [size, size], [size // 8, size // 8]
         n_synth = MixedLoader.n_synth_for(B, len(src), proto.synth_len)
-        synth = ArtiBoostLoader.from_assets(assets, proto.cfg, cfg["DATA_PRESET"], n_synth, proto.synth_len, compute_dtype=torch.bfloat16, random_seed=3)
+        synth = ArtiBoostLoader.from_assets(assets, proto.cfg, cfg["DATA_PRESET"], n_synth, proto.synth_len, compute_dtype=cdt, random_seed=3)
         synth.prepare()
-        ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.bfloat16, seed=2), synth, B, seed=4)
-        arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16", INIT_SEED=3)
+        ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=cdt, seed=2), synth, B, seed=4)
+        arch = dict(cfg["ARCH"], COMPUTE_DTYPE=dtype, INIT_SEED=3)
         model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
         crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
         hb = model.model_list[0]

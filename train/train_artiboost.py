@@ -155,47 +155,101 @@ def main():
     loader = ArtiBoostLoader(train_data, arg=arg, arg_extra=arg_extra, cfg=cfg["MANAGER"], cfg_dataset=cfg["DATASET"],
                              cfg_preset=cfg["DATA_PRESET"], time_f=time_f, batch_size=per_rank, shuffle=True,
                              num_workers=int(arg.workers), pin_memory=True, drop_last=arg.drop_last, collate_fn=ho_collate,
-                             random_seed=seed, rank=rank, world_size=world)
+                             random_seed=seed, rank=rank, world_size=world,
+                             compute_dtype=getattr(getattr(model.model_list[0], "net", None), "dtype", torch.float32))
     epoch0 = 0
     if arg.resume:
         epoch0 = recorder.resume_checkpoints(model, optimizer, scheduler, arg.resume, resume_epoch=arg.resume_epoch or None)
         recorder.resume_artiboost_loader(loader, epoch0, arg.resume)
 
-    ts = rec = None
-    for epoch_idx in range(epoch0, cfg["TRAIN"]["EPOCH"]):
-        loader.prepare()
-        if len(loader) == 0:
-            raise SystemExit("empty epoch: SYNTH_LEN / the real set give fewer samples than one batch per rank")
-        model.train()
+    # ---- the TEST pass of the reference (train_artiboost.py:112-122,224-240): eval-mode epoch over DATASET.TEST every
+    # --test_freq epochs, and once (then exit) under --evaluate.  HO3D / DexYCB are downloads: when the real test set is absent
+    # the pass runs over a VAL-mode synthetic epoch instead (OVGSet.val(), ovg_set.py:108-118: uniform over the admissible CCV
+    # triplets, no augmentation re-weighting) and says so in its record.
+    test_data = builder.build_dataset(cfg["DATASET"]["TEST"], preset_cfg=cfg["DATA_PRESET"])
+    test_state = {}
+
+    def test_pass(epoch_idx):
+        model.eval()
         evaluator.reset_all()
-        if ts is None:
-            static = loader.new_static_batch()
-            loader.load_batch(static, 0)
-            ts = TrainStep(model, criterion, optimizer, static, use_graph=True, renderer=loader,
-                           dist_group=torch.distributed.group.WORLD if world > 1 else None,
-                           pipeline_render="opt" if world > 1 else False)
-            rec = DeferredEpochMetrics(ts, len(loader), evaluator) if ts.fused is not None else None
-        t0 = time.time()
-        ts.prime(loader, 0)
-        for bi in range(len(loader)):
-            ts.stage(loader, bi)
-            preds, losses, _ = ts()
-            if rec is not None:
-                rec.collect()
+        n = 0
+        with torch.no_grad():
+            if len(test_data) > 0:
+                from artiboost_amd.realdata import RealBatcher
+                if "real" not in test_state:
+                    test_state["real"] = RealBatcher(test_data, cfg["DATA_PRESET"], aug=False, device=dev, compute_dtype=loader.dtype, seed=seed)
+                rb = test_state["real"]
+                idxs = np.random.permutation(len(test_data))[rank::world]        # shuffle=True, drop_last=False (train_artiboost.py:113-121)
+                source = (rb.batch(idxs[i:i + per_rank].tolist()) for i in range(0, len(idxs), per_rank))
+                what = f"{len(test_data)} frames of DATASET.TEST ({cfg['DATASET']['TEST']['TYPE']})"
             else:
-                evaluator.feed_all(ts.predictions(), ts.static, losses)
-        if rec is not None:
-            rec.flush(evaluator)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
-        scheduler.step()
-        loader.step_eval(epoch_idx=epoch_idx, evaluator=evaluator)
-        recorder.record_checkpoints(model, optimizer, scheduler, epoch_idx, arg.snapshot)
-        recorder.record_evaluator(evaluator, epoch_idx, TrainMode.TRAIN)
-        summarizer.summarize_evaluator(evaluator, epoch_idx, train_mode=TrainMode.TRAIN)
-        recorder.record_artiboost_loader(loader, epoch_idx)
+                saved = loader.epoch, loader.cursor, loader.synth_len
+                admissible = int((~loader.blacklist_map).sum())
+                loader.synth_len = min(loader.synth_len, admissible // (per_rank * world) * per_rank * world)
+                loader.prepare(is_train=False)
+                source = iter(loader)                                             # rendered batches with the reference's keys, one at a time
+                what = (f"DATASET.TEST ({cfg['DATASET']['TEST']['TYPE']}) is absent (a download): {len(loader) * per_rank} synthetic "
+                        f"val-mode CCV samples per rank instead")
+            for batch in source:
+                pd = model(batch)
+                predicts = {}
+                for key in pd:
+                    predicts.update(pd[key])
+                _, losses = criterion.compute_losses(predicts, batch)
+                evaluator.feed_all(predicts, batch, losses)
+                n += int(batch["root_joint"].shape[0])
+            if len(test_data) == 0:
+                loader.epoch, loader.cursor, loader.synth_len = saved
+        recorder.record_evaluator(evaluator, epoch_idx, TrainMode.TEST)
+        summarizer.summarize_evaluator(evaluator, epoch_idx, train_mode=TrainMode.TEST)
         if rank == 0:
-            print(f"epoch {epoch_idx}: {len(loader) * per_rank * world / dt:8.0f} samples/s on {world} GPU(s) | {evaluator}", flush=True)
+            print(f"test  {epoch_idx}: {n} samples per rank | {what} | {evaluator}", flush=True)
+
+    n_epochs = cfg["TRAIN"]["EPOCH"]
+    if arg.evaluate:
+        n_epochs = max(epoch0, 0) + 1             # "enter into the train loop" once (train_artiboost.py:144-145)
+        epoch0 = n_epochs - 1
+    ts = rec = None
+    for epoch_idx in range(epoch0, n_epochs):
+        if not arg.evaluate:
+            loader.prepare()
+            if len(loader) == 0:
+                raise SystemExit("empty epoch: SYNTH_LEN / the real set give fewer samples than one batch per rank")
+            model.train()
+            evaluator.reset_all()
+            if ts is None:
+                static = loader.new_static_batch()
+                loader.load_batch(static, 0)
+                ts = TrainStep(model, criterion, optimizer, static, use_graph=True, renderer=loader,
+                               dist_group=torch.distributed.group.WORLD if world > 1 else None,
+                               pipeline_render="opt" if world > 1 else False)
+                rec = DeferredEpochMetrics(ts, len(loader), evaluator) if ts.fused is not None else None
+            t0 = time.time()
+            ts.prime(loader, 0)
+            for bi in range(len(loader)):
+                ts.stage(loader, bi)
+                preds, losses, _ = ts()
+                if rec is not None:
+                    rec.collect()
+                else:
+                    evaluator.feed_all(ts.predictions(), ts.static, losses)
+                    summarizer.summarize_losses(ts.fused.losses_dict() if ts.fused is not None else losses)
+            if rec is not None:
+                rec.flush(evaluator, summarizer=summarizer)      # per-step loss scalars (epoch_pass: summarizer.summarize_losses) from the records
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            scheduler.step()
+            loader.step_eval(epoch_idx=epoch_idx, evaluator=evaluator)
+            recorder.record_checkpoints(model, optimizer, scheduler, epoch_idx, arg.snapshot)
+            recorder.record_evaluator(evaluator, epoch_idx, TrainMode.TRAIN)
+            summarizer.summarize_evaluator(evaluator, epoch_idx, train_mode=TrainMode.TRAIN)
+            recorder.record_artiboost_loader(loader, epoch_idx)
+            if rank == 0:
+                print(f"epoch {epoch_idx}: {len(loader) * per_rank * world / dt:8.0f} samples/s on {world} GPU(s) | {evaluator}", flush=True)
+        if arg.evaluate or (arg.test_freq > 0 and epoch_idx % arg.test_freq == arg.test_freq - 1):
+            test_pass(epoch_idx)
+            if arg.evaluate:
+                break
     if world > 1:
         torch.distributed.destroy_process_group()
 
