@@ -1,6 +1,10 @@
-"""ctypes binding of libartiboost_hip.so (the C ABI declared in include/artiboost_hip.h).
+"""Binding of libartiboost_hip.so (the C ABI declared in include/artiboost_hip.h).
 
-The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is raised."""
+Default: through the PyTorch dispatcher -- `lib().ab_xxx(...)` calls `torch.ops.artiboost_hip.xxx` (libartiboost_torch.so: one
+TORCH_LIBRARY registration per entry point, generated from the header by gen_torch_ops.py; tensors in, current HIP stream inside).
+AB_BINDING=ctypes calls the same entry points through ctypes instead (A/B of the binding cost; same library, same kernels).
+
+The product path has NO fallback: if a library is missing or a call fails, a RuntimeError is raised."""
 import ctypes
 import os
 import re
@@ -10,12 +14,16 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ARTIBOOST_HIP_LIB selects another build of the same library (A/B timing of kernel changes); still no CPU fallback
 LIB_PATH = os.environ.get("ARTIBOOST_HIP_LIB") or os.path.join(HERE, "libartiboost_hip.so")
+TORCH_LIB_PATH = os.path.join(HERE, "libartiboost_torch.so")
 HEADER = os.path.join(HERE, "..", "include", "artiboost_hip.h")
+BINDING = os.environ.get("AB_BINDING", "ctypes" if os.environ.get("ARTIBOOST_HIP_LIB") else "torch")
 
 _lib = None
+_cdll = None
 
 DT_F32, DT_BF16 = 0, 1
 _DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16}
+_STREAM = object()          # placeholder for the trailing `void* stream` argument (see stream())
 
 
 def declared_symbols():
@@ -31,16 +39,90 @@ def _long_symbols():
     return set(re.findall(r"\blong\s+(ab_\w+)\s*\(", txt))
 
 
+def cdll():
+    """The raw shared library (symbol checks, the ctypes binding)."""
+    global _cdll
+    if _cdll is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m artiboost_amd.build` (there is no CPU fallback)")
+        _cdll = ctypes.CDLL(LIB_PATH)
+        longs = _long_symbols()
+        for name in declared_symbols():
+            fn = getattr(_cdll, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = ctypes.c_long if name in longs else ctypes.c_int
+    return _cdll
+
+
+def _host_bytes(a):
+    """ctypes Structure / array / byref(...) -> CPU uint8 tensor over the SAME memory (host structs of the C ABI)."""
+    if hasattr(a, "_obj"):
+        a = a._obj
+    return torch.frombuffer(a, dtype=torch.uint8)
+
+
+class _TorchOps:
+    """lib().ab_xxx(args..., stream()) -> torch.ops.artiboost_hip.xxx(args...)."""
+
+    def __init__(self):
+        if not os.path.exists(TORCH_LIB_PATH):
+            raise RuntimeError(f"{TORCH_LIB_PATH} is missing: run `python -m artiboost_amd.build` (there is no CPU fallback)")
+        cdll()                                   # fail loudly on a missing / incomplete libartiboost_hip.so first
+        torch.ops.load_library(TORCH_LIB_PATH)
+        self._ns = torch.ops.artiboost_hip
+
+    def __getattr__(self, name):
+        op = getattr(self._ns, name[3:])
+
+        def call(*args):
+            conv = []
+            for a in args:
+                if a is _STREAM:
+                    continue
+                if a is None or isinstance(a, (torch.Tensor, int, float)):
+                    conv.append(a)
+                elif isinstance(a, ctypes.c_void_p):
+                    raise TypeError(f"{name}: raw pointer argument (pass the tensor: _lib.ptr returns it)")
+                else:
+                    conv.append(_host_bytes(a))
+            r = op(*conv)
+            return 0 if r is None else r
+        self.__dict__[name] = call
+        return call
+
+
+class _Ctypes:
+    """The same call convention on ctypes (AB_BINDING=ctypes)."""
+
+    def __init__(self):
+        from . import gen_torch_ops
+        self._c = cdll()
+        self._sig = {name: params for _, name, params in gen_torch_ops.declarations()}
+
+    def __getattr__(self, name):
+        fn, params = getattr(self._c, name), self._sig[name]
+
+        def call(*args):
+            conv = []
+            for a, (ty, _) in zip(args, params):
+                if a is _STREAM:
+                    conv.append(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                elif ty.endswith("*"):
+                    conv.append(ctypes.c_void_p(a.data_ptr()) if isinstance(a, torch.Tensor) else (ctypes.c_void_p(0) if a is None else a))
+                elif ty == "float":
+                    conv.append(ctypes.c_float(a))
+                elif ty == "long":
+                    conv.append(ctypes.c_long(a))
+                else:
+                    conv.append(ctypes.c_int(a))
+            return fn(*conv)
+        self.__dict__[name] = call
+        return call
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m artiboost_amd.build` (there is no CPU fallback)")
-        _lib = ctypes.CDLL(LIB_PATH)
-        longs = _long_symbols()
-        for name in declared_symbols():
-            fn = getattr(_lib, name)  # AttributeError if a declared symbol is not exported
-            fn.restype = ctypes.c_long if name in longs else ctypes.c_int
+        _lib = _TorchOps() if BINDING == "torch" else _Ctypes()
     return _lib
 
 
@@ -52,34 +134,49 @@ def dt(t: torch.Tensor) -> int:
 
 
 def ptr(t):
+    """A device buffer argument: the tensor itself (None = NULL), checked."""
     if t is None:
-        return ctypes.c_void_p(0)
+        return None
     if not t.is_cuda:
         raise RuntimeError("artiboost_hip ops need device tensors (HIP); got a CPU tensor")
     if not t.is_contiguous():
         raise RuntimeError("artiboost_hip ops need contiguous tensors")
-    return ctypes.c_void_p(t.data_ptr())
+    return t
+
+
+def view_ptr(t):
+    """A (possibly row-pitched) device view whose pitch is passed separately: no contiguity check."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("artiboost_hip ops need device tensors (HIP); got a CPU tensor")
+    return t
+
+
+def addr(t):
+    """Device address for a field of a host-side struct of the C ABI (ab_symcorner, ab_scene)."""
+    return ctypes.c_void_p(ptr(t).data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _STREAM
 
 
 def check(rc, what):
-    if rc != 0:
+    if rc:
         raise RuntimeError(f"{what} failed with code {rc}" + (" (hipError)" if rc > 0 else " (argument error)"))
 
 
 def f(x):
-    return ctypes.c_float(float(x))
+    return float(x)
 
 
 def i(x):
-    return ctypes.c_int(int(x))
+    return int(x)
 
 
 def l(x):
-    return ctypes.c_long(int(x))
+    return int(x)
 
 
 class WgradReduceDesc(ctypes.Structure):

@@ -10,6 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libartiboost_hip.so")
+TORCH_LIB = os.path.join(HERE, "libartiboost_torch.so")      # the same entry points as torch.ops.artiboost_hip.* (gen_torch_ops.py)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
 
@@ -47,7 +48,36 @@ def build(force=False, verbose=False):
     if force or procs or _stale(LIB, objs):
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         subprocess.check_call(cmd)
+    build_torch_ops(force=force, verbose=verbose)
     return LIB
+
+
+def build_torch_ops(force=False, verbose=False):
+    """libartiboost_torch.so: TORCH_LIBRARY(artiboost_hip) registrations over the C ABI (one generated translation unit, host
+    compiler + torch headers; links libartiboost_hip.so by $ORIGIN so both travel together in-tree)."""
+    import torch
+    from torch.utils import cpp_extension as ce
+    from . import gen_torch_ops
+    src, _ = gen_torch_ops.generate()
+    hdr = os.path.join(HERE, "..", "include", "artiboost_hip.h")
+    if not (force or _stale(TORCH_LIB, [src, hdr, LIB])):
+        return TORCH_LIB
+    try:
+        inc = ce.include_paths(device_type="cuda")
+    except TypeError:
+        inc = ce.include_paths(True)
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = (["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)] + ["-I" + i for i in inc] + ["-I/opt/rocm/include"] +
+           [src, "-o", TORCH_LIB, "-L" + libdir, "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_hip", "-lc10_hip", "-L" + HERE, "-lartiboost_hip",
+            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + libdir])
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout.decode())
+        raise RuntimeError("g++ failed on torch_ops_gen.cpp")
+    return TORCH_LIB
 
 
 if __name__ == "__main__":

@@ -524,8 +524,8 @@ class FusedPoseCriterion:
             obj = t(Queries.OBJ_IDX)
             if obj.dtype != torch.int64:
                 raise TypeError("obj_idx must be int64")
-            self._sym_struct = L.SymCorner(L.ptr(Rd), L.ptr(td), int(Rd.shape[1]), L.ptr(obj), L.ptr(t(Queries.OBJ_TRANSF)),
-                                           float(self.sym.lambda_sym_corners_3d), float(self.sym_weight), L.ptr(o["sym_loss"]))
+            self._sym_struct = L.SymCorner(L.addr(Rd), L.addr(td), int(Rd.shape[1]), L.addr(obj), L.addr(t(Queries.OBJ_TRANSF)),
+                                           float(self.sym.lambda_sym_corners_3d), float(self.sym_weight), L.addr(o["sym_loss"]))
             symp = ctypes.byref(self._sym_struct)
         L.check(L.lib().ab_pose_loss_sym(
             L.ptr(kp3d), L.ptr(box6d_buf), L.i(box_stride), L.ptr(t(Queries.ROOT_JOINT)), L.ptr(t(Queries.CAM_INTR)),

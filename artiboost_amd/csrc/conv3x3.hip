@@ -27,6 +27,9 @@ struct Conv3Args {
     int tiles_x, tiles_y;    // tiles per image
     // optional fused BatchNorm-backward reduction over the OUTPUT of this (data-gradient) launch: see ab_conv2d_dgrad_bnstats
     const void* bn_y; const void* bn_out; const float* bnp; float* bn_part;
+    // X3 = 3 (eval-mode forward with the BatchNorm that follows folded in): Out / Out_lo are the (hi, lo) planes of
+    // relu?(acc * bnp[c] + bnp[Cn + c] + residual); residual = res_hi + res_lo planes, or the fp32 `addend`; OutF (optional) = the fp32 value
+    void* Out_lo; const void* res_hi; const void* res_lo; float* OutF; int ep_relu;
     int flip;                // 0: tap t reads input (t/3-1, t%3-1); 1 (data gradient): (1-t/3, 1-t%3).  Weight K offset = t*C.
 };                           // (no per-tap tables: a dynamically indexed kernarg array becomes a VMEM load inside the K loop,
                              //  and the vmcnt wait for it would drain the in-flight LDS-DMA prefetch)
@@ -50,6 +53,11 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsig
 // tile in bn_part -- the standalone reduction pass over (dout, y, mask) disappears.  The tile of bn_y (and of the mask
 // plane / the addend) this thread will need is requested at kernel entry and sits in registers while the K loop runs,
 // so the epilogue adds arithmetic only (exposed reads at the end of a workgroup were what made the bf16 variant lose).
+//
+// X3 = 3: X3 forward launch in EVAL mode: BatchNorm's (scale, shift) are known before the launch (running statistics), so the
+// epilogue applies them, adds the residual, applies the ReLU and writes the next convolution's operand planes directly -- with
+// the same expression order as bn_apply_x3_kernel (norm_pool.hip), i.e. bit-identical to conv + separate apply pass.  The fp32
+// conv output is never stored (no BatchNorm partials either).
 template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
     constexpr bool BNR = X3 == 2;
@@ -310,6 +318,46 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         constexpr int CPRF = BN / 4;                          // 16-byte chunks (4 channels) per tile row
         static_assert(NT % CPRF == 0, "a thread keeps one channel group over all its rows");
         float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (X3 == 3) {
+            bf16_t* __restrict__ OutHi = (bf16_t*)g.Out;
+            bf16_t* __restrict__ OutLo = (bf16_t*)g.Out_lo;
+            const bf16_t* __restrict__ RH = (const bf16_t*)g.res_hi;
+            const bf16_t* __restrict__ RL = (const bf16_t*)g.res_lo;
+            const int c4 = tid % CPRF, col = n0 + c4 * 4;               // NT % CPRF == 0: a thread keeps its channel group
+            const bool cok = col < g.Cn;
+            float sc[4], sh[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sc[k] = cok ? g.bnp[col + k] : 0.f; sh[k] = cok ? g.bnp[g.Cn + col + k] : 0.f; }
+            for (int row = tid / CPRF; row < BM; row += NT / CPRF) {
+                const int yy = ty0 + row / TW, xx = tx0 + row % TW;
+                if (yy < g.H && xx < g.W && cok) {
+                    const float4 v4 = *(const float4*)(smem + row * SPF + c4 * 16);
+                    const long o = (((long)img * g.H + yy) * g.W + xx) * g.Cn + col;
+                    float v[4] = {v4.x * sc[0] + sh[0], v4.y * sc[1] + sh[1], v4.z * sc[2] + sh[2], v4.w * sc[3] + sh[3]};
+                    if (RH) {
+                        const uint2 h2 = *(const uint2*)(RH + o), l2 = *(const uint2*)(RL + o);
+                        v[0] += __uint_as_float(h2.x << 16) + __uint_as_float(l2.x << 16);
+                        v[1] += __uint_as_float(h2.x & 0xffff0000u) + __uint_as_float(l2.x & 0xffff0000u);
+                        v[2] += __uint_as_float(h2.y << 16) + __uint_as_float(l2.y << 16);
+                        v[3] += __uint_as_float(h2.y & 0xffff0000u) + __uint_as_float(l2.y & 0xffff0000u);
+                    } else if (AddF) {
+                        const float4 a = *(const float4*)(AddF + o);
+                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                    }
+                    if (g.ep_relu) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                    }
+                    uint2 h, l;
+                    h.x = pack_bf16x2(v[0], v[1]); h.y = pack_bf16x2(v[2], v[3]);
+                    l.x = pack_bf16x2(v[0] - __uint_as_float(h.x << 16), v[1] - __uint_as_float(h.x & 0xffff0000u));
+                    l.y = pack_bf16x2(v[2] - __uint_as_float(h.y << 16), v[3] - __uint_as_float(h.y & 0xffff0000u));
+                    *(uint2*)(OutHi + o) = h; *(uint2*)(OutLo + o) = l;
+                    if (g.OutF) *(float4*)(g.OutF + o) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            return;
+        }
         if constexpr (BNR) {
             const float* __restrict__ BnY = (const float*)g.bn_y;
             const bf16_t* __restrict__ BnM = (const bf16_t*)g.bn_out;
@@ -610,11 +658,14 @@ int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn) {
     return conv3x3_tiles(N, H, W, (C + 63) / 64 * 64, Cn);
 }
 
+struct C3EvalBn { void* out_hi; void* out_lo; float* out_f32; const void* res_hi; const void* res_lo; int relu; };
+
 int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W,
                    int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st, const float* bn_y,
-                   const void* bn_out_hi, const float* bnp, float* bn_part) {
+                   const void* bn_out_hi, const float* bnp, float* bn_part, const C3EvalBn* ev) {
     if (C % 32) return AB_ESHAPE;
     if (bn_y && (!flip || stats || !bnp || !bn_part)) return AB_EINVAL;
+    if (ev && (flip || stats || bn_y || !bnp || !ev->out_hi || !ev->out_lo || (ev->res_hi && (addend || !ev->res_lo)))) return AB_EINVAL;
     int cfg = c3_config(N, H, W, (C + 63) / 64 * 64, Cn);
     if (!cfg || Cn % 4) return AB_ESHAPE;
     const long delta = (const char*)wt_lo - (const char*)wt_hi;
@@ -623,6 +674,7 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
     g.X = x_hi; g.X_lo = x_lo; g.Wt = wt_hi; g.wlo_delta = (unsigned)delta; g.Out = out; g.addend = addend; g.stats = stats;
     g.N = N; g.H = H; g.W = W; g.C = C; g.Cn = Cn; g.ktot = 9 * C; g.flip = flip;
     g.bn_y = bn_y; g.bn_out = bn_out_hi; g.bnp = bnp; g.bn_part = bn_part;
+    if (ev) { g.Out = ev->out_hi; g.Out_lo = ev->out_lo; g.OutF = ev->out_f32; g.res_hi = ev->res_hi; g.res_lo = ev->res_lo; g.ep_relu = ev->relu; }
     if (bn_y) {      // masked gradient + BatchNorm-backward partials from the epilogue
         if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, 1, 2>(g, st);
         if (cfg == 2) return c3_launch<256, 32, 128, 4, 2, 1, 2>(g, st);
@@ -631,6 +683,15 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
         if (cfg == 6) return c3_launch<256, 16, 64, 4, 2, 1, 2>(g, st);
         if (cfg == 7) return c3_launch<256, 32, 64, 4, 2, 1, 2>(g, st);
         return c3_launch<128, 16, 64, 4, 2, 1, 2>(g, st);
+    }
+    if (g.Out_lo) {      // eval-mode forward with the following BatchNorm folded in (conv3x3_x3_evalbn_run fills these fields)
+        if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, 0, 3>(g, st);
+        if (cfg == 2) return c3_launch<256, 32, 128, 4, 2, 0, 3>(g, st);
+        if (cfg == 3) return c3_launch<128, 16, 128, 4, 2, 0, 3>(g, st);
+        if (cfg == 5) return c3_launch<64, 8, 128, 2, 4, 0, 3>(g, st);
+        if (cfg == 6) return c3_launch<256, 16, 64, 4, 2, 0, 3>(g, st);
+        if (cfg == 7) return c3_launch<256, 32, 64, 4, 2, 0, 3>(g, st);
+        return c3_launch<128, 16, 64, 4, 2, 0, 3>(g, st);
     }
 #define C3X_GO(FL) \
     do { \

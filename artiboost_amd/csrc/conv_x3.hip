@@ -10,9 +10,10 @@
 #include "conv_common.h"
 
 int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn);
+struct C3EvalBn { void* out_hi; void* out_lo; float* out_f32; const void* res_hi; const void* res_lo; int relu; };
 int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W,
                    int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st, const float* bn_y = nullptr,
-                   const void* bn_out_hi = nullptr, const float* bnp = nullptr, float* bn_part = nullptr);
+                   const void* bn_out_hi = nullptr, const float* bnp = nullptr, float* bn_part = nullptr, const C3EvalBn* ev = nullptr);
 int conv_gemm2_x3_mtiles(int M, int Cn, int nsteps, int nclass);
 int conv_gemm2_x3_run(ConvGemmArgs& g, hipStream_t st);
 int wgrad3x3_x3_slices(int N, int H, int W, int Cin, int Cout);
@@ -87,6 +88,25 @@ extern "C" int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* 
         g.dh[i * kw + j] = (int8_t)(i - pad); g.dw[i * kw + j] = (int8_t)(j - pad); g.koff[i * kw + j] = (i * kw + j) * Cin;
     }
     return conv_gemm2_x3_run(g, as_stream(stream));
+}
+
+// Eval-mode 3x3 / stride 1 / pad 1 convolution with the BatchNorm that follows it folded into the epilogue (resnet.py:85-101 in
+// eval(): running statistics, so (scale, shift) = bnp[0..Cout) | bnp[Cout..2 Cout) are launch constants):
+//   out = relu?(conv(x, w) * scale + shift + residual)   written as (hi, lo) planes [N,H,W,Cout] (+ fp32 when out_f32 != NULL)
+// residual: (res_hi, res_lo) planes, or the fp32 tensor res_f32, or none.  AB_ESHAPE when the 3x3 kernel does not take the shape
+// (the caller then runs ab_conv2d_fwd_x3 + ab_bn_apply_x3; results are bit-identical either way).
+extern "C" int ab_conv2d_fwd_x3_evalbn_ok(int N, int H, int W, int Cin, int Cout) {
+    return conv3x3_x3_tiles(N, H, W, Cin, Cout) > 0 && Cout % 4 == 0;
+}
+
+extern "C" int ab_conv2d_fwd_x3_evalbn(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, int N, int H, int W,
+                                       int Cin, int Cout, const float* bnp, const void* res_hi, const void* res_lo,
+                                       const float* res_f32, int relu, void* out_hi, void* out_lo, float* out_f32, void* stream) {
+    if (!x_hi || !x_lo || !w_hi || !w_lo || !bnp || !out_hi || !out_lo) return AB_EINVAL;
+    if (Cin % 32) return AB_ESHAPE;
+    C3EvalBn ev = {out_hi, out_lo, out_f32, res_hi, res_lo, relu};
+    return conv3x3_x3_run(x_hi, x_lo, w_hi, w_lo, nullptr, N, H, W, Cin, Cout, 0, res_f32, nullptr, as_stream(stream), nullptr, nullptr,
+                          bnp, nullptr, &ev);
 }
 
 // ---------------------------------------------------------------- data gradient (== transposed-convolution forward)

@@ -56,24 +56,64 @@ def softargmax3d_bwd_x3(logits, C, D, DP, uvd, conf, stat, g_uvd, g_conf=None, d
     return dl
 
 
-class _SoftArgmax3D(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, logits, C, D, DP):
-        uvd, conf, stat = softargmax3d_fwd(logits, C, D, DP)
-        ctx.save_for_backward(logits, uvd, conf, stat)
-        ctx.dims = (C, D, DP)
-        return uvd, conf
+# ---- the differentiable op, registered with the dispatcher: torch.ops.artiboost_hip.softargmax3d
+# (the raw kernels are torch.ops.artiboost_hip.softargmax3d_fwd / _bwd -- libartiboost_torch.so; this functional op allocates the
+# outputs, and autograd / fake-tensor rules are registered on it, so it composes with torch.autograd and torch.compile's tracing)
+_FRAG = torch.library.Library("artiboost_hip", "FRAGMENT")
+_FRAG.define("softargmax3d(Tensor logits, int nclasses, int depth, int depth_pitch) -> (Tensor, Tensor, Tensor)")
+_FRAG.define("softargmax3d_backward(Tensor logits, int nclasses, int depth, int depth_pitch, Tensor uvd, Tensor conf, Tensor stat, "
+             "Tensor g_uvd, Tensor? g_conf) -> Tensor")
 
-    @staticmethod
-    def backward(ctx, g_uvd, g_conf):
-        logits, uvd, conf, stat = ctx.saved_tensors
-        C, D, DP = ctx.dims
-        if g_uvd is None:
-            g_uvd = torch.zeros_like(uvd)
-        return softargmax3d_bwd(logits, C, D, DP, uvd, conf, stat, g_uvd, g_conf), None, None, None
+
+def _sam_fwd_impl(logits, nclasses, depth, depth_pitch):
+    return softargmax3d_fwd(logits.contiguous(), nclasses, depth, depth_pitch)
+
+
+def _sam_bwd_impl(logits, nclasses, depth, depth_pitch, uvd, conf, stat, g_uvd, g_conf):
+    return softargmax3d_bwd(logits, nclasses, depth, depth_pitch, uvd, conf, stat, g_uvd, g_conf)
+
+
+_FRAG.impl("softargmax3d", _sam_fwd_impl, "CUDA")
+_FRAG.impl("softargmax3d_backward", _sam_bwd_impl, "CUDA")
+
+
+@torch.library.register_fake("artiboost_hip::softargmax3d")
+def _sam_fake(logits, nclasses, depth, depth_pitch):
+    B = logits.shape[0]
+    f = lambda *s: logits.new_empty(s, dtype=torch.float32)   # noqa: E731
+    return f(B, nclasses, 3), f(B, nclasses), f(B, nclasses, 2)
+
+
+@torch.library.register_fake("artiboost_hip::softargmax3d_backward")
+def _sam_bwd_fake(logits, nclasses, depth, depth_pitch, uvd, conf, stat, g_uvd, g_conf):
+    return torch.empty_like(logits)
+
+
+def _sam_setup(ctx, inputs, output):
+    logits, C, D, DP = inputs
+    uvd, conf, stat = output
+    ctx.save_for_backward(logits, uvd, conf, stat)
+    ctx.dims = (C, D, DP)
+
+
+def _sam_backward(ctx, g_uvd, g_conf, g_stat):
+    logits, uvd, conf, stat = ctx.saved_tensors
+    C, D, DP = ctx.dims
+    if g_uvd is None:
+        g_uvd = torch.zeros_like(uvd)
+    dl = torch.ops.artiboost_hip.softargmax3d_backward(logits, C, D, DP, uvd, conf, stat, g_uvd.contiguous().float(),
+                                                       g_conf.contiguous().float() if g_conf is not None else None)
+    return dl, None, None, None
+
+
+torch.library.register_autograd("artiboost_hip::softargmax3d", _sam_backward, setup_context=_sam_setup)
 
 
 def softargmax3d(logits_nhwc: torch.Tensor, nclasses: int, depth: int, depth_pitch: int = None):
     """logits (B, H, W, nclasses*depth_pitch) NHWC, channel = c*depth_pitch + d (d < depth valid)
-    ->  uvd (B, nclasses, 3), conf (B, nclasses).  Differentiable (autograd wrapper over the two HIP kernels)."""
-    return _SoftArgmax3D.apply(logits_nhwc.contiguous(), nclasses, depth, depth_pitch or depth)
+    ->  uvd (B, nclasses, 3), conf (B, nclasses).  Differentiable: torch.ops.artiboost_hip.softargmax3d (dispatcher op with
+    registered autograd) over the two HIP kernels."""
+    if not logits_nhwc.is_cuda:
+        raise RuntimeError("artiboost_hip ops need device tensors (HIP); got a CPU tensor")
+    uvd, conf, _ = torch.ops.artiboost_hip.softargmax3d(logits_nhwc.contiguous(), nclasses, depth, depth_pitch or depth)
+    return uvd, conf

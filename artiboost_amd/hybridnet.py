@@ -429,6 +429,11 @@ class HybridNet:
             for b in range(nblk):
                 stride = 2 if (b == 0 and li > 1) else 1
                 pre = f"backbone.layer{li}.{b}"
+                if not tr and self.x3 and self.eval_fold:
+                    x = self._eval_block(x, pre, stride, inpl != planes, last=(li == 4 and b == nblk - 1))
+                    S["blocks"].append(dict(pre=pre))
+                    inpl = planes
+                    continue
                 y1, st1 = self._conv_fwd(x, pre + ".conv1.weight", stride, 1, want_stats=True)
                 cnt = y1.shape[0] * y1.shape[1] * y1.shape[2]
                 a1, bnp1 = self._bn(pre + ".bn1", y1, st1, cnt)
@@ -484,6 +489,28 @@ class HybridNet:
         self.saved = S if tr else None
         self.last = dict(feat=feat, fmean=fmean, logits=logits, box_raw=b3.view(N, BOX_OUT_PAD))
         return logits, box6d
+
+    eval_fold = os.environ.get("AB_EVAL_FOLD", "1") != "0"       # bf16x3 eval: BatchNorm folded into the 3x3 conv epilogues
+
+    def _eval_block(self, x, pre, stride, has_ds, last):
+        """One BasicBlock in eval mode (resnet.py:85-101 with running statistics): where the 3x3 kernel takes the shape the
+        BatchNorm after a convolution (+ residual + ReLU) rides in its epilogue and the fp32 conv output is never stored;
+        bit-identical to conv + ab_bn_apply_x3 (AB_EVAL_FOLD=0)."""
+        def conv_bn(inp, cname, bname, s, res, relu, want_f32=False):
+            w = self.w(cname)
+            bnp = self._bn_params(bname, None, 0)
+            if s == 1 and K.conv2d_fwd_x3_evalbn_ok(inp, w):
+                return K.conv2d_fwd_x3_evalbn(inp, w, bnp, res=res, relu=relu, want_f32=want_f32)
+            y = K.conv2d_fwd_x3(inp, w, s, 1)
+            return K.bn_apply_x3(y, bnp, res=res, relu=relu, want_f32=want_f32)
+
+        a1 = conv_bn(x, pre + ".conv1.weight", pre + ".bn1", stride, None, True)
+        if stride != 1 or has_ds:
+            yd = K.conv2d_fwd_x3(x, self.w(pre + ".downsample.0.weight"), stride, 0)
+            r = K.bn_apply(yd, self._bn_params(pre + ".downsample.1", None, 0), relu=False)
+        else:
+            r = x
+        return conv_bn(a1, pre + ".conv2.weight", pre + ".bn2", 1, r, True, want_f32=last or not self.res_planes)
 
     def head_fwd(self, logits):
         """-> kp3d [N,22,3], conf [N,22], stat (kept for head_bwd)."""

@@ -472,6 +472,36 @@ def conv2d_fwd_x3(x, w_split, stride, pad, bias=None, want_stats=False, relu=Fal
     return (y, stats) if want_stats else y
 
 
+def conv2d_fwd_x3_evalbn_ok(x, w_split):
+    xh = x[0] if x.dtype == torch.bfloat16 else x
+    N, H, W, Cin = xh.shape
+    _, Cout, kh, kw, _ = w_split.shape
+    return (kh, kw) == (3, 3) and bool(L.lib().ab_conv2d_fwd_x3_evalbn_ok(L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout)))
+
+
+def conv2d_fwd_x3_evalbn(x, w_split, bnp, res=None, relu=True, want_f32=False):
+    """Eval-mode 3x3/s1 convolution + the BatchNorm after it (+ residual, ReLU) in one launch -> split planes [2,N,H,W,Cout]
+    (want_f32: the fp32 tensor with the planes cached on it, as bn_apply_x3 returns).  res: split planes, fp32 tensor or None."""
+    xh, xl = _planes(x)
+    N, H, W, Cin = xh.shape
+    Cout = w_split.shape[1]
+    sp = torch.empty((2, N, H, W, Cout), dtype=torch.bfloat16, device=xh.device)
+    o = torch.empty((N, H, W, Cout), dtype=torch.float32, device=xh.device) if want_f32 else None
+    rh = rl = rf = None
+    if res is not None:
+        if res.dtype == torch.bfloat16:
+            rh, rl = res[0], res[1]
+        else:
+            rf = res
+    L.check(L.lib().ab_conv2d_fwd_x3_evalbn(L.ptr(xh), L.ptr(xl), L.ptr(w_split[0]), L.ptr(w_split[1]), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                            L.i(Cout), L.ptr(bnp), L.ptr(rh), L.ptr(rl), L.ptr(rf), L.i(1 if relu else 0), L.ptr(sp[0]),
+                                            L.ptr(sp[1]), L.ptr(o), L.stream()), "ab_conv2d_fwd_x3_evalbn")
+    if o is None:
+        return sp
+    o._ab_split = sp
+    return o
+
+
 def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=False, bn=None):
     """dy: fp32 / split [.., N,Ho,Wo,Cout]; wt_split [2,Cin,kh,kw,Cout] -> dx fp32 [N,H,W,Cin] (+ BN partials of dx).
 

@@ -213,8 +213,7 @@ class RealBatcher:
 
 
 def _ptr(t):
-    import ctypes
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    return L.view_ptr(t)
 
 
 class MixedLoader:

@@ -32,11 +32,8 @@ def nearest_dist(x, ypts, obj_idx=None, rot=None, scale=None, shift=None, out=No
 
 
 def ctypes_ptr(t):
-    """Pointer of a (possibly row-pitched) device view."""
-    import ctypes
-    if not t.is_cuda:
-        raise RuntimeError("artiboost_hip ops need device tensors (HIP); got a CPU tensor")
-    return ctypes.c_void_p(t.data_ptr())
+    """A (possibly row-pitched) device view as a buffer argument (the pitch is passed next to it)."""
+    return L.view_ptr(t)
 
 
 def linear_fused(x, w, bias=None, scale=None, shift=None, residual=None, act=0, slope=0.2, out=None):

@@ -123,6 +123,15 @@ int ab_conv2d_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int k
 int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* y, int N, int H, int W,
                      int Cin, int Cout, int kh, int kw, int stride, int pad, const float* bias, float* stats, int relu,
                      void* stream);
+/* Eval-mode BasicBlock convolutions (anakin/models/resnet.py:85-101 under model.eval(): train/submit_reload.py:26-79, the TEST
+ * pass of train/train_artiboost.py:224-240): 3x3 / stride 1 / pad 1 convolution with the BatchNorm that follows folded into the
+ * epilogue -- bnp = [scale Cout | shift Cout | ..] from ab_bn_eval_params; out = relu?(conv * scale + shift + residual) as (hi, lo)
+ * planes (+ fp32 copy when out_f32 != NULL); residual = (res_hi, res_lo) planes, or fp32 res_f32, or none.  _ok(): 1 when the
+ * shape is taken (otherwise run ab_conv2d_fwd_x3 + ab_bn_apply_x3: same bits). */
+int ab_conv2d_fwd_x3_evalbn_ok(int N, int H, int W, int Cin, int Cout);
+int ab_conv2d_fwd_x3_evalbn(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, int N, int H, int W, int Cin,
+                            int Cout, const float* bnp, const void* res_hi, const void* res_lo, const float* res_f32, int relu,
+                            void* out_hi, void* out_lo, float* out_f32, void* stream);
 int ab_conv2d_dgrad_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H,
                        int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend, float* stats,

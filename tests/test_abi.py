@@ -15,6 +15,30 @@ def test_library_exports_every_declared_symbol():
     assert L.lib().ab_abi_version() >= 1
 
 
+def test_every_entry_point_is_a_registered_torch_op():
+    """The boundary as PyTorch custom ops (north_star / SURVEY 8b): libartiboost_torch.so registers torch.ops.artiboost_hip.<name>
+    for every declaration of include/artiboost_hip.h (generated binding), loads without a GPU, and is the default route of the
+    package's calls; host-only query ops run here."""
+    import torch
+    from artiboost_amd import _lib as L
+    from artiboost_amd import build
+    build.build()
+    assert os.path.exists(L.TORCH_LIB_PATH)
+    torch.ops.load_library(L.TORCH_LIB_PATH)
+    ns = torch.ops.artiboost_hip
+    for n in L.declared_symbols():
+        assert hasattr(ns, n[3:]), f"{n}: no torch.ops.artiboost_hip.{n[3:]}"
+    assert ns.abi_version() == ctypes.CDLL(L.LIB_PATH).ab_abi_version()
+    assert ns.conv2d_x3_stat_rows(64, 16, 16, 256, 256, 3, 3, 1, 1) == 128
+    if "AB_BINDING" not in os.environ and "ARTIBOOST_HIP_LIB" not in os.environ:
+        assert L.BINDING == "torch" and type(L.lib()).__name__ == "_TorchOps"
+    # mutable outputs are declared as such in the schema (first output of the soft-argmax forward)
+    schema = str(ns.softargmax3d_fwd.default._schema)
+    assert "!" in schema and "Tensor" in schema
+    with __import__("pytest").raises(RuntimeError):          # a CPU tensor where a device buffer is expected: the binding refuses
+        L.ptr(torch.zeros(4))
+
+
 def test_ops_fail_loudly_without_device_tensors():
     import pytest
     import torch

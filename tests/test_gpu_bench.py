@@ -1,0 +1,47 @@
+"""bench.py end to end on the GPU box: the two-rank schedule the driver's SCALE run will execute (one process per rank, split
+backward graphs, side-stream gradient averaging, next-batch render overlapped with the last range + optimizer), on shared devices
+over gloo when the box has one GPU -- so the first real multi-GPU run exercises a path that has run whole at least once -- and the
+BASELINE configs[1] eval leg."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-3000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_two_ranks_end_to_end():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--allow-shared-devices", "--steps", "3", "--warmup", "2",
+           "--sustain", "0.5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["config"]["render_overlap"] is True and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 128
+    assert line["final_loss"] is not None and 0 < line["final_loss"] < 1.0
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["achieved"] and 0 < roof["frac"] < 1
+    assert line["sustained"]["sustained_samples_per_s"] > 0
+
+
+def test_bench_eval_leg_configs1():
+    """`bench.py --eval`: BASELINE configs[1] (eval-mode forward, bs 64) as a line of its own with its roofline."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--eval", "--steps", "10", "--warmup", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = _last_json(r.stdout)
+    assert "eval" in line["metric"] and line["dtype"] == "bf16x3" and line["n_gpus"] == 1
+    assert line["value"] > 1000 and line["ms_per_step"] < 64.0
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["conv_launches"] >= 36

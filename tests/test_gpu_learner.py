@@ -189,3 +189,35 @@ def _segment_runs(runs, size, heat, B, seed, steps, dtype, build_optimizer):
             segs = list(hb._segments.values())
             assert len(segs) == 2 and all(s.fwd is not None for s in segs) and any(s.bwd is not None for s in segs)
         runs[seg] = (losses, evals, hb.store.flat.detach().cpu().clone(), hb.store.stats.cpu().clone())
+
+
+@pytest.mark.parametrize("g,B", [(224, 2), (256, 3)])
+def test_eval_forward_with_folded_batchnorm_is_bit_identical(g, B, monkeypatch):
+    """Eval-mode forward (BASELINE configs[1]: submit_reload.py / the TEST pass, resnet.py:85-101 under eval()) with the
+    BatchNorm of every 3x3/s1 convolution folded into the conv epilogue (ab_conv2d_fwd_x3_evalbn: the fp32 conv outputs are never
+    stored) == conv + ab_bn_apply_x3 as separate launches, bit for bit -- after a few training steps, so that running statistics,
+    scales and shifts are non-trivial."""
+    from artiboost_amd import kernels as K
+    size, heat, seed = g, g // 8, 5
+    model, crit, _ = build(size, heat, "bf16x3", seed, SEGMENT_GRAPHS=False)
+    hb = model.model_list[0]
+    model.train()
+    for it in range(2):                     # move the running statistics away from (0, 1)
+        model(make_batch(B, size, seed + it))
+    model.eval()
+    batch = make_batch(B, size, seed + 50)
+    calls = []
+    orig = K.conv2d_fwd_x3_evalbn
+    monkeypatch.setattr(K, "conv2d_fwd_x3_evalbn", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    outs = {}
+    for fold in (True, False):
+        hb.net.eval_fold = fold
+        with torch.no_grad():
+            p = model(batch)["HybridBaseline"]
+        outs[fold] = {k: v.detach().cpu().clone() for k, v in p.items()}
+        outs[fold]["logits"] = hb.net.last["logits"].detach().cpu().clone()
+        outs[fold]["feat"] = hb.net.last["feat"].detach().float().cpu().clone()
+    assert len(calls) == 29                 # 32 3x3/s1 convolutions of ResNet-34 minus conv1 of the three down-sampling blocks
+    for k in outs[True]:
+        assert torch.equal(outs[True][k], outs[False][k]), k
+    assert torch.isfinite(outs[True]["joints_3d_abs"]).all()
