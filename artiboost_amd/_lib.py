@@ -69,23 +69,32 @@ class _TorchOps:
         cdll()                                   # fail loudly on a missing / incomplete libartiboost_hip.so first
         torch.ops.load_library(TORCH_LIB_PATH)
         self._ns = torch.ops.artiboost_hip
+        from . import gen_torch_ops
+        self._sig = {name: params for _, name, params in gen_torch_ops.declarations()}
 
     def __getattr__(self, name):
-        op = getattr(self._ns, name[3:])
-
-        def call(*args):
-            conv = []
-            for a in args:
-                if a is _STREAM:
-                    continue
-                if a is None or isinstance(a, (torch.Tensor, int, float)):
-                    conv.append(a)
-                elif isinstance(a, ctypes.c_void_p):
-                    raise TypeError(f"{name}: raw pointer argument (pass the tensor: _lib.ptr returns it)")
-                else:
-                    conv.append(_host_bytes(a))
-            r = op(*conv)
-            return 0 if r is None else r
+        op = getattr(self._ns, name[3:]).default            # the OpOverload: no overload resolution per call
+        params = self._sig[name]
+        has_stream = bool(params) and params[-1] == ("void*", "stream")
+        # positions that may carry a HOST object of the C ABI (ctypes struct / array / byref): passed on as CPU byte tensors
+        # (the header names host pointers `*_host`; struct pointers are host structs, or device tables that arrive as tensors anyway)
+        host = tuple(i for i, (ty, pn) in enumerate(params) if "ab_" in ty or pn.endswith("_host"))
+        Tensor = torch.Tensor
+        if not host:
+            if has_stream:
+                def call(*args):
+                    return op(*args[:-1]) or 0
+            else:
+                def call(*args):
+                    return op(*args) or 0
+        else:
+            def call(*args):
+                a = list(args[:-1] if has_stream else args)
+                for i in host:
+                    x = a[i]
+                    if x is not None and not isinstance(x, Tensor):
+                        a[i] = _host_bytes(x)
+                return op(*a) or 0
         self.__dict__[name] = call
         return call
 

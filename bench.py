@@ -337,7 +337,7 @@ def cpu_baseline(args, cfg):
             state["vs"] = [torch.zeros_like(leaf[k]) for k in state["names"]]
         lo.clip_and_adam([leaf[k].detach() for k in state["names"]], [leaf[k].grad for k in state["names"]], state["ms"], state["vs"], it + 1)
 
-    # thread-count calibration: one learner step of the SAME batch size at each candidate, the fastest is used for the measured
+    # thread-count calibration (8 / 16 / 32 / 64): one learner step of the SAME batch size at each candidate, the fastest is used for the measured
     # steps (the box has 64 cores / 256 hardware threads; torch's CPU convolutions at batch 64 stop scaling well before that)
     calib = {}
     if not getattr(args, "cpu_threads_fixed", False) and (os.cpu_count() or 1) >= 64:
@@ -348,7 +348,7 @@ def cpu_baseline(args, cfg):
         for k in ("root_joint", "cam_intr", "corners_can", "joints_3d", "corners_3d", "joints_vis", "corners_vis"):
             b0[k] = torch.from_numpy(np.stack([g[k] for g in sc0["gt"]]).astype(np.float32))
         st0 = {}
-        for nt in (16, 32, 64):
+        for nt in (8, 16, 32, 64):
             torch.set_num_threads(nt)
             t0 = time.time()
             learner_step(b0, 0, st0)
