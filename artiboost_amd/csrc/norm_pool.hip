@@ -149,6 +149,21 @@ __global__ void bn_eval_params_kernel(int C, const float* gamma, const float* be
     bnp[c] = sc; bnp[C + c] = beta[c] - rm[c] * sc; bnp[2 * C + c] = rm[c]; bnp[3 * C + c] = invstd;
 }
 
+// every BatchNorm of a network in ONE launch: desc[n][5] = (gamma offset, beta offset in `flat`; running_mean, running_var offset in
+// `stats`; output offset in `out`), C = desc[n][5 * .. ] -- see ab_bn_eval_params_batch
+__global__ void bn_eval_params_batch_kernel(const float* __restrict__ flat, const float* __restrict__ stats, const int* __restrict__ desc,
+                                            float eps, float* __restrict__ out) {
+    const int* d = desc + blockIdx.y * 6;
+    const int C = d[5];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float* gamma = flat + d[0]; const float* beta = flat + d[1]; const float* rm = stats + d[2]; const float* rv = stats + d[3];
+    float* bnp = out + d[4];
+    float invstd = 1.f / sqrtf(rv[c] + eps);
+    float sc = gamma[c] * invstd;
+    bnp[c] = sc; bnp[C + c] = beta[c] - rm[c] * sc; bnp[2 * C + c] = rm[c]; bnp[3 * C + c] = invstd;
+}
+
 // ---------------------------------------------------------------- BN apply (+residual) (+ReLU)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res,
@@ -1021,6 +1036,14 @@ extern "C" int ab_bn_eval_params(int C, const float* gamma, const float* beta, c
                                  float eps, float* bnp, void* stream) {
     if (!gamma || !beta || !rm || !rv || !bnp) return AB_EINVAL;
     bn_eval_params_kernel<<<(C + 255) / 256, 256, 0, as_stream(stream)>>>(C, gamma, beta, rm, rv, eps, bnp);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int ab_bn_eval_params_batch(const float* flat, const float* stats, const int32_t* desc_dev, int n, int max_c, float eps,
+                                       float* out, void* stream) {
+    if (!flat || !stats || !desc_dev || !out) return AB_EINVAL;
+    if (n <= 0 || max_c <= 0) return AB_ESHAPE;
+    bn_eval_params_batch_kernel<<<dim3((max_c + 255) / 256, n), 256, 0, as_stream(stream)>>>(flat, stats, (const int*)desc_dev, eps, out);
     AB_LAUNCH_CHECK(); return 0;
 }
 

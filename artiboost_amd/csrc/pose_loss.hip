@@ -511,6 +511,84 @@ static int pose_loss_impl(const float* kp3d, const float* box6d, int box_stride,
     return 0;
 }
 
+// ---- M4 alone (eval-mode forwards: no targets, no criterion): hybridbaseline.py:49-96 for one sample per wave -- the same
+// arithmetic, in the same order, as the assembly phase of pose_loss_kernel above.
+__global__ __launch_bounds__(64) void pose_assemble_kernel(const float* __restrict__ kp3d, const float* __restrict__ box6d, int box_stride,
+                                                           const float* __restrict__ root_joint, const float* __restrict__ cam_intr,
+                                                           const float* __restrict__ corners_can, int center_idx, float res_w, float res_h,
+                                                           float depth_range, float* __restrict__ joints_abs, float* __restrict__ corners_abs,
+                                                           float* __restrict__ rotmat, float* __restrict__ uvd2d, float* __restrict__ joints_rel,
+                                                           float* __restrict__ corners_rel, float* __restrict__ boxroot) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ float kp[66], Kc[9], CAN[8][3], RJ[3], avec[3], bvec[3], P[22][3], C[8][3], R[3][3];
+    kp[lane] = kp3d[(long)b * 66 + lane];
+    if (lane < 2) kp[64 + lane] = kp3d[(long)b * 66 + 64 + lane];
+    if (lane < 9) Kc[lane] = cam_intr[(long)b * 9 + lane];
+    if (lane < 24) (&CAN[0][0])[lane] = corners_can[(long)b * 24 + lane];
+    if (lane < 3) { RJ[lane] = root_joint[b * 3 + lane]; avec[lane] = box6d[(long)b * box_stride + lane]; }
+    else if (lane < 6) bvec[lane - 3] = box6d[(long)b * box_stride + lane];
+    __syncthreads();
+    const float fx = Kc[0], fy = Kc[4], cx = Kc[2], cy = Kc[5], rootz = RJ[2];
+    if (lane < 22) {
+        float u = kp[lane * 3], v = kp[lane * 3 + 1], d = kp[lane * 3 + 2];
+        float z = (d - 0.5f) * depth_range + rootz;
+        P[lane][0] = (u * res_w - cx) / fx * z;
+        P[lane][1] = (v * res_h - cy) / fy * z;
+        P[lane][2] = z;
+    }
+    if (lane == 0) {
+        float xh[3], yh[3], zh[3], zraw[3];
+        float n = sqrtf(dot3(avec, avec)); n = fmaxf(n, 1e-8f);
+        for (int i = 0; i < 3; ++i) xh[i] = avec[i] / n;
+        cross3(xh, bvec, zraw);
+        float m = sqrtf(dot3(zraw, zraw)); m = fmaxf(m, 1e-8f);
+        for (int i = 0; i < 3; ++i) zh[i] = zraw[i] / m;
+        cross3(zh, xh, yh);
+        for (int i = 0; i < 3; ++i) { R[i][0] = xh[i]; R[i][1] = yh[i]; R[i][2] = zh[i]; }
+    }
+    __syncthreads();
+    if (lane < 24) {
+        int c = lane / 3, i = lane % 3;
+        const float* can = CAN[c];
+        C[c][i] = R[i][0] * can[0] + R[i][1] * can[1] + R[i][2] * can[2] + P[21][i];
+    }
+    __syncthreads();
+    if (lane < 63) {
+        const float v = P[lane / 3][lane % 3];
+        joints_abs[(long)b * 63 + lane] = v;
+        if (joints_rel) joints_rel[(long)b * 63 + lane] = v - P[center_idx][lane % 3];
+    }
+    if (lane < 24) {
+        const float v = C[lane / 3][lane % 3];
+        corners_abs[(long)b * 24 + lane] = v;
+        if (corners_rel) corners_rel[(long)b * 24 + lane] = v - P[center_idx][lane % 3];
+    }
+    if (lane < 9) rotmat[(long)b * 9 + lane] = R[lane / 3][lane % 3];
+    if (lane < 3 && boxroot) boxroot[b * 3 + lane] = P[21][lane];
+    if (uvd2d) {
+        float* o = uvd2d + (long)b * 90;
+        if (lane < 21) { o[lane * 3] = kp[lane * 3]; o[lane * 3 + 1] = kp[lane * 3 + 1]; o[lane * 3 + 2] = kp[lane * 3 + 2]; }
+        if (lane < 8) {
+            const float* K = Kc;
+            float X = C[lane][0], Y = C[lane][1], Z = C[lane][2];
+            float hx = K[0] * X + K[1] * Y + K[2] * Z, hy = K[3] * X + K[4] * Y + K[5] * Z, hz = K[6] * X + K[7] * Y + K[8] * Z;
+            o[(21 + lane) * 3] = hx / hz / res_w; o[(21 + lane) * 3 + 1] = hy / hz / res_h; o[(21 + lane) * 3 + 2] = 0.f;
+        }
+        if (lane < 3) o[29 * 3 + lane] = kp[21 * 3 + lane];
+    }
+}
+
+extern "C" int ab_pose_assemble(const float* kp3d, const float* box6d, int box_stride, const float* root_joint, const float* cam_intr,
+                                const float* corners_can, int B, int center_idx, float res_w, float res_h, float* joints_abs,
+                                float* corners_abs, float* rotmat, float* uvd2d, float* joints_rel, float* corners_rel, float* boxroot,
+                                void* stream) {
+    if (!kp3d || !box6d || !root_joint || !cam_intr || !corners_can || !joints_abs || !corners_abs || !rotmat) return AB_EINVAL;
+    if (B <= 0 || center_idx < 0 || center_idx > 20 || box_stride < 6) return AB_ESHAPE;
+    pose_assemble_kernel<<<B, 64, 0, as_stream(stream)>>>(kp3d, box6d, box_stride, root_joint, cam_intr, corners_can, center_idx, res_w, res_h,
+                                                          0.4f, joints_abs, corners_abs, rotmat, uvd2d, joints_rel, corners_rel, boxroot);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
 extern "C" int ab_pose_loss(const float* kp3d, const float* box6d, int box_stride, const float* root_joint,
                             const float* cam_intr, const float* corners_can, const float* joints_3d,
                             const float* corners_3d, const float* joints_vis, const float* corners_vis,

@@ -365,8 +365,32 @@ class HybridNet:
         if self.training:
             return K.bn_finalize(stats_part, count, p.view(prefix + ".weight"), p.view(prefix + ".bias"),
                                  p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
+        ev = getattr(self, "_eval_bnp", None)
+        if ev is not None:
+            return ev[prefix]                      # this forward's batched launch (forward() -> _eval_params_all)
         return K.bn_eval_params(p.view(prefix + ".weight"), p.view(prefix + ".bias"),
                                 p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
+
+    def _eval_params_all(self):
+        """Eval mode: (scale, shift, mean, invstd) of all 38 BatchNorms in ONE launch per forward (they are re-derived at every
+        forward: weights and running statistics move between evaluations) instead of one tiny launch each."""
+        p = self.p
+        if getattr(self, "_eval_desc", None) is None:
+            import numpy as np
+            rows, off, views = [], 0, {}
+            prefixes = [k[:-len(".running_mean")] for k in p.buffers if k.endswith(".running_mean")]
+            for pre in prefixes:
+                c = p.entries[pre + ".weight"].numel
+                rows.append((p.entries[pre + ".weight"].offset, p.entries[pre + ".bias"].offset, p.buffers[pre + ".running_mean"][0],
+                             p.buffers[pre + ".running_var"][0], off, c))
+                views[pre] = (off, c)
+                off += 4 * _round_up(c, 64)
+            self._eval_desc = torch.from_numpy(np.asarray(rows, np.int32)).to(p.device)
+            self._eval_out = torch.empty(off, dtype=torch.float32, device=p.device)
+            self._eval_views = {pre: self._eval_out[o:o + 4 * c].view(4, c) for pre, (o, c) in views.items()}
+            self._eval_maxc = max(r[5] for r in rows)
+        K.bn_eval_params_batch(p.flat, p.stats, self._eval_desc, self._eval_desc.shape[0], self._eval_maxc, self._eval_out)
+        return self._eval_views
 
     def _bn(self, prefix, y, stats_part, count, res=None, relu=True, feeds_conv=True, keep_f32=False, res_bnp=None):
         """feeds_conv / keep_f32 (bf16x3 only): the activation feeds a convolution (it is written as split planes by this
@@ -398,6 +422,7 @@ class HybridNet:
             # the stem kernels take ONE dtype code for image and weights: a mismatch would read the weights as the image's type
             raise TypeError(f"HybridNet({'bf16x3' if self.x3 else dt}) needs the padded image in {dt}, got {xpad.dtype} "
                             f"(build the loader with compute_dtype=net.dtype)")
+        self._eval_bnp = None if tr else self._eval_params_all()
         if tr and not torch.cuda.is_current_stream_capturing():
             p.num_batches_tracked += 1      # nn.BatchNorm2d's counter (momentum is fixed, so only checkpoints read it); graph replays count themselves
         N = xpad.shape[0]

@@ -188,6 +188,13 @@ def bn_eval_params(gamma, beta, rm, rv, eps=1e-5):
     return bnp
 
 
+def bn_eval_params_batch(flat, stats, desc_dev, n, max_c, out, eps=1e-5):
+    """Eval-mode (scale, shift, mean, invstd) of n BatchNorms in one launch; desc_dev int32 [n,6] (see the header)."""
+    L.check(L.lib().ab_bn_eval_params_batch(L.ptr(flat), L.ptr(stats), L.ptr(desc_dev), L.i(n), L.i(max_c), L.f(eps), L.ptr(out), L.stream()),
+            "ab_bn_eval_params_batch")
+    return out
+
+
 def bn_apply(y, bnp, res=None, relu=True, out=None):
     C = y.shape[-1]
     M = y.numel() // C
@@ -680,3 +687,17 @@ def col_sum_x3(x_split, out):
     part = torch.empty((lib.ab_col_stats_nparts(L.l(M)), C, 2), dtype=torch.float32, device=x_split.device)
     L.check(lib.ab_col_sum_x3(L.ptr(x_split[0]), L.ptr(x_split[1]), L.l(M), L.i(C), L.ptr(part), L.ptr(out), L.stream()), "ab_col_sum_x3")
     return out
+
+
+def pose_assemble(kp3d, box6d, root_joint, cam_intr, corners_can, center_idx, inp_res):
+    """hybridbaseline.py:49-96 in one launch (eval-mode forwards): kp3d [B,22,3] f32, box6d [B,>=6] (row-pitched view allowed),
+    -> dict of the module's geometric outputs."""
+    B, dev = kp3d.shape[0], kp3d.device
+    z = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)   # noqa: E731
+    o = dict(joints_3d_abs=z(B, 21, 3), corners_3d_abs=z(B, 8, 3), box_rot_rotmat=z(B, 3, 3), uvd2d=z(B, 30, 3), joints_3d=z(B, 21, 3),
+             corners_3d=z(B, 8, 3), boxroot_3d_abs=z(B, 1, 3))
+    L.check(L.lib().ab_pose_assemble(L.ptr(kp3d), L.view_ptr(box6d), L.i(box6d.stride(0)), L.ptr(root_joint), L.ptr(cam_intr), L.ptr(corners_can),
+                                     L.i(B), L.i(center_idx), L.f(inp_res[0]), L.f(inp_res[1]), L.ptr(o["joints_3d_abs"]),
+                                     L.ptr(o["corners_3d_abs"]), L.ptr(o["box_rot_rotmat"]), L.ptr(o["uvd2d"]), L.ptr(o["joints_3d"]),
+                                     L.ptr(o["corners_3d"]), L.ptr(o["boxroot_3d_abs"]), L.stream()), "ab_pose_assemble")
+    return o

@@ -198,6 +198,8 @@ class HybridBaseline(nn.Module):
         self.net.training = mode
         return self
 
+    fused_assembly = os.environ.get("AB_FUSED_ASSEMBLY", "1") != "0"      # eval / no_grad forwards: pose assembly as one kernel
+
     def _segment(self, image, xpad):
         """The graph pair for this call's (mode, input shape), or None when segment graphs do not apply."""
         src = xpad if xpad is not None else image
@@ -248,6 +250,15 @@ class HybridBaseline(nn.Module):
                     kp3d, conf, _ = self.net.head_fwd(logits)
         root_in = inputs[Queries.ROOT_JOINT].to(dev)
         intr = inputs[Queries.CAM_INTR].to(dev)
+        if not kp3d.requires_grad and self.fused_assembly and (W, H) == tuple(self.inp_res):
+            # no autograd graph to build (eval / no_grad): the whole pose assembly below is ONE kernel (ab_pose_assemble)
+            from . import kernels as K
+            f32c = lambda t: t.to(dev, torch.float32).contiguous()      # noqa: E731
+            o = K.pose_assemble(kp3d.contiguous(), box6d if box6d.stride(-1) == 1 else box6d.contiguous(), f32c(root_in), f32c(intr),
+                                f32c(inputs[Queries.CORNERS_CAN]), self.center_idx, self.inp_res)
+            return {"joints_3d_abs": o["joints_3d_abs"], "corners_3d_abs": o["corners_3d_abs"], "joints_3d": o["joints_3d"],
+                    "corners_3d": o["corners_3d"], "2d_uvd": o["uvd2d"], "boxroot_3d_abs": o["boxroot_3d_abs"],
+                    "box_rot_rotmat": o["box_rot_rotmat"], "kp3d": kp3d, "kp3d_confd": conf}
         pose_3d_abs = batch_uvd2xyz(kp3d, root_in, intr, self.inp_res)
         joints_3d_abs = pose_3d_abs[:, 0:21, :]
         boxroot_3d_abs = pose_3d_abs[:, 21:22, :]

@@ -191,6 +191,11 @@ int ab_bn_finalize(const float* part, int nparts, int C, long count, const float
                    float eps, float momentum, float* running_mean, float* running_var, float* bnp, void* stream);
 int ab_bn_eval_params(int C, const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                       float* bnp, void* stream);
+/* ... for EVERY BatchNorm of a network in one launch (eval mode re-derives them at each forward: the running statistics may have
+ * moved): desc_dev = device int32 [n][6] = (gamma, beta element offset in `flat`; running_mean, running_var offset in `stats`;
+ * bnp offset in `out`; C).  max_c = the largest C. */
+int ab_bn_eval_params_batch(const float* flat, const float* stats, const int32_t* desc_dev, int n, int max_c, float eps, float* out,
+                            void* stream);
 int ab_bn_apply(const void* y, const void* res, const float* bnp, int dtype, long M, int C, int relu, void* out,
                 void* stream);
 /* part: float [ab_col_stats_nparts(M)][C][2]; bwdp: float [2][C]; dz_out optional (gradient of the residual branch).
@@ -285,6 +290,14 @@ int ab_clip_adam_x3(float* param, const float* grad, float* m, float* v, long n,
  * (per-sample partial sums; [5],[6] = joint / corner EPE in mm), losses float[8] = joints_3d_loss, corners_3d_loss,
  * joint_ord_loss, part_ord_loss, scene_ord_loss, final_loss, mean EPE joints, mean EPE corners;
  * g_kp3d [B,22,3], g_box6d [B,6] = d final_loss / d input (NULL g_kp3d: forward only).                          */
+/* M4 alone -- the pose assembly of an EVAL-mode forward (no targets, no criterion): anakin/models/hybridbaseline.py:49-96
+ * (uvd -> xyz with the crop intrinsics, 6-D -> R, canonical corners -> camera frame, 2-D re-projection).  One launch instead of the
+ * ~50 small tensor ops of the module's forward.  joints_abs [B,21,3], corners_abs [B,8,3], rotmat [B,3,3]; optional: uvd2d
+ * [B,30,3] (hybridbaseline.py:80-84), joints_rel / corners_rel (minus the predicted joint `center_idx`), boxroot [B,3]. */
+int ab_pose_assemble(const float* kp3d, const float* box6d, int box_stride, const float* root_joint, const float* cam_intr,
+                     const float* corners_can, int B, int center_idx, float res_w, float res_h, float* joints_abs,
+                     float* corners_abs, float* rotmat, float* uvd2d, float* joints_rel, float* corners_rel, float* boxroot,
+                     void* stream);
 int ab_pose_loss(const float* kp3d, const float* box6d, int box_stride, const float* root_joint,
                  const float* cam_intr, const float* corners_can, const float* joints_3d, const float* corners_3d,
                  const float* joints_vis, const float* corners_vis, const float* hand_views, int nvh,

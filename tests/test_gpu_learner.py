@@ -221,3 +221,22 @@ def test_eval_forward_with_folded_batchnorm_is_bit_identical(g, B, monkeypatch):
     for k in outs[True]:
         assert torch.equal(outs[True][k], outs[False][k]), k
     assert torch.isfinite(outs[True]["joints_3d_abs"]).all()
+
+
+def test_eval_pose_assembly_kernel_matches_the_module_arithmetic():
+    """M4 in eval mode: ab_pose_assemble (one launch) == the tensor-op restatement of hybridbaseline.py:49-96 in models.forward, for all
+    nine output keys, on a row-pitched box-head output and non-trivial intrinsics."""
+    size, heat, seed, B = 64, 8, 9, 5
+    model, _, _ = build(size, heat, "bf16x3", seed, SEGMENT_GRAPHS=False)
+    hb = model.model_list[0]
+    model.eval()
+    batch = make_batch(B, size, seed + 1)
+    outs = {}
+    for fused in (True, False):
+        hb.fused_assembly = fused
+        with torch.no_grad():
+            outs[fused] = {k: v.detach().float().cpu().numpy() for k, v in model(batch)["HybridBaseline"].items()}
+    assert set(outs[True]) == set(outs[False])
+    for k in outs[False]:
+        assert outs[True][k].shape == outs[False][k].shape, k
+        np.testing.assert_allclose(outs[True][k], outs[False][k], rtol=2e-6, atol=2e-7, err_msg=k)
