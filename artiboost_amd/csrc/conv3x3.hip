@@ -319,41 +319,53 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         static_assert(NT % CPRF == 0, "a thread keeps one channel group over all its rows");
         float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (X3 == 3) {
+            // a thread owns one 8-channel group over its rows: two 16-byte staging reads -> one 16-byte store per plane
             bf16_t* __restrict__ OutHi = (bf16_t*)g.Out;
             bf16_t* __restrict__ OutLo = (bf16_t*)g.Out_lo;
             const bf16_t* __restrict__ RH = (const bf16_t*)g.res_hi;
             const bf16_t* __restrict__ RL = (const bf16_t*)g.res_lo;
-            const int c4 = tid % CPRF, col = n0 + c4 * 4;               // NT % CPRF == 0: a thread keeps its channel group
+            constexpr int CPR8 = BN / 8;
+            static_assert(NT % CPR8 == 0, "a thread keeps one channel group over all its rows");
+            const int c8 = tid % CPR8, col = n0 + c8 * 8;
             const bool cok = col < g.Cn;
-            float sc[4], sh[4];
+            float sc[8], sh[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { sc[k] = cok ? g.bnp[col + k] : 0.f; sh[k] = cok ? g.bnp[g.Cn + col + k] : 0.f; }
-            for (int row = tid / CPRF; row < BM; row += NT / CPRF) {
+            for (int k = 0; k < 8; ++k) { sc[k] = cok ? g.bnp[col + k] : 0.f; sh[k] = cok ? g.bnp[g.Cn + col + k] : 0.f; }
+            for (int row = tid / CPR8; row < BM; row += NT / CPR8) {
                 const int yy = ty0 + row / TW, xx = tx0 + row % TW;
                 if (yy < g.H && xx < g.W && cok) {
-                    const float4 v4 = *(const float4*)(smem + row * SPF + c4 * 16);
+                    const float4 va = *(const float4*)(smem + row * SPF + c8 * 32), vb = *(const float4*)(smem + row * SPF + c8 * 32 + 16);
                     const long o = (((long)img * g.H + yy) * g.W + xx) * g.Cn + col;
-                    float v[4] = {v4.x * sc[0] + sh[0], v4.y * sc[1] + sh[1], v4.z * sc[2] + sh[2], v4.w * sc[3] + sh[3]};
+                    float v[8] = {va.x * sc[0] + sh[0], va.y * sc[1] + sh[1], va.z * sc[2] + sh[2], va.w * sc[3] + sh[3],
+                                  vb.x * sc[4] + sh[4], vb.y * sc[5] + sh[5], vb.z * sc[6] + sh[6], vb.w * sc[7] + sh[7]};
                     if (RH) {
-                        const uint2 h2 = *(const uint2*)(RH + o), l2 = *(const uint2*)(RL + o);
-                        v[0] += __uint_as_float(h2.x << 16) + __uint_as_float(l2.x << 16);
-                        v[1] += __uint_as_float(h2.x & 0xffff0000u) + __uint_as_float(l2.x & 0xffff0000u);
-                        v[2] += __uint_as_float(h2.y << 16) + __uint_as_float(l2.y << 16);
-                        v[3] += __uint_as_float(h2.y & 0xffff0000u) + __uint_as_float(l2.y & 0xffff0000u);
+                        const uint4 h4 = *(const uint4*)(RH + o), l4 = *(const uint4*)(RL + o);
+                        const uint32_t hw[4] = {h4.x, h4.y, h4.z, h4.w}, lw[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            v[2 * k] += __uint_as_float(hw[k] << 16) + __uint_as_float(lw[k] << 16);
+                            v[2 * k + 1] += __uint_as_float(hw[k] & 0xffff0000u) + __uint_as_float(lw[k] & 0xffff0000u);
+                        }
                     } else if (AddF) {
-                        const float4 a = *(const float4*)(AddF + o);
-                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                        const float4 a0 = *(const float4*)(AddF + o), a1 = *(const float4*)(AddF + o + 4);
+                        v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
                     }
                     if (g.ep_relu) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
                     }
-                    uint2 h, l;
-                    h.x = pack_bf16x2(v[0], v[1]); h.y = pack_bf16x2(v[2], v[3]);
-                    l.x = pack_bf16x2(v[0] - __uint_as_float(h.x << 16), v[1] - __uint_as_float(h.x & 0xffff0000u));
-                    l.y = pack_bf16x2(v[2] - __uint_as_float(h.y << 16), v[3] - __uint_as_float(h.y & 0xffff0000u));
-                    *(uint2*)(OutHi + o) = h; *(uint2*)(OutLo + o) = l;
-                    if (g.OutF) *(float4*)(g.OutF + o) = make_float4(v[0], v[1], v[2], v[3]);
+                    uint32_t h[4], l[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        h[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+                        l[k] = pack_bf16x2(v[2 * k] - __uint_as_float(h[k] << 16), v[2 * k + 1] - __uint_as_float(h[k] & 0xffff0000u));
+                    }
+                    *(uint4*)(OutHi + o) = make_uint4(h[0], h[1], h[2], h[3]);
+                    *(uint4*)(OutLo + o) = make_uint4(l[0], l[1], l[2], l[3]);
+                    if (g.OutF) {
+                        *(float4*)(g.OutF + o) = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)(g.OutF + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
                 }
             }
             return;

@@ -96,7 +96,7 @@ extern "C" int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* 
 // residual: (res_hi, res_lo) planes, or the fp32 tensor res_f32, or none.  AB_ESHAPE when the 3x3 kernel does not take the shape
 // (the caller then runs ab_conv2d_fwd_x3 + ab_bn_apply_x3; results are bit-identical either way).
 extern "C" int ab_conv2d_fwd_x3_evalbn_ok(int N, int H, int W, int Cin, int Cout) {
-    return conv3x3_x3_tiles(N, H, W, Cin, Cout) > 0 && Cout % 4 == 0;
+    return conv3x3_x3_tiles(N, H, W, Cin, Cout) > 0 && Cout % 8 == 0;
 }
 
 extern "C" int ab_conv2d_fwd_x3_evalbn(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, int N, int H, int W,

@@ -219,7 +219,8 @@ class ParamStore:
             if not grads and pre is not None and pre + ".running_mean" in self.buffers:
                 out[pre + ".running_mean"] = self.stat(pre + ".running_mean").clone()
                 out[pre + ".running_var"] = self.stat(pre + ".running_var").clone()
-                out[pre + ".num_batches_tracked"] = torch.tensor(int(self.num_batches_tracked), dtype=torch.int64)
+                if not (getattr(self, "frozen_bn", False) and pre.startswith("backbone.")):     # FrozenBatchNorm2d keeps no counter (resnet.py:45-55)
+                    out[pre + ".num_batches_tracked"] = torch.tensor(int(self.num_batches_tracked), dtype=torch.int64)
         return out
 
     def init_reference_like(self, seed=1):
@@ -260,6 +261,7 @@ class HybridNet:
         self.x3 = compute_dtype in ("bf16x3", "x3")           # split-bf16 convolutions on fp32 tensors
         self.dtype = torch.float32 if self.x3 else compute_dtype
         self.training = True
+        self.frozen_bn = False   # BACKBONE.FREEZE_BATCHNORM: backbone BatchNorms are fixed affine maps (resnet.py:33-69, 146-149)
         self.lp = None           # low-precision copy of the flat params (bf16 mode)
         self.tr = {}             # IHWO (data-gradient) copies of conv weights in the compute dtype
         self._packed = False
@@ -354,14 +356,36 @@ class HybridNet:
             return K.conv2d_dgrad_x3(dy, self.tr[name], in_hw, stride, pad, addend=addend, want_stats=want_stats, bn=bn)
         return K.conv2d_dgrad(dy, self.tr[name], in_hw, stride, pad, addend=addend, bn=bn, want_stats=want_stats)
 
+    # bf16x3, AB_WGRAD_1PASS=1 (a precision / speed STUDY, never the default -- DESIGN 12.1): weight gradients from the hi planes only
+    # (one MFMA pass, bf16 operands, fp32 accumulate).  Their rounding does not propagate (nothing consumes a weight gradient but Adam).
+    wgrad_1pass = os.environ.get("AB_WGRAD_1PASS", "0") == "1"
+
     def _conv_wgrad(self, x, dy, kh, kw, stride, pad, out=None, **kws):
+        if self.x3 and self.wgrad_1pass:
+            return K.conv2d_wgrad(K._planes(x)[0], K._planes(dy)[0], kh, kw, stride, pad, out=out, **kws)
         if self.x3:
             return K.conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=out, **kws)
         return K.conv2d_wgrad(x, dy, kh, kw, stride, pad, out=out, **kws)
 
     # ------------------------------------------------------------------ BN helper
+    def _frozen(self, prefix):
+        return self.frozen_bn and prefix.startswith("backbone.")
+
+    def _zero_part(self, C):
+        """BatchNorm-backward partial sums of a FROZEN BatchNorm: zero, so that ab_bn_bwd* yields dy = scale * dz and zero parameter
+        gradients (FrozenBatchNorm2d has no learnable state: its weight / bias are buffers)."""
+        z = getattr(self, "_zparts", None)
+        if z is None:
+            z = self._zparts = {}
+        if C not in z:
+            z[C] = torch.zeros((1, C, 2), dtype=torch.float32, device=self.p.device)
+        return z[C]
+
     def _bn_params(self, prefix, stats_part, count):
         p = self.p
+        if self.training and self._frozen(prefix):
+            return K.bn_eval_params(p.view(prefix + ".weight"), p.view(prefix + ".bias"),
+                                    p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
         if self.training:
             return K.bn_finalize(stats_part, count, p.view(prefix + ".weight"), p.view(prefix + ".bias"),
                                  p.stat(prefix + ".running_mean"), p.stat(prefix + ".running_var"))
@@ -405,6 +429,15 @@ class HybridNet:
     def _bn_bwd(self, *a, **kw):
         """BatchNorm backward; the gradient wrt the conv output goes to convolutions only: split planes under bf16x3.
         bf16x3 with `part`: the data gradient that produced the input already masked and reduced it (conv3x3.hip, X3 = 2)."""
+        if kw.pop("frozen", False):
+            # frozen BatchNorm: no batch statistics took part in the forward, so dy = scale * (masked gradient) -- the regular passes with
+            # all-zero partial sums (and dgamma = dbeta = 0).  A fused reduction that arrived with the gradient is simply not used.
+            C = a[2].shape[-1]
+            premasked = kw.get("part") is not None
+            kw["part"] = self._zero_part(C)
+            if self.x3:
+                return K.bn_bwd_x3(*a, premasked=premasked, **kw)
+            return K.bn_bwd(*a, **kw)
         if self.x3:
             return K.bn_bwd_x3(*a, premasked=kw.get("part") is not None, **kw)
         return K.bn_bwd(*a, **kw)
@@ -684,19 +717,20 @@ class HybridNet:
         for k, rec in enumerate(blocks):
             pre, stride, x = rec["pre"], rec["stride"], rec["x"]
             nxt = blocks[k + 1] if k + 1 < len(blocks) else below
+            fz = self._frozen(pre)
             dy2, dz = self._bn_bwd(dout, rec["out"], rec["y2"], rec["bnp2"], gv(pre + ".bn2.weight"), gv(pre + ".bn2.bias"),
-                               relu=True, want_dz=True, part=dout_part)
+                               relu=True, want_dz=True, part=dout_part, frozen=fz)
             self._wgrad_side(self._conv_wgrad, rec["a1"], dy2, 3, 3, 1, 1, out=gv(pre + ".conv2.weight"))
             # the BN-backward reduction of bn1 rides in the epilogue of the data gradient that produces its input
             da1, part1 = self._conv_dgrad(dy2, pre + ".conv2.weight", (dy2.shape[-3], dy2.shape[-2]), 1, 1,
                                           bn=(rec["y1"], None, rec["bnp1"]))
             dy1 = self._bn_bwd(da1, rec["a1"], rec["y1"], rec["bnp1"], gv(pre + ".bn1.weight"), gv(pre + ".bn1.bias"),
-                            relu="recompute", part=part1)
+                            relu="recompute", part=part1, frozen=fz)
             self._wgrad_side(self._conv_wgrad, x, dy1, 3, 3, stride, 1, out=gv(pre + ".conv1.weight"))
             bn_below = (nxt["y2"], nxt["out"], nxt["bnp2"]) if nxt is not None else None
             if rec["ds"]:
                 dyd = self._bn_bwd(dz, None, rec["yd"], rec["bnpd"], gv(pre + ".downsample.1.weight"),
-                               gv(pre + ".downsample.1.bias"), relu=False)
+                               gv(pre + ".downsample.1.bias"), relu=False, frozen=fz)
                 self._wgrad_side(self._conv_wgrad, x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
                 if self.x3 and stride == 2 and self.pair_dgrad:      # both branches in one launch (the 1x1 as a tap of the 3x3/s2)
                     dout = K.conv2d_dgrad_x3_pair(dy1, self.tr[pre + ".conv1.weight"], dyd, self.tr[pre + ".downsample.0.weight"],
@@ -718,7 +752,11 @@ class HybridNet:
         dout, _ = self._backward_blocks(dout, blocks, dout_part)
         # ---- stem
         dy0 = None
-        if self.x3 and self.fuse_stem and self.stem_pool_reduce:
+        if self.frozen_bn:      # frozen stem BatchNorm: max-pool backward, then the apply pass with zero partial sums (no fused reduction)
+            y0 = S["y0"]
+            da0 = K.maxpool_bwd(S["pool_idx"], dout, (y0.shape[1], y0.shape[2]))
+            dy0 = self._bn_bwd(da0, None, y0, S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"), relu="recompute", frozen=True)
+        elif self.x3 and self.fuse_stem and self.stem_pool_reduce:
             # the max-pool backward pass also masks and reduces for the stem BatchNorm (AB_STEM_POOL_REDUCE=0: separate passes)
             dy0 = K.bn_relu_maxpool_bwd_x3(dout, S["pool_idx"], S["y0"], S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"),
                                            ywin=S.get("pool_ywin"))
@@ -731,6 +769,9 @@ class HybridNet:
             da0 = K.maxpool_bwd(S["pool_idx"], dout, (y0.shape[1], y0.shape[2]))
             dy0 = self._bn_bwd(da0, None, y0, S["bnp0"], gv("backbone.bn1.weight"), gv("backbone.bn1.bias"), relu="recompute")
         H, W = S["HW"]
-        self._wgrad_side(K.conv2d_stem_wgrad_x3 if self.x3 else K.conv2d_stem_wgrad, S["xpad"], dy0, H, W, out=gv("backbone.conv1.weight"))
+        if self.x3 and self.wgrad_1pass:
+            self._wgrad_side(K.conv2d_stem_wgrad, K._planes(S["xpad"])[0], K._planes(dy0)[0], H, W, out=gv("backbone.conv1.weight"))
+        else:
+            self._wgrad_side(K.conv2d_stem_wgrad_x3 if self.x3 else K.conv2d_stem_wgrad, S["xpad"], dy0, H, W, out=gv("backbone.conv1.weight"))
         self._wgrad_join()
         self.saved = None

@@ -156,8 +156,6 @@ class HybridBaseline(nn.Module):
             raise NotImplementedError("the HIP path implements the ResNet34 backbone of the clasbased configs")
         if head.get("NORM_TYPE", "softmax") != "softmax" or head.get("FINAL_CONV_KERNEL", 1) != 1:
             raise NotImplementedError("IntegralDeconvHead: softmax norm + 1x1 final conv only")
-        if cfg["BACKBONE"].get("FREEZE_BATCHNORM", False):
-            raise NotImplementedError("FREEZE_BATCHNORM")
         if cfg["BACKBONE"].get("PRETRAINED") is True:
             # resnet.py:249-262 fetches torchvision's ImageNet weights (a download); here the backbone keeps its seeded
             # initialisation unless ARCH.PRETRAINED names a checkpoint in the reference's state-dict layout
@@ -171,6 +169,9 @@ class HybridBaseline(nn.Module):
         self.net = HybridNet(self.store, image_size=self.inp_res,
                              compute_dtype=(torch.bfloat16 if cd in ("bf16", torch.bfloat16) else
                                             "bf16x3" if cd in ("bf16x3", "x3") else torch.float32))
+        # BACKBONE.FREEZE_BATCHNORM (resnet.py:146-149: bn_layer = FrozenBatchNorm2d): the backbone's BatchNorms are fixed affine maps in
+        # both modes, their weight / bias receive no gradient (zero gradient -> Adam leaves them) and carry no num_batches_tracked
+        self.net.frozen_bn = self.store.frozen_bn = bool(cfg["BACKBONE"].get("FREEZE_BATCHNORM", False))
         self.flat_param = nn.Parameter(self.store.flat, requires_grad=True)   # shares storage with the store
         self.flat_param._ab_owner = self                                      # netutils.build_optimizer recognises it
         self.segment_graphs = bool(cfg.get("SEGMENT_GRAPHS", os.environ.get("AB_SEGMENT_GRAPHS", "1") != "0"))

@@ -446,6 +446,9 @@ def main():
     ap.add_argument("--sustain", type=float, default=3.0,
                     help="seconds of the sustained block run after the timed steps (extra keys of the line; 0 = off)")
     ap.add_argument("--no-eval-leg", action="store_true", help="skip the configs[1] eval-forward sub-object of the default line")
+    ap.add_argument("--wgrad-1pass", action="store_true",
+                    help="PRECISION STUDY, not a parity configuration (DESIGN 12.1): weight gradients from the hi planes only (one bf16 MFMA "
+                         "pass instead of three); the line's dtype says so")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` is the whole multi-GPU command (the reference's is `train_artiboost.py --gpu_id 0,1,..`,
@@ -461,6 +464,8 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
 
+    if args.wgrad_1pass:
+        os.environ["AB_WGRAD_1PASS"] = "1"          # read when artiboost_amd.hybridnet is imported (below)
     import torch
     if args.dry_launch:
         world = int(os.environ.get("WORLD_SIZE", 1))
@@ -577,8 +582,10 @@ def main():
             base = cpu_baseline(args, cfg)
         out = {"metric": f"synth samples/sec (render+fwd+bwd) {args.size}x{args.size} bs={args.bs}", "value": round(value, 2), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-               "dtype_note": DTYPE_NOTE[args.dtype],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": args.dtype + ("+wgrad_bf16_1pass" if args.wgrad_1pass else ""),
+               "dtype_note": DTYPE_NOTE[args.dtype] + ("; STUDY: weight gradients from bf16 (hi-plane) operands in one MFMA pass -- below the "
+                                                        "reference's operand precision, not a parity configuration" if args.wgrad_1pass else ""),
                "data": "synthetic (seeded stand-in meshes/textures/grasps; random-init weights)",
                "config": {"workload": f"train_artiboost HO3Dv2-clasbased (HybridBaseline/ResNet-34, 22x28x{args.size // 8}x{args.size // 8} heat-map) "
                                       f"+ online CCV render 512->{args.size}, per-GPU batch {args.bs}, {args.dataset}-like objects",

@@ -120,8 +120,12 @@ def _bn(x, p, prefix, training, eps=1e-5, momentum=0.1, stats=None):
     return (x - mean[None, :, None, None]) * (inv * w)[None, :, None, None] + b[None, :, None, None]
 
 
-def resnet34_forward(p, image, training=True, stats=None, feats=None):
-    """ResNet.forward (resnet.py:199-221) with BasicBlock.forward (resnet.py:85-101)."""
+def resnet34_forward(p, image, training=True, stats=None, feats=None, frozen_bn=False):
+    """ResNet.forward (resnet.py:199-221) with BasicBlock.forward (resnet.py:85-101).
+    frozen_bn: BACKBONE.FREEZE_BATCHNORM (resnet.py:146-149 bn_layer = FrozenBatchNorm2d, resnet.py:33-69): every backbone BatchNorm is the
+    fixed affine map scale = w * rsqrt(running_var + 1e-5), bias = b - running_mean * scale in BOTH modes (weight / bias are buffers)."""
+    if frozen_bn:
+        training = False
     x = F.conv2d(image, p["backbone.conv1.weight"], stride=2, padding=3)
     x = F.relu(_bn(x, p, "backbone.bn1", training, stats=stats))
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
@@ -213,11 +217,11 @@ def box_head_forward(p, x):
     return F.linear(x, p["box_head.layers.4.weight"], p["box_head.layers.4.bias"])
 
 
-def hybrid_forward(p, batch, inp_res, nclasses=22, depth=28, center_idx=0, training=True, stats=None, keep=None):
+def hybrid_forward(p, batch, inp_res, nclasses=22, depth=28, center_idx=0, training=True, stats=None, keep=None, frozen_bn=False):
     """HybridBaseline.forward (hybridbaseline.py:37-96)."""
     image = batch["image"]
     H, W = image.shape[2], image.shape[3]
-    feat, feat_mean = resnet34_forward(p, image, training, stats=stats, feats=keep)
+    feat, feat_mean = resnet34_forward(p, image, training, stats=stats, feats=keep, frozen_bn=frozen_bn)
     kp3d, conf = head_forward(p, feat, nclasses, depth, training, stats=stats, keep=keep)
     box6d = box_head_forward(p, feat_mean)
     pose_abs = uvd2xyz(kp3d, batch["root_joint"], batch["cam_intr"], inp_res)

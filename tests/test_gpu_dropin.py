@@ -15,7 +15,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_reference_epoch_pass_sequence_two_epochs(tmp_path, monkeypatch):
+@pytest.mark.parametrize("segment_graphs", ["1", "0"])
+def test_reference_epoch_pass_sequence_two_epochs(tmp_path, monkeypatch, segment_graphs):
+    # "0": the loop issued kernel by kernel through torch.ops.artiboost_hip.* (no hipGraph inside the model): same sequence, same checks
+    monkeypatch.setenv("AB_SEGMENT_GRAPHS", segment_graphs)
     monkeypatch.setattr(sys, "argv", ["train_artiboost.py", "--cfg", os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml"),
                                       "--batch_size", "8", "--gpu_render_id", "0", "--exp_id", "default"])
     for m in [k for k in sys.modules if k == "anakin.opt" or k == "anakin.opt_extra"]:

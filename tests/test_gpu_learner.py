@@ -240,3 +240,57 @@ def test_eval_pose_assembly_kernel_matches_the_module_arithmetic():
     for k in outs[False]:
         assert outs[True][k].shape == outs[False][k].shape, k
         np.testing.assert_allclose(outs[True][k], outs[False][k], rtol=2e-6, atol=2e-7, err_msg=k)
+
+
+def test_frozen_batchnorm_backbone_matches_oracle():
+    """BACKBONE.FREEZE_BATCHNORM: true (anakin/models/resnet.py:33-69,146-149: FrozenBatchNorm2d in every backbone slot) in TRAINING mode:
+    the backbone BatchNorms are fixed affine maps of the running statistics, the head's stay ordinary BatchNorm2d.  Forward, losses and the
+    gradient of every parameter vs the torch-CPU oracle with the same semantics; frozen weight / bias get zero gradient, running statistics
+    of the backbone do not move, the state dict carries no num_batches_tracked for them."""
+    size, heat, seed, B = 64, 8, 21, 4
+    model, crit, params = build(size, heat, "bf16x3", seed, SEGMENT_GRAPHS=False,
+                                BACKBONE={"TYPE": "ResNet34", "PRETRAINED": False, "FREEZE_BATCHNORM": True})
+    hb = model.model_list[0]
+    g = torch.Generator().manual_seed(seed)
+    sd = {k: v.clone() for k, v in params.items()}
+    for k in sd:                                            # non-trivial frozen statistics and affine parameters
+        if k.startswith("backbone.") and k.endswith("running_mean"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        elif k.startswith("backbone.") and k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(sd[k].shape, generator=g)
+    hb.load_state_dict(sd)
+    stats0 = hb.store.stats.clone()
+    batch = make_batch(B, size, seed + 100)
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in sd.items()}
+    random.seed(3); torch.manual_seed(3)
+    preds_r = lo.hybrid_forward(leaf, batch, [size, size], 22, 28, 0, training=True, frozen_bn=True)
+    total_r, losses_r, _ = lo.criterion(preds_r, batch)
+    total_r.backward()
+    model.train()
+    preds = model(batch)["HybridBaseline"]
+    random.seed(3); torch.manual_seed(3)
+    total, losses = crit.compute_losses(preds, batch)
+    total.backward()
+    for k in ("joints_3d_abs", "corners_3d_abs"):
+        np.testing.assert_allclose(preds[k].detach().cpu().numpy(), preds_r[k].detach().numpy(), rtol=0, atol=2e-4, err_msg=k)
+    np.testing.assert_allclose(float(total), float(total_r), rtol=3e-4)
+    grads = hb.store.reference_state_dict(grads=True)
+    bad = []
+    for k, v in leaf.items():
+        if not (v.dtype.is_floating_point and v.requires_grad) or k.startswith("backbone.fc"):
+            continue
+        gr = v.grad if v.grad is not None else torch.zeros_like(v)
+        if k.startswith("backbone.") and (".bn" in k or "downsample.1" in k):
+            assert float(grads[k].abs().max()) == 0.0, k                       # frozen: buffers in the reference, zero gradient here
+            continue
+        a, r = float(grads[k].cpu().norm()), float(gr.norm())
+        if abs(a - r) > 1.5e-2 * r + 1e-12:
+            bad.append((k, a, r))
+    assert not bad, bad[:5]
+    # the backbone's running statistics did not move; the head's (ordinary BatchNorm2d) did
+    off = {k: hb.store.buffers[k] for k in hb.store.buffers}
+    for k, (o, c) in off.items():
+        moved = not torch.equal(hb.store.stats[o:o + c], stats0[o:o + c])
+        assert moved == (not k.startswith("backbone.")), k
+    keys = set(hb.state_dict())
+    assert "backbone.layer1.0.bn1.num_batches_tracked" not in keys and "hybrid_head.deconv_layers.1.num_batches_tracked" in keys
