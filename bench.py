@@ -30,9 +30,13 @@ DTYPE_NOTE = {"bf16x3": "fp32 conv outputs/gradients/BatchNorm/optimizer; post-a
               "f32": "exact f32 MFMA everywhere", "bf16": "bf16 operands and activations (misses the 1e-3 parity bound)"}
 
 
-def ref_cfg(size):
+CFG_OF = {"HO3D": "ho3dv2_clasbased_artiboost_mi355x.yaml",             # BASELINE configs[2] / [3]
+          "DexYCB": "dexycb_clasbased_sym_mi355x.yaml"}                  # BASELINE configs[4]: 21 objects, + SymCornerLoss
+
+
+def ref_cfg(size, dataset="HO3D"):
     import yaml
-    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", CFG_OF[dataset])))
     cfg["DATA_PRESET"]["IMAGE_SIZE"] = [size, size]
     cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [size // 8, size // 8]
     cfg["ARCH"]["BACKBONE"]["PRETRAINED"] = False       # ImageNet weights are a download; random init (stated in `data`)
@@ -48,7 +52,7 @@ def build_everything(args, rank, world, device):
     from artiboost_amd.optim import FusedClipAdam
     from artiboost_amd.synth import ArtiBoostLoader
     from artiboost_amd.train import TrainStep
-    cfg = ref_cfg(args.size)
+    cfg = ref_cfg(args.size, args.dataset)
     arch_cfg = dict(cfg["ARCH"], COMPUTE_DTYPE=args.dtype, DEVICE=device, INIT_SEED=cfg["TRAIN"]["MANUAL_SEED"])
     model = Arch({"ARCH": arch_cfg}, R.build_arch_model_list(arch_cfg, preset_cfg=cfg["DATA_PRESET"]))
     crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
@@ -72,6 +76,35 @@ def build_everything(args, rank, world, device):
     args.render_overlap = bool(overlap)
     ts.static = static
     return cfg, model, crit, opt, loader, ts, static
+
+
+def dexycb_leg(args, device, steps=10, warmup=3):
+    """BASELINE configs[4] on ONE GPU (its 8-GPU form is this step under the data-parallel schedule of configs[3]): DexYCB-like scenes
+    (21 objects at 16 k faces) and the DexYCB criterion list (+ SymCornerLoss in the fused pose/loss kernel), same geometry and precision."""
+    import copy
+    import torch
+    a = copy.copy(args)
+    a.dataset, a.steps, a.warmup, a.pipeline, a.pipeline_opt = "DexYCB", steps, warmup, False, False
+    cfg, model, crit, opt, loader, ts, static = build_everything(a, 0, 1, device)
+    nb = len(loader)
+    ts.prime(loader, 0)
+    for i in range(warmup):
+        ts.stage(loader, i % nb)
+        ts()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ts.stage(loader, (warmup + i) % nb)
+        ts()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ld = ts.fused.losses_dict() if ts.fused is not None else {}
+    return {"metric": f"synth samples/sec (render+fwd+bwd) {args.size}x{args.size} bs={args.bs}", "value": round(args.bs * steps / dt, 1),
+            "unit": "samples/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "n_gpus": 1,
+            "workload": f"train_artiboost DexYCB clasbased_sym ({CFG_OF['DexYCB']}: 21 objects at 16 k faces, JointsLoss + HandOrdLoss + SceneOrdLoss + "
+                        f"SymCornerLoss) + online CCV render 512->{args.size}, batch {args.bs}, {args.dtype}",
+            "final_loss": float(ld["final_loss"]) if "final_loss" in ld else None,
+            "sym_corners_3d_loss": float(ld["sym_corners_3d_loss"]) if "sym_corners_3d_loss" in ld else None}
 
 
 def conv_kernel_time_ms(ts, loader, static, iters=3):
@@ -446,6 +479,7 @@ def main():
     ap.add_argument("--sustain", type=float, default=3.0,
                     help="seconds of the sustained block run after the timed steps (extra keys of the line; 0 = off)")
     ap.add_argument("--no-eval-leg", action="store_true", help="skip the configs[1] eval-forward sub-object of the default line")
+    ap.add_argument("--no-dexycb-leg", action="store_true", help="skip the configs[4]-on-one-GPU sub-object of the default line")
     ap.add_argument("--wgrad-1pass", action="store_true",
                     help="PRECISION STUDY, not a parity configuration (DESIGN 12.1): weight gradients from the hi planes only (one bf16 MFMA "
                          "pass instead of three); the line's dtype says so")
@@ -577,6 +611,12 @@ def main():
                 ev = eval_forward(args, model, static)
             except Exception as e:   # noqa: BLE001
                 ev = {"error": repr(e)}
+        dex = None
+        if world == 1 and args.dataset == "HO3D" and not args.no_dexycb_leg and not args.eager:
+            try:
+                dex = dexycb_leg(args, device)
+            except Exception as e:   # noqa: BLE001
+                dex = {"error": repr(e)}
         roof["peak_note"] = ("dense bf16 MFMA peak / 3 passes" if args.dtype == "bf16x3" else "dense MFMA peak of the operand type")
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(args, cfg)
@@ -595,7 +635,8 @@ def main():
                "final_loss": losses[5] if losses else None,
                "roofline": roof, "cpu_baseline": base,
                "sustained": sustained,                 # same process, >= --sustain seconds after the timed block (+ observed sclk / power)
-               "configs1_eval_forward": ev}            # BASELINE configs[1] (forward only) with its own roofline; `bench.py --eval` prints it as the line
+               "configs1_eval_forward": ev,            # BASELINE configs[1] (forward only) with its own roofline; `bench.py --eval` prints it as the line
+               "configs4_dexycb_1gpu": dex}            # BASELINE configs[4]'s per-GPU step (DexYCB scenes + SymCornerLoss) on this one GPU
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
