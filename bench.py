@@ -78,6 +78,52 @@ def build_everything(args, rank, world, device):
     return cfg, model, crit, opt, loader, ts, static
 
 
+def hbm_rooflines(args, loader, static, model):
+    """The two HBM-bound halves of the step against the HBM roof (north_star: "rocprof HBM GB/s (rasterizer)"), measured live with HIP
+    events on the compute stream; ALGORITHMIC bytes per sample from SURVEY.md section 8d: render chain (LBS output -> raster -> shade ->
+    composite -> augment) 2.0 MB, soft-argmax head 2.52 MB forward + 2 x 2.52 MB backward at 256^2 (1.93 MB at 224^2).
+    The committed PMC passes (profiles/) give the bytes these kernels actually move."""
+    import torch
+    from artiboost_amd.head import softargmax3d_fwd, softargmax3d_bwd_x3, softargmax3d_bwd
+    out = {}
+
+    def timed(fn, n=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e-3
+
+    t = timed(lambda: loader.render_into(static))
+    byts = 2.0e6 * args.bs
+    out["render"] = {"bound": "hbm", "achieved": round(byts / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(byts / t / 8e12, 4),
+                     "traffic": None, "ms": round(t * 1e3, 3),
+                     "kernel": "render chain: raster_setup, raster_shade (512^2, LDS z-buffer), gauss_blur, jitter_stats, warp_jitter -- latency / VALU bound "
+                               "(LDS atomics, dependent texel fetches, PIL's HSV arithmetic), the reference's full-frame-then-crop flow moves 4.5x these bytes"}
+    hb = model.model_list[0]
+    C, D, DP = hb.nclasses, hb.depth_res, 32
+    hw = args.size // 8
+    logits = torch.randn((args.bs, hw, hw, C * DP), dtype=torch.float32, device=static["image_nhwc4_padded"].device)
+    uvd, conf, stat = softargmax3d_fwd(logits, C, D, DP)
+    g = torch.randn_like(uvd)
+    tf = timed(lambda: softargmax3d_fwd(logits, C, D, DP))
+    if hb.net.x3:
+        tb = timed(lambda: softargmax3d_bwd_x3(logits, C, D, DP, uvd, conf, stat, g))
+    else:
+        tb = timed(lambda: softargmax3d_bwd(logits, C, D, DP, uvd, conf, stat, g))
+    per = 22 * 28 * hw * hw * 4.0 * args.bs
+    out["softargmax"] = {"bound": "hbm", "achieved": round(3 * per / (tf + tb) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(3 * per / (tf + tb) / 8e12, 4), "traffic": None, "ms_fwd": round(tf * 1e3, 3), "ms_bwd": round(tb * 1e3, 3),
+                         "kernel": "sam_stage1/2 (logits read once) + sam_bwd (logits read once, dlogits written once; depth pitch 32: the kernels "
+                                   "move 32/28 of the algorithmic bytes)"}
+    return out
+
+
 def dexycb_leg(args, device, steps=10, warmup=3):
     """BASELINE configs[4] on ONE GPU (its 8-GPU form is this step under the data-parallel schedule of configs[3]): DexYCB-like scenes
     (21 objects at 16 k faces) and the DexYCB criterion list (+ SymCornerLoss in the fused pose/loss kernel), same geometry and precision."""
@@ -611,6 +657,11 @@ def main():
                 ev = eval_forward(args, model, static)
             except Exception as e:   # noqa: BLE001
                 ev = {"error": repr(e)}
+        hbm = None
+        try:
+            hbm = hbm_rooflines(args, loader, static, model)
+        except Exception as e:   # noqa: BLE001
+            hbm = {"error": repr(e)}
         dex = None
         if world == 1 and args.dataset == "HO3D" and not args.no_dexycb_leg and not args.eager:
             try:
@@ -634,6 +685,7 @@ def main():
                           "render_overlap": bool(getattr(args, "render_overlap", False))},
                "final_loss": losses[5] if losses else None,
                "roofline": roof, "cpu_baseline": base,
+               "roofline_hbm_kernels": hbm,            # the HBM-bound halves (render chain, soft-argmax head) against the 8 TB/s roof
                "sustained": sustained,                 # same process, >= --sustain seconds after the timed block (+ observed sclk / power)
                "configs1_eval_forward": ev,            # BASELINE configs[1] (forward only) with its own roofline; `bench.py --eval` prints it as the line
                "configs4_dexycb_1gpu": dex}            # BASELINE configs[4]'s per-GPU step (DexYCB scenes + SymCornerLoss) on this one GPU
