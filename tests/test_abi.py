@@ -86,3 +86,26 @@ def test_only_tests_smoke_and_cpu_baseline_touch_the_oracle():
     bad += offenders(os.path.join(root, "bench.py"), allowed_funcs=("cpu_baseline",))
     bad += offenders(os.path.join(root, "__graft_entry__.py"), allowed_funcs=("smoke",))
     assert not bad, bad
+
+
+def _build_c_host(outdir):
+    """gcc (plain C, no torch, no Python) on tests/c_host/abi_host_test.c against include/artiboost_hip.h + libartiboost_hip.so."""
+    import subprocess
+    from artiboost_amd import _lib as L
+    from artiboost_amd import build
+    build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(outdir), "abi_host_test")
+    libdir = os.path.dirname(L.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", os.path.join(root, "tests", "c_host", "abi_host_test.c"), "-I", os.path.join(root, "include"),
+           "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L", libdir, "-lartiboost_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_header_is_plain_c_and_links_from_a_c_host(tmp_path):
+    """The boundary has no torch (or C++) types in it: a C99 translation unit including include/artiboost_hip.h compiles with
+    -Wall -Werror and links against the shared library (the GPU run of the same binary is tests/test_gpu_head.py)."""
+    assert os.path.exists(_build_c_host(tmp_path))

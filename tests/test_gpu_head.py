@@ -100,3 +100,13 @@ def test_softargmax_bwd_x3_bias_sums(shape, with_conf):
     ref = full.double().sum((0, 1, 2))
     scale = float(full.abs().double().sum((0, 1, 2)).max()) + 1e-30
     assert float((dbias.double() - ref).abs().max()) <= 2e-6 * scale
+
+
+def test_c_abi_from_a_plain_c_host(tmp_path):
+    """No Python, no torch between the caller and the kernels: tests/c_host/abi_host_test.c (hipMalloc, its own stream) calls
+    ab_softargmax3d_fwd and ab_split_f32 through the C ABI and checks them against arithmetic restated from the reference formulas."""
+    import subprocess
+    from test_abi import _build_c_host
+    exe = _build_c_host(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "C_ABI_HOST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
