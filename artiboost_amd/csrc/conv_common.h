@@ -30,6 +30,9 @@ struct ConvGemmArgs {
     // convolution next to it as one more tap of parity class (even, even).
     const void* A2; const void* A2_lo; const void* Bw2; const void* Bw2_lo;
     int alt_tap1, ktot2;
+    // conv_gemm2 X3 only, eval-mode forwards: per-channel affine of the BatchNorm that follows -- out = relu?(acc * ep_scale[c] + bias[c])
+    // (`bias` carries the shift) -- and, when out_hi != NULL, the result leaves as (hi, lo) bf16 planes instead of fp32 `Out`
+    const float* ep_scale; void* out_hi; void* out_lo;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -268,12 +268,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
             const int col = n0 + cl;
             const bool cok = col < g.Cn;
             const float bj = (g.bias && cok) ? g.bias[col] : 0.f;
+            const float scj = (g.ep_scale && cok) ? g.ep_scale[col] : 1.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (wave_m * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-                    float v = (acc[i][j][r] + accx[i][j][r]) + bj;
+                    float v = acc[i][j][r] + accx[i][j][r];
+                    v = g.ep_scale ? v * scj + bj : v + bj;          // (bn_apply's own expression: bit-identical to conv + apply pass)
                     if (g.relu) v = fmaxf(v, 0.f);
                     *(float*)(smem + row * SPF + cl * 4) = v;
                     if (cok && s_outpix[row] >= 0) { csum[j] += v; csq[j] += v * v; }
@@ -290,7 +292,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
                 if (op < 0 || col >= g.Cn) continue;
                 const long o = (long)op * g.Cn + col;
                 float4 v = *(const float4*)(smem + row * SPF + c4 * 16);
-                if (vec_ok) {
+                if (g.out_hi) {          // eval-mode fold: the next convolution's operand planes, no fp32 tensor (Cn % 4 == 0 checked by the host)
+                    uint2 h, l;
+                    h.x = pack_bf16x2(v.x, v.y); h.y = pack_bf16x2(v.z, v.w);
+                    l.x = pack_bf16x2(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
+                    l.y = pack_bf16x2(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
+                    *(uint2*)((bf16_t*)g.out_hi + o) = h; *(uint2*)((bf16_t*)g.out_lo + o) = l;
+                } else if (vec_ok) {
                     if (AddF) { const float4 a = *(const float4*)(AddF + o); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
                     *(float4*)(OutF + o) = v;
                 } else {

@@ -69,17 +69,18 @@ extern "C" int ab_conv2d_x3_stat_rows(int N, int H, int W, int Cin, int Cout, in
     return conv_gemm2_x3_mtiles(N * Ho * Wo, Cout, kh * kw * (Cin / 32), 0);
 }
 
-extern "C" int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* y, int N, int H,
-                                int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* bias, float* stats,
-                                int relu, void* stream) {
-    if (!x_hi || !x_lo || !w_hi || !w_lo || !y) return AB_EINVAL;
+static int fwd_x3_impl(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* y, int N, int H,
+                       int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* bias, float* stats,
+                       int relu, void* stream, const float* ep_scale = nullptr, void* out_hi = nullptr, void* out_lo = nullptr) {
+    if (!x_hi || !x_lo || !w_hi || !w_lo || (!y && !out_hi)) return AB_EINVAL;
     if (kh * kw > CG_MAXTAPS || Cin % 32) return AB_ESHAPE;
-    if (x3_is_c3(kh, kw, stride, pad) && !bias && !relu) {
+    if (x3_is_c3(kh, kw, stride, pad) && !bias && !relu && !ep_scale) {
         int rc = conv3x3_x3_run(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, 0, nullptr, stats, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
     ConvGemmArgs g = {};
     g.A = x_hi; g.A_lo = x_lo; g.Bw = w_hi; g.Bw_lo = w_lo; g.Out = y; g.bias = bias; g.stats = stats; g.relu = relu;
+    g.ep_scale = ep_scale; g.out_hi = out_hi; g.out_lo = out_lo;
     g.N = N; g.Ha = H; g.Wa = W; g.Ca = Cin;
     g.Ho = (H + 2 * pad - kh) / stride + 1; g.Wo = (W + 2 * pad - kw) / stride + 1; g.Cn = Cout;
     g.P = g.Ho; g.Q = g.Wo; g.out_sh = g.out_sw = 1; g.a_sh = g.a_sw = stride;
@@ -88,6 +89,23 @@ extern "C" int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* 
         g.dh[i * kw + j] = (int8_t)(i - pad); g.dw[i * kw + j] = (int8_t)(j - pad); g.koff[i * kw + j] = (i * kw + j) * Cin;
     }
     return conv_gemm2_x3_run(g, as_stream(stream));
+}
+
+extern "C" int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* y, int N, int H,
+                                int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* bias, float* stats,
+                                int relu, void* stream) {
+    return fwd_x3_impl(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, kh, kw, stride, pad, bias, stats, relu, stream);
+}
+
+// Eval-mode forms of the GENERIC convolution and of the transposed convolution (the strided 3x3, the 1x1 downsample and the two
+// ConvTranspose2d of the head: resnet.py:85-101,181-184, simplebaseline.py:161-172 under model.eval()): the BatchNorm that follows as a
+// per-channel affine in the epilogue, out = relu?(conv * scale + shift), written as fp32 (out_f32) or as (hi, lo) planes -- one of the two.
+extern "C" int ab_conv2d_fwd_x3_affine(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, int N, int H, int W, int Cin,
+                                       int Cout, int kh, int kw, int stride, int pad, const float* scale, const float* shift, int relu,
+                                       float* out_f32, void* out_hi, void* out_lo, void* stream) {
+    if (!scale || !shift || (!out_f32 == !out_hi) || (out_hi && !out_lo)) return AB_EINVAL;
+    if (Cout % 4) return AB_ESHAPE;
+    return fwd_x3_impl(x_hi, x_lo, w_hi, w_lo, out_f32, N, H, W, Cin, Cout, kh, kw, stride, pad, shift, nullptr, relu, stream, scale, out_hi, out_lo);
 }
 
 // Eval-mode 3x3 / stride 1 / pad 1 convolution with the BatchNorm that follows it folded into the epilogue (resnet.py:85-101 in
@@ -124,18 +142,20 @@ extern "C" int ab_conv2d_dgrad_x3_stat_rows(int N, int H, int W, int Cin, int Co
 static int dgrad_x3_impl(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N,
                          int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend,
                          float* stats, void* stream, const void* dy2_hi = nullptr, const void* dy2_lo = nullptr,
-                         const void* wt2_hi = nullptr, const void* wt2_lo = nullptr) {
-    if (!dy_hi || !dy_lo || !wt_hi || !wt_lo || !dx) return AB_EINVAL;
+                         const void* wt2_hi = nullptr, const void* wt2_lo = nullptr, const float* ep_scale = nullptr,
+                         const float* ep_shift = nullptr, int ep_relu = 0, void* out_hi = nullptr, void* out_lo = nullptr) {
+    if (!dy_hi || !dy_lo || !wt_hi || !wt_lo || (!dx && !out_hi)) return AB_EINVAL;
     if (Cout % 32 || (stride != 1 && stride != 2)) return AB_ESHAPE;
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (stride == 2 && ((H & 1) || (W & 1) || kh > 4 || kw > 4)) return AB_ESHAPE;
     if (stats && (addend || !ab_conv2d_dgrad_x3_stat_rows(N, H, W, Cin, Cout, kh, kw, stride, pad))) return AB_ESHAPE;
-    if (x3_is_c3(kh, kw, stride, pad)) {
+    if (x3_is_c3(kh, kw, stride, pad) && !ep_scale) {
         int rc = conv3x3_x3_run(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cout, Cin, 1, addend, nullptr, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
     ConvGemmArgs g = {};
     g.A = dy_hi; g.A_lo = dy_lo; g.Bw = wt_hi; g.Bw_lo = wt_lo; g.Out = dx; g.addend = addend; g.stats = stats;
+    g.ep_scale = ep_scale; g.bias = ep_shift; g.relu = ep_relu; g.out_hi = out_hi; g.out_lo = out_lo;
     g.N = N; g.Ha = Ho; g.Wa = Wo; g.Ca = Cout;
     g.Ho = H; g.Wo = W; g.Cn = Cin;
     g.a_sh = g.a_sw = 1; g.cpt = Cout / 32; g.ktot = kh * kw * Cout;
@@ -181,6 +201,16 @@ extern "C" int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const vo
                                   int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend,
                                   float* stats, void* stream) {
     return dgrad_x3_impl(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cin, Cout, kh, kw, stride, pad, addend, stats, stream);
+}
+
+// ConvTranspose2d forward (== data gradient of the mirrored convolution) in eval mode with the following BatchNorm (+ ReLU) folded in
+extern "C" int ab_conv2d_dgrad_x3_affine(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, int N, int H, int W,
+                                         int Cin, int Cout, int kh, int kw, int stride, int pad, const float* scale, const float* shift,
+                                         int relu, float* out_f32, void* out_hi, void* out_lo, void* stream) {
+    if (!scale || !shift || (!out_f32 == !out_hi) || (out_hi && !out_lo)) return AB_EINVAL;
+    if (Cin % 4) return AB_ESHAPE;
+    return dgrad_x3_impl(dy_hi, dy_lo, wt_hi, wt_lo, out_f32, N, H, W, Cin, Cout, kh, kw, stride, pad, nullptr, nullptr, stream, nullptr, nullptr,
+                         nullptr, nullptr, scale, shift, relu, out_hi, out_lo);
 }
 
 // dx = dgrad(dy, wt; kh x kw / stride 2) + dgrad(dy2, wt2; 1x1 / stride 2 / pad 0) [+ addend]: the two branches that leave a

@@ -531,10 +531,17 @@ class HybridNet:
             d = self._conv_dgrad(x, name, hw, 2, 1)
             return d, (K.col_stats(d) if tr else None)
 
-        d1, st1 = deconv(feat, "hybrid_head.deconv_layers.0.weight", (2 * h4, 2 * w4))
-        e1, bnpd1 = self._bn("hybrid_head.deconv_layers.1", d1, st1, N * 4 * h4 * w4)
-        d2, st2 = deconv(e1, "hybrid_head.deconv_layers.3.weight", (4 * h4, 4 * w4))
-        e2, bnpd2 = self._bn("hybrid_head.deconv_layers.4", d2, st2, N * 16 * h4 * w4)
+        if not tr and self.x3 and self.eval_fold:      # eval: BatchNorm + ReLU of the two transposed convolutions in their epilogues
+            d1 = d2 = bnpd1 = bnpd2 = None
+            e1 = K.conv2d_dgrad_x3_affine(feat, self.tr["hybrid_head.deconv_layers.0.weight"], (2 * h4, 2 * w4), 2, 1,
+                                          self._bn_params("hybrid_head.deconv_layers.1", None, 0))
+            e2 = K.conv2d_dgrad_x3_affine(e1, self.tr["hybrid_head.deconv_layers.3.weight"], (4 * h4, 4 * w4), 2, 1,
+                                          self._bn_params("hybrid_head.deconv_layers.4", None, 0))
+        else:
+            d1, st1 = deconv(feat, "hybrid_head.deconv_layers.0.weight", (2 * h4, 2 * w4))
+            e1, bnpd1 = self._bn("hybrid_head.deconv_layers.1", d1, st1, N * 4 * h4 * w4)
+            d2, st2 = deconv(e1, "hybrid_head.deconv_layers.3.weight", (4 * h4, 4 * w4))
+            e2, bnpd2 = self._bn("hybrid_head.deconv_layers.4", d2, st2, N * 16 * h4 * w4)
         logits = self._conv_fwd(e2, "hybrid_head.final_layer.weight", 1, 0, bias=p.view("hybrid_head.final_layer.bias"))
         # ---- MLP_O box head, always f32 (tiny; keeps the 6-D rotation at full precision)
         m0 = fmean.view(N, 512)
@@ -559,13 +566,15 @@ class HybridNet:
             bnp = self._bn_params(bname, None, 0)
             if s == 1 and K.conv2d_fwd_x3_evalbn_ok(inp, w):
                 return K.conv2d_fwd_x3_evalbn(inp, w, bnp, res=res, relu=relu, want_f32=want_f32)
+            if res is None and not want_f32:          # strided 3x3: affine + ReLU in the generic kernel's epilogue
+                return K.conv2d_fwd_x3_affine(inp, w, bnp, s, 1, relu=relu, planes=True)
             y = K.conv2d_fwd_x3(inp, w, s, 1)
             return K.bn_apply_x3(y, bnp, res=res, relu=relu, want_f32=want_f32)
 
         a1 = conv_bn(x, pre + ".conv1.weight", pre + ".bn1", stride, None, True)
         if stride != 1 or has_ds:
-            yd = K.conv2d_fwd_x3(x, self.w(pre + ".downsample.0.weight"), stride, 0)
-            r = K.bn_apply(yd, self._bn_params(pre + ".downsample.1", None, 0), relu=False)
+            r = K.conv2d_fwd_x3_affine(x, self.w(pre + ".downsample.0.weight"), self._bn_params(pre + ".downsample.1", None, 0), stride, 0,
+                                       relu=False, planes=False)
         else:
             r = x
         return conv_bn(a1, pre + ".conv2.weight", pre + ".bn2", 1, r, True, want_f32=last or not self.res_planes)

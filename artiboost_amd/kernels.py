@@ -509,6 +509,33 @@ def conv2d_fwd_x3_evalbn(x, w_split, bnp, res=None, relu=True, want_f32=False):
     return o
 
 
+def conv2d_fwd_x3_affine(x, w_split, bnp, stride, pad, relu=True, planes=True):
+    """Eval-mode generic convolution + following BatchNorm (+ ReLU) in the epilogue -> split planes [2,N,Ho,Wo,Cout] or fp32 [N,Ho,Wo,Cout]."""
+    xh, xl = _planes(x)
+    N, H, W, Cin = xh.shape
+    _, Cout, kh, kw, _ = w_split.shape
+    Ho, Wo = conv_out(H, kh, stride, pad), conv_out(W, kw, stride, pad)
+    sp = torch.empty((2, N, Ho, Wo, Cout), dtype=torch.bfloat16, device=xh.device) if planes else None
+    o = None if planes else torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=xh.device)
+    L.check(L.lib().ab_conv2d_fwd_x3_affine(L.ptr(xh), L.ptr(xl), L.ptr(w_split[0]), L.ptr(w_split[1]), L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout),
+                                            L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(bnp[0]), L.ptr(bnp[1]), L.i(1 if relu else 0), L.ptr(o),
+                                            L.ptr(sp[0] if planes else None), L.ptr(sp[1] if planes else None), L.stream()), "ab_conv2d_fwd_x3_affine")
+    return sp if planes else o
+
+
+def conv2d_dgrad_x3_affine(dy, wt_split, in_hw, stride, pad, bnp, relu=True):
+    """Eval-mode transposed convolution (data-gradient form) + following BatchNorm (+ ReLU) -> split planes [2,N,H,W,Cin]."""
+    dh, dl = _planes(dy)
+    N, Ho, Wo, Cout = dh.shape
+    _, Cin, kh, kw, _ = wt_split.shape
+    H, W = in_hw
+    sp = torch.empty((2, N, H, W, Cin), dtype=torch.bfloat16, device=dh.device)
+    L.check(L.lib().ab_conv2d_dgrad_x3_affine(L.ptr(dh), L.ptr(dl), L.ptr(wt_split[0]), L.ptr(wt_split[1]), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                              L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(bnp[0]), L.ptr(bnp[1]), L.i(1 if relu else 0),
+                                              L.ptr(None), L.ptr(sp[0]), L.ptr(sp[1]), L.stream()), "ab_conv2d_dgrad_x3_affine")
+    return sp
+
+
 def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=False, bn=None):
     """dy: fp32 / split [.., N,Ho,Wo,Cout]; wt_split [2,Cin,kh,kw,Cout] -> dx fp32 [N,H,W,Cin] (+ BN partials of dx).
 

@@ -132,6 +132,15 @@ int ab_conv2d_fwd_x3_evalbn_ok(int N, int H, int W, int Cin, int Cout);
 int ab_conv2d_fwd_x3_evalbn(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, int N, int H, int W, int Cin,
                             int Cout, const float* bnp, const void* res_hi, const void* res_lo, const float* res_f32, int relu,
                             void* out_hi, void* out_lo, float* out_f32, void* stream);
+/* ... and of the generic convolutions (strided 3x3, 1x1 downsample: resnet.py:85-101,181-184) / the head's ConvTranspose2d
+ * (simplebaseline.py:161-172; dgrad form as ab_conv2d_dgrad_x3): out = relu?(conv * scale + shift) as fp32 `out_f32` OR as planes
+ * (out_hi, out_lo) -- exactly one of the two; bit-identical to the conv followed by ab_bn_apply / ab_bn_apply_x3. */
+int ab_conv2d_fwd_x3_affine(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, int N, int H, int W, int Cin,
+                            int Cout, int kh, int kw, int stride, int pad, const float* scale, const float* shift, int relu,
+                            float* out_f32, void* out_hi, void* out_lo, void* stream);
+int ab_conv2d_dgrad_x3_affine(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, int N, int H, int W, int Cin,
+                              int Cout, int kh, int kw, int stride, int pad, const float* scale, const float* shift, int relu,
+                              float* out_f32, void* out_hi, void* out_lo, void* stream);
 int ab_conv2d_dgrad_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dx, int N, int H,
                        int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend, float* stats,
