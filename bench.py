@@ -336,7 +336,8 @@ def eval_forward(args, model, static, steps=30, warmup=5, want_roofline=True):
                                f"soft-argmax, pose assembly), bs {args.bs}, {args.size}x{args.size}, batch resident in HBM, graph replay",
                    "finite": bool(torch.isfinite(out["HybridBaseline"]["joints_3d_abs"]).all())}
             if want_roofline:
-                names = ["conv2d_fwd_x3", "conv2d_stem_fwd_x3", "conv2d_dgrad_x3", "conv2d_fwd_x3_evalbn", "conv2d_fwd", "conv2d_stem_fwd", "conv2d_dgrad"]
+                names = ["conv2d_fwd_x3", "conv2d_stem_fwd_x3", "conv2d_dgrad_x3", "conv2d_fwd_x3_evalbn", "conv2d_fwd_x3_affine", "conv2d_dgrad_x3_affine",
+                         "conv2d_fwd", "conv2d_stem_fwd", "conv2d_dgrad"]
                 orig = {n: getattr(K, n) for n in names}
                 spans = []
 
@@ -371,7 +372,8 @@ def eval_forward(args, model, static, steps=30, warmup=5, want_roofline=True):
                 ach = fl / (conv_ms * 1e-3) / 1e12
                 res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                    "frac": round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4), "traffic": None,
-                                   "kernel": "forward conv stack (conv3x3_kernel<..,X3=3> with folded BatchNorm, conv_gemm2_kernel, stem_halo_x3_kernel)",
+                                   "kernel": "forward conv stack, eval-mode BatchNorm folded into every epilogue (conv3x3_kernel<..,X3=3>, conv_gemm2_kernel with the "
+                                             "affine epilogue, stem_halo_x3_kernel)",
                                    "conv_ms_per_batch": round(conv_ms, 3), "conv_launches": nl}
     finally:
         hb.segment_graphs = seg
