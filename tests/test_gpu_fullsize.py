@@ -69,7 +69,8 @@ def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name):
             if getattr(v, "grad", None) is not None:
                 v.grad = None
         random.seed(100 + step); torch.manual_seed(100 + step)
-        preds = lo.hybrid_forward(leaf, batch, [size, size], 22, 28, 0, training=True)
+        run_stats = {}
+        preds = lo.hybrid_forward(leaf, batch, [size, size], 22, 28, 0, training=True, stats=run_stats)
         total, ref, _ = lo.criterion(preds, batch, lambdas=lam[:3])
         if sym is not None:      # Criterion.compute_losses adds LAMBDAS[3] * (LAMBDA_SYM_CORNERS_3D * loss) (criterion.py:57-67)
             sref = lo.sym_corner_loss(preds, batch, sym.R.cpu(), sym.t.cpu())
@@ -83,6 +84,8 @@ def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name):
             ms = [torch.zeros_like(leaf[k]) for k in names]
             vs = [torch.zeros_like(leaf[k]) for k in names]
         rnorm = float(lo.clip_and_adam([leaf[k].detach() for k in names], [leaf[k].grad for k in names], ms, vs, step + 1, lr=lr, max_norm=clip))
+        for k, v in run_stats.items():             # the oracle's running statistics follow the same two training forwards
+            leaf[k] = v.detach().clone()
         for k in ts.fused.LOSS_KEYS:
             r = float(ref[k])
             # step 0: same weights on both sides (measured 1e-6).  Later steps follow an Adam update, whose first step is
@@ -92,6 +95,19 @@ def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name):
             tol = 3e-4 if step == 0 or k != "part_ord_loss" else 1.5e-3
             assert abs(got[k] - r) <= tol * abs(r) + 1e-9, (step, k, got[k], r)
         assert abs(gnorm - rnorm) <= 1e-2 * rnorm, (step, gnorm, rnorm)
+    # BASELINE configs[1] at ITS size: the eval-mode forward (running statistics of the two steps above, BatchNorm folded into the conv
+    # epilogues, ab_pose_assemble) on the last batch vs the oracle in eval mode with ITS running statistics and updated weights
+    sd_now = {k: v.clone() for k, v in hb.state_dict().items()}          # the GPU model's weights and running statistics after two steps
+    for k in ("backbone.bn1.running_mean", "backbone.layer3.2.bn1.running_var", "hybrid_head.deconv_layers.4.running_var"):
+        np.testing.assert_allclose(sd_now[k].numpy(), leaf[k].detach().numpy(), rtol=2e-3, atol=1e-6, err_msg=k)   # vs the oracle's
+    model.eval()
+    with torch.no_grad():
+        pe = model(static)["HybridBaseline"]
+        pr = lo.hybrid_forward(sd_now, batch, [size, size], 22, 28, 0, training=False)
+    for k in ("joints_3d_abs", "corners_3d_abs"):
+        err = float((pe[k].float().cpu() - pr[k]).abs().max())
+        assert err <= 2e-4, (k, err)               # metres (well-conditioned statistics here; the random-weight goldens get 5e-4)
+    model.train()
     # after two updates the weights moved the same way: compare the update of a large early and a late tensor
     sd = hb.state_dict()
     for k in ("backbone.layer1.0.conv1.weight", "hybrid_head.final_layer.weight"):
