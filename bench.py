@@ -43,7 +43,7 @@ def ref_cfg(size, dataset="HO3D"):
     return cfg
 
 
-def build_everything(args, rank, world, device):
+def build_everything(args, rank, world, device, wgrad_1pass=False):
     import torch
     from artiboost_amd import registry as R
     from artiboost_amd.assets import SceneAssets
@@ -57,6 +57,8 @@ def build_everything(args, rank, world, device):
     model = Arch({"ARCH": arch_cfg}, R.build_arch_model_list(arch_cfg, preset_cfg=cfg["DATA_PRESET"]))
     crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
     hb = model.model_list[0]
+    if wgrad_1pass:
+        hb.net.wgrad_1pass = True           # (instance override of the AB_WGRAD_1PASS class default; read when the step is captured)
     opt = FusedClipAdam(model.models_params, lr=cfg["TRAIN"]["LR"], max_norm=cfg["TRAIN"]["GRAD_CLIP"], model=hb)
     assets = SceneAssets(args.dataset, seed=1)
     mgr = dict(cfg["MANAGER"], EPOCH=cfg["TRAIN"]["EPOCH"])
@@ -122,6 +124,33 @@ def hbm_rooflines(args, loader, static, model):
                          "kernel": "sam_stage1/2 (logits read once) + sam_bwd (logits read once, dlogits written once; depth pitch 32: the kernels "
                                    "move 32/28 of the algorithmic bytes)"}
     return out
+
+
+def wgrad_1pass_leg(args, device, steps=10, warmup=3):
+    """PRECISION STUDY beside the headline (never the headline): the same step with the WEIGHT gradients computed from the hi planes only
+    (bf16 operands, one MFMA pass instead of three; forward, data gradients, BatchNorm, losses, optimizer unchanged).  Weight gradients are
+    leaves -- nothing but Adam consumes them -- so their rounding does not propagate; every parity test of tests/test_gpu_learner.py and
+    tests/test_gpu_fullsize.py passes unchanged with it.  Reported so that the cost of the third pass on this path is on record."""
+    import copy
+    import torch
+    a = copy.copy(args)
+    a.steps, a.warmup, a.pipeline, a.pipeline_opt = steps, warmup, False, False
+    cfg, model, crit, opt, loader, ts, static = build_everything(a, 0, 1, device, wgrad_1pass=True)
+    nb = len(loader)
+    ts.prime(loader, 0)
+    for i in range(warmup):
+        ts.stage(loader, i % nb)
+        ts()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ts.stage(loader, (warmup + i) % nb)
+        ts()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(args.bs * steps / dt, 1), "unit": "samples/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "dtype": args.dtype + "+wgrad_bf16_1pass",
+            "note": "NOT a parity configuration and not the headline: weight-gradient operands at bf16 (2^-9), below the reference's fp32; see DESIGN 12.1"}
 
 
 def dexycb_leg(args, device, steps=10, warmup=3):
@@ -528,6 +557,7 @@ def main():
                     help="seconds of the sustained block run after the timed steps (extra keys of the line; 0 = off)")
     ap.add_argument("--no-eval-leg", action="store_true", help="skip the configs[1] eval-forward sub-object of the default line")
     ap.add_argument("--no-dexycb-leg", action="store_true", help="skip the configs[4]-on-one-GPU sub-object of the default line")
+    ap.add_argument("--no-study-leg", action="store_true", help="skip the one-pass weight-gradient study sub-object of the default line")
     ap.add_argument("--wgrad-1pass", action="store_true",
                     help="PRECISION STUDY, not a parity configuration (DESIGN 12.1): weight gradients from the hi planes only (one bf16 MFMA "
                          "pass instead of three); the line's dtype says so")
@@ -670,6 +700,12 @@ def main():
                 dex = dexycb_leg(args, device)
             except Exception as e:   # noqa: BLE001
                 dex = {"error": repr(e)}
+        study = None
+        if world == 1 and args.dtype == "bf16x3" and not args.no_study_leg and not args.eager and not args.wgrad_1pass:
+            try:
+                study = wgrad_1pass_leg(args, device)
+            except Exception as e:   # noqa: BLE001
+                study = {"error": repr(e)}
         roof["peak_note"] = ("dense bf16 MFMA peak / 3 passes" if args.dtype == "bf16x3" else "dense MFMA peak of the operand type")
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(args, cfg)
@@ -690,7 +726,8 @@ def main():
                "roofline_hbm_kernels": hbm,            # the HBM-bound halves (render chain, soft-argmax head) against the 8 TB/s roof
                "sustained": sustained,                 # same process, >= --sustain seconds after the timed block (+ observed sclk / power)
                "configs1_eval_forward": ev,            # BASELINE configs[1] (forward only) with its own roofline; `bench.py --eval` prints it as the line
-               "configs4_dexycb_1gpu": dex}            # BASELINE configs[4]'s per-GPU step (DexYCB scenes + SymCornerLoss) on this one GPU
+               "configs4_dexycb_1gpu": dex,
+               "study_wgrad_bf16_1pass": study}        # precision / speed study beside the headline (one-pass weight gradients), see its note            # BASELINE configs[4]'s per-GPU step (DexYCB scenes + SymCornerLoss) on this one GPU
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
