@@ -13,6 +13,21 @@
 
 struct Acc { float m, s, su, sv, sd; };
 
+// NORM_TYPE of IntegralDeconvHead (simplebaseline.py:16-40): 0 = softmax, 1 = sigmoid.  The sigmoid head is
+//   w = sigmoid(x),  conf = max w,  uvd = sum(w * coord) / (sum(w) + 1e-7)
+// which is the softmax machinery below applied to x' = log w = log sigmoid(x): exp(x' - m') = w / w_max, so the online (max, sum,
+// moments) accumulation, the tile merge and the backward's exp(x' - m') factor carry over unchanged; stage 2 rescales by
+// w_max = exp(m') for the 1e-7 and the confidence, the backward multiplies by d x'/d x = sigmoid(-x).
+// ("divide_sum" -- raw, possibly negative weights -- has no log form; the reference itself warns against it.  Not implemented.)
+template <int NORM> __device__ __forceinline__ float sam_pre(float x) {
+    if (NORM == 1) return fminf(x, 0.f) - log1pf(__expf(-fabsf(x)));       // log sigmoid(x), stable on both sides
+    return x;
+}
+template <int NORM> __device__ __forceinline__ float sam_dpre(float x) {  // d sam_pre / dx
+    if (NORM == 1) return 1.f / (1.f + __expf(x));                          // sigmoid(-x)
+    return 1.f;
+}
+
 __device__ __forceinline__ void acc_merge(Acc& a, const Acc& b) {
     float m = fmaxf(a.m, b.m);
     float fa = (a.m == -INFINITY) ? 0.f : __expf(a.m - m);
@@ -25,7 +40,7 @@ __device__ __forceinline__ void acc_merge(Acc& a, const Acc& b) {
 }
 
 // ---- generic scalar kernels (any C*DP; used when C*DP is odd, where rows are not 4-byte aligned)
-template <typename T>
+template <typename T, int NORM = 0>
 __global__ __launch_bounds__(SAM_THREADS) void sam_stage1_scalar(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                           int ntile, float* __restrict__ part) {
     // grid: (ntile, B).  4 waves; wave w handles pixels w, w+4, ... of the tile; lane handles channels lane+64k.
@@ -49,7 +64,7 @@ __global__ __launch_bounds__(SAM_THREADS) void sam_stage1_scalar(const T* __rest
         for (int k = 0; k < KMAX; ++k) {
             int ch = lane + 64 * k;
             if (ch < CD && (ch % DP) < D) {
-                float x = ld_f32(row + ch);
+                float x = sam_pre<NORM>(ld_f32(row + ch));
                 float m = fmaxf(acc[k].m, x);
                 float f = (acc[k].m == -INFINITY) ? 0.f : __expf(acc[k].m - m);
                 float e = __expf(x - m);
@@ -100,7 +115,7 @@ template <> __device__ __forceinline__ void ld_pair<bf16_t>(const bf16_t* p, flo
 
 // KP: channel-pair groups of 128 channels a lane walks (ceil(C*DP / 128) rounded up to an instantiated value): the launch of the
 // 22 x 32 head (704 channels) runs with 6 instead of the maximal 8 -- a quarter fewer loads and exps, 48 instead of 64 KB of LDS.
-template <typename T, int KP = SAM_MAXCH / 128>
+template <typename T, int KP = SAM_MAXCH / 128, int NORM = 0>
 __global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                           int ntile, float* __restrict__ part) {
     // grid: (ntile, B).  4 waves; wave w handles pixels w, w+4, ... of the tile, four at a time (all their loads in flight,
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ 
             for (int k = 0; k < KP; ++k) {
                 float a, c2;
                 ld_pair<T>(row + choff[k], a, c2);
-                x[j][2 * k] = pv ? a : -INFINITY; x[j][2 * k + 1] = pv ? c2 : -INFINITY;
+                x[j][2 * k] = pv ? sam_pre<NORM>(a) : -INFINITY; x[j][2 * k + 1] = pv ? sam_pre<NORM>(c2) : -INFINITY;
             }
         }
 #pragma unroll
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(SAM_THREADS) void sam_stage1(const T* __restrict__ 
 }
 
 __global__ void sam_stage2(const float* __restrict__ part, int C, int ntile, float* __restrict__ uvd,
-                           float* __restrict__ conf, float* __restrict__ stat) {
+                           float* __restrict__ conf, float* __restrict__ stat, int norm = 0) {
     // one wave per (b, c)
     const int bc = blockIdx.x;
     const int b = bc / C, c = bc - b * C;
@@ -230,16 +245,22 @@ __global__ void sam_stage2(const float* __restrict__ part, int C, int ntile, flo
         // softmax sums to 1 (up to rounding); the reference then divides by (sum + 1e-7): simplebaseline.py:187
         const float z = 1.0f + 1e-7f;
         float inv = 1.f / (r.s * z);
+        float cf = 1.f / r.s;  // max p = exp(max - max) / sum
+        if (norm == 1) {       // sigmoid: sums are in units of w_max = exp(m): uvd = su w_max / (s w_max + 1e-7), conf = w_max
+            const float wmax = __expf(r.m);
+            inv = wmax / (r.s * wmax + 1e-7f);
+            cf = wmax;
+        }
         uvd[bc * 3 + 0] = r.su * inv;
         uvd[bc * 3 + 1] = r.sv * inv;
         uvd[bc * 3 + 2] = r.sd * inv;
-        conf[bc] = 1.f / r.s;  // max p = exp(max - max) / sum
+        conf[bc] = cf;
         stat[bc * 2 + 0] = r.m;
         stat[bc * 2 + 1] = r.s;
     }
 }
 
-template <typename T>
+template <typename T, int NORM = 0>
 __global__ __launch_bounds__(256) void sam_bwd_scalar(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                const float* __restrict__ uvd, const float* __restrict__ conf,
                                                const float* __restrict__ stat, const float* __restrict__ g_uvd,
@@ -259,7 +280,8 @@ __global__ __launch_bounds__(256) void sam_bwd_scalar(const T* __restrict__ logi
         int c = ch / DP, d = ch - c * DP;
         if (d >= D) { st_f32(drow + ch, 0.f); continue; }
         int bc = b * C + c;
-        float x = ld_f32(row + ch);
+        const float xraw = ld_f32(row + ch);
+        float x = sam_pre<NORM>(xraw);
         float m = stat[bc * 2], s = stat[bc * 2 + 1];
         float pr = __expf(x - m) / s;
         float u = uvd[bc * 3] * z, v = uvd[bc * 3 + 1] * z, dd = uvd[bc * 3 + 2] * z;  // sum p*coord
@@ -269,6 +291,7 @@ __global__ __launch_bounds__(256) void sam_bwd_scalar(const T* __restrict__ logi
             float cf = conf[bc];
             out += g_conf[bc] * cf * ((x == m ? 1.f : 0.f) - pr);
         }
+        out *= sam_dpre<NORM>(xraw);
         st_f32(drow + ch, out);
     }
 }
@@ -290,7 +313,7 @@ template <> __device__ __forceinline__ void st_pair<bf16_t>(bf16_t* p, float a, 
 // colpart != NULL (PIX pixels per workgroup): the workgroup also writes the column sums of its dlogits rows (fixed order: a
 // lane over its pixels, then the four waves), colpart[(b * gridDim.x + blockIdx.x)][CD] -- the final layer's bias gradient
 // without another pass over the planes.
-template <typename T, bool SPLIT = false, int PIX = SAM_BWD_PIX>
+template <typename T, bool SPLIT = false, int PIX = SAM_BWD_PIX, int NORM = 0>
 __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                const float* __restrict__ uvd, const float* __restrict__ conf,
                                                const float* __restrict__ stat, const float* __restrict__ g_uvd,
@@ -350,9 +373,11 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 int kk = 2 * k + t;
-                float e = __expf(x[kk] - cm[kk]);
+                const float xp = sam_pre<NORM>(x[kk]);
+                float e = __expf(xp - cm[kk]);
                 float out = e * ((ca[kk] * cu + cb[kk] * cv) + ck[kk]);
-                if (g_conf) out += cst[5][ch + t] * ((x[kk] == cm[kk] ? 1.f : 0.f) - e * cst[4][ch + t]);
+                if (g_conf) out += cst[5][ch + t] * ((xp == cm[kk] ? 1.f : 0.f) - e * cst[4][ch + t]);
+                if (NORM != 0) out *= sam_dpre<NORM>(x[kk]);
                 o[t] = out;
                 csum[kk] += out;
             }
@@ -389,35 +414,61 @@ __global__ __launch_bounds__(256) void sam_bias_finalize(const float* __restrict
 
 extern "C" int ab_softargmax3d_ntiles(int H, int W) { return (H * W + SAM_TILE_PIX - 1) / SAM_TILE_PIX; }
 
-extern "C" int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, float* part,
-                                   float* uvd, float* conf, float* stat, void* stream) {
+static int sam_fwd_impl(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, float* part,
+                        float* uvd, float* conf, float* stat, int norm, void* stream) {
     if (!logits || !part || !uvd || !conf || !stat) return AB_EINVAL;
-    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH) return AB_ESHAPE;
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH || norm < 0 || norm > 1) return AB_ESHAPE;
     int ntile = ab_softargmax3d_ntiles(H, W);
     dim3 grid(ntile, B);
     const bool pair = ((C * DP) & 1) == 0;
     hipStream_t st = as_stream(stream);
-    if (dtype == AB_DT_F32) {
-        if (pair) {
-            const int kp = (C * DP + 127) / 128;
-            if (kp <= 2) sam_stage1<float, 2><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
-            else if (kp <= 4) sam_stage1<float, 4><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
-            else if (kp <= 6) sam_stage1<float, 6><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
-            else sam_stage1<float, 8><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
-        }
-        else sam_stage1_scalar<float><<<grid, SAM_THREADS, 0, st>>>((const float*)logits, C, D, DP, H, W, ntile, part);
-    } else if (dtype == AB_DT_BF16) {
-        if (pair) {
-            const int kp = (C * DP + 127) / 128;
-            if (kp <= 2) sam_stage1<bf16_t, 2><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
-            else if (kp <= 4) sam_stage1<bf16_t, 4><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
-            else if (kp <= 6) sam_stage1<bf16_t, 6><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
-            else sam_stage1<bf16_t, 8><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
-        }
-        else sam_stage1_scalar<bf16_t><<<grid, SAM_THREADS, 0, st>>>((const bf16_t*)logits, C, D, DP, H, W, ntile, part);
-    } else return AB_EINVAL;
+    const int kp = (C * DP + 127) / 128;
+#define SAM_S1(TT, NN) \
+    do { \
+        if (!pair) sam_stage1_scalar<TT, NN><<<grid, SAM_THREADS, 0, st>>>((const TT*)logits, C, D, DP, H, W, ntile, part); \
+        else if (kp <= 2) sam_stage1<TT, 2, NN><<<grid, SAM_THREADS, 0, st>>>((const TT*)logits, C, D, DP, H, W, ntile, part); \
+        else if (kp <= 4) sam_stage1<TT, 4, NN><<<grid, SAM_THREADS, 0, st>>>((const TT*)logits, C, D, DP, H, W, ntile, part); \
+        else if (kp <= 6) sam_stage1<TT, 6, NN><<<grid, SAM_THREADS, 0, st>>>((const TT*)logits, C, D, DP, H, W, ntile, part); \
+        else sam_stage1<TT, 8, NN><<<grid, SAM_THREADS, 0, st>>>((const TT*)logits, C, D, DP, H, W, ntile, part); \
+    } while (0)
+    if (dtype == AB_DT_F32) { if (norm) SAM_S1(float, 1); else SAM_S1(float, 0); }
+    else if (dtype == AB_DT_BF16) { if (norm) SAM_S1(bf16_t, 1); else SAM_S1(bf16_t, 0); }
+    else return AB_EINVAL;
+#undef SAM_S1
     AB_LAUNCH_CHECK();
-    sam_stage2<<<B * C, 64, 0, as_stream(stream)>>>(part, C, ntile, uvd, conf, stat);
+    sam_stage2<<<B * C, 64, 0, st>>>(part, C, ntile, uvd, conf, stat, norm);
+    AB_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, float* part,
+                                   float* uvd, float* conf, float* stat, void* stream) {
+    return sam_fwd_impl(logits, dtype, B, C, D, DP, H, W, part, uvd, conf, stat, 0, stream);
+}
+extern "C" int ab_softargmax3d_fwd_norm(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, int norm_type, float* part,
+                                        float* uvd, float* conf, float* stat, void* stream) {
+    return sam_fwd_impl(logits, dtype, B, C, D, DP, H, W, part, uvd, conf, stat, norm_type, stream);
+}
+
+static int sam_bwd_impl(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, const float* uvd,
+                        const float* conf, const float* stat, const float* g_uvd, const float* g_conf, void* dlogits, int norm, void* stream) {
+    if (!logits || !uvd || !conf || !stat || !g_uvd || !dlogits) return AB_EINVAL;
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH || norm < 0 || norm > 1) return AB_ESHAPE;
+    if (norm && g_conf) return AB_EINVAL;          // the sigmoid head's confidence (max w) is not differentiated here
+    const bool pair = ((C * DP) & 1) == 0;
+    hipStream_t st = as_stream(stream);
+    dim3 grid(pair ? (H * W + SAM_BWD_PIX - 1) / SAM_BWD_PIX : (H * W + 3) / 4, B);
+#define SAM_BWD_ARGS(TT) (const TT*)logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, (TT*)dlogits
+#define SAM_BW(TT, NN) \
+    do { \
+        if (pair) sam_bwd<TT, false, SAM_BWD_PIX, NN><<<grid, 256, 0, st>>>(SAM_BWD_ARGS(TT)); \
+        else sam_bwd_scalar<TT, NN><<<grid, 256, 0, st>>>(SAM_BWD_ARGS(TT)); \
+    } while (0)
+    if (dtype == AB_DT_F32) { if (norm) SAM_BW(float, 1); else SAM_BW(float, 0); }
+    else if (dtype == AB_DT_BF16) { if (norm) SAM_BW(bf16_t, 1); else SAM_BW(bf16_t, 0); }
+    else return AB_EINVAL;
+#undef SAM_BW
+#undef SAM_BWD_ARGS
     AB_LAUNCH_CHECK();
     return 0;
 }
@@ -425,54 +476,68 @@ extern "C" int ab_softargmax3d_fwd(const void* logits, int dtype, int B, int C, 
 extern "C" int ab_softargmax3d_bwd(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, const float* uvd,
                                    const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
                                    void* dlogits, void* stream) {
-    if (!logits || !uvd || !conf || !stat || !g_uvd || !dlogits) return AB_EINVAL;
-    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH) return AB_ESHAPE;
-    const bool pair = ((C * DP) & 1) == 0;
-    hipStream_t st = as_stream(stream);
-    dim3 grid(pair ? (H * W + SAM_BWD_PIX - 1) / SAM_BWD_PIX : (H * W + 3) / 4, B);
-#define SAM_BWD_ARGS(TT) (const TT*)logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, (TT*)dlogits
-    if (dtype == AB_DT_F32) {
-        if (pair) sam_bwd<float><<<grid, 256, 0, st>>>(SAM_BWD_ARGS(float));
-        else sam_bwd_scalar<float><<<grid, 256, 0, st>>>(SAM_BWD_ARGS(float));
-    } else if (dtype == AB_DT_BF16) {
-        if (pair) sam_bwd<bf16_t><<<grid, 256, 0, st>>>(SAM_BWD_ARGS(bf16_t));
-        else sam_bwd_scalar<bf16_t><<<grid, 256, 0, st>>>(SAM_BWD_ARGS(bf16_t));
-    } else return AB_EINVAL;
-#undef SAM_BWD_ARGS
-    AB_LAUNCH_CHECK();
-    return 0;
+    return sam_bwd_impl(logits, dtype, B, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, dlogits, 0, stream);
+}
+extern "C" int ab_softargmax3d_bwd_norm(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, int norm_type, const float* uvd,
+                                        const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
+                                        void* dlogits, void* stream) {
+    return sam_bwd_impl(logits, dtype, B, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, dlogits, norm_type, stream);
 }
 
 // fp32 logits in, dlogits out as split-bf16 planes (C * DP even)
+static int sam_bwd_x3_impl(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
+                           const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
+                           void* dl_hi, void* dl_lo, int norm, void* stream) {
+    if (!logits || !uvd || !conf || !stat || !g_uvd || !dl_hi || !dl_lo) return AB_EINVAL;
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH || ((C * DP) & 1) || norm < 0 || norm > 1) return AB_ESHAPE;
+    if (norm && g_conf) return AB_EINVAL;
+    dim3 grid((H * W + SAM_BWD_PIX - 1) / SAM_BWD_PIX, B);
+    if (norm) sam_bwd<float, true, SAM_BWD_PIX, 1><<<grid, 256, 0, as_stream(stream)>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
+                                                                                         (bf16_t*)dl_hi, (bf16_t*)dl_lo);
+    else sam_bwd<float, true><<<grid, 256, 0, as_stream(stream)>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
+                                                                   (bf16_t*)dl_hi, (bf16_t*)dl_lo);
+    AB_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int ab_softargmax3d_bwd_x3(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
                                       const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
                                       void* dl_hi, void* dl_lo, void* stream) {
-    if (!logits || !uvd || !conf || !stat || !g_uvd || !dl_hi || !dl_lo) return AB_EINVAL;
-    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH || ((C * DP) & 1)) return AB_ESHAPE;
-    dim3 grid((H * W + SAM_BWD_PIX - 1) / SAM_BWD_PIX, B);
-    sam_bwd<float, true><<<grid, 256, 0, as_stream(stream)>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
-                                                              (bf16_t*)dl_hi, (bf16_t*)dl_lo);
-    AB_LAUNCH_CHECK();
-    return 0;
+    return sam_bwd_x3_impl(logits, B, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, dl_hi, dl_lo, 0, stream);
 }
 
 // ... and the column sums of dlogits over all B*H*W rows (the bias gradient of the layer that produced the logits) -> dbias [C*DP]
 // fp32.  colpart: scratch of ab_softargmax3d_bwd_x3_bias_rows(B, H, W) x C*DP floats.
 #define SAM_BWD_PIX_BIAS 64
 extern "C" int ab_softargmax3d_bwd_x3_bias_rows(int B, int H, int W) { return B * ((H * W + SAM_BWD_PIX_BIAS - 1) / SAM_BWD_PIX_BIAS); }
-extern "C" int ab_softargmax3d_bwd_x3_bias(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
-                                           const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
-                                           void* dl_hi, void* dl_lo, float* colpart, float* dbias, void* stream) {
+static int sam_bwd_x3_bias_impl(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
+                                const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
+                                void* dl_hi, void* dl_lo, float* colpart, float* dbias, int norm, void* stream) {
     if (!logits || !uvd || !conf || !stat || !g_uvd || !dl_hi || !dl_lo || !colpart || !dbias) return AB_EINVAL;
-    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH || ((C * DP) & 1)) return AB_ESHAPE;
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH || ((C * DP) & 1) || norm < 0 || norm > 1) return AB_ESHAPE;
+    if (norm && g_conf) return AB_EINVAL;
     dim3 grid((H * W + SAM_BWD_PIX_BIAS - 1) / SAM_BWD_PIX_BIAS, B);
     hipStream_t st = as_stream(stream);
-    sam_bwd<float, true, SAM_BWD_PIX_BIAS><<<grid, 256, 0, st>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
-                                                                 (bf16_t*)dl_hi, (bf16_t*)dl_lo, colpart);
+    if (norm) sam_bwd<float, true, SAM_BWD_PIX_BIAS, 1><<<grid, 256, 0, st>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
+                                                                               (bf16_t*)dl_hi, (bf16_t*)dl_lo, colpart);
+    else sam_bwd<float, true, SAM_BWD_PIX_BIAS><<<grid, 256, 0, st>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
+                                                                      (bf16_t*)dl_hi, (bf16_t*)dl_lo, colpart);
     AB_LAUNCH_CHECK();
     sam_bias_finalize<<<(C * DP + 7) / 8, 256, 0, st>>>(colpart, (int)(grid.x * grid.y), C * DP, dbias);
     AB_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int ab_softargmax3d_bwd_x3_bias(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
+                                           const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
+                                           void* dl_hi, void* dl_lo, float* colpart, float* dbias, void* stream) {
+    return sam_bwd_x3_bias_impl(logits, B, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, dl_hi, dl_lo, colpart, dbias, 0, stream);
+}
+// NORM_TYPE-aware form of the two split-plane backwards (colpart / dbias NULL: no bias gradient)
+extern "C" int ab_softargmax3d_bwd_x3_norm(const float* logits, int B, int C, int D, int DP, int H, int W, int norm_type, const float* uvd,
+                                           const float* conf, const float* stat, const float* g_uvd, void* dl_hi, void* dl_lo,
+                                           float* colpart, float* dbias, void* stream) {
+    if (colpart && dbias)
+        return sam_bwd_x3_bias_impl(logits, B, C, D, DP, H, W, uvd, conf, stat, g_uvd, nullptr, dl_hi, dl_lo, colpart, dbias, norm_type, stream);
+    return sam_bwd_x3_impl(logits, B, C, D, DP, H, W, uvd, conf, stat, g_uvd, nullptr, dl_hi, dl_lo, norm_type, stream);
 }
 
 extern "C" int ab_abi_version(void) { return 2; }

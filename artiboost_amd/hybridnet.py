@@ -261,6 +261,7 @@ class HybridNet:
         self.x3 = compute_dtype in ("bf16x3", "x3")           # split-bf16 convolutions on fp32 tensors
         self.dtype = torch.float32 if self.x3 else compute_dtype
         self.training = True
+        self.norm = 0            # HYBRID_HEAD.NORM_TYPE code (head.NORM_CODE): 0 softmax, 1 sigmoid
         self.frozen_bn = False   # BACKBONE.FREEZE_BATCHNORM: backbone BatchNorms are fixed affine maps (resnet.py:33-69, 146-149)
         self.lp = None           # low-precision copy of the flat params (bf16 mode)
         self.tr = {}             # IHWO (data-gradient) copies of conv weights in the compute dtype
@@ -581,16 +582,17 @@ class HybridNet:
 
     def head_fwd(self, logits):
         """-> kp3d [N,22,3], conf [N,22], stat (kept for head_bwd)."""
-        return softargmax3d_fwd(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH)
+        return softargmax3d_fwd(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, self.norm)
 
     def head_bwd(self, logits, kp3d, conf, stat, g_kp3d, g_conf=None):
         """dlogits, written in place over the logits buffer (they are not needed again); bf16x3: as split planes."""
         if self.x3:
             # (the final layer's bias gradient = column sums of dlogits comes out of the same pass; backward() sees the tag)
             dbias = self.p.gview("hybrid_head.final_layer.bias") if (self.sam_bias and self.saved is not None) else None
-            return softargmax3d_bwd_x3(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf, dbias=dbias)
+            return softargmax3d_bwd_x3(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf, dbias=dbias,
+                                       norm=self.norm)
         return softargmax3d_bwd(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf,
-                                inplace=True)
+                                inplace=True, norm=self.norm)
 
     # ------------------------------------------------------------------ backward
     # Weight gradients are off the critical path (nothing consumes them before the optimizer), so they CAN be issued on

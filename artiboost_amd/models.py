@@ -154,8 +154,10 @@ class HybridBaseline(nn.Module):
         self.depth_res = head["DEPTH_RESOLUTION"]
         if cfg["BACKBONE"]["TYPE"] != "ResNet34":
             raise NotImplementedError("the HIP path implements the ResNet34 backbone of the clasbased configs")
-        if head.get("NORM_TYPE", "softmax") != "softmax" or head.get("FINAL_CONV_KERNEL", 1) != 1:
-            raise NotImplementedError("IntegralDeconvHead: softmax norm + 1x1 final conv only")
+        from .head import norm_code
+        norm = norm_code(head.get("NORM_TYPE", "softmax"))          # softmax / sigmoid (simplebaseline.py:16-40); divide_sum raises
+        if head.get("FINAL_CONV_KERNEL", 1) != 1:
+            raise NotImplementedError("IntegralDeconvHead: 1x1 final conv only")
         if cfg["BACKBONE"].get("PRETRAINED") is True:
             # resnet.py:249-262 fetches torchvision's ImageNet weights (a download); here the backbone keeps its seeded
             # initialisation unless ARCH.PRETRAINED names a checkpoint in the reference's state-dict layout
@@ -172,6 +174,7 @@ class HybridBaseline(nn.Module):
         # BACKBONE.FREEZE_BATCHNORM (resnet.py:146-149: bn_layer = FrozenBatchNorm2d): the backbone's BatchNorms are fixed affine maps in
         # both modes, their weight / bias receive no gradient (zero gradient -> Adam leaves them) and carry no num_batches_tracked
         self.net.frozen_bn = self.store.frozen_bn = bool(cfg["BACKBONE"].get("FREEZE_BATCHNORM", False))
+        self.net.norm = norm
         self.flat_param = nn.Parameter(self.store.flat, requires_grad=True)   # shares storage with the store
         self.flat_param._ab_owner = self                                      # netutils.build_optimizer recognises it
         self.segment_graphs = bool(cfg.get("SEGMENT_GRAPHS", os.environ.get("AB_SEGMENT_GRAPHS", "1") != "0"))

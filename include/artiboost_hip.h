@@ -56,6 +56,19 @@ int ab_softargmax3d_bwd_x3_bias_rows(int B, int H, int W);
 int ab_softargmax3d_bwd_x3_bias(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
                                 const float* conf, const float* stat, const float* g_uvd, const float* g_conf, void* dl_hi,
                                 void* dl_lo, float* colpart, float* dbias, void* stream);
+/* NORM_TYPE of IntegralDeconvHead (anakin/models/simplebaseline.py:16-40): norm_type 0 = "softmax" (the entry points above),
+ * 1 = "sigmoid": w = sigmoid(x), conf = max w, uvd = sum(w * coord) / (sum(w) + 1e-7) -- evaluated in the log domain with the same
+ * kernels (x' = log sigmoid(x); `stat` holds (log w_max, sum w / w_max)).  g_conf must be NULL for the sigmoid head.
+ * ("divide_sum" is not implemented: raw weights can be negative, and the reference's own docstring advises against it.)
+ * _bwd_x3_norm: dlogits as split planes; colpart + dbias non-NULL: also the bias gradient (scratch as for _bwd_x3_bias). */
+int ab_softargmax3d_fwd_norm(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, int norm_type, float* part,
+                             float* uvd, float* conf, float* stat, void* stream);
+int ab_softargmax3d_bwd_norm(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, int norm_type, const float* uvd,
+                             const float* conf, const float* stat, const float* g_uvd, const float* g_conf, void* dlogits,
+                             void* stream);
+int ab_softargmax3d_bwd_x3_norm(const float* logits, int B, int C, int D, int DP, int H, int W, int norm_type, const float* uvd,
+                                const float* conf, const float* stat, const float* g_uvd, void* dl_hi, void* dl_lo, float* colpart,
+                                float* dbias, void* stream);
 
 /* ---- M1/M2: convolution stack (implicit GEMM on MFMA) ----------------------------------------------------------
  * replaces cuDNN behind nn.Conv2d / nn.ConvTranspose2d / nn.Linear:

@@ -150,12 +150,19 @@ def resnet34_forward(p, image, training=True, stats=None, feats=None, frozen_bn=
 
 
 # ----------------------------------------------------------------------------- M2/M3 head
-def softargmax3d(logits, nclasses, depth, height, width):
-    """norm_heatmap('softmax') + confd + renorm + integral_heatmap3d
+def softargmax3d(logits, nclasses, depth, height, width, norm_type="softmax"):
+    """norm_heatmap(norm_type) + confd + renorm + integral_heatmap3d
     (simplebaseline.py:16-40, 177-190, 43-71).  logits (B, nclasses*depth, H, W) -> uvd (B,C,3), conf (B,C)."""
     B = logits.shape[0]
     x = logits.reshape(B, nclasses, -1)
-    x = F.softmax(x, 2)
+    if norm_type == "softmax":
+        x = F.softmax(x, 2)
+    elif norm_type == "sigmoid":
+        x = x.sigmoid()
+    elif norm_type == "divide_sum":
+        x = x / x.sum(dim=2, keepdim=True)
+    else:
+        raise NotImplementedError(norm_type)
     conf = torch.max(x, dim=-1).values
     x = x / (x.sum(dim=-1, keepdim=True) + 1e-7)
     x = x.reshape(B, nclasses, depth, height, width)
@@ -171,7 +178,7 @@ def softargmax3d(logits, nclasses, depth, height, width):
     return torch.cat([u, v, d], dim=-1), conf
 
 
-def head_forward(p, feat, nclasses, depth, training=True, stats=None, keep=None):
+def head_forward(p, feat, nclasses, depth, training=True, stats=None, keep=None, norm_type="softmax"):
     """IntegralDeconvHead.forward (simplebaseline.py:177-190); deconv stack (simplebaseline.py:152-175)."""
     x = F.conv_transpose2d(feat, p["hybrid_head.deconv_layers.0.weight"], stride=2, padding=1)
     x = F.relu(_bn(x, p, "hybrid_head.deconv_layers.1", training, stats=stats))
@@ -181,7 +188,7 @@ def head_forward(p, feat, nclasses, depth, training=True, stats=None, keep=None)
     if keep is not None:
         keep["logits"] = logits
     H, W = logits.shape[2], logits.shape[3]
-    return softargmax3d(logits, nclasses, depth, H, W)
+    return softargmax3d(logits, nclasses, depth, H, W, norm_type)
 
 
 # ----------------------------------------------------------------------------- M4 pose assembly
@@ -217,12 +224,13 @@ def box_head_forward(p, x):
     return F.linear(x, p["box_head.layers.4.weight"], p["box_head.layers.4.bias"])
 
 
-def hybrid_forward(p, batch, inp_res, nclasses=22, depth=28, center_idx=0, training=True, stats=None, keep=None, frozen_bn=False):
+def hybrid_forward(p, batch, inp_res, nclasses=22, depth=28, center_idx=0, training=True, stats=None, keep=None, frozen_bn=False,
+                   norm_type="softmax"):
     """HybridBaseline.forward (hybridbaseline.py:37-96)."""
     image = batch["image"]
     H, W = image.shape[2], image.shape[3]
     feat, feat_mean = resnet34_forward(p, image, training, stats=stats, feats=keep, frozen_bn=frozen_bn)
-    kp3d, conf = head_forward(p, feat, nclasses, depth, training, stats=stats, keep=keep)
+    kp3d, conf = head_forward(p, feat, nclasses, depth, training, stats=stats, keep=keep, norm_type=norm_type)
     box6d = box_head_forward(p, feat_mean)
     pose_abs = uvd2xyz(kp3d, batch["root_joint"], batch["cam_intr"], inp_res)
     joints_abs = pose_abs[:, 0:21]

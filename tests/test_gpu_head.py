@@ -110,3 +110,52 @@ def test_c_abi_from_a_plain_c_host(tmp_path):
     exe = _build_c_host(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "C_ABI_HOST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("tag", ["tiny", "odd", "g256"])
+def test_sigmoid_head_vs_reference_golden(golden_dir, tag):
+    """IntegralDeconvHead NORM_TYPE: sigmoid (simplebaseline.py:16-40,183-189) on the same kernels in the log domain
+    (ab_softargmax3d_fwd_norm / _bwd_norm), against vectors from the reference's own norm_heatmap + integral_heatmap3d
+    (tests/golden/head_sigmoid.npz, oracle/gen_head_sigmoid_golden.py).  "odd": C*D odd -> the scalar kernels."""
+    from artiboost_amd.head import softargmax3d
+    g = np.load(os.path.join(golden_dir, "head_sigmoid.npz"))
+    seed, B, C, D, H, W = [int(x) for x in g[f"{tag}.seed"]]
+    gen = torch.Generator().manual_seed(seed)
+    logits = 3.0 * torch.randn(B, C * D, H, W, generator=gen)
+    x = _nhwc(logits).cuda().requires_grad_(True)
+    uvd, conf = softargmax3d(x, C, D, norm_type="sigmoid")
+    np.testing.assert_allclose(uvd.detach().cpu().numpy(), g[f"{tag}.uvd"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(conf.detach().cpu().numpy(), g[f"{tag}.conf"], rtol=3e-6, atol=0)
+    gu = torch.from_numpy(g[f"{tag}.g_uvd"]).cuda()
+    (uvd * gu).sum().backward()
+    dl = x.grad.permute(0, 3, 1, 2).reshape(B, C, -1)[:, :, ::53].cpu().numpy()
+    ref = g[f"{tag}.dlogits.sample"]
+    np.testing.assert_allclose(dl, ref, rtol=3e-4, atol=2e-6 * np.abs(ref).max() + 1e-12)
+    np.testing.assert_allclose(float(x.grad.abs().sum()), float(g[f"{tag}.dlogits.abs_sum"]), rtol=1e-4)
+
+
+def test_sigmoid_head_split_plane_backward_and_padded_depth():
+    """The bf16x3 form (fp32 logits, dlogits as (hi, lo) planes + the final layer's bias gradient, depth pitch 32 > depth 28) of the
+    sigmoid head vs the oracle's autograd."""
+    from artiboost_amd.head import softargmax3d_bwd_x3, softargmax3d_fwd
+    B, C, D, DP, H, W = 3, 22, 28, 32, 8, 8
+    gen = torch.Generator().manual_seed(7)
+    core = (2.0 * torch.randn(B, C, D, H, W, generator=gen))
+    ref_in = core.reshape(B, C * D, H, W).clone().requires_grad_(True)
+    uvd_r, conf_r = lo.softargmax3d(ref_in, C, D, H, W, norm_type="sigmoid")
+    gu = torch.randn(uvd_r.shape, generator=gen)
+    (uvd_r * gu).sum().backward()
+    pad = torch.full((B, C, DP, H, W), 7.0)                       # garbage in the padded depth slots must not matter
+    pad[:, :, :D] = core
+    x = pad.reshape(B, C * DP, H, W).permute(0, 2, 3, 1).contiguous().cuda()
+    uvd, conf, stat = softargmax3d_fwd(x, C, D, DP, norm=1)
+    np.testing.assert_allclose(uvd.cpu().numpy(), uvd_r.detach().numpy(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(conf.cpu().numpy(), conf_r.detach().numpy(), rtol=3e-6)
+    dbias = torch.zeros(C * DP, device="cuda")
+    dl = softargmax3d_bwd_x3(x, C, D, DP, uvd, conf, stat, gu.cuda(), dbias=dbias, norm=1)
+    got = (dl[0].float() + dl[1].float()).permute(0, 3, 1, 2).reshape(B, C, DP, H, W).cpu()
+    ref = ref_in.grad.reshape(B, C, D, H, W)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(got[:, :, :D].numpy(), ref.numpy(), rtol=2e-4, atol=2e-5 * scale)
+    assert float(got[:, :, D:].abs().max()) == 0.0
+    np.testing.assert_allclose(dbias.cpu().reshape(C, DP)[:, :D].numpy(), ref.sum(dim=(0, 3, 4)).numpy(), rtol=1e-3, atol=1e-5 * scale * B * H * W)
