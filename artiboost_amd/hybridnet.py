@@ -50,8 +50,15 @@ def _round_up(x, m):
 class ParamStore:
     """Flat parameter / gradient / running-stat storage with reference <-> kernel layout conversion."""
 
-    def __init__(self, nclasses=22, depth=28, device="cuda"):
+    def __init__(self, nclasses=22, depth=28, device="cuda", layers=(3, 4, 6, 3), head_prefix="hybrid_head", box_head=True):
+        """layers: BasicBlock counts per stage ((3,4,6,3) = ResNet-34, (2,2,2,2) = ResNet-18: resnet.py:236-248); head_prefix: the
+        IntegralDeconvHead's attribute name in the reference module ("hybrid_head" in HybridBaseline, "pose_head" in SimpleBaseline:
+        hybridbaseline.py:31, simplebaseline.py:207); box_head: MLP_O present (HybridBaseline only).
+        The final layer is laid out for `nclasses_pad` classes (even, so that its channel count is a multiple of 64 for the weight-gradient
+        kernels): a padding class has zero weights, zero bias and receives zero gradient."""
         self.nclasses, self.depth = nclasses, depth
+        self.nclasses_pad = nclasses + (nclasses & 1)
+        self.layers, self.hp, self.box_head = tuple(layers), head_prefix, bool(box_head)
         self.entries = OrderedDict()
         self.buffers = OrderedDict()   # running stats: name -> (offset, C)
         self._build_table()
@@ -81,11 +88,11 @@ class ParamStore:
         self.buffers[prefix + ".running_var"] = (0, c)
 
     def _build_table(self):
-        C, D = self.nclasses, self.depth
+        C, D, CP, hp = self.nclasses, self.depth, self.nclasses_pad, self.hp
         self._add("backbone.conv1.weight", "stem", (64, 3, 7, 7), (64, 7, 8, 4))
         self._add_bn("backbone.bn1", 64)
         inpl = 64
-        for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET34_LAYERS), start=1):
+        for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], self.layers), start=1):
             for b in range(nblk):
                 stride = 2 if (b == 0 and li > 1) else 1
                 p = f"backbone.layer{li}.{b}"
@@ -100,12 +107,14 @@ class ParamStore:
         # backbone.fc exists in the reference state_dict (resnet.py:164) but never receives a gradient
         self._add("backbone.fc.weight", "frozen", (1000, 512), (1000, 512))
         self._add("backbone.fc.bias", "frozen", (1000,), (1000,))
-        self._add("hybrid_head.deconv_layers.0.weight", "deconv", (512, 256, 4, 4), (512, 4, 4, 256))
-        self._add_bn("hybrid_head.deconv_layers.1", 256)
-        self._add("hybrid_head.deconv_layers.3.weight", "deconv", (256, 256, 4, 4), (256, 4, 4, 256))
-        self._add_bn("hybrid_head.deconv_layers.4", 256)
-        self._add("hybrid_head.final_layer.weight", "final_w", (C * D, 256, 1, 1), (C * DEPTH_PITCH, 1, 1, 256))
-        self._add("hybrid_head.final_layer.bias", "final_b", (C * D,), (C * DEPTH_PITCH,))
+        self._add(hp + ".deconv_layers.0.weight", "deconv", (512, 256, 4, 4), (512, 4, 4, 256))
+        self._add_bn(hp + ".deconv_layers.1", 256)
+        self._add(hp + ".deconv_layers.3.weight", "deconv", (256, 256, 4, 4), (256, 4, 4, 256))
+        self._add_bn(hp + ".deconv_layers.4", 256)
+        self._add(hp + ".final_layer.weight", "final_w", (C * D, 256, 1, 1), (CP * DEPTH_PITCH, 1, 1, 256))
+        self._add(hp + ".final_layer.bias", "final_b", (C * D,), (CP * DEPTH_PITCH,))
+        if not self.box_head:
+            return
         self._add("box_head.layers.0.weight", "linear", (256, 512), (256, 1, 1, 512))
         self._add("box_head.layers.0.bias", "vec", (256,), (256,))
         self._add("box_head.layers.2.weight", "linear", (128, 256), (128, 1, 1, 256))
@@ -141,12 +150,12 @@ class ParamStore:
         if e.kind == "deconv":       # ConvT weight [Cin_t, Cout_t, kh, kw] -> OHWI of the mirrored conv [Cin_t, kh, kw, Cout_t]
             return t.permute(0, 2, 3, 1).contiguous()
         if e.kind == "final_w":
-            k = torch.zeros((C, DEPTH_PITCH, 256), dtype=torch.float32, device=t.device)
-            k[:, :D] = t.reshape(C, D, 256)
+            k = torch.zeros((self.nclasses_pad, DEPTH_PITCH, 256), dtype=torch.float32, device=t.device)
+            k[:C, :D] = t.reshape(C, D, 256)
             return k.reshape(e.kshape)
         if e.kind == "final_b":
-            k = torch.zeros((C, DEPTH_PITCH), dtype=torch.float32, device=t.device)
-            k[:, :D] = t.reshape(C, D)
+            k = torch.zeros((self.nclasses_pad, DEPTH_PITCH), dtype=torch.float32, device=t.device)
+            k[:C, :D] = t.reshape(C, D)
             return k.reshape(e.kshape)
         if e.kind == "linear":
             return t.reshape(e.kshape)
@@ -167,9 +176,9 @@ class ParamStore:
         if e.kind in ("conv", "deconv"):
             return k.permute(0, 3, 1, 2).contiguous()
         if e.kind == "final_w":
-            return k.reshape(C, DEPTH_PITCH, 256)[:, :D].reshape(e.ref_shape).contiguous()
+            return k.reshape(self.nclasses_pad, DEPTH_PITCH, 256)[:C, :D].reshape(e.ref_shape).contiguous()
         if e.kind == "final_b":
-            return k.reshape(C, DEPTH_PITCH)[:, :D].reshape(e.ref_shape).contiguous()
+            return k.reshape(self.nclasses_pad, DEPTH_PITCH)[:C, :D].reshape(e.ref_shape).contiguous()
         if e.kind == "linear":
             return k.reshape(e.ref_shape).contiguous()
         if e.kind == "linear_pad":
@@ -318,12 +327,12 @@ class HybridNet:
             self._tr_plan = K.transpose_plan(pairs) or False
             # fp32 [in][out] copies of the box-head weights (its data gradients run as NT products too)
             self.box_t, bpairs = {}, []
-            for name in ("box_head.layers.0.weight", "box_head.layers.2.weight", "box_head.layers.4.weight"):
+            for name in (("box_head.layers.0.weight", "box_head.layers.2.weight", "box_head.layers.4.weight") if p.box_head else ()):
                 O, _, _, I = p.entries[name].kshape
                 dst = self.box_t[name] = torch.empty((I, O), dtype=torch.float32, device=p.device)
                 bpairs.append((p.view(name).reshape(O, 1, I), dst.view(I, 1, O)))
             self._box_pairs = bpairs
-            self._box_plan = K.transpose_plan(bpairs) or False
+            self._box_plan = (K.transpose_plan(bpairs) or False) if bpairs else False
         if self._box_plan:
             K.transpose_oki_batch(self._box_plan)
         else:
@@ -484,7 +493,8 @@ class HybridNet:
             x._ab_split = K.split(x)      # layer1.0 reads the pooled tensor three times (conv1, residual, conv1's weight gradient)
         S.update(y0=y0, bnp0=bnp0, pool_idx=pool_idx)
         inpl = 64
-        for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET34_LAYERS), start=1):
+        hp = p.hp
+        for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], p.layers), start=1):
             for b in range(nblk):
                 stride = 2 if (b == 0 and li > 1) else 1
                 pre = f"backbone.layer{li}.{b}"
@@ -534,22 +544,26 @@ class HybridNet:
 
         if not tr and self.x3 and self.eval_fold:      # eval: BatchNorm + ReLU of the two transposed convolutions in their epilogues
             d1 = d2 = bnpd1 = bnpd2 = None
-            e1 = K.conv2d_dgrad_x3_affine(feat, self.tr["hybrid_head.deconv_layers.0.weight"], (2 * h4, 2 * w4), 2, 1,
-                                          self._bn_params("hybrid_head.deconv_layers.1", None, 0))
-            e2 = K.conv2d_dgrad_x3_affine(e1, self.tr["hybrid_head.deconv_layers.3.weight"], (4 * h4, 4 * w4), 2, 1,
-                                          self._bn_params("hybrid_head.deconv_layers.4", None, 0))
+            e1 = K.conv2d_dgrad_x3_affine(feat, self.tr[hp + ".deconv_layers.0.weight"], (2 * h4, 2 * w4), 2, 1,
+                                          self._bn_params(hp + ".deconv_layers.1", None, 0))
+            e2 = K.conv2d_dgrad_x3_affine(e1, self.tr[hp + ".deconv_layers.3.weight"], (4 * h4, 4 * w4), 2, 1,
+                                          self._bn_params(hp + ".deconv_layers.4", None, 0))
         else:
-            d1, st1 = deconv(feat, "hybrid_head.deconv_layers.0.weight", (2 * h4, 2 * w4))
-            e1, bnpd1 = self._bn("hybrid_head.deconv_layers.1", d1, st1, N * 4 * h4 * w4)
-            d2, st2 = deconv(e1, "hybrid_head.deconv_layers.3.weight", (4 * h4, 4 * w4))
-            e2, bnpd2 = self._bn("hybrid_head.deconv_layers.4", d2, st2, N * 16 * h4 * w4)
-        logits = self._conv_fwd(e2, "hybrid_head.final_layer.weight", 1, 0, bias=p.view("hybrid_head.final_layer.bias"))
+            d1, st1 = deconv(feat, hp + ".deconv_layers.0.weight", (2 * h4, 2 * w4))
+            e1, bnpd1 = self._bn(hp + ".deconv_layers.1", d1, st1, N * 4 * h4 * w4)
+            d2, st2 = deconv(e1, hp + ".deconv_layers.3.weight", (4 * h4, 4 * w4))
+            e2, bnpd2 = self._bn(hp + ".deconv_layers.4", d2, st2, N * 16 * h4 * w4)
+        logits = self._conv_fwd(e2, hp + ".final_layer.weight", 1, 0, bias=p.view(hp + ".final_layer.bias"))
         # ---- MLP_O box head, always f32 (tiny; keeps the 6-D rotation at full precision)
         m0 = fmean.view(N, 512)
-        lw = lambda n: p.view(n).view(p.entries[n].kshape[0], -1)      # noqa: E731  ([out][in] rows of the 1x1 layout)
-        b1 = K.linear_fwd(m0, lw("box_head.layers.0.weight"), p.view("box_head.layers.0.bias"), relu=True)
-        b2 = K.linear_fwd(b1, lw("box_head.layers.2.weight"), p.view("box_head.layers.2.bias"), relu=True)
-        b3 = K.linear_fwd(b2, lw("box_head.layers.4.weight"), p.view("box_head.layers.4.bias"))
+        if p.box_head:
+            lw = lambda n: p.view(n).view(p.entries[n].kshape[0], -1)      # noqa: E731  ([out][in] rows of the 1x1 layout)
+            b1 = K.linear_fwd(m0, lw("box_head.layers.0.weight"), p.view("box_head.layers.0.bias"), relu=True)
+            b2 = K.linear_fwd(b1, lw("box_head.layers.2.weight"), p.view("box_head.layers.2.bias"), relu=True)
+            b3 = K.linear_fwd(b2, lw("box_head.layers.4.weight"), p.view("box_head.layers.4.bias"))
+        else:                     # SimpleBaseline: no MLP_O (simplebaseline.py:205-208); a zero placeholder keeps the call contract
+            b1 = b2 = None
+            b3 = torch.zeros((N, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
         box6d = b3.view(N, BOX_OUT_PAD)[:, :6]
         S.update(feat=feat, d1=d1, e1=e1, bnpd1=bnpd1, d2=d2, e2=e2, bnpd2=bnpd2, logits=logits, m0=m0, b1=b1, b2=b2)
         self.saved = S if tr else None
@@ -582,16 +596,30 @@ class HybridNet:
 
     def head_fwd(self, logits):
         """-> kp3d [N,22,3], conf [N,22], stat (kept for head_bwd)."""
-        return softargmax3d_fwd(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, self.norm)
+        kp3d, conf, stat = softargmax3d_fwd(logits, self.p.nclasses_pad, self.p.depth, DEPTH_PITCH, self.norm)
+        if self.p.nclasses_pad != self.p.nclasses:        # the padding class: dropped from what the model sees, kept for the backward
+            self._head_full = (kp3d, conf)
+            return kp3d[:, :self.p.nclasses].contiguous(), conf[:, :self.p.nclasses].contiguous(), stat
+        return kp3d, conf, stat
 
     def head_bwd(self, logits, kp3d, conf, stat, g_kp3d, g_conf=None):
         """dlogits, written in place over the logits buffer (they are not needed again); bf16x3: as split planes."""
+        hp, CP = self.p.hp, self.p.nclasses_pad
+        if CP != self.p.nclasses:             # zero gradient for the padding class; forward outputs of all CP classes from head_fwd
+            kp3d, conf = self._head_full
+            gk = torch.zeros((g_kp3d.shape[0], CP, 3), dtype=torch.float32, device=g_kp3d.device)
+            gk[:, :self.p.nclasses].copy_(g_kp3d)
+            g_kp3d = gk
+            if g_conf is not None:
+                gc = torch.zeros((g_conf.shape[0], CP), dtype=torch.float32, device=g_conf.device)
+                gc[:, :self.p.nclasses].copy_(g_conf)
+                g_conf = gc
         if self.x3:
             # (the final layer's bias gradient = column sums of dlogits comes out of the same pass; backward() sees the tag)
-            dbias = self.p.gview("hybrid_head.final_layer.bias") if (self.sam_bias and self.saved is not None) else None
-            return softargmax3d_bwd_x3(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf, dbias=dbias,
+            dbias = self.p.gview(hp + ".final_layer.bias") if (self.sam_bias and self.saved is not None) else None
+            return softargmax3d_bwd_x3(logits, CP, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf, dbias=dbias,
                                        norm=self.norm)
-        return softargmax3d_bwd(logits, self.p.nclasses, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf,
+        return softargmax3d_bwd(logits, CP, self.p.depth, DEPTH_PITCH, kp3d, conf, stat, g_kp3d, g_conf,
                                 inplace=True, norm=self.norm)
 
     # ------------------------------------------------------------------ backward
@@ -678,37 +706,41 @@ class HybridNet:
         if stage == 2:
             dout, blocks, part = S.pop("_dout"), S.pop("_blocks_left"), S.pop("_dout_part")
             return self._backward_trunk(S, dout, blocks, part)
+        hp = p.hp
         # ---- box head (f32)
-        g3 = torch.zeros((N, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
-        g3[:, :6].copy_(g_box6d)
-        lw = lambda n: p.view(n).view(p.entries[n].kshape[0], -1)      # noqa: E731
-        lg = lambda n: gv(n).view(p.entries[n].kshape[0], -1)          # noqa: E731
-        K.linear_wgrad(g3, S["b2"], lg("box_head.layers.4.weight"), gv("box_head.layers.4.bias"))
-        gb2 = K.linear_dgrad(g3, self.box_t["box_head.layers.4.weight"], act_out=S["b2"])
-        K.linear_wgrad(gb2, S["b1"], lg("box_head.layers.2.weight"), gv("box_head.layers.2.bias"))
-        gb1 = K.linear_dgrad(gb2, self.box_t["box_head.layers.2.weight"], act_out=S["b1"])
-        K.linear_wgrad(gb1, S["m0"], lg("box_head.layers.0.weight"), gv("box_head.layers.0.bias"))
-        g_mean = K.linear_dgrad(gb1, self.box_t["box_head.layers.0.weight"])
+        g_mean = None
+        if p.box_head:
+            g3 = torch.zeros((N, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
+            g3[:, :6].copy_(g_box6d)
+            lw = lambda n: p.view(n).view(p.entries[n].kshape[0], -1)      # noqa: E731
+            lg = lambda n: gv(n).view(p.entries[n].kshape[0], -1)          # noqa: E731
+            K.linear_wgrad(g3, S["b2"], lg("box_head.layers.4.weight"), gv("box_head.layers.4.bias"))
+            gb2 = K.linear_dgrad(g3, self.box_t["box_head.layers.4.weight"], act_out=S["b2"])
+            K.linear_wgrad(gb2, S["b1"], lg("box_head.layers.2.weight"), gv("box_head.layers.2.bias"))
+            gb1 = K.linear_dgrad(gb2, self.box_t["box_head.layers.2.weight"], act_out=S["b1"])
+            K.linear_wgrad(gb1, S["m0"], lg("box_head.layers.0.weight"), gv("box_head.layers.0.bias"))
+            g_mean = K.linear_dgrad(gb1, self.box_t["box_head.layers.0.weight"])
         # ---- head
         e2, e1, feat = S["e2"], S["e1"], S["feat"]
         if self.x3 and dlogits.dtype == torch.bfloat16:       # planes straight from the soft-argmax backward
             if not getattr(dlogits, "_ab_bias_done", False):
-                K.col_sum_x3(dlogits, gv("hybrid_head.final_layer.bias"))
+                K.col_sum_x3(dlogits, gv(hp + ".final_layer.bias"))
         else:
-            K.col_sum(dlogits, gv("hybrid_head.final_layer.bias"))
+            K.col_sum(dlogits, gv(hp + ".final_layer.bias"))
             if self.x3:
                 dlogits = K.split(dlogits)        # one split serves the weight and the data gradient
-        self._wgrad_side(self._conv_wgrad, e2, dlogits, 1, 1, 1, 0, out=gv("hybrid_head.final_layer.weight"))
-        de2 = self._conv_dgrad(dlogits, "hybrid_head.final_layer.weight", (e2.shape[-3], e2.shape[-2]), 1, 0)
-        dd2 = self._bn_bwd(de2, e2, S["d2"], S["bnpd2"], gv("hybrid_head.deconv_layers.4.weight"),
-                       gv("hybrid_head.deconv_layers.4.bias"), relu="recompute")
-        self._wgrad_side(self._conv_wgrad, dd2, e1, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.3.weight"))
-        de1 = self._conv_fwd(dd2, "hybrid_head.deconv_layers.3.weight", 2, 1)
-        dd1 = self._bn_bwd(de1, e1, S["d1"], S["bnpd1"], gv("hybrid_head.deconv_layers.1.weight"),
-                       gv("hybrid_head.deconv_layers.1.bias"), relu="recompute")
-        self._wgrad_side(self._conv_wgrad, dd1, feat, 4, 4, 2, 1, out=gv("hybrid_head.deconv_layers.0.weight"))
-        dout = self._conv_fwd(dd1, "hybrid_head.deconv_layers.0.weight", 2, 1)
-        K.avgpool_bwd(g_mean, dout, accumulate=True)
+        self._wgrad_side(self._conv_wgrad, e2, dlogits, 1, 1, 1, 0, out=gv(hp + ".final_layer.weight"))
+        de2 = self._conv_dgrad(dlogits, hp + ".final_layer.weight", (e2.shape[-3], e2.shape[-2]), 1, 0)
+        dd2 = self._bn_bwd(de2, e2, S["d2"], S["bnpd2"], gv(hp + ".deconv_layers.4.weight"),
+                       gv(hp + ".deconv_layers.4.bias"), relu="recompute")
+        self._wgrad_side(self._conv_wgrad, dd2, e1, 4, 4, 2, 1, out=gv(hp + ".deconv_layers.3.weight"))
+        de1 = self._conv_fwd(dd2, hp + ".deconv_layers.3.weight", 2, 1)
+        dd1 = self._bn_bwd(de1, e1, S["d1"], S["bnpd1"], gv(hp + ".deconv_layers.1.weight"),
+                       gv(hp + ".deconv_layers.1.bias"), relu="recompute")
+        self._wgrad_side(self._conv_wgrad, dd1, feat, 4, 4, 2, 1, out=gv(hp + ".deconv_layers.0.weight"))
+        dout = self._conv_fwd(dd1, hp + ".deconv_layers.0.weight", 2, 1)
+        if g_mean is not None:
+            K.avgpool_bwd(g_mean, dout, accumulate=True)
         # ---- backbone, last block first
         blocks = list(reversed(S["blocks"]))
         if stage == 0:

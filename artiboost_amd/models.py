@@ -141,19 +141,28 @@ class _NetBridge(torch.autograd.Function):
         return None, None, None, None, None
 
 
+BASIC_BLOCK_LAYERS = {"ResNet18": (2, 2, 2, 2), "ResNet34": (3, 4, 6, 3)}       # resnet.py:236-248 (BasicBlock stages)
+
+
 @MODEL.register_module
 class HybridBaseline(nn.Module):
+    HEAD_KEY, HEAD_PREFIX, HAS_BOX_HEAD = "HYBRID_HEAD", "hybrid_head", True      # config block / attribute name of the heat-map head
+
     @enable_lower_param
     def __init__(self, **cfg):
         super().__init__()
         preset = cfg["DATA_PRESET"]
         self.center_idx = preset.get("CENTER_IDX", 9)
         self.inp_res = preset["IMAGE_SIZE"]
-        head = cfg["HYBRID_HEAD"]
+        head = cfg[self.HEAD_KEY]
         self.nclasses = head["NCLASSES"]
         self.depth_res = head["DEPTH_RESOLUTION"]
-        if cfg["BACKBONE"]["TYPE"] != "ResNet34":
-            raise NotImplementedError("the HIP path implements the ResNet34 backbone of the clasbased configs")
+        if cfg["BACKBONE"]["TYPE"] not in BASIC_BLOCK_LAYERS:
+            raise NotImplementedError(f"backbone {cfg['BACKBONE']['TYPE']}: the HIP path implements the BasicBlock ResNets (ResNet18, ResNet34); "
+                                      f"the Bottleneck ones (ResNet50/101/152, resnet.py:104-141) are not built")
+        if (head.get("NUM_DECONV_LAYERS", 2), list(head.get("NUM_DECONV_FILTERS", [256, 256])), list(head.get("NUM_DECONV_KERNELS", [4, 4])),
+                head.get("INPUT_CHANNEL", 512), bool(head.get("DECONV_WITH_BIAS", False))) != (2, [256, 256], [4, 4], 512, False):
+            raise NotImplementedError("IntegralDeconvHead: 2 x (ConvTranspose2d 4x4/s2, 256 filters, no bias) on 512 input channels only")
         from .head import norm_code
         norm = norm_code(head.get("NORM_TYPE", "softmax"))          # softmax / sigmoid (simplebaseline.py:16-40); divide_sum raises
         if head.get("FINAL_CONV_KERNEL", 1) != 1:
@@ -166,7 +175,8 @@ class HybridBaseline(nn.Module):
                           "pass a converted checkpoint through ARCH.PRETRAINED")
         dev = cfg.get("DEVICE", "cuda")
         cd = cfg.get("COMPUTE_DTYPE", "bf16x3")     # the reference's precision (fp32-grade); "bf16" / "f32" opt in
-        self.store = ParamStore(self.nclasses, self.depth_res, device=dev)
+        self.store = ParamStore(self.nclasses, self.depth_res, device=dev, layers=BASIC_BLOCK_LAYERS[cfg["BACKBONE"]["TYPE"]],
+                                head_prefix=self.HEAD_PREFIX, box_head=self.HAS_BOX_HEAD)
         self.store.init_reference_like(seed=int(cfg.get("INIT_SEED", 1)))
         self.net = HybridNet(self.store, image_size=self.inp_res,
                              compute_dtype=(torch.bfloat16 if cd in ("bf16", torch.bfloat16) else
@@ -252,6 +262,11 @@ class HybridBaseline(nn.Module):
                 else:
                     logits, box6d = self.net.forward(image=image, xpad=xpad)
                     kp3d, conf, _ = self.net.head_fwd(logits)
+        return self._assemble(inputs, kp3d, conf, box6d, H, W)
+
+    def _assemble(self, inputs, kp3d, conf, box6d, H, W):
+        """hybridbaseline.py:49-96: uvd -> xyz, 6-D -> R, canonical corners -> camera frame, 2-D re-projection."""
+        dev = self.store.device
         root_in = inputs[Queries.ROOT_JOINT].to(dev)
         intr = inputs[Queries.CAM_INTR].to(dev)
         if not kp3d.requires_grad and self.fused_assembly and (W, H) == tuple(self.inp_res):
@@ -288,6 +303,24 @@ class HybridBaseline(nn.Module):
             "kp3d": kp3d,
             "kp3d_confd": conf,
         }
+
+
+@MODEL.register_module
+class SimpleBaseline(HybridBaseline):
+    """anakin/models/simplebaseline.py:194-241: backbone + IntegralDeconvHead with ONE heat map per key point (29 = 21 joints + 8 corners,
+    no MLP_O box head); the same HIP executor with `pose_head.*` parameter names, no box head and a zero-weight padding class (the final
+    layer's channel count must be a multiple of 64 for the weight-gradient kernels).  Losses run through the registry classes + autograd
+    (the fused pose/loss kernel is HybridBaseline's assembly)."""
+    HEAD_KEY, HEAD_PREFIX, HAS_BOX_HEAD = "HEAD", "pose_head", False
+
+    def _assemble(self, inputs, kp3d, conf, box6d, H, W):
+        dev = self.store.device
+        kp3d_abs = batch_uvd2xyz(kp3d, inputs[Queries.ROOT_JOINT].to(dev), inputs[Queries.CAM_INTR].to(dev), self.inp_res)
+        nj = 21                                           # CONST.NUM_JOINTS (misc.py)
+        joints_3d_abs, corners_3d_abs = kp3d_abs[:, :nj], kp3d_abs[:, nj:]
+        root_joint = joints_3d_abs[:, self.center_idx, :]
+        return {"joints_3d_abs": joints_3d_abs, "corners_3d_abs": corners_3d_abs, "joints_3d": joints_3d_abs - root_joint.unsqueeze(1),
+                "corners_3d": corners_3d_abs - root_joint.unsqueeze(1), "2d_uvd": kp3d}
 
 
 class Arch(nn.Module):

@@ -83,6 +83,11 @@ class TrainStep:
             self.rstatic["image_nhwc4_padded"] = torch.zeros_like(self.static["image_nhwc4_padded"])
             self.render_stream = torch.cuda.Stream(device=self.dev)
         self.fused = None
+        self.model_key = type(self.hb).__name__                      # the key of this model's outputs in Arch's result dict
+        if not getattr(self.hb, "HAS_BOX_HEAD", True):               # SimpleBaseline: the fused pose/loss kernel is HybridBaseline's assembly
+            fused_criterion = False
+            self.split = False
+            self.use_graph = False
         if fused_criterion:
             from .criterions import FusedPoseCriterion
             try:
@@ -126,7 +131,7 @@ class TrainStep:
     def _learn(self):
         if self.fused is not None:
             return self._fwd_bwd_fused()
-        preds = self.model(self.static)["HybridBaseline"]
+        preds = self.model(self.static)[self.model_key]
         total, losses = self.crit.compute_losses(preds, self.static)
         self.opt.zero_grad(set_to_none=True)
         total.backward()

@@ -23,9 +23,11 @@ JOINTS_IDX_PARENTS = [0, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 0, 13, 14, 15, 0,
 
 
 # ----------------------------------------------------------------------------- parameters
-def param_shapes(nclasses=22, depth=28):
+def param_shapes(nclasses=22, depth=28, layers=None, head_prefix="hybrid_head", box_head=True):
     """Ordered (name, shape) list == reference state_dict of Arch(HybridBaseline) minus the Arch prefix
-    (resnet.py:142-168, simplebaseline.py:78-101,152-175, mlp.py:11-22)."""
+    (resnet.py:142-168, simplebaseline.py:78-101,152-175, mlp.py:11-22).  layers / head_prefix / box_head: the SimpleBaseline
+    variant (simplebaseline.py:194-241: `pose_head`, no MLP_O) and the ResNet-18 stage counts (resnet.py:236-241)."""
+    layers = list(layers) if layers is not None else RESNET34_LAYERS
     out = []
 
     def bn(prefix, c):
@@ -35,7 +37,7 @@ def param_shapes(nclasses=22, depth=28):
     out.append(("backbone.conv1.weight", (64, 3, 7, 7)))
     bn("backbone.bn1", 64)
     inpl = 64
-    for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET34_LAYERS), start=1):
+    for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], layers), start=1):
         for b in range(nblk):
             stride = 2 if (b == 0 and li > 1) else 1
             p = f"backbone.layer{li}.{b}"
@@ -49,13 +51,14 @@ def param_shapes(nclasses=22, depth=28):
             inpl = planes
     out.append(("backbone.fc.weight", (1000, 512)))
     out.append(("backbone.fc.bias", (1000,)))
-    out.append(("hybrid_head.deconv_layers.0.weight", (512, 256, 4, 4)))
-    bn("hybrid_head.deconv_layers.1", 256)
-    out.append(("hybrid_head.deconv_layers.3.weight", (256, 256, 4, 4)))
-    bn("hybrid_head.deconv_layers.4", 256)
-    out.append(("hybrid_head.final_layer.weight", (nclasses * depth, 256, 1, 1)))
-    out.append(("hybrid_head.final_layer.bias", (nclasses * depth,)))
-    for i, (a, b) in zip((0, 2, 4), ((512, 256), (256, 128), (128, 6))):
+    hp = head_prefix
+    out.append((hp + ".deconv_layers.0.weight", (512, 256, 4, 4)))
+    bn(hp + ".deconv_layers.1", 256)
+    out.append((hp + ".deconv_layers.3.weight", (256, 256, 4, 4)))
+    bn(hp + ".deconv_layers.4", 256)
+    out.append((hp + ".final_layer.weight", (nclasses * depth, 256, 1, 1)))
+    out.append((hp + ".final_layer.bias", (nclasses * depth,)))
+    for i, (a, b) in (zip((0, 2, 4), ((512, 256), (256, 128), (128, 6))) if box_head else ()):
         out.append((f"box_head.layers.{i}.weight", (b, a)))
         out.append((f"box_head.layers.{i}.bias", (b,)))
     return out
@@ -120,17 +123,18 @@ def _bn(x, p, prefix, training, eps=1e-5, momentum=0.1, stats=None):
     return (x - mean[None, :, None, None]) * (inv * w)[None, :, None, None] + b[None, :, None, None]
 
 
-def resnet34_forward(p, image, training=True, stats=None, feats=None, frozen_bn=False):
+def resnet34_forward(p, image, training=True, stats=None, feats=None, frozen_bn=False, layers=None):
     """ResNet.forward (resnet.py:199-221) with BasicBlock.forward (resnet.py:85-101).
     frozen_bn: BACKBONE.FREEZE_BATCHNORM (resnet.py:146-149 bn_layer = FrozenBatchNorm2d, resnet.py:33-69): every backbone BatchNorm is the
     fixed affine map scale = w * rsqrt(running_var + 1e-5), bias = b - running_mean * scale in BOTH modes (weight / bias are buffers)."""
     if frozen_bn:
         training = False
+    layers = list(layers) if layers is not None else RESNET34_LAYERS
     x = F.conv2d(image, p["backbone.conv1.weight"], stride=2, padding=3)
     x = F.relu(_bn(x, p, "backbone.bn1", training, stats=stats))
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     inpl = 64
-    for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], RESNET34_LAYERS), start=1):
+    for li, (planes, nblk) in enumerate(zip([64, 128, 256, 512], layers), start=1):
         for b in range(nblk):
             stride = 2 if (b == 0 and li > 1) else 1
             pre = f"backbone.layer{li}.{b}"
@@ -178,13 +182,13 @@ def softargmax3d(logits, nclasses, depth, height, width, norm_type="softmax"):
     return torch.cat([u, v, d], dim=-1), conf
 
 
-def head_forward(p, feat, nclasses, depth, training=True, stats=None, keep=None, norm_type="softmax"):
+def head_forward(p, feat, nclasses, depth, training=True, stats=None, keep=None, norm_type="softmax", hp="hybrid_head"):
     """IntegralDeconvHead.forward (simplebaseline.py:177-190); deconv stack (simplebaseline.py:152-175)."""
-    x = F.conv_transpose2d(feat, p["hybrid_head.deconv_layers.0.weight"], stride=2, padding=1)
-    x = F.relu(_bn(x, p, "hybrid_head.deconv_layers.1", training, stats=stats))
-    x = F.conv_transpose2d(x, p["hybrid_head.deconv_layers.3.weight"], stride=2, padding=1)
-    x = F.relu(_bn(x, p, "hybrid_head.deconv_layers.4", training, stats=stats))
-    logits = F.conv2d(x, p["hybrid_head.final_layer.weight"], p["hybrid_head.final_layer.bias"])
+    x = F.conv_transpose2d(feat, p[hp + ".deconv_layers.0.weight"], stride=2, padding=1)
+    x = F.relu(_bn(x, p, hp + ".deconv_layers.1", training, stats=stats))
+    x = F.conv_transpose2d(x, p[hp + ".deconv_layers.3.weight"], stride=2, padding=1)
+    x = F.relu(_bn(x, p, hp + ".deconv_layers.4", training, stats=stats))
+    logits = F.conv2d(x, p[hp + ".final_layer.weight"], p[hp + ".final_layer.bias"])
     if keep is not None:
         keep["logits"] = logits
     H, W = logits.shape[2], logits.shape[3]
@@ -254,6 +258,18 @@ def hybrid_forward(p, batch, inp_res, nclasses=22, depth=28, center_idx=0, train
         "kp3d": kp3d,
         "kp3d_confd": conf,
     }
+
+
+def simple_forward(p, batch, inp_res, nclasses=29, depth=28, center_idx=0, training=True, stats=None, layers=None, norm_type="softmax"):
+    """SimpleBaseline.forward (simplebaseline.py:211-241): backbone -> pose_head -> uvd2xyz; 21 joints + 8 corners straight from
+    the heat maps (no box head)."""
+    feat, _ = resnet34_forward(p, batch["image"], training, stats=stats, layers=layers)
+    kp3d, conf = head_forward(p, feat, nclasses, depth, training, stats=stats, norm_type=norm_type, hp="pose_head")
+    abs_ = uvd2xyz(kp3d, batch["root_joint"], batch["cam_intr"], inp_res)
+    joints_abs, corners_abs = abs_[:, :21], abs_[:, 21:]
+    root = joints_abs[:, center_idx]
+    return {"joints_3d_abs": joints_abs, "corners_3d_abs": corners_abs, "joints_3d": joints_abs - root[:, None],
+            "corners_3d": corners_abs - root[:, None], "2d_uvd": kp3d, "kp3d_confd": conf}
 
 
 # ----------------------------------------------------------------------------- L1-L3 losses

@@ -76,6 +76,25 @@ def test_param_store_roundtrip_and_layouts():
         st.load_reference_state_dict({"backbone.conv1.weight": torch.zeros(64, 3, 3, 3)}, strict=False)
 
 
+def test_param_store_variants_speak_the_reference_keys():
+    """SimpleBaseline on ResNet-18 (simplebaseline.py:194-241, resnet.py:236-241): `pose_head.*` names, no box head, BasicBlock stage counts
+    (2, 2, 2, 2) -- the key list (order included) is the one the reference's own class produced when oracle/gen_simplebaseline_golden.py
+    ran (asserted there against lo.param_shapes)."""
+    from artiboost_amd.hybridnet import ParamStore
+    st = ParamStore(29, 28, device="cpu", layers=(2, 2, 2, 2), head_prefix="pose_head", box_head=False)
+    want = lo.param_shapes(29, 28, layers=(2, 2, 2, 2), head_prefix="pose_head", box_head=False)
+    sd = st.reference_state_dict()
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, tuple(s)) for k, s in want]
+    assert st.nclasses_pad == 30 and st.view("pose_head.final_layer.weight").shape == (960, 1, 1, 256)
+    params = lo.fill_params(want, seed=2)
+    st.load_reference_state_dict(params)
+    back = st.reference_state_dict()
+    for k, v in params.items():
+        if v.dtype.is_floating_point:
+            np.testing.assert_array_equal(back[k].numpy(), v.numpy(), err_msg=k)
+    assert float(st.view("pose_head.final_layer.weight").reshape(30, 32, 256)[29].abs().max()) == 0.0      # the padding class
+
+
 def test_gt_geometry_and_views_match_reference(golden_dir):
     from artiboost_amd import synth
     g = np.load(os.path.join(golden_dir, "misc.npz"))

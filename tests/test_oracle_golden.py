@@ -159,3 +159,33 @@ def test_pose_generator_oracle_matches_reference_class(golden_dir):
     np.testing.assert_allclose(obj_pose, g["final_obj_pose"], rtol=1e-5, atol=2e-6)
     np.testing.assert_allclose(verts, g["final_hand_verts"], rtol=1e-5, atol=5e-6)
     np.testing.assert_allclose(joints, g["final_joints"], rtol=1e-5, atol=5e-6)
+
+
+def test_simplebaseline_oracle_matches_reference_class(golden_dir):
+    """lo.simple_forward (SimpleBaseline, simplebaseline.py:194-241, on a ResNet-18 backbone) against the reference's own class run on
+    the same seeded weights (tests/golden/simplebaseline.npz, oracle/gen_simplebaseline_golden.py): eval and train predictions, the
+    JointsLoss value, every parameter's gradient norm."""
+    import torch
+    from gen_batch import make_batch
+    g = np.load(os.path.join(golden_dir, "simplebaseline.npz"))
+    size, heat, depth, B, seed = [int(x) for x in g["meta"]]
+    shapes = lo.param_shapes(29, depth, layers=(2, 2, 2, 2), head_prefix="pose_head", box_head=False)
+    params = lo.fill_params(shapes, seed=seed)
+    batch = make_batch(B, size, seed + 100)
+    batch["corners_3d"] = torch.from_numpy(g["corners_3d"])
+    with torch.no_grad():
+        pe = lo.simple_forward(params, batch, [size, size], 29, depth, 0, training=False, layers=(2, 2, 2, 2))
+    for k in ("joints_3d_abs", "corners_3d_abs", "2d_uvd"):
+        np.testing.assert_allclose(pe[k].numpy(), g[f"eval.pred.{k}"], rtol=0, atol=2e-5, err_msg=k)
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in params.items()}
+    pt = lo.simple_forward(leaf, batch, [size, size], 29, depth, 0, training=True, layers=(2, 2, 2, 2))
+    for k in ("joints_3d_abs", "corners_3d_abs"):
+        np.testing.assert_allclose(pt[k].detach().numpy(), g[f"train.pred.{k}"], rtol=0, atol=2e-5, err_msg=k)
+    total, _ = lo.joints_loss(pt, batch)
+    np.testing.assert_allclose(float(total), float(g["loss.total"]), rtol=1e-4)
+    total.backward()
+    ref = dict(zip([str(n) for n in g["grad.names"]], g["grad.norms"]))
+    for n, r in ref.items():
+        if n.startswith("backbone.fc"):
+            continue
+        np.testing.assert_allclose(float(leaf[n].grad.norm()), r, rtol=2e-3, atol=1e-9, err_msg=n)
