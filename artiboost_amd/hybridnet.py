@@ -50,7 +50,8 @@ def _round_up(x, m):
 class ParamStore:
     """Flat parameter / gradient / running-stat storage with reference <-> kernel layout conversion."""
 
-    def __init__(self, nclasses=22, depth=28, device="cuda", layers=(3, 4, 6, 3), head_prefix="hybrid_head", box_head=True):
+    def __init__(self, nclasses=22, depth=28, device="cuda", layers=(3, 4, 6, 3), head_prefix="hybrid_head", box_head=True,
+                 block="basic", box_dims=(512, 256, 128)):
         """layers: BasicBlock counts per stage ((3,4,6,3) = ResNet-34, (2,2,2,2) = ResNet-18: resnet.py:236-248); head_prefix: the
         IntegralDeconvHead's attribute name in the reference module ("hybrid_head" in HybridBaseline, "pose_head" in SimpleBaseline:
         hybridbaseline.py:31, simplebaseline.py:207); box_head: MLP_O present (HybridBaseline only).
@@ -59,6 +60,10 @@ class ParamStore:
         self.nclasses, self.depth = nclasses, depth
         self.nclasses_pad = nclasses + (nclasses & 1)
         self.layers, self.hp, self.box_head = tuple(layers), head_prefix, bool(box_head)
+        # block: "basic" (ResNet-18/34, resnet.py:72-101) or "bottleneck" (ResNet-50/101/152, resnet.py:104-141: 1x1 -> 3x3 (stride) -> 1x1 x4)
+        self.block, self.expansion = block, (4 if block == "bottleneck" else 1)
+        self.feat_ch = 512 * self.expansion                # res_layer4 channels = the head's INPUT_CHANNEL
+        self.box_dims = tuple(box_dims)                    # MLP_O LAYERS_N (mlp.py:11-25)
         self.entries = OrderedDict()
         self.buffers = OrderedDict()   # running stats: name -> (offset, C)
         self._build_table()
@@ -96,6 +101,19 @@ class ParamStore:
             for b in range(nblk):
                 stride = 2 if (b == 0 and li > 1) else 1
                 p = f"backbone.layer{li}.{b}"
+                if self.block == "bottleneck":
+                    outp = planes * 4
+                    self._add(p + ".conv1.weight", "conv", (planes, inpl, 1, 1), (planes, 1, 1, inpl))
+                    self._add_bn(p + ".bn1", planes)
+                    self._add(p + ".conv2.weight", "conv", (planes, planes, 3, 3), (planes, 3, 3, planes))
+                    self._add_bn(p + ".bn2", planes)
+                    self._add(p + ".conv3.weight", "conv", (outp, planes, 1, 1), (outp, 1, 1, planes))
+                    self._add_bn(p + ".bn3", outp)
+                    if stride != 1 or inpl != outp:
+                        self._add(p + ".downsample.0.weight", "conv", (outp, inpl, 1, 1), (outp, 1, 1, inpl))
+                        self._add_bn(p + ".downsample.1", outp)
+                    inpl = outp
+                    continue
                 self._add(p + ".conv1.weight", "conv", (planes, inpl, 3, 3), (planes, 3, 3, inpl))
                 self._add_bn(p + ".bn1", planes)
                 self._add(p + ".conv2.weight", "conv", (planes, planes, 3, 3), (planes, 3, 3, planes))
@@ -105,9 +123,9 @@ class ParamStore:
                     self._add_bn(p + ".downsample.1", planes)
                 inpl = planes
         # backbone.fc exists in the reference state_dict (resnet.py:164) but never receives a gradient
-        self._add("backbone.fc.weight", "frozen", (1000, 512), (1000, 512))
+        self._add("backbone.fc.weight", "frozen", (1000, self.feat_ch), (1000, self.feat_ch))
         self._add("backbone.fc.bias", "frozen", (1000,), (1000,))
-        self._add(hp + ".deconv_layers.0.weight", "deconv", (512, 256, 4, 4), (512, 4, 4, 256))
+        self._add(hp + ".deconv_layers.0.weight", "deconv", (self.feat_ch, 256, 4, 4), (self.feat_ch, 4, 4, 256))
         self._add_bn(hp + ".deconv_layers.1", 256)
         self._add(hp + ".deconv_layers.3.weight", "deconv", (256, 256, 4, 4), (256, 4, 4, 256))
         self._add_bn(hp + ".deconv_layers.4", 256)
@@ -115,11 +133,12 @@ class ParamStore:
         self._add(hp + ".final_layer.bias", "final_b", (C * D,), (CP * DEPTH_PITCH,))
         if not self.box_head:
             return
-        self._add("box_head.layers.0.weight", "linear", (256, 512), (256, 1, 1, 512))
-        self._add("box_head.layers.0.bias", "vec", (256,), (256,))
-        self._add("box_head.layers.2.weight", "linear", (128, 256), (128, 1, 1, 256))
-        self._add("box_head.layers.2.bias", "vec", (128,), (128,))
-        self._add("box_head.layers.4.weight", "linear_pad", (6, 128), (BOX_OUT_PAD, 1, 1, 128))
+        d0, d1, d2 = self.box_dims
+        self._add("box_head.layers.0.weight", "linear", (d1, d0), (d1, 1, 1, d0))
+        self._add("box_head.layers.0.bias", "vec", (d1,), (d1,))
+        self._add("box_head.layers.2.weight", "linear", (d2, d1), (d2, 1, 1, d1))
+        self._add("box_head.layers.2.bias", "vec", (d2,), (d2,))
+        self._add("box_head.layers.4.weight", "linear_pad", (6, d2), (BOX_OUT_PAD, 1, 1, d2))
         self._add("box_head.layers.4.bias", "vec_pad", (6,), (BOX_OUT_PAD,))
 
     # ------------------------------------------------------------------ views
@@ -498,6 +517,11 @@ class HybridNet:
             for b in range(nblk):
                 stride = 2 if (b == 0 and li > 1) else 1
                 pre = f"backbone.layer{li}.{b}"
+                if p.block == "bottleneck":
+                    x, rec = self._bottleneck_fwd(x, pre, planes, stride, stride != 1 or inpl != planes * 4, last=(li == 4 and b == nblk - 1))
+                    S["blocks"].append(rec if tr else dict(pre=pre))
+                    inpl = planes * 4
+                    continue
                 if not tr and self.x3 and self.eval_fold:
                     x = self._eval_block(x, pre, stride, inpl != planes, last=(li == 4 and b == nblk - 1))
                     S["blocks"].append(dict(pre=pre))
@@ -555,7 +579,7 @@ class HybridNet:
             e2, bnpd2 = self._bn(hp + ".deconv_layers.4", d2, st2, N * 16 * h4 * w4)
         logits = self._conv_fwd(e2, hp + ".final_layer.weight", 1, 0, bias=p.view(hp + ".final_layer.bias"))
         # ---- MLP_O box head, always f32 (tiny; keeps the 6-D rotation at full precision)
-        m0 = fmean.view(N, 512)
+        m0 = fmean.view(N, p.feat_ch)
         if p.box_head:
             lw = lambda n: p.view(n).view(p.entries[n].kshape[0], -1)      # noqa: E731  ([out][in] rows of the 1x1 layout)
             b1 = K.linear_fwd(m0, lw("box_head.layers.0.weight"), p.view("box_head.layers.0.bias"), relu=True)
@@ -571,6 +595,54 @@ class HybridNet:
         return logits, box6d
 
     eval_fold = os.environ.get("AB_EVAL_FOLD", "1") != "0"       # bf16x3 eval: BatchNorm folded into the 3x3 conv epilogues
+
+    def _bottleneck_fwd(self, x, pre, planes, stride, has_ds, last):
+        """Bottleneck.forward (resnet.py:104-141): 1x1 -> bn -> relu -> 3x3 (stride) -> bn -> relu -> 1x1 (x4) -> bn, + identity /
+        downsample(x), relu.  The same kernels as the BasicBlock path (the 1x1 convolutions run on the generic implicit GEMM)."""
+        y1, st1 = self._conv_fwd(x, pre + ".conv1.weight", 1, 0, want_stats=True)
+        a1, bnp1 = self._bn(pre + ".bn1", y1, st1, y1.shape[0] * y1.shape[1] * y1.shape[2])
+        y2, st2 = self._conv_fwd(a1, pre + ".conv2.weight", stride, 1, want_stats=True)
+        cnt = y2.shape[0] * y2.shape[1] * y2.shape[2]
+        a2, bnp2 = self._bn(pre + ".bn2", y2, st2, cnt)
+        y3, st3 = self._conv_fwd(a2, pre + ".conv3.weight", 1, 0, want_stats=True)
+        rec = dict(kind="bottleneck", pre=pre, stride=stride, x=x, y1=y1, a1=a1, bnp1=bnp1, y2=y2, a2=a2, bnp2=bnp2, y3=y3, ds=False)
+        if has_ds:
+            yd, std_ = self._conv_fwd(x, pre + ".downsample.0.weight", stride, 0, want_stats=True)
+            if self.x3 and self.fuse_ds_bn:
+                r, bnpd = yd, self._bn_params(pre + ".downsample.1", std_, cnt)
+            else:
+                r, bnpd = self._bn(pre + ".downsample.1", yd, std_, cnt, relu=False, feeds_conv=False)
+            rec.update(ds=True, yd=yd, bnpd=bnpd)
+        else:
+            r, bnpd = x, None
+        out, bnp3 = self._bn(pre + ".bn3", y3, st3, cnt, res=r, relu=True, keep_f32=(not self.res_planes) or last or not self.x3,
+                             res_bnp=bnpd if (self.x3 and self.fuse_ds_bn and has_ds) else None)
+        rec.update(bnp3=bnp3, out=out, y2_last=y3, bnp_last=bnp3)
+        return out, rec
+
+    def _bottleneck_bwd(self, dout, rec, dout_part, nxt):
+        """Backward of one Bottleneck block; returns (gradient wrt the block input, its fused BatchNorm partials or None)."""
+        gv = self.p.gview
+        pre, stride, x = rec["pre"], rec["stride"], rec["x"]
+        fz = self._frozen(pre)
+        dy3, dz = self._bn_bwd(dout, rec["out"], rec["y3"], rec["bnp3"], gv(pre + ".bn3.weight"), gv(pre + ".bn3.bias"),
+                           relu=True, want_dz=True, part=dout_part, frozen=fz)
+        a2, a1 = rec["a2"], rec["a1"]
+        self._wgrad_side(self._conv_wgrad, a2, dy3, 1, 1, 1, 0, out=gv(pre + ".conv3.weight"))
+        da2, part2 = self._conv_dgrad(dy3, pre + ".conv3.weight", (dy3.shape[-3], dy3.shape[-2]), 1, 0, bn=(rec["y2"], None, rec["bnp2"]))
+        dy2 = self._bn_bwd(da2, a2, rec["y2"], rec["bnp2"], gv(pre + ".bn2.weight"), gv(pre + ".bn2.bias"), relu="recompute", part=part2, frozen=fz)
+        self._wgrad_side(self._conv_wgrad, a1, dy2, 3, 3, stride, 1, out=gv(pre + ".conv2.weight"))
+        h1, w1 = (a1.shape[-3], a1.shape[-2])
+        da1, part1 = self._conv_dgrad(dy2, pre + ".conv2.weight", (h1, w1), stride, 1, bn=(rec["y1"], None, rec["bnp1"]))
+        dy1 = self._bn_bwd(da1, a1, rec["y1"], rec["bnp1"], gv(pre + ".bn1.weight"), gv(pre + ".bn1.bias"), relu="recompute", part=part1, frozen=fz)
+        self._wgrad_side(self._conv_wgrad, x, dy1, 1, 1, 1, 0, out=gv(pre + ".conv1.weight"))
+        hw = (x.shape[-3], x.shape[-2])
+        if rec["ds"]:
+            dyd = self._bn_bwd(dz, None, rec["yd"], rec["bnpd"], gv(pre + ".downsample.1.weight"), gv(pre + ".downsample.1.bias"), relu=False, frozen=fz)
+            self._wgrad_side(self._conv_wgrad, x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
+            dx = self._conv_dgrad(dy1, pre + ".conv1.weight", hw, 1, 0)
+            return self._conv_dgrad(dyd, pre + ".downsample.0.weight", hw, stride, 0, addend=dx), None
+        return self._conv_dgrad(dy1, pre + ".conv1.weight", hw, 1, 0, addend=dz), None
 
     def _eval_block(self, x, pre, stride, has_ds, last):
         """One BasicBlock in eval mode (resnet.py:85-101 with running statistics): where the 3x3 kernel takes the shape the
@@ -760,6 +832,9 @@ class HybridNet:
         for k, rec in enumerate(blocks):
             pre, stride, x = rec["pre"], rec["stride"], rec["x"]
             nxt = blocks[k + 1] if k + 1 < len(blocks) else below
+            if rec.get("kind") == "bottleneck":
+                dout, dout_part = self._bottleneck_bwd(dout, rec, dout_part, nxt)
+                continue
             fz = self._frozen(pre)
             dy2, dz = self._bn_bwd(dout, rec["out"], rec["y2"], rec["bnp2"], gv(pre + ".bn2.weight"), gv(pre + ".bn2.bias"),
                                relu=True, want_dz=True, part=dout_part, frozen=fz)

@@ -141,7 +141,9 @@ class _NetBridge(torch.autograd.Function):
         return None, None, None, None, None
 
 
-BASIC_BLOCK_LAYERS = {"ResNet18": (2, 2, 2, 2), "ResNet34": (3, 4, 6, 3)}       # resnet.py:236-248 (BasicBlock stages)
+# resnet.py:232-276: block type and stage counts of the five registered backbones
+BACKBONES = {"ResNet18": ("basic", (2, 2, 2, 2)), "ResNet34": ("basic", (3, 4, 6, 3)), "ResNet50": ("bottleneck", (3, 4, 6, 3)),
+             "ResNet101": ("bottleneck", (3, 4, 23, 3)), "ResNet152": ("bottleneck", (3, 8, 36, 3))}
 
 
 @MODEL.register_module
@@ -157,12 +159,19 @@ class HybridBaseline(nn.Module):
         head = cfg[self.HEAD_KEY]
         self.nclasses = head["NCLASSES"]
         self.depth_res = head["DEPTH_RESOLUTION"]
-        if cfg["BACKBONE"]["TYPE"] not in BASIC_BLOCK_LAYERS:
-            raise NotImplementedError(f"backbone {cfg['BACKBONE']['TYPE']}: the HIP path implements the BasicBlock ResNets (ResNet18, ResNet34); "
-                                      f"the Bottleneck ones (ResNet50/101/152, resnet.py:104-141) are not built")
+        if cfg["BACKBONE"]["TYPE"] not in BACKBONES:
+            raise NotImplementedError(f"backbone {cfg['BACKBONE']['TYPE']}: one of {sorted(BACKBONES)} (resnet.py:232-276)")
+        block, layers = BACKBONES[cfg["BACKBONE"]["TYPE"]]
+        feat_ch = 512 * (4 if block == "bottleneck" else 1)
         if (head.get("NUM_DECONV_LAYERS", 2), list(head.get("NUM_DECONV_FILTERS", [256, 256])), list(head.get("NUM_DECONV_KERNELS", [4, 4])),
-                head.get("INPUT_CHANNEL", 512), bool(head.get("DECONV_WITH_BIAS", False))) != (2, [256, 256], [4, 4], 512, False):
-            raise NotImplementedError("IntegralDeconvHead: 2 x (ConvTranspose2d 4x4/s2, 256 filters, no bias) on 512 input channels only")
+                head.get("INPUT_CHANNEL", feat_ch), bool(head.get("DECONV_WITH_BIAS", False))) != (2, [256, 256], [4, 4], feat_ch, False):
+            raise NotImplementedError(f"IntegralDeconvHead: 2 x (ConvTranspose2d 4x4/s2, 256 filters, no bias) on the backbone's {feat_ch} channels only")
+        box_dims = (feat_ch, 256, 128)
+        if self.HAS_BOX_HEAD:
+            bh = cfg.get("BOX_HEAD", {})
+            box_dims = tuple(bh.get("LAYERS_N", [feat_ch, 256, 128]))
+            if len(box_dims) != 3 or box_dims[0] != feat_ch or bh.get("OUT_CHANNEL", 6) != 6:
+                raise NotImplementedError(f"MLP_O: LAYERS_N [{feat_ch}, h1, h2] and OUT_CHANNEL 6 only")
         from .head import norm_code
         norm = norm_code(head.get("NORM_TYPE", "softmax"))          # softmax / sigmoid (simplebaseline.py:16-40); divide_sum raises
         if head.get("FINAL_CONV_KERNEL", 1) != 1:
@@ -175,8 +184,8 @@ class HybridBaseline(nn.Module):
                           "pass a converted checkpoint through ARCH.PRETRAINED")
         dev = cfg.get("DEVICE", "cuda")
         cd = cfg.get("COMPUTE_DTYPE", "bf16x3")     # the reference's precision (fp32-grade); "bf16" / "f32" opt in
-        self.store = ParamStore(self.nclasses, self.depth_res, device=dev, layers=BASIC_BLOCK_LAYERS[cfg["BACKBONE"]["TYPE"]],
-                                head_prefix=self.HEAD_PREFIX, box_head=self.HAS_BOX_HEAD)
+        self.store = ParamStore(self.nclasses, self.depth_res, device=dev, layers=layers, head_prefix=self.HEAD_PREFIX,
+                                box_head=self.HAS_BOX_HEAD, block=block, box_dims=box_dims)
         self.store.init_reference_like(seed=int(cfg.get("INIT_SEED", 1)))
         self.net = HybridNet(self.store, image_size=self.inp_res,
                              compute_dtype=(torch.bfloat16 if cd in ("bf16", torch.bfloat16) else

@@ -23,7 +23,7 @@ JOINTS_IDX_PARENTS = [0, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 0, 13, 14, 15, 0,
 
 
 # ----------------------------------------------------------------------------- parameters
-def param_shapes(nclasses=22, depth=28, layers=None, head_prefix="hybrid_head", box_head=True):
+def param_shapes(nclasses=22, depth=28, layers=None, head_prefix="hybrid_head", box_head=True, bottleneck=False):
     """Ordered (name, shape) list == reference state_dict of Arch(HybridBaseline) minus the Arch prefix
     (resnet.py:142-168, simplebaseline.py:78-101,152-175, mlp.py:11-22).  layers / head_prefix / box_head: the SimpleBaseline
     variant (simplebaseline.py:194-241: `pose_head`, no MLP_O) and the ResNet-18 stage counts (resnet.py:236-241)."""
@@ -41,6 +41,19 @@ def param_shapes(nclasses=22, depth=28, layers=None, head_prefix="hybrid_head", 
         for b in range(nblk):
             stride = 2 if (b == 0 and li > 1) else 1
             p = f"backbone.layer{li}.{b}"
+            if bottleneck:                      # Bottleneck (resnet.py:104-141), expansion 4
+                outp = planes * 4
+                out.append((p + ".conv1.weight", (planes, inpl, 1, 1)))
+                bn(p + ".bn1", planes)
+                out.append((p + ".conv2.weight", (planes, planes, 3, 3)))
+                bn(p + ".bn2", planes)
+                out.append((p + ".conv3.weight", (outp, planes, 1, 1)))
+                bn(p + ".bn3", outp)
+                if stride != 1 or inpl != outp:
+                    out.append((p + ".downsample.0.weight", (outp, inpl, 1, 1)))
+                    bn(p + ".downsample.1", outp)
+                inpl = outp
+                continue
             out.append((p + ".conv1.weight", (planes, inpl, 3, 3)))
             bn(p + ".bn1", planes)
             out.append((p + ".conv2.weight", (planes, planes, 3, 3)))
@@ -49,16 +62,17 @@ def param_shapes(nclasses=22, depth=28, layers=None, head_prefix="hybrid_head", 
                 out.append((p + ".downsample.0.weight", (planes, inpl, 1, 1)))
                 bn(p + ".downsample.1", planes)
             inpl = planes
-    out.append(("backbone.fc.weight", (1000, 512)))
+    fch = 2048 if bottleneck else 512
+    out.append(("backbone.fc.weight", (1000, fch)))
     out.append(("backbone.fc.bias", (1000,)))
     hp = head_prefix
-    out.append((hp + ".deconv_layers.0.weight", (512, 256, 4, 4)))
+    out.append((hp + ".deconv_layers.0.weight", (fch, 256, 4, 4)))
     bn(hp + ".deconv_layers.1", 256)
     out.append((hp + ".deconv_layers.3.weight", (256, 256, 4, 4)))
     bn(hp + ".deconv_layers.4", 256)
     out.append((hp + ".final_layer.weight", (nclasses * depth, 256, 1, 1)))
     out.append((hp + ".final_layer.bias", (nclasses * depth,)))
-    for i, (a, b) in (zip((0, 2, 4), ((512, 256), (256, 128), (128, 6))) if box_head else ()):
+    for i, (a, b) in (zip((0, 2, 4), ((fch, 256), (256, 128), (128, 6))) if box_head else ()):
         out.append((f"box_head.layers.{i}.weight", (b, a)))
         out.append((f"box_head.layers.{i}.bias", (b,)))
     return out
@@ -123,7 +137,7 @@ def _bn(x, p, prefix, training, eps=1e-5, momentum=0.1, stats=None):
     return (x - mean[None, :, None, None]) * (inv * w)[None, :, None, None] + b[None, :, None, None]
 
 
-def resnet34_forward(p, image, training=True, stats=None, feats=None, frozen_bn=False, layers=None):
+def resnet34_forward(p, image, training=True, stats=None, feats=None, frozen_bn=False, layers=None, bottleneck=False):
     """ResNet.forward (resnet.py:199-221) with BasicBlock.forward (resnet.py:85-101).
     frozen_bn: BACKBONE.FREEZE_BATCHNORM (resnet.py:146-149 bn_layer = FrozenBatchNorm2d, resnet.py:33-69): every backbone BatchNorm is the
     fixed affine map scale = w * rsqrt(running_var + 1e-5), bias = b - running_mean * scale in BOTH modes (weight / bias are buffers)."""
@@ -139,6 +153,15 @@ def resnet34_forward(p, image, training=True, stats=None, feats=None, frozen_bn=
             stride = 2 if (b == 0 and li > 1) else 1
             pre = f"backbone.layer{li}.{b}"
             res = x
+            if bottleneck:                      # Bottleneck.forward (resnet.py:119-141): the stride sits on the 3x3 convolution
+                out = F.relu(_bn(F.conv2d(x, p[pre + ".conv1.weight"]), p, pre + ".bn1", training, stats=stats))
+                out = F.relu(_bn(F.conv2d(out, p[pre + ".conv2.weight"], stride=stride, padding=1), p, pre + ".bn2", training, stats=stats))
+                out = _bn(F.conv2d(out, p[pre + ".conv3.weight"]), p, pre + ".bn3", training, stats=stats)
+                if stride != 1 or inpl != planes * 4:
+                    res = _bn(F.conv2d(x, p[pre + ".downsample.0.weight"], stride=stride), p, pre + ".downsample.1", training, stats=stats)
+                x = F.relu(out + res)
+                inpl = planes * 4
+                continue
             out = F.conv2d(x, p[pre + ".conv1.weight"], stride=stride, padding=1)
             out = F.relu(_bn(out, p, pre + ".bn1", training, stats=stats))
             out = F.conv2d(out, p[pre + ".conv2.weight"], stride=1, padding=1)
@@ -229,11 +252,11 @@ def box_head_forward(p, x):
 
 
 def hybrid_forward(p, batch, inp_res, nclasses=22, depth=28, center_idx=0, training=True, stats=None, keep=None, frozen_bn=False,
-                   norm_type="softmax"):
+                   norm_type="softmax", layers=None, bottleneck=False):
     """HybridBaseline.forward (hybridbaseline.py:37-96)."""
     image = batch["image"]
     H, W = image.shape[2], image.shape[3]
-    feat, feat_mean = resnet34_forward(p, image, training, stats=stats, feats=keep, frozen_bn=frozen_bn)
+    feat, feat_mean = resnet34_forward(p, image, training, stats=stats, feats=keep, frozen_bn=frozen_bn, layers=layers, bottleneck=bottleneck)
     kp3d, conf = head_forward(p, feat, nclasses, depth, training, stats=stats, keep=keep, norm_type=norm_type)
     box6d = box_head_forward(p, feat_mean)
     pose_abs = uvd2xyz(kp3d, batch["root_joint"], batch["cam_intr"], inp_res)
@@ -260,10 +283,11 @@ def hybrid_forward(p, batch, inp_res, nclasses=22, depth=28, center_idx=0, train
     }
 
 
-def simple_forward(p, batch, inp_res, nclasses=29, depth=28, center_idx=0, training=True, stats=None, layers=None, norm_type="softmax"):
+def simple_forward(p, batch, inp_res, nclasses=29, depth=28, center_idx=0, training=True, stats=None, layers=None, norm_type="softmax",
+                   bottleneck=False):
     """SimpleBaseline.forward (simplebaseline.py:211-241): backbone -> pose_head -> uvd2xyz; 21 joints + 8 corners straight from
     the heat maps (no box head)."""
-    feat, _ = resnet34_forward(p, batch["image"], training, stats=stats, layers=layers)
+    feat, _ = resnet34_forward(p, batch["image"], training, stats=stats, layers=layers, bottleneck=bottleneck)
     kp3d, conf = head_forward(p, feat, nclasses, depth, training, stats=stats, norm_type=norm_type, hp="pose_head")
     abs_ = uvd2xyz(kp3d, batch["root_joint"], batch["cam_intr"], inp_res)
     joints_abs, corners_abs = abs_[:, :21], abs_[:, 21:]

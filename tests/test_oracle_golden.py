@@ -189,3 +189,29 @@ def test_simplebaseline_oracle_matches_reference_class(golden_dir):
         if n.startswith("backbone.fc"):
             continue
         np.testing.assert_allclose(float(leaf[n].grad.norm()), r, rtol=2e-3, atol=1e-9, err_msg=n)
+
+
+def test_bottleneck_oracle_matches_reference_resnet50(golden_dir):
+    """lo.hybrid_forward(bottleneck=True) -- HybridBaseline on ResNet50 (resnet.py:104-141,252-258) -- against the reference's own class on
+    seeded weights (tests/golden/resnet50_hybrid.npz, oracle/gen_resnet50_golden.py)."""
+    import torch
+    from gen_batch import make_batch
+    g = np.load(os.path.join(golden_dir, "resnet50_hybrid.npz"))
+    size, heat, depth, B, seed = [int(x) for x in g["meta"]]
+    params = lo.fill_params(lo.param_shapes(22, depth, bottleneck=True), seed=seed)
+    batch = make_batch(B, size, seed + 100)
+    with torch.no_grad():
+        pe = lo.hybrid_forward(params, batch, [size, size], 22, depth, 0, training=False, bottleneck=True)
+    for k in ("joints_3d_abs", "corners_3d_abs", "2d_uvd"):
+        np.testing.assert_allclose(pe[k].numpy(), g[f"eval.pred.{k}"], rtol=0, atol=3e-5, err_msg=k)
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in params.items()}
+    pt = lo.hybrid_forward(leaf, batch, [size, size], 22, depth, 0, training=True, bottleneck=True)
+    for k in ("joints_3d_abs", "corners_3d_abs"):
+        np.testing.assert_allclose(pt[k].detach().numpy(), g[f"train.pred.{k}"], rtol=0, atol=3e-5, err_msg=k)
+    total, _ = lo.joints_loss(pt, batch)
+    np.testing.assert_allclose(float(total), float(g["loss.total"]), rtol=1e-4)
+    total.backward()
+    ref = dict(zip([str(n) for n in g["grad.names"]], g["grad.norms"]))
+    for n, r in ref.items():
+        if not n.startswith("backbone.fc"):
+            np.testing.assert_allclose(float(leaf[n].grad.norm()), r, rtol=3e-3, atol=1e-9, err_msg=n)
