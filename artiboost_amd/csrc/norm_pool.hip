@@ -243,8 +243,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const uint8_t* __restrict__ pool_idx = nullptr, int pH = 0, int pW = 0,
                                                             const bf16_t* __restrict__ out_hi = nullptr) {
     constexpr int V = Vec<T>::N;
-    const int vc = C / V, rl = 256 / vc;
-    const int cv = threadIdx.x % vc, rr = threadIdx.x / vc;
+    // wide tensors (C / V > 256: the 2048-channel stage of the Bottleneck ResNets): gridDim.y slices of CS = C / gridDim.y channels
+    const int CS = C / (int)gridDim.y, vcs = CS / V, rl = 256 / vcs;
+    const int cv = (int)blockIdx.y * vcs + (int)(threadIdx.x % vcs), rr = threadIdx.x / vcs;
     long r0 = (long)blockIdx.x * rows_per_block;
     long r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
     float s[V], q[V], mean[V], istd[V], sc[V], sh[V];
@@ -281,14 +282,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             }
         }
     extern __shared__ float sm[];
+    const int cl0 = (int)blockIdx.y * CS;                 // first channel of this slice
     if (rr < rl)
 #pragma unroll
-        for (int i = 0; i < V; ++i) { sm[(rr * C + cv * V + i) * 2] = s[i]; sm[(rr * C + cv * V + i) * 2 + 1] = q[i]; }
+        for (int i = 0; i < V; ++i) { sm[(rr * CS + cv * V + i - cl0) * 2] = s[i]; sm[(rr * CS + cv * V + i - cl0) * 2 + 1] = q[i]; }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < CS; c += 256) {
         float a = 0.f, b = 0.f;
-        for (int k = 0; k < rl; ++k) { a += sm[(k * C + c) * 2]; b += sm[(k * C + c) * 2 + 1]; }
-        part[((long)blockIdx.x * C + c) * 2] = a; part[((long)blockIdx.x * C + c) * 2 + 1] = b;
+        for (int k = 0; k < rl; ++k) { a += sm[(k * CS + c) * 2]; b += sm[(k * CS + c) * 2 + 1]; }
+        part[((long)blockIdx.x * C + cl0 + c) * 2] = a; part[((long)blockIdx.x * C + cl0 + c) * 2 + 1] = b;
     }
 }
 
@@ -1069,11 +1071,13 @@ static int bn_bwd_impl(const void* dout, const void* out, const void* y, const f
                        int relu, float* part, float* bwdp, float* dgamma, float* dbeta, void* dy, void* dz_out,
                        const uint8_t* pool_idx, int pH, int pW, hipStream_t st, int given_parts = 0) {
     int V = dtype == AB_DT_F32 ? 4 : 8;
-    if (C % V || C / V > 256) return AB_ESHAPE;
-    int np = given_parts > 0 ? given_parts : ab_col_stats_nparts(M); int rl = 256 / (C / V); size_t sh = (size_t)rl * C * 2 * 4;
+    int ysl = 1;                                  // channel slices of the reduction (<= 256 V-channel groups each)
+    while (C / V / ysl > 256) ysl *= 2;
+    if (C % V || C % (V * ysl)) return AB_ESHAPE;
+    int np = given_parts > 0 ? given_parts : ab_col_stats_nparts(M); const int cs = C / ysl; int rl = 256 / (cs / V); size_t sh = (size_t)rl * cs * 2 * 4;
     if (given_parts <= 0)
-    DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, red_rows(M), part, pool_idx, pH, pW)),
-             (bn_bwd_reduce_kernel<bf16_t><<<np, 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, red_rows(M), part, pool_idx, pH, pW)));
+    DISPATCH(dtype, (bn_bwd_reduce_kernel<float><<<dim3(np, ysl), 256, sh, st>>>((const float*)dout, (const float*)out, (const float*)y, bnp, M, C, relu, red_rows(M), part, pool_idx, pH, pW)),
+             (bn_bwd_reduce_kernel<bf16_t><<<dim3(np, ysl), 256, sh, st>>>((const bf16_t*)dout, (const bf16_t*)out, (const bf16_t*)y, bnp, M, C, relu, red_rows(M), part, pool_idx, pH, pW)));
     AB_LAUNCH_CHECK();
     launch_bn_bwd_finalize(part, np, C, dgamma, dbeta, bwdp, st);
     AB_LAUNCH_CHECK();
@@ -1263,12 +1267,14 @@ extern "C" int ab_bn_bwd_x3(const float* dout, const void* out, int out_is_hi_pl
         return AB_EINVAL;
     const float* out_f = out_is_hi_plane ? nullptr : (const float*)out;
     const bf16_t* out_h = out_is_hi_plane ? (const bf16_t*)out : nullptr;
-    if (C % 8 || C / 4 > 256) return AB_ESHAPE;
+    int ysl = 1;                                  // channel slices of the reduction (<= 256 four-channel groups each)
+    while (C / 4 / ysl > 256) ysl *= 2;
+    if (C % 8 || C % (4 * ysl)) return AB_ESHAPE;
     hipStream_t st = as_stream(stream);
     int np = nparts_given > 0 ? nparts_given : ab_col_stats_nparts(M);
     if (nparts_given <= 0) {
-        const int rl = 256 / (C / 4); const size_t sh = (size_t)rl * C * 2 * 4;
-        bn_bwd_reduce_kernel<float><<<np, 256, sh, st>>>(dout, out_f, y, bnp, M, C, relu, red_rows(M), part, nullptr, 0, 0, out_h);
+        const int cs = C / ysl, rl = 256 / (cs / 4); const size_t sh = (size_t)rl * cs * 2 * 4;
+        bn_bwd_reduce_kernel<float><<<dim3(np, ysl), 256, sh, st>>>(dout, out_f, y, bnp, M, C, relu, red_rows(M), part, nullptr, 0, 0, out_h);
         AB_LAUNCH_CHECK();
     }
     launch_bn_bwd_finalize(part, np, C, dgamma, dbeta, bwdp, st);
