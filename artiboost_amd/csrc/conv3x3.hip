@@ -564,11 +564,17 @@ static size_t c3_lds(int nchunks) {
 
 // config choice: 0 = unsupported, 1 = <128,32,64,2,2>, 2 = <256,32,128,2,2>, 3 = <128,16,128,2,2>, 4 = <128,16,64,2,2>,
 // 5 = <64,8,128,2,2>
-static int c3_config(int N, int H, int W, int C, int Cn) {
+// x3plain: a split-bf16 launch WITHOUT the fused BatchNorm-backward epilogue (forward, plain data gradient, eval-mode fold).
+static int c3_config(int N, int H, int W, int C, int Cn, bool x3plain = false) {
     if (C % 64 || Cn % 8 || getenv("AB_CONV3_OFF")) return 0;
-    if (const char* f = getenv("AB_C3_FORCE")) return atoi(f);      // tile-shape probes (tools/bench_conv_x3.py)
-    if (const char* f = getenv("AB_C3_FORCE")) return atoi(f);      // tile-shape probes (tools/bench_conv_x3.py)
+    if (const char* f = getenv("AB_C3_FORCE")) return atoi(f);      // tile-shape probes (tools/bench_conv_x3.py, tools/ab_l1_tiles.py)
     if (W >= 24) {
+        // Layer 1 in bf16x3 (64 -> 64 channels on 64 x 64 maps), in-process A/B on one box (tools/ab_l1_tiles.py, round 3): the 8 x 16-pixel
+        // tile of 128 pixels (4: patch 10 x 18 = 1.41 x its outputs, two workgroups per CU) runs the forward in 63.9 us and the plain data
+        // gradient in 61.4 against 71.9 / 70.7 on the 256-pixel tile (7) and 78.4 / 74.7 on 4 x 32 pixels (1) -- but the data gradient WITH the
+        // fused BatchNorm-backward epilogue prefers the 256-pixel tile (86.8 vs 95.2 us), so only the plain launches switch.  AB_C3_L1T16=0: off.
+        static const int l1t16 = getenv("AB_C3_L1T16") ? atoi(getenv("AB_C3_L1T16")) : 1;
+        if (x3plain && l1t16 && Cn <= 64 && W % 16 == 0 && H % 8 == 0) return 4;
         // 64 output channels: a 256-pixel tile (64 x 32 per wave: 1 KB of fragment reads per MFMA instead of 1.33) where that
         // still leaves every CU two workgroups -- layer 1 at B = 64: 10.66 -> 10.54 ms/step in bf16x3.  AB_C3_L1ALT=0: 128 pixels.
         // (=2: whatever the tile count -- tests)
@@ -665,9 +671,21 @@ int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, i
 
 // ---- split-bf16 ("bf16x3") launches: x / wt given as (hi, lo) bf16 planes, out / addend / stats fp32.
 // Tile shapes are those of the bf16 path, always on 8 waves (the accumulators of both chains need the registers).
+static int c3_tiles_of(int cfg, int N, int H, int W) {
+    if (!cfg) return 0;
+    int bm, tw, bn; c3_geom(cfg, &bm, &tw, &bn);
+    int th = bm / tw;
+    return N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
+}
+
+// BatchNorm partial rows of the split-bf16 launches: of a forward / plain launch, and of a data gradient with the fused reduction
 int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn) {
     if (C % 32) return 0;
-    return conv3x3_tiles(N, H, W, (C + 63) / 64 * 64, Cn);
+    return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, true), N, H, W);
+}
+int conv3x3_x3_tiles_bnr(int N, int H, int W, int C, int Cn) {
+    if (C % 32) return 0;
+    return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, false), N, H, W);
 }
 
 struct C3EvalBn { void* out_hi; void* out_lo; float* out_f32; const void* res_hi; const void* res_lo; int relu; };
@@ -678,7 +696,7 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
     if (C % 32) return AB_ESHAPE;
     if (bn_y && (!flip || stats || !bnp || !bn_part)) return AB_EINVAL;
     if (ev && (flip || stats || bn_y || !bnp || !ev->out_hi || !ev->out_lo || (ev->res_hi && (addend || !ev->res_lo)))) return AB_EINVAL;
-    int cfg = c3_config(N, H, W, (C + 63) / 64 * 64, Cn);
+    int cfg = c3_config(N, H, W, (C + 63) / 64 * 64, Cn, /*x3plain=*/!bn_y);
     if (!cfg || Cn % 4) return AB_ESHAPE;
     const long delta = (const char*)wt_lo - (const char*)wt_hi;
     if (delta < 0 || delta >= (1L << 31)) return AB_EINVAL;       // the lo plane is addressed as a 32-bit offset from the hi plane

@@ -10,6 +10,7 @@
 #include "conv_common.h"
 
 int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn);
+int conv3x3_x3_tiles_bnr(int N, int H, int W, int C, int Cn);
 struct C3EvalBn { void* out_hi; void* out_lo; float* out_f32; const void* res_hi; const void* res_lo; int relu; };
 int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W,
                    int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st, const float* bn_y = nullptr,
@@ -232,7 +233,7 @@ extern "C" int ab_conv2d_dgrad_x3_pair(const void* dy_hi, const void* dy_lo, con
 // of that BatchNorm backward is gone.  rows = ab_conv2d_dgrad_x3_bn_rows(...); 0: shape not handled (use ab_conv2d_dgrad_x3).
 extern "C" int ab_conv2d_dgrad_x3_bn_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
     if (!x3_is_c3(kh, kw, stride, pad) || getenv("AB_X3_BNFUSE_OFF")) return 0;
-    return conv3x3_x3_tiles(N, H, W, Cout, Cin);
+    return conv3x3_x3_tiles_bnr(N, H, W, Cout, Cin);
 }
 
 extern "C" int ab_conv2d_dgrad_x3_bn(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dz, int N,
