@@ -251,8 +251,10 @@ def test_conv_dgrad_x3_bn_fused(case, mask_src):
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 64, 64), (2, 56, 40, 64, 64), (3, 32, 32, 64, 64)])
 def test_conv3x3_x3_256x64_tile(case, monkeypatch):
-    """The 256-pixel x 64-channel tile of the 64-channel 3x3 layers (picked on its own only when the launch has >= 512 tiles,
-    i.e. at benchmark size) forced onto small shapes: forward + statistics, data gradient, fused BatchNorm-backward epilogue."""
+    """The two tiles of the 64-channel 3x3 layers: 8 x 16 pixels for the forward / plain data gradient (round 3: tools/ab_l1_tiles.py) and
+    256 pixels (8 x 32) for the data gradient with the fused BatchNorm-backward epilogue (picked on its own only when the launch has >= 512
+    tiles, i.e. at benchmark size; forced here): forward + statistics, data gradient, fused epilogue -- and the partial-row counts that say
+    which geometry ran."""
     from artiboost_amd import kernels as K
     monkeypatch.setenv("AB_C3_L1ALT", "2")
     N, H, W, Cin, Cout = case
@@ -262,7 +264,8 @@ def test_conv3x3_x3_256x64_tile(case, monkeypatch):
     ref = F.conv2d(x.double(), w.double(), padding=1)
     y, stats = K.conv2d_fwd_x3(nhwc(x).cuda(), K.split(w.permute(0, 2, 3, 1).contiguous().cuda()), 1, 1, want_stats=True)
     close(nchw(y.cpu()), ref)
-    assert stats.shape[0] == N * ((H + 7) // 8) * ((W + 31) // 32)          # one partial row per 8 x 32 tile: the new geometry ran
+    t16 = W % 16 == 0 and H % 8 == 0
+    assert stats.shape[0] == N * ((H + 7) // 8) * ((W + 15) // 16 if t16 else (W + 31) // 32)      # one partial row per 8 x 16 (else 8 x 32) tile
     yy = y.double().cpu().reshape(-1, Cout)
     np.testing.assert_allclose(stats.double().sum(0).cpu()[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)
     dy = torch.randn((N, Cout, H, W), generator=g)
@@ -274,6 +277,7 @@ def test_conv3x3_x3_256x64_tile(case, monkeypatch):
     ybn = torch.randn((N, H, W, Cin), generator=g)
     bnp = K.bn_finalize(K.col_stats(ybn.cuda()), N * H * W, torch.ones(Cin).cuda(), torch.zeros(Cin).cuda(), torch.zeros(Cin).cuda(), torch.ones(Cin).cuda())
     dz, part = K.conv2d_dgrad_x3(nhwc(dy).cuda(), wt, (H, W), 1, 1, addend=nhwc(add).cuda(), bn=(ybn.cuda(), None, bnp))
+    assert part.shape[0] == N * ((H + 7) // 8) * ((W + 31) // 32)           # the fused epilogue keeps the 8 x 32 tile
     ref_dz = nhwc(ref_dx) * (((ybn - bnp[2].cpu()) * bnp[3].cpu()) > 0).double()
     close(dz.cpu(), ref_dz)
     np.testing.assert_allclose(part.double().sum(0).cpu()[:, 0].numpy(), ref_dz.sum((0, 1, 2)).numpy(), rtol=1e-4,

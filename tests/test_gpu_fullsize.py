@@ -94,7 +94,9 @@ def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name):
             # between two equally valid tilings of the same kernel; the large terms stay within 1.6e-4.
             tol = 3e-4 if step == 0 or k != "part_ord_loss" else 1.5e-3
             assert abs(got[k] - r) <= tol * abs(r) + 1e-9, (step, k, got[k], r)
-        assert abs(gnorm - rnorm) <= 1e-2 * rnorm, (step, gnorm, rnorm)
+        # step 0: identical weights on both sides.  Step 1 runs on weights that differ by Adam's first update (lr * sign(g): entries whose
+        # gradient is rounding-level flip sign between two equally valid summation orders), measured 0.05 - 1.3 % over tile geometries
+        assert abs(gnorm - rnorm) <= (1e-2 if step == 0 else 2e-2) * rnorm, (step, gnorm, rnorm)
     # BASELINE configs[1] at ITS size: the eval-mode forward (running statistics of the two steps above, BatchNorm folded into the conv
     # epilogues, ab_pose_assemble) on the last batch vs the oracle in eval mode with ITS running statistics and updated weights
     sd_now = {k: v.clone() for k, v in hb.state_dict().items()}          # the GPU model's weights and running statistics after two steps
