@@ -35,15 +35,32 @@ struct Tables {
 };
 
 struct Reader {
-    const unsigned char* p; uint32_t pos, end; uint64_t acc; int n; uint32_t ff;
-    // MSB-first: the next bit is bit 63 of acc, n valid bits.  A fetched FF takes its stuffed 00 with it; `ff` remembers which of the
-    // buffered bytes those were, so that position() does not depend on how far ahead the buffer was filled.
+    // The scan is read as aligned 8-byte words (one word ahead in flight), byte-swapped so that the next raw byte is the top byte of `cur`.
+    // Decoded bits sit MSB-first in `acc` (the next bit is bit 63, n valid bits).  A fetched FF takes its stuffed 00 with it; `ff` remembers
+    // which of the buffered bytes those were, so that position() does not depend on how far ahead the buffer was filled.
+    const uint64_t* w; uint32_t pos, end, widx; uint64_t cur, nxt, acc; int cur_n, n; uint32_t ff;
+    __device__ __forceinline__ uint64_t word(uint32_t i) const { return __builtin_bswap64(w[i]); }
+    __device__ __forceinline__ uint32_t raw_at(uint32_t o) const { return (uint32_t)(word(o >> 3) >> (56 - 8 * (o & 7))) & 255u; }
+    __device__ __forceinline__ void raw_advance(int k) {
+        cur <<= 8 * k; cur_n -= k;
+        if (cur_n == 0) { cur = nxt; cur_n = 8; nxt = word(widx++); }
+    }
     __device__ __forceinline__ void fill() {
         while (n <= 56) {
+            if (n <= 32 && cur_n >= 4 && pos + 4 <= end) {   // four bytes at once when none of them is FF
+                const uint32_t x = (uint32_t)(cur >> 32), y = ~x;
+                if (!((y - 0x01010101u) & ~y & 0x80808080u)) {
+                    acc |= (uint64_t)x << (32 - n);
+                    n += 32; ff <<= 4; pos += 4;
+                    raw_advance(4);
+                    continue;
+                }
+            }
             uint32_t c = 0, isff = 0;
             if (pos < end) {
-                c = p[pos];
-                if (c == 0xFF && pos + 1 < end && p[pos + 1] == 0) { pos++; isff = 1; }
+                c = (uint32_t)(cur >> 56);
+                raw_advance(1);
+                if (c == 0xFF && pos + 1 < end && (uint32_t)(cur >> 56) == 0) { raw_advance(1); pos++; isff = 1; }
             }
             pos++;                                           // past the end: zero bytes, the position keeps counting
             acc |= (uint64_t)c << (56 - n);
@@ -58,11 +75,15 @@ struct Reader {
     }
     __device__ __forceinline__ uint32_t peek(int k) const { return k ? (uint32_t)(acc >> (64 - k)) : 0u; }
     __device__ __forceinline__ void skip(int k) { acc <<= k; n -= k; }
-    // start at bit position P (a value position() returned, or 8 * a byte offset for a fresh start at a subsequence boundary)
-    __device__ __forceinline__ void seek(const unsigned char* base, uint32_t seg_start, uint32_t seg_end, uint32_t P) {
-        p = base; end = seg_end; acc = 0; n = 0; ff = 0;
+    // start at bit position P (a value position() returned, or 8 * a byte offset for a fresh start at a subsequence boundary); offsets are
+    // relative to `data`, which is 8-byte aligned
+    __device__ __forceinline__ void seek(const unsigned char* data, uint32_t seg_start, uint32_t seg_end, uint32_t P) {
+        w = reinterpret_cast<const uint64_t*>(data); end = seg_end; acc = 0; n = 0; ff = 0;
         const uint32_t q = P >> 3;
-        pos = (q > seg_start && q < seg_end && base[q] == 0 && base[q - 1] == 0xFF) ? q - 1 : q;
+        pos = (q > seg_start && q < seg_end && raw_at(q) == 0 && raw_at(q - 1) == 0xFF) ? q - 1 : q;
+        widx = pos >> 3;
+        cur = word(widx) << (8 * (pos & 7)); cur_n = 8 - (int)(pos & 7);
+        nxt = word(widx + 1); widx += 2;
         fill();
         skip((int)(P & 7u));
     }
@@ -128,7 +149,8 @@ __global__ __launch_bounds__(NT) void jpeg_entropy_kernel(EntropyArgs a) {
     const int tid = threadIdx.x;
     const int32_t* d = a.desc + (size_t)blockIdx.x * AB_JPEG_DESC_INTS;
     const int ncomp = d[D_NCOMP], bpm = d[D_BPM], nseg = d[D_NSEG], nsub = d[D_NSUB], ri = d[D_RI];
-    const unsigned char* base = a.data + d[D_OFF];
+    const unsigned char* base = a.data;                      // every offset below is relative to `data` (8-byte aligned)
+    const uint32_t off0 = (uint32_t)d[D_OFF];
     const int32_t* segs = a.segs + (size_t)d[D_SEG_OFF] * 4;
     // ---- decode tables of this image: 8 slots x (16 counts + 256 symbols)
     for (int i = tid; i < 8 * (1 << LUT_BITS); i += NT) (&T.lut[0][0])[i] = 0;
@@ -167,15 +189,15 @@ __global__ __launch_bounds__(NT) void jpeg_entropy_kernel(EntropyArgs a) {
     // ---- round 0: every subsequence from its first bit, state (block 0 of the MCU, k = 0)
     for (int u = tid; u < nsub; u += NT) {
         const int s = seg_of_sub(segs, nseg, u);
-        const uint32_t s0 = (uint32_t)segs[s * 4], s1 = s0 + (uint32_t)segs[s * 4 + 1];
+        const uint32_t s0 = off0 + (uint32_t)segs[s * 4], s1 = s0 + (uint32_t)segs[s * 4 + 1];
         const uint32_t j = (uint32_t)(u - segs[s * 4 + 2]);
         const uint32_t endbits = min(s1, s0 + (j + 1) * SB) * 8u;
         Reader r; r.seek(base, s0, s1, (s0 + j * SB) * 8u);
-        int b = 0, k = 0;
+        int b = 0, k = 0, nb = 0;
         r.fill();
-        while (r.position() < endbits) { symbol<false>(r, T, b, k, bpm, nullptr); r.fill(); }
+        while (r.position() < endbits) { nb += symbol<false>(r, T, b, k, bpm, nullptr) ? 1 : 0; r.fill(); }
         const uint32_t P = r.position(), S = (uint32_t)b | ((uint32_t)k << 8);
-        sP[u] = P; sS[u] = S;
+        sP[u] = P; sS[u] = S; sN[u] = nb;
         cP[u] = P; cS[u] = S;                                // the chain of the thread that started at u, now at the end of u
     }
     __syncthreads();
@@ -189,35 +211,22 @@ __global__ __launch_bounds__(NT) void jpeg_entropy_kernel(EntropyArgs a) {
             const int s = seg_of_sub(segs, nseg, u);
             const int last = (s + 1 < nseg ? segs[(s + 1) * 4 + 2] : nsub) - 1;          // last subsequence of the segment
             if (v > last) { cP[u] = 0xFFFFFFFFu; continue; }
-            const uint32_t s0 = (uint32_t)segs[s * 4], s1 = s0 + (uint32_t)segs[s * 4 + 1];
+            const uint32_t s0 = off0 + (uint32_t)segs[s * 4], s1 = s0 + (uint32_t)segs[s * 4 + 1];
             const uint32_t j = (uint32_t)(v - segs[s * 4 + 2]);
             const uint32_t endbits = min(s1, s0 + (j + 1) * SB) * 8u;
             Reader r; r.seek(base, s0, s1, P0);
-            int b = (int)(cS[u] & 255u), k = (int)(cS[u] >> 8);
+            int b = (int)(cS[u] & 255u), k = (int)(cS[u] >> 8), nb = 0;
             r.fill();
-            while (r.position() < endbits) { symbol<false>(r, T, b, k, bpm, nullptr); r.fill(); }
+            while (r.position() < endbits) { nb += symbol<false>(r, T, b, k, bpm, nullptr) ? 1 : 0; r.fill(); }
             const uint32_t P = r.position(), S = (uint32_t)b | ((uint32_t)k << 8);
+            // the chains reach v in order of decreasing start index, the last one (matching or not) carries the true state into v: its
+            // count of blocks completed inside v is the one that stays
+            sN[v] = nb;
             if (sP[v] == P && sS[v] == S) cP[u] = 0xFFFFFFFFu;                      // synchronised: from here on it is v's chain
             else { sP[v] = P; sS[v] = S; cP[u] = P; cS[u] = S; active = 1; }
         }
-        if (!__syncthreads_or(active)) break;
+        if (!__syncthreads_or(active)) { if (tid == 0) cP[0] = (uint32_t)rnd; break; }      // diagnostic: rounds this image took
     }
-    // ---- blocks completed inside each subsequence, from its true start state
-    for (int u = tid; u < nsub; u += NT) {
-        const int s = seg_of_sub(segs, nseg, u);
-        const uint32_t s0 = (uint32_t)segs[s * 4], s1 = s0 + (uint32_t)segs[s * 4 + 1];
-        const int jf = segs[s * 4 + 2];
-        const uint32_t j = (uint32_t)(u - jf);
-        const uint32_t endbits = min(s1, s0 + (j + 1) * SB) * 8u;
-        Reader r; int b = 0, k = 0;
-        if (u == jf) r.seek(base, s0, s1, s0 * 8u);
-        else { r.seek(base, s0, s1, sP[u - 1]); b = (int)(sS[u - 1] & 255u); k = (int)(sS[u - 1] >> 8); }
-        int nb = 0;
-        r.fill();
-        while (r.position() < endbits) { nb += symbol<false>(r, T, b, k, bpm, nullptr) ? 1 : 0; r.fill(); }
-        sN[u] = nb;
-    }
-    __syncthreads();
     // ---- exclusive scan of the counts over the image's subsequences (restarted at segment starts in the next pass by subtraction)
     if (tid == 0) s_carry = 0;
     __syncthreads();
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(NT) void jpeg_entropy_kernel(EntropyArgs a) {
     short* coefs = a.coefs + (size_t)d[D_BLK_BASE] * 64;
     for (int u = tid; u < nsub; u += NT) {
         const int s = seg_of_sub(segs, nseg, u);
-        const uint32_t s0 = (uint32_t)segs[s * 4], s1 = s0 + (uint32_t)segs[s * 4 + 1];
+        const uint32_t s0 = off0 + (uint32_t)segs[s * 4], s1 = s0 + (uint32_t)segs[s * 4 + 1];
         const int jf = segs[s * 4 + 2];
         const uint32_t j = (uint32_t)(u - jf);
         const uint32_t endbits = min(s1, s0 + (j + 1) * SB) * 8u;
@@ -389,12 +398,45 @@ __device__ __forceinline__ int upsampled(const PlaneRef& c, int x, int y) {     
 }
 __device__ __forceinline__ int clamp255(int x) { return x < 0 ? 0 : x > 255 ? 255 : x; }
 
+// four horizontally adjacent samples (x0 .. x0 + 3, x0 % 4 == 0) of one component at full resolution
+__device__ __forceinline__ void upsampled4(const PlaneRef& c, int x0, int y, int* v) {
+    if (c.hr == 1 && c.vr == 1) {
+        const uint32_t q = *reinterpret_cast<const uint32_t*>(c.P + (size_t)y * c.pitch + x0);
+        v[0] = q & 255; v[1] = (q >> 8) & 255; v[2] = (q >> 16) & 255; v[3] = q >> 24;
+        return;
+    }
+    if (c.hr == 2 && c.dw > 2 && (c.vr == 1 || c.vr == 2)) {      // fancy h2v1 / h2v2: columns i0 - 1 .. i0 + 2 of one or two rows
+        const int i0 = x0 >> 1, last = c.dw - 1;
+        const int ja = max(i0 - 1, 0), jb = min(i0, last), jc = min(i0 + 1, last), jd = min(i0 + 2, last);
+        if (c.vr == 1) {
+            const unsigned char* r = c.P + (size_t)y * c.pitch;
+            const int a = r[ja], b = r[jb], cc = r[jc], d = r[jd];
+            v[0] = i0 == 0 ? b : (b * 3 + a + 1) >> 2;
+            v[1] = i0 == last ? b : (b * 3 + cc + 2) >> 2;
+            v[2] = (cc * 3 + b + 1) >> 2;
+            v[3] = i0 + 1 >= last ? cc : (cc * 3 + d + 2) >> 2;
+        } else {
+            const int ir = y >> 1; int nr = (y & 1) ? ir + 1 : ir - 1;
+            nr = nr < 0 ? 0 : nr > c.dh - 1 ? c.dh - 1 : nr;
+            const unsigned char *r0 = c.P + (size_t)ir * c.pitch, *r1 = c.P + (size_t)nr * c.pitch;
+            const int a = r0[ja] * 3 + r1[ja], b = r0[jb] * 3 + r1[jb], cc = r0[jc] * 3 + r1[jc], d = r0[jd] * 3 + r1[jd];
+            v[0] = i0 == 0 ? (b * 4 + 8) >> 4 : (b * 3 + a + 8) >> 4;
+            v[1] = i0 == last ? (b * 4 + 7) >> 4 : (b * 3 + cc + 7) >> 4;
+            v[2] = (cc * 3 + b + 8) >> 4;
+            v[3] = i0 + 1 >= last ? (cc * 4 + 7) >> 4 : (cc * 3 + d + 7) >> 4;
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = upsampled(c, x0 + i, y);
+}
+
 __global__ __launch_bounds__(256) void jpeg_color_kernel(const int32_t* desc, const unsigned char* planes, unsigned char* out, int channels) {
     const int32_t* d = desc + (size_t)blockIdx.y * AB_JPEG_DESC_INTS;
-    const int W = d[D_W], H = d[D_H];
+    const int W = d[D_W], H = d[D_H], W4 = (W + 3) >> 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= W * H) return;
-    const int y = i / W, x = i - y * W;
+    if (i >= W4 * H) return;
+    const int y = i / W4, x0 = (i - y * W4) * 4;
     const int ncomp = d[D_NCOMP], hmax = d[D_HMAX], vmax = d[D_VMAX];
     PlaneRef pr[3];
     size_t po = (size_t)d[D_PLANE_BASE];
@@ -404,17 +446,28 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const int32_t* desc, co
         pr[c].dw = (W * h + hmax - 1) / hmax; pr[c].dh = (H * v + vmax - 1) / vmax; pr[c].hr = hmax / h; pr[c].vr = vmax / v;
         po += (size_t)pr[c].pitch * d[D_MCUY] * v * 8;
     }
-    const int Y = upsampled(pr[0], x, y);
-    int R = Y, G = Y, B = Y;
-    if (ncomp == 3) {
-        const int cb = upsampled(pr[1], x, y) - 128, cr = upsampled(pr[2], x, y) - 128;
-        R = clamp255(Y + ((91881 * cr + 32768) >> 16));
-        G = clamp255(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
-        B = clamp255(Y + ((116130 * cb + 32768) >> 16));
+    int Y[4], Cb[4], Cr[4];
+    upsampled4(pr[0], x0, y, Y);
+    if (ncomp == 3) { upsampled4(pr[1], x0, y, Cb); upsampled4(pr[2], x0, y, Cr); }
+    uint32_t px[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int R = Y[j], G = Y[j], B = Y[j];
+        if (ncomp == 3) {
+            const int cb = Cb[j] - 128, cr = Cr[j] - 128;
+            R = clamp255(Y[j] + ((91881 * cr + 32768) >> 16));
+            G = clamp255(Y[j] + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+            B = clamp255(Y[j] + ((116130 * cb + 32768) >> 16));
+        }
+        px[j] = (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16);
     }
-    unsigned char* o = out + ((size_t)d[D_OUT_OFF] + (size_t)y * d[D_OUT_PITCH] + x) * channels;
-    if (channels == 4) *reinterpret_cast<uint32_t*>(o) = (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16);
-    else { o[0] = (unsigned char)R; o[1] = (unsigned char)G; o[2] = (unsigned char)B; }
+    const size_t o0 = (size_t)d[D_OUT_OFF] + (size_t)y * d[D_OUT_PITCH] + x0;
+    if (channels == 4 && x0 + 3 < W && !(o0 & 3)) { *reinterpret_cast<uint4*>(out + o0 * 4) = make_uint4(px[0], px[1], px[2], px[3]); return; }
+    for (int j = 0; j < 4 && x0 + j < W; j++) {
+        unsigned char* o = out + (o0 + j) * channels;
+        if (channels == 4) *reinterpret_cast<uint32_t*>(o) = px[j];
+        else { o[0] = (unsigned char)px[j]; o[1] = (unsigned char)(px[j] >> 8); o[2] = (unsigned char)(px[j] >> 16); }
+    }
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -444,7 +497,7 @@ extern "C" int ab_jpeg_decode_batch(const void* data, const int32_t* desc, const
     AB_LAUNCH_CHECK();
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_blocks + 31) / 32, n), dim3(256), 0, st, desc, coefs, (const unsigned short*)qtabs, planes);
     AB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_pixels + 255) / 256, n), dim3(256), 0, st, desc, planes, (unsigned char*)out, out_channels);
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_pixels / 4 + 255) / 256, n), dim3(256), 0, st, desc, planes, (unsigned char*)out, out_channels);
     AB_LAUNCH_CHECK();
     return 0;
 }

@@ -176,7 +176,7 @@ class _Plan:
             blk_base += nblk
             plane_base += (nblk * 64 + 255) & ~255
             seg_off += len(sg)
-            self.max_blocks, self.max_pixels = max(self.max_blocks, nblk), max(self.max_pixels, it.width * it.height)
+            self.max_blocks, self.max_pixels = max(self.max_blocks, nblk), max(self.max_pixels, 4 * ((it.width + 3) // 4) * it.height)
         self.n, self.sub_bytes = n, sub_bytes
         self.total_blocks, self.total_sub, self.plane_bytes, self.data_bytes = blk_base, sub_base, plane_base, data_off
         self.desc, self.segs = desc, np.concatenate(segs).astype(np.int32)
@@ -259,4 +259,13 @@ class JpegDecoder:
                                          L.ptr(part(4, plan.ht.nbytes)), L.i(n), L.i(plan.sub_bytes), L.l(plan.total_blocks), L.l(plan.total_sub),
                                          L.l(plan.plane_bytes), L.i(plan.max_blocks), L.i(plan.max_pixels), L.i(channels), L.view_ptr(out),
                                          L.ptr(self._ws), L.stream()), "ab_jpeg_decode_batch")
+        self._last = (plan.total_blocks, plan.total_sub, plan.desc[:, 25].copy())
         return res
+
+    def last_rounds(self):
+        """Diagnostic: synchronisation rounds each image of the last batch took (jpeg_entropy_kernel leaves the count in its chain array)."""
+        tb, ts, sub_base = self._last
+        a256 = lambda x: (x + 255) & ~255      # noqa: E731
+        off = a256(tb * 128) + 3 * a256(ts * 4)
+        torch.cuda.synchronize()
+        return self._ws[off:off + a256(ts * 4)].view(torch.int32)[torch.from_numpy(sub_base).long().to(self.dev)].cpu().numpy()

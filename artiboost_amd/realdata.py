@@ -26,6 +26,12 @@ class HOdataSource:
         """uint8 [H, W, 3] RGB (Image.open(path).convert("RGB"), ho3d.py:228-231)."""
         raise NotImplementedError
 
+    def get_image_bytes(self, idx):
+        """Optional: the bytes of the frame's .jpg file.  When a source provides them, RealBatcher uploads the FILES and decodes them on the
+        device (jpeg.JpegDecoder: bit-identical to get_image's Pillow decode); None (the default) or a file the device decoder does not
+        cover -> get_image."""
+        return None
+
     def get_annots(self, idx):
         """dict: cam_intr (3,3), joints_3d (21,3), joints_2d (21,2), corners_3d (8,3), corners_2d (8,2), corners_can (8,3),
         obj_transf (4,4), obj_idx int, side str, bbox_center (2,), bbox_scale float (get_center_scale_wrt_bbox)."""
@@ -129,6 +135,7 @@ class RealBatcher:
         self.rng = np.random.default_rng(seed)
         self._ws = None
         self._pin, self._pin_i = None, 0
+        self._jpeg = None               # jpeg.JpegDecoder, created with the first batch of file bytes
 
     def draw(self, n):
         """One set of augmentation draws per sample (hodata.py:346-359,435-442: ranges hard-coded at hodata.py:107-112)."""
@@ -147,14 +154,28 @@ class RealBatcher:
         W, H = self.src.raw_size
         # decoded frames go, RGB and contiguous, into one of two pinned staging buffers (a strided RGB -> RGBX scatter on the
         # host costs 1 ms per 640x480 frame; the X byte is added on the device) and are uploaded with one asynchronous copy
-        if self._pin is None or self._pin[0].shape[0] < n or tuple(self._pin[0].shape[1:3]) != (H, W):
-            self._pin = [torch.empty((n, H, W, 3), dtype=torch.uint8).pin_memory() if torch.cuda.is_available()
-                         else torch.empty((n, H, W, 3), dtype=torch.uint8) for _ in range(2)]
-        self._pin_i ^= 1
-        stage = self._pin[self._pin_i][:n]
-        frames = stage.numpy()
-        for i, idx in enumerate(idxs):
-            frames[i] = self.src.get_image(idx)
+        files = infos = None
+        if getattr(self.src, "get_image_bytes", None) is not None:
+            from .jpeg import JpegUnsupported, parse
+            files = [self.src.get_image_bytes(idx) for idx in idxs]
+            try:                                                   # header walk only (15 us per file); the decode runs in augment()
+                infos = None if any(f is None for f in files) else [parse(f) for f in files]
+            except JpegUnsupported:
+                infos = None
+            if infos is not None and any((it.width, it.height) != (W, H) for it in infos):
+                infos = None
+        if infos is not None:
+            stage = None
+        else:
+            files = None
+            if self._pin is None or self._pin[0].shape[0] < n or tuple(self._pin[0].shape[1:3]) != (H, W):
+                self._pin = [torch.empty((n, H, W, 3), dtype=torch.uint8).pin_memory() if torch.cuda.is_available()
+                             else torch.empty((n, H, W, 3), dtype=torch.uint8) for _ in range(2)]
+            self._pin_i ^= 1
+            stage = self._pin[self._pin_i][:n]
+            frames = stage.numpy()
+            for i, idx in enumerate(idxs):
+                frames[i] = self.src.get_image(idx)
         r = assemble_real_gt_batch([self.src.get_annots(idx) for idx in idxs], self.image_size, self.src.raw_size, draws, self.center_idx,
                                    self.bbox_expand, self.center_jit, self.scale_jit, self.src.sides)
         gt = {k: r[k] for k in self.GT_KEYS}
@@ -168,7 +189,7 @@ class RealBatcher:
             blur = None
         else:
             order, factor, blur = draws["order"], draws["factor"], draws["blur"]
-        return dict(frames=stage, gt={k: np.asarray(v, np.float32) for k, v in gt.items()}, inv=inv, flip=flip, obj_idx=obj_idx,
+        return dict(frames=stage, files=files, jpeg_infos=infos, gt={k: np.asarray(v, np.float32) for k, v in gt.items()}, inv=inv, flip=flip, obj_idx=obj_idx,
                     order=order, factor=factor, blur=blur, idxs=np.asarray(idxs, np.int64))
 
     def augment(self, host, out_pad=None, out_chw=None):
@@ -183,9 +204,16 @@ class RealBatcher:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         if out_pad is None and out_chw is None:
             out_chw = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=self.dev)
-        rgb = host["frames"].to(self.dev, non_blocking=True)
-        frames = torch.zeros(rgb.shape[:3] + (4,), dtype=torch.uint8, device=self.dev)
-        frames[..., :3].copy_(rgb)                                  # RGBX: the kernels fetch a pixel as one aligned dword
+        if host.get("files") is not None:                          # the .jpg files themselves: Huffman decode .. RGBX on the device
+            if self._jpeg is None:
+                from .jpeg import JpegDecoder
+                self._jpeg = JpegDecoder(self.dev)
+            frames = torch.empty((n, H, W, 4), dtype=torch.uint8, device=self.dev)
+            self._jpeg.decode(host["files"], out=frames, infos=host["jpeg_infos"])
+        else:
+            rgb = host["frames"].to(self.dev, non_blocking=True)
+            frames = torch.zeros(rgb.shape[:3] + (4,), dtype=torch.uint8, device=self.dev)
+            frames[..., :3].copy_(rgb)                              # RGBX: the kernels fetch a pixel as one aligned dword
         order, factor, inv, flip = t(host["order"]), t(host["factor"]), t(host["inv"]), t(host["flip"])
         blur = t(host["blur"]) if host["blur"] is not None else None
         dt = L.dt(out_pad) if out_pad is not None else 0

@@ -408,6 +408,7 @@ int ab_augment_batch(const void* rgbx, int B, int W, int H, const int32_t* order
  *   segs   int32 [.][4] per restart interval (one per image without restart markers): byte offset in the scan, bytes, first subsequence,
  *          first block (both relative to the image)
  *   qtabs  uint16 [.][4][64] in natural (row-major) order;  htabs  uint8 [.][8][16 + 256]: DC tables 0-3, AC tables 0-3 as in the DHT segment
+ * max_blocks: the largest descriptor field 28; max_pixels: the largest 4 * ceil(width / 4) * height.
  * out: uint8, out_channels 3 (RGB) or 4 (RGBX, X = 0).  Supported files: SOF0 / SOF1, 8 bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart
  * intervals; anything else is refused by the host parser (the caller keeps Pillow for those files, as the reference does for all).      */
 #define AB_JPEG_DESC_INTS 40

@@ -116,6 +116,61 @@ def test_real_batch_on_gpu_vs_oracle_and_reference():
     np.testing.assert_array_equal(b0["image"][0].cpu().numpy(), ref0)
 
 
+class JpegSource(GoldenSource):
+    """The golden frames as .jpg files: get_image decodes them with Pillow (the reference's path, ho3d.py:228-231), get_image_bytes hands the
+    file to the device decoder."""
+
+    def __init__(self, quality=92, subsampling=2):
+        import io
+        from PIL import Image
+        super().__init__()
+        self.files = []
+        for f in self.g["frames"]:
+            b = io.BytesIO()
+            Image.fromarray(f).save(b, "JPEG", quality=quality, subsampling=subsampling)
+            self.files.append(b.getvalue())
+
+    def get_image(self, idx):
+        import io
+        from PIL import Image
+        return np.asarray(Image.open(io.BytesIO(self.files[idx % 3])).convert("RGB"))
+
+    def get_image_bytes(self, idx):
+        return self.files[idx % 3]
+
+
+class PillowOnly(JpegSource):
+    get_image_bytes = None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subsampling", [0, 2])
+def test_real_batch_from_jpeg_files_equals_pillow_path(subsampling):
+    """A source that serves .jpg FILES (decoded on the device by ab_jpeg_decode_batch) gives bit-identical batches -- augmented images
+    and ground truth -- to the same source decoded with Pillow on the host (the reference's Image.open(...).convert("RGB"))."""
+    pytest.importorskip("PIL")
+    from artiboost_amd.realdata import RealBatcher
+    a, b = JpegSource(subsampling=subsampling), PillowOnly(subsampling=subsampling)
+    res = int(a.g["res"])
+    cfg = {"IMAGE_SIZE": [res, res], "CENTER_IDX": 0, "BBOX_EXPAND_RATIO": 1.2}
+    ra, rbb = RealBatcher(a, cfg, compute_dtype=torch.float32, seed=5), RealBatcher(b, cfg, compute_dtype=torch.float32, seed=5)
+    for it in range(2):
+        idxs = [0, 1, 2, 4, 8][: 5 - it]
+        ha, hb = ra.assemble(idxs), rbb.assemble(idxs)           # (both consume one set of augmentation draws)
+        assert ha["files"] is not None and ha["frames"] is None and hb["files"] is None
+        ba, bb = ra.batch(idxs), rbb.batch(idxs)
+        for k in ba:
+            torch.testing.assert_close(ba[k], bb[k], rtol=0, atol=0, msg=k)
+    # a file the device decoder does not cover (progressive): the batch falls back to get_image
+    import io
+    from PIL import Image
+    pb = io.BytesIO()
+    Image.fromarray(a.g["frames"][0]).save(pb, "JPEG", progressive=True)
+    a.files[0] = b.files[0] = pb.getvalue()
+    assert ra.assemble([0, 1])["files"] is None and rbb.assemble([0, 1])["files"] is None
+    torch.testing.assert_close(ra.batch([0, 1])["image"], rbb.batch([0, 1])["image"], rtol=0, atol=0)
+
+
 @pytest.mark.gpu
 def test_mixed_loader_batches():
     """MixedDataset semantics with a static split: real rows first (is_synth False, CCV ids -1), synthetic rows after."""
