@@ -9,10 +9,16 @@
 // subsequence boundary equals what the thread that started there recorded -- Huffman streams re-synchronise after a few dozen symbols.
 // The recorded states then are the true ones (the first thread of a segment started right), a prefix sum of the blocks completed per
 // subsequence gives every thread its output position, and a second pass over its own subsequence writes the coefficients.
-//   jpeg_entropy_kernel  one workgroup per image: decode tables -> LDS, synchronisation rounds, block-count scan, coefficient pass, DC prediction scan
+//   jpeg_tables_kernel   LUT + canonical-code tables of every distinct DHT set of the batch
+//   jpeg_unstuff_kernel  FF 00 -> FF (one workgroup per image: count, scan, copy), unstuffed extent of every restart interval
+//   jpeg_sync_kernel     one launch per round (R_MAX + 1 of them; a round in which an image has no live chain exits at once), one thread per subsequence
+//   jpeg_finish_kernel   one workgroup per image: any rounds beyond R_MAX (never seen on photographs), block-count scan
+//   jpeg_coef_kernel     second pass over every subsequence from its true state, coefficients (de-zigzagged) to their blocks
+//   jpeg_dc_kernel       DC prediction: segmented running sum per component
 //   jpeg_idct_kernel     de-quantise + jidctint.c "islow" 8x8 integer IDCT, 8 lanes per block, planes of uint8 samples
 //   jpeg_color_kernel    jdsample.c fancy h2v1 / h2v2 up-sampling (replication for widths <= 2) + jdcolor.c YCbCr -> RGB, RGB(X) rows out
-// Byte stuffing (FF 00) is handled by the bit reader; the JFIF header (a few hundred bytes) is parsed on the host (artiboost_amd/jpeg.py).
+// The JFIF header (a few hundred bytes) is parsed on the host (artiboost_amd/jpeg.py).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -24,115 +30,111 @@ __device__ const unsigned char ZZ[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 2
 enum { D_OFF = 0, D_LEN, D_W, D_H, D_NCOMP, D_HMAX, D_VMAX, D_COMP0 /* h v tq td ta x3 */, D_RI = 22, D_SEG_OFF, D_NSEG, D_SUB_BASE, D_NSUB, D_BLK_BASE,
        D_NBLK, D_PLANE_BASE, D_OUT_OFF, D_OUT_PITCH, D_MCUX, D_MCUY, D_BPM, D_QT, D_HT };
 
-constexpr int LUT_BITS = 10, NT = 1024;
+constexpr int LUT_BITS = 9, LUT2 = 1024, NT = 1024, NW = 256, R_MAX = 16;
 
-struct Tables {
-    uint16_t lut[8][1 << LUT_BITS];      // (length << 8) | symbol for codes of <= LUT_BITS bits; 0: longer
+// decode tables of one set of DHT segments (8 slots: DC 0-3, AC 0-3), built once per batch; every decoding workgroup copies the two
+// look-up levels to LDS.  Level 1: the first LUT_BITS bits of the 16-bit look-ahead.  Level 2: canonical codes longer than LUT_BITS bits are
+// the numerically LARGEST look-aheads (>= base2), a few hundred values for the tables encoders write -- indexed directly.  A table whose long
+// codes span more than LUT2 values falls back to the bit-by-bit canonical search in memory (slow2 == 0).
+struct HuffLuts {
+    uint16_t lut1[8][1 << LUT_BITS];     // (length << 8) | symbol; 0: longer than LUT_BITS bits
+    uint16_t lut2[8][LUT2];               // the same for look-ahead values base2 + i
+    uint32_t base2[8];
+    uint32_t ok2[8];
+};
+struct HuffTables {
+    HuffLuts luts;
     int maxcode[8][17];                   // largest code of each length, -1: none
     int valoff[8][17];                    // vals index of the first code of that length minus that code
     unsigned char vals[8][256];
-    unsigned char tb_dc[10], tb_ac[10];   // table slot (0-3 DC, 4-7 AC) of each block of the MCU
+};
+static_assert(sizeof(HuffLuts) % 16 == 0 && sizeof(HuffTables) % 16 == 0, "copied as uint4");
+
+struct Lds {
+    HuffLuts T;
+    unsigned char zz[64];
+    unsigned char tb_dc[12], tb_ac[12];   // table slot of each block of the MCU
 };
 
+// MSB-first bit reader over the UNSTUFFED scan (jpeg_unstuff_kernel), in aligned 32-bit words: the next bit is bit 63 of acc, n valid bits;
+// bytes past `end` read as zero.  STAGED: the words of this thread's stretch were copied to LDS up front (lds[j * NW + thread], word w0 + j) --
+// one batch of independent loads instead of a dependent load every five symbols; otherwise straight from memory, one word ahead.
+constexpr int STAGE_MAX_SUB = 128, STAGE_WORDS = STAGE_MAX_SUB / 4 + 4;
+template <bool STAGED>
 struct Reader {
-    // The scan is read as aligned 8-byte words (one word ahead in flight), byte-swapped so that the next raw byte is the top byte of `cur`.
-    // Decoded bits sit MSB-first in `acc` (the next bit is bit 63, n valid bits).  A fetched FF takes its stuffed 00 with it; `ff` remembers
-    // which of the buffered bytes those were, so that position() does not depend on how far ahead the buffer was filled.
-    const uint64_t* w; uint32_t pos, end, widx; uint64_t cur, nxt, acc; int cur_n, n; uint32_t ff;
-    __device__ __forceinline__ uint64_t word(uint32_t i) const { return __builtin_bswap64(w[i]); }
-    __device__ __forceinline__ uint32_t raw_at(uint32_t o) const { return (uint32_t)(word(o >> 3) >> (56 - 8 * (o & 7))) & 255u; }
-    __device__ __forceinline__ void raw_advance(int k) {
-        cur <<= 8 * k; cur_n -= k;
-        if (cur_n == 0) { cur = nxt; cur_n = 8; nxt = word(widx++); }
+    const uint32_t* base; uint32_t widx, w0, end, pre; uint64_t acc; int n;
+    __device__ __forceinline__ uint32_t load(uint32_t i) const { return STAGED ? base[(i - w0) * NW] : base[i]; }
+    __device__ __forceinline__ uint32_t cooked(uint32_t raw, uint32_t i) const {          // big-endian, bytes past `end` zero
+        const uint32_t x = __builtin_bswap32(raw), o = i * 4u;
+        return o + 4u <= end ? x : o >= end ? 0u : x & (0xFFFFFFFFu << (8u * (4u - (end - o))));
     }
-    __device__ __forceinline__ void fill() {
-        while (n <= 56) {
-            if (n <= 32 && cur_n >= 4 && pos + 4 <= end) {   // four bytes at once when none of them is FF
-                const uint32_t x = (uint32_t)(cur >> 32), y = ~x;
-                if (!((y - 0x01010101u) & ~y & 0x80808080u)) {
-                    acc |= (uint64_t)x << (32 - n);
-                    n += 32; ff <<= 4; pos += 4;
-                    raw_advance(4);
-                    continue;
-                }
-            }
-            uint32_t c = 0, isff = 0;
-            if (pos < end) {
-                c = (uint32_t)(cur >> 56);
-                raw_advance(1);
-                if (c == 0xFF && pos + 1 < end && (uint32_t)(cur >> 56) == 0) { raw_advance(1); pos++; isff = 1; }
-            }
-            pos++;                                           // past the end: zero bytes, the position keeps counting
-            acc |= (uint64_t)c << (56 - n);
-            n += 8; ff = (ff << 1) | isff;
+    __device__ __forceinline__ void fill() {                 // one refill per symbol: a symbol takes at most 16 + 15 bits
+        if (n <= 32) {
+            acc |= (uint64_t)cooked(pre, widx) << (32 - n);
+            n += 32; widx++;
+            pre = load(widx);                                // raw: not looked at before the next refill
         }
     }
-    // bit position of the next bit, in units that depend only on where it is in the file: 8 * (offset just past its byte, stuffing
-    // included) - (bits of that byte not yet consumed)
-    __device__ __forceinline__ uint32_t position() const {
-        const int later = (n - 1) >> 3;
-        return pos * 8u - (uint32_t)n - 8u * (uint32_t)__popc(ff & ((1u << later) - 1u));
-    }
-    __device__ __forceinline__ uint32_t peek(int k) const { return k ? (uint32_t)(acc >> (64 - k)) : 0u; }
-    __device__ __forceinline__ void skip(int k) { acc <<= k; n -= k; }
-    // start at bit position P (a value position() returned, or 8 * a byte offset for a fresh start at a subsequence boundary); offsets are
-    // relative to `data`, which is 8-byte aligned
-    __device__ __forceinline__ void seek(const unsigned char* data, uint32_t seg_start, uint32_t seg_end, uint32_t P) {
-        w = reinterpret_cast<const uint64_t*>(data); end = seg_end; acc = 0; n = 0; ff = 0;
-        const uint32_t q = P >> 3;
-        pos = (q > seg_start && q < seg_end && raw_at(q) == 0 && raw_at(q - 1) == 0xFF) ? q - 1 : q;
-        widx = pos >> 3;
-        cur = word(widx) << (8 * (pos & 7)); cur_n = 8 - (int)(pos & 7);
-        nxt = word(widx + 1); widx += 2;
+    __device__ __forceinline__ uint32_t position() const { return widx * 32u - (uint32_t)n; }
+    // b: the unstuffed scans as words (STAGED: this thread's LDS column, filled by stage()); P: bit position to start at
+    __device__ __forceinline__ void seek(const uint32_t* b, uint32_t seg_end, uint32_t P) {
+        base = b; end = seg_end; widx = P >> 5; w0 = widx; acc = 0; n = 0;
+        pre = load(widx);
         fill();
-        skip((int)(P & 7u));
+        acc <<= (P & 31u); n -= (int)(P & 31u);
     }
 };
+// copies the words [P >> 5, (endbits + 95) >> 5] of the unstuffed scan to this thread's LDS column
+__device__ __forceinline__ void stage(uint32_t* col, const uint32_t* words, uint32_t P, uint32_t endbits) {
+    const uint32_t w0 = P >> 5, cnt = min(((endbits + 95u) >> 5) - w0 + 1u, (uint32_t)STAGE_WORDS);
+    uint32_t v[STAGE_WORDS];
+#pragma unroll
+    for (int j = 0; j < STAGE_WORDS; j++) v[j] = (uint32_t)j < cnt ? words[w0 + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < STAGE_WORDS; j++) col[j * NW] = v[j];
+}
 
-__device__ __forceinline__ int extend(int v, int s) { return (s && v < (1 << (s - 1))) ? v - (1 << s) + 1 : v; }
-
-// one Huffman symbol (+ its value bits) of state (b, k); returns true when it completed a block
-template <bool WRITE>
-__device__ __forceinline__ bool symbol(Reader& r, const Tables& T, int& b, int& k, int bpm, short* blk_out) {
+// one Huffman symbol (+ its value bits) in state (b, k); returns 1 when it completed a block
+template <bool WRITE, bool STAGED>
+__device__ __forceinline__ int symbol(Reader<STAGED>& r, const Lds& L, const HuffTables* G, int& b, int& k, int& tdc, int& tac, int bpm, short* blk_out) {
     r.fill();
-    const int t = k == 0 ? T.tb_dc[b] : T.tb_ac[b];
-    const uint32_t pk = r.peek(16);
-    int len, sym;
-    const uint32_t e = T.lut[t][pk >> (16 - LUT_BITS)];
-    if (e) { len = e >> 8; sym = e & 255; }
-    else {
-        len = 16; sym = 0;
-        for (int l = LUT_BITS + 1; l <= 16; l++) {
-            const int code = (int)(pk >> (16 - l));
-            if (code <= T.maxcode[t][l]) { len = l; sym = T.vals[t][(T.valoff[t][l] + code) & 255]; break; }
-        }
-    }
-    r.skip(len);
-    if (k == 0) {
-        const int s = sym & 15;
-        const int v = extend((int)r.peek(s), s);
-        r.skip(s);
-        if (WRITE) blk_out[0] = (short)v;                    // the DC difference; the prediction scan below turns it into the value
-        k = 1;
-    } else {
-        const int run = sym >> 4, s = sym & 15;
-        if (s == 0) k = run == 15 ? k + 16 : 64;
+    const bool isdc = k == 0;
+    const int t = isdc ? tdc : tac;
+    const uint32_t pk = (uint32_t)(r.acc >> 48);
+    uint32_t e = L.T.lut1[t][pk >> (16 - LUT_BITS)];
+    if (e == 0) {
+        const uint32_t i2 = pk - L.T.base2[t];
+        if (L.T.ok2[t]) e = L.T.lut2[t][i2 & (LUT2 - 1)];
         else {
-            k += run;
-            const int v = extend((int)r.peek(s), s);
-            r.skip(s);
-            if (WRITE && k < 64) blk_out[ZZ[k]] = (short)v;
-            k++;
+            e = 16u << 8;                                    // invalid code: 16 bits, symbol 0 (libjpeg: warning + 0)
+            for (int l = LUT_BITS + 1; l <= 16; l++) {
+                const int code = (int)(pk >> (16 - l));
+                if (code <= G->maxcode[t][l]) { e = ((uint32_t)l << 8) | G->vals[t][(G->valoff[t][l] + code) & 255]; break; }
+            }
         }
     }
-    if (k >= 64) { k = 0; b = b + 1 == bpm ? 0 : b + 1; return true; }
-    return false;
+    const int len = (int)(e >> 8), sym = (int)(e & 255u);
+    const int s = sym & 15, run = isdc ? 0 : sym >> 4;
+    r.acc <<= len;
+    const int bits = (int)((r.acc >> 1) >> (63 - s));       // s == 0: 0
+    r.acc <<= s; r.n -= len + s;
+    const int v = (s && bits < (1 << (s - 1))) ? bits - (1 << s) + 1 : bits;
+    const bool eob = !isdc && s == 0 && run != 15;
+    const int kn = k + run;
+    if (WRITE && s && kn < 64) blk_out[L.zz[kn]] = (short)v;        // DC: the difference; jpeg_dc_kernel turns it into the value
+    k = eob ? 64 : kn + 1;
+    if (k >= 64) {
+        k = 0; b = b + 1 == bpm ? 0 : b + 1;
+        tdc = L.tb_dc[b]; tac = L.tb_ac[b];
+        return 1;
+    }
+    return 0;
 }
 
 struct EntropyArgs {
-    const unsigned char* data; const int32_t* desc; const int32_t* segs; const unsigned char* htabs;
-    short* coefs; uint32_t* sP; uint32_t* sS; int32_t* sN; uint32_t* cP; uint32_t* cS;
-    int sub_bytes;
+    const unsigned char* data; unsigned char* clean; const int32_t* desc; const int32_t* segs; int32_t* segc; int32_t* kp; const unsigned char* htabs;
+    HuffTables* tables; short* coefs; uint32_t* sP; uint32_t* sS; int32_t* sN; uint32_t* cP; uint32_t* cS; int32_t* act;
+    int sub_bytes, n_tables, no_lut2;
 };
 
 __device__ __forceinline__ int seg_of_sub(const int32_t* segs, int nseg, int u) {       // segs[s][2] = first subsequence of segment s
@@ -141,98 +143,273 @@ __device__ __forceinline__ int seg_of_sub(const int32_t* segs, int nseg, int u) 
     return lo;
 }
 
-__global__ __launch_bounds__(NT) void jpeg_entropy_kernel(EntropyArgs a) {
-    __shared__ Tables T;
-    __shared__ int s_scan[NT];
-    __shared__ int s_flag[NT];
-    __shared__ int s_carry;
+// ---- per batch: the decode tables of every distinct set of DHT segments
+__global__ __launch_bounds__(256) void jpeg_tables_kernel(EntropyArgs a) {
+    __shared__ unsigned char s_ht[8 * 272];
+    __shared__ uint32_t s_base2[8], s_ok2[8];
+    HuffTables& T = a.tables[blockIdx.x];
+    const unsigned char* ht = a.htabs + (size_t)blockIdx.x * (8 * 272);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 8 * 272; i += 256) s_ht[i] = ht[i];
+    for (int i = tid; i < 8 * (1 << LUT_BITS); i += 256) (&T.luts.lut1[0][0])[i] = 0;
+    for (int i = tid; i < 8 * LUT2; i += 256) (&T.luts.lut2[0][0])[i] = (uint16_t)(16u << 8);      // not a code: 16 bits, symbol 0
+    __syncthreads();
+    for (int i = tid; i < 8 * 256; i += 256) T.vals[i >> 8][i & 255] = s_ht[(i >> 8) * 272 + 16 + (i & 255)];
+    if (tid < 8) {
+        const unsigned char* cnt = s_ht + tid * 272;
+        int code = 0;
+        for (int l = 1; l <= LUT_BITS; l++) code = (code + cnt[l - 1]) << 1;          // first code of length LUT_BITS + 1
+        const uint32_t b2 = (uint32_t)code << (16 - (LUT_BITS + 1));
+        s_base2[tid] = b2; s_ok2[tid] = !a.no_lut2 && b2 <= 65536u && 65536u - b2 <= (uint32_t)LUT2;
+        T.luts.base2[tid] = b2; T.luts.ok2[tid] = s_ok2[tid];
+    }
+    __syncthreads();
+    // thread j of a slot: the j-th symbol -- its code from the counts, then its LUT entries; threads 0..16 also the per-length tables
+    for (int slot = 0; slot < 8; slot++) {
+        const unsigned char* cnt = s_ht + slot * 272;
+        if (tid <= 16) {
+            if (tid >= 1) {
+                int code = 0, kk = 0;
+                for (int l = 1; l < tid; l++) { code = (code + cnt[l - 1]) << 1; kk += cnt[l - 1]; }
+                T.valoff[slot][tid] = kk - code;
+                T.maxcode[slot][tid] = cnt[tid - 1] ? code + cnt[tid - 1] - 1 : -1;
+            } else { T.valoff[slot][0] = 0; T.maxcode[slot][0] = -1; }
+        }
+        int code = 0, kk = 0, l = 1;
+        for (; l <= 16; l++) {                               // which length does symbol index tid have?
+            if (tid < kk + cnt[l - 1]) break;
+            code = (code + cnt[l - 1]) << 1; kk += cnt[l - 1];
+        }
+        if (l > 16) continue;
+        const int c = code + (tid - kk);
+        const uint16_t e = (uint16_t)((l << 8) | cnt[16 + tid]);
+        if (l <= LUT_BITS) {
+            const int first = c << (LUT_BITS - l), nfill = 1 << (LUT_BITS - l);
+            if (first + nfill <= (1 << LUT_BITS))
+                for (int f = 0; f < nfill; f++) T.luts.lut1[slot][first + f] = e;
+        } else if (s_ok2[slot]) {
+            const uint32_t first = ((uint32_t)c << (16 - l)) - s_base2[slot], nfill = 1u << (16 - l);
+            if (first + nfill <= (uint32_t)LUT2)
+                for (uint32_t f = 0; f < nfill; f++) T.luts.lut2[slot][first + f] = e;
+        }
+    }
+}
+
+// exclusive scan of one int per thread over a workgroup of NT threads (wave shuffles + one LDS hop); *total = the sum
+__device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave /* [NT / 64 + 1] */, int* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < NT / 64; i++) { const int t = s_wave[i]; s_wave[i] = run; run += t; }
+        s_wave[NT / 64] = run;
+    }
+    __syncthreads();
+    const int r = s_wave[wv] + inc - v;
+    *total = s_wave[NT / 64];
+    __syncthreads();
+    return r;
+}
+
+// ---- per image: FF 00 -> FF over the whole scan (restart markers between the intervals stay where they fall), the unstuffed extent of
+// every restart interval.  Tiles of NT x 16 bytes: aligned 16-byte loads, kept bytes compacted in LDS, coalesced byte stores; kp[chunk] =
+// bytes kept in front of each 16-byte chunk (for the interval extents).
+__global__ __launch_bounds__(NT) void jpeg_unstuff_kernel(EntropyArgs a) {
+    __shared__ unsigned char s_out[NT * 16];
+    __shared__ int s_wave[NT / 64 + 1];
     const int tid = threadIdx.x;
     const int32_t* d = a.desc + (size_t)blockIdx.x * AB_JPEG_DESC_INTS;
-    const int ncomp = d[D_NCOMP], bpm = d[D_BPM], nseg = d[D_NSEG], nsub = d[D_NSUB], ri = d[D_RI];
-    const unsigned char* base = a.data;                      // every offset below is relative to `data` (8-byte aligned)
-    const uint32_t off0 = (uint32_t)d[D_OFF];
+    const uint32_t off0 = (uint32_t)d[D_OFF], len = (uint32_t)d[D_LEN], A = off0 & ~15u, hi = off0 + len;
+    const unsigned char* src = a.data;
+    unsigned char* dst = a.clean + off0;
+    int32_t* kp = a.kp + (A >> 4);
+    uint32_t running = 0;
+    for (uint32_t t0 = A; t0 < hi; t0 += NT * 16) {
+        const uint32_t i = t0 + tid * 16;
+        uint32_t keep = 0; uint4 q = make_uint4(0, 0, 0, 0);
+        if (i < hi) {
+            q = *reinterpret_cast<const uint4*>(src + i);
+            unsigned prev = i > off0 ? src[i - 1] : 0u;
+            const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const unsigned c = (wds[j >> 2] >> (8 * (j & 3))) & 255u;
+                const bool in = i + j >= off0 && i + j < hi;
+                keep |= (in && !(c == 0 && prev == 0xFF)) ? 1u << j : 0u;
+                prev = c;
+            }
+        }
+        int total;
+        const int ex = block_exclusive_scan(__popc(keep), s_wave, &total);
+        if (i < hi) {
+            kp[(i - A) >> 4] = (int32_t)(running + ex);
+            const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+            int o = ex;
+#pragma unroll
+            for (int j = 0; j < 16; j++) if (keep >> j & 1u) s_out[o++] = (unsigned char)((wds[j >> 2] >> (8 * (j & 3))) & 255u);
+        }
+        __syncthreads();
+        for (int o = tid; o < total; o += NT) dst[running + o] = s_out[o];
+        running += (uint32_t)total;
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    // bytes kept in front of scan offset x (relative to off0)
+    auto kept_before = [&](uint32_t x) {
+        const uint32_t ab = off0 + x;
+        if (ab >= hi) return running;
+        const uint32_t cs = ab & ~15u;
+        uint32_t r = (uint32_t)kp[(cs - A) >> 4];
+        unsigned pv = cs > off0 ? src[cs - 1] : 0u;
+        for (uint32_t i = cs; i < ab; i++) { const unsigned c = src[i]; r += (i >= off0 && !(c == 0 && pv == 0xFF)) ? 1u : 0u; pv = c; }
+        return r;
+    };
     const int32_t* segs = a.segs + (size_t)d[D_SEG_OFF] * 4;
-    // ---- decode tables of this image: 8 slots x (16 counts + 256 symbols)
-    for (int i = tid; i < 8 * (1 << LUT_BITS); i += NT) (&T.lut[0][0])[i] = 0;
-    const unsigned char* ht = a.htabs + (size_t)d[D_HT] * (8 * 272);
-    for (int i = tid; i < 8 * 256; i += NT) T.vals[i >> 8][i & 255] = ht[(i >> 8) * 272 + 16 + (i & 255)];
-    if (tid < 10) {
+    int32_t* segc = a.segc + (size_t)d[D_SEG_OFF] * 2;
+    for (int sgi = tid; sgi < d[D_NSEG]; sgi += NT) {
+        const uint32_t x0 = (uint32_t)segs[sgi * 4], x1 = x0 + (uint32_t)segs[sgi * 4 + 1];
+        const uint32_t c0 = kept_before(x0), c1 = kept_before(x1);
+        segc[sgi * 2] = (int32_t)(off0 + c0); segc[sgi * 2 + 1] = (int32_t)(c1 - c0);
+    }
+}
+
+struct ImageCtx {
+    const int32_t *d, *segs, *segc; int ncomp, bpm, nseg, nsub; uint32_t SB;
+    uint32_t *sP, *sS, *cP, *cS; int32_t* sN;
+};
+__device__ __forceinline__ ImageCtx image_ctx(const EntropyArgs& a, int img) {
+    ImageCtx c;
+    c.d = a.desc + (size_t)img * AB_JPEG_DESC_INTS;
+    c.segs = a.segs + (size_t)c.d[D_SEG_OFF] * 4; c.segc = a.segc + (size_t)c.d[D_SEG_OFF] * 2;
+    c.ncomp = c.d[D_NCOMP]; c.bpm = c.d[D_BPM]; c.nseg = c.d[D_NSEG]; c.nsub = c.d[D_NSUB]; c.SB = (uint32_t)a.sub_bytes;
+    const int sb = c.d[D_SUB_BASE];
+    c.sP = a.sP + sb; c.sS = a.sS + sb; c.sN = a.sN + sb; c.cP = a.cP + sb; c.cS = a.cS + sb;
+    return c;
+}
+__device__ __forceinline__ void load_lds(Lds& L, const EntropyArgs& a, const int32_t* d, int tid, int nthreads) {
+    const uint4* src = reinterpret_cast<const uint4*>(&a.tables[d[D_HT]].luts);
+    uint4* dst = reinterpret_cast<uint4*>(&L.T);
+    for (int i = tid; i < (int)(sizeof(HuffLuts) / 16); i += nthreads) dst[i] = src[i];
+    if (tid < 64) L.zz[tid] = ZZ[tid];
+    if (tid < 12) {
         int c = 0, acc = 0;
+        const int ncomp = d[D_NCOMP];
         for (; c < ncomp; c++) { const int nb = d[D_COMP0 + 5 * c] * d[D_COMP0 + 5 * c + 1]; if (tid < acc + nb) break; acc += nb; }
         c = c < ncomp ? c : 0;
-        T.tb_dc[tid] = (unsigned char)(d[D_COMP0 + 5 * c + 3] & 3);
-        T.tb_ac[tid] = (unsigned char)(4 + (d[D_COMP0 + 5 * c + 4] & 3));
+        L.tb_dc[tid] = (unsigned char)(d[D_COMP0 + 5 * c + 3] & 3);
+        L.tb_ac[tid] = (unsigned char)(4 + (d[D_COMP0 + 5 * c + 4] & 3));
     }
     __syncthreads();
-    if (tid < 8) {
-        const unsigned char* cnt = ht + tid * 272;
-        int code = 0, kk = 0;
-        for (int l = 1; l <= 16; l++) {
-            T.valoff[tid][l] = kk - code;
-            const int nl = cnt[l - 1];
-            if (l <= LUT_BITS)
-                for (int j = 0; j < nl; j++) {
-                    const uint16_t e = (uint16_t)((l << 8) | cnt[16 + kk + j]);
-                    const int first = (code + j) << (LUT_BITS - l);
-                    if (first + (1 << (LUT_BITS - l)) <= (1 << LUT_BITS))
-                        for (int f = 0; f < (1 << (LUT_BITS - l)); f++) T.lut[tid][first + f] = e;
-                }
-            code += nl; kk += nl;
-            T.maxcode[tid][l] = nl ? code - 1 : -1;
-            code <<= 1;
+}
+// bit range [start, end) of subsequence v of segment s in the unstuffed scan, and the end of the segment; false: v is empty
+struct SubRange { uint32_t startbits, endbits, seg_end; };
+__device__ __forceinline__ bool sub_range(const ImageCtx& c, int s, int v, SubRange& r) {
+    const uint32_t c0 = (uint32_t)c.segc[s * 2], c1 = c0 + (uint32_t)c.segc[s * 2 + 1];
+    const uint32_t j = (uint32_t)(v - c.segs[s * 4 + 2]);
+    const uint32_t st = c0 + j * c.SB;
+    r.startbits = st * 8u; r.endbits = min(c1, st + c.SB) * 8u; r.seg_end = c1;
+    return st < c1 || j == 0;
+}
+// decode (without writing) from (P, b, k) to the end of a subsequence; returns the blocks completed
+template <bool STAGED>
+__device__ __forceinline__ int run_sub(const uint32_t* words, uint32_t* col, const Lds& L, const HuffTables* G, const SubRange& sr, int bpm, uint32_t& P, int& b, int& k) {
+    Reader<STAGED> r;
+    if (STAGED) { stage(col, words, P, sr.endbits); r.seek(col, sr.seg_end, P); }
+    else r.seek(words, sr.seg_end, P);
+    int tdc = L.tb_dc[b], tac = L.tb_ac[b], nb = 0;
+    while (r.position() < sr.endbits) nb += symbol<false>(r, L, G, b, k, tdc, tac, bpm, nullptr);
+    P = r.position();
+    return nb;
+}
+
+// ---- round 0 (rnd == 0): every subsequence from its first bit in state (block 0 of the MCU, k = 0); rounds rnd >= 1: the chain that
+// started at u continues through subsequence u + rnd until it meets the recorded state there.  grid (ceil(max nsub / NW), images).
+template <bool STAGED>
+__global__ __launch_bounds__(NW) void jpeg_sync_kernel(EntropyArgs a, int rnd) {
+    __shared__ Lds L;
+    __shared__ uint32_t s_stage[STAGED ? STAGE_WORDS * NW : 1];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(a.clean);
+    uint32_t* col = s_stage + (STAGED ? tid : 0);
+    const ImageCtx c = image_ctx(a, img);
+    if ((int)(blockIdx.x * NW) >= c.nsub) return;
+    int32_t* act = a.act + (size_t)img * (R_MAX + 2);
+    if (rnd > 0 && !act[rnd - 1]) return;                    // every chain of this image has synchronised already
+    load_lds(L, a, c.d, tid, NW);
+    const int u = blockIdx.x * NW + tid;
+    if (u >= c.nsub) return;
+    const int s = seg_of_sub(c.segs, c.nseg, u);
+    SubRange sr;
+    if (rnd == 0) {
+        const bool live = sub_range(c, s, u, sr);
+        uint32_t P = sr.startbits; int b = 0, k = 0, nb = 0;
+        if (live) nb = run_sub<STAGED>(words, col, L, a.tables + c.d[D_HT], sr, c.bpm, P, b, k);
+        const uint32_t S = (uint32_t)b | ((uint32_t)k << 8);
+        c.sP[u] = P; c.sS[u] = S; c.sN[u] = nb;
+        c.cP[u] = live ? P : 0xFFFFFFFFu; c.cS[u] = S;
+        if (live) act[0] = 1;
+        return;
+    }
+    uint32_t P = c.cP[u];
+    if (P == 0xFFFFFFFFu) return;
+    const int v = u + rnd;
+    const int last = (s + 1 < c.nseg ? c.segs[(s + 1) * 4 + 2] : c.nsub) - 1;
+    if (v > last || !sub_range(c, s, v, sr)) { c.cP[u] = 0xFFFFFFFFu; return; }
+    int b = (int)(c.cS[u] & 255u), k = (int)(c.cS[u] >> 8);
+    const int nb = run_sub<STAGED>(words, col, L, a.tables + c.d[D_HT], sr, c.bpm, P, b, k);
+    const uint32_t S = (uint32_t)b | ((uint32_t)k << 8);
+    // the chains reach v in order of decreasing start index, the last one (matching or not) carries the true state into v: its count of
+    // blocks completed inside v is the one that stays
+    c.sN[v] = nb;
+    if (c.sP[v] == P && c.sS[v] == S) c.cP[u] = 0xFFFFFFFFu;                        // synchronised: from here on it is v's chain
+    else { c.sP[v] = P; c.sS[v] = S; c.cP[u] = P; c.cS[u] = S; act[rnd] = 1; }
+}
+
+// ---- per image: whatever R_MAX rounds left unsynchronised (normally nothing) is finished inside one workgroup; then the exclusive scan
+// of the block counts over the image's subsequences
+__global__ __launch_bounds__(NT) void jpeg_finish_kernel(EntropyArgs a) {
+    __shared__ Lds L;
+    __shared__ int s_scan[NT];
+    __shared__ int s_carry;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const ImageCtx c = image_ctx(a, img);
+    int32_t* act = a.act + (size_t)img * (R_MAX + 2);
+    if (act[R_MAX]) {
+        load_lds(L, a, c.d, tid, NT);
+        for (int rnd = R_MAX + 1;; rnd++) {
+            int active = 0;
+            for (int u = tid; u < c.nsub; u += NT) {
+                uint32_t P = c.cP[u];
+                if (P == 0xFFFFFFFFu) continue;
+                const int v = u + rnd;
+                const int s = seg_of_sub(c.segs, c.nseg, u);
+                const int last = (s + 1 < c.nseg ? c.segs[(s + 1) * 4 + 2] : c.nsub) - 1;
+                SubRange sr;
+                if (v > last || !sub_range(c, s, v, sr)) { c.cP[u] = 0xFFFFFFFFu; continue; }
+                int b = (int)(c.cS[u] & 255u), k = (int)(c.cS[u] >> 8);
+                const int nb = run_sub<false>(reinterpret_cast<const uint32_t*>(a.clean), nullptr, L, a.tables + c.d[D_HT], sr, c.bpm, P, b, k);
+                const uint32_t S = (uint32_t)b | ((uint32_t)k << 8);
+                c.sN[v] = nb;
+                if (c.sP[v] == P && c.sS[v] == S) c.cP[u] = 0xFFFFFFFFu;
+                else { c.sP[v] = P; c.sS[v] = S; c.cP[u] = P; c.cS[u] = S; active = 1; }
+            }
+            if (!__syncthreads_or(active)) { if (tid == 0) act[R_MAX + 1] = rnd; break; }     // diagnostic: rounds this image took
         }
+    } else if (tid == 0) {
+        int r = 0;
+        while (r < R_MAX && act[r]) r++;
+        act[R_MAX + 1] = r;
     }
-    __syncthreads();
-    uint32_t* sP = a.sP + d[D_SUB_BASE]; uint32_t* sS = a.sS + d[D_SUB_BASE]; int32_t* sN = a.sN + d[D_SUB_BASE];
-    uint32_t* cP = a.cP + d[D_SUB_BASE]; uint32_t* cS = a.cS + d[D_SUB_BASE];
-    const uint32_t SB = (uint32_t)a.sub_bytes;
-    // ---- round 0: every subsequence from its first bit, state (block 0 of the MCU, k = 0)
-    for (int u = tid; u < nsub; u += NT) {
-        const int s = seg_of_sub(segs, nseg, u);
-        const uint32_t s0 = off0 + (uint32_t)segs[s * 4], s1 = s0 + (uint32_t)segs[s * 4 + 1];
-        const uint32_t j = (uint32_t)(u - segs[s * 4 + 2]);
-        const uint32_t endbits = min(s1, s0 + (j + 1) * SB) * 8u;
-        Reader r; r.seek(base, s0, s1, (s0 + j * SB) * 8u);
-        int b = 0, k = 0, nb = 0;
-        r.fill();
-        while (r.position() < endbits) { nb += symbol<false>(r, T, b, k, bpm, nullptr) ? 1 : 0; r.fill(); }
-        const uint32_t P = r.position(), S = (uint32_t)b | ((uint32_t)k << 8);
-        sP[u] = P; sS[u] = S; sN[u] = nb;
-        cP[u] = P; cS[u] = S;                                // the chain of the thread that started at u, now at the end of u
-    }
-    __syncthreads();
-    // ---- rounds r = 1, 2, ...: chain u continues through subsequence u + r until it meets the recorded state there
-    for (int rnd = 1;; rnd++) {
-        int active = 0;
-        for (int u = tid; u < nsub; u += NT) {
-            const uint32_t P0 = cP[u];
-            if (P0 == 0xFFFFFFFFu) continue;
-            const int v = u + rnd;
-            const int s = seg_of_sub(segs, nseg, u);
-            const int last = (s + 1 < nseg ? segs[(s + 1) * 4 + 2] : nsub) - 1;          // last subsequence of the segment
-            if (v > last) { cP[u] = 0xFFFFFFFFu; continue; }
-            const uint32_t s0 = off0 + (uint32_t)segs[s * 4], s1 = s0 + (uint32_t)segs[s * 4 + 1];
-            const uint32_t j = (uint32_t)(v - segs[s * 4 + 2]);
-            const uint32_t endbits = min(s1, s0 + (j + 1) * SB) * 8u;
-            Reader r; r.seek(base, s0, s1, P0);
-            int b = (int)(cS[u] & 255u), k = (int)(cS[u] >> 8), nb = 0;
-            r.fill();
-            while (r.position() < endbits) { nb += symbol<false>(r, T, b, k, bpm, nullptr) ? 1 : 0; r.fill(); }
-            const uint32_t P = r.position(), S = (uint32_t)b | ((uint32_t)k << 8);
-            // the chains reach v in order of decreasing start index, the last one (matching or not) carries the true state into v: its
-            // count of blocks completed inside v is the one that stays
-            sN[v] = nb;
-            if (sP[v] == P && sS[v] == S) cP[u] = 0xFFFFFFFFu;                      // synchronised: from here on it is v's chain
-            else { sP[v] = P; sS[v] = S; cP[u] = P; cS[u] = S; active = 1; }
-        }
-        if (!__syncthreads_or(active)) { if (tid == 0) cP[0] = (uint32_t)rnd; break; }      // diagnostic: rounds this image took
-    }
-    // ---- exclusive scan of the counts over the image's subsequences (restarted at segment starts in the next pass by subtraction)
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int u0 = 0; u0 < nsub; u0 += NT) {
+    for (int u0 = 0; u0 < c.nsub; u0 += NT) {
         const int u = u0 + tid;
-        const int v = u < nsub ? sN[u] : 0;
+        const int v = u < c.nsub ? c.sN[u] : 0;
         s_scan[tid] = v;
         __syncthreads();
         for (int o = 1; o < NT; o <<= 1) {
@@ -242,39 +419,56 @@ __global__ __launch_bounds__(NT) void jpeg_entropy_kernel(EntropyArgs a) {
             __syncthreads();
         }
         const int carry = s_carry;
-        if (u < nsub) sN[u] = carry + s_scan[tid] - v;
+        if (u < c.nsub) c.sN[u] = carry + s_scan[tid] - v;
         __syncthreads();
         if (tid == NT - 1) s_carry = carry + s_scan[tid];
         __syncthreads();
     }
-    // ---- coefficient pass
+}
+
+// ---- coefficient pass: every subsequence from its true start state, writing at its true block position.  grid as jpeg_sync_kernel
+template <bool STAGED>
+__global__ __launch_bounds__(NW) void jpeg_coef_kernel(EntropyArgs a) {
+    __shared__ Lds L;
+    __shared__ uint32_t s_stage[STAGED ? STAGE_WORDS * NW : 1];
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const ImageCtx c = image_ctx(a, img);
+    if ((int)(blockIdx.x * NW) >= c.nsub) return;
+    load_lds(L, a, c.d, tid, NW);
+    const int u = blockIdx.x * NW + tid;
+    if (u >= c.nsub) return;
+    const int s = seg_of_sub(c.segs, c.nseg, u);
+    SubRange sr;
+    if (!sub_range(c, s, u, sr)) return;
+    const int jf = c.segs[s * 4 + 2];
+    const int seg_first_blk = c.segs[s * 4 + 3];
+    const int seg_nblk = (s + 1 < c.nseg ? c.segs[(s + 1) * 4 + 3] : c.d[D_NBLK]) - seg_first_blk;
+    uint32_t P = sr.startbits; int b = 0, k = 0;
+    if (u != jf) { P = c.sP[u - 1]; b = (int)(c.sS[u - 1] & 255u); k = (int)(c.sS[u - 1] >> 8); }
+    int nb = c.sN[u] - c.sN[jf];                             // blocks of this segment completed before this subsequence
+    short* coefs = a.coefs + ((size_t)c.d[D_BLK_BASE] + seg_first_blk) * 64;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(a.clean);
+    Reader<STAGED> r;
+    if (STAGED) { stage(s_stage + tid, words, P, sr.endbits); r.seek(s_stage + tid, sr.seg_end, P); }
+    else r.seek(words, sr.seg_end, P);
+    int tdc = L.tb_dc[b], tac = L.tb_ac[b];
+    while (r.position() < sr.endbits && nb < seg_nblk) nb += symbol<true>(r, L, a.tables + c.d[D_HT], b, k, tdc, tac, c.bpm, coefs + (size_t)nb * 64);
+}
+
+// ---- DC prediction: running sum of the differences per component, in scan order, reset at restart intervals.  One workgroup per image
+__global__ __launch_bounds__(NT) void jpeg_dc_kernel(EntropyArgs a) {
+    __shared__ int s_scan[NT];
+    __shared__ int s_flag[NT];
+    const int tid = threadIdx.x;
+    const int32_t* d = a.desc + (size_t)blockIdx.x * AB_JPEG_DESC_INTS;
+    const int ncomp = d[D_NCOMP], bpm = d[D_BPM], ri = d[D_RI];
     short* coefs = a.coefs + (size_t)d[D_BLK_BASE] * 64;
-    for (int u = tid; u < nsub; u += NT) {
-        const int s = seg_of_sub(segs, nseg, u);
-        const uint32_t s0 = off0 + (uint32_t)segs[s * 4], s1 = s0 + (uint32_t)segs[s * 4 + 1];
-        const int jf = segs[s * 4 + 2];
-        const uint32_t j = (uint32_t)(u - jf);
-        const uint32_t endbits = min(s1, s0 + (j + 1) * SB) * 8u;
-        const int seg_first_blk = segs[s * 4 + 3];
-        const int seg_nblk = (s + 1 < nseg ? segs[(s + 1) * 4 + 3] : d[D_NBLK]) - seg_first_blk;
-        Reader r; int b = 0, k = 0;
-        if (u == jf) r.seek(base, s0, s1, s0 * 8u);
-        else { r.seek(base, s0, s1, sP[u - 1]); b = (int)(sS[u - 1] & 255u); k = (int)(sS[u - 1] >> 8); }
-        int nb = sN[u] - sN[jf];                             // blocks of this segment completed before this subsequence
-        r.fill();
-        while (r.position() < endbits && nb < seg_nblk) {
-            nb += symbol<true>(r, T, b, k, bpm, coefs + (size_t)(seg_first_blk + nb) * 64) ? 1 : 0;
-            r.fill();
-        }
-    }
-    __syncthreads();
-    // ---- DC prediction: running sum of the differences per component, in scan order, reset at restart intervals
     const int nmcu = d[D_MCUX] * d[D_MCUY];
     int off = 0;
     for (int c = 0; c < ncomp; c++) {
         const int nbc = d[D_COMP0 + 5 * c] * d[D_COMP0 + 5 * c + 1];
-        const int count = nmcu * nbc, L = (count + NT - 1) / NT;
-        const int q0 = min(tid * L, count), q1 = min(q0 + L, count);
+        const int count = nmcu * nbc, Lq = (count + NT - 1) / NT;
+        const int q0 = min(tid * Lq, count), q1 = min(q0 + Lq, count);
         int run = 0, hasreset = 0;
         for (int q = q0; q < q1; q++) {
             const int m = q / nbc, w = q - m * nbc;
@@ -431,24 +625,26 @@ __device__ __forceinline__ void upsampled4(const PlaneRef& c, int x0, int y, int
     for (int i = 0; i < 4; i++) v[i] = upsampled(c, x0 + i, y);
 }
 
+// grid (ceil(max width / 256), ceil(max height / 4), images), block (64, 4): four pixels of one row per thread.  The host parser only lets
+// through luma at full resolution over 1 x 1 chroma (4:4:4 / 4:2:2 / 4:2:0) and grey.
 __global__ __launch_bounds__(256) void jpeg_color_kernel(const int32_t* desc, const unsigned char* planes, unsigned char* out, int channels) {
-    const int32_t* d = desc + (size_t)blockIdx.y * AB_JPEG_DESC_INTS;
-    const int W = d[D_W], H = d[D_H], W4 = (W + 3) >> 2;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= W4 * H) return;
-    const int y = i / W4, x0 = (i - y * W4) * 4;
-    const int ncomp = d[D_NCOMP], hmax = d[D_HMAX], vmax = d[D_VMAX];
-    PlaneRef pr[3];
-    size_t po = (size_t)d[D_PLANE_BASE];
-    for (int c = 0; c < ncomp; c++) {
-        const int h = d[D_COMP0 + 5 * c], v = d[D_COMP0 + 5 * c + 1];
-        pr[c].P = planes + po; pr[c].pitch = d[D_MCUX] * h * 8;
-        pr[c].dw = (W * h + hmax - 1) / hmax; pr[c].dh = (H * v + vmax - 1) / vmax; pr[c].hr = hmax / h; pr[c].vr = vmax / v;
-        po += (size_t)pr[c].pitch * d[D_MCUY] * v * 8;
-    }
+    const int32_t* d = desc + (size_t)blockIdx.z * AB_JPEG_DESC_INTS;
+    const int W = d[D_W], H = d[D_H];
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= W || y >= H) return;
+    const int ncomp = d[D_NCOMP], hmax = d[D_HMAX], vmax = d[D_VMAX], mcux = d[D_MCUX], mcuy = d[D_MCUY];
+    PlaneRef py;
+    py.P = planes + (size_t)d[D_PLANE_BASE]; py.pitch = mcux * hmax * 8; py.dw = W; py.dh = H; py.hr = 1; py.vr = 1;
     int Y[4], Cb[4], Cr[4];
-    upsampled4(pr[0], x0, y, Y);
-    if (ncomp == 3) { upsampled4(pr[1], x0, y, Cb); upsampled4(pr[2], x0, y, Cr); }
+    upsampled4(py, x0, y, Y);
+    if (ncomp == 3) {
+        PlaneRef pc;
+        pc.pitch = mcux * 8; pc.dw = (W + hmax - 1) >> (hmax - 1); pc.dh = (H + vmax - 1) >> (vmax - 1); pc.hr = hmax; pc.vr = vmax;
+        pc.P = py.P + (size_t)py.pitch * mcuy * vmax * 8;
+        upsampled4(pc, x0, y, Cb);
+        pc.P += (size_t)pc.pitch * mcuy * 8;
+        upsampled4(pc, x0, y, Cr);
+    }
     uint32_t px[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -474,30 +670,48 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
-extern "C" long ab_jpeg_workspace_bytes(long total_blocks, long total_subseq, long plane_bytes) {
-    return (long)(align256((size_t)total_blocks * 128) + 5 * align256((size_t)total_subseq * 4) + align256((size_t)plane_bytes));
+extern "C" long ab_jpeg_workspace_bytes(long total_blocks, long total_subseq, long plane_bytes, long data_bytes, long total_segs, int n, int n_tables) {
+    return (long)(align256((size_t)total_blocks * 128) + 5 * align256((size_t)total_subseq * 4) + align256((size_t)plane_bytes) +
+                  align256((size_t)data_bytes + 64) + align256((size_t)total_segs * 8) + align256((size_t)n * (R_MAX + 2) * 4) +
+                  align256((size_t)n_tables * sizeof(HuffTables)) + align256(((size_t)data_bytes / 16 + 4) * 4));
 }
 
 extern "C" int ab_jpeg_decode_batch(const void* data, const int32_t* desc, const int32_t* segs, const void* qtabs, const void* htabs, int n,
-                                    int sub_bytes, long total_blocks, long total_subseq, long plane_bytes, int max_blocks, int max_pixels,
-                                    int out_channels, void* out, void* workspace, void* stream) {
+                                    int n_tables, int sub_bytes, long total_blocks, long total_subseq, long plane_bytes, long data_bytes,
+                                    long total_segs, int max_blocks, int max_width, int max_height, int max_subseq, int out_channels, void* out,
+                                    void* workspace, void* stream) {
     if (n <= 0) return 0;
-    if (sub_bytes < 16 || (out_channels != 3 && out_channels != 4) || !data || !desc || !segs || !qtabs || !htabs || !out || !workspace) return -1;
+    if (sub_bytes < 16 || sub_bytes > STAGE_MAX_SUB || (out_channels != 3 && out_channels != 4) || !data || !desc || !segs || !qtabs || !htabs || !out || !workspace ||
+        n_tables <= 0 || n > 65535 || max_subseq <= 0 || max_width <= 0 || max_height <= 0 || max_height > 4 * 65535) return -1;
+    static const int no_lut2 = getenv("AB_JPEG_NO_LUT2") ? atoi(getenv("AB_JPEG_NO_LUT2")) : 0;    // test hook: canonical search for every long code
     hipStream_t st = as_stream(stream);
     char* w = (char*)workspace;
     short* coefs = (short*)w; w += align256((size_t)total_blocks * 128);
     uint32_t* arr[5];
     for (int i = 0; i < 5; i++) { arr[i] = (uint32_t*)w; w += align256((size_t)total_subseq * 4); }
-    unsigned char* planes = (unsigned char*)w;
-    (void)plane_bytes;
+    unsigned char* planes = (unsigned char*)w; w += align256((size_t)plane_bytes);
+    unsigned char* clean = (unsigned char*)w; w += align256((size_t)data_bytes + 64);
+    int32_t* segc = (int32_t*)w; w += align256((size_t)total_segs * 8);
+    int32_t* act = (int32_t*)w; w += align256((size_t)n * (R_MAX + 2) * 4);
+    HuffTables* tables = (HuffTables*)w; w += align256((size_t)n_tables * sizeof(HuffTables));
+    int32_t* kp = (int32_t*)w;
     hipError_t e = hipMemsetAsync(coefs, 0, (size_t)total_blocks * 128, st);
     if (e != hipSuccess) return (int)e;
-    EntropyArgs a{(const unsigned char*)data, desc, segs, (const unsigned char*)htabs, coefs, arr[0], arr[1], (int32_t*)arr[2], arr[3], arr[4], sub_bytes};
-    hipLaunchKernelGGL(jpeg_entropy_kernel, dim3(n), dim3(NT), 0, st, a);
+    e = hipMemsetAsync(act, 0, (size_t)n * (R_MAX + 2) * 4, st);
+    if (e != hipSuccess) return (int)e;
+    EntropyArgs a{(const unsigned char*)data, clean, desc, segs, segc, kp, (const unsigned char*)htabs, tables, coefs,
+                  arr[0], arr[1], (int32_t*)arr[2], arr[3], arr[4], act, sub_bytes, n_tables, no_lut2};
+    hipLaunchKernelGGL(jpeg_tables_kernel, dim3(n_tables), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(jpeg_unstuff_kernel, dim3(n), dim3(NT), 0, st, a);
+    const dim3 gw((max_subseq + NW - 1) / NW, n);
+    for (int rnd = 0; rnd <= R_MAX; rnd++) hipLaunchKernelGGL(jpeg_sync_kernel<true>, gw, dim3(NW), 0, st, a, rnd);
+    hipLaunchKernelGGL(jpeg_finish_kernel, dim3(n), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL(jpeg_coef_kernel<true>, gw, dim3(NW), 0, st, a);
+    hipLaunchKernelGGL(jpeg_dc_kernel, dim3(n), dim3(NT), 0, st, a);
     AB_LAUNCH_CHECK();
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3((max_blocks + 31) / 32, n), dim3(256), 0, st, desc, coefs, (const unsigned short*)qtabs, planes);
     AB_LAUNCH_CHECK();
-    hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_pixels / 4 + 255) / 256, n), dim3(256), 0, st, desc, planes, (unsigned char*)out, out_channels);
+    hipLaunchKernelGGL(jpeg_color_kernel, dim3((max_width + 255) / 256, (max_height + 3) / 4, n), dim3(64, 4), 0, st, desc, planes, (unsigned char*)out, out_channels);
     AB_LAUNCH_CHECK();
     return 0;
 }

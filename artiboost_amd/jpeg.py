@@ -149,7 +149,7 @@ class _Plan:
         segs, qts, hts = [], [], []
         ht_index = {}
         data_off, sub_base, blk_base, plane_base, seg_off = 0, 0, 0, 0, 0
-        self.max_blocks = self.max_pixels = 0
+        self.max_blocks = self.max_w = self.max_h = self.max_sub = 0
         for i, (f, it) in enumerate(zip(files, infos)):
             nmcu = it.mcux * it.mcuy
             nblk = nmcu * it.bpm
@@ -176,7 +176,8 @@ class _Plan:
             blk_base += nblk
             plane_base += (nblk * 64 + 255) & ~255
             seg_off += len(sg)
-            self.max_blocks, self.max_pixels = max(self.max_blocks, nblk), max(self.max_pixels, 4 * ((it.width + 3) // 4) * it.height)
+            self.max_blocks, self.max_w, self.max_h = max(self.max_blocks, nblk), max(self.max_w, it.width), max(self.max_h, it.height)
+            self.max_sub = max(self.max_sub, int(nsub.sum()))
         self.n, self.sub_bytes = n, sub_bytes
         self.total_blocks, self.total_sub, self.plane_bytes, self.data_bytes = blk_base, sub_base, plane_base, data_off
         self.desc, self.segs = desc, np.concatenate(segs).astype(np.int32)
@@ -207,6 +208,8 @@ class JpegDecoder:
     Keeps its pinned staging blob, device blob and workspace between calls."""
 
     def __init__(self, device="cuda", sub_bytes=128):
+        if not 16 <= int(sub_bytes) <= 128:
+            raise ValueError("sub_bytes: 16 .. 128 (the subsequence a thread stages in LDS)")
         self.dev, self.sub_bytes = torch.device(device), int(sub_bytes)
         self._pins, self._evs, self._k = [None, None], [None, None], 0      # two pinned staging blobs, reused alternately
         self._dev_blob = self._ws = None
@@ -250,22 +253,27 @@ class JpegDecoder:
         self._evs[k] = torch.cuda.Event()
         self._evs[k].record()
         lib = L.lib()
-        wb = lib.ab_jpeg_workspace_bytes(L.l(plan.total_blocks), L.l(plan.total_sub), L.l(plan.plane_bytes))
+        nseg, nht = len(plan.segs), len(plan.ht)
+        wb = lib.ab_jpeg_workspace_bytes(L.l(plan.total_blocks), L.l(plan.total_sub), L.l(plan.plane_bytes), L.l(plan.data_bytes), L.l(nseg), L.i(n),
+                                         L.i(nht))
         if self._ws is None or self._ws.numel() < wb:
             self._ws = torch.empty(int(wb * 1.5), dtype=torch.uint8, device=self.dev)
         part = lambda k, nb: self._dev_blob[offs[k]:offs[k] + nb]      # noqa: E731
         L.check(lib.ab_jpeg_decode_batch(L.ptr(part(0, plan.data_bytes + 16)), L.ptr(part(1, plan.desc.nbytes).view(torch.int32)),
                                          L.ptr(part(2, plan.segs.nbytes).view(torch.int32)), L.ptr(part(3, plan.qt.nbytes)),
-                                         L.ptr(part(4, plan.ht.nbytes)), L.i(n), L.i(plan.sub_bytes), L.l(plan.total_blocks), L.l(plan.total_sub),
-                                         L.l(plan.plane_bytes), L.i(plan.max_blocks), L.i(plan.max_pixels), L.i(channels), L.view_ptr(out),
-                                         L.ptr(self._ws), L.stream()), "ab_jpeg_decode_batch")
-        self._last = (plan.total_blocks, plan.total_sub, plan.desc[:, 25].copy())
+                                         L.ptr(part(4, plan.ht.nbytes)), L.i(n), L.i(nht), L.i(plan.sub_bytes), L.l(plan.total_blocks),
+                                         L.l(plan.total_sub), L.l(plan.plane_bytes), L.l(plan.data_bytes), L.l(nseg), L.i(plan.max_blocks),
+                                         L.i(plan.max_w), L.i(plan.max_h), L.i(plan.max_sub), L.i(channels), L.view_ptr(out), L.ptr(self._ws), L.stream()),
+                "ab_jpeg_decode_batch")
+        self._last = (plan.total_blocks, plan.total_sub, plan.plane_bytes, plan.data_bytes, nseg, n)
         return res
 
+    R_MAX = 16          # csrc/jpeg.hip
+
     def last_rounds(self):
-        """Diagnostic: synchronisation rounds each image of the last batch took (jpeg_entropy_kernel leaves the count in its chain array)."""
-        tb, ts, sub_base = self._last
+        """Diagnostic: synchronisation rounds each image of the last batch took (left by jpeg_finish_kernel in the workspace)."""
+        tb, ts, pb, db, nseg, n = self._last
         a256 = lambda x: (x + 255) & ~255      # noqa: E731
-        off = a256(tb * 128) + 3 * a256(ts * 4)
+        off = a256(tb * 128) + 5 * a256(ts * 4) + a256(pb) + a256(db + 64) + a256(nseg * 8)      # layout: ab_jpeg_decode_batch
         torch.cuda.synchronize()
-        return self._ws[off:off + a256(ts * 4)].view(torch.int32)[torch.from_numpy(sub_base).long().to(self.dev)].cpu().numpy()
+        return self._ws[off:off + n * (self.R_MAX + 2) * 4].view(torch.int32).view(n, self.R_MAX + 2)[:, self.R_MAX + 1].cpu().numpy()

@@ -153,6 +153,53 @@ def wgrad_1pass_leg(args, device, steps=10, warmup=3):
             "note": "NOT a parity configuration and not the headline: weight-gradient operands at bf16 (2^-9), below the reference's fp32; see DESIGN 12.1"}
 
 
+def jpeg_leg(device, n=64, iters=20):  # noqa: C901
+    """SURVEY 8f-3, the decode in front of the real-data half: n 640 x 480 .jpg frames (the HO3D / DexYCB frame size; synthetic photographs
+    written by Pillow at quality 92, 4:2:0) -> RGBX on the device through ab_jpeg_decode_batch (Huffman decode included), HIP-event timed on the
+    stream; the reference's decoder (Pillow = libjpeg-turbo, one DataLoader worker) timed on this host beside it.  Bit-identical outputs
+    (tests/test_gpu_jpeg.py); sized to ~2 s."""
+    import io
+    import numpy as np
+    import torch
+    try:
+        from PIL import Image
+    except ImportError:
+        return {"error": "Pillow not importable: no files to decode"}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_jpeg import _photo
+    from artiboost_amd.jpeg import JpegDecoder, parse
+    files = []
+    for i in range(n):
+        b = io.BytesIO()
+        Image.fromarray(_photo(640, 480, i)).save(b, "JPEG", quality=92, subsampling=2)
+        files.append(b.getvalue())
+    t0 = time.perf_counter()
+    for f in files[:16]:
+        np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))
+    t_pil = (time.perf_counter() - t0) / 16
+    out = torch.empty((n, 480, 640, 4), dtype=torch.uint8, device=device)
+    dec = JpegDecoder(device)
+    for _ in range(3):
+        dec.decode(files, out=out)
+    torch.cuda.synchronize()
+    infos = [parse(f) for f in files]             # the host's share: a marker walk, 15 us per file (tools/bench_jpeg.py)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dec.decode(files, out=out, infos=infos)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    rr = dec.last_rounds()
+    return {"metric": "real frames/sec decoded (.jpg 640x480 -> RGBX on the device)", "value": round(n / ms * 1e3, 1), "unit": "frames/s",
+            "ms_per_batch": round(ms, 3), "batch": n, "file_kb": round(sum(len(f) for f in files) / n / 1024, 1), "dtype": "u8/int32",
+            "sync_rounds_mean_max": [round(float(rr.mean()), 1), int(rr.max())],
+            "bound": "latency of one thread's Huffman chain (VALU + LDS look-ups), not HBM: algorithmic bytes per frame "
+                     f"{round(sum(len(f) for f in files) / n / 1e6 + 640 * 480 * 4 / 1e6, 2)} MB",
+            "cpu_reference": {"kind": "reference", "decoder": "Pillow (libjpeg-turbo) Image.open().convert('RGB'), 1 thread = one DataLoader worker",
+                              "value": round(1.0 / t_pil, 1), "unit": "frames/s", "sample": "16 of the same files"}}
+
+
 def dexycb_leg(args, device, steps=10, warmup=3):
     """BASELINE configs[4] on ONE GPU (its 8-GPU form is this step under the data-parallel schedule of configs[3]): DexYCB-like scenes
     (21 objects at 16 k faces) and the DexYCB criterion list (+ SymCornerLoss in the fused pose/loss kernel), same geometry and precision."""
@@ -557,6 +604,7 @@ def main():
                     help="seconds of the sustained block run after the timed steps (extra keys of the line; 0 = off)")
     ap.add_argument("--no-eval-leg", action="store_true", help="skip the configs[1] eval-forward sub-object of the default line")
     ap.add_argument("--no-dexycb-leg", action="store_true", help="skip the configs[4]-on-one-GPU sub-object of the default line")
+    ap.add_argument("--no-jpeg-leg", action="store_true", help="skip the real-frame JPEG decode sub-object of the default line")
     ap.add_argument("--no-study-leg", action="store_true", help="skip the one-pass weight-gradient study sub-object of the default line")
     ap.add_argument("--wgrad-1pass", action="store_true",
                     help="PRECISION STUDY, not a parity configuration (DESIGN 12.1): weight gradients from the hi planes only (one bf16 MFMA "
@@ -706,6 +754,12 @@ def main():
                 study = wgrad_1pass_leg(args, device)
             except Exception as e:   # noqa: BLE001
                 study = {"error": repr(e)}
+        jpg = None
+        if world == 1 and not args.no_jpeg_leg and not args.eager:
+            try:
+                jpg = jpeg_leg(device)
+            except Exception as e:   # noqa: BLE001
+                jpg = {"error": repr(e)}
         roof["peak_note"] = ("dense bf16 MFMA peak / 3 passes" if args.dtype == "bf16x3" else "dense MFMA peak of the operand type")
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(args, cfg)
@@ -727,6 +781,7 @@ def main():
                "sustained": sustained,                 # same process, >= --sustain seconds after the timed block (+ observed sclk / power)
                "configs1_eval_forward": ev,            # BASELINE configs[1] (forward only) with its own roofline; `bench.py --eval` prints it as the line
                "configs4_dexycb_1gpu": dex,
+               "real_half_jpeg_decode": jpg,           # .jpg files -> frames on the device, beside Pillow on this host
                "study_wgrad_bf16_1pass": study}        # precision / speed study beside the headline (one-pass weight gradients), see its note            # BASELINE configs[4]'s per-GPU step (DexYCB scenes + SymCornerLoss) on this one GPU
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -397,7 +397,7 @@ int ab_augment_batch(const void* rgbx, int B, int W, int H, const int32_t* order
 /* SURVEY section 8f-3, the decode in front of that chain: baseline JPEG files -> RGB(X) frames on the device, bit-identical to what
  * `Image.open(path).convert("RGB")` returns in the reference's DataLoader workers (anakin/datasets/ho3d.py:228-231, dexycb.py:226-229,
  * fhb.py:257-260: Pillow / libjpeg-turbo defaults, JDCT_ISLOW + fancy up-sampling).  Huffman decode (self-synchronising, one thread per
- * `sub_bytes` of scan data), de-quantisation + integer IDCT, chroma up-sampling and colour conversion all run on the device; the host
+ * `sub_bytes` of scan data, 16 <= sub_bytes <= 128), de-quantisation + integer IDCT, chroma up-sampling and colour conversion all run on the device; the host
  * only reads the marker segments (artiboost_amd/jpeg.py) into:
  *   data   the files' bytes (device; each image's scan is addressed through its descriptor)
  *   desc   int32 [n][AB_JPEG_DESC_INTS]: 0 scan offset in data, 1 scan bytes, 2 width, 3 height, 4 components (1 | 3), 5 hmax, 6 vmax,
@@ -408,14 +408,17 @@ int ab_augment_batch(const void* rgbx, int B, int W, int H, const int32_t* order
  *   segs   int32 [.][4] per restart interval (one per image without restart markers): byte offset in the scan, bytes, first subsequence,
  *          first block (both relative to the image)
  *   qtabs  uint16 [.][4][64] in natural (row-major) order;  htabs  uint8 [.][8][16 + 256]: DC tables 0-3, AC tables 0-3 as in the DHT segment
- * max_blocks: the largest descriptor field 28; max_pixels: the largest 4 * ceil(width / 4) * height.
+ * max_blocks / max_width / max_height: the largest descriptor fields 28 / 2 / 3 of the batch.
  * out: uint8, out_channels 3 (RGB) or 4 (RGBX, X = 0).  Supported files: SOF0 / SOF1, 8 bit, grey or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart
  * intervals; anything else is refused by the host parser (the caller keeps Pillow for those files, as the reference does for all).      */
 #define AB_JPEG_DESC_INTS 40
-long ab_jpeg_workspace_bytes(long total_blocks, long total_subseq, long plane_bytes);
+/* workspace: coefficients, per-subsequence states, sample planes, the unstuffed scans, decode tables.  n_tables: sets of 8 Huffman tables in
+ * htabs; data_bytes: bytes of `data`; total_segs: rows of segs; max_subseq: the largest descriptor field 26.                              */
+long ab_jpeg_workspace_bytes(long total_blocks, long total_subseq, long plane_bytes, long data_bytes, long total_segs, int n, int n_tables);
 int ab_jpeg_decode_batch(const void* data, const int32_t* desc, const int32_t* segs, const void* qtabs, const void* htabs, int n,
-                         int sub_bytes, long total_blocks, long total_subseq, long plane_bytes, int max_blocks, int max_pixels,
-                         int out_channels, void* out, void* workspace, void* stream);
+                         int n_tables, int sub_bytes, long total_blocks, long total_subseq, long plane_bytes, long data_bytes,
+                         long total_segs, int max_blocks, int max_width, int max_height, int max_subseq, int out_channels, void* out,
+                         void* workspace, void* stream);
 /* Small-batch fp32 linear layers (the box-rotation MLP, anakin/models/mlp.py:11-25; nn.Linear weights [N][K]):
  *   fwd   y[M][N]  = act(x[M][K] W^T + bias)            (relu != 0: ReLU)
  *   dgrad gx[M][K] = (g[M][N] W) masked by act_out > 0   (act_out NULL: no mask); takes wt = W transposed, [K][N]

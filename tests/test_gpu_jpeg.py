@@ -19,11 +19,12 @@ def _golden():
     return [(bytes(g[f"file{i}"]), g[f"rgb{i}"]) for i in range(int(g["n"]))]
 
 
-@pytest.mark.parametrize("sub_bytes", [16, 64, 128, 1024])
+@pytest.mark.parametrize("sub_bytes", [16, 36, 64, 128])
 @pytest.mark.parametrize("channels", [3, 4])
 def test_jpeg_goldens_bit_exact(sub_bytes, channels):
     """Every golden file (4:4:4 / 4:2:2 / 4:2:0 / grey, custom Huffman tables, restart intervals down to one MCU, 1 x 1 to 160 x 120) in ONE
-    ragged batch, for several subsequence lengths (16 bytes: chains cross many subsequences; 1024: one thread per small file)."""
+    ragged batch, for several subsequence lengths (16 bytes: chains cross many subsequences and more rounds than the launched ones, finished in
+    jpeg_finish_kernel; 128: one thread per small file)."""
     from artiboost_amd.jpeg import JpegDecoder
     cases = _golden()
     dec = JpegDecoder("cuda", sub_bytes=sub_bytes)
@@ -35,6 +36,19 @@ def test_jpeg_goldens_bit_exact(sub_bytes, channels):
         np.testing.assert_array_equal(got[..., :3], rgb, err_msg=f"case {i}")
         if channels == 4:
             assert not got[..., 3].any()
+
+
+def test_jpeg_long_codes_by_canonical_search():
+    """AB_JPEG_NO_LUT2=1 (read once per process: run in a child): codes longer than the first look-up level go through the canonical
+    bit-by-bit search the kernels keep for tables whose long codes do not fit the second level."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from artiboost_amd.jpeg import JpegDecoder; g = np.load(%r); "
+            "n = int(g['n']); outs = JpegDecoder('cuda').decode([bytes(g[f'file{i}']) for i in range(n)], channels=3); "
+            "assert all(np.array_equal(o.cpu().numpy(), g[f'rgb{i}']) for i, o in enumerate(outs)); print('same')"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), GOLD))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AB_JPEG_NO_LUT2="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "same" in r.stdout, r.stderr[-2000:]
 
 
 def _photo(w, h, seed):
@@ -73,6 +87,29 @@ def test_jpeg_full_size_batch_vs_oracle_and_pillow():
         if i < 8:
             np.testing.assert_array_equal(got[i, ..., :3], np.asarray(Image.open(io.BytesIO(f)).convert("RGB")))
     assert not got[..., 3].any()
+
+
+def test_jpeg_large_and_odd_shapes_vs_oracle():
+    """1920 x 1080 (several thousand subsequences per image, more than one workgroup of them), a 3000 x 17 strip, a 9 x 2000 column and a
+    grey 1001 x 999 frame in one ragged batch: bit-exact vs the C oracle."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    from artiboost_amd.jpeg import JpegDecoder
+    rng = np.random.default_rng(3)
+    files = []
+    for (w, h, sub, q, grey) in [(1920, 1080, 2, 90, False), (3000, 17, 1, 85, False), (9, 2000, 2, 95, False), (1001, 999, 0, 80, True),
+                                 (1920, 1080, 0, 97, False)]:
+        img = _photo(w, h, w + h)
+        img = np.clip(img.astype(np.int32) + rng.integers(-20, 20, img.shape), 0, 255).astype(np.uint8)
+        b = io.BytesIO()
+        if grey:
+            Image.fromarray(img[..., 0]).save(b, "JPEG", quality=q)
+        else:
+            Image.fromarray(img).save(b, "JPEG", quality=q, subsampling=sub)
+        files.append(b.getvalue())
+    outs = JpegDecoder("cuda").decode(files, channels=3)
+    for i, (f, o) in enumerate(zip(files, outs)):
+        np.testing.assert_array_equal(o.cpu().numpy(), jo.decode(f), err_msg=f"file {i}")
 
 
 def test_jpeg_refuses_unsupported_before_device_work():
