@@ -37,24 +37,36 @@ constexpr int LUT_BITS = 9, LUT2 = 1024, NT = 1024, NW = 256, R_MAX = 16;
 // the numerically LARGEST look-aheads (>= base2), a few hundred values for the tables encoders write -- indexed directly.  A table whose long
 // codes span more than LUT2 values falls back to the bit-by-bit canonical search in memory (slow2 == 0).
 struct HuffLuts {
-    uint16_t lut1[8][1 << LUT_BITS];     // (length << 8) | symbol; 0: longer than LUT_BITS bits
-    uint16_t lut2[8][LUT2];               // the same for look-ahead values base2 + i
-    uint32_t base2[8];
-    uint32_t ok2[8];
+    uint16_t lut1[8][1 << LUT_BITS];     // (length << 8) | symbol; longer than LUT_BITS bits: 0x8000 | i (the code is in lut2[128 i ..]) or 0x4000
+    uint16_t lut2[8][LUT2];               // (length << 8) | symbol for look-ahead values base2 + i
 };
 struct HuffTables {
     HuffLuts luts;
     int maxcode[8][17];                   // largest code of each length, -1: none
     int valoff[8][17];                    // vals index of the first code of that length minus that code
     unsigned char vals[8][256];
+    uint32_t base2[8], ok2[8];
 };
 static_assert(sizeof(HuffLuts) % 16 == 0 && sizeof(HuffTables) % 16 == 0, "copied as uint4");
 
 struct Lds {
     HuffLuts T;
     unsigned char zz[64];
-    unsigned char tb_dc[12], tb_ac[12];   // table slot of each block of the MCU
 };
+// table slots of the blocks of one MCU, 3 bits each (<= 10 blocks): DC slots 0-3, AC slots 4-7
+struct McuTables { uint32_t dc, ac; };
+__device__ __forceinline__ McuTables mcu_tables(const int32_t* d) {
+    McuTables m{0u, 0u};
+    int j = 0;
+    for (int c = 0; c < d[4 /* D_NCOMP */]; c++) {
+        const int nb = d[7 + 5 * c] * d[7 + 5 * c + 1];
+        for (int i = 0; i < nb && j < 10; i++, j++) {
+            m.dc |= (uint32_t)(d[7 + 5 * c + 3] & 3) << (3 * j);
+            m.ac |= (uint32_t)(4 + (d[7 + 5 * c + 4] & 3)) << (3 * j);
+        }
+    }
+    return m;
+}
 
 // MSB-first bit reader over the UNSTUFFED scan (jpeg_unstuff_kernel), in aligned 32-bit words: the next bit is bit 63 of acc, n valid bits;
 // bytes past `end` read as zero.  STAGED: the words of this thread's stretch were copied to LDS up front (lds[j * NW + thread], word w0 + j) --
@@ -96,15 +108,14 @@ __device__ __forceinline__ void stage(uint32_t* col, const uint32_t* words, uint
 
 // one Huffman symbol (+ its value bits) in state (b, k); returns 1 when it completed a block
 template <bool WRITE, bool STAGED>
-__device__ __forceinline__ int symbol(Reader<STAGED>& r, const Lds& L, const HuffTables* G, int& b, int& k, int& tdc, int& tac, int bpm, short* blk_out) {
+__device__ __forceinline__ int symbol(Reader<STAGED>& r, const Lds& L, const HuffTables* G, const McuTables mt, int& b, int& k, int bpm, short* blk_out) {
     r.fill();
     const bool isdc = k == 0;
-    const int t = isdc ? tdc : tac;
+    const int t = (int)(((isdc ? mt.dc : mt.ac) >> (3 * b)) & 7u);
     const uint32_t pk = (uint32_t)(r.acc >> 48);
     uint32_t e = L.T.lut1[t][pk >> (16 - LUT_BITS)];
-    if (e == 0) {
-        const uint32_t i2 = pk - L.T.base2[t];
-        if (L.T.ok2[t]) e = L.T.lut2[t][i2 & (LUT2 - 1)];
+    if (e & 0xC000u) {
+        if (e & 0x8000u) e = L.T.lut2[t][((e & 7u) << 7) | (pk & 127u)];
         else {
             e = 16u << 8;                                    // invalid code: 16 bits, symbol 0 (libjpeg: warning + 0)
             for (int l = LUT_BITS + 1; l <= 16; l++) {
@@ -123,12 +134,10 @@ __device__ __forceinline__ int symbol(Reader<STAGED>& r, const Lds& L, const Huf
     const int kn = k + run;
     if (WRITE && s && kn < 64) blk_out[L.zz[kn]] = (short)v;        // DC: the difference; jpeg_dc_kernel turns it into the value
     k = eob ? 64 : kn + 1;
-    if (k >= 64) {
-        k = 0; b = b + 1 == bpm ? 0 : b + 1;
-        tdc = L.tb_dc[b]; tac = L.tb_ac[b];
-        return 1;
-    }
-    return 0;
+    const int done = k >= 64;
+    k = done ? 0 : k;
+    b = done ? (b + 1 == bpm ? 0 : b + 1) : b;
+    return done;
 }
 
 struct EntropyArgs {
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256) void jpeg_tables_kernel(EntropyArgs a) {
     const unsigned char* ht = a.htabs + (size_t)blockIdx.x * (8 * 272);
     const int tid = threadIdx.x;
     for (int i = tid; i < 8 * 272; i += 256) s_ht[i] = ht[i];
-    for (int i = tid; i < 8 * (1 << LUT_BITS); i += 256) (&T.luts.lut1[0][0])[i] = 0;
+    for (int i = tid; i < 8 * (1 << LUT_BITS); i += 256) (&T.luts.lut1[0][0])[i] = (uint16_t)0x4000u;     // no code here: the canonical search says so
     for (int i = tid; i < 8 * LUT2; i += 256) (&T.luts.lut2[0][0])[i] = (uint16_t)(16u << 8);      // not a code: 16 bits, symbol 0
     __syncthreads();
     for (int i = tid; i < 8 * 256; i += 256) T.vals[i >> 8][i & 255] = s_ht[(i >> 8) * 272 + 16 + (i & 255)];
@@ -161,7 +170,10 @@ __global__ __launch_bounds__(256) void jpeg_tables_kernel(EntropyArgs a) {
         for (int l = 1; l <= LUT_BITS; l++) code = (code + cnt[l - 1]) << 1;          // first code of length LUT_BITS + 1
         const uint32_t b2 = (uint32_t)code << (16 - (LUT_BITS + 1));
         s_base2[tid] = b2; s_ok2[tid] = !a.no_lut2 && b2 <= 65536u && 65536u - b2 <= (uint32_t)LUT2;
-        T.luts.base2[tid] = b2; T.luts.ok2[tid] = s_ok2[tid];
+        T.base2[tid] = b2; T.ok2[tid] = s_ok2[tid];
+        // level-1 entries of the prefixes that belong to longer codes (canonical: the LARGEST prefixes, base2 is a multiple of 128)
+        for (uint32_t p = b2 >> (16 - LUT_BITS); p < (1u << LUT_BITS); p++)
+            T.luts.lut1[tid][p] = s_ok2[tid] ? (uint16_t)(0x8000u | (p - (b2 >> (16 - LUT_BITS)))) : (uint16_t)0x4000u;
     }
     __syncthreads();
     // thread j of a slot: the j-th symbol -- its code from the counts, then its LUT entries; threads 0..16 also the per-length tables
@@ -296,14 +308,6 @@ __device__ __forceinline__ void load_lds(Lds& L, const EntropyArgs& a, const int
     uint4* dst = reinterpret_cast<uint4*>(&L.T);
     for (int i = tid; i < (int)(sizeof(HuffLuts) / 16); i += nthreads) dst[i] = src[i];
     if (tid < 64) L.zz[tid] = ZZ[tid];
-    if (tid < 12) {
-        int c = 0, acc = 0;
-        const int ncomp = d[D_NCOMP];
-        for (; c < ncomp; c++) { const int nb = d[D_COMP0 + 5 * c] * d[D_COMP0 + 5 * c + 1]; if (tid < acc + nb) break; acc += nb; }
-        c = c < ncomp ? c : 0;
-        L.tb_dc[tid] = (unsigned char)(d[D_COMP0 + 5 * c + 3] & 3);
-        L.tb_ac[tid] = (unsigned char)(4 + (d[D_COMP0 + 5 * c + 4] & 3));
-    }
     __syncthreads();
 }
 // bit range [start, end) of subsequence v of segment s in the unstuffed scan, and the end of the segment; false: v is empty
@@ -317,12 +321,12 @@ __device__ __forceinline__ bool sub_range(const ImageCtx& c, int s, int v, SubRa
 }
 // decode (without writing) from (P, b, k) to the end of a subsequence; returns the blocks completed
 template <bool STAGED>
-__device__ __forceinline__ int run_sub(const uint32_t* words, uint32_t* col, const Lds& L, const HuffTables* G, const SubRange& sr, int bpm, uint32_t& P, int& b, int& k) {
+__device__ __forceinline__ int run_sub(const uint32_t* words, uint32_t* col, const Lds& L, const HuffTables* G, const McuTables mt, const SubRange& sr, int bpm, uint32_t& P, int& b, int& k) {
     Reader<STAGED> r;
     if (STAGED) { stage(col, words, P, sr.endbits); r.seek(col, sr.seg_end, P); }
     else r.seek(words, sr.seg_end, P);
-    int tdc = L.tb_dc[b], tac = L.tb_ac[b], nb = 0;
-    while (r.position() < sr.endbits) nb += symbol<false>(r, L, G, b, k, tdc, tac, bpm, nullptr);
+    int nb = 0;
+    while (r.position() < sr.endbits) nb += symbol<false>(r, L, G, mt, b, k, bpm, nullptr);
     P = r.position();
     return nb;
 }
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(NW) void jpeg_sync_kernel(EntropyArgs a, int rnd) {
     int32_t* act = a.act + (size_t)img * (R_MAX + 2);
     if (rnd > 0 && !act[rnd - 1]) return;                    // every chain of this image has synchronised already
     load_lds(L, a, c.d, tid, NW);
+    const McuTables mt = mcu_tables(c.d);
     const int u = blockIdx.x * NW + tid;
     if (u >= c.nsub) return;
     const int s = seg_of_sub(c.segs, c.nseg, u);
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(NW) void jpeg_sync_kernel(EntropyArgs a, int rnd) {
     if (rnd == 0) {
         const bool live = sub_range(c, s, u, sr);
         uint32_t P = sr.startbits; int b = 0, k = 0, nb = 0;
-        if (live) nb = run_sub<STAGED>(words, col, L, a.tables + c.d[D_HT], sr, c.bpm, P, b, k);
+        if (live) nb = run_sub<STAGED>(words, col, L, a.tables + c.d[D_HT], mt, sr, c.bpm, P, b, k);
         const uint32_t S = (uint32_t)b | ((uint32_t)k << 8);
         c.sP[u] = P; c.sS[u] = S; c.sN[u] = nb;
         c.cP[u] = live ? P : 0xFFFFFFFFu; c.cS[u] = S;
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(NW) void jpeg_sync_kernel(EntropyArgs a, int rnd) {
     const int last = (s + 1 < c.nseg ? c.segs[(s + 1) * 4 + 2] : c.nsub) - 1;
     if (v > last || !sub_range(c, s, v, sr)) { c.cP[u] = 0xFFFFFFFFu; return; }
     int b = (int)(c.cS[u] & 255u), k = (int)(c.cS[u] >> 8);
-    const int nb = run_sub<STAGED>(words, col, L, a.tables + c.d[D_HT], sr, c.bpm, P, b, k);
+    const int nb = run_sub<STAGED>(words, col, L, a.tables + c.d[D_HT], mt, sr, c.bpm, P, b, k);
     const uint32_t S = (uint32_t)b | ((uint32_t)k << 8);
     // the chains reach v in order of decreasing start index, the last one (matching or not) carries the true state into v: its count of
     // blocks completed inside v is the one that stays
@@ -381,6 +386,7 @@ __global__ __launch_bounds__(NT) void jpeg_finish_kernel(EntropyArgs a) {
     int32_t* act = a.act + (size_t)img * (R_MAX + 2);
     if (act[R_MAX]) {
         load_lds(L, a, c.d, tid, NT);
+        const McuTables mt = mcu_tables(c.d);
         for (int rnd = R_MAX + 1;; rnd++) {
             int active = 0;
             for (int u = tid; u < c.nsub; u += NT) {
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(NT) void jpeg_finish_kernel(EntropyArgs a) {
                 SubRange sr;
                 if (v > last || !sub_range(c, s, v, sr)) { c.cP[u] = 0xFFFFFFFFu; continue; }
                 int b = (int)(c.cS[u] & 255u), k = (int)(c.cS[u] >> 8);
-                const int nb = run_sub<false>(reinterpret_cast<const uint32_t*>(a.clean), nullptr, L, a.tables + c.d[D_HT], sr, c.bpm, P, b, k);
+                const int nb = run_sub<false>(reinterpret_cast<const uint32_t*>(a.clean), nullptr, L, a.tables + c.d[D_HT], mt, sr, c.bpm, P, b, k);
                 const uint32_t S = (uint32_t)b | ((uint32_t)k << 8);
                 c.sN[v] = nb;
                 if (c.sP[v] == P && c.sS[v] == S) c.cP[u] = 0xFFFFFFFFu;
@@ -451,8 +457,8 @@ __global__ __launch_bounds__(NW) void jpeg_coef_kernel(EntropyArgs a) {
     Reader<STAGED> r;
     if (STAGED) { stage(s_stage + tid, words, P, sr.endbits); r.seek(s_stage + tid, sr.seg_end, P); }
     else r.seek(words, sr.seg_end, P);
-    int tdc = L.tb_dc[b], tac = L.tb_ac[b];
-    while (r.position() < sr.endbits && nb < seg_nblk) nb += symbol<true>(r, L, a.tables + c.d[D_HT], b, k, tdc, tac, c.bpm, coefs + (size_t)nb * 64);
+    const McuTables mt = mcu_tables(c.d);
+    while (r.position() < sr.endbits && nb < seg_nblk) nb += symbol<true>(r, L, a.tables + c.d[D_HT], mt, b, k, c.bpm, coefs + (size_t)nb * 64);
 }
 
 // ---- DC prediction: running sum of the differences per component, in scan order, reset at restart intervals.  One workgroup per image

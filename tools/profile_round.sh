@@ -25,3 +25,20 @@ cp $(find /tmp/prof_$tag/eval -name "*kernel_stats.csv" | head -1) $out/${tag}_e
 python $root/tools/step_trace.py $(find /tmp/prof_$tag/eval -name "*kernel_trace.csv" | head -1) sam_stage2 -8 > $out/${tag}_eval_step_trace.txt
 tail -1 $out/${tag}_bench_line.txt | cut -c1-200
 tail -1 $out/${tag}_eval_line.txt | cut -c1-200
+# 4. the real-frame JPEG decode: kernel-trace summary of tools/bench_jpeg.py + one ab_jpeg_decode_batch call in launch order
+cd $root
+bash tools/trace_jpeg.sh > $out/${tag}_jpeg_call_trace.txt 2>&1
+cp $(find /tmp/pj3 -name "*kernel_trace.csv" | head -1) /tmp/pj3_trace.csv
+python - <<PY > $out/${tag}_jpeg_kernel_stats.csv
+import csv, collections
+rows = list(csv.DictReader(open('/tmp/pj3_trace.csv')))
+agg = collections.defaultdict(list)
+for r in rows:
+    if 'jpeg' in r['Kernel_Name']:
+        agg[r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0]].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+print('"Name","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs"')
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+    print(f'"{k}",{len(v)},{sum(v)},{sum(v) / len(v):.1f},{min(v)},{max(v)}')
+PY
+timeout 200 python tools/bench_jpeg.py --sub-bytes 128 2>&1 | tail -2 >> $out/${tag}_jpeg_call_trace.txt
+tail -3 $out/${tag}_jpeg_call_trace.txt
