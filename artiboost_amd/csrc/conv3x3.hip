@@ -9,6 +9,8 @@
 //
 // LDS image (both operands are lane-linear global_load_lds fills, so the swizzle sits on the source address):
 //   patch : pixel pp = py*(TW+2) + px at byte pp*128, logical chunk c stored at slot c ^ ((px >> 1) & 7)
+//           (TW = 8, where a ds_read_b128 lane group spans four patch rows: c ^ (((px >> 1) & 3) | ((py & 1) << 2)), row pitch TW + 3 --
+//           with the px-only mask every fragment read of that tile was a 2-way bank conflict: SQ_LDS_BANK_CONFLICT 0.33 of the LDS cycles)
 //   weight: row r (output channel) at byte r*128, logical chunk c at slot c ^ ((r >> 1) & 7)
 // Both are conflict-free for the 16-lane groups of ds_read_b128 (for TW = 16 two half-rows complement each other).
 #include "conv_common.h"
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NRING = 3;
     constexpr int PATCH0 = NRING * BBYTES;             // LDS: [weight ring x3][patch 0][patch 1][stats]
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WN, wave_n = wave % WN;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         int py = pp / PW, px = pp - py * PW;
         int y = ty0 + py - 1, x = tx0 + px - 1;
         p_ok[j] = (ii < PI) && (pp < NPIX) && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-        int c = (lane & 7) ^ ((px >> 1) & 7);
+        int c = (lane & 7) ^ (TW == 8 ? (((px >> 1) & 3) | ((py & 1) << 2)) : ((px >> 1) & 7));
         const bf16_t* plane = (X3 && (c & 4)) ? Xlo : X;
         if (X3) c &= 3;
         p_src[j] = p_ok[j] ? plane + ((((long)img * g.H + y) * g.W + x) * g.C + c * 8) : zp;
@@ -174,7 +176,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             int px = ox + d;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                a_rel[i][d][kk] = lds0 + PATCH0 + (oy * PW + px) * 128 + (((kk * 2 + fhalf) ^ ((px >> 1) & 7)) << 4);
+                a_rel[i][d][kk] = lds0 + PATCH0 + (oy * PW + px) * 128 +
+                                  (((kk * 2 + fhalf) ^ (TW == 8 ? (((px >> 1) & 3) | ((oy & 1) << 2)) : ((px >> 1) & 7))) << 4);      // TW = 8: tap row dh flips bit 6 below
         }
     }
 
@@ -238,6 +241,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             const int t3 = t / 3, tr = t % 3;
             const int dh = FLIP ? 2 - t3 : t3, dw = FLIP ? 2 - tr : tr;     // compile-time per unrolled tap
             const unsigned aoff = pbase + dh * PW * 128;
+            const unsigned aflip = (TW == 8 && (dh & 1)) ? 64u : 0u;      // the (py & 1) bit of the TW = 8 swizzle: patch row = oy + dh (bases are 128-byte aligned)
             if constexpr (X3) {
                 // slots kk = 0,1: hi k-slices (16 channels each), kk = 2,3: the lo planes of the same channels
                 u32x4 fa[4][TM], fb[4][TN];
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) fa[k2 + 2 * h][i] = *(const lds_u32x4*)(a_rel[i][dw][k2 + 2 * h] + aoff);
+                        for (int i = 0; i < TM; ++i) fa[k2 + 2 * h][i] = *(const lds_u32x4*)((a_rel[i][dw][k2 + 2 * h] ^ aflip) + aoff);
 #pragma unroll
                         for (int j = 0; j < TN; ++j) fb[k2 + 2 * h][j] = *(const lds_u32x4*)(b_rel[j][k2 + 2 * h] + (t % 3) * BBYTES);
                     }
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             } else {
             u32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *(const lds_u32x4*)(a_rel[i][dw][0] + aoff);
+            for (int i = 0; i < TM; ++i) fa[0][i] = *(const lds_u32x4*)((a_rel[i][dw][0] ^ aflip) + aoff);
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[0][j] = *(const lds_u32x4*)(b_rel[j][0] + (t % 3) * BBYTES);
 #pragma unroll
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
                 if (kk < 3) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        fa[(kk + 1) & 1][i] = *(const lds_u32x4*)(a_rel[i][dw][kk + 1] + aoff);
+                        fa[(kk + 1) & 1][i] = *(const lds_u32x4*)((a_rel[i][dw][kk + 1] ^ aflip) + aoff);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         fb[(kk + 1) & 1][j] = *(const lds_u32x4*)(b_rel[j][kk + 1] + (t % 3) * BBYTES);
