@@ -70,7 +70,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     // patch row pitch: TW + 2, or TW + 3 for TW = 8 so that consecutive patch rows alternate LDS half (pixel parity) --
     // a 16-lane fragment read then spans two image rows with the same px set and would otherwise hit the same banks
-    constexpr int TH = BM / TW, PW = (TW == 8) ? TW + 3 : TW + 2, PH = TH + 2;
+    // STACK (BM = 128 on TW = 8): the tile is TWO whole 8 x 8 images, handed over by the launch as one 16-row image (the same bytes); the
+    // patch holds each image with its own zero halo rows (2 x 10 rows), so no tap of one image reads the other.  Layer 4: a 128-pixel x
+    // 64-channel tile streams half the weight bytes per product of the 64 x 128 one at the same 256 workgroups (the launch waits on its
+    // L2 -> LDS weight stream: SQ_WAIT_ANY 0.61 of the wave cycles, tools/pmc_conv.sh).
+    constexpr bool STACK = (TW == 8 && BM == 128);
+    constexpr int TH = BM / TW, PW = (TW == 8) ? TW + 3 : TW + 2, PH = STACK ? TH + 4 : TH + 2;
     constexpr int NPIX = PH * PW;
     constexpr int PI = (NPIX + 7) / 8;                 // 1-KiB instructions per patch
     constexpr int LP = (PI + NW - 1) / NW;             // per wave
@@ -141,6 +146,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         int pp = ii * 8 + (lane >> 3);
         int py = pp / PW, px = pp - py * PW;
         int y = ty0 + py - 1, x = tx0 + px - 1;
+        if constexpr (STACK) { const int ps = py / 10, pr = py - ps * 10; y = (pr == 0 || pr == 9) ? -1 : ps * 8 + pr - 1; }
         p_ok[j] = (ii < PI) && (pp < NPIX) && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
         int c = (lane & 7) ^ (TW == 8 ? (((px >> 1) & 3) | ((py & 1) << 2)) : ((px >> 1) & 7));
         const bf16_t* plane = (X3 && (c & 4)) ? Xlo : X;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             int px = ox + d;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                a_rel[i][d][kk] = lds0 + PATCH0 + (oy * PW + px) * 128 +
+                a_rel[i][d][kk] = lds0 + PATCH0 + ((STACK ? oy + 2 * (oy >> 3) : oy) * PW + px) * 128 +
                                   (((kk * 2 + fhalf) ^ (TW == 8 ? (((px >> 1) & 3) | ((oy & 1) << 2)) : ((px >> 1) & 7))) << 4);      // TW = 8: tap row dh flips bit 6 below
         }
     }
@@ -554,7 +560,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
 template <int BM, int TW, int BN, int WM, int WN, int X3 = 0>
 static size_t c3_lds(int nchunks) {
     constexpr int NW = WM * WN;
-    constexpr int TH = BM / TW, NPIX = (TH + 2) * ((TW == 8) ? TW + 3 : TW + 2), PI = (NPIX + 7) / 8, LP = (PI + NW - 1) / NW;
+    constexpr int TH = BM / TW, NPIX = ((TW == 8 && BM == 128) ? TH + 4 : TH + 2) * ((TW == 8) ? TW + 3 : TW + 2), PI = (NPIX + 7) / 8, LP = (PI + NW - 1) / NW;
     size_t need = (size_t)(nchunks > 1 ? 2 : 1) * LP * NW * 1024 + 3 * BN * 128 + WM * BN * 8;
     size_t stage = ((size_t)BM * (BN * 2 + 16) + 15) / 16 * 16;      // epilogue staging tile
     stage += (size_t)(64 * NW / (BN / 8)) * BN * 8;                    // + fused BN-backward partials [NT/CPR][BN][2]
@@ -569,7 +575,7 @@ static size_t c3_lds(int nchunks) {
 // config choice: 0 = unsupported, 1 = <128,32,64,2,2>, 2 = <256,32,128,2,2>, 3 = <128,16,128,2,2>, 4 = <128,16,64,2,2>,
 // 5 = <64,8,128,2,2>
 // x3plain: a split-bf16 launch WITHOUT the fused BatchNorm-backward epilogue (forward, plain data gradient, eval-mode fold).
-static int c3_config(int N, int H, int W, int C, int Cn, bool x3plain = false) {
+static int c3_config(int N, int H, int W, int C, int Cn, bool x3plain = false, bool x3 = false) {
     if (C % 64 || Cn % 8 || getenv("AB_CONV3_OFF")) return 0;
     if (const char* f = getenv("AB_C3_FORCE")) return atoi(f);      // tile-shape probes (tools/bench_conv_x3.py, tools/ab_l1_tiles.py)
     if (W >= 24) {
@@ -591,7 +597,12 @@ static int c3_config(int N, int H, int W, int C, int Cn, bool x3plain = false) {
         if (alt && W <= 16 && H % 16 == 0 && Cn % 64 == 0) return 6;      // whole 16x16 image x 64 channels per workgroup
         return (Cn <= 64) ? 4 : 3;
     }
-    if (W >= 5 && W <= 8 && H <= 8 && Cn > 64) return 5;      // one whole (<= 8x8) image per workgroup
+    if (W >= 5 && W <= 8 && H <= 8 && Cn > 64) {
+        // bf16x3, 8 x 8 maps (layer 4): two images x 64 channels per workgroup (8) instead of one image x 128 channels (5).  AB_C3_STACK=0: off
+        static const int stack = getenv("AB_C3_STACK") ? atoi(getenv("AB_C3_STACK")) : 1;
+        if (x3 && stack && H == 8 && W == 8 && N % 2 == 0 && Cn % 64 == 0) return 8;
+        return 5;      // one whole (<= 8x8) image per workgroup
+    }
     return 0;
 }
 static void c3_geom(int cfg, int* bm, int* tw, int* bn) {
@@ -601,6 +612,7 @@ static void c3_geom(int cfg, int* bm, int* tw, int* bn) {
     else if (cfg == 5) { *bm = 64; *tw = 8; *bn = 128; }
     else if (cfg == 6) { *bm = 256; *tw = 16; *bn = 64; }
     else if (cfg == 7) { *bm = 256; *tw = 32; *bn = 64; }
+    else if (cfg == 8) { *bm = 128; *tw = 8; *bn = 64; }
     else { *bm = 128; *tw = 16; *bn = 64; }
 }
 
@@ -616,6 +628,7 @@ int conv3x3_tiles(int N, int H, int W, int C, int Cn) {
 template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0>
 static int c3_launch(Conv3Args& g, hipStream_t st) {
     constexpr int TH = BM / TW;
+    if constexpr (TW == 8 && BM == 128) { g.N /= 2; g.H = 16; }        // two 8 x 8 images as one 16-row image: the same bytes
     g.tiles_x = (g.W + TW - 1) / TW; g.tiles_y = (g.H + TH - 1) / TH;
     int blocks = g.N * g.tiles_x * g.tiles_y * ((g.Cn + BN - 1) / BN);
     size_t lds = c3_lds<BM, TW, BN, WM, WN, X3>(g.C / (X3 ? 32 : 64));
@@ -677,6 +690,7 @@ int conv3x3_run(const void* x, const void* wt, void* out, int N, int H, int W, i
 // Tile shapes are those of the bf16 path, always on 8 waves (the accumulators of both chains need the registers).
 static int c3_tiles_of(int cfg, int N, int H, int W) {
     if (!cfg) return 0;
+    if (cfg == 8) return N / 2;                    // two stacked 8 x 8 images per tile
     int bm, tw, bn; c3_geom(cfg, &bm, &tw, &bn);
     int th = bm / tw;
     return N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
@@ -685,11 +699,11 @@ static int c3_tiles_of(int cfg, int N, int H, int W) {
 // BatchNorm partial rows of the split-bf16 launches: of a forward / plain launch, and of a data gradient with the fused reduction
 int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn) {
     if (C % 32) return 0;
-    return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, true), N, H, W);
+    return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, true, true), N, H, W);
 }
 int conv3x3_x3_tiles_bnr(int N, int H, int W, int C, int Cn) {
     if (C % 32) return 0;
-    return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, false), N, H, W);
+    return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, false, true), N, H, W);
 }
 
 struct C3EvalBn { void* out_hi; void* out_lo; float* out_f32; const void* res_hi; const void* res_lo; int relu; };
@@ -700,7 +714,7 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
     if (C % 32) return AB_ESHAPE;
     if (bn_y && (!flip || stats || !bnp || !bn_part)) return AB_EINVAL;
     if (ev && (flip || stats || bn_y || !bnp || !ev->out_hi || !ev->out_lo || (ev->res_hi && (addend || !ev->res_lo)))) return AB_EINVAL;
-    int cfg = c3_config(N, H, W, (C + 63) / 64 * 64, Cn, /*x3plain=*/!bn_y);
+    int cfg = c3_config(N, H, W, (C + 63) / 64 * 64, Cn, /*x3plain=*/!bn_y, /*x3=*/true);
     if (!cfg || Cn % 4) return AB_ESHAPE;
     const long delta = (const char*)wt_lo - (const char*)wt_hi;
     if (delta < 0 || delta >= (1L << 31)) return AB_EINVAL;       // the lo plane is addressed as a 32-bit offset from the hi plane
@@ -716,6 +730,7 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
         if (cfg == 5) return c3_launch<64, 8, 128, 2, 4, 1, 2>(g, st);
         if (cfg == 6) return c3_launch<256, 16, 64, 4, 2, 1, 2>(g, st);
         if (cfg == 7) return c3_launch<256, 32, 64, 4, 2, 1, 2>(g, st);
+        if (cfg == 8) return c3_launch<128, 8, 64, 4, 2, 1, 2>(g, st);
         return c3_launch<128, 16, 64, 4, 2, 1, 2>(g, st);
     }
     if (g.Out_lo) {      // eval-mode forward with the following BatchNorm folded in (conv3x3_x3_evalbn_run fills these fields)
@@ -725,6 +740,7 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
         if (cfg == 5) return c3_launch<64, 8, 128, 2, 4, 0, 3>(g, st);
         if (cfg == 6) return c3_launch<256, 16, 64, 4, 2, 0, 3>(g, st);
         if (cfg == 7) return c3_launch<256, 32, 64, 4, 2, 0, 3>(g, st);
+        if (cfg == 8) return c3_launch<128, 8, 64, 4, 2, 0, 3>(g, st);
         return c3_launch<128, 16, 64, 4, 2, 0, 3>(g, st);
     }
 #define C3X_GO(FL) \
@@ -735,6 +751,7 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
         if (cfg == 5) return c3_launch<64, 8, 128, 2, 4, FL, 1>(g, st); \
         if (cfg == 6) return c3_launch<256, 16, 64, 4, 2, FL, 1>(g, st); \
         if (cfg == 7) return c3_launch<256, 32, 64, 4, 2, FL, 1>(g, st); \
+        if (cfg == 8) return c3_launch<128, 8, 64, 4, 2, FL, 1>(g, st); \
         return c3_launch<128, 16, 64, 4, 2, FL, 1>(g, st); \
     } while (0)
     if (flip) C3X_GO(1);
