@@ -698,7 +698,8 @@ class HybridNet:
     # Weight gradients are off the critical path (nothing consumes them before the optimizer), so they CAN be issued on
     # a side stream to co-run with the HBM-bound BatchNorm-backward passes of the layers below.  Measured on MI355X
     # (B=64, 256x256, graph replay): 7366 samples/s with the side stream vs 7715 without -- co-scheduled workgroups evict
-    # each other's L2 / LDS residency and the single-queue order is faster.  Kept as an opt-in (AB_WGRAD_OVERLAP=1).
+    # each other's L2 / LDS residency and the single-queue order is faster.  Round 3, bf16x3 (tools/ab_env.sh AB_WGRAD_OVERLAP 0 1 2):
+    # 9.68 ms/step in one queue, 9.84 / 10.01 with the side stream.  Kept as an opt-in (AB_WGRAD_OVERLAP=1).
     overlap_wgrad = os.environ.get("AB_WGRAD_OVERLAP", "0") == "1"
     fuse_stem = os.environ.get("AB_STEM_FUSE", "1") != "0"       # stem BN+ReLU+max-pool as one pass (forward)
     fuse_stem_bwd = os.environ.get("AB_STEM_FUSE_BWD", "0") == "1"   # ... and the gather-based fused backward
