@@ -250,12 +250,12 @@ def conv_kernel_time_ms(ts, loader, static, iters=3):
             return r
         return f
 
-    total = 0.0
+    totals = []
     try:
         for n in names:
             setattr(K, n, wrap(orig[n]))
-        for it in range(iters):
-            spans.clear()
+        for it in range(iters + 1):          # iteration 0 is not counted: the first eager step allocates its activations (slow hipMallocs
+            spans.clear()                    # can outlast the spin below, and the spans would then hold launch latency)
             loader.load_batch(static, it % max(len(loader), 1))
             ts.crit.draw(ts.dev)
             # park the stream behind a long spin so that the whole eager step is ENQUEUED before any of it runs: the
@@ -269,12 +269,13 @@ def conv_kernel_time_ms(ts, loader, static, iters=3):
                 empties.append((e0, e1))
             torch.cuda.synchronize()
             empty_ms = sorted(a.elapsed_time(b) for a, b in empties)[len(empties) // 2]
-            total += sum(max(a.elapsed_time(b) - empty_ms, 0.0) for a, b in spans)
+            if it:
+                totals.append(sum(max(a.elapsed_time(b) - empty_ms, 0.0) for a, b in spans))
             nl = len(spans)
     finally:
         for n in names:
             setattr(K, n, orig[n])
-    return total / iters, nl
+    return sorted(totals)[len(totals) // 2], nl          # median of the counted iterations
 
 
 def pmc_traffic(args):
@@ -424,11 +425,11 @@ def eval_forward(args, model, static, steps=30, warmup=5, want_roofline=True):
                         spans.append((e0, e1))
                         return r
                     return f
-                tot = 0.0
+                tots = []
                 try:
                     for n in names:
                         setattr(K, n, wrap(orig[n]))
-                    for _ in range(3):
+                    for it in range(4):          # iteration 0 not counted (first-use allocations), median of the other three
                         spans.clear()
                         torch.cuda._sleep(60_000_000)
                         model(batch)
@@ -438,12 +439,13 @@ def eval_forward(args, model, static, steps=30, warmup=5, want_roofline=True):
                             e0.record(); e1.record(); empties.append((e0, e1))
                         torch.cuda.synchronize()
                         em = sorted(a.elapsed_time(b) for a, b in empties)[8]
-                        tot += sum(max(a.elapsed_time(b) - em, 0.0) for a, b in spans)
+                        if it:
+                            tots.append(sum(max(a.elapsed_time(b) - em, 0.0) for a, b in spans))
                         nl = len(spans)
                 finally:
                     for n in names:
                         setattr(K, n, orig[n])
-                conv_ms = tot / 3
+                conv_ms = sorted(tots)[1]
                 fl = GFLOP_FWD_PER_SAMPLE.get(args.size, 10.698) * 1e9 * args.bs
                 ach = fl / (conv_ms * 1e-3) / 1e12
                 res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
