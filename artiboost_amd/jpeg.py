@@ -23,7 +23,17 @@ class JpegInfo:
 
 def parse(data) -> JpegInfo:
     """Marker walk up to the start of scan (ITU T.81 B.2): frame / scan headers, DQT, DHT, DRI, then the extent of the entropy-coded
-    data and, with a restart interval, of each interval."""
+    data and, with a restart interval, of each interval.  Anything the kernels do not cover, and any malformed / truncated header, raises
+    JpegUnsupported."""
+    try:
+        return _parse(data)
+    except (IndexError, ValueError) as e:
+        if isinstance(e, JpegUnsupported):
+            raise
+        raise JpegUnsupported(f"malformed JPEG header: {e}") from None
+
+
+def _parse(data) -> JpegInfo:
     mv = memoryview(data)
     n = len(mv)
     if n < 4 or mv[0] != 0xFF or mv[1] != 0xD8:
@@ -178,6 +188,8 @@ class _Plan:
             seg_off += len(sg)
             self.max_blocks, self.max_w, self.max_h = max(self.max_blocks, nblk), max(self.max_w, it.width), max(self.max_h, it.height)
             self.max_sub = max(self.max_sub, int(nsub.sum()))
+        if data_off * 8 >= 1 << 32 or blk_base * 64 >= 1 << 31:
+            raise ValueError("batch too large for 32-bit bit positions / coefficient offsets: decode it in smaller batches")
         self.n, self.sub_bytes = n, sub_bytes
         self.total_blocks, self.total_sub, self.plane_bytes, self.data_bytes = blk_base, sub_base, plane_base, data_off
         self.desc, self.segs = desc, np.concatenate(segs).astype(np.int32)
