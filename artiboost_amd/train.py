@@ -52,14 +52,18 @@ class TrainStep:
         self.g_fwd_bwd = None
         self.g_opt = None
         self._fake_comm = os.environ.get("AB_FAKE_COMM") == "1"     # timing probe: the DDP stream choreography without RCCL
-        self.comm_stream = torch.cuda.Stream(device=self.dev) if (self.world > 1 or self._fake_comm) else None
+        # AB_DDP_SINGLE_RANK=1 with a process group of ONE rank: the whole multi-rank schedule (three backward graphs, bucketed
+        # ReduceOp.AVG all-reduces on the comm stream, post-all-reduce clip) with the real collective -- what a 1-GPU box can execute
+        # of the RCCL path (tests/test_gpu_bench.py::test_rccl_single_rank_schedule)
+        self.comm = self.world > 1 or (dist_group is not None and os.environ.get("AB_DDP_SINGLE_RANK") == "1")
+        self.comm_stream = torch.cuda.Stream(device=self.dev) if (self.comm or self._fake_comm) else None
         self.steps = 0
         # DDP overlap: the backward is captured as three graphs (heads + layer4 | layer3 | layer2 .. stem).  The first
         # stage produces 68 % of the gradient bytes, the second 27 %; each range is all-reduced on the comm stream while
         # the next stage computes, so only the last 5 MB are exposed.  AB_DDP_SPLIT=1 forces the split on one GPU
         # (tests), =0 disables it.
         env = os.environ.get("AB_DDP_SPLIT", "")
-        self.split = bool(use_graph and fused_criterion and (self.world > 1 or env == "1") and env != "0")   # (cleared below
+        self.split = bool(use_graph and fused_criterion and (self.comm or env == "1") and env != "0")   # (cleared below
         #                                                                                            if the criterion is not fusable)
         self.g_bwd_rest = []
         # Render/learn pipelining (the reference overlaps them through DataLoader worker processes,
@@ -242,7 +246,7 @@ class TrainStep:
         with torch.cuda.stream(s):          # warm-up on a side stream (allocator, lazy state) before capture
             self.crit.freeze_draws(True)
             self._fwd_bwd()
-            if self.world > 1:                 # the warm-up is a real optimizer step: it must see the averaged gradient too
+            if self.comm:                      # the warm-up is a real optimizer step: it must see the averaged gradient too
                 self._allreduce()
             self._optim()
         torch.cuda.current_stream(self.dev).wait_stream(s)
@@ -313,7 +317,7 @@ class TrainStep:
                 self.render_stream.wait_stream(cur)
                 with torch.cuda.stream(self.render_stream):
                     self._render_next()
-            if self.world > 1:
+            if self.comm:
                 self._allreduce()
             self._optim()
             if self.pipeline_opt:
@@ -327,7 +331,7 @@ class TrainStep:
             self.hb.store.num_batches_tracked += 1           # the replayed forward is a training-mode BatchNorm forward
             if self.split:
                 ranges = self.hb.net.grad_stage_ranges()
-                comm = self.world > 1 or self._fake_comm
+                comm = self.comm or self._fake_comm
                 if comm:
                     self._allreduce_range(*ranges[0])
                 for g, rng in zip(self.g_bwd_rest, ranges[1:]):
@@ -339,7 +343,7 @@ class TrainStep:
                     torch.cuda.current_stream(self.dev).wait_stream(self.comm_stream)
             else:
                 self._launch_render_next()
-                if self.world > 1:
+                if self.comm:
                     self._allreduce()
             self.g_opt.replay()
             if self.pipeline_opt:

@@ -68,11 +68,11 @@ def build_everything(args, rank, world, device, wgrad_1pass=False):
     loader.prepare()
     static = loader.new_static_batch()
     loader.load_batch(static, 0)
-    group = torch.distributed.group.WORLD if world > 1 else None
+    group = torch.distributed.group.WORLD if (world > 1 or getattr(args, "rccl_single_rank", False)) else None
     model.train()
     # N > 1: the north-star schedule -- batch t+1 is rendered on a second stream while step t's last gradient range is
     # all-reduced and its clip + Adam runs (on one GPU that concurrency measured slower than the single queue, so it stays off)
-    overlap = args.pipeline_opt or (world > 1 and not args.no_render_overlap)
+    overlap = args.pipeline_opt or ((world > 1 or getattr(args, "rccl_single_rank", False)) and not args.no_render_overlap)
     ts = TrainStep(model, crit, opt, static, use_graph=not args.eager, dist_group=group, renderer=loader,
                    pipeline_render=("opt" if overlap else args.pipeline))
     args.render_overlap = bool(overlap)
@@ -606,6 +606,9 @@ def main():
                     help="seconds of the sustained block run after the timed steps (extra keys of the line; 0 = off)")
     ap.add_argument("--no-eval-leg", action="store_true", help="skip the configs[1] eval-forward sub-object of the default line")
     ap.add_argument("--no-dexycb-leg", action="store_true", help="skip the configs[4]-on-one-GPU sub-object of the default line")
+    ap.add_argument("--rccl-single-rank", action="store_true",
+                    help="N = 1 only: run the multi-rank schedule (three backward graphs, ReduceOp.AVG all-reduces on the comm stream, render "
+                         "overlap) over a ONE-rank RCCL group -- the part of the RCCL path a 1-GPU box can execute; not the headline")
     ap.add_argument("--no-jpeg-leg", action="store_true", help="skip the real-frame JPEG decode sub-object of the default line")
     ap.add_argument("--no-study-leg", action="store_true", help="skip the one-pass weight-gradient study sub-object of the default line")
     ap.add_argument("--wgrad-1pass", action="store_true",
@@ -667,6 +670,18 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
+    if args.rccl_single_rank:
+        if world != 1:
+            raise SystemExit("bench.py: --rccl-single-rank is an N = 1 mode")
+        import socket
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ["AB_DDP_SINGLE_RANK"] = "1"
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                             device_id=torch.device(device))
+        args.no_eval_leg = args.no_dexycb_leg = args.no_study_leg = args.no_jpeg_leg = args.no_cpu_baseline = True
     cfg, model, crit, opt, loader, ts, static = build_everything(args, rank, world, device)
 
     def barrier():
@@ -774,7 +789,8 @@ def main():
                "data": "synthetic (seeded stand-in meshes/textures/grasps; random-init weights)",
                "config": {"workload": f"train_artiboost HO3Dv2-clasbased (HybridBaseline/ResNet-34, 22x28x{args.size // 8}x{args.size // 8} heat-map) "
                                       f"+ online CCV render 512->{args.size}, per-GPU batch {args.bs}, {args.dataset}-like objects",
-                          "global_batch": args.bs * world, "image": args.size, "parallelism": f"dp{world}",
+                          "global_batch": args.bs * world, "image": args.size,
+                          "parallelism": f"dp{world}" + ("+multi_rank_schedule_over_one_rank_rccl" if args.rccl_single_rank else ""),
                           "graph": not args.eager, "shared_devices": bool(shared),
                           "render_overlap": bool(getattr(args, "render_overlap", False))},
                "final_loss": losses[5] if losses else None,
@@ -788,6 +804,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
+    if world > 1 or args.rccl_single_rank:
         torch.distributed.destroy_process_group()
 
 

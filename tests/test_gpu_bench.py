@@ -60,3 +60,38 @@ def test_dropin_loop_without_segment_graphs_stays_device_bound():
     assert line["segment_graphs"] is False and line["batch"] == 64 and line["size"] == 256
     assert line["ms_per_step"] <= 12.5, line
     assert 0 < line["final_loss"] < 1.0
+
+
+
+def test_rccl_single_rank_schedule():
+    """What a 1-GPU box can execute of the RCCL path: tools/ddp_smoke.py under torch.distributed.run with ONE rank and
+    AB_DDP_SINGLE_RANK=1 -- init_process_group("nccl") on the device, the three-graph backward with bucketed ReduceOp.AVG all-reduces on
+    the comm stream, the render of the next batch under the last range, post-all-reduce clip + Adam.  An average over one rank is the
+    identity, so five steps must end in bit-identical weights to the same schedule with the collective replaced by a touch of the same
+    bytes (AB_FAKE_COMM=1)."""
+    import re
+    import subprocess
+    import sys
+    outs = []
+    for i, extra in enumerate(({"AB_DDP_SINGLE_RANK": "1"}, {"AB_FAKE_COMM": "1", "AB_DDP_SPLIT": "1"})):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                            "--master-port", str(29541 + i), os.path.join(ROOT, "tools", "ddp_smoke.py")], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("backend=")][-1]
+        outs.append(line)
+    assert "backend=nccl world=1" in outs[0] and "comm=True" in outs[0] and "comm=False" in outs[1], outs
+    key = lambda l: re.search(r"final_loss=(\S+) weight_sum=(\S+)", l).groups()      # noqa: E731
+    assert key(outs[0]) == key(outs[1]), outs
+
+
+def test_bench_rccl_single_rank_mode():
+    """`bench.py --rccl-single-rank`: init_process_group("nccl", device_id=...) exactly as the N > 1 launch does it, the multi-rank
+    schedule with the real collective over one rank, one JSON line that says so."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl-single-rank", "--steps", "3", "--warmup", "2", "--sustain", "0"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"].endswith("one_rank_rccl") and d["config"]["render_overlap"] is True
+    assert d["value"] > 0 and d["final_loss"] == d["final_loss"] and d["roofline"]["frac"] > 0

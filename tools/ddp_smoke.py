@@ -2,7 +2,9 @@
    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/ddp_smoke.py
 Checks: the split-graph + side-stream all-reduce path runs -- by default with the north-star schedule (the render of batch
 t+1 on a second stream under the last all-reduce range and the optimizer; AB_DDP_OVERLAP=0 turns it off) in the benchmarked
-precision (AB_DDP_DTYPE, default bf16x3) -- losses are finite, and the ranks hold identical weights."""
+precision (AB_DDP_DTYPE, default bf16x3) -- losses are finite, and the ranks hold identical weights.
+With --nproc-per-node 1 and AB_DDP_SINGLE_RANK=1 the same schedule runs with a ONE-rank RCCL group: the real init_process_group("nccl"),
+bucketed ReduceOp.AVG all-reduces on the comm stream between the backward graphs -- what a 1-GPU box can execute of the RCCL path."""
 import os, sys
 import torch
 import torch.distributed as dist
@@ -17,6 +19,9 @@ from artiboost_amd.synth import ArtiBoostLoader
 from artiboost_amd.train import TrainStep
 
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+import random
+import numpy as np
+random.seed(100 + rank); np.random.seed(100 + rank); torch.manual_seed(100 + rank)      # the ordinal losses draw their pairs from these
 ngpu = torch.cuda.device_count()
 dev = f"cuda:{rank % ngpu}"
 torch.cuda.set_device(dev)
@@ -53,6 +58,7 @@ ws = [torch.empty_like(w) for _ in range(world)]
 dist.all_gather(ws, w)
 same = all(torch.equal(ws[0], x) for x in ws)
 if rank == 0:
-    print(f"backend={backend} world={world} dtype={dtype} render_overlap={overlap} final_loss={float(losses[5]):.5f} weights_identical_across_ranks={same}")
+    print(f"backend={backend} world={world} dtype={dtype} render_overlap={overlap} comm={ts.comm} final_loss={float(losses[5]):.9f} "
+          f"weight_sum={float(w.double().sum()):.12f} weights_identical_across_ranks={same}")
 assert same
 dist.destroy_process_group()
