@@ -136,6 +136,19 @@ class RealBatcher:
         self._ws = None
         self._pin, self._pin_i = None, 0
         self._jpeg = None               # jpeg.JpegDecoder, created with the first batch of file bytes
+        self._jpeg_cache, self._jpeg_tables = {}, {}
+
+    def _jpeg_info(self, idx, data, parse):
+        """parse(data), remembered per frame index (a dataset re-reads the same files every epoch); the quantisation / Huffman tables of
+        the entries are shared between frames that carry the same ones."""
+        hit = self._jpeg_cache.get(idx)
+        if hit is not None and hit[0] == len(data):
+            return hit[1]
+        it = parse(data)
+        it.qt = self._jpeg_tables.setdefault(it.qt.tobytes(), it.qt)
+        it.ht = self._jpeg_tables.setdefault(it.ht.tobytes(), it.ht)
+        self._jpeg_cache[idx] = (len(data), it)
+        return it
 
     def draw(self, n):
         """One set of augmentation draws per sample (hodata.py:346-359,435-442: ranges hard-coded at hodata.py:107-112)."""
@@ -158,8 +171,8 @@ class RealBatcher:
         if getattr(self.src, "get_image_bytes", None) is not None:
             from .jpeg import JpegUnsupported, parse
             files = [self.src.get_image_bytes(idx) for idx in idxs]
-            try:                                                   # header walk only (15 us per file); the decode runs in augment()
-                infos = None if any(f is None for f in files) else [parse(f) for f in files]
+            try:                                                   # header walk only (15 - 30 us per file, once per frame: cached); the decode runs in augment()
+                infos = None if any(f is None for f in files) else [self._jpeg_info(idx, f, parse) for idx, f in zip(idxs, files)]
             except JpegUnsupported:
                 infos = None
             if infos is not None and any((it.width, it.height) != (W, H) for it in infos):

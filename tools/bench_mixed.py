@@ -48,6 +48,46 @@ class MemorySource(HOdataSource):
         return self.ann[idx]
 
 
+class JpegFileSource(MemorySource):
+    """The same split as .jpg FILES in memory (what a dataset's disk cache holds): get_image decodes with Pillow on the host (the reference's
+    path), get_image_bytes hands the file to the device decoder."""
+
+    def __init__(self, n=256, seed=0, device_decode=True):
+        import io
+        from PIL import Image
+        from bench_jpeg import _photo
+        super().__init__(n, seed)
+        self.files = []
+        for i in range(16):
+            b = io.BytesIO()
+            Image.fromarray(_photo(640, 480, i)).save(b, "JPEG", quality=92, subsampling=2)
+            self.files.append(b.getvalue())
+        if not device_decode:
+            self.get_image_bytes = None
+
+    def get_image(self, idx):
+        import io
+        from PIL import Image
+        return np.asarray(Image.open(io.BytesIO(self.files[idx % 16])).convert("RGB"))
+
+    def get_image_bytes(self, idx):
+        return self.files[idx % 16]
+
+
+def jpeg_compare(cfg):
+    """40 real frames per batch from .jpg files: decode on the device vs Pillow on this host (one thread, as one DataLoader worker)."""
+    for dev_dec in (True, False):
+        src = JpegFileSource(n=1024, device_decode=dev_dec)
+        real = RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.bfloat16)
+        idxs = list(range(40))
+        real.batch(idxs); torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(10):
+            real.batch(idxs)
+        torch.cuda.synchronize()
+        print(f".jpg files, decode on the {'device (ab_jpeg_decode_batch)' if dev_dec else 'host (Pillow, 1 thread)'}: "
+              f"{(time.time() - t0) / 10 * 1e3:.2f} ms per batch of 40 real frames (GT assembly + decode + ab_augment_batch)")
+
+
 def main():
     cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
     cfg["DATA_PRESET"]["IMAGE_SIZE"] = [256, 256]
@@ -73,6 +113,8 @@ def main():
         n += 1
     torch.cuda.synchronize()
     print(f"MixedLoader: {(time.time() - t0) / max(n, 1) * 1e3:.2f} ms per mixed batch ({n} batches)")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    jpeg_compare(cfg)
 
 
 if __name__ == "__main__":
