@@ -308,3 +308,44 @@ class MixedLoader:
                 sv = static[k]
                 out[k] = torch.cat([v, sv.to(v.dtype) if sv.dtype != v.dtype else sv])
             yield out
+
+
+class StreamPrefetcher:
+    """Iterates a device-batch loader (MixedLoader, or anything that yields dicts of device tensors) ONE BATCH AHEAD on its own HIP stream:
+    while the training step of batch i runs on the caller's stream, batch i + 1 is decoded (ab_jpeg_decode_batch), augmented, rendered and
+    concatenated on the side stream -- the role of the reference's DataLoader worker processes (train_artiboost.py: num_workers), without
+    processes.  The batches are the loader's own, in its order (same draws, same bytes); a batch is handed over with a stream wait and
+    `record_stream`, so the caching allocator does not recycle its memory while the consumer reads it."""
+
+    def __init__(self, loader, device=None):
+        self.loader = loader
+        self.dev = torch.device(device) if device is not None else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        dev = self.dev
+        side = None
+        nxt = None
+
+        def produce():
+            nonlocal side, dev
+            if side is None:
+                dev = dev or torch.device("cuda", torch.cuda.current_device())
+                side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))      # the previous batch's buffers may be freed by the consumer's stream
+            with torch.cuda.stream(side):
+                return next(it, None)
+
+        nxt = produce()
+        while nxt is not None:
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_stream(side)
+            batch = nxt
+            for v in batch.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)
+            nxt = produce()
+            yield batch

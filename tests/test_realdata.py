@@ -263,3 +263,39 @@ def test_graph_replayed_training_step_over_mixed_batches(dtype):
     np.testing.assert_array_equal(wg, wg2)
     np.testing.assert_array_equal(lg, le)             # the capture warm-up leaves no trace: graph == eager
     np.testing.assert_array_equal(wg, we)
+
+
+@pytest.mark.gpu
+def test_stream_prefetcher_yields_the_loaders_batches():
+    """StreamPrefetcher (next batch decoded / augmented / rendered on a side stream while the current one is consumed) hands over exactly the
+    batches MixedLoader yields on its own, .jpg frames decoded on the device included; consumer work between batches does not disturb them."""
+    pytest.importorskip("PIL")
+    import yaml
+    from test_gpu_synth import _loader
+    from artiboost_amd.realdata import MixedLoader, RealBatcher, StreamPrefetcher
+    from artiboost_amd.synth import ArtiBoostLoader
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    B, size = 8, 64
+
+    def make():
+        src = JpegSource()
+        assets, proto = _loader(size=size)
+        cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+        cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [size, size], [size // 8, size // 8]
+        n_synth = MixedLoader.n_synth_for(B, len(src), proto.synth_len)
+        synth = ArtiBoostLoader.from_assets(assets, proto.cfg, cfg["DATA_PRESET"], n_synth, proto.synth_len, compute_dtype=torch.float32, random_seed=3)
+        synth.prepare()
+        return MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.float32, seed=2), synth, B, seed=4)
+
+    plain = [{k: v.clone() for k, v in b.items()} for b in make()]
+    got = []
+    junk = torch.randn(2048, 2048, device="cuda")
+    for b in StreamPrefetcher(make()):
+        junk = junk @ junk * 1e-3                       # the consumer's own work on the main stream while the next batch is produced
+        got.append({k: v.clone() for k, v in b.items()})
+    torch.cuda.synchronize()
+    assert len(got) == len(plain) >= 2
+    for a, b in zip(plain, got):
+        assert a.keys() == b.keys()
+        for k in a:
+            torch.testing.assert_close(a[k], b[k], rtol=0, atol=0, msg=k)

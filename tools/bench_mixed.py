@@ -88,6 +88,54 @@ def jpeg_compare(cfg):
               f"{(time.time() - t0) / 10 * 1e3:.2f} ms per batch of 40 real frames (GT assembly + decode + ab_augment_batch)")
 
 
+def train_loop(cfg, steps=30):
+    """The training step (hipGraph replay, bf16x3, B = 64, 256 x 256) over MixedLoader batches -- 40 real frames served as .jpg files and
+    decoded on the device + 24 synthetic samples rendered per batch -- with the batch assembly on the step's own stream, and one batch
+    ahead on a side stream (realdata.StreamPrefetcher)."""
+    import random
+    from artiboost_amd import registry as R
+    from artiboost_amd.criterions import Criterion
+    from artiboost_amd.models import Arch
+    from artiboost_amd.optim import FusedClipAdam
+    from artiboost_amd.realdata import StreamPrefetcher
+    from artiboost_amd.train import TrainStep
+    B = 64
+    res = {}
+    for mode in ("same stream", "side stream, one batch ahead"):
+        random.seed(5); torch.manual_seed(5); np.random.seed(5)
+        src = JpegFileSource(n=4096)
+        synth_len = int(0.6 * len(src))
+        n_synth = MixedLoader.n_synth_for(B, len(src), synth_len)
+        synth = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], n_synth, synth_len, compute_dtype=torch.float32)
+        synth.prepare()
+        ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.float32), synth, B)
+        arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16x3", INIT_SEED=3)
+        model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
+        crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+        hb = model.model_list[0]
+        opt = FusedClipAdam(model.models_params, lr=5e-5, max_norm=0.001, model=hb)
+        model.train()
+        loader = ml if mode == "same stream" else StreamPrefetcher(ml)
+        it = iter(loader)
+        first = next(it)
+        ts = TrainStep(model, crit, opt, {k: v.clone() for k, v in first.items()}, use_graph=True, renderer=None)
+        for _ in range(3):
+            ts(next(it))
+        torch.cuda.synchronize()
+        t0 = time.time()
+        n = 0
+        for b in it:
+            _, losses, _ = ts(b)
+            n += 1
+            if n == steps:
+                break
+        torch.cuda.synchronize()
+        res[mode] = (time.time() - t0) / n * 1e3
+        print(f"training over mixed batches (40 real .jpg frames decoded on the device + 24 synthetic, bf16x3), batch assembly on the {mode}: "
+              f"{res[mode]:.2f} ms per step ({n} steps), final loss {float(losses[5]):.5f}")
+    return res
+
+
 def main():
     cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
     cfg["DATA_PRESET"]["IMAGE_SIZE"] = [256, 256]
@@ -115,6 +163,7 @@ def main():
     print(f"MixedLoader: {(time.time() - t0) / max(n, 1) * 1e3:.2f} ms per mixed batch ({n} batches)")
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     jpeg_compare(cfg)
+    train_loop(cfg)
 
 
 if __name__ == "__main__":
