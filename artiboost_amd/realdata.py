@@ -137,6 +137,34 @@ class RealBatcher:
         self._pin, self._pin_i = None, 0
         self._jpeg = None               # jpeg.JpegDecoder, created with the first batch of file bytes
         self._jpeg_cache, self._jpeg_tables = {}, {}
+        self._predecoded = {}           # frames of upcoming batches decoded together: predecode()
+
+    def predecode(self, idx_lists):
+        """Decode the .jpg files of SEVERAL upcoming batches in one ab_jpeg_decode_batch call (its time is set by the longest Huffman chain,
+        nearly independent of the number of frames up to a few hundred: DESIGN 12.4); augment() then takes a batch's frames from here.
+        Does nothing when the source has no file bytes or a file is not covered (those batches decode as before)."""
+        if getattr(self.src, "get_image_bytes", None) is None:
+            return
+        from .jpeg import JpegDecoder, JpegUnsupported, parse
+        flat = [int(i) for idxs in idx_lists for i in idxs]
+        files = [self.src.get_image_bytes(i) for i in flat]
+        W, H = self.src.raw_size
+        try:
+            if any(f is None for f in files):
+                return
+            infos = [self._jpeg_info(i, f, parse) for i, f in zip(flat, files)]
+        except JpegUnsupported:
+            return
+        if any((it.width, it.height) != (W, H) for it in infos):
+            return
+        if self._jpeg is None:
+            self._jpeg = JpegDecoder(self.dev)
+        frames = torch.empty((len(flat), H, W, 4), dtype=torch.uint8, device=self.dev)
+        self._jpeg.decode(files, out=frames, infos=infos)
+        o = 0
+        for idxs in idx_lists:
+            self._predecoded[tuple(int(i) for i in idxs)] = frames[o:o + len(idxs)]
+            o += len(idxs)
 
     def _jpeg_info(self, idx, data, parse):
         """parse(data), remembered per frame index (a dataset re-reads the same files every epoch); the quantisation / Huffman tables of
@@ -217,7 +245,10 @@ class RealBatcher:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         if out_pad is None and out_chw is None:
             out_chw = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=self.dev)
-        if host.get("files") is not None:                          # the .jpg files themselves: Huffman decode .. RGBX on the device
+        pre = self._predecoded.pop(tuple(int(i) for i in host["idxs"]), None) if self._predecoded else None
+        if pre is not None:
+            frames = pre
+        elif host.get("files") is not None:                        # the .jpg files themselves: Huffman decode .. RGBX on the device
             if self._jpeg is None:
                 from .jpeg import JpegDecoder
                 self._jpeg = JpegDecoder(self.dev)
@@ -266,8 +297,11 @@ class MixedLoader:
     real set is sharded like a DistributedSampler (shared permutation, rank r takes perm[r::world]); the synthetic loader
     shards its own epoch the same way."""
 
-    def __init__(self, real: RealBatcher, synth_loader, batch_size, seed=1, rank=0, world_size=1):
+    def __init__(self, real: RealBatcher, synth_loader, batch_size, seed=1, rank=0, world_size=1, decode_group=4):
         self.real, self.synth, self.B = real, synth_loader, batch_size
+        # the .jpg frames of `decode_group` consecutive batches are decoded in one call (sources that serve file bytes): the call's time is the
+        # longest Huffman chain, not the frame count -- 11.55 -> 11.24 ms per mixed step at 4 (tools/bench_mixed.py); 1: per batch
+        self.decode_group = max(1, int(decode_group))
         self.rank, self.world = rank, world_size      # DistributedSampler semantics: one shared permutation, rank r keeps perm[r::world]
         self.rng = np.random.default_rng(seed)
         self.update()
@@ -294,6 +328,8 @@ class MixedLoader:
         W, H = self.real.image_size
         static = self.synth.new_static_batch() if self.n_synth else None
         for bi in range(len(self)):
+            if self.decode_group > 1 and bi % self.decode_group == 0:
+                self.real.predecode([perm[b * self.n_real:(b + 1) * self.n_real] for b in range(bi, min(bi + self.decode_group, len(self)))])
             pad = torch.zeros((self.B, H + 6, W + 8, 4), dtype=self.real.dtype, device=self.real.dev)
             rb = self.real.batch(perm[bi * self.n_real:(bi + 1) * self.n_real], out_pad=pad[:self.n_real])
             if not self.n_synth:
