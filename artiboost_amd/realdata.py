@@ -325,6 +325,7 @@ class MixedLoader:
 
     def __iter__(self):
         perm = self.rng.permutation(self.real_len)[self.rank::self.world]      # same seed on every rank -> disjoint slices
+        self.real._predecoded.clear()      # frames decoded ahead for an epoch that was not finished
         W, H = self.real.image_size
         static = self.synth.new_static_batch() if self.n_synth else None
         for bi in range(len(self)):
