@@ -112,6 +112,48 @@ def test_jpeg_large_and_odd_shapes_vs_oracle():
         np.testing.assert_array_equal(o.cpu().numpy(), jo.decode(f), err_msg=f"file {i}")
 
 
+def test_jpeg_random_sweep_vs_oracle():
+    """120 files of random size (1 .. 230 pixels a side), content (smooth / photo-like / noise / saturated), quality 5 .. 100, sampling,
+    Huffman tables (standard / optimised) and restart interval, decoded in two ragged batches with different subsequence lengths: every
+    file bit-exact vs the C oracle (which is pinned to Pillow)."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image, ImageFile
+    from artiboost_amd.jpeg import JpegDecoder
+    ImageFile.MAXBLOCK = 1 << 24
+    rng = np.random.default_rng(2024)
+    files = []
+    for i in range(120):
+        w, h = int(rng.integers(1, 231)), int(rng.integers(1, 231))
+        kind = i % 4
+        if kind == 0:
+            img = _photo(w, h, i)
+        elif kind == 1:
+            img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        elif kind == 2:
+            img = np.clip(_photo(w, h, i).astype(np.int32) * 3 - 200, 0, 255).astype(np.uint8)          # saturated: range-limit paths
+        else:
+            y, x = np.mgrid[0:h, 0:w]
+            img = np.stack([(x * 5) % 256, (y * 7) % 256, ((x + y) * 3) % 256], -1).astype(np.uint8)
+        kw = {}
+        r = int(rng.integers(0, 4))
+        if r == 1:
+            kw["optimize"] = True
+        elif r == 2:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 9))
+        elif r == 3:
+            kw["restart_marker_rows"] = int(rng.integers(1, 4))
+        b = io.BytesIO()
+        if i % 11 == 0:
+            Image.fromarray(img[..., 0]).save(b, "JPEG", quality=int(rng.integers(5, 101)), **kw)
+        else:
+            Image.fromarray(img).save(b, "JPEG", quality=int(rng.integers(5, 101)), subsampling=int(rng.integers(0, 3)), **kw)
+        files.append(b.getvalue())
+    for part, sb in ((files[:60], 128), (files[60:], 48)):
+        outs = JpegDecoder("cuda", sub_bytes=sb).decode(part, channels=3)
+        for i, (f, o) in enumerate(zip(part, outs)):
+            np.testing.assert_array_equal(o.cpu().numpy(), jo.decode(f), err_msg=f"file {i} (sub_bytes {sb})")
+
+
 def test_jpeg_refuses_unsupported_before_device_work():
     PIL = pytest.importorskip("PIL")
     from PIL import Image
