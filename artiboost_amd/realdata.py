@@ -6,6 +6,8 @@ augmentation chain (flip, GaussianBlur, colour jitter, affine crop) in PIL on th
 Here the decoded frames of a batch are uploaded once and the whole chain runs in `ab_augment_batch` (the same kernels as
 the tail of the synthetic render); the ground-truth geometry stays on the host in the reference's arithmetic.  The datasets
 themselves (HO3D / DexYCB) are downloads: a source only has to provide the getters of `HOdataSource`."""
+import os
+
 import numpy as np
 import torch
 
@@ -297,11 +299,14 @@ class MixedLoader:
     real set is sharded like a DistributedSampler (shared permutation, rank r takes perm[r::world]); the synthetic loader
     shards its own epoch the same way."""
 
-    def __init__(self, real: RealBatcher, synth_loader, batch_size, seed=1, rank=0, world_size=1, decode_group=4):
+    def __init__(self, real: RealBatcher, synth_loader, batch_size, seed=1, rank=0, world_size=1, decode_group=4, decode_ahead=None):
         self.real, self.synth, self.B = real, synth_loader, batch_size
         # the .jpg frames of `decode_group` consecutive batches are decoded in one call (sources that serve file bytes): the call's time is the
         # longest Huffman chain, not the frame count -- 11.55 -> 11.24 ms per mixed step at 4 (tools/bench_mixed.py); 1: per batch
         self.decode_group = max(1, int(decode_group))
+        # ... and the NEXT group on a side stream while this group's steps run: the decode is a latency-bound chain of small launches, the
+        # one two-stream schedule measured to pay here (10.79 -> 10.49 ms per mixed step).  AB_JPEG_SIDE_STREAM=0 / decode_ahead=False: off
+        self.decode_ahead = (os.environ.get("AB_JPEG_SIDE_STREAM", "1") != "0") if decode_ahead is None else bool(decode_ahead)
         self.rank, self.world = rank, world_size      # DistributedSampler semantics: one shared permutation, rank r keeps perm[r::world]
         self.rng = np.random.default_rng(seed)
         self.update()
@@ -330,7 +335,25 @@ class MixedLoader:
         static = self.synth.new_static_batch() if self.n_synth else None
         for bi in range(len(self)):
             if self.decode_group > 1 and bi % self.decode_group == 0:
-                self.real.predecode([perm[b * self.n_real:(b + 1) * self.n_real] for b in range(bi, min(bi + self.decode_group, len(self)))])
+                G = self.decode_group
+                group = lambda g0: [perm[b * self.n_real:(b + 1) * self.n_real] for b in range(g0, min(g0 + G, len(self)))]      # noqa: E731
+                if not self.decode_ahead:
+                    self.real.predecode(group(bi))
+                else:      # group g + 1 is decoded on its own stream while the steps of group g run
+                    cur = torch.cuda.current_stream(self.real.dev)
+                    if bi == 0:
+                        self._dec_stream = torch.cuda.Stream(device=self.real.dev)
+                        self.real.predecode(group(0))
+                    else:
+                        cur.wait_event(self._dec_event)
+                    if bi + G < len(self):
+                        self._dec_stream.wait_stream(cur)
+                        with torch.cuda.stream(self._dec_stream):
+                            self.real.predecode(group(bi + G))
+                        self._dec_event = torch.cuda.Event()
+                        self._dec_event.record(self._dec_stream)
+                        for fr in self.real._predecoded.values():
+                            fr.record_stream(cur)
             pad = torch.zeros((self.B, H + 6, W + 8, 4), dtype=self.real.dtype, device=self.real.dev)
             rb = self.real.batch(perm[bi * self.n_real:(bi + 1) * self.n_real], out_pad=pad[:self.n_real])
             if not self.n_synth:

@@ -277,7 +277,7 @@ def test_stream_prefetcher_yields_the_loaders_batches():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     B, size = 8, 64
 
-    def make(decode_group=1):      # (MixedLoader's default is 4)
+    def make(decode_group=1, decode_ahead=False):      # (MixedLoader's defaults: 4, True)
         src = JpegSource()
         assets, proto = _loader(size=size)
         cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
@@ -285,7 +285,7 @@ def test_stream_prefetcher_yields_the_loaders_batches():
         n_synth = MixedLoader.n_synth_for(B, len(src), proto.synth_len)
         synth = ArtiBoostLoader.from_assets(assets, proto.cfg, cfg["DATA_PRESET"], n_synth, proto.synth_len, compute_dtype=torch.float32, random_seed=3)
         synth.prepare()
-        return MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.float32, seed=2), synth, B, seed=4, decode_group=decode_group)
+        return MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.float32, seed=2), synth, B, seed=4, decode_group=decode_group, decode_ahead=decode_ahead)
 
     plain = [{k: v.clone() for k, v in b.items()} for b in make()]
     got = []
@@ -295,8 +295,13 @@ def test_stream_prefetcher_yields_the_loaders_batches():
         got.append({k: v.clone() for k, v in b.items()})
     torch.cuda.synchronize()
     grouped = [{k: v.clone() for k, v in b.items()} for b in make(decode_group=3)]      # frames of three batches decoded per call
-    assert len(got) == len(plain) == len(grouped) >= 2
-    for other in (got, grouped):
+    ahead = []
+    for b in make(decode_group=2, decode_ahead=True):      # ... and the next group on a side stream while this one is consumed
+        junk = junk @ junk * 1e-3
+        ahead.append({k: v.clone() for k, v in b.items()})
+    torch.cuda.synchronize()
+    assert len(got) == len(plain) == len(grouped) == len(ahead) >= 2
+    for other in (got, grouped, ahead):
         for a, b in zip(plain, other):
             assert a.keys() == b.keys()
             for k in a:

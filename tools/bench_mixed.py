@@ -101,14 +101,17 @@ def train_loop(cfg, steps=30):
     from artiboost_amd.train import TrainStep
     B = 64
     res = {}
-    for mode in ("same stream", "same stream, frames of 4 batches decoded per call", "side stream, one batch ahead"):
+    for mode in ("same stream", "same stream, frames of 4 batches decoded per call", "same stream, frames of 4 batches decoded per call one group ahead on a side stream",
+                 "side stream, one batch ahead"):
         random.seed(5); torch.manual_seed(5); np.random.seed(5)
+        ahead = "one group ahead" in mode
         src = JpegFileSource(n=4096)
         synth_len = int(0.6 * len(src))
         n_synth = MixedLoader.n_synth_for(B, len(src), synth_len)
         synth = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], n_synth, synth_len, compute_dtype=torch.float32)
         synth.prepare()
-        ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.float32), synth, B, decode_group=4 if "4 batches" in mode else 1)
+        ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.float32), synth, B, decode_group=4 if "4 batches" in mode else 1,
+                         decode_ahead=ahead)
         arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16x3", INIT_SEED=3)
         model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
         crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
