@@ -331,6 +331,8 @@ class MixedLoader:
     def __iter__(self):
         perm = self.rng.permutation(self.real_len)[self.rank::self.world]      # same seed on every rank -> disjoint slices
         self.real._predecoded.clear()      # frames decoded ahead for an epoch that was not finished
+        if getattr(self, "_dec_stream", None) is not None:      # ... and a decode of that epoch possibly still in flight on the side stream
+            torch.cuda.current_stream(self.real.dev).wait_stream(self._dec_stream)
         W, H = self.real.image_size
         static = self.synth.new_static_batch() if self.n_synth else None
         for bi in range(len(self)):
@@ -342,7 +344,8 @@ class MixedLoader:
                 else:      # group g + 1 is decoded on its own stream while the steps of group g run
                     cur = torch.cuda.current_stream(self.real.dev)
                     if bi == 0:
-                        self._dec_stream = torch.cuda.Stream(device=self.real.dev)
+                        if getattr(self, "_dec_stream", None) is None:
+                            self._dec_stream = torch.cuda.Stream(device=self.real.dev)
                         self.real.predecode(group(0))
                     else:
                         cur.wait_event(self._dec_event)
