@@ -200,6 +200,23 @@ def jpeg_leg(device, n=64, iters=20):  # noqa: C901
                               "value": round(1.0 / t_pil, 1), "unit": "frames/s", "sample": "16 of the same files"}}
 
 
+def mixed_leg(args, steps=20):
+    """The reference's actual training mix (MixedDataset: real frames + the epoch's synthetic samples, mixed_dataset.py:5-37) as one step:
+    40 real 640 x 480 frames served as .jpg files (decoded on the device, augmented by ab_augment_batch) + 24 rendered samples per batch of 64,
+    hipGraph-replayed bf16x3 step; MixedLoader's default schedule (frames of four batches per decode call, the next group on a side stream)."""
+    import yaml
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_mixed
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", CFG_OF["HO3D"])))
+    cfg["DATA_PRESET"]["IMAGE_SIZE"] = [args.size, args.size]
+    cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [args.size // 8, args.size // 8]
+    mode = "same stream, frames of 4 batches decoded per call one group ahead on a side stream"
+    r = bench_mixed.train_loop(cfg, steps=steps, modes=(mode,), quiet=True)
+    return {"metric": "mixed samples/sec (40 real .jpg frames decoded + augmented on the device, 24 rendered; fwd+bwd+optimizer)", "value": round(64 / r[mode] * 1e3, 1),
+            "unit": "samples/s", "ms_per_step": round(r[mode], 3), "steps": steps, "batch": 64, "final_loss": r["final_loss"],
+            "workload": "MixedLoader (decode_group 4, decode_ahead) + TrainStep graph replay, bf16x3; SURVEY 8f-3"}
+
+
 def dexycb_leg(args, device, steps=10, warmup=3):
     """BASELINE configs[4] on ONE GPU (its 8-GPU form is this step under the data-parallel schedule of configs[3]): DexYCB-like scenes
     (21 objects at 16 k faces) and the DexYCB criterion list (+ SymCornerLoss in the fused pose/loss kernel), same geometry and precision."""
@@ -609,6 +626,7 @@ def main():
     ap.add_argument("--rccl-single-rank", action="store_true",
                     help="N = 1 only: run the multi-rank schedule (three backward graphs, ReduceOp.AVG all-reduces on the comm stream, render "
                          "overlap) over a ONE-rank RCCL group -- the part of the RCCL path a 1-GPU box can execute; not the headline")
+    ap.add_argument("--no-mixed-leg", action="store_true", help="skip the mixed real + synthetic training-step sub-object of the default line")
     ap.add_argument("--no-jpeg-leg", action="store_true", help="skip the real-frame JPEG decode sub-object of the default line")
     ap.add_argument("--no-study-leg", action="store_true", help="skip the one-pass weight-gradient study sub-object of the default line")
     ap.add_argument("--wgrad-1pass", action="store_true",
@@ -681,7 +699,7 @@ def main():
             port = sk.getsockname()[1]
         torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                                              device_id=torch.device(device))
-        args.no_eval_leg = args.no_dexycb_leg = args.no_study_leg = args.no_jpeg_leg = args.no_cpu_baseline = True
+        args.no_eval_leg = args.no_dexycb_leg = args.no_study_leg = args.no_jpeg_leg = args.no_mixed_leg = args.no_cpu_baseline = True
     cfg, model, crit, opt, loader, ts, static = build_everything(args, rank, world, device)
 
     def barrier():
@@ -777,6 +795,12 @@ def main():
                 jpg = jpeg_leg(device)
             except Exception as e:   # noqa: BLE001
                 jpg = {"error": repr(e)}
+        mixed = None
+        if world == 1 and not args.no_mixed_leg and not args.eager and args.dtype == "bf16x3" and args.bs == 64:
+            try:
+                mixed = mixed_leg(args)
+            except Exception as e:   # noqa: BLE001
+                mixed = {"error": repr(e)}
         roof["peak_note"] = ("dense bf16 MFMA peak / 3 passes" if args.dtype == "bf16x3" else "dense MFMA peak of the operand type")
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(args, cfg)
@@ -799,6 +823,7 @@ def main():
                "sustained": sustained,                 # same process, >= --sustain seconds after the timed block (+ observed sclk / power)
                "configs1_eval_forward": ev,            # BASELINE configs[1] (forward only) with its own roofline; `bench.py --eval` prints it as the line
                "configs4_dexycb_1gpu": dex,
+               "mixed_real_synth_step": mixed,         # the reference's MixedDataset batch (real .jpg frames + synthetic) as one training step
                "real_half_jpeg_decode": jpg,           # .jpg files -> frames on the device, beside Pillow on this host
                "study_wgrad_bf16_1pass": study}        # precision / speed study beside the headline (one-pass weight gradients), see its note            # BASELINE configs[4]'s per-GPU step (DexYCB scenes + SymCornerLoss) on this one GPU
         print(json.dumps(out), flush=True)

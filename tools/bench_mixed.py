@@ -88,7 +88,9 @@ def jpeg_compare(cfg):
               f"{(time.time() - t0) / 10 * 1e3:.2f} ms per batch of 40 real frames (GT assembly + decode + ab_augment_batch)")
 
 
-def train_loop(cfg, steps=30):
+def train_loop(cfg, steps=30, modes=("same stream", "same stream, frames of 4 batches decoded per call",
+                                     "same stream, frames of 4 batches decoded per call one group ahead on a side stream", "side stream, one batch ahead"),
+               quiet=False):
     """The training step (hipGraph replay, bf16x3, B = 64, 256 x 256) over MixedLoader batches -- 40 real frames served as .jpg files and
     decoded on the device + 24 synthetic samples rendered per batch -- with the batch assembly on the step's own stream, and one batch
     ahead on a side stream (realdata.StreamPrefetcher)."""
@@ -101,8 +103,7 @@ def train_loop(cfg, steps=30):
     from artiboost_amd.train import TrainStep
     B = 64
     res = {}
-    for mode in ("same stream", "same stream, frames of 4 batches decoded per call", "same stream, frames of 4 batches decoded per call one group ahead on a side stream",
-                 "side stream, one batch ahead"):
+    for mode in modes:
         random.seed(5); torch.manual_seed(5); np.random.seed(5)
         ahead = "one group ahead" in mode
         src = JpegFileSource(n=4096)
@@ -134,8 +135,10 @@ def train_loop(cfg, steps=30):
                 break
         torch.cuda.synchronize()
         res[mode] = (time.time() - t0) / n * 1e3
-        print(f"training over mixed batches (40 real .jpg frames decoded on the device + 24 synthetic, bf16x3), batch assembly on the {mode}: "
-              f"{res[mode]:.2f} ms per step ({n} steps), final loss {float(losses[5]):.5f}")
+        res["final_loss"] = float(losses[5])
+        if not quiet:
+            print(f"training over mixed batches (40 real .jpg frames decoded on the device + 24 synthetic, bf16x3), batch assembly on the {mode}: "
+                  f"{res[mode]:.2f} ms per step ({n} steps), final loss {float(losses[5]):.5f}")
     return res
 
 
