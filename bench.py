@@ -200,6 +200,23 @@ def jpeg_leg(device, n=64, iters=20):  # noqa: C901
                               "value": round(1.0 / t_pil, 1), "unit": "frames/s", "sample": "16 of the same files"}}
 
 
+def rccl_leg(args, ms_main):
+    """The multi-rank schedule over a ONE-rank RCCL group (`--rccl-single-rank`, a child process: a process group cannot be added to this
+    one after the fact): the RCCL path as far as a 1-GPU box can execute it, and what the schedule costs before any link time."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--rccl-single-rank", "--steps", str(args.steps), "--warmup", str(args.warmup), "--sustain", "0",
+           "--bs", str(args.bs), "--size", str(args.size), "--dtype", args.dtype, "--dataset", args.dataset]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    if r.returncode != 0 or not lines:
+        return {"error": (r.stderr or r.stdout)[-600:]}
+    d = json.loads(lines[-1])
+    return {"value": d["value"], "unit": "samples/s", "ms_per_step": d["ms_per_step"], "schedule_overhead_ms": round(d["ms_per_step"] - ms_main, 3),
+            "parallelism": d["config"]["parallelism"], "render_overlap": d["config"]["render_overlap"], "final_loss": d["final_loss"],
+            "what": "init_process_group('nccl', device_id=...), three backward graphs, bucketed ReduceOp.AVG all-reduces on the comm stream, next "
+                    "batch rendered under the last range -- over ONE rank: no link time, not a scaling measurement"}
+
+
 def mixed_leg(args, steps=20):
     """The reference's actual training mix (MixedDataset: real frames + the epoch's synthetic samples, mixed_dataset.py:5-37) as one step:
     40 real 640 x 480 frames served as .jpg files (decoded on the device, augmented by ab_augment_batch) + 24 rendered samples per batch of 64,
@@ -626,6 +643,7 @@ def main():
     ap.add_argument("--rccl-single-rank", action="store_true",
                     help="N = 1 only: run the multi-rank schedule (three backward graphs, ReduceOp.AVG all-reduces on the comm stream, render "
                          "overlap) over a ONE-rank RCCL group -- the part of the RCCL path a 1-GPU box can execute; not the headline")
+    ap.add_argument("--no-rccl-leg", action="store_true", help="skip the one-rank RCCL schedule sub-object of the default line")
     ap.add_argument("--no-mixed-leg", action="store_true", help="skip the mixed real + synthetic training-step sub-object of the default line")
     ap.add_argument("--no-jpeg-leg", action="store_true", help="skip the real-frame JPEG decode sub-object of the default line")
     ap.add_argument("--no-study-leg", action="store_true", help="skip the one-pass weight-gradient study sub-object of the default line")
@@ -699,7 +717,7 @@ def main():
             port = sk.getsockname()[1]
         torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                                              device_id=torch.device(device))
-        args.no_eval_leg = args.no_dexycb_leg = args.no_study_leg = args.no_jpeg_leg = args.no_mixed_leg = args.no_cpu_baseline = True
+        args.no_eval_leg = args.no_dexycb_leg = args.no_study_leg = args.no_jpeg_leg = args.no_mixed_leg = args.no_rccl_leg = args.no_cpu_baseline = True
     cfg, model, crit, opt, loader, ts, static = build_everything(args, rank, world, device)
 
     def barrier():
@@ -801,6 +819,13 @@ def main():
                 mixed = mixed_leg(args)
             except Exception as e:   # noqa: BLE001
                 mixed = {"error": repr(e)}
+        rccl1 = None
+        if world == 1 and not args.no_rccl_leg and not args.eager and not args.rccl_single_rank:
+            try:
+                torch.cuda.synchronize()
+                rccl1 = rccl_leg(args, ms)
+            except Exception as e:   # noqa: BLE001
+                rccl1 = {"error": repr(e)}
         roof["peak_note"] = ("dense bf16 MFMA peak / 3 passes" if args.dtype == "bf16x3" else "dense MFMA peak of the operand type")
         if world == 1 and not args.no_cpu_baseline:
             base = cpu_baseline(args, cfg)
@@ -823,6 +848,7 @@ def main():
                "sustained": sustained,                 # same process, >= --sustain seconds after the timed block (+ observed sclk / power)
                "configs1_eval_forward": ev,            # BASELINE configs[1] (forward only) with its own roofline; `bench.py --eval` prints it as the line
                "configs4_dexycb_1gpu": dex,
+               "rccl_one_rank_schedule": rccl1,        # the N > 1 code path with the real collective over one rank (the box has one GPU)
                "mixed_real_synth_step": mixed,         # the reference's MixedDataset batch (real .jpg frames + synthetic) as one training step
                "real_half_jpeg_decode": jpg,           # .jpg files -> frames on the device, beside Pillow on this host
                "study_wgrad_bf16_1pass": study}        # precision / speed study beside the headline (one-pass weight gradients), see its note            # BASELINE configs[4]'s per-GPU step (DexYCB scenes + SymCornerLoss) on this one GPU
