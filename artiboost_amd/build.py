@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libartiboost_hip.so")
 TORCH_LIB = os.path.join(HERE, "libartiboost_torch.so")      # the same entry points as torch.ops.artiboost_hip.* (gen_torch_ops.py)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result", "-Wno-array-bounds"]
 
 
 def sources():

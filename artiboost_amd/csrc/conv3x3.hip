@@ -13,28 +13,9 @@
 //           with the px-only mask every fragment read of that tile was a 2-way bank conflict: SQ_LDS_BANK_CONFLICT 0.33 of the LDS cycles)
 //   weight: row r (output channel) at byte r*128, logical chunk c at slot c ^ ((r >> 1) & 7)
 // Both are conflict-free for the 16-lane groups of ds_read_b128 (for TW = 16 two half-rows complement each other).
-#include "conv_common.h"
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+#include "conv3x3.h"
 
 static __device__ uint4 c3_zero_page[2];     // zero-initialised: source of every out-of-image chunk
-
-struct Conv3Args {
-    const void* X; const void* Wt; void* Out; const void* addend; float* stats;
-    const void* X_lo; unsigned wlo_delta;   // X3 (split-bf16) launches: low-order plane of X; byte distance Wt_lo - Wt
-    int N, H, W, C;          // input  [N,H,W,C]  (C % 64 == 0)
-    int Cn;                  // output [N,H,W,Cn]
-    int ktot;                // weight row length (9*C)
-    int tiles_x, tiles_y;    // tiles per image
-    // optional fused BatchNorm-backward reduction over the OUTPUT of this (data-gradient) launch: see ab_conv2d_dgrad_bnstats
-    const void* bn_y; const void* bn_out; const float* bnp; float* bn_part;
-    // X3 = 3 (eval-mode forward with the BatchNorm that follows folded in): Out / Out_lo are the (hi, lo) planes of
-    // relu?(acc * bnp[c] + bnp[Cn + c] + residual); residual = res_hi + res_lo planes, or the fp32 `addend`; OutF (optional) = the fp32 value
-    void* Out_lo; const void* res_hi; const void* res_lo; float* OutF; int ep_relu;
-    int flip;                // 0: tap t reads input (t/3-1, t%3-1); 1 (data gradient): (1-t/3, 1-t%3).  Weight K offset = t*C.
-};                           // (no per-tap tables: a dynamically indexed kernarg array becomes a VMEM load inside the K loop,
-                             //  and the vmcnt wait for it would drain the in-flight LDS-DMA prefetch)
 
 // saddr-form LDS-DMA: per-lane 32-bit byte offset + wave-uniform 64-bit base (no VALU 64-bit address arithmetic)
 __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_byte_addr) {
@@ -698,17 +679,24 @@ static int c3_tiles_of(int cfg, int N, int H, int W) {
     return N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
 }
 
+// conv3x3v.hip: weights streamed L2 -> VGPR in fragment order
+int c3v_config(int N, int H, int W, int C, int Cn);
+int c3v_tiles(int N, int H, int W, int C, int Cn);
+int c3v_run(Conv3Args& g, int x3, hipStream_t st);
+int c3v_pack(const void* w_hi, const void* w_lo, int C, int Cn, void* out, hipStream_t st);
+long c3v_frag_bytes(int C, int Cn);
+
 // BatchNorm partial rows of the split-bf16 launches: of a forward / plain launch, and of a data gradient with the fused reduction
 int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn) {
     if (C % 32) return 0;
+    if (int t = c3v_tiles(N, H, W, C, Cn)) return t;
     return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, true, true), N, H, W);
 }
 int conv3x3_x3_tiles_bnr(int N, int H, int W, int C, int Cn) {
     if (C % 32) return 0;
+    if (int t = c3v_tiles(N, H, W, C, Cn)) return t;
     return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, false, true), N, H, W);
 }
-
-struct C3EvalBn { void* out_hi; void* out_lo; float* out_f32; const void* res_hi; const void* res_lo; int relu; };
 
 int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W,
                    int C, int Cn, int flip, const float* addend, float* stats, hipStream_t st, const float* bn_y,
@@ -725,6 +713,18 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
     g.N = N; g.H = H; g.W = W; g.C = C; g.Cn = Cn; g.ktot = 9 * C; g.flip = flip;
     g.bn_y = bn_y; g.bn_out = bn_out_hi; g.bnp = bnp; g.bn_part = bn_part;
     if (ev) { g.Out = ev->out_hi; g.Out_lo = ev->out_lo; g.OutF = ev->out_f32; g.res_hi = ev->res_hi; g.res_lo = ev->res_lo; g.ep_relu = ev->relu; }
+    if (c3v_config(N, H, W, C, Cn)) {
+        // Opt-in probe (AB_C3V=1, round 4): the second-generation K loop of conv3x3v.hip.  Its fragment-ordered weight
+        // copy is re-packed into a process-wide scratch buffer on EVERY call (one more ~6 us launch, single stream only): the probe
+        // did not clear its kill criterion, so the copy was never moved into the optimizer's refresh pass.
+        static void* scratch = nullptr; static long scratch_bytes = 0;
+        const long need = c3v_frag_bytes(C, Cn);
+        if (need > scratch_bytes) { if (scratch) (void)hipFree(scratch); if (hipMalloc(&scratch, need) != hipSuccess) return AB_EINVAL; scratch_bytes = need; }
+        int rc = c3v_pack(wt_hi, wt_lo, C, Cn, scratch, st);
+        if (rc) return rc;
+        g.Wf = scratch;
+        return c3v_run(g, bn_y ? 2 : (ev ? 3 : 1), st);
+    }
     if (bn_y) {      // masked gradient + BatchNorm-backward partials from the epilogue
         if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, 1, 2>(g, st);
         if (cfg == 2) return c3_launch<256, 32, 128, 4, 2, 1, 2>(g, st);

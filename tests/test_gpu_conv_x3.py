@@ -434,3 +434,18 @@ def test_previous_tile_choices_still_correct():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "--timeout", "900"], env=env, capture_output=True,
                        text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_vgpr_streamed_weights_probe_kernel_is_correct():
+    """conv3x3v.hip (round-4 probe, opt-in AB_C3V=1: weights streamed L2 -> VGPR in fragment order, one barrier per chunk):
+    the forward / data-gradient / fused-BatchNorm-backward tests of this file again in a child process that routes every shape the
+    probe kernel takes (256-pixel tiles, Cout % 64 == 0) through it."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("AB_C3V") == "1":
+        pytest.skip("already the child")
+    env = dict(os.environ, AB_C3V="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "--timeout", "900", "-k",
+                        "fwd_x3 or dgrad_wgrad or bn_fused"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
