@@ -143,9 +143,14 @@ def _parse(data) -> JpegInfo:
             raise JpegUnsupported("missing restart markers")
         info.segs = np.stack([starts[:nseg], ends[:nseg] - starts[:nseg]], 1).astype(np.int64)
     else:
-        end = b.rfind(b"\xff\xd9")
-        end = len(b) if end < sos else end
-        info.segs = np.array([[0, end - sos]], np.int64)
+        # the first marker behind SOS that is neither a stuffed 0xFF00, a fill byte nor RSTn ends the entropy-coded segment (normally EOI) --
+        # NOT the last FFD9 of the file: MPF / appended previews carry EOIs of their own behind the first image
+        arr = np.frombuffer(b, np.uint8, offset=sos)
+        idx = np.flatnonzero(arr[:-1] == 0xFF)
+        nxt = arr[idx + 1]
+        stop = idx[(nxt != 0) & ((nxt < 0xD0) | (nxt > 0xD7)) & (nxt != 0xFF)]
+        end = int(stop[0]) if len(stop) else len(arr)
+        info.segs = np.array([[0, end]], np.int64)
     info.scan_off, info.scan_len = sos, int(info.segs[-1, 0] + info.segs[-1, 1])
     return info
 

@@ -24,8 +24,14 @@ def build_optimizer(params: Iterable, **cfg):
     groups = [dict(g, params=list(g["params"])) if isinstance(g, dict) else {"params": [g]} for g in params]
     name = cfg["OPTIMIZER"]
     wd = float(cfg.get("WEIGHT_DECAY", 0.0))
+    owner = _flat_hip_owner(groups)
+    if owner is not None and getattr(owner.store, "frozen_bn", False) and (wd != 0.0 or name not in ("Adam", "adam")):
+        # FrozenBatchNorm2d's weight / bias are BUFFERS in the reference (resnet.py:33-69): no optimizer ever touches them.  Here they
+        # live in the one flat parameter and are protected by a zero gradient -- which only the fused Adam (no decay) honours: a torch
+        # optimizer with weight decay, or SGD with momentum state, would move them.
+        raise NotImplementedError("BACKBONE.FREEZE_BATCHNORM with WEIGHT_DECAY != 0 or OPTIMIZER != Adam: the frozen affine terms share the "
+                                  "flat parameter and would be decayed; not built (no shipped config combines them)")
     if name in ("Adam", "adam"):
-        owner = _flat_hip_owner(groups)
         if owner is not None and wd == 0.0 and owner.flat_param.is_cuda:
             from .optim import FusedClipAdam
             return FusedClipAdam(groups, lr=cfg["LR"], max_norm=None, model=owner)

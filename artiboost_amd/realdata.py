@@ -138,13 +138,17 @@ class RealBatcher:
         self._ws = None
         self._pin, self._pin_i = None, 0
         self._jpeg = None               # jpeg.JpegDecoder, created with the first batch of file bytes
+        self._jpeg_side = None          # a SECOND decoder (its own device blob and workspace) for predecode(side=True): see there
         self._jpeg_cache, self._jpeg_tables = {}, {}
         self._predecoded = {}           # frames of upcoming batches decoded together: predecode()
 
-    def predecode(self, idx_lists):
+    def predecode(self, idx_lists, side=False):
         """Decode the .jpg files of SEVERAL upcoming batches in one ab_jpeg_decode_batch call (its time is set by the longest Huffman chain,
         nearly independent of the number of frames up to a few hundred: DESIGN 12.4); augment() then takes a batch's frames from here.
-        Does nothing when the source has no file bytes or a file is not covered (those batches decode as before)."""
+        Does nothing when the source has no file bytes or a file is not covered (those batches decode as before).
+        side=True: the caller runs this on a stream of its own next to augment() calls on the main stream -- the call then uses a SECOND
+        JpegDecoder, because augment()'s per-batch decode (the path a group takes when ITS predecode bailed out) shares nothing with it:
+        one decoder's device blob and workspace must never be written from two streams at once."""
         if getattr(self.src, "get_image_bytes", None) is None:
             return
         from .jpeg import JpegDecoder, JpegUnsupported, parse
@@ -159,10 +163,16 @@ class RealBatcher:
             return
         if any((it.width, it.height) != (W, H) for it in infos):
             return
-        if self._jpeg is None:
-            self._jpeg = JpegDecoder(self.dev)
+        if side:
+            if self._jpeg_side is None:
+                self._jpeg_side = JpegDecoder(self.dev)
+            dec = self._jpeg_side
+        else:
+            if self._jpeg is None:
+                self._jpeg = JpegDecoder(self.dev)
+            dec = self._jpeg
         frames = torch.empty((len(flat), H, W, 4), dtype=torch.uint8, device=self.dev)
-        self._jpeg.decode(files, out=frames, infos=infos)
+        dec.decode(files, out=frames, infos=infos)
         o = 0
         for idxs in idx_lists:
             self._predecoded[tuple(int(i) for i in idxs)] = frames[o:o + len(idxs)]
@@ -198,7 +208,8 @@ class RealBatcher:
         # decoded frames go, RGB and contiguous, into one of two pinned staging buffers (a strided RGB -> RGBX scatter on the
         # host costs 1 ms per 640x480 frame; the X byte is added on the device) and are uploaded with one asynchronous copy
         files = infos = None
-        if getattr(self.src, "get_image_bytes", None) is not None:
+        predecoded = tuple(int(i) for i in idxs) in self._predecoded      # predecode() read, parsed and decoded these files already
+        if not predecoded and getattr(self.src, "get_image_bytes", None) is not None:
             from .jpeg import JpegUnsupported, parse
             files = [self.src.get_image_bytes(idx) for idx in idxs]
             try:                                                   # header walk only (15 - 30 us per file, once per frame: cached); the decode runs in augment()
@@ -207,7 +218,7 @@ class RealBatcher:
                 infos = None
             if infos is not None and any((it.width, it.height) != (W, H) for it in infos):
                 infos = None
-        if infos is not None:
+        if infos is not None or predecoded:
             stage = None
         else:
             files = None
@@ -352,7 +363,7 @@ class MixedLoader:
                     if bi + G < len(self):
                         self._dec_stream.wait_stream(cur)
                         with torch.cuda.stream(self._dec_stream):
-                            self.real.predecode(group(bi + G))
+                            self.real.predecode(group(bi + G), side=True)
                         self._dec_event = torch.cuda.Event()
                         self._dec_event.record(self._dec_stream)
                         for fr in self.real._predecoded.values():

@@ -394,3 +394,21 @@ def test_alias_leaf_modules_resolve():
         m = importlib.import_module(mod)
         for n in names:
             assert hasattr(m, n), (mod, n)
+
+
+def test_frozen_batchnorm_refuses_optimizers_that_would_move_its_buffers():
+    """FrozenBatchNorm2d's affine terms are buffers in the reference (resnet.py:33-69); here they sit in the flat parameter, protected by a
+    zero gradient that only the decay-free Adam honours: weight decay or SGD must be refused, not silently diverge."""
+    import types
+    import torch
+    from artiboost_amd import netutils
+    p = torch.nn.Parameter(torch.zeros(8))
+    owner = types.SimpleNamespace(flat_param=p, store=types.SimpleNamespace(frozen_bn=True))
+    p._ab_owner = owner
+    with pytest.raises(NotImplementedError):
+        netutils.build_optimizer([p], OPTIMIZER="Adam", LR=1e-4, WEIGHT_DECAY=1e-4)
+    with pytest.raises(NotImplementedError):
+        netutils.build_optimizer([p], OPTIMIZER="SGD", LR=1e-4)
+    assert isinstance(netutils.build_optimizer([p], OPTIMIZER="Adam", LR=1e-4), torch.optim.Adam)      # CPU parameter: torch's Adam, no decay
+    owner.store.frozen_bn = False
+    assert isinstance(netutils.build_optimizer([p], OPTIMIZER="SGD", LR=1e-4, WEIGHT_DECAY=1e-4), torch.optim.SGD)

@@ -71,3 +71,14 @@ def test_plan_lays_out_one_blob():
         assert bytes(blob[offs[0] + d[i, 0]:offs[0] + d[i, 0] + 8]) == f[so:so + 8]
     with pytest.raises(ValueError):
         J.JpegDecoder.__init__(J.JpegDecoder.__new__(J.JpegDecoder), "cpu", sub_bytes=512)
+
+
+def test_scan_ends_at_the_first_eoi_not_the_last():
+    """A file with data appended behind its EOI -- an MPF second image, a preview -- that carries an EOI of its own: the entropy segment
+    handed to the device must end at the FIRST image's EOI (the extent used to be rfind(FFD9) over the whole file)."""
+    for data, _ in _files():
+        it = J.parse(data)
+        tail = b"\xff\xd8\xff\xe0\x00\x04\x00\x00" + bytes(range(1, 200)) + b"\xff\xd9" + b"trailing junk"
+        it2 = J.parse(data + tail)
+        assert (it2.scan_off, it2.scan_len) == (it.scan_off, it.scan_len)
+        np.testing.assert_array_equal(it2.segs, it.segs)

@@ -306,3 +306,54 @@ def test_stream_prefetcher_yields_the_loaders_batches():
             assert a.keys() == b.keys()
             for k in a:
                 torch.testing.assert_close(a[k], b[k], rtol=0, atol=0, msg=k)
+
+
+class _OneProgressive(JpegSource):
+    """Twelve DISTINCT .jpg files (the golden frames shifted by idx); file 0 is progressive: the device decoder refuses it."""
+
+    def __init__(self):
+        import io
+        from PIL import Image
+        super().__init__()
+        self.files = []
+        for i in range(self.n):
+            b = io.BytesIO()
+            Image.fromarray(np.roll(self.g["frames"][i % 3], 7 * i, axis=1)).save(b, "JPEG", quality=92, progressive=(i == 0))
+            self.files.append(b.getvalue())
+
+    def get_image(self, idx):
+        import io
+        from PIL import Image
+        return np.asarray(Image.open(io.BytesIO(self.files[idx])).convert("RGB"))
+
+    def get_image_bytes(self, idx):
+        return self.files[idx]
+
+
+class _OneProgressivePillow(_OneProgressive):
+    get_image_bytes = None
+
+
+@pytest.mark.gpu
+def test_group_that_cannot_be_predecoded_does_not_share_the_side_stream_decoder():
+    """Round-3 advisor finding: with decode_ahead the NEXT group is decoded on a side stream; a group whose own predecode bailed out (one file
+    the device decoder does not cover) decodes batch by batch on the MAIN stream at the same time -- with a decoder of its own, not the side
+    stream's device blob / workspace.  Every batch must equal the all-Pillow source's, bit for bit, whatever the interleaving."""
+    pytest.importorskip("PIL")
+    from artiboost_amd.realdata import MixedLoader, RealBatcher
+    cfg = {"IMAGE_SIZE": [64, 64], "CENTER_IDX": 0, "BBOX_EXPAND_RATIO": 1.2}
+    junk = torch.randn(1024, 1024, device="cuda")
+    for seed in (1, 2, 3):
+        ref = [{k: v.clone() for k, v in b.items()} for b in
+               MixedLoader(RealBatcher(_OneProgressivePillow(), cfg, compute_dtype=torch.float32, seed=5), None, 2, seed=seed, decode_group=1, decode_ahead=False)]
+        ml = MixedLoader(RealBatcher(_OneProgressive(), cfg, compute_dtype=torch.float32, seed=5), None, 2, seed=seed, decode_group=2, decode_ahead=True)
+        got = []
+        for b in ml:
+            junk = junk @ junk * 1e-3
+            got.append({k: v.clone() for k, v in b.items()})
+        torch.cuda.synchronize()
+        assert len(got) == len(ref) == 6
+        assert ml.real._jpeg is not None and ml.real._jpeg_side is not None and ml.real._jpeg is not ml.real._jpeg_side
+        for a, r in zip(got, ref):
+            for k in r:
+                torch.testing.assert_close(a[k], r[k], rtol=0, atol=0, msg=k)

@@ -179,7 +179,10 @@ def main():
                 if "real" not in test_state:
                     test_state["real"] = RealBatcher(test_data, cfg["DATA_PRESET"], aug=False, device=dev, compute_dtype=loader.dtype, seed=seed)
                 rb = test_state["real"]
-                idxs = np.random.permutation(len(test_data))[rank::world]        # shuffle=True, drop_last=False (train_artiboost.py:113-121)
+                # shuffle=True, drop_last=False (train_artiboost.py:113-121).  Every rank evaluates the WHOLE test set (the reference's
+                # DataParallel process does): no cross-rank reduction of the evaluator is needed and rank 0's record covers every frame;
+                # the order comes from a dedicated generator, not from the global numpy state the ranks may have advanced differently
+                idxs = np.random.default_rng(seed + 7919 * (epoch_idx + 1)).permutation(len(test_data))
                 source = (rb.batch(idxs[i:i + per_rank].tolist()) for i in range(0, len(idxs), per_rank))
                 what = f"{len(test_data)} frames of DATASET.TEST ({cfg['DATASET']['TEST']['TYPE']})"
             else:
