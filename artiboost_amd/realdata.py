@@ -127,8 +127,12 @@ class RealBatcher:
     GT_KEYS = (Queries.CAM_INTR, Queries.ROOT_JOINT, Queries.JOINTS_3D, Queries.JOINTS_2D, Queries.JOINTS_VIS, Queries.CORNERS_3D,
                Queries.CORNERS_2D, Queries.CORNERS_VIS, Queries.CORNERS_CAN, Queries.OBJ_TRANSF)
 
-    def __init__(self, source: HOdataSource, cfg_preset, aug=True, aug_param=None, device="cuda", compute_dtype=torch.bfloat16, seed=1):
+    def __init__(self, source: HOdataSource, cfg_preset, aug=True, aug_param=None, device="cuda", compute_dtype=torch.bfloat16, seed=1,
+                 num_workers=None):
         self.src, self.dev, self.dtype, self.aug = source, torch.device(device), compute_dtype, aug
+        # host decode threads (the reference's DataLoader num_workers, anakin/opt.py:16 / train_artiboost.py:175-190): zlib inflates of the
+        # PNG path and the Pillow decodes of sources without file bytes run on this many threads (None: AB_DECODE_WORKERS or min(32, cores))
+        self.num_workers = num_workers
         self.image_size = list(cfg_preset["IMAGE_SIZE"])
         self.center_idx = int(cfg_preset.get("CENTER_IDX", 9))
         self.bbox_expand = float(cfg_preset.get("BBOX_EXPAND_RATIO", 1.2))
@@ -139,8 +143,10 @@ class RealBatcher:
         self._pin, self._pin_i = None, 0
         self._jpeg = None               # jpeg.JpegDecoder, created with the first batch of file bytes
         self._jpeg_side = None          # a SECOND decoder (its own device blob and workspace) for predecode(side=True): see there
-        self._jpeg_cache, self._jpeg_tables = {}, {}
+        self._png = self._png_side = None      # png.PngDecoder (host inflate pool + ab_png_unfilter_batch), same roles
+        self._jpeg_cache, self._jpeg_tables, self._png_cache = {}, {}, {}
         self._predecoded = {}           # frames of upcoming batches decoded together: predecode()
+        self._jobs = {}                 # inflate jobs of a group started ahead of its predecode(): prefetch_files()
 
     def predecode(self, idx_lists, side=False):
         """Decode the .jpg files of SEVERAL upcoming batches in one ab_jpeg_decode_batch call (its time is set by the longest Huffman chain,
@@ -151,32 +157,84 @@ class RealBatcher:
         one decoder's device blob and workspace must never be written from two streams at once."""
         if getattr(self.src, "get_image_bytes", None) is None:
             return
-        from .jpeg import JpegDecoder, JpegUnsupported, parse
         flat = [int(i) for idxs in idx_lists for i in idxs]
         files = [self.src.get_image_bytes(i) for i in flat]
         W, H = self.src.raw_size
-        try:
-            if any(f is None for f in files):
-                return
-            infos = [self._jpeg_info(i, f, parse) for i, f in zip(flat, files)]
-        except JpegUnsupported:
+        kind, infos = self._parse_files(flat, files)
+        if kind is None:
             return
-        if any((it.width, it.height) != (W, H) for it in infos):
-            return
-        if side:
-            if self._jpeg_side is None:
-                self._jpeg_side = JpegDecoder(self.dev)
-            dec = self._jpeg_side
-        else:
-            if self._jpeg is None:
-                self._jpeg = JpegDecoder(self.dev)
-            dec = self._jpeg
+        dec = self._decoder(kind, side)
         frames = torch.empty((len(flat), H, W, 4), dtype=torch.uint8, device=self.dev)
-        dec.decode(files, out=frames, infos=infos)
+        job = self._jobs.pop(tuple(flat), None)
+        if job is not None and kind == "png":
+            dec.complete(job, out=frames)          # the inflates were started by prefetch_files() a group earlier
+        else:
+            dec.decode(files, out=frames, infos=infos)
         o = 0
         for idxs in idx_lists:
             self._predecoded[tuple(int(i) for i in idxs)] = frames[o:o + len(idxs)]
             o += len(idxs)
+
+    def prefetch_files(self, idx_lists, side=False):
+        """Start the HOST share of a later predecode(idx_lists, side) now and return at once: for .png sources the zlib inflates of the group
+        are handed to the decode pool (they take a few milliseconds per frame: started here, a group ahead, they are off the critical path
+        of the step loop).  Nothing to do for .jpg sources (their host share is a header walk) or sources without file bytes."""
+        if getattr(self.src, "get_image_bytes", None) is None:
+            return
+        flat = [int(i) for idxs in idx_lists for i in idxs]
+        files = [self.src.get_image_bytes(i) for i in flat]
+        kind, infos = self._parse_files(flat, files)
+        if kind == "png" and tuple(flat) not in self._jobs:
+            self.drop_jobs()                       # a job nobody collected (an epoch cut short): its staging buffer is needed again
+            self._jobs[tuple(flat)] = self._decoder("png", side).submit(files, infos)
+
+    def drop_jobs(self):
+        """Await and forget inflate jobs that were started ahead and never collected."""
+        for j in self._jobs.values():
+            for f in j["futs"]:
+                f.exception()
+        self._jobs.clear()
+
+    def _decoder(self, kind, side=False):
+        """The device decoder of file kind "jpeg" / "png"; side=True: the second instance, for calls on another stream (predecode)."""
+        name = "_" + kind + ("_side" if side else "")
+        dec = getattr(self, name)
+        if dec is None:
+            if kind == "jpeg":
+                from .jpeg import JpegDecoder
+                dec = JpegDecoder(self.dev)
+            else:
+                from .png import PngDecoder
+                dec = PngDecoder(self.dev, workers=self.num_workers)
+            setattr(self, name, dec)
+        return dec
+
+    def _parse_files(self, idxs, files):
+        """-> ("jpeg" | "png", infos) when every file of the batch is covered by ONE device decoder and has the dataset's frame size
+        (header walks only, cached per frame index), else (None, None): the batch then decodes through get_image."""
+        if any(f is None for f in files):
+            return None, None
+        from .jpeg import JpegUnsupported, parse as jparse
+        from .png import SIGNATURE, PngUnsupported, parse as pparse
+        W, H = self.src.raw_size
+        try:
+            if all(bytes(memoryview(f)[:8]) == SIGNATURE for f in files):
+                kind, infos = "png", [self._png_info(i, f, pparse) for i, f in zip(idxs, files)]
+            else:
+                kind, infos = "jpeg", [self._jpeg_info(i, f, jparse) for i, f in zip(idxs, files)]
+        except (JpegUnsupported, PngUnsupported):
+            return None, None
+        if any((it.width, it.height) != (W, H) for it in infos):
+            return None, None
+        return kind, infos
+
+    def _png_info(self, idx, data, parse):
+        hit = self._png_cache.get(idx)
+        if hit is not None and hit[0] == len(data):
+            return hit[1]
+        it = parse(data)
+        self._png_cache[idx] = (len(data), it)
+        return it
 
     def _jpeg_info(self, idx, data, parse):
         """parse(data), remembered per frame index (a dataset re-reads the same files every epoch); the quantisation / Huffman tables of
@@ -209,15 +267,10 @@ class RealBatcher:
         # host costs 1 ms per 640x480 frame; the X byte is added on the device) and are uploaded with one asynchronous copy
         files = infos = None
         predecoded = tuple(int(i) for i in idxs) in self._predecoded      # predecode() read, parsed and decoded these files already
+        kind = None
         if not predecoded and getattr(self.src, "get_image_bytes", None) is not None:
-            from .jpeg import JpegUnsupported, parse
-            files = [self.src.get_image_bytes(idx) for idx in idxs]
-            try:                                                   # header walk only (15 - 30 us per file, once per frame: cached); the decode runs in augment()
-                infos = None if any(f is None for f in files) else [self._jpeg_info(idx, f, parse) for idx, f in zip(idxs, files)]
-            except JpegUnsupported:
-                infos = None
-            if infos is not None and any((it.width, it.height) != (W, H) for it in infos):
-                infos = None
+            files = [self.src.get_image_bytes(idx) for idx in idxs]      # header walk only (15 - 50 us per file, cached); the decode runs in augment()
+            kind, infos = self._parse_files([int(i) for i in idxs], files)
         if infos is not None or predecoded:
             stage = None
         else:
@@ -228,8 +281,11 @@ class RealBatcher:
             self._pin_i ^= 1
             stage = self._pin[self._pin_i][:n]
             frames = stage.numpy()
-            for i, idx in enumerate(idxs):
-                frames[i] = self.src.get_image(idx)
+
+            def one(a):                     # Pillow's decoders release the GIL: the frames of a batch decode side by side
+                frames[a[0]] = self.src.get_image(a[1])
+            from .png import pool
+            list(pool(self.num_workers).map(one, enumerate(idxs)))
         r = assemble_real_gt_batch([self.src.get_annots(idx) for idx in idxs], self.image_size, self.src.raw_size, draws, self.center_idx,
                                    self.bbox_expand, self.center_jit, self.scale_jit, self.src.sides)
         gt = {k: r[k] for k in self.GT_KEYS}
@@ -243,7 +299,7 @@ class RealBatcher:
             blur = None
         else:
             order, factor, blur = draws["order"], draws["factor"], draws["blur"]
-        return dict(frames=stage, files=files, jpeg_infos=infos, gt={k: np.asarray(v, np.float32) for k, v in gt.items()}, inv=inv, flip=flip, obj_idx=obj_idx,
+        return dict(frames=stage, files=files, file_kind=kind, file_infos=infos, gt={k: np.asarray(v, np.float32) for k, v in gt.items()}, inv=inv, flip=flip, obj_idx=obj_idx,
                     order=order, factor=factor, blur=blur, idxs=np.asarray(idxs, np.int64))
 
     def augment(self, host, out_pad=None, out_chw=None):
@@ -261,12 +317,9 @@ class RealBatcher:
         pre = self._predecoded.pop(tuple(int(i) for i in host["idxs"]), None) if self._predecoded else None
         if pre is not None:
             frames = pre
-        elif host.get("files") is not None:                        # the .jpg files themselves: Huffman decode .. RGBX on the device
-            if self._jpeg is None:
-                from .jpeg import JpegDecoder
-                self._jpeg = JpegDecoder(self.dev)
+        elif host.get("files") is not None:                        # the .jpg / .png files themselves: decoded to RGBX on the device
             frames = torch.empty((n, H, W, 4), dtype=torch.uint8, device=self.dev)
-            self._jpeg.decode(host["files"], out=frames, infos=host["jpeg_infos"])
+            self._decoder(host["file_kind"]).decode(host["files"], out=frames, infos=host["file_infos"])
         else:
             rgb = host["frames"].to(self.dev, non_blocking=True)
             frames = torch.zeros(rgb.shape[:3] + (4,), dtype=torch.uint8, device=self.dev)
@@ -342,6 +395,7 @@ class MixedLoader:
     def __iter__(self):
         perm = self.rng.permutation(self.real_len)[self.rank::self.world]      # same seed on every rank -> disjoint slices
         self.real._predecoded.clear()      # frames decoded ahead for an epoch that was not finished
+        self.real.drop_jobs()
         if getattr(self, "_dec_stream", None) is not None:      # ... and a decode of that epoch possibly still in flight on the side stream
             torch.cuda.current_stream(self.real.dev).wait_stream(self._dec_stream)
         W, H = self.real.image_size
@@ -366,6 +420,8 @@ class MixedLoader:
                             self.real.predecode(group(bi + G), side=True)
                         self._dec_event = torch.cuda.Event()
                         self._dec_event.record(self._dec_stream)
+                        if bi + 2 * G < len(self):      # ... and the host share (PNG inflates) of the group after that one
+                            self.real.prefetch_files(group(bi + 2 * G), side=True)
                         for fr in self.real._predecoded.values():
                             fr.record_stream(cur)
             pad = torch.zeros((self.B, H + 6, W + 8, 4), dtype=self.real.dtype, device=self.real.dev)

@@ -419,6 +419,21 @@ int ab_jpeg_decode_batch(const void* data, const int32_t* desc, const int32_t* s
                          int n_tables, int sub_bytes, long total_blocks, long total_subseq, long plane_bytes, long data_bytes,
                          long total_segs, int max_blocks, int max_width, int max_height, int max_subseq, int out_channels, void* out,
                          void* workspace, void* stream);
+/* SURVEY section 8f-3, the same decode for .png frames -- HO3D v2, the dataset of BASELINE.json's configs[1..3], stores rgb/NNNN.png
+ * (anakin/datasets/ho3d.py:181, decoded at :228-231 by `Image.open(path).convert("RGB")`): the scanline reconstruction of the PNG
+ * specification (filter types None / Sub / Up / Average / Paeth, what Pillow's libImaging/ZipDecode.c applies behind zlib) and the sample
+ * selection of convert("RGB"), bit-identical.  The zlib inflate of the IDAT streams stays on the host (a thread pool, artiboost_amd/png.py).
+ *   raw    the inflated scanlines of the n images (device): per image `height` lines of 1 filter byte + width * bpp sample bytes;
+ *          the buffer must be readable for 8 bytes past the last line (samples are fetched 4 / 8 bytes at a time)
+ *   desc   int32 [n][AB_PNG_DESC_INTS]: 0 / 1 byte offset of the image in raw (low / high word), 2 width, 3 height, 4 bytes per pixel
+ *          (3 RGB8, 4 RGBA8, 6 RGB16, 8 RGBA16, 1 grey8), 5 byte offsets of the R, G, B samples inside a pixel as c0 | c1 << 8 | c2 << 16
+ *          (16-bit samples: the high byte, as Pillow keeps), 6 output offset (pixels), 7 output row pitch (pixels)
+ *   max_width / max_bpp: the largest descriptor fields 2 / 4 of the batch
+ *   out    uint8, out_channels 3 (RGB) or 4 (RGBX, X = 0);  status (device int32 or NULL): bit 0 <- a filter byte above 4 was met
+ * Interlaced, palette, 1/2/4-bit, 16-bit grey and grey + alpha files are refused by the host parser (the caller keeps Pillow for those).  */
+#define AB_PNG_DESC_INTS 8
+int ab_png_unfilter_batch(const void* raw, const int32_t* desc, int n, int max_width, int max_bpp, int out_channels, void* out, int* status,
+                          void* stream);
 /* Small-batch fp32 linear layers (the box-rotation MLP, anakin/models/mlp.py:11-25; nn.Linear weights [N][K]):
  *   fwd   y[M][N]  = act(x[M][K] W^T + bias)            (relu != 0: ReLU)
  *   dgrad gx[M][K] = (g[M][N] W) masked by act_out > 0   (act_out NULL: no mask); takes wt = W transposed, [K][N]

@@ -74,6 +74,23 @@ class JpegFileSource(MemorySource):
         return self.files[idx % 16]
 
 
+class PngFileSource(JpegFileSource):
+    """The same frames as .png FILES (HO3D v2's own format, ho3d.py:181): zlib inflate on the host pool, scanline reconstruction on the device."""
+
+    def __init__(self, n=256, seed=0, device_decode=True):
+        import io
+        from PIL import Image
+        from bench_jpeg import _photo
+        MemorySource.__init__(self, n, seed)
+        self.files = []
+        for i in range(16):
+            b = io.BytesIO()
+            Image.fromarray(_photo(640, 480, i)).save(b, "PNG")
+            self.files.append(b.getvalue())
+        if not device_decode:
+            self.get_image_bytes = None
+
+
 def jpeg_compare(cfg):
     """40 real frames per batch from .jpg files: decode on the device vs Pillow on this host (one thread, as one DataLoader worker)."""
     for dev_dec in (True, False):
@@ -90,7 +107,7 @@ def jpeg_compare(cfg):
 
 def train_loop(cfg, steps=30, modes=("same stream", "same stream, frames of 4 batches decoded per call",
                                      "same stream, frames of 4 batches decoded per call one group ahead on a side stream", "side stream, one batch ahead"),
-               quiet=False):
+               quiet=False, source="jpeg"):
     """The training step (hipGraph replay, bf16x3, B = 64, 256 x 256) over MixedLoader batches -- 40 real frames served as .jpg files and
     decoded on the device + 24 synthetic samples rendered per batch -- with the batch assembly on the step's own stream, and one batch
     ahead on a side stream (realdata.StreamPrefetcher)."""
@@ -106,7 +123,7 @@ def train_loop(cfg, steps=30, modes=("same stream", "same stream, frames of 4 ba
     for mode in modes:
         random.seed(5); torch.manual_seed(5); np.random.seed(5)
         ahead = "one group ahead" in mode
-        src = JpegFileSource(n=4096)
+        src = {"jpeg": JpegFileSource, "png": PngFileSource, "png-pillow": lambda n: PngFileSource(n, device_decode=False)}[source](n=4096)
         synth_len = int(0.6 * len(src))
         n_synth = MixedLoader.n_synth_for(B, len(src), synth_len)
         synth = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], n_synth, synth_len, compute_dtype=torch.float32)
@@ -137,7 +154,7 @@ def train_loop(cfg, steps=30, modes=("same stream", "same stream, frames of 4 ba
         res[mode] = (time.time() - t0) / n * 1e3
         res["final_loss"] = float(losses[5])
         if not quiet:
-            print(f"training over mixed batches (40 real .jpg frames decoded on the device + 24 synthetic, bf16x3), batch assembly on the {mode}: "
+            print(f"training over mixed batches (40 real {source} frames + 24 synthetic, bf16x3), batch assembly on the {mode}: "
                   f"{res[mode]:.2f} ms per step ({n} steps), final loss {float(losses[5]):.5f}")
     return res
 
@@ -170,6 +187,9 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     jpeg_compare(cfg)
     train_loop(cfg)
+    ahead = ("same stream, frames of 4 batches decoded per call one group ahead on a side stream",)
+    train_loop(cfg, modes=ahead, source="png")             # HO3D v2's own frame format: pooled inflate + device reconstruction
+    train_loop(cfg, modes=ahead, source="png-pillow")      # ... and the same files through Pillow on the decode pool (no file bytes served)
 
 
 if __name__ == "__main__":
