@@ -473,6 +473,61 @@ int ab_mano_lbs(const float* pose, const float* betas, const float* v_template, 
                 const float* posedirs, const float* J_regressor, const float* weights, const float* hands_mean,
                 int B, float* verts, float* joints, float* T_abs, void* stream);
 
+/* ---- Argument contracts of the dispatcher ops (torch.ops.artiboost_hip.*, libartiboost_torch.so) ------------------------------------------
+ * The C entry points above take raw pointers and trust their caller.  Their PyTorch-dispatcher form (ops that "validate
+ * with TORCH_CHECK") is generated from this header by artiboost_amd/gen_torch_ops.py and checks, before the C call, for EVERY op:
+ *   - a tensor passed for a device pointer is a contiguous HIP tensor of the current device; one passed for a host pointer (`*_host`, the
+ *     ab_* descriptor structs) is a contiguous CPU tensor;
+ *   - a typed pointer fixes the dtype: float* float32, int32_t* / int* int32, int64_t* int64, uint8_t* uint8;
+ * and, per op, the clauses of its `@check` line below (C expressions over the op's integer arguments; co() = convolution output size):
+ *   names >= expr        every named tensor holds at least `expr` elements (a wrong B / H / C no longer overruns a buffer: RuntimeError)
+ *   bytes names >= expr  ... at least `expr` bytes (workspaces)
+ *   bf16|u8|i32|f32: names     dtype of `void*` arguments
+ *   dt(code): names            dtype given by the op's AB_DT_* argument `code`
+ * A violated clause raises RuntimeError naming the op, the argument and both sizes; nothing is launched.
+ * @check ab_softargmax3d_fwd: dt(dtype): logits; logits >= B*H*W*C*DP; part >= B*ab_softargmax3d_ntiles(H,W)*C*8; uvd >= B*C*3; conf >= B*C; stat >= B*C*2
+ * @check ab_softargmax3d_bwd: dt(dtype): logits dlogits; logits dlogits >= B*H*W*C*DP; uvd g_uvd >= B*C*3; conf g_conf >= B*C; stat >= B*C*2
+ * @check ab_softargmax3d_bwd_x3: bf16: dl_hi dl_lo; logits dl_hi dl_lo >= B*H*W*C*DP; uvd g_uvd >= B*C*3; conf g_conf >= B*C; stat >= B*C*2
+ * @check ab_split_f32: bf16: hi lo; src hi lo >= n
+ * @check ab_cast_f32_bf16: bf16: dst; src dst >= n
+ * @check ab_conv2d_fwd_x3: bf16: x_hi x_lo w_hi w_lo; x_hi x_lo >= N*H*W*Cin; w_hi w_lo >= Cout*kh*kw*Cin; y >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; bias >= Cout; stats >= ab_conv2d_x3_stat_rows(N,H,W,Cin,Cout,kh,kw,stride,pad)*Cout*2
+ * @check ab_conv2d_fwd_x3_evalbn: bf16: x_hi x_lo w_hi w_lo res_hi res_lo out_hi out_lo; x_hi x_lo >= N*H*W*Cin; w_hi w_lo >= Cout*9*Cin; bnp >= 2*Cout; res_hi res_lo res_f32 out_hi out_lo out_f32 >= N*H*W*Cout
+ * @check ab_conv2d_fwd_x3_affine: bf16: x_hi x_lo w_hi w_lo out_hi out_lo; x_hi x_lo >= N*H*W*Cin; w_hi w_lo >= Cout*kh*kw*Cin; scale shift >= Cout; out_f32 out_hi out_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout
+ * @check ab_conv2d_dgrad_x3: bf16: dy_hi dy_lo wt_hi wt_lo; dy_hi dy_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; wt_hi wt_lo >= Cin*kh*kw*Cout; dx addend >= N*H*W*Cin
+ * @check ab_conv2d_dgrad_x3_pair: bf16: dy_hi dy_lo wt_hi wt_lo dy2_hi dy2_lo wt2_hi wt2_lo; dy_hi dy_lo dy2_hi dy2_lo >= N*(H/2)*(W/2)*Cout; wt_hi wt_lo >= Cin*kh*kw*Cout; wt2_hi wt2_lo >= Cin*Cout; dx addend >= N*H*W*Cin
+ * @check ab_conv2d_dgrad_x3_bn: bf16: dy_hi dy_lo wt_hi wt_lo bn_out_hi; dy_hi dy_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; wt_hi wt_lo >= Cin*kh*kw*Cout; dz addend bn_y bn_out_hi >= N*H*W*Cin; bnp >= 4*Cin; bn_part >= ab_conv2d_dgrad_x3_bn_rows(N,H,W,Cin,Cout,kh,kw,stride,pad)*Cin*2
+ * @check ab_conv2d_wgrad_x3: bf16: x_hi x_lo dy_hi dy_lo; x_hi x_lo >= N*H*W*Cin; dy_hi dy_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; dw >= Cout*kh*kw*Cin; bytes workspace >= ab_conv2d_wgrad_x3_workspace(N,H,W,Cin,Cout,kh,kw,stride,pad)
+ * @check ab_conv2d_stem_fwd_x3: bf16: xpad_hi xpad_lo w_hi w_lo; xpad_hi xpad_lo >= N*(H+6)*(W+8)*4; w_hi w_lo >= Cout*7*8*4; y >= N*(H/2)*(W/2)*Cout; stats >= ab_conv2d_stem_x3_stat_rows(N,H,W)*Cout*2
+ * @check ab_conv2d_stem_wgrad_x3: bf16: xpad_hi xpad_lo dy_hi dy_lo; xpad_hi xpad_lo >= N*(H+6)*(W+8)*4; dy_hi dy_lo >= N*(H/2)*(W/2)*Cout; dw >= Cout*7*8*4
+ * @check ab_conv2d_fwd: dt(dtype): x w y; x >= N*H*W*Cin; w >= Cout*kh*kw*Cin; y >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; bias >= Cout
+ * @check ab_conv2d_dgrad: dt(dtype): dy wt dx addend; dy >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; wt >= Cin*kh*kw*Cout; dx addend >= N*H*W*Cin
+ * @check ab_bn_apply_x3: bf16: out_hi out_lo; y res out out_hi out_lo >= M*C; bnp >= 2*C
+ * @check ab_bn_apply_x3_respl: bf16: res_hi res_lo out_hi out_lo; y res_hi res_lo out out_hi out_lo >= M*C; bnp >= 2*C
+ * @check ab_bn_bwd_x3: bf16: dy_hi dy_lo; dout y dy_hi dy_lo dz_out >= M*C; bnp >= 4*C; dgamma dbeta >= C
+ * @check ab_bn_finalize: part >= nparts*C*2; gamma beta running_mean running_var >= C; bnp >= 4*C
+ * @check ab_bn_eval_params: gamma beta rm rv >= C; bnp >= 4*C
+ * @check ab_col_stats: dt(dtype): x; x >= M*C; part >= ab_col_stats_nparts(M)*C*2
+ * @check ab_bn_relu_maxpool3x3s2_fwd_x3w: bf16: out_hi out_lo; y >= N*H*W*C; bnp >= 2*C; out out_hi out_lo ywin >= N*(H/2)*(W/2)*C; bytes idx >= N*(H/2)*(W/2)*C
+ * @check ab_avgpool_fwd: dt(dtype): x; x >= N*HW*C; out >= N*C
+ * @check ab_image_pad_nhwc4: dt(dtype): out; img_nchw >= N*3*H*W; out >= N*(H+6)*(W+8)*4
+ * @check ab_grad_norm: grad >= n; total_norm >= 1
+ * @check ab_clip_adam: bf16: lp; param grad m v lp >= n; total_norm >= 1
+ * @check ab_clip_adam_x3: bf16: lp_hi lp_lo; param grad m v lp_hi lp_lo >= n; total_norm >= 1
+ * @check ab_pose_assemble: kp3d >= B*22*3; root_joint >= B*3; cam_intr >= B*9; corners_can >= B*24; joints_abs joints_rel >= B*63; corners_abs corners_rel >= B*24; rotmat >= B*9; uvd2d >= B*90
+ * @check ab_pose_loss: kp3d g_kp3d >= B*22*3; root_joint >= B*3; cam_intr >= B*9; corners_can corners_3d >= B*24; joints_3d >= B*63; joints_vis >= B*21; corners_vis >= B*8; hand_views >= nvh*3; scene_views >= nvs*3; j0 j1 >= njp; p0 p1 >= npp; s0 s1 >= nsp; weights8_host >= 8
+ * @check ab_render_batch: bytes samples >= B*96; hand_verts >= B*778*3; order factor >= B*4; inv_affine >= B*6; blur_radius >= B; dt(out_dtype): out_pad; out_pad >= B*(oh+6)*(ow+8)*4; out_chw >= B*3*oh*ow
+ * @check ab_gaussian_blur: u8: rgbx out; rgbx out >= B*W*H*4; radius >= B
+ * @check ab_augment_batch: u8: rgbx; rgbx >= B*W*H*4; order factor >= B*4; inv_affine >= B*6; blur_radius flip >= B; dt(out_dtype): out_pad; out_pad >= B*(oh+6)*(ow+8)*4; out_chw >= B*3*oh*ow; bytes workspace >= ab_augment_workspace_bytes(B,W,H)
+ * @check ab_color_jitter: u8: rgbx out; rgbx out >= B*npix*4; order factor >= B*4; bytes lsum_ws >= B*8
+ * @check ab_jpeg_decode_batch: u8: data out; bytes data >= data_bytes; desc >= n*AB_JPEG_DESC_INTS; segs >= total_segs*4; bytes qtabs >= n*4*64*2; bytes htabs >= n_tables*8*272; bytes workspace >= ab_jpeg_workspace_bytes(total_blocks,total_subseq,plane_bytes,data_bytes,total_segs,n,n_tables)
+ * @check ab_png_unfilter_batch: u8: raw out; desc >= n*AB_PNG_DESC_INTS; status >= 1
+ * @check ab_linear_fwd: x >= M*K; w >= N*K; bias >= N; y >= M*N
+ * @check ab_linear_dgrad: g act_out >= M*N; wt >= K*N; gx >= M*K
+ * @check ab_linear_wgrad: g >= M*N; x >= M*K; dw >= N*K; db >= N
+ * @check ab_nearest_dist: x >= B*P1*3; rot >= B*9; obj_idx >= B; scale shift >= P1; dist >= B*ld; idx_out >= B*P1
+ * @check ab_mano_lbs: pose >= B*48; betas >= B*10; v_template >= 778*3; shapedirs >= 778*3*10; posedirs >= 778*3*135; J_regressor >= 16*778; weights >= 778*16; hands_mean >= 45; verts >= B*778*3; joints >= B*21*3; T_abs >= B*16*16
+ */
+
 #ifdef __cplusplus
 }
 #endif

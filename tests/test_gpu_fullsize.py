@@ -131,3 +131,80 @@ def test_full_size_step_is_deterministic(monkeypatch):
     np.testing.assert_array_equal(w0, w1)
     np.testing.assert_array_equal(l0, l2)
     np.testing.assert_array_equal(w0, w2)
+
+
+def test_full_size_mixed_step_matches_cpu_oracle():
+    """The benchmarked `mixed_real_synth_step` (the reference's MixedDataset batch as ONE training step) against the oracle: B = 64 =
+    40 real 640 x 480 frames served as .jpg files -- decoded on the device (ab_jpeg_decode_batch), flipped / blurred / jittered / cropped by
+    ab_augment_batch -- + 24 samples rendered on the device, through MixedLoader's default schedule (frames of four batches per decode call,
+    the next group on a side stream) and the graph-replayed bf16x3 step; learner_oracle is fed the batch the step trained on.  Same bounds
+    as the synthetic-only test above: losses 3e-4 (step 2: part_ord_loss 1.5e-3), pre-clip gradient norm 1 % / 2 %."""
+    pytest.importorskip("PIL")
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_mixed
+    from artiboost_amd import registry as R
+    from artiboost_amd.assets import SceneAssets
+    from artiboost_amd.criterions import Criterion
+    from artiboost_amd.models import Arch
+    from artiboost_amd.optim import FusedClipAdam
+    from artiboost_amd.realdata import MixedLoader, RealBatcher
+    from artiboost_amd.synth import ArtiBoostLoader
+    from artiboost_amd.train import TrainStep
+    B, size, lr, clip = 64, 256, 5e-5, 0.001
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [size, size], [size // 8, size // 8]
+    random.seed(5); torch.manual_seed(5); np.random.seed(5)
+    src = bench_mixed.JpegFileSource(n=1024)
+    synth_len = int(0.6 * len(src))
+    n_synth = MixedLoader.n_synth_for(B, len(src), synth_len)
+    synth = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], n_synth, synth_len, compute_dtype=torch.float32)
+    synth.prepare()
+    ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.float32), synth, B)      # decode_group 4, decode_ahead: the defaults
+    assert (ml.n_real, ml.n_synth) == (40, 24)
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16x3", INIT_SEED=3)
+    model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
+    crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+    hb = model.model_list[0]
+    opt = FusedClipAdam(model.models_params, lr=lr, max_norm=clip, model=hb)
+    model.train()
+    params0 = {k: v.clone() for k, v in hb.state_dict().items()}
+    it = iter(ml)
+    first = next(it)
+    ts = TrainStep(model, crit, opt, {k: v.clone() for k, v in first.items()}, use_graph=True, renderer=None)
+    leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in params0.items()}
+    names = ms = vs = None
+    b = first
+    for step in range(2):
+        random.seed(100 + step); torch.manual_seed(100 + step)
+        _, losses, _ = ts(b)
+        got = {k: float(v) for k, v in zip(ts.fused.LOSS_KEYS, losses.float().cpu())}
+        gnorm = float(opt.total_norm.cpu())
+        assert b["is_synth"].tolist() == [False] * 40 + [True] * 24
+        xpad = b["image_nhwc4_padded"].float().cpu()
+        batch = {"image": xpad[:, 3:3 + size, 3:3 + size, :3].permute(0, 3, 1, 2).contiguous()}
+        assert float(batch["image"][:40].std()) > 0.05 and float(batch["image"][40:].std()) > 0.05      # both halves carry pictures
+        for k in ("root_joint", "cam_intr", "corners_can", "joints_3d", "corners_3d", "joints_vis", "corners_vis", "obj_transf"):
+            batch[k] = b[k].float().cpu()
+        batch["obj_idx"] = b["obj_idx"].cpu()
+        for v in leaf.values():
+            if getattr(v, "grad", None) is not None:
+                v.grad = None
+        random.seed(100 + step); torch.manual_seed(100 + step)
+        run_stats = {}
+        preds = lo.hybrid_forward(leaf, batch, [size, size], 22, 28, 0, training=True, stats=run_stats)
+        total, ref, _ = lo.criterion(preds, batch, lambdas=cfg["LAMBDAS"][:3])
+        total.backward()
+        if names is None:
+            names = [k for k, v in leaf.items() if v.dtype.is_floating_point and getattr(v, "grad", None) is not None]
+            ms = [torch.zeros_like(leaf[k]) for k in names]
+            vs = [torch.zeros_like(leaf[k]) for k in names]
+        rnorm = float(lo.clip_and_adam([leaf[k].detach() for k in names], [leaf[k].grad for k in names], ms, vs, step + 1, lr=lr, max_norm=clip))
+        for k, v in run_stats.items():
+            leaf[k] = v.detach().clone()
+        for k in ts.fused.LOSS_KEYS:
+            r = float(ref[k])
+            tol = 3e-4 if step == 0 or k != "part_ord_loss" else 1.5e-3
+            assert abs(got[k] - r) <= tol * abs(r) + 1e-9, (step, k, got[k], r)
+        assert abs(gnorm - rnorm) <= (1e-2 if step == 0 else 2e-2) * rnorm, (step, gnorm, rnorm)
+        b = next(it)
