@@ -824,6 +824,166 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_x3_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------- BatchNorm finalize INSIDE the apply passes (round 4)
+// The 76 bn_finalize / bn_bwd_finalize launches of a step (~5 us each: a launch + one dependent reduction over the partial rows) sit on the
+// step's dependency chain between the convolution that leaves the per-tile sums and the elementwise pass that needs (scale, shift).  Where
+// the partial rows are few (<= BNFIN_MAX_ROWS: layers 2 - 4, the head) the apply pass reduces them itself: a workgroup owns a SLICE of 64
+// channels (256 B of every pixel's fp32 row, 128 B of each plane -- whole cache lines) over a strip of pixels, so its prologue reads only
+// rows x 64 x 8 bytes (16 - 128 KB from L2) with 4 row-lanes per channel, fixed summation order (rows r = lane, lane + 4, ... in a double
+// each, then the four lanes in order): deterministic.  The workgroup of pixel strip 0 writes bnp / the running statistics / dgamma, dbeta
+// for its slice.  Arithmetic of the parameters and of the elementwise body: bn_finalize_kernel / bn_apply_x3_kernel / bn_bwd_apply_x3_kernel.
+#define BNFIN_MAX_ROWS 256
+#define BNFIN_SLICE 64
+
+// (s, q) = column sums of part[nparts][C][2] for channel c0 + (tid & 63); valid in every thread after the call
+__device__ __forceinline__ void bnfin_reduce(const float* __restrict__ part, int nparts, int C, int c0, double* sm /* [4][64][2] */, double& s, double& q) {
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    double a = 0, b = 0;
+#pragma unroll 4
+    for (int r = rl; r < nparts; r += 4) { const float2 v = *(const float2*)(part + ((long)r * C + c0 + cl) * 2); a += v.x; b += v.y; }
+    sm[(rl * 64 + cl) * 2] = a; sm[(rl * 64 + cl) * 2 + 1] = b;
+    __syncthreads();
+    s = ((sm[cl * 2] + sm[(64 + cl) * 2]) + sm[(128 + cl) * 2]) + sm[(192 + cl) * 2];
+    q = ((sm[cl * 2 + 1] + sm[(64 + cl) * 2 + 1]) + sm[(128 + cl) * 2 + 1]) + sm[(192 + cl) * 2 + 1];
+}
+
+struct BnFinArgs {
+    const float* part; int nparts; long count; const float* gamma; const float* beta; float eps, momentum;
+    float* running_mean; float* running_var; float* bnp;      // bnp [4][C]: written by the strip-0 workgroups
+};
+
+// RES: 0 no residual / fp32 residual `res`, 1 residual as (hi, lo) planes, 2 `res` is a raw conv output normalised by res_bnp on the fly
+template <int RES>
+__global__ __launch_bounds__(256) void bn_fin_apply_x3_kernel(BnFinArgs fa, const float* __restrict__ y, const float* __restrict__ res,
+                                                              const bf16_t* __restrict__ res_hi, const bf16_t* __restrict__ res_lo,
+                                                              const float* __restrict__ res_bnp, long M, int C, int relu,
+                                                              float* __restrict__ out, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+    __shared__ double sm[4 * 64 * 2];
+    __shared__ float par[2][BNFIN_SLICE];
+    const int nsl = C / BNFIN_SLICE, slice = blockIdx.x % nsl, strip = blockIdx.x / nsl, nstrips = gridDim.x / nsl;
+    const int c0 = slice * BNFIN_SLICE;
+    double s, q; bnfin_reduce(fa.part, fa.nparts, C, c0, sm, s, q);
+    if (threadIdx.x < 64) {
+        const int c = c0 + threadIdx.x;
+        const float g = fa.gamma[c], bt = fa.beta[c];
+        double mean = s / (double)fa.count;
+        double var = q / (double)fa.count - mean * mean; if (var < 0) var = 0;
+        float invstd = (float)(1.0 / sqrt(var + (double)fa.eps));
+        float sc = g * invstd, sh = bt - (float)mean * sc;
+        par[0][threadIdx.x] = sc; par[1][threadIdx.x] = sh;
+        if (strip == 0) {
+            fa.bnp[c] = sc; fa.bnp[C + c] = sh; fa.bnp[2 * C + c] = (float)mean; fa.bnp[3 * C + c] = invstd;
+            if (fa.running_mean) {
+                double unb = fa.count > 1 ? var * (double)fa.count / (double)(fa.count - 1) : var;
+                fa.running_mean[c] = (1.f - fa.momentum) * fa.running_mean[c] + fa.momentum * (float)mean;
+                fa.running_var[c] = (1.f - fa.momentum) * fa.running_var[c] + fa.momentum * (float)unb;
+            }
+        }
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 7, pl = threadIdx.x >> 3;             // 8 channel groups of a pixel, 32 pixels per pass
+    float sc[8], sh[8], sc2[RES == 2 ? 8 : 1], sh2[RES == 2 ? 8 : 1];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = par[0][j * 8 + k]; sh[k] = par[1][j * 8 + k]; }
+    if constexpr (RES == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc2[k] = res_bnp[c0 + j * 8 + k]; sh2[k] = res_bnp[C + c0 + j * 8 + k]; }
+    }
+    for (long p = (long)strip * 32 + pl; p < M; p += (long)nstrips * 32) {
+        const long e = p * C + c0 + j * 8;
+        float f[8], r[8];
+        load8(y + e, f);
+        if constexpr (RES == 1) {
+            const uint4 h4 = *(const uint4*)(res_hi + e), l4 = *(const uint4*)(res_lo + e);
+            const uint32_t hw[4] = {h4.x, h4.y, h4.z, h4.w}, lw[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[2 * k] = __uint_as_float(hw[k] << 16) + __uint_as_float(lw[k] << 16);
+                r[2 * k + 1] = __uint_as_float(hw[k] & 0xffff0000u) + __uint_as_float(lw[k] & 0xffff0000u);
+            }
+        } else if (res) load8(res + e, r);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = f[k] * sc[k] + sh[k];
+            if constexpr (RES == 2) r[k] = r[k] * sc2[k] + sh2[k];
+            if (RES == 1 || res) v += r[k];
+            if (relu) v = fmaxf(v, 0.f);
+            f[k] = v;
+        }
+        if (out) store8(out + e, f);
+        store_split8(hi, lo, e, f);
+    }
+}
+
+// BatchNorm backward, pass 2 with its finalize inside: part[nparts][C][2] = per-tile (sum dz, sum dz * xhat)
+__global__ __launch_bounds__(256) void bn_fin_bwd_apply_x3_kernel(const float* __restrict__ part, int nparts, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, float* __restrict__ bwdp,
+                                                                  const float* __restrict__ dout, const float* __restrict__ out,
+                                                                  const float* __restrict__ y, const float* __restrict__ bnp, int C, long M,
+                                                                  int relu, bf16_t* __restrict__ dy_hi, bf16_t* __restrict__ dy_lo,
+                                                                  float* __restrict__ dz_out, const bf16_t* __restrict__ out_hi) {
+    __shared__ double sm[4 * 64 * 2];
+    __shared__ float par[2][BNFIN_SLICE];
+    const int nsl = C / BNFIN_SLICE, slice = blockIdx.x % nsl, strip = blockIdx.x / nsl, nstrips = gridDim.x / nsl;
+    const int c0 = slice * BNFIN_SLICE;
+    double s, q; bnfin_reduce(part, nparts, C, c0, sm, s, q);
+    if (threadIdx.x < 64) {
+        par[0][threadIdx.x] = (float)s; par[1][threadIdx.x] = (float)q;
+        if (strip == 0) {
+            const int c = c0 + threadIdx.x;
+            dbeta[c] = (float)s; dgamma[c] = (float)q; bwdp[c] = (float)s; bwdp[C + c] = (float)q;
+        }
+    }
+    __syncthreads();
+    const float invM = 1.f / (float)M;
+    const int j = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    float ga[8], sh[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = c0 + j * 8 + k;
+        ga[k] = bnp[c]; sh[k] = bnp[C + c]; mu[k] = bnp[2 * C + c]; is[k] = bnp[3 * C + c];
+        k1[k] = par[0][j * 8 + k] * invM; k2[k] = par[1][j * 8 + k] * invM;
+    }
+    for (long p = (long)strip * 32 + pl; p < M; p += (long)nstrips * 32) {
+        const long e = p * C + c0 + j * 8;
+        float g[8], o[8], yy[8], d[8];
+        load8(dout + e, g);
+        load8(y + e, yy);
+        if (relu == 1) {
+            if (out_hi) {
+                const uint4 h = *(const uint4*)(out_hi + e);
+                const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { o[2 * k] = __uint_as_float(hw[k] << 16); o[2 * k + 1] = __uint_as_float(hw[k] & 0xffff0000u); }
+            } else load8(out + e, o);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool dead = relu == 1 ? !(o[k] > 0.f) : relu == 2 ? !(yy[k] * ga[k] + sh[k] > 0.f) : false;
+            const float dz = dead ? 0.f : g[k];
+            const float xhat = (yy[k] - mu[k]) * is[k];
+            d[k] = ga[k] * (dz - k1[k] - xhat * k2[k]);
+            g[k] = dz;
+        }
+        store_split8(dy_hi, dy_lo, e, d);
+        if (dz_out) store8(dz_out + e, g);
+    }
+}
+
+static bool bnfin_ok(int nparts, int C) {
+    static const int on = getenv("AB_BNFIN_FUSE") ? atoi(getenv("AB_BNFIN_FUSE")) : 1;
+    return on && nparts > 0 && nparts <= BNFIN_MAX_ROWS && C % BNFIN_SLICE == 0;
+}
+// workgroups: every channel slice x enough pixel strips for ~4 workgroups per CU (each pays the prologue once)
+static int bnfin_grid(long M, int C) {
+    const int nsl = C / BNFIN_SLICE;
+    long strips = (M + 31) / 32;
+    const long want = (1024 + nsl - 1) / nsl;
+    if (strips > want) strips = want;
+    if (strips < 1) strips = 1;
+    return (int)(strips * nsl);
+}
+
 // maxpool3x3/2(relu(bn(y))) forward of the split-bf16 path (the stem): maxpool_fwd_kernel<float>'s arithmetic and scan order with 8
 // channels per thread and PFX_ROWS output rows per thread: consecutive output rows share an input row (2ho+1 = 2(ho+1)-1), which the
 // one-row-per-workgroup version read twice (268 MB of input became ~400 MB of reads); here the bottom taps of a window are carried
@@ -1258,6 +1418,28 @@ extern "C" int ab_bn_apply_x3_respl(const float* y, const void* res_hi, const vo
     AB_LAUNCH_CHECK(); return 0;
 }
 
+// BatchNorm finalize + apply in ONE launch (training forward): part [nparts][C][2] are the per-tile (sum, sum of squares) a convolution's
+// epilogue left, count = elements per channel; writes bnp [4][C] and updates the running statistics like ab_bn_finalize, then applies like
+// ab_bn_apply_x3 / _respl (res_hi != NULL) / _resbn (res_bnp != NULL).  AB_ESHAPE when the shape is not taken (nparts > 256 or C % 64:
+// ab_bn_fin_apply_x3_ok says so beforehand) -- the caller then runs ab_bn_finalize + ab_bn_apply_x3*.
+extern "C" int ab_bn_fin_apply_x3_ok(int nparts, int C) { return bnfin_ok(nparts, C) ? 1 : 0; }
+
+extern "C" int ab_bn_fin_apply_x3(const float* part, int nparts, long count, const float* gamma, const float* beta, float eps, float momentum,
+                                  float* running_mean, float* running_var, float* bnp, const float* y, const float* res,
+                                  const void* res_hi, const void* res_lo, const float* res_bnp, long M, int C, int relu, float* out,
+                                  void* out_hi, void* out_lo, void* stream) {
+    if (!part || !gamma || !beta || !bnp || !y || !out_hi || !out_lo || (!res_hi != !res_lo) || (res_bnp && !res) || (res_hi && (res || res_bnp)))
+        return AB_EINVAL;
+    if (!bnfin_ok(nparts, C)) return AB_ESHAPE;
+    BnFinArgs fa = {part, nparts, count, gamma, beta, eps, momentum, running_mean, running_var, bnp};
+    const int grid = bnfin_grid(M, C);
+    hipStream_t st = as_stream(stream);
+    if (res_hi) bn_fin_apply_x3_kernel<1><<<grid, 256, 0, st>>>(fa, y, nullptr, (const bf16_t*)res_hi, (const bf16_t*)res_lo, nullptr, M, C, relu, out, (bf16_t*)out_hi, (bf16_t*)out_lo);
+    else if (res_bnp) bn_fin_apply_x3_kernel<2><<<grid, 256, 0, st>>>(fa, y, res, nullptr, nullptr, res_bnp, M, C, relu, out, (bf16_t*)out_hi, (bf16_t*)out_lo);
+    else bn_fin_apply_x3_kernel<0><<<grid, 256, 0, st>>>(fa, y, res, nullptr, nullptr, nullptr, M, C, relu, out, (bf16_t*)out_hi, (bf16_t*)out_lo);
+    AB_LAUNCH_CHECK(); return 0;
+}
+
 // ab_bn_bwd / ab_bn_bwd_apply with dy as split planes: nparts_given = 0 runs the reduction pass into `part`
 // ([ab_col_stats_nparts(M)][C][2]); > 0 takes `part` as already reduced per-tile sums (see ab_bn_bwd_apply).
 extern "C" int ab_bn_bwd_x3(const float* dout, const void* out, int out_is_hi_plane, const float* y, const float* bnp, long M, int C,
@@ -1276,6 +1458,11 @@ extern "C" int ab_bn_bwd_x3(const float* dout, const void* out, int out_is_hi_pl
         const int cs = C / ysl, rl = 256 / (cs / 4); const size_t sh = (size_t)rl * cs * 2 * 4;
         bn_bwd_reduce_kernel<float><<<dim3(np, ysl), 256, sh, st>>>(dout, out_f, y, bnp, M, C, relu, red_rows(M), part, nullptr, 0, 0, out_h);
         AB_LAUNCH_CHECK();
+    }
+    if (bnfin_ok(np, C)) {          // few partial rows: the apply pass reduces them itself (no finalize launch)
+        bn_fin_bwd_apply_x3_kernel<<<bnfin_grid(M, C), 256, 0, st>>>(part, np, dgamma, dbeta, bwdp, dout, out_f, y, bnp, C, M, relu, (bf16_t*)dy_hi,
+                                                                     (bf16_t*)dy_lo, dz_out, out_h);
+        AB_LAUNCH_CHECK(); return 0;
     }
     launch_bn_bwd_finalize(part, np, C, dgamma, dbeta, bwdp, st);
     AB_LAUNCH_CHECK();

@@ -73,6 +73,12 @@ def checks_for(name, ps, clauses):
     ptrs = {pn: ty for ty, pn in ps if ty.endswith("*")}
     ints = {pn for ty, pn in ps if not ty.endswith("*")}
     lines = []
+    strided = set()
+    for cl in clauses:                          # `strided: names` -- arguments addressed through a row-pitch argument: views are legitimate
+        m = re.match(r"^strided:\s*(.+)$", cl)
+        if m:
+            strided |= set(m.group(1).split())
+    assert strided <= set(ptrs), f"{name}: @check strided names {sorted(strided - set(ptrs))}, not pointer arguments"
     for pn, ty in ptrs.items():
         base = ty.replace("const", "").replace("*", "").strip()
         dt = TYPED.get(base, "-1")
@@ -80,10 +86,12 @@ def checks_for(name, ps, clauses):
         if where == "host":
             lines.append(f'ck_host(OP, "{pn}", {pn});')
         elif where == "dev":
-            lines.append(f'ck_dev(OP, "{pn}", {pn}, (int){dt});')
-        else:
+            lines.append(f'ck_dev(OP, "{pn}", {pn}, (int){dt}, {"false" if pn in strided else "true"});')
+        elif pn not in strided:
             lines.append(f'ck_contig(OP, "{pn}", {pn});')
     for cl in clauses:
+        if cl.startswith("strided:"):
+            continue
         m = re.match(r"^dt\((\w+)\):\s*(.+)$", cl)
         if m:
             assert m.group(1) in ints, f"{name}: @check dt({m.group(1)}) is not an integer argument"
@@ -162,11 +170,11 @@ static inline bool has(const OptT& t) { return t.has_value() && t->defined(); }
 static inline void ck_contig(const char* op, const char* a, const OptT& t) {
     if (has(t)) TORCH_CHECK(t->is_contiguous(), op, ": argument '", a, "' must be contiguous (the kernels take raw buffers)");
 }
-static inline void ck_dev(const char* op, const char* a, const OptT& t, int dt) {
+static inline void ck_dev(const char* op, const char* a, const OptT& t, int dt, bool contiguous) {
     if (!has(t)) return;
     TORCH_CHECK(t->is_cuda(), op, ": argument '", a, "' must be a HIP tensor, got a ", t->device().str(), " tensor");
     TORCH_CHECK(t->get_device() == c10::hip::current_device(), op, ": argument '", a, "' lives on device ", t->get_device(), ", the current device is ", (int)c10::hip::current_device());
-    TORCH_CHECK(t->is_contiguous(), op, ": argument '", a, "' must be contiguous (the kernels take raw buffers)");
+    if (contiguous) TORCH_CHECK(t->is_contiguous(), op, ": argument '", a, "' must be contiguous (the kernel takes it as a raw buffer without a pitch)");
     if (dt >= 0) TORCH_CHECK((int)t->scalar_type() == dt, op, ": argument '", a, "' must be ", c10::toString((at::ScalarType)dt), ", got ", c10::toString(t->scalar_type()));
 }
 static inline void ck_host(const char* op, const char* a, const OptT& t) {

@@ -643,6 +643,35 @@ def bn_apply_x3(y, bnp, res=None, relu=True, want_f32=False, res_bnp=None):
     return o
 
 
+def bn_fin_apply_x3_ok(part, C):
+    """True when ab_bn_fin_apply_x3 takes this BatchNorm (few partial rows, C % 64 == 0): finalize and apply in one launch."""
+    return part is not None and bool(L.lib().ab_bn_fin_apply_x3_ok(L.i(part.shape[0]), L.i(C)))
+
+
+def bn_fin_apply_x3(y, part, count, gamma, beta, running_mean=None, running_var=None, res=None, relu=True, want_f32=False, res_bnp=None,
+                    eps=1e-5, momentum=0.1):
+    """bn_finalize + bn_apply_x3 in ONE launch (see ab_bn_fin_apply_x3) -> (activation as bn_apply_x3 returns it, bnp [4, C])."""
+    C = y.shape[-1]
+    M = y.numel() // C
+    bnp = torch.empty((4, C), dtype=torch.float32, device=y.device)
+    sp = torch.empty((2,) + tuple(y.shape), dtype=torch.bfloat16, device=y.device)
+    o = torch.empty_like(y) if want_f32 else None
+    rh = rl = rf = None
+    if res is not None and res.dtype == torch.bfloat16:
+        assert res_bnp is None
+        rh, rl = res[0], res[1]
+    else:
+        rf = res
+    L.check(L.lib().ab_bn_fin_apply_x3(L.ptr(part), L.i(part.shape[0]), L.l(count), L.ptr(gamma), L.ptr(beta), L.f(eps), L.f(momentum),
+                                       L.ptr(running_mean), L.ptr(running_var), L.ptr(bnp), L.ptr(y), L.ptr(rf), L.ptr(rh), L.ptr(rl),
+                                       L.ptr(res_bnp), L.l(M), L.i(C), L.i(1 if relu else 0), L.ptr(o), L.ptr(sp[0]), L.ptr(sp[1]), L.stream()),
+            "ab_bn_fin_apply_x3")
+    if o is None:
+        return sp, bnp
+    o._ab_split = sp
+    return o, bnp
+
+
 def bn_bwd_x3(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, part=None, premasked=False):
     """As bn_bwd on fp32 tensors, with dy returned as split planes [2, *y.shape] (-> dy [, dz fp32]).
     premasked (with part): `dout` is already the masked gradient dz and `part` its reduction (conv2d_dgrad_x3(bn=...))."""

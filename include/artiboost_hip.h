@@ -197,6 +197,17 @@ int ab_bn_apply_x3_resbn(const float* y, const float* res_y, const float* bnp, c
 /* ... the residual given as its (hi, lo) bf16 planes (a block input that exists only as the planes its producer wrote). */
 int ab_bn_apply_x3_respl(const float* y, const void* res_hi, const void* res_lo, const float* bnp, long M, int C, int relu,
                          float* out, void* out_hi, void* out_lo, void* stream);
+/* BatchNorm finalize + apply in ONE launch for the training forward (round 4; nn.BatchNorm2d in train mode, resnet.py:85-101 /
+ * simplebaseline.py:152-175): part [nparts][C][2] = the per-tile (sum, sum of squares) of a convolution's epilogue, count = elements per
+ * channel.  Writes bnp [4][C] and updates the running statistics exactly like ab_bn_finalize, then applies like ab_bn_apply_x3
+ * (res fp32 or NULL), ab_bn_apply_x3_respl (res_hi / res_lo) or ab_bn_apply_x3_resbn (res + res_bnp).  Taken when
+ * ab_bn_fin_apply_x3_ok(nparts, C) (nparts <= 256, C % 64 == 0); AB_ESHAPE otherwise (run ab_bn_finalize + ab_bn_apply_x3*).
+ * ab_bn_bwd_x3 takes the same route internally for its finalize.                                                              */
+int ab_bn_fin_apply_x3_ok(int nparts, int C);
+int ab_bn_fin_apply_x3(const float* part, int nparts, long count, const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, float* bnp, const float* y, const float* res, const void* res_hi,
+                       const void* res_lo, const float* res_bnp, long M, int C, int relu, float* out, void* out_hi, void* out_lo,
+                       void* stream);
 /* out (relu == 1): the stored activation as fp32, or -- out_is_hi_plane != 0 -- the hi plane (bf16) of its split form: the
  * ReLU mask only needs the sign, and the plane is half the bytes                                                     */
 int ab_bn_bwd_x3(const float* dout, const void* out, int out_is_hi_plane, const float* y, const float* bnp, long M, int C,
@@ -484,6 +495,7 @@ int ab_mano_lbs(const float* pose, const float* betas, const float* v_template, 
  *   bytes names >= expr  ... at least `expr` bytes (workspaces)
  *   bf16|u8|i32|f32: names     dtype of `void*` arguments
  *   dt(code): names            dtype given by the op's AB_DT_* argument `code`
+ *   strided: names             arguments the op addresses through a row-pitch argument (ld*, *_stride): non-contiguous views are accepted
  * A violated clause raises RuntimeError naming the op, the argument and both sizes; nothing is launched.
  * @check ab_softargmax3d_fwd: dt(dtype): logits; logits >= B*H*W*C*DP; part >= B*ab_softargmax3d_ntiles(H,W)*C*8; uvd >= B*C*3; conf >= B*C; stat >= B*C*2
  * @check ab_softargmax3d_bwd: dt(dtype): logits dlogits; logits dlogits >= B*H*W*C*DP; uvd g_uvd >= B*C*3; conf g_conf >= B*C; stat >= B*C*2
@@ -503,6 +515,7 @@ int ab_mano_lbs(const float* pose, const float* betas, const float* v_template, 
  * @check ab_conv2d_dgrad: dt(dtype): dy wt dx addend; dy >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; wt >= Cin*kh*kw*Cout; dx addend >= N*H*W*Cin
  * @check ab_bn_apply_x3: bf16: out_hi out_lo; y res out out_hi out_lo >= M*C; bnp >= 2*C
  * @check ab_bn_apply_x3_respl: bf16: res_hi res_lo out_hi out_lo; y res_hi res_lo out out_hi out_lo >= M*C; bnp >= 2*C
+ * @check ab_bn_fin_apply_x3: bf16: res_hi res_lo out_hi out_lo; part >= nparts*C*2; gamma beta running_mean running_var >= C; bnp >= 4*C; res_bnp >= 2*C; y res res_hi res_lo out out_hi out_lo >= M*C
  * @check ab_bn_bwd_x3: bf16: dy_hi dy_lo; dout y dy_hi dy_lo dz_out >= M*C; bnp >= 4*C; dgamma dbeta >= C
  * @check ab_bn_finalize: part >= nparts*C*2; gamma beta running_mean running_var >= C; bnp >= 4*C
  * @check ab_bn_eval_params: gamma beta rm rv >= C; bnp >= 4*C
@@ -513,8 +526,8 @@ int ab_mano_lbs(const float* pose, const float* betas, const float* v_template, 
  * @check ab_grad_norm: grad >= n; total_norm >= 1
  * @check ab_clip_adam: bf16: lp; param grad m v lp >= n; total_norm >= 1
  * @check ab_clip_adam_x3: bf16: lp_hi lp_lo; param grad m v lp_hi lp_lo >= n; total_norm >= 1
- * @check ab_pose_assemble: kp3d >= B*22*3; root_joint >= B*3; cam_intr >= B*9; corners_can >= B*24; joints_abs joints_rel >= B*63; corners_abs corners_rel >= B*24; rotmat >= B*9; uvd2d >= B*90
- * @check ab_pose_loss: kp3d g_kp3d >= B*22*3; root_joint >= B*3; cam_intr >= B*9; corners_can corners_3d >= B*24; joints_3d >= B*63; joints_vis >= B*21; corners_vis >= B*8; hand_views >= nvh*3; scene_views >= nvs*3; j0 j1 >= njp; p0 p1 >= npp; s0 s1 >= nsp; weights8_host >= 8
+ * @check ab_pose_assemble: strided: box6d; kp3d >= B*22*3; root_joint >= B*3; cam_intr >= B*9; corners_can >= B*24; joints_abs joints_rel >= B*63; corners_abs corners_rel >= B*24; rotmat >= B*9; uvd2d >= B*90
+ * @check ab_pose_loss: strided: box6d g_box6d; kp3d g_kp3d >= B*22*3; root_joint >= B*3; cam_intr >= B*9; corners_can corners_3d >= B*24; joints_3d >= B*63; joints_vis >= B*21; corners_vis >= B*8; hand_views >= nvh*3; scene_views >= nvs*3; j0 j1 >= njp; p0 p1 >= npp; s0 s1 >= nsp; weights8_host >= 8
  * @check ab_render_batch: bytes samples >= B*96; hand_verts >= B*778*3; order factor >= B*4; inv_affine >= B*6; blur_radius >= B; dt(out_dtype): out_pad; out_pad >= B*(oh+6)*(ow+8)*4; out_chw >= B*3*oh*ow
  * @check ab_gaussian_blur: u8: rgbx out; rgbx out >= B*W*H*4; radius >= B
  * @check ab_augment_batch: u8: rgbx; rgbx >= B*W*H*4; order factor >= B*4; inv_affine >= B*6; blur_radius flip >= B; dt(out_dtype): out_pad; out_pad >= B*(oh+6)*(ow+8)*4; out_chw >= B*3*oh*ow; bytes workspace >= ab_augment_workspace_bytes(B,W,H)
@@ -524,7 +537,9 @@ int ab_mano_lbs(const float* pose, const float* betas, const float* v_template, 
  * @check ab_linear_fwd: x >= M*K; w >= N*K; bias >= N; y >= M*N
  * @check ab_linear_dgrad: g act_out >= M*N; wt >= K*N; gx >= M*K
  * @check ab_linear_wgrad: g >= M*N; x >= M*K; dw >= N*K; db >= N
- * @check ab_nearest_dist: x >= B*P1*3; rot >= B*9; obj_idx >= B; scale shift >= P1; dist >= B*ld; idx_out >= B*P1
+ * @check ab_nearest_dist: strided: dist; x >= B*P1*3; rot >= B*9; obj_idx >= B; scale shift >= P1; idx_out >= B*P1
+ * @check ab_pose_loss_sym: strided: box6d g_box6d; kp3d g_kp3d >= B*22*3; root_joint >= B*3; cam_intr >= B*9
+ * @check ab_linear_fused: strided: residual y; x >= M*K; w >= N*K; bias scale shift >= N
  * @check ab_mano_lbs: pose >= B*48; betas >= B*10; v_template >= 778*3; shapedirs >= 778*3*10; posedirs >= 778*3*135; J_regressor >= 16*778; weights >= 778*16; hands_mean >= 45; verts >= B*778*3; joints >= B*21*3; T_abs >= B*16*16
  */
 
