@@ -827,12 +827,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_x3_kernel(const float* __res
 // ---------------------------------------------------------------- BatchNorm finalize INSIDE the apply passes (round 4)
 // The 76 bn_finalize / bn_bwd_finalize launches of a step (~5 us each: a launch + one dependent reduction over the partial rows) sit on the
 // step's dependency chain between the convolution that leaves the per-tile sums and the elementwise pass that needs (scale, shift).  Where
-// the partial rows are few (<= BNFIN_MAX_ROWS: layers 2 - 4, the head) the apply pass reduces them itself: a workgroup owns a SLICE of 64
+// the partial rows are few (<= BNFIN_MAX_ROWS = 64: layers 3 - 4; measured per step at B = 64: off 9.72 ms, rows <= 32 9.69, <= 64 9.66, <= 256 9.73 --
+// at 256 rows the prologue's 64 dependent row loads per lane cost more than the launch they replace) the apply pass reduces them itself: a workgroup owns a SLICE of 64
 // channels (256 B of every pixel's fp32 row, 128 B of each plane -- whole cache lines) over a strip of pixels, so its prologue reads only
 // rows x 64 x 8 bytes (16 - 128 KB from L2) with 4 row-lanes per channel, fixed summation order (rows r = lane, lane + 4, ... in a double
 // each, then the four lanes in order): deterministic.  The workgroup of pixel strip 0 writes bnp / the running statistics / dgamma, dbeta
 // for its slice.  Arithmetic of the parameters and of the elementwise body: bn_finalize_kernel / bn_apply_x3_kernel / bn_bwd_apply_x3_kernel.
-#define BNFIN_MAX_ROWS 256
+#define BNFIN_MAX_ROWS 64
 #define BNFIN_SLICE 64
 
 // (s, q) = column sums of part[nparts][C][2] for channel c0 + (tid & 63); valid in every thread after the call
@@ -972,7 +973,8 @@ __global__ __launch_bounds__(256) void bn_fin_bwd_apply_x3_kernel(const float* _
 
 static bool bnfin_ok(int nparts, int C) {
     static const int on = getenv("AB_BNFIN_FUSE") ? atoi(getenv("AB_BNFIN_FUSE")) : 1;
-    return on && nparts > 0 && nparts <= BNFIN_MAX_ROWS && C % BNFIN_SLICE == 0;
+    static const int maxrows = getenv("AB_BNFIN_ROWS") ? atoi(getenv("AB_BNFIN_ROWS")) : BNFIN_MAX_ROWS;
+    return on && nparts > 0 && nparts <= maxrows && nparts <= BNFIN_MAX_ROWS && C % BNFIN_SLICE == 0;
 }
 // workgroups: every channel slice x enough pixel strips for ~4 workgroups per CU (each pays the prologue once)
 static int bnfin_grid(long M, int C) {
@@ -1420,7 +1422,7 @@ extern "C" int ab_bn_apply_x3_respl(const float* y, const void* res_hi, const vo
 
 // BatchNorm finalize + apply in ONE launch (training forward): part [nparts][C][2] are the per-tile (sum, sum of squares) a convolution's
 // epilogue left, count = elements per channel; writes bnp [4][C] and updates the running statistics like ab_bn_finalize, then applies like
-// ab_bn_apply_x3 / _respl (res_hi != NULL) / _resbn (res_bnp != NULL).  AB_ESHAPE when the shape is not taken (nparts > 256 or C % 64:
+// ab_bn_apply_x3 / _respl (res_hi != NULL) / _resbn (res_bnp != NULL).  AB_ESHAPE when the shape is not taken (nparts > 64 or C % 64:
 // ab_bn_fin_apply_x3_ok says so beforehand) -- the caller then runs ab_bn_finalize + ab_bn_apply_x3*.
 extern "C" int ab_bn_fin_apply_x3_ok(int nparts, int C) { return bnfin_ok(nparts, C) ? 1 : 0; }
 

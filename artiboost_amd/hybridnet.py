@@ -449,7 +449,7 @@ class HybridNet:
         """feeds_conv / keep_f32 (bf16x3 only): the activation feeds a convolution (it is written as split planes by this
         pass) / is also needed in fp32 (residual input, ReLU mask of the backward, pooling)."""
         if (self.x3 and feeds_conv and self.training and not self._frozen(prefix) and K.bn_fin_apply_x3_ok(stats_part, y.shape[-1])):
-            p = self.p      # few partial rows (layers 2 - 4, the head): the apply pass finalizes the statistics itself, one launch less
+            p = self.p      # few partial rows (layers 3 - 4): the apply pass finalizes the statistics itself, one launch less
             return K.bn_fin_apply_x3(y, stats_part, count, p.view(prefix + ".weight"), p.view(prefix + ".bias"), p.stat(prefix + ".running_mean"),
                                      p.stat(prefix + ".running_var"), res=res, relu=relu, want_f32=keep_f32, res_bnp=res_bnp)
         bnp = self._bn_params(prefix, stats_part, count)

@@ -201,7 +201,7 @@ int ab_bn_apply_x3_respl(const float* y, const void* res_hi, const void* res_lo,
  * simplebaseline.py:152-175): part [nparts][C][2] = the per-tile (sum, sum of squares) of a convolution's epilogue, count = elements per
  * channel.  Writes bnp [4][C] and updates the running statistics exactly like ab_bn_finalize, then applies like ab_bn_apply_x3
  * (res fp32 or NULL), ab_bn_apply_x3_respl (res_hi / res_lo) or ab_bn_apply_x3_resbn (res + res_bnp).  Taken when
- * ab_bn_fin_apply_x3_ok(nparts, C) (nparts <= 256, C % 64 == 0); AB_ESHAPE otherwise (run ab_bn_finalize + ab_bn_apply_x3*).
+ * ab_bn_fin_apply_x3_ok(nparts, C) (nparts <= 64, C % 64 == 0); AB_ESHAPE otherwise (run ab_bn_finalize + ab_bn_apply_x3*).
  * ab_bn_bwd_x3 takes the same route internally for its finalize.                                                              */
 int ab_bn_fin_apply_x3_ok(int nparts, int C);
 int ab_bn_fin_apply_x3(const float* part, int nparts, long count, const float* gamma, const float* beta, float eps, float momentum,
