@@ -449,3 +449,48 @@ def test_vgpr_streamed_weights_probe_kernel_is_correct():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "--timeout", "900", "-k",
                         "fwd_x3 or dgrad_wgrad or bn_fused"], env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("C,rows", [(256, 64), (512, 32), (64, 7)])
+@pytest.mark.parametrize("resmode", ["none", "f32", "planes", "resbn"])
+def test_bn_finalize_inside_the_apply_passes(C, rows, resmode):
+    """ab_bn_fin_apply_x3 (round 4: the statistics are finalized in the apply pass's prologue, one launch instead of two) == ab_bn_finalize +
+    ab_bn_apply_x3* : same (scale, shift, mean, invstd) and running statistics to 1e-6 (the partial rows are summed in another fixed order),
+    the same activation planes; and ab_bn_bwd_x3 given few partial rows (its in-kernel finalize) == the same call with the reduction redone
+    by its own reduce + finalize launches."""
+    from artiboost_amd import kernels as K
+    g = torch.Generator().manual_seed(C + rows)
+    N, H, W = rows, 6, 4                                         # one partial row per image
+    y = (torch.randn(N, H, W, C, generator=g) * 2 + 0.3).cuda()
+    part = torch.stack([y.reshape(N, -1, C).sum(1), (y * y).reshape(N, -1, C).sum(1)], -1).contiguous()
+    assert K.bn_fin_apply_x3_ok(part, C) and not K.bn_fin_apply_x3_ok(torch.empty(65, C, 2), C)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    count = N * H * W
+    res = res_bnp = None
+    if resmode == "f32":
+        res = torch.randn(N, H, W, C, generator=g).cuda()
+    elif resmode == "planes":
+        res = K.split(torch.randn(N, H, W, C, generator=g).cuda())
+    elif resmode == "resbn":
+        res = torch.randn(N, H, W, C, generator=g).cuda()
+        res_bnp = torch.randn(4, C, generator=g).cuda()
+    rm1, rv1, rm2, rv2 = torch.zeros(C).cuda(), torch.ones(C).cuda(), torch.zeros(C).cuda(), torch.ones(C).cuda()
+    bnp_ref = K.bn_finalize(part, count, gamma, beta, rm1, rv1)
+    ref = K.bn_apply_x3(y, bnp_ref, res=res, relu=True, want_f32=True, res_bnp=res_bnp)
+    got, bnp = K.bn_fin_apply_x3(y, part, count, gamma, beta, rm2, rv2, res=res, relu=True, want_f32=True, res_bnp=res_bnp)
+    torch.testing.assert_close(bnp, bnp_ref, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(rm2, rm1, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(rv2, rv1, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(got, ref, rtol=2e-6, atol=2e-6)
+    sp, spr = got._ab_split.float(), ref._ab_split.float()
+    torch.testing.assert_close(sp[0] + sp[1], spr[0] + spr[1], rtol=2e-6, atol=2e-6)
+    # backward: few partial rows handed over (in-kernel finalize) vs the call that reduces for itself
+    dz = torch.randn(N, H, W, C, generator=g).cuda()
+    xhat = (y - bnp_ref[2]) * bnp_ref[3]
+    bpart = torch.stack([dz.reshape(N, -1, C).sum(1), (dz * xhat).reshape(N, -1, C).sum(1)], -1).contiguous()
+    dg1, db1, dg2, db2 = (torch.zeros(C).cuda() for _ in range(4))
+    dy1 = K.bn_bwd_x3(dz, None, y, bnp_ref, dg1, db1, relu=False, part=bpart)
+    dy2 = K.bn_bwd_x3(dz, None, y, bnp_ref, dg2, db2, relu=False)
+    torch.testing.assert_close(dg1, dg2, rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(db1, db2, rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(dy1.float().sum(0), dy2.float().sum(0), rtol=1e-4, atol=2e-5)
