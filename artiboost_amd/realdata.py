@@ -377,7 +377,8 @@ class MixedLoader:
 
     def update(self):
         self.real_len = len(self.real.src)
-        self.synth_len = self.synth.epoch_len if (self.synth is not None and self.synth.use_synth and self.synth.epoch is not None) else 0
+        # the synthetic loader's NOMINAL epoch length (all ranks, before trimming to whole batches): the number n_synth_for() was given
+        self.synth_len = self.synth.synth_len if (self.synth is not None and self.synth.use_synth and self.synth.epoch is not None) else 0
         tot = self.real_len + self.synth_len
         self.n_real = self.B if self.synth_len == 0 else int(round(self.B * self.real_len / tot))
         self.n_synth = self.B - self.n_real

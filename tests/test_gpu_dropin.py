@@ -190,3 +190,32 @@ def test_train_script_two_ranks_on_a_shared_device(tmp_path):
     assert len(lines) == 2 and "on 2 GPU(s)" in lines[-1] and "final_loss" in lines[-1]
     exp = [d for d in os.listdir(tmp_path / "exp") if d.startswith("two_")]
     assert len(exp) == 1            # only rank 0 records
+
+
+def test_train_script_mixes_a_real_ho3d_download_with_the_synthetic_share(tmp_path):
+    """train/train_artiboost.py with DATA_ROOT pointing at a (miniature) HO3D v2 download: the reference's MixedDataset loop -- every batch
+    holds real frames (read by datasets.HO3D, decoded from their .png files and augmented on the device) and synthetic samples rendered for
+    the same step; two epochs, the TEST pass over the real evaluation split, checkpoint."""
+    import subprocess
+    import yaml
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ho3d_fake_tree as T
+    data = tmp_path / "data"
+    T.build(str(data), seed=7)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["TRAIN"]["EPOCH"] = 2
+    cfg["DATASET"]["TRAIN"]["DATA_ROOT"] = cfg["DATASET"]["TEST"]["DATA_ROOT"] = str(data)
+    cfg["DATA_PRESET"].update(USE_CACHE=True, FILTER_NO_CONTACT=False, FILTER_THRESH=0.0)
+    y = tmp_path / "cfg.yaml"
+    y.write_text(yaml.dump(cfg))
+    cmd = [sys.executable, os.path.join(ROOT, "train", "train_artiboost.py"), "--cfg", str(y), "--gpu_id", "0", "--gpu_render_id", "0",
+           "--batch_size", "8", "--exp_id", "m", "--snapshot", "1", "--synth_len", "8", "--size", "64", "--test_freq", "2", "--workers", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("epoch ")]
+    assert len(lines) == 2 and "4 real + 4 synthetic per batch of 8" in lines[-1] and "final_loss" in lines[-1]
+    tests_ = [l for l in out.stdout.splitlines() if l.startswith("test ")]
+    assert len(tests_) == 1 and "5 frames of DATASET.TEST (HO3D)" in tests_[0]
+    exp = [d for d in os.listdir(tmp_path / "exp") if d.startswith("m_")]
+    assert (tmp_path / "exp" / exp[0] / "checkpoints" / "checkpoint" / "HybridBaseline.pth.tar").exists()
+    assert os.path.isdir(tmp_path / "common" / "cache" / "HO3D")

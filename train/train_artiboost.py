@@ -152,11 +152,29 @@ def main():
                            "EPOCH": cfg["TRAIN"]["EPOCH"]})
     train_data = builder.build_dataset(cfg["DATASET"]["TRAIN"], preset_cfg=cfg["DATA_PRESET"])
     arg_extra = data_generation_manager_parse()
+    # A real training set that is present (DATA_ROOT holds the download): the reference's MixedDataset (mixed_dataset.py:5-37) -- every batch
+    # holds its share of real frames (decoded and augmented on the device) and of the epoch's synthetic samples.  The synthetic loader then
+    # renders only ITS share of the per-rank batch; realdata.MixedLoader assembles the batches.
+    from artiboost_amd.realdata import MixedLoader, RealBatcher, StreamPrefetcher
+    real_len = len(train_data)
+    synth_share = per_rank
+    if real_len > 0:
+        total_synth = int(synth_len) if synth_len else int(cfg["MANAGER"].get("SYNTH_FACTOR", 0.0) * real_len)
+        synth_share = MixedLoader.n_synth_for(per_rank, real_len, total_synth) if total_synth > 0 else 0
+        if synth_share == 0:
+            raise SystemExit("a real training set with no synthetic share (SYNTH_FACTOR 0): not the ArtiBoost loop; use a plain training script")
     loader = ArtiBoostLoader(train_data, arg=arg, arg_extra=arg_extra, cfg=cfg["MANAGER"], cfg_dataset=cfg["DATASET"],
-                             cfg_preset=cfg["DATA_PRESET"], time_f=time_f, batch_size=per_rank, shuffle=True,
+                             cfg_preset=cfg["DATA_PRESET"], time_f=time_f, batch_size=synth_share, shuffle=True,
+                             **({"synth_len": total_synth} if real_len > 0 else {}),
                              num_workers=int(arg.workers), pin_memory=True, drop_last=arg.drop_last, collate_fn=ho_collate,
                              random_seed=seed, rank=rank, world_size=world,
                              compute_dtype=getattr(getattr(model.model_list[0], "net", None), "dtype", torch.float32))
+    mixed = None
+    if real_len > 0:
+        tr = cfg["DATASET"]["TRAIN"]
+        mixed = MixedLoader(RealBatcher(train_data, cfg["DATA_PRESET"], aug=bool(tr.get("AUG", False)), aug_param=tr.get("AUG_PARAM") or None, device=dev,
+                                        compute_dtype=loader.dtype, seed=seed, num_workers=int(arg.workers) or None),
+                            loader, per_rank, seed=seed, rank=rank, world_size=world)
     epoch0 = 0
     if arg.resume:
         epoch0 = recorder.resume_checkpoints(model, optimizer, scheduler, arg.resume, resume_epoch=arg.resume_epoch or None)
@@ -220,6 +238,40 @@ def main():
                 raise SystemExit("empty epoch: SYNTH_LEN / the real set give fewer samples than one batch per rank")
             model.train()
             evaluator.reset_all()
+            if mixed is not None:
+                # real + synthetic batches: assembled one batch ahead on a side stream (the role of the reference's DataLoader workers),
+                # the graph-replayed step copies each into its static inputs
+                mixed.update()
+                t0 = time.time()
+                nb = 0
+                for batch in StreamPrefetcher(mixed):
+                    if ts is None:
+                        ts = TrainStep(model, criterion, optimizer, {k: v.clone() for k, v in batch.items()}, use_graph=True, renderer=None,
+                                       dist_group=torch.distributed.group.WORLD if world > 1 else None)
+                        rec = DeferredEpochMetrics(ts, len(mixed), evaluator) if ts.fused is not None else None
+                    preds, losses, _ = ts(batch)
+                    nb += 1
+                    if rec is not None:
+                        rec.collect()
+                    else:
+                        evaluator.feed_all(ts.predictions(), ts.static, losses)
+                        summarizer.summarize_losses(ts.fused.losses_dict() if ts.fused is not None else losses)
+                if rec is not None:
+                    rec.flush(evaluator, summarizer=summarizer)
+                torch.cuda.synchronize()
+                dt = time.time() - t0
+                scheduler.step()
+                loader.step_eval(epoch_idx=epoch_idx, evaluator=evaluator)
+                recorder.record_checkpoints(model, optimizer, scheduler, epoch_idx, arg.snapshot)
+                recorder.record_evaluator(evaluator, epoch_idx, TrainMode.TRAIN)
+                summarizer.summarize_evaluator(evaluator, epoch_idx, train_mode=TrainMode.TRAIN)
+                recorder.record_artiboost_loader(loader, epoch_idx)
+                if rank == 0:
+                    print(f"epoch {epoch_idx}: {nb * per_rank * world / dt:8.0f} samples/s on {world} GPU(s), {mixed.n_real} real + {mixed.n_synth} synthetic "
+                          f"per batch of {per_rank} | {evaluator}", flush=True)
+                if arg.test_freq > 0 and epoch_idx % arg.test_freq == arg.test_freq - 1:
+                    test_pass(epoch_idx)
+                continue
             if ts is None:
                 static = loader.new_static_batch()
                 loader.load_batch(static, 0)
