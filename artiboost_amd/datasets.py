@@ -5,7 +5,7 @@ HO3D / DexYCB are downloads (README.md:73-91 of the reference) and are not in th
 resolve the reference's YAML (`TYPE: HO3D`, `DATA_ROOT: ./data`, ...) to an EMPTY real set when the data root is absent --
 ArtiBoostLoader then trains on the synthetic share alone.  When `DATA_ROOT/HO3D` exists, `HO3D` reads it (round 4: the v2 download's
 own layout, ho3d.py:55-190) and serves the getters of `realdata.HOdataSource`, the .png frames as FILE BYTES for the device decode path;
-HO3D v3 / DexYCB still raise if their root is given (their readers are not part of this build), so a misconfigured path is not
+HO3D v3 is the same reader on .jpg frames; DexYCB still raises if its root is given (its reader is not part of this build), so a misconfigured path is not
 silently ignored."""
 import hashlib
 import json
@@ -73,7 +73,7 @@ class HO3D(_DownloadedSet):
     w.r.t. the bbox-centred canonical mesh: :405-438, canonical corners :476-485); `get_annots` packs what HOdata.__getitem__ reads.
     The annotation index is cached next to the reference's own cache (common/cache/HO3D/<md5 of the same identifier>.ab.pkl, own format:
     arrays only).  Not built: SPLIT_MODE v1 / v2 (hard-coded sequence lists of ho3dutils), FILTER_NO_CONTACT (needs MANO_RIGHT.pkl)."""
-    name, subdir = "HO3D", "HO3D"
+    name, subdir, ext = "HO3D", "HO3D", ".png"
     raw_size = (640, 480)
     REORDER = np.array([0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8, 9, 20])      # ho3d.py:41
     CAM_EXTR = np.diag([1.0, -1.0, -1.0]).astype(np.float32)                                            # ho3d.py:44-49 (rotation part)
@@ -151,7 +151,7 @@ class HO3D(_DownloadedSet):
 
     def get_image_path(self, idx):
         seq, frame = self.ann["frames"][self.sample_idxs[idx]]
-        return os.path.join(self.root, self.subfolder, seq, "rgb", f"{frame}.png")
+        return os.path.join(self.root, self.subfolder, seq, "rgb", frame + self.ext)
 
     def get_image(self, idx):
         from PIL import Image
@@ -204,8 +204,10 @@ class HO3D(_DownloadedSet):
 
 
 @DATASET.register_module
-class HO3DV3(_DownloadedSet):
-    name, subdir = "HO3DV3", "HO3D_v3"
+class HO3DV3(HO3D):
+    """HO3D v3 (ho3d.py:573-606): the v2 reader on DATA_ROOT/HO3D_v3 with its frames as baseline .jpg files (device JPEG decode path);
+    the annotation cache goes to common/cache/HO3D_v3."""
+    name, subdir, ext = "HO3D_v3", "HO3D_v3", ".jpg"
 
 
 @DATASET.register_module

@@ -41,11 +41,20 @@ def main():
     if not hasattr(np, "asfarray"):                                      # removed in NumPy 2 (ho3dutils.py:28, ho3d.py:393)
         np.asfarray = lambda a, dtype=np.float64: np.asarray(a, dtype=dtype)
     import anakin.datasets.hodata  # noqa
-    from anakin.datasets.ho3d import HO3D
+    from anakin.datasets.ho3d import HO3D, HO3DV3
     root = tempfile.mkdtemp(prefix="ho3d_fake_")
     T.build(root, seed=7)
+    root3 = tempfile.mkdtemp(prefix="ho3dv3_fake_")
+    T.build(root3, seed=9, version=3)
     os.chdir(tempfile.mkdtemp(prefix="ho3d_cache_"))                       # the reference writes common/cache/... relative to the cwd
     out = {}
+    ds3 = HO3DV3(DATA_ROOT=root3, DATA_SPLIT="train", SPLIT_MODE="paper", AUG=False, AUG_PARAM=None, MINI_FACTOR=1.0,
+                 DATA_PRESET={"USE_CACHE": False, "FILTER_NO_CONTACT": False, "FILTER_THRESH": 0.0, "BBOX_EXPAND_RATIO": 1.2, "FULL_IMAGE": False,
+                              "IMAGE_SIZE": [224, 224], "CENTER_IDX": 0, "CROP_MODEL": "root_obj"})
+    out["v3.n"] = np.int64(len(ds3))
+    for i in range(len(ds3)):                                               # v3: the same getters on the other root, frames as .jpg
+        out[f"v3.{i}.joints_3d"], out[f"v3.{i}.obj_transf"] = ds3.get_joints_3d(i), ds3.get_obj_transf(i)
+        out[f"v3.{i}.path"] = np.frombuffer(os.path.relpath(ds3.get_image_path(i), root3).encode(), np.uint8)
     for split in ("train", "test"):
         for crop in ("root_obj", "hand_obj"):
             ds = HO3D(DATA_ROOT=root, DATA_SPLIT=split, SPLIT_MODE="paper", AUG=False, AUG_PARAM=None, MINI_FACTOR=1.0,

@@ -35,8 +35,10 @@ def _write_obj(path, verts, faces):
             f.write("f %d/1 %d/2 %d/3\n" % (a + 1, b + 1, c + 1))
 
 
-def build(root, seed=7, size=(640, 480)):
-    """-> dict(train=[(seq, frame)], test=[...]) of what was written under `root` (a fresh directory)."""
+def build(root, seed=7, size=(640, 480), version=2):
+    """-> dict(train=[(seq, frame)], test=[...]) of what was written under `root` (a fresh directory).  version=3: the layout of the v3
+    download (DATA_ROOT/HO3D_v3, frames as .jpg: ho3d.py:573-596)."""
+    name = "HO3D" if version == 2 else "HO3D_v3"
     from PIL import Image
     rng = np.random.default_rng(seed)
     W, H = size
@@ -52,7 +54,7 @@ def build(root, seed=7, size=(640, 480)):
     for split, sub, seqs, listing in (("train", "train", TRAIN, "train.txt"), ("test", "evaluation", TEST, "evaluation.txt")):
         lines = []
         for seq, nfr, obj in seqs:
-            rgb, meta = os.path.join(root, "HO3D", sub, seq, "rgb"), os.path.join(root, "HO3D", sub, seq, "meta")
+            rgb, meta = os.path.join(root, name, sub, seq, "rgb"), os.path.join(root, name, sub, seq, "meta")
             os.makedirs(rgb, exist_ok=True)
             os.makedirs(meta, exist_ok=True)
             v = verts[obj]
@@ -61,7 +63,10 @@ def build(root, seed=7, size=(640, 480)):
             for fi in range(nfr):
                 frame = f"{fi:04d}"
                 img = np.stack([(xx * (2 + c) + yy * 3 + 50 * np.sin(xx / (7.0 + fi)) + 20 * rng.standard_normal((H, W))) % 256 for c in range(3)], -1)
-                Image.fromarray(img.astype(np.uint8)).save(os.path.join(rgb, frame + ".png"), compress_level=int(rng.integers(1, 7)))
+                if version == 2:
+                    Image.fromarray(img.astype(np.uint8)).save(os.path.join(rgb, frame + ".png"), compress_level=int(rng.integers(1, 7)))
+                else:
+                    Image.fromarray(img.astype(np.uint8)).save(os.path.join(rgb, frame + ".jpg"), quality=int(rng.integers(80, 96)), subsampling=2)
                 K = np.array([[614.6 + fi, 0, 320.3], [0, 614.2, 239.7 - fi], [0, 0, 1.0]], np.float32)
                 root_j = np.array([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), -rng.uniform(0.4, 0.6)], np.float32)   # HO3D's OpenGL frame: -z forward
                 ann = {"camMat": K, "objRot": rng.normal(0, 1.0, (3, 1)).astype(np.float32), "objName": obj,
@@ -76,7 +81,7 @@ def build(root, seed=7, size=(640, 480)):
                 with open(os.path.join(meta, frame + ".pkl"), "wb") as f:
                     pickle.dump(ann, f, protocol=2)
                 lines.append(f"{seq}/{frame}")
-        with open(os.path.join(root, "HO3D", listing), "w") as f:
+        with open(os.path.join(root, name, listing), "w") as f:
             f.write("\n".join(lines) + "\n")
         out[split] = [tuple(l.split("/")) for l in lines]
     return out

@@ -89,3 +89,24 @@ def test_real_batches_over_the_reader_decode_png_on_the_device(tree, tmp_path, m
     for k in ba:
         torch.testing.assert_close(ba[k], bb[k], rtol=0, atol=0, msg=k)
     assert ba["obj_idx"].tolist() == [12, 9, 5, 9]
+
+
+def test_v3_reader_is_the_v2_reader_on_jpg_frames(tmp_path, monkeypatch):
+    pytest.importorskip("PIL")
+    from artiboost_amd import datasets as D
+    from artiboost_amd import jpeg
+    monkeypatch.chdir(tmp_path)
+    root = tmp_path / "data"
+    T.build(str(root), seed=9, version=3)
+    g = np.load(GOLD, allow_pickle=False)
+    ds = D.HO3DV3(DATA_ROOT=str(root), DATA_SPLIT="train", SPLIT_MODE="paper", AUG=True, DATA_PRESET=dict(PRESET, CROP_MODEL="root_obj"))
+    assert len(ds) == int(g["v3.n"]) > 0
+    for i in range(len(ds)):
+        a = ds.get_annots(i)
+        np.testing.assert_allclose(a["joints_3d"], g[f"v3.{i}.joints_3d"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(a["obj_transf"], g[f"v3.{i}.obj_transf"], rtol=2e-6, atol=2e-6)
+        assert os.path.relpath(ds.get_image_path(i), str(root)) == bytes(g[f"v3.{i}.path"]).decode()
+    it = jpeg.parse(ds.get_image_bytes(0))                    # baseline .jpg: the device decoder's header walk accepts it
+    assert (it.width, it.height) == (640, 480)
+    assert os.path.isdir(tmp_path / "common" / "cache" / "HO3D_v3")
+    assert len(D.HO3DV3(DATA_ROOT=str(tmp_path / "none"), DATA_PRESET=PRESET)) == 0
