@@ -302,12 +302,48 @@ class RealBatcher:
         return dict(frames=stage, files=files, file_kind=kind, file_infos=infos, gt={k: np.asarray(v, np.float32) for k, v in gt.items()}, inv=inv, flip=flip, obj_idx=obj_idx,
                     order=order, factor=factor, blur=blur, idxs=np.asarray(idxs, np.int64))
 
-    def augment(self, host, out_pad=None, out_chw=None):
-        """Upload + ab_augment_batch.  out_pad: zero-bordered NHWC4 rows to fill (a slice of the training batch)."""
+    def _upload(self, arrays):
+        """{name: host array} -> {name: device tensor} through ONE pinned blob and ONE asynchronous copy.  The small per-batch arrays
+        (ground truth, jitter draws, inverse affines: 15 of them) used to go up one `.to(device)` each from pageable memory -- every one a
+        blocking staged copy queued behind the training step on the same stream, i.e. the host could not run ahead of the device and the
+        batch assembly ended up serialised behind each step (round 4: the mixed step 10.9 -> see DESIGN 13.8)."""
+        items = [(k, np.ascontiguousarray(v)) for k, v in arrays.items() if v is not None]
+        offs, o = [], 0
+        for _, a in items:
+            offs.append(o)
+            o += (a.nbytes + 15) & ~15
+        k = self._up_k = getattr(self, "_up_k", 0) ^ 1
+        pins = self.__dict__.setdefault("_up_pins", [None, None])
+        evs = self.__dict__.setdefault("_up_evs", [None, None])
+        if pins[k] is None or pins[k].numel() < o:
+            pins[k] = torch.empty(max(2 * o, 1 << 16), dtype=torch.uint8)
+            if self.dev.type == "cuda":
+                pins[k] = pins[k].pin_memory()
+            evs[k] = None
+        if evs[k] is not None:
+            evs[k].synchronize()                   # the copy that last read this staging buffer (two uploads ago)
+        stage = pins[k].numpy()
+        for (_, a), of in zip(items, offs):
+            stage[of:of + a.nbytes] = a.view(np.uint8).reshape(-1)
+        blob = torch.empty(max(o, 16), dtype=torch.uint8, device=self.dev)
+        blob[:o].copy_(pins[k][:o], non_blocking=True)
+        if self.dev.type == "cuda":
+            evs[k] = torch.cuda.Event()
+            evs[k].record()
+        out = {}
+        for (name, a), of in zip(items, offs):
+            tdt = torch.from_numpy(a[:0].reshape(-1)).dtype if a.dtype != np.bool_ else torch.bool
+            out[name] = blob[of:of + a.nbytes].view(tdt).view(a.shape)
+        return out
+
+    def augment(self, host, out_pad=None, out_chw=None, dev=None):
+        """Upload + ab_augment_batch.  out_pad: zero-bordered NHWC4 rows to fill (a slice of the training batch).  dev: the batch's small
+        arrays already on the device (batch() uploads them together with the ground truth)."""
         n = len(host["idxs"])
         W, H = self.src.raw_size
         ow, oh = self.image_size
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev, non_blocking=True)   # noqa: E731
+        if dev is None:
+            dev = self._upload(dict(order=host["order"], factor=host["factor"], inv=host["inv"], flip=host["flip"], blur=host["blur"]))
         lib = L.lib()
         need = lib.ab_augment_workspace_bytes(L.i(n), L.i(W), L.i(H))
         if self._ws is None or self._ws.numel() < need:
@@ -324,8 +360,7 @@ class RealBatcher:
             rgb = host["frames"].to(self.dev, non_blocking=True)
             frames = torch.zeros(rgb.shape[:3] + (4,), dtype=torch.uint8, device=self.dev)
             frames[..., :3].copy_(rgb)                              # RGBX: the kernels fetch a pixel as one aligned dword
-        order, factor, inv, flip = t(host["order"]), t(host["factor"]), t(host["inv"]), t(host["flip"])
-        blur = t(host["blur"]) if host["blur"] is not None else None
+        order, factor, inv, flip, blur = dev["order"], dev["factor"], dev["inv"], dev["flip"], dev.get("blur")
         dt = L.dt(out_pad) if out_pad is not None else 0
         L.check(lib.ab_augment_batch(L.ptr(frames), L.i(n), L.i(W), L.i(H), L.ptr(order), L.ptr(factor), L.ptr(inv), L.ptr(blur),
                                      L.ptr(flip), L.i(ow), L.i(oh), L.i(dt), _ptr(out_pad), L.ptr(out_chw), L.ptr(self._ws), L.stream()),
@@ -338,10 +373,14 @@ class RealBatcher:
         n = len(idxs)
         ow, oh = self.image_size
         chw = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=self.dev) if want_chw else None
-        self.augment(host, out_pad=out_pad, out_chw=chw)
-        b = {k: torch.from_numpy(v).to(self.dev) for k, v in host["gt"].items()}
-        b[Queries.OBJ_IDX] = torch.from_numpy(host["obj_idx"]).to(self.dev)
-        b[Queries.SAMPLE_IDX] = torch.from_numpy(host["idxs"]).to(self.dev)
+        small = dict(host["gt"], __order=host["order"], __factor=host["factor"], __inv=host["inv"], __flip=host["flip"], __blur=host["blur"],
+                     __obj_idx=np.asarray(host["obj_idx"], np.int64), __idxs=host["idxs"])
+        up = self._upload(small)                   # every small array of the batch: one pinned blob, one asynchronous copy
+        self.augment(host, out_pad=out_pad, out_chw=chw,
+                     dev=dict(order=up["__order"], factor=up["__factor"], inv=up["__inv"], flip=up["__flip"], blur=up.get("__blur")))
+        b = {k: up[k] for k in host["gt"]}
+        b[Queries.OBJ_IDX] = up["__obj_idx"]
+        b[Queries.SAMPLE_IDX] = up["__idxs"]
         b[SynthQueries.IS_SYNTH] = torch.zeros(n, dtype=torch.bool, device=self.dev)
         for k in (SynthQueries.OBJ_ID, SynthQueries.PERSP_ID, SynthQueries.GRASP_ID):
             b[k] = torch.full((n,), -1, dtype=torch.int64, device=self.dev)
