@@ -367,23 +367,25 @@ class RealBatcher:
                 "ab_augment_batch")
         return out_chw
 
-    def batch(self, idxs, draws=None, out_pad=None, want_chw=True):
-        """Device batch dict with the reference's keys (hodata.py:315-450; IS_SYNTH false, CCV ids -1)."""
+    def batch(self, idxs, draws=None, out_pad=None, want_chw=True, out_chw=None):
+        """Device batch dict with the reference's keys (hodata.py:315-450; IS_SYNTH false, CCV ids -1).  out_pad / out_chw: rows of a larger
+        batch's tensors to write the frames into."""
         host = self.assemble(idxs, draws)
         n = len(idxs)
         ow, oh = self.image_size
-        chw = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=self.dev) if want_chw else None
+        chw = out_chw if out_chw is not None else (torch.empty((n, 3, oh, ow), dtype=torch.float32, device=self.dev) if want_chw else None)
         small = dict(host["gt"], __order=host["order"], __factor=host["factor"], __inv=host["inv"], __flip=host["flip"], __blur=host["blur"],
-                     __obj_idx=np.asarray(host["obj_idx"], np.int64), __idxs=host["idxs"])
+                     __obj_idx=np.asarray(host["obj_idx"], np.int64), __idxs=host["idxs"],
+                     __is_synth=np.zeros(n, np.bool_), __minus1=np.full(n, -1, np.int64))
         up = self._upload(small)                   # every small array of the batch: one pinned blob, one asynchronous copy
         self.augment(host, out_pad=out_pad, out_chw=chw,
                      dev=dict(order=up["__order"], factor=up["__factor"], inv=up["__inv"], flip=up["__flip"], blur=up.get("__blur")))
         b = {k: up[k] for k in host["gt"]}
         b[Queries.OBJ_IDX] = up["__obj_idx"]
         b[Queries.SAMPLE_IDX] = up["__idxs"]
-        b[SynthQueries.IS_SYNTH] = torch.zeros(n, dtype=torch.bool, device=self.dev)
+        b[SynthQueries.IS_SYNTH] = up["__is_synth"]
         for k in (SynthQueries.OBJ_ID, SynthQueries.PERSP_ID, SynthQueries.GRASP_ID):
-            b[k] = torch.full((n,), -1, dtype=torch.int64, device=self.dev)
+            b[k] = up["__minus1"]                  # one read-only tensor for the three CCV ids of a real sample
         if chw is not None:
             b[Queries.IMAGE] = chw
         return b
@@ -402,8 +404,16 @@ class MixedLoader:
     real set is sharded like a DistributedSampler (shared permutation, rank r takes perm[r::world]); the synthetic loader
     shards its own epoch the same way."""
 
-    def __init__(self, real: RealBatcher, synth_loader, batch_size, seed=1, rank=0, world_size=1, decode_group=4, decode_ahead=None):
+    def __init__(self, real: RealBatcher, synth_loader, batch_size, seed=1, rank=0, world_size=1, decode_group=4, decode_ahead=None,
+                 want_chw=True, reuse_buffers=0):
         self.real, self.synth, self.B = real, synth_loader, batch_size
+        # want_chw: also the reference-shaped float CHW `image` (hodata.py:446) next to the zero-bordered NHWC4 tensor the HIP model reads
+        # (50 MB written, concatenated and copied per batch of 64 that a loop feeding TrainStep never looks at).
+        # reuse_buffers = n > 0: the image tensors of a batch come from a ring of n zero-bordered buffers (no 70 MB fill per batch) and are
+        # overwritten n batches later -- for loops that consume a batch before asking for the next but n - 1 (TrainStep copies it into its
+        # static inputs; StreamPrefetcher runs one ahead: n >= 3).  0: fresh tensors per batch, like a DataLoader.
+        self.want_chw, self.reuse_buffers = bool(want_chw), int(reuse_buffers)
+        self._ring, self._ring_i = [], 0
         # the .jpg frames of `decode_group` consecutive batches are decoded in one call (sources that serve file bytes): the call's time is the
         # longest Huffman chain, not the frame count -- 11.55 -> 11.24 ms per mixed step at 4 (tools/bench_mixed.py); 1: per batch
         self.decode_group = max(1, int(decode_group))
@@ -464,20 +474,41 @@ class MixedLoader:
                             self.real.prefetch_files(group(bi + 2 * G), side=True)
                         for fr in self.real._predecoded.values():
                             fr.record_stream(cur)
-            pad = torch.zeros((self.B, H + 6, W + 8, 4), dtype=self.real.dtype, device=self.real.dev)
-            rb = self.real.batch(perm[bi * self.n_real:(bi + 1) * self.n_real], out_pad=pad[:self.n_real])
+            pad, chw = self._image_buffers(H, W)
+            rb = self.real.batch(perm[bi * self.n_real:(bi + 1) * self.n_real], out_pad=pad[:self.n_real], want_chw=self.want_chw,
+                                 out_chw=None if chw is None else chw[:self.n_real])
             if not self.n_synth:
                 rb["image_nhwc4_padded"] = pad
                 yield rb
                 continue
+            # both halves write their frames straight into the batch's tensors: the renderer into rows n_real.. (no copy, no concatenation)
             self.synth.load_batch(static, bi)
-            self.synth.render_into(static, want_chw=True)
-            pad[self.n_real:] = static["image_nhwc4_padded"]
+            self.synth.render_into(static, want_chw=self.want_chw, out_pad=pad[self.n_real:], out_chw=None if chw is None else chw[self.n_real:])
             out = {"image_nhwc4_padded": pad}
+            if chw is not None:
+                out[Queries.IMAGE] = chw
             for k, v in rb.items():
+                if k == Queries.IMAGE:
+                    continue
                 sv = static[k]
                 out[k] = torch.cat([v, sv.to(v.dtype) if sv.dtype != v.dtype else sv])
             yield out
+
+    def _image_buffers(self, H, W):
+        """(zero-bordered NHWC4 [B, H + 6, W + 8, 4], float CHW [B, 3, H, W] or None) of the next batch: fresh, or the next of the ring."""
+        dev, dt = self.real.dev, self.real.dtype
+        fresh = lambda: (torch.zeros((self.B, H + 6, W + 8, 4), dtype=dt, device=dev),      # noqa: E731
+                         torch.empty((self.B, 3, H, W), dtype=torch.float32, device=dev) if self.want_chw else None)
+        if self.reuse_buffers <= 0:
+            return fresh()
+        if len(self._ring) < self.reuse_buffers or self._ring[0][0].shape[1:3] != (H + 6, W + 8):
+            if self._ring and self._ring[0][0].shape[1:3] != (H + 6, W + 8):
+                self._ring = []
+            self._ring.append(fresh())      # the borders are zeroed once: neither half ever writes them
+            self._ring_i = len(self._ring) - 1
+            return self._ring[-1]
+        self._ring_i = (self._ring_i + 1) % self.reuse_buffers
+        return self._ring[self._ring_i]
 
 
 class StreamPrefetcher:

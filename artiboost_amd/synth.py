@@ -733,16 +733,17 @@ class ArtiBoostLoader:
                 continue
             static[k].copy_(v[s0:s0 + self.batch_size], non_blocking=True)
 
-    def render_into(self, static, want_chw=False):
-        """Enqueue the batched render of the samples currently in `static` (hipGraph-capturable)."""
+    def render_into(self, static, want_chw=False, out_pad=None, out_chw=None):
+        """Enqueue the batched render of the samples currently in `static` (hipGraph-capturable).  out_pad / out_chw: rows of a larger
+        batch's tensors to render into instead of static's own (realdata.MixedLoader: the synthetic share of a mixed batch)."""
         W, H = self.image_size
-        chw = None
-        if want_chw:
+        chw = out_chw
+        if want_chw and chw is None:
             chw = static.get(Queries.IMAGE)
             if chw is None:
                 chw = static[Queries.IMAGE] = torch.empty((self.batch_size, 3, H, W), dtype=torch.float32, device=self.dev)
         self.renderer.render(static["_samples"], static["_hand_verts"], static["_order"], static["_factor"],
-                             static["_inv_affine"], W, H, out_pad=static["image_nhwc4_padded"], out_chw=chw,
+                             static["_inv_affine"], W, H, out_pad=static["image_nhwc4_padded"] if out_pad is None else out_pad, out_chw=chw,
                              blur=static["_blur"])
 
     def __iter__(self):

@@ -357,3 +357,32 @@ def test_group_that_cannot_be_predecoded_does_not_share_the_side_stream_decoder(
         for a, r in zip(got, ref):
             for k in r:
                 torch.testing.assert_close(a[k], r[k], rtol=0, atol=0, msg=k)
+
+
+@pytest.mark.gpu
+def test_mixed_batches_from_the_buffer_ring_equal_fresh_ones():
+    """MixedLoader(want_chw=False, reuse_buffers=n) -- both halves write their frames straight into the batch's image tensor, which comes from a ring
+    of n zero-bordered buffers -- yields, batch by batch, the same tensors as the default loader (fresh tensors, float CHW `image` as well); the
+    ring hands a buffer out again n batches later with its borders still zero."""
+    from test_gpu_synth import _loader
+    from artiboost_amd.realdata import MixedLoader, RealBatcher
+    from artiboost_amd.synth import ArtiBoostLoader
+    B = 4
+
+    def make(**kw):
+        src = GoldenSource()
+        assets, proto = _loader(size=64)
+        n_synth = MixedLoader.n_synth_for(B, len(src), proto.synth_len)
+        synth = ArtiBoostLoader.from_assets(assets, proto.cfg, proto.preset, n_synth, proto.synth_len, compute_dtype=torch.float32, random_seed=3)
+        synth.prepare()
+        return MixedLoader(RealBatcher(src, proto.preset, compute_dtype=torch.float32, seed=2), synth, B, seed=4, **kw)
+    ref = [{k: v.clone() for k, v in b.items()} for b in make()]
+    seen = []
+    for i, b in enumerate(make(want_chw=False, reuse_buffers=3)):
+        assert "image" not in b and set(b) == set(ref[i]) - {"image"}
+        for k, v in b.items():
+            assert torch.equal(v, ref[i][k]), (i, k)
+        pad = b["image_nhwc4_padded"]
+        seen.append(pad.data_ptr())
+        assert float(pad[:, :3].abs().max()) == 0 and float(pad[:, :, :3].abs().max()) == 0 and float(pad[:, -3:].abs().max()) == 0
+    assert len(ref) == len(seen) >= 4 and len(set(seen)) == 3 and seen[3] == seen[0]

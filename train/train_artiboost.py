@@ -174,7 +174,7 @@ def main():
         tr = cfg["DATASET"]["TRAIN"]
         mixed = MixedLoader(RealBatcher(train_data, cfg["DATA_PRESET"], aug=bool(tr.get("AUG", False)), aug_param=tr.get("AUG_PARAM") or None, device=dev,
                                         compute_dtype=loader.dtype, seed=seed, num_workers=int(arg.workers) or None),
-                            loader, per_rank, seed=seed, rank=rank, world_size=world)
+                            loader, per_rank, seed=seed, rank=rank, world_size=world, want_chw=False, reuse_buffers=4)      # TrainStep copies a batch in
     epoch0 = 0
     if arg.resume:
         epoch0 = recorder.resume_checkpoints(model, optimizer, scheduler, arg.resume, resume_epoch=arg.resume_epoch or None)
