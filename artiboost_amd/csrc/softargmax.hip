@@ -313,7 +313,10 @@ template <> __device__ __forceinline__ void st_pair<bf16_t>(bf16_t* p, float a, 
 // colpart != NULL (PIX pixels per workgroup): the workgroup also writes the column sums of its dlogits rows (fixed order: a
 // lane over its pixels, then the four waves), colpart[(b * gridDim.x + blockIdx.x)][CD] -- the final layer's bias gradient
 // without another pass over the planes.
-template <typename T, bool SPLIT = false, int PIX = SAM_BWD_PIX, int NORM = 0>
+// V, KV: a lane walks KV groups of V consecutive channels (group k: channels V * (lane + 64 k) ..): V = 2 covers any even C*DP with 8-byte loads
+// and 4-byte plane stores; V = 4 (C*DP % 4 == 0) moves 16 bytes per load and 8 per plane store, and KV = 3 covers the 22 x 32 head's 704 channels
+// with 768 slots where the V = 2 walk always took SAM_MAXCH = 1024 (a quarter of its loads and exps were padding): 98 -> see DESIGN 13.8.
+template <typename T, bool SPLIT = false, int PIX = SAM_BWD_PIX, int NORM = 0, int V = 2, int KV = SAM_MAXCH / 128>
 __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int C, int D, int DP, int H, int W,
                                                const float* __restrict__ uvd, const float* __restrict__ conf,
                                                const float* __restrict__ stat, const float* __restrict__ g_uvd,
@@ -322,7 +325,8 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
                                                float* __restrict__ colpart = nullptr) {
     const int CD = C * DP, npix = H * W;      // CD even
     const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int KP = SAM_MAXCH / 128, NCH = 2 * KP;
+    constexpr int NCH = V * KV;
+    static_assert((V == 2 || V == 4) && NCH * 64 <= SAM_MAXCH, "channel walk");
     const float z = 1.0f + 1e-7f;
     // per-channel constants: computed once per workgroup (rolled loop), exchanged through LDS
     __shared__ float cst[6][SAM_MAXCH];
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
     float cm[NCH], ca[NCH], cb[NCH], ck[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
-        int ch = 2 * (lane + 64 * (k >> 1)) + (k & 1);
+        int ch = V * (lane + 64 * (k / V)) + (k % V);
         cm[k] = cst[0][ch]; ca[k] = cst[1][ch]; cb[k] = cst[2][ch]; ck[k] = cst[3][ch];
     }
     float csum[NCH];
@@ -365,14 +369,18 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
         const size_t prow = ((size_t)b * npix + p) * CD;
         float x[NCH];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) ld_pair<T>(row + min(2 * (lane + 64 * k), CD - 2), x[2 * k], x[2 * k + 1]);
+        for (int k = 0; k < KV; ++k) {
+            const T* src = row + min(V * (lane + 64 * k), CD - V);
+            ld_pair<T>(src, x[V * k], x[V * k + 1]);
+            if constexpr (V == 4) ld_pair<T>(src + 2, x[V * k + 2], x[V * k + 3]);      // (merged with the first into one 16-byte load)
+        }
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            int ch = 2 * (lane + 64 * k);
-            float o[2];
+        for (int k = 0; k < KV; ++k) {
+            int ch = V * (lane + 64 * k);
+            float o[V];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                int kk = 2 * k + t;
+            for (int t = 0; t < V; ++t) {
+                int kk = V * k + t;
                 const float xp = sam_pre<NORM>(x[kk]);
                 float e = __expf(xp - cm[kk]);
                 float out = e * ((ca[kk] * cu + cb[kk] * cv) + ck[kk]);
@@ -384,16 +392,27 @@ __global__ __launch_bounds__(256) void sam_bwd(const T* __restrict__ logits, int
             if (ch < CD) {
                 if constexpr (SPLIT) {
                     const uint32_t hw = pack_bf16x2(o[0], o[1]);
-                    *(uint32_t*)(dl_hi + prow + ch) = hw;
-                    *(uint32_t*)(dl_lo + prow + ch) = pack_bf16x2(o[0] - __uint_as_float(hw << 16), o[1] - __uint_as_float(hw & 0xffff0000u));
-                } else st_pair<T>(drow + ch, o[0], o[1]);
+                    const uint32_t lw = pack_bf16x2(o[0] - __uint_as_float(hw << 16), o[1] - __uint_as_float(hw & 0xffff0000u));
+                    if constexpr (V == 4) {
+                        const uint32_t hw2 = pack_bf16x2(o[2], o[3]);
+                        const uint32_t lw2 = pack_bf16x2(o[2] - __uint_as_float(hw2 << 16), o[3] - __uint_as_float(hw2 & 0xffff0000u));
+                        *(uint2*)(dl_hi + prow + ch) = make_uint2(hw, hw2);
+                        *(uint2*)(dl_lo + prow + ch) = make_uint2(lw, lw2);
+                    } else {
+                        *(uint32_t*)(dl_hi + prow + ch) = hw;
+                        *(uint32_t*)(dl_lo + prow + ch) = lw;
+                    }
+                } else {
+                    st_pair<T>(drow + ch, o[0], o[1]);
+                    if constexpr (V == 4) st_pair<T>(drow + ch + 2, o[2], o[3]);
+                }
             }
         }
     }
     if (colpart) {
         __syncthreads();                                     // cst is free: rows 0..3 take the four waves' sums
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) cst[wave][2 * (lane + 64 * (k >> 1)) + (k & 1)] = csum[k];
+        for (int k = 0; k < NCH; ++k) cst[wave][V * (lane + 64 * (k / V)) + (k % V)] = csum[k];
         __syncthreads();
         float* dst = colpart + ((size_t)b * gridDim.x + blockIdx.x) * CD;
         for (int ch = threadIdx.x; ch < CD; ch += 256) dst[ch] = ((cst[0][ch] + cst[1][ch]) + cst[2][ch]) + cst[3][ch];
@@ -484,6 +503,17 @@ extern "C" int ab_softargmax3d_bwd_norm(const void* logits, int dtype, int B, in
     return sam_bwd_impl(logits, dtype, B, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, dlogits, norm_type, stream);
 }
 
+// the split-plane launches: 4 channels per lane and group where C*DP allows (3 groups up to 768 channels, else 4), otherwise pairs
+#define SAM_BWX_ARGS logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr, (bf16_t*)dl_hi, (bf16_t*)dl_lo, colpart
+#define SAM_BWX_N(PIXV, NN) \
+    do { \
+        static const int quad = getenv("AB_SAM_BWD_QUAD") ? atoi(getenv("AB_SAM_BWD_QUAD")) : 1; \
+        if (quad && (C * DP) % 4 == 0 && C * DP <= 768) sam_bwd<float, true, PIXV, NN, 4, 3><<<grid, 256, 0, st>>>(SAM_BWX_ARGS); \
+        else if (quad && (C * DP) % 4 == 0) sam_bwd<float, true, PIXV, NN, 4, 4><<<grid, 256, 0, st>>>(SAM_BWX_ARGS); \
+        else sam_bwd<float, true, PIXV, NN><<<grid, 256, 0, st>>>(SAM_BWX_ARGS); \
+    } while (0)
+#define SAM_BWX(PIXV) do { if (norm) SAM_BWX_N(PIXV, 1); else SAM_BWX_N(PIXV, 0); } while (0)
+
 // fp32 logits in, dlogits out as split-bf16 planes (C * DP even)
 static int sam_bwd_x3_impl(const float* logits, int B, int C, int D, int DP, int H, int W, const float* uvd,
                            const float* conf, const float* stat, const float* g_uvd, const float* g_conf,
@@ -492,10 +522,9 @@ static int sam_bwd_x3_impl(const float* logits, int B, int C, int D, int DP, int
     if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || DP < D || C * DP > SAM_MAXCH || ((C * DP) & 1) || norm < 0 || norm > 1) return AB_ESHAPE;
     if (norm && g_conf) return AB_EINVAL;
     dim3 grid((H * W + SAM_BWD_PIX - 1) / SAM_BWD_PIX, B);
-    if (norm) sam_bwd<float, true, SAM_BWD_PIX, 1><<<grid, 256, 0, as_stream(stream)>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
-                                                                                         (bf16_t*)dl_hi, (bf16_t*)dl_lo);
-    else sam_bwd<float, true><<<grid, 256, 0, as_stream(stream)>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
-                                                                   (bf16_t*)dl_hi, (bf16_t*)dl_lo);
+    hipStream_t st = as_stream(stream);
+    float* colpart = nullptr;
+    SAM_BWX(SAM_BWD_PIX);
     AB_LAUNCH_CHECK();
     return 0;
 }
@@ -517,10 +546,7 @@ static int sam_bwd_x3_bias_impl(const float* logits, int B, int C, int D, int DP
     if (norm && g_conf) return AB_EINVAL;
     dim3 grid((H * W + SAM_BWD_PIX_BIAS - 1) / SAM_BWD_PIX_BIAS, B);
     hipStream_t st = as_stream(stream);
-    if (norm) sam_bwd<float, true, SAM_BWD_PIX_BIAS, 1><<<grid, 256, 0, st>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
-                                                                               (bf16_t*)dl_hi, (bf16_t*)dl_lo, colpart);
-    else sam_bwd<float, true, SAM_BWD_PIX_BIAS><<<grid, 256, 0, st>>>(logits, C, D, DP, H, W, uvd, conf, stat, g_uvd, g_conf, nullptr,
-                                                                      (bf16_t*)dl_hi, (bf16_t*)dl_lo, colpart);
+    SAM_BWX(SAM_BWD_PIX_BIAS);
     AB_LAUNCH_CHECK();
     sam_bias_finalize<<<(C * DP + 7) / 8, 256, 0, st>>>(colpart, (int)(grid.x * grid.y), C * DP, dbias);
     AB_LAUNCH_CHECK();
