@@ -421,72 +421,86 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
 }
 
 // ------------------------------------------------------------------ PIL-semantics colour jitter (see the oracle)
+// Branch-free forms (round 4): the kernels that run these per pixel are VALU-issue bound (jitter_stats: 44 M wave instructions per
+// 64 x 512^2 launch, + 20 M scalar ones for the exec-mask bookkeeping of the divergent branches the first versions had).  Every
+// function below returns, for every input, what its branching predecessor returned: checked over all 2^24 RGB triples against the
+// oracle (tests/test_gpu_render.py) and, for the hue op, over all 2^24 triples x all 256 hue shifts (tools/hue_exhaustive.py).
 __device__ __forceinline__ uint8_t blend8(int in1, int in2, float f) {
-    float t = (float)in1 + f * (float)(in2 - in1);
-    if (f >= 0.f && f <= 1.f) return (uint8_t)t;
-    if (t <= 0.f) return 0;
-    if (t >= 255.f) return 255;
-    return (uint8_t)t;
+    // ImageEnhance: in1 + f (in2 - in1), truncated; clipped to 0..255 when f is outside [0, 1] -- inside it the value lies between
+    // the two inputs, so clipping always is the same function.
+    const float t = (float)in1 + f * (float)(in2 - in1);
+    return (uint8_t)min((unsigned)fmaxf(t, 0.f), 255u);
 }
 __device__ __forceinline__ int luma8(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
-__device__ __forceinline__ void rgb2hsv8(const uint8_t* in, uint8_t* out) {
-    int r = in[0], g = in[1], b = in[2];
-    int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
-    uint8_t uh, us, uv = (uint8_t)maxc;
-    if (minc == maxc) { uh = 0; us = 0; }
-    else {
-        float cr = (float)(maxc - minc);
-        float s = cr / (float)maxc;
-        float rc = ((float)(maxc - r)) / cr, gc = ((float)(maxc - g)) / cr, bc = ((float)(maxc - b)) / cr;
-        float h;
-        if (r == maxc) h = bc - gc;
-        else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
-        else h = (float)(4.0 + (double)gc - (double)rc);
-        { const double hv6 = (double)h / 6.0 + 1.0; h = (float)(hv6 - floor(hv6)); }   // == fmod(hv6, 1.0) exactly: hv6 is in [5/6, 11/6]
-        int ih = (int)((double)h * 255.0), is = (int)((double)s * 255.0);
-        uh = (uint8_t)(ih < 0 ? 0 : ih > 255 ? 255 : ih);
-        us = (uint8_t)(is < 0 ? 0 : is > 255 ? 255 : is);
-    }
-    out[0] = uh; out[1] = us; out[2] = uv;
-}
-// Per-byte terms of hsv2rgb8, tabulated once per workgroup with the very expressions PIL's C code evaluates per pixel:
-// sector i = floor(h*6/255), fraction f = h*6/255 - i (as float), fs = s/255 (as float).  Three double divisions per
-// pixel become three LDS reads.
-struct HueLut { const uint8_t* sect; const float* frac; const float* sat; };
-__device__ __forceinline__ void hue_lut_fill(uint8_t* sect, float* frac, float* sat) {
+// Per-byte terms, tabulated once per workgroup with the very expressions PIL's C code evaluates per pixel:
+//   hsv -> rgb: sector i = floor(h*6/255), fraction f = h*6/255 - i (as float), fs = s/255 (as float)
+//   rgb -> hsv: rcp[d] = 1.0 / d as a double.  For integers 0 <= a <= 255, 1 <= d <= 255 the float quotient (float)a / (float)d
+//   equals (float)((double)a * rcp[d]): a/d is never within 2^-33 (relative) of a float rounding boundary, the double product is
+//   within 2^-52 of it.  Four IEEE float divisions per pixel become two 8-byte LDS reads and four double multiplies.
+struct HueLut { const uint8_t* sect; const float* frac; const float* sat; const double* rcp; };
+__device__ __forceinline__ void hue_lut_fill(uint8_t* sect, float* frac, float* sat, double* rcp) {
     for (int v = threadIdx.x; v < 256; v += blockDim.x) {
         const int i = (int)floor((double)(float)v * 6.0 / 255.0);
         sect[v] = (uint8_t)i;
         frac[v] = (float)((double)(float)v * 6.0 / 255.0 - (double)(float)i);
         sat[v] = (float)((double)(float)v / 255.0);
+        rcp[v] = v ? 1.0 / (double)v : 0.0;
     }
+}
+#define HUE_LUT_DECL __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256]; __shared__ double l_rcp[256]; \
+    hue_lut_fill(l_sect, l_frac, l_sat, l_rcp); __syncthreads(); const HueLut lut = {l_sect, l_frac, l_sat, l_rcp}
+
+__device__ __forceinline__ void rgb2hsv8(const HueLut& lut, const uint8_t* in, uint8_t* out) {
+    const int r = in[0], g = in[1], b = in[2];
+    const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+    const int d = maxc - minc;                              // gray pixels (d = 0): rcp[0] = 0, every term below is finite, h = s = 0 selected at the end
+    const double rd = lut.rcp[d], rm = lut.rcp[maxc];
+    const float s = (float)((double)d * rm);
+    // PIL: rc = (max - r) / d .. as floats; h = bc - gc | 2 + rc - bc | 4 + gc - rc for the first of r, g, b that equals the maximum.  Only the
+    // two terms of the taken case are formed; the float difference bc - gc equals (float)(0.0 + (double)bc - (double)gc) (the double difference
+    // of two floats in [0, 1] is exact), so one double expression serves all three cases.
+    const bool rmax = r == maxc, gmax = g == maxc;
+    const int nx = maxc - (rmax ? b : gmax ? r : g), ny = maxc - (rmax ? g : gmax ? b : r);
+    const double base = rmax ? 0.0 : gmax ? 2.0 : 4.0;
+    const float xf = (float)((double)nx * rd), yf = (float)((double)ny * rd);
+    float h = (float)(base + (double)xf - (double)yf);
+    {   // (double)h / 6.0, correctly rounded: reciprocal estimate + one residual step (exact for every h this function produces: checked
+        // exhaustively), then the fmod-free wrap: hv6 is in [5/6, 11/6]
+        const double hd = (double)h, r6 = 1.0 / 6.0;
+        double q = hd * r6;
+        q = fma(fma(-6.0, q, hd), r6, q);
+        const double hv6 = q + 1.0;
+        h = (float)(hv6 - floor(hv6));
+    }
+    const int ih = (int)((double)h * 255.0), is = (int)((double)s * 255.0);
+    out[0] = d ? (uint8_t)min(max(ih, 0), 255) : 0;
+    out[1] = d ? (uint8_t)min(max(is, 0), 255) : 0;
+    out[2] = (uint8_t)maxc;
 }
 // round() for x >= 0 (half away from zero), exact: x - trunc(x) is exact for |x| < 2^52
 __device__ __forceinline__ int round_pos(double x) { const double t = trunc(x); return (int)(x - t >= 0.5 ? t + 1.0 : t); }
 
 __device__ __forceinline__ void hsv2rgb8(const HueLut& lut, const uint8_t* in, uint8_t* out) {
-    uint8_t h = in[0], s = in[1], v = in[2];
-    if (s == 0) { out[0] = out[1] = out[2] = v; return; }
-    const int i = lut.sect[h];
-    const float f = lut.frac[h], fs = lut.sat[s];
-    int p = round_pos((double)(float)v * (1.0 - (double)fs));
-    int q = round_pos((double)(float)v * (1.0 - (double)fs * (double)f));
-    int t = round_pos((double)(float)v * (1.0 - (double)fs * (1.0 - (double)f)));
-    p = p > 255 ? 255 : p; q = q > 255 ? 255 : q; t = t > 255 ? 255 : t;
-    switch (i % 6) {
-        case 0: out[0] = v; out[1] = (uint8_t)t; out[2] = (uint8_t)p; break;
-        case 1: out[0] = (uint8_t)q; out[1] = v; out[2] = (uint8_t)p; break;
-        case 2: out[0] = (uint8_t)p; out[1] = v; out[2] = (uint8_t)t; break;
-        case 3: out[0] = (uint8_t)p; out[1] = (uint8_t)q; out[2] = v; break;
-        case 4: out[0] = (uint8_t)t; out[1] = (uint8_t)p; out[2] = v; break;
-        default: out[0] = v; out[1] = (uint8_t)p; out[2] = (uint8_t)q; break;
-    }
+    const uint8_t h = in[0], s = in[1], v = in[2];
+    const int i = lut.sect[h];                              // 0 .. 6 (h = 255 -> 6 -> sector 0 below, as i % 6)
+    const double f = (double)lut.frac[h], fs = (double)lut.sat[s], vd = (double)(float)v;
+    const int p = min(round_pos(vd * (1.0 - fs)), 255);
+    // odd sectors use q = v (1 - fs f), even ones t = v (1 - fs (1 - f)), never both: one product, named for both
+    const int u = min(round_pos(vd * (1.0 - fs * ((i & 1) ? f : 1.0 - f))), 255);
+    const int q = u, t = u;
+    // sector:  0: v t p   1: q v p   2: p v t   3: p q v   4: t p v   5: v p q      (s = 0: v v v)
+    const bool z = s == 0;
+    const int o0 = (i == 0 || i >= 5) ? v : (i == 1) ? q : (i == 4) ? t : p;
+    const int o1 = (i == 1 || i == 2) ? v : (i == 0 || i == 6) ? t : (i == 3) ? q : p;
+    const int o2 = (i == 3 || i == 4) ? v : (i == 2) ? t : (i == 5) ? q : p;
+    out[0] = (uint8_t)(z ? v : o0); out[1] = (uint8_t)(z ? v : o1); out[2] = (uint8_t)(z ? v : o2);
 }
 __device__ __forceinline__ void jitter_op(const HueLut& lut, int op, float f, int mean_gray, uint8_t* px) {
-    if (op == 0) { for (int c = 0; c < 3; ++c) px[c] = blend8(0, px[c], f); }
-    else if (op == 1) { int l = luma8(px[0], px[1], px[2]); for (int c = 0; c < 3; ++c) px[c] = blend8(l, px[c], f); }
-    else if (op == 2) { uint8_t hsv[3]; rgb2hsv8(px, hsv); hsv[0] = (uint8_t)(hsv[0] + (uint8_t)(int)(f * 255.0f)); hsv2rgb8(lut, hsv, px); }
-    else { for (int c = 0; c < 3; ++c) px[c] = blend8(mean_gray, px[c], f); }
+    if (op == 2) { uint8_t hsv[3]; rgb2hsv8(lut, px, hsv); hsv[0] = (uint8_t)(hsv[0] + (uint8_t)(int)(f * 255.0f)); hsv2rgb8(lut, hsv, px); return; }
+    // brightness (towards 0), saturation (towards the pixel's luma), contrast (towards the image's mean luma): one blend, the op picks the target
+    const int target = op == 0 ? 0 : op == 1 ? luma8(px[0], px[1], px[2]) : mean_gray;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) px[c] = blend8(target, px[c], f);
 }
 
 // ------------------------------------------------------------------ PIL GaussianBlur (rendered_dataset.py:257-258)
@@ -584,10 +598,7 @@ __global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __rest
                                                            unsigned long long* __restrict__ lsum,
                                                            const uint8_t* __restrict__ rgbx_blur = nullptr,
                                                            const float* __restrict__ radius = nullptr) {
-    __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256];
-    hue_lut_fill(l_sect, l_frac, l_sat);
-    __syncthreads();
-    const HueLut lut = {l_sect, l_frac, l_sat};
+    HUE_LUT_DECL;
     const int b = blockIdx.y;
     const uint8_t* rgbx = (radius && blur_params(radius[b]).on) ? rgbx_blur : rgbx_plain;     // blurred copy exists only where the blur acts
     const int32_t* ord = order + b * 4; const float* fac = factor + b * 4;
@@ -598,8 +609,13 @@ __global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __rest
         // four pixels (one 16-byte load) per lane and iteration; the tail (npix % 4) one by one
         const uint8_t* img = rgbx + (size_t)b * npix * 4;
         const int nq = npix >> 2;
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
-            const uint4 q4 = *(const uint4*)(img + (size_t)i * 16);
+        const int stride = gridDim.x * 256;
+        int i = blockIdx.x * 256 + threadIdx.x;
+        uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
+        if (i < nq) nxt = *(const uint4*)(img + (size_t)i * 16);
+        for (; i < nq; i += stride) {
+            const uint4 q4 = nxt;                               // the next iteration's pixels are requested before this one's ~600 instructions
+            if (i + stride < nq) nxt = *(const uint4*)(img + (size_t)(i + stride) * 16);
             const uint32_t qq[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -629,10 +645,7 @@ __global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restr
                                                           T* __restrict__ out_pad, float* __restrict__ out_chw,
                                                           const uint8_t* __restrict__ rgbx_blur, const float* __restrict__ radius,
                                                           const uint8_t* __restrict__ flip = nullptr) {
-    __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256];
-    hue_lut_fill(l_sect, l_frac, l_sat);
-    __syncthreads();
-    const HueLut lut = {l_sect, l_frac, l_sat};
+    HUE_LUT_DECL;
     const int b = blockIdx.y;
     const uint8_t* rgbx = (radius && blur_params(radius[b]).on) ? rgbx_blur : rgbx_plain;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -683,10 +696,7 @@ static SceneDev to_dev(const ab_scene* s) {
 __global__ __launch_bounds__(256) void jitter_apply_kernel(const uint8_t* __restrict__ rgbx, int npix,
                                                            const int32_t* __restrict__ order, const float* __restrict__ factor,
                                                            const unsigned long long* __restrict__ lsum, uint8_t* __restrict__ out) {
-    __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256];
-    hue_lut_fill(l_sect, l_frac, l_sat);
-    __syncthreads();
-    const HueLut lut = {l_sect, l_frac, l_sat};
+    HUE_LUT_DECL;
     const int b = blockIdx.y;
     const int mean = (int)((double)lsum[b] / (double)npix + 0.5);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
