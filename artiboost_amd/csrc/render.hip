@@ -225,11 +225,13 @@ __device__ __forceinline__ void bg_sample(const SceneDev& sc, const SampleDev& s
     o[0] = (uint8_t)q; o[1] = (uint8_t)(q >> 8); o[2] = (uint8_t)(q >> 16); o[3] = 0;
 }
 
+// recs: this sample's records as raster_setup_kernel stored them -- the same TriRec setup_tri() would rebuild for the winning face (six
+// divisions, snapping, depth quantisation, orientation), read back as one 48-byte load instead
 __device__ __forceinline__ void shade_pixel(const SceneDev& sc, const SampleDev& sm, const float* hv, uint64_t key, int x,
-                                            int y, const BgCoef* bgc, uint8_t o[4]) {
+                                            int y, const BgCoef* bgc, uint8_t o[4], const TriRec* __restrict__ recs) {
     if (key == ~(uint64_t)0) { bg_sample(sc, sm, bgc[x & (TILE - 1)], bgc[TILE + (y & (TILE - 1))], o); return; }
     int gid = (int)(uint32_t)key;
-    TriRec t; setup_tri(sc, sm, hv, gid, t);
+    const TriRec t = recs[gid];
     float P[3][3]; int vid[3];
     face_verts(sc, sm, hv, gid, P, vid);
     if (t.valid == 2) {
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
         int y = ty0 + i / TILE, x = tx0 + i % TILE;
         uint64_t key = zb[i];
         uint8_t o[4];
-        shade_pixel(sc, sm, hv, key, x, y, bgc, o);
+        shade_pixel(sc, sm, hv, key, x, y, bgc, o, tri + (size_t)b * maxf);
         size_t pix = ((size_t)b * sc.H + y) * sc.W + x;
         *(uint32_t*)(rgbx + pix * 4) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
         if (keys_out) keys_out[pix] = key;
