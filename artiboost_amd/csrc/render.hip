@@ -183,6 +183,32 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(SceneDev sc, const Sa
             }
 }
 
+// ------------------------------------------------------------------ kernel 1b: dispatch order of the tiles
+// One tile in five holds triangles, and such a tile lives ~10x longer than a background-only one (rasterise, barrier, shade: serial
+// phases of a few busy waves).  In (sample, tile) launch order a CU holds one of them among four short-lived neighbours and the launch
+// lasts (tiles with triangles per CU) x (their life).  Listed first -- all samples' triangle tiles, then all background tiles -- five of
+// them share a CU and overlap each other's phases.  Which slot a tile gets depends on the order the samples' workgroups reach the
+// cursor; what a workgroup computes for its (sample, tile) does not.  (sample << 16 | tile): <= 65 535 tiles per frame.
+__global__ __launch_bounds__(256) void tile_order_kernel(const int* __restrict__ bin_count, int ntile, int* __restrict__ order_act,
+                                                         int* __restrict__ order_bg, int* __restrict__ cursor) {
+    __shared__ int s_cnt[2], s_base[2];
+    const int b = blockIdx.x;
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int slot[8];                                            // ntile <= 2048
+    for (int t = threadIdx.x, k = 0; t < ntile; t += 256, ++k) {
+        const int act = bin_count[b * ntile + t] > 0;
+        slot[k] = atomicAdd(&s_cnt[act ? 0 : 1], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) s_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    for (int t = threadIdx.x, k = 0; t < ntile; t += 256, ++k) {
+        const int act = bin_count[b * ntile + t] > 0;
+        (act ? order_act : order_bg)[s_base[act ? 0 : 1] + slot[k]] = (b << 16) | t;
+    }
+}
+
 // ------------------------------------------------------------------ kernel 2: tile raster + shade
 // Background = the sample's random crop resized to the render size with cv2's INTER_LINEAR fixed-point arithmetic
 // (renderer.py:125-136; restated in oracle/render_oracle.c bg_pixel / lin_coef, which this must match bit for bit).
@@ -315,19 +341,25 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
                                                            const float* __restrict__ hand_verts, int maxf,
                                                            const TriRec* __restrict__ tri, const int4* __restrict__ tails_g,
                                                            const int* __restrict__ bin_count, const int* __restrict__ bin_list,
-                                                           uint8_t* __restrict__ rgbx, uint64_t* __restrict__ keys_out) {
+                                                           uint8_t* __restrict__ rgbx, uint64_t* __restrict__ keys_out,
+                                                           const int* __restrict__ order_act, const int* __restrict__ order_bg,
+                                                           const int* __restrict__ cursor) {
     __shared__ unsigned long long zb[TILE * TILE];
     __shared__ BgCoef bgc[2 * TILE];
-    const int b = blockIdx.y;
+    // workgroup -> (sample, tile) through tile_order_kernel's lists: every tile that holds triangles, of every sample, is dispatched
+    // before the background-only ones (see there)
     const int tiles_x = sc.W / TILE;
-    const int ty0 = (blockIdx.x / tiles_x) * TILE, tx0 = (blockIdx.x % tiles_x) * TILE;
+    const int wg = blockIdx.x, nact = cursor[0];
+    const int packed = wg < nact ? order_act[wg] : order_bg[wg - nact];
+    const int b = packed >> 16, tile_id = packed & 0xffff;
+    const int ty0 = (tile_id / tiles_x) * TILE, tx0 = (tile_id % tiles_x) * TILE;
     const SampleDev sm = samples[b];
     const float* hv = hand_verts + (size_t)b * HAND_VERTS * 3;
     for (int i = threadIdx.x; i < TILE * TILE; i += RS_THREADS) zb[i] = ~0ull;
     bg_coef_fill(sc, sm, tx0, ty0, bgc);
     __syncthreads();
     const int ntile = tiles_x * (sc.H / TILE);
-    const int nbin = bin_count[b * ntile + blockIdx.x];
+    const int nbin = bin_count[b * ntile + tile_id];
     const bool active = nbin > 0;
     if (active) {
         const int nf = HAND_FACES + (sc.obj_face_off[sm.obj_id + 1] - sc.obj_face_off[sm.obj_id]);
@@ -379,7 +411,7 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
         };
         if (nbin <= BIN_CAP) {
             // the tile's own list (typically ~100 triangles: one round of the lanes)
-            const int* lst = bin_list + ((size_t)b * ntile + blockIdx.x) * BIN_CAP;
+            const int* lst = bin_list + ((size_t)b * ntile + tile_id) * BIN_CAP;
             for (int i = threadIdx.x; i < nbin; i += RS_THREADS) { const int gid = lst[i]; raster_tri(gid, tl[gid]); }
         } else {
             // overflowed list: scan every record; four tails per lane are fetched before any is examined
@@ -720,7 +752,8 @@ extern "C" long ab_render_workspace_bytes(int B, int W, int H, int max_faces) {
     auto al = [](long x) { return (x + 255) / 256 * 256; };
     return al((long)B * max_faces * 48) + al((long)B * W * H * 4) + al((long)B * 8) + al((long)B * 16) + al((long)B * max_faces * 16) +
            al((long)B * (W / TILE) * (H / TILE) * 4) + al((long)B * (W / TILE) * (H / TILE) * BIN_CAP * 4) +
-           al((long)B * W * H * 4);        // last: the blurred copy of the samples the GaussianBlur acts on
+           al((long)B * W * H * 4) +       // the blurred copy of the samples the GaussianBlur acts on
+           2 * al((long)B * (W / TILE) * (H / TILE) * 4);      // dispatch order of the tiles (with triangles | background only)
 }
 
 extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, const float* hand_verts,
@@ -744,18 +777,23 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
     const long ntile = (long)(sc.W / TILE) * (sc.H / TILE);
     int* bin_count = (int*)ws; ws += al(B * ntile * 4);
     int* bin_list = (int*)ws; ws += al(B * ntile * BIN_CAP * 4);
-    uint8_t* rgbx_blur = (uint8_t*)ws;
+    uint8_t* rgbx_blur = (uint8_t*)ws; ws += al((long)B * sc.W * sc.H * 4);
+    int* order_act = (int*)ws; ws += al(B * ntile * 4);
+    int* order_bg = (int*)ws;
+    int* cursor = (int*)(lsum + B);                           // the two words behind the B luma sums (the reserved slot), zeroed with them
+    if (ntile > 2048 || B > 32767) return AB_ESHAPE;
     // zeroing by kernel, not hipMemsetAsync: under stream capture the 64 KiB memset node of bin_count faulted on replay
     // (ROCm 7.2), so neither buffer goes through a memset node
-    zero_words_kernel<<<(unsigned)((B * 2 + 255) / 256), 256, 0, st>>>((unsigned*)lsum, (long)B * 2);
+    zero_words_kernel<<<(unsigned)((B * 2 + 2 + 255) / 256), 256, 0, st>>>((unsigned*)lsum, (long)B * 2 + 2);
     zero_words_kernel<<<(unsigned)((B * ntile + 255) / 256), 256, 0, st>>>((unsigned*)bin_count, B * ntile);
     AB_LAUNCH_CHECK();
     raster_setup_kernel<<<dim3((max_faces + 255) / 256, B), 256, (size_t)ntile * 12, st>>>(sc, (const SampleDev*)samples, hand_verts,
                                                                            max_faces, tri, tails, bin_count, bin_list);
     AB_LAUNCH_CHECK();
-    raster_shade_kernel<<<dim3((sc.W / TILE) * (sc.H / TILE), B), RS_THREADS, 0, st>>>(sc, (const SampleDev*)samples, hand_verts,
-                                                                                 max_faces, tri, tails, bin_count, bin_list, rgbx,
-                                                                                 (uint64_t*)keys_out);
+    tile_order_kernel<<<B, 256, 0, st>>>(bin_count, (int)ntile, order_act, order_bg, cursor);
+    AB_LAUNCH_CHECK();
+    raster_shade_kernel<<<(unsigned)(ntile * B), RS_THREADS, 0, st>>>(sc, (const SampleDev*)samples, hand_verts, max_faces, tri, tails,
+                                                                     bin_count, bin_list, rgbx, (uint64_t*)keys_out, order_act, order_bg, cursor);
     AB_LAUNCH_CHECK();
     int npix = sc.W * sc.H;
     if (blur_radius) {
