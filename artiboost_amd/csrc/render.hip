@@ -254,7 +254,8 @@ __device__ __forceinline__ void bg_sample(const SceneDev& sc, const SampleDev& s
 // recs: this sample's records as raster_setup_kernel stored them -- the same TriRec setup_tri() would rebuild for the winning face (six
 // divisions, snapping, depth quantisation, orientation), read back as one 48-byte load instead
 __device__ __forceinline__ void shade_pixel(const SceneDev& sc, const SampleDev& sm, const float* hv, uint64_t key, int x,
-                                            int y, const BgCoef* bgc, uint8_t o[4], const TriRec* __restrict__ recs) {
+                                            int y, const BgCoef* bgc, uint8_t o[4], const TriRec* __restrict__ recs,
+                                            const float* s2l, const uint8_t* l2s) {
     if (key == ~(uint64_t)0) { bg_sample(sc, sm, bgc[x & (TILE - 1)], bgc[TILE + (y & (TILE - 1))], o); return; }
     int gid = (int)(uint32_t)key;
     const TriRec t = recs[gid];
@@ -326,13 +327,13 @@ __device__ __forceinline__ void shade_pixel(const SceneDev& sc, const SampleDev&
     const uint8_t* texel = tex + ((size_t)ty * ts + tx) * 3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        float base = sc.srgb2lin[texel[c]];
+        float base = s2l[texel[c]];
         float F = PBR_F0 * (1.0f - PBR_METALLIC) + PBR_METALLIC * base;
         float dif = ((1.0f - F) * (((1.0f - PBR_F0) * (1.0f - PBR_METALLIC)) * base)) * PBR_INV_PI;
         float lin = base * PBR_AMBIENT + nlrad * (dif + F * gd4);
         if (lin < 0.f) lin = 0.f;
         if (lin > 1.f) lin = 1.f;
-        o[c] = sc.lin2srgb[(int)(lin * 4095.0f + 0.5f)];
+        o[c] = l2s[(int)(lin * 4095.0f + 0.5f)];
     }
     o[3] = 255;
 }
@@ -346,6 +347,8 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
                                                            const int* __restrict__ cursor) {
     __shared__ unsigned long long zb[TILE * TILE];
     __shared__ BgCoef bgc[2 * TILE];
+    __shared__ float l_s2l[256];                            // the two sRGB tables of the shading, copied per tile with triangles: the last two
+    __shared__ uint32_t l_l2s[1024];                        // of a shaded pixel's five dependent look-ups stay inside the CU
     // workgroup -> (sample, tile) through tile_order_kernel's lists: every tile that holds triangles, of every sample, is dispatched
     // before the background-only ones (see there)
     const int tiles_x = sc.W / TILE;
@@ -362,6 +365,8 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
     const int nbin = bin_count[b * ntile + tile_id];
     const bool active = nbin > 0;
     if (active) {
+        l_s2l[threadIdx.x & 255] = sc.srgb2lin[threadIdx.x & 255];
+        for (int i = threadIdx.x; i < 1024; i += RS_THREADS) l_l2s[i] = ((const uint32_t*)sc.lin2srgb)[i];
         const int nf = HAND_FACES + (sc.obj_face_off[sm.obj_id + 1] - sc.obj_face_off[sm.obj_id]);
         const TriRec* tb = tri + (size_t)b * maxf;
         const int4* tl = tails_g + (size_t)b * maxf;
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
         int y = ty0 + i / TILE, x = tx0 + i % TILE;
         uint64_t key = zb[i];
         uint8_t o[4];
-        shade_pixel(sc, sm, hv, key, x, y, bgc, o, tri + (size_t)b * maxf);
+        shade_pixel(sc, sm, hv, key, x, y, bgc, o, tri + (size_t)b * maxf, l_s2l, (const uint8_t*)l_l2s);
         size_t pix = ((size_t)b * sc.H + y) * sc.W + x;
         *(uint32_t*)(rgbx + pix * 4) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
         if (keys_out) keys_out[pix] = key;

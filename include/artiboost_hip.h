@@ -380,7 +380,8 @@ int ab_pose_loss_sym(const float* kp3d, const float* box6d, int box_stride, cons
  * the jitter (rendered_dataset.py:257-258, radius = U(0,1) * 0.1); each radius must be < 1.41 (box radius < 1 px).
  * out_pad: zero-bordered NHWC4 [B, oh+6, ow+8, 4] in out_dtype (interior written; border must already be zero);
  * out_chw: optional float [B,3,oh,ow] (the reference's `image` tensor).  keys_out (optional) uint64 [B,H,W]:
- * depth24<<32 | face id, ~0 = background.  rgbx_out (optional) uint8 [B,H,W,4] pre-jitter render.                 */
+ * depth24<<32 | face id, ~0 = background.  rgbx_out (optional) uint8 [B,H,W,4] pre-jitter render.
+ * ab_scene.srgb2lin: float [256], lin2srgb: uint8 [4096] (4-byte aligned: a tile with triangles copies it to LDS as words). */
 typedef struct ab_scene {
     const void* hand_faces; const void* hand_normals; const void* hand_uv; const void* hand_map; const void* hand_tex; int hts;
     const void* obj_verts; const void* obj_normals; const void* obj_uv; const void* obj_faces;
