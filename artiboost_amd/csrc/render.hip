@@ -477,13 +477,32 @@ __device__ __forceinline__ int luma8(int r, int g, int b) { return (r * 19595 + 
 //   equals (float)((double)a * rcp[d]): a/d is never within 2^-33 (relative) of a float rounding boundary, the double product is
 //   within 2^-52 of it.  Four IEEE float divisions per pixel become two 8-byte LDS reads and four double multiplies.
 struct HueLut { const uint8_t* sect; const float* frac; const float* sat; const double* rcp; };
+// The tables are computed once per process by hue_tab_init_kernel (four double divisions per entry: as a per-workgroup prologue they were
+// a quarter of jitter_stats' time at 64 workgroups per sample) and copied to LDS by every workgroup.
+struct HueTab { double rcp[256]; float frac[256], sat[256]; uint8_t sect[256]; };
+static __device__ HueTab g_hue_tab;
+__global__ void hue_tab_init_kernel() {
+    const int v = threadIdx.x;
+    const int i = (int)floor((double)(float)v * 6.0 / 255.0);
+    g_hue_tab.sect[v] = (uint8_t)i;
+    g_hue_tab.frac[v] = (float)((double)(float)v * 6.0 / 255.0 - (double)(float)i);
+    g_hue_tab.sat[v] = (float)((double)(float)v / 255.0);
+    g_hue_tab.rcp[v] = v ? 1.0 / (double)v : 0.0;
+}
+static void hue_tab_ready(hipStream_t st) {
+    // First use: fill the tables on `st` and wait, so that launches on OTHER streams (the real-frame augmentation runs beside the render)
+    // never read them half-written.  Inside a stream capture nothing may wait: the fill becomes a node in front of its reader and the
+    // next un-captured call still does the one-time fill.
+    static bool done = false;
+    if (done) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    hue_tab_init_kernel<<<1, 256, 0, st>>>();
+    if (cs == hipStreamCaptureStatusNone) { (void)hipStreamSynchronize(st); done = true; }
+}
 __device__ __forceinline__ void hue_lut_fill(uint8_t* sect, float* frac, float* sat, double* rcp) {
     for (int v = threadIdx.x; v < 256; v += blockDim.x) {
-        const int i = (int)floor((double)(float)v * 6.0 / 255.0);
-        sect[v] = (uint8_t)i;
-        frac[v] = (float)((double)(float)v * 6.0 / 255.0 - (double)(float)i);
-        sat[v] = (float)((double)(float)v / 255.0);
-        rcp[v] = v ? 1.0 / (double)v : 0.0;
+        sect[v] = g_hue_tab.sect[v]; frac[v] = g_hue_tab.frac[v]; sat[v] = g_hue_tab.sat[v]; rcp[v] = g_hue_tab.rcp[v];
     }
 }
 #define HUE_LUT_DECL __shared__ uint8_t l_sect[256]; __shared__ float l_frac[256], l_sat[256]; __shared__ double l_rcp[256]; \
@@ -632,11 +651,13 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const uint8_t* __restri
 }
 
 // kernel 3: luma sum of the image as it is when the contrast op is reached (ops before it applied on the fly)
+#define LSUM_STRIDE 16     // u64 slots between two samples' sums in the render / augment workspaces: device-scope atomics serialise per 128-byte line
+#define JS_WGS 64          // workgroups per sample (16 / 32 / 64 / 128 / 256 measure 93 / 78 / 66 / 66 / 72 us once the sums below no longer share lines)
 __global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __restrict__ rgbx_plain, int npix,
                                                            const int32_t* __restrict__ order, const float* __restrict__ factor,
                                                            unsigned long long* __restrict__ lsum,
                                                            const uint8_t* __restrict__ rgbx_blur = nullptr,
-                                                           const float* __restrict__ radius = nullptr) {
+                                                           const float* __restrict__ radius = nullptr, int ls = 1) {
     HUE_LUT_DECL;
     const int b = blockIdx.y;
     const uint8_t* rgbx = (radius && blur_params(radius[b]).on) ? rgbx_blur : rgbx_plain;     // blurred copy exists only where the blur acts
@@ -672,7 +693,15 @@ __global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __rest
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&lsum[b], s);     // integer: order-independent, exact
+    // ONE atomic per workgroup: the B sums sit 16 to a 128-byte line and device-scope atomics on a line serialise at ~21 ns each -- with one
+    // per wave (4 096 per line at 64 workgroups per sample) the launch was as long as its atomics (86 of 93 us)
+    __shared__ unsigned long long wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (t) atomicAdd(&lsum[(size_t)b * ls], t);                             // integer: order-independent, exact
+    }
 }
 
 // kernel 4: nearest-neighbour affine crop + full jitter chain + normalise; writes zero-bordered NHWC4 and/or CHW f32
@@ -683,7 +712,7 @@ __global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restr
                                                           const unsigned long long* __restrict__ lsum, int ow, int oh,
                                                           T* __restrict__ out_pad, float* __restrict__ out_chw,
                                                           const uint8_t* __restrict__ rgbx_blur, const float* __restrict__ radius,
-                                                          const uint8_t* __restrict__ flip = nullptr) {
+                                                          const uint8_t* __restrict__ flip = nullptr, int ls = 1) {
     HUE_LUT_DECL;
     const int b = blockIdx.y;
     const uint8_t* rgbx = (radius && blur_params(radius[b]).on) ? rgbx_blur : rgbx_plain;
@@ -701,7 +730,7 @@ __global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restr
         if (flip && flip[b]) sx = W - 1 - sx;
         uint32_t q = *(const uint32_t*)(rgbx + (((size_t)b * H + sy) * W + sx) * 4);
         uint8_t px[3] = {(uint8_t)q, (uint8_t)(q >> 8), (uint8_t)(q >> 16)};
-        int mean = (int)((double)lsum[b] / (double)(W * H) + 0.5);
+        int mean = (int)((double)lsum[(size_t)b * ls] / (double)(W * H) + 0.5);
         for (int k = 0; k < 4; ++k) jitter_op(lut, order[b * 4 + k], factor[b * 4 + k], mean, px);
         v[0] = (float)px[0]; v[1] = (float)px[1]; v[2] = (float)px[2];
     }
@@ -755,7 +784,7 @@ __global__ void zero_words_kernel(unsigned* __restrict__ p, long n) {
 extern "C" long ab_render_workspace_bytes(int B, int W, int H, int max_faces) {
     // tri records + rgbx + lsum + sbox + compact (valid, bbox) tails + per-tile bin counts and lists, each 256-byte aligned
     auto al = [](long x) { return (x + 255) / 256 * 256; };
-    return al((long)B * max_faces * 48) + al((long)B * W * H * 4) + al((long)B * 8) + al((long)B * 16) + al((long)B * max_faces * 16) +
+    return al((long)B * max_faces * 48) + al((long)B * W * H * 4) + al((long)B * 8 * LSUM_STRIDE) + al((long)B * 16) + al((long)B * max_faces * 16) +
            al((long)B * (W / TILE) * (H / TILE) * 4) + al((long)B * (W / TILE) * (H / TILE) * BIN_CAP * 4) +
            al((long)B * W * H * 4) +       // the blurred copy of the samples the GaussianBlur acts on
            2 * al((long)B * (W / TILE) * (H / TILE) * 4);      // dispatch order of the tiles (with triangles | background only)
@@ -776,7 +805,7 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
     char* ws = (char*)workspace;
     TriRec* tri = (TriRec*)ws; ws += al((long)B * max_faces * 48);
     uint8_t* rgbx = rgbx_out ? (uint8_t*)rgbx_out : (uint8_t*)ws; ws += al((long)B * sc.W * sc.H * 4);
-    unsigned long long* lsum = (unsigned long long*)ws; ws += al((long)B * 8);
+    unsigned long long* lsum = (unsigned long long*)ws; ws += al((long)B * 8 * LSUM_STRIDE);      // one 128-byte line per sample
     ws += al((long)B * 16);                                   // (reserved)
     int4* tails = (int4*)ws; ws += al((long)B * max_faces * 16);
     const long ntile = (long)(sc.W / TILE) * (sc.H / TILE);
@@ -785,11 +814,11 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
     uint8_t* rgbx_blur = (uint8_t*)ws; ws += al((long)B * sc.W * sc.H * 4);
     int* order_act = (int*)ws; ws += al(B * ntile * 4);
     int* order_bg = (int*)ws;
-    int* cursor = (int*)(lsum + B);                           // the two words behind the B luma sums (the reserved slot), zeroed with them
+    int* cursor = (int*)(lsum + (size_t)B * LSUM_STRIDE);     // the two words behind the luma sums (the reserved slot), zeroed with them
     if (ntile > 2048 || B > 32767) return AB_ESHAPE;
     // zeroing by kernel, not hipMemsetAsync: under stream capture the 64 KiB memset node of bin_count faulted on replay
     // (ROCm 7.2), so neither buffer goes through a memset node
-    zero_words_kernel<<<(unsigned)((B * 2 + 2 + 255) / 256), 256, 0, st>>>((unsigned*)lsum, (long)B * 2 + 2);
+    zero_words_kernel<<<(unsigned)((B * 2 * LSUM_STRIDE + 2 + 255) / 256), 256, 0, st>>>((unsigned*)lsum, (long)B * 2 * LSUM_STRIDE + 2);
     zero_words_kernel<<<(unsigned)((B * ntile + 255) / 256), 256, 0, st>>>((unsigned*)bin_count, B * ntile);
     AB_LAUNCH_CHECK();
     raster_setup_kernel<<<dim3((max_faces + 255) / 256, B), 256, (size_t)ntile * 12, st>>>(sc, (const SampleDev*)samples, hand_verts,
@@ -805,13 +834,14 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
         gauss_blur_kernel<<<dim3((unsigned)ntile, B), 256, 0, st>>>(rgbx, rgbx_blur, sc.W, sc.H, blur_radius, 0);
         AB_LAUNCH_CHECK();
     }
-    jitter_stats_kernel<<<dim3(64, B), 256, 0, st>>>(rgbx, npix, order, factor, lsum, rgbx_blur, blur_radius);
+    hue_tab_ready(st);
+    jitter_stats_kernel<<<dim3(JS_WGS, B), 256, 0, st>>>(rgbx, npix, order, factor, lsum, rgbx_blur, blur_radius, LSUM_STRIDE);
     AB_LAUNCH_CHECK();
     dim3 g((ow * oh + 255) / 256, B);
     if (out_dtype == AB_DT_F32)
-        warp_jitter_kernel<float><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (float*)out_pad, out_chw, rgbx_blur, blur_radius);
+        warp_jitter_kernel<float><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (float*)out_pad, out_chw, rgbx_blur, blur_radius, nullptr, LSUM_STRIDE);
     else if (out_dtype == AB_DT_BF16)
-        warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw, rgbx_blur, blur_radius);
+        warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw, rgbx_blur, blur_radius, nullptr, LSUM_STRIDE);
     else return AB_EINVAL;
     AB_LAUNCH_CHECK();
     return 0;
@@ -824,7 +854,8 @@ extern "C" int ab_color_jitter(const void* rgbx, int B, int npix, const int32_t*
     if (!rgbx || !order || !factor || !out || !lsum_ws || B < 1 || npix < 1) return AB_EINVAL;
     hipStream_t st = as_stream(stream);
     zero_words_kernel<<<(unsigned)((B * 2 + 255) / 256), 256, 0, st>>>((unsigned*)lsum_ws, (long)B * 2);
-    jitter_stats_kernel<<<dim3(64, B), 256, 0, st>>>((const uint8_t*)rgbx, npix, order, factor, (unsigned long long*)lsum_ws);
+    hue_tab_ready(st);
+    jitter_stats_kernel<<<dim3(JS_WGS, B), 256, 0, st>>>((const uint8_t*)rgbx, npix, order, factor, (unsigned long long*)lsum_ws);
     AB_LAUNCH_CHECK();
     jitter_apply_kernel<<<dim3(256, B), 256, 0, st>>>((const uint8_t*)rgbx, npix, order, factor,
                                                        (const unsigned long long*)lsum_ws, (uint8_t*)out);
@@ -846,7 +877,7 @@ extern "C" int ab_gaussian_blur(const void* rgbx, int B, int W, int H, const flo
 // one size: the same kernels as the tail of ab_render_batch.  workspace: ab_augment_workspace_bytes(B, W, H).
 extern "C" long ab_augment_workspace_bytes(int B, int W, int H) {
     auto al = [](long x) { return (x + 255) / 256 * 256; };
-    return al((long)B * 8) + al((long)B * W * H * 4);
+    return al((long)B * 8 * LSUM_STRIDE) + al((long)B * W * H * 4);
 }
 extern "C" int ab_augment_batch(const void* rgbx_in, int B, int W, int H, const int32_t* order, const float* factor,
                                 const float* inv_affine, const float* blur_radius, const uint8_t* flip, int ow, int oh,
@@ -857,16 +888,17 @@ extern "C" int ab_augment_batch(const void* rgbx_in, int B, int W, int H, const 
     auto al = [](long x) { return (x + 255) / 256 * 256; };
     const uint8_t* rgbx = (const uint8_t*)rgbx_in;
     unsigned long long* lsum = (unsigned long long*)workspace;
-    uint8_t* rgbx_blur = (uint8_t*)workspace + al((long)B * 8);
-    zero_words_kernel<<<(unsigned)((B * 2 + 255) / 256), 256, 0, st>>>((unsigned*)lsum, (long)B * 2);
+    uint8_t* rgbx_blur = (uint8_t*)workspace + al((long)B * 8 * LSUM_STRIDE);
+    zero_words_kernel<<<(unsigned)((B * 2 * LSUM_STRIDE + 255) / 256), 256, 0, st>>>((unsigned*)lsum, (long)B * 2 * LSUM_STRIDE);
     if (blur_radius) gauss_blur_kernel<<<dim3((unsigned)((W / TILE) * (H / TILE)), B), 256, 0, st>>>(rgbx, rgbx_blur, W, H, blur_radius, 0);
-    jitter_stats_kernel<<<dim3(64, B), 256, 0, st>>>(rgbx, W * H, order, factor, lsum, rgbx_blur, blur_radius);
+    hue_tab_ready(st);
+    jitter_stats_kernel<<<dim3(JS_WGS, B), 256, 0, st>>>(rgbx, W * H, order, factor, lsum, rgbx_blur, blur_radius, LSUM_STRIDE);
     AB_LAUNCH_CHECK();
     dim3 g((ow * oh + 255) / 256, B);
     if (out_dtype == AB_DT_F32)
-        warp_jitter_kernel<float><<<g, 256, 0, st>>>(rgbx, W, H, order, factor, inv_affine, lsum, ow, oh, (float*)out_pad, out_chw, rgbx_blur, blur_radius, flip);
+        warp_jitter_kernel<float><<<g, 256, 0, st>>>(rgbx, W, H, order, factor, inv_affine, lsum, ow, oh, (float*)out_pad, out_chw, rgbx_blur, blur_radius, flip, LSUM_STRIDE);
     else if (out_dtype == AB_DT_BF16)
-        warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, W, H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw, rgbx_blur, blur_radius, flip);
+        warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, W, H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw, rgbx_blur, blur_radius, flip, LSUM_STRIDE);
     else return AB_EINVAL;
     AB_LAUNCH_CHECK();
     return 0;
