@@ -463,7 +463,7 @@ __global__ __launch_bounds__(RS_THREADS) void raster_shade_kernel(SceneDev sc, c
 // Branch-free forms (round 4): the kernels that run these per pixel are VALU-issue bound (jitter_stats: 44 M wave instructions per
 // 64 x 512^2 launch, + 20 M scalar ones for the exec-mask bookkeeping of the divergent branches the first versions had).  Every
 // function below returns, for every input, what its branching predecessor returned: checked over all 2^24 RGB triples against the
-// oracle (tests/test_gpu_render.py) and, for the hue op, over all 2^24 triples x all 256 hue shifts (tools/hue_exhaustive.py).
+// oracle (tests/test_gpu_render.py) and, for the hue op, over all 2^24 triples x all 256 hue shifts (tests/hue_exhaustive.py).
 __device__ __forceinline__ uint8_t blend8(int in1, int in2, float f) {
     // ImageEnhance: in1 + f (in2 - in1), truncated; clipped to 0..255 when f is outside [0, 1] -- inside it the value lies between
     // the two inputs, so clipping always is the same function.

@@ -1,6 +1,6 @@
 """The hue op of ab_color_jitter (PIL: RGB -> HSV, H += shift mod 256, -> RGB) over ALL 2^24 RGB triples x ALL 256 hue shifts against the C oracle
 (oracle/render_oracle.c, pinned to Pillow): the branch-free rgb2hsv8 / hsv2rgb8 of render.hip are the same functions as PIL's.
-usage: python tools/hue_exhaustive.py [first_shift [last_shift]]      (~2 s per shift on the host for the oracle)"""
+usage: python tests/hue_exhaustive.py [first_shift [last_shift]]      (~2 s per shift on the host for the oracle)"""
 import ctypes
 import os
 import sys
@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")      # (a checker: lives under tests/, the only place besides smoke / cpu_baseline that may use oracle/)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import render_oracle as ro      # noqa: E402

@@ -92,7 +92,7 @@ def test_color_jitter_all_rgb_values_vs_oracle():
     rgbx = np.stack([(v >> 16) & 255, (v >> 8) & 255, v & 255, np.full_like(v, 255)], axis=1).astype(np.uint8).reshape(4096, 4096, 4)
     cases = [([2, 0, 1, 3], [0.075, 1.1, 0.9, 1.05]), ([3, 2, 1, 0], [0.93, -0.075, 1.1, 0.95]),
              ([1, 3, 0, 2], [1.07, 1.1, 0.9, -0.031]), ([2, 2, 2, 2], [0.5, 0.013, -0.2, 0.33]),
-             ([2, 2, 2, 2], [100.5 / 255, 200.5 / 255, 254.5 / 255, 0.0])]      # (all 256 hue shifts x all triples: tools/hue_exhaustive.py, 0 mismatches)
+             ([2, 2, 2, 2], [100.5 / 255, 200.5 / 255, 254.5 / 255, 0.0])]      # (all 256 hue shifts x all triples: tests/hue_exhaustive.py, 0 mismatches)
     src = torch.from_numpy(rgbx).cuda()
     ws = torch.empty(8, dtype=torch.uint8, device="cuda")
     for order, factor in cases:
