@@ -787,7 +787,9 @@ class HybridNet:
         # ---- box head (f32)
         g_mean = None
         if p.box_head:
-            g3 = torch.zeros((N, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
+            g3 = getattr(self, "_g3", None)      # padded copy of g_box6d: columns 6.. are zeroed once, only the six live ones are rewritten
+            if g3 is None or g3.shape[0] != N or g3.device != p.device:
+                g3 = self._g3 = torch.zeros((N, BOX_OUT_PAD), dtype=torch.float32, device=p.device)
             g3[:, :6].copy_(g_box6d)
             lw = lambda n: p.view(n).view(p.entries[n].kshape[0], -1)      # noqa: E731
             lg = lambda n: gv(n).view(p.entries[n].kshape[0], -1)          # noqa: E731
