@@ -16,6 +16,7 @@
 // incrementally and resolves visibility with ds_min_u64; tiles with an empty list go straight to the background.  The
 // HBM side is small (a 48-byte record per face, 4 bytes per pixel out).
 #include "common.h"
+#include <atomic>
 
 #define HAND_FACES 1538
 #define HAND_VERTS 778
@@ -493,12 +494,17 @@ static void hue_tab_ready(hipStream_t st) {
     // First use: fill the tables on `st` and wait, so that launches on OTHER streams (the real-frame augmentation runs beside the render)
     // never read them half-written.  Inside a stream capture nothing may wait: the fill becomes a node in front of its reader and the
     // next un-captured call still does the one-time fill.
-    static bool done = false;
-    if (done) return;
+    // g_hue_tab is a PER-DEVICE symbol: the flag is kept per device (a process that renders on cuda:1 after cuda:0 -- tests, tools -- would
+    // otherwise read an all-zero table there), and atomically (two host threads may race to the first call; a double fill is harmless).
+    static std::atomic<bool> done[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (done[dev].load(std::memory_order_acquire)) return;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(st, &cs);
     hue_tab_init_kernel<<<1, 256, 0, st>>>();
-    if (cs == hipStreamCaptureStatusNone) { (void)hipStreamSynchronize(st); done = true; }
+    if (cs == hipStreamCaptureStatusNone) { (void)hipStreamSynchronize(st); done[dev].store(true, std::memory_order_release); }
 }
 __device__ __forceinline__ void hue_lut_fill(uint8_t* sect, float* frac, float* sat, double* rcp) {
     for (int v = threadIdx.x; v < 256; v += blockDim.x) {

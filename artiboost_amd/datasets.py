@@ -116,9 +116,13 @@ class HO3D(_DownloadedSet):
         if ann is None:
             ann = self._read_annotations(seq_frames)
             if bool(preset.get("USE_CACHE", True)):
+                # every rank may get here: write to a private temporary and rename, so that a rank starting later never unpickles a
+                # half-written file (os.replace is atomic; the ranks write identical bytes)
                 os.makedirs(os.path.dirname(cache), exist_ok=True)
-                with open(cache, "wb") as f:
+                tmp = f"{cache}.{os.getpid()}.tmp"
+                with open(tmp, "wb") as f:
                     pickle.dump(ann, f, protocol=4)
+                os.replace(tmp, cache)
         self.ann = ann
         self.sample_idxs = list(range(len(ann["frames"])))
         if self.mini_factor != 1.0:                                     # ho3d.py:112-114
@@ -148,6 +152,11 @@ class HO3D(_DownloadedSet):
     # ---- HOdataSource
     def __len__(self):
         return len(self.sample_idxs) if self.available else 0
+
+    def get_sample_idxs(self):
+        """Dataset indices behind positions 0 .. len-1 (ho3d.py:112-114, hodata.py: __getitem__ reports get_sample_idxs()[idx] as SAMPLE_IDX;
+        differs from the position only with MINI_FACTOR != 1)."""
+        return self.sample_idxs
 
     def get_image_path(self, idx):
         seq, frame = self.ann["frames"][self.sample_idxs[idx]]

@@ -117,6 +117,8 @@ def inflate_into(data, info: PngInfo, dst: np.ndarray):
         rc = 0
         try:
             for o, n in info.idat:
+                if n == 0:          # a legal zero-length IDAT chunk: inflate() with no input returns Z_BUF_ERROR
+                    continue
                 s.next_in, s.avail_in = base + o, n
                 rc = z.inflate(ctypes.byref(s), 0)              # Z_NO_FLUSH
                 if rc not in (0, 1) or (rc == 0 and s.avail_in):      # an error, or output space exhausted with input left
@@ -126,6 +128,7 @@ def inflate_into(data, info: PngInfo, dst: np.ndarray):
             z.inflateEnd(ctypes.byref(s))
         if rc != 1 or done != info.raw_bytes or avail_in:      # Z_STREAM_END exactly at the promised size
             raise PngUnsupported("corrupt IDAT stream, or scanline bytes do not match the header")
+        _check_filter_types(info, dst)
         return
     mv = memoryview(data)
     if len(info.idat) == 1:
@@ -140,6 +143,15 @@ def inflate_into(data, info: PngInfo, dst: np.ndarray):
     if len(raw) != info.raw_bytes:
         raise PngUnsupported("scanline bytes do not match the header")
     dst[:] = np.frombuffer(raw, np.uint8)
+    _check_filter_types(info, dst)
+
+
+def _check_filter_types(info: PngInfo, raw: np.ndarray):
+    """Every scanline starts with its filter type 0..4; Pillow's ZipDecode raises on anything else, the device kernel's output for such a
+    line is undefined (ab_png_unfilter_batch is called without a status word): refuse on the host, H bytes per frame."""
+    pitch = info.raw_bytes // info.height
+    if pitch * info.height == info.raw_bytes and raw[:info.raw_bytes:pitch].max(initial=0) > 4:
+        raise PngUnsupported("scanline with a filter type above 4")
 
 
 _pool = None

@@ -166,10 +166,15 @@ class RealBatcher:
         dec = self._decoder(kind, side)
         frames = torch.empty((len(flat), H, W, 4), dtype=torch.uint8, device=self.dev)
         job = self._jobs.pop(tuple(flat), None)
-        if job is not None and kind == "png":
-            dec.complete(job, out=frames)          # the inflates were started by prefetch_files() a group earlier
-        else:
-            dec.decode(files, out=frames, infos=infos)
+        from .jpeg import JpegUnsupported
+        from .png import PngUnsupported
+        try:
+            if job is not None and kind == "png":
+                dec.complete(job, out=frames)          # the inflates were started by prefetch_files() a group earlier
+            else:
+                dec.decode(files, out=frames, infos=infos)
+        except (JpegUnsupported, PngUnsupported):      # a stream that only fails while decoding (corrupt / short IDAT, bad filter byte):
+            return                                     # nothing is kept; each batch of the group decodes on its own (augment() falls back to Pillow)
         o = 0
         for idxs in idx_lists:
             self._predecoded[tuple(int(i) for i in idxs)] = frames[o:o + len(idxs)]
@@ -286,8 +291,10 @@ class RealBatcher:
                 frames[a[0]] = self.src.get_image(a[1])
             from .png import pool
             list(pool(self.num_workers).map(one, enumerate(idxs)))
+        # splits other than train / trainval: JOINTS_VIS / CORNERS_VIS are forced to ones (hodata.py:296-313, 389-391)
         r = assemble_real_gt_batch([self.src.get_annots(idx) for idx in idxs], self.image_size, self.src.raw_size, draws, self.center_idx,
-                                   self.bbox_expand, self.center_jit, self.scale_jit, self.src.sides)
+                                   self.bbox_expand, self.center_jit, self.scale_jit, self.src.sides,
+                                   train_split=getattr(self.src, "data_split", "train") in ("train", "trainval"))
         gt = {k: r[k] for k in self.GT_KEYS}
         full = np.tile(np.eye(3), (n, 1, 1))
         full[:, :2] = r["affine"][:, :2].astype(np.float64)
@@ -355,7 +362,14 @@ class RealBatcher:
             frames = pre
         elif host.get("files") is not None:                        # the .jpg / .png files themselves: decoded to RGBX on the device
             frames = torch.empty((n, H, W, 4), dtype=torch.uint8, device=self.dev)
-            self._decoder(host["file_kind"]).decode(host["files"], out=frames, infos=host["file_infos"])
+            from .jpeg import JpegUnsupported
+            from .png import PngUnsupported
+            try:
+                self._decoder(host["file_kind"]).decode(host["files"], out=frames, infos=host["file_infos"])
+            except (JpegUnsupported, PngUnsupported):      # fails only while decoding: this batch goes through Pillow (the reference's get_image)
+                rgb = torch.from_numpy(np.stack([np.asarray(self.src.get_image(i))[..., :3] for i in host["idxs"]])).to(self.dev)
+                frames.zero_()
+                frames[..., :3].copy_(rgb)
         else:
             rgb = host["frames"].to(self.dev, non_blocking=True)
             frames = torch.zeros(rgb.shape[:3] + (4,), dtype=torch.uint8, device=self.dev)
@@ -367,6 +381,14 @@ class RealBatcher:
                 "ab_augment_batch")
         return out_chw
 
+    def _sample_idx_of(self, idxs):
+        """SAMPLE_IDX as the reference reports it: the dataset index get_sample_idxs()[position] (hodata.py __getitem__), not the position."""
+        gs = getattr(self.src, "get_sample_idxs", None)
+        if gs is None:
+            return idxs
+        m = gs()
+        return np.asarray([m[int(i)] for i in idxs], np.int64)
+
     def batch(self, idxs, draws=None, out_pad=None, want_chw=True, out_chw=None):
         """Device batch dict with the reference's keys (hodata.py:315-450; IS_SYNTH false, CCV ids -1).  out_pad / out_chw: rows of a larger
         batch's tensors to write the frames into."""
@@ -375,7 +397,7 @@ class RealBatcher:
         ow, oh = self.image_size
         chw = out_chw if out_chw is not None else (torch.empty((n, 3, oh, ow), dtype=torch.float32, device=self.dev) if want_chw else None)
         small = dict(host["gt"], __order=host["order"], __factor=host["factor"], __inv=host["inv"], __flip=host["flip"], __blur=host["blur"],
-                     __obj_idx=np.asarray(host["obj_idx"], np.int64), __idxs=host["idxs"],
+                     __obj_idx=np.asarray(host["obj_idx"], np.int64), __idxs=self._sample_idx_of(host["idxs"]),
                      __is_synth=np.zeros(n, np.bool_), __minus1=np.full(n, -1, np.int64))
         up = self._upload(small)                   # every small array of the batch: one pinned blob, one asynchronous copy
         self.augment(host, out_pad=out_pad, out_chw=chw,
@@ -439,11 +461,19 @@ class MixedLoader:
         return batch_size - int(round(batch_size * real_len / (real_len + synth_len)))
 
     def __len__(self):
-        n = len(range(self.rank, self.real_len, self.world)) // self.n_real if self.n_real else 0
+        # RANK-INDEPENDENT (drop_last over ranks, as plan_epoch does for the synthetic share): every rank keeps real_len // world samples.
+        # len(range(rank, real_len, world)) differs by one between ranks when real_len % world != 0, and a rank with one more batch
+        # than the others would wait forever in the gradient all-reduce.
+        n = (self.real_len // self.world) // self.n_real if self.n_real else 0
         return min(n, len(self.synth)) if self.n_synth else n
 
+    def _epoch_perm(self):
+        """This rank's real sample indices of the next epoch: the same seed on every rank -> one shared permutation, cut to
+        world * (real_len // world) first so that the rank slices are disjoint AND equally long."""
+        return self.rng.permutation(self.real_len)[:self.world * (self.real_len // self.world)][self.rank::self.world]
+
     def __iter__(self):
-        perm = self.rng.permutation(self.real_len)[self.rank::self.world]      # same seed on every rank -> disjoint slices
+        perm = self._epoch_perm()
         self.real._predecoded.clear()      # frames decoded ahead for an epoch that was not finished
         self.real.drop_jobs()
         if getattr(self, "_dec_stream", None) is not None:      # ... and a decode of that epoch possibly still in flight on the side stream

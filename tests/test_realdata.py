@@ -386,3 +386,37 @@ def test_mixed_batches_from_the_buffer_ring_equal_fresh_ones():
         seen.append(pad.data_ptr())
         assert float(pad[:, :3].abs().max()) == 0 and float(pad[:, :, :3].abs().max()) == 0 and float(pad[:, -3:].abs().max()) == 0
     assert len(ref) == len(seen) >= 4 and len(set(seen)) == 3 and seen[3] == seen[0]
+
+
+def test_mixed_loader_epoch_length_is_the_same_on_every_rank():
+    """Advisor finding (round 4): len(range(rank, real_len, world)) differs by one between ranks when real_len % world != 0; a rank with one
+    more batch would hang in the gradient all-reduce.  The real share is cut to world * (real_len // world) before the rank slices."""
+    from types import SimpleNamespace
+    from artiboost_amd.realdata import MixedLoader
+
+    class Synth:      # what MixedLoader reads of the ArtiBoostLoader: nominal epoch length, batch size, trimmed step count
+        use_synth, epoch = True, object()
+
+        def __init__(self, synth_len, bs, steps):
+            self.synth_len, self.batch_size, self._steps = synth_len, bs, steps
+
+        def __len__(self):
+            return self._steps
+
+    for real_len, factor, world, B in ((85805, 0.2, 2, 64), (11, 0.0, 2, 3), (1001, 0.6, 8, 16), (66034, 0.6, 8, 128), (37, 0.5, 3, 4)):
+        synth_len = int(real_len * factor)
+        lens, perms = [], []
+        for rank in range(world):
+            real = SimpleNamespace(src=range(real_len))
+            if synth_len:
+                ns = MixedLoader.n_synth_for(B, real_len, synth_len)
+                synth = Synth(synth_len, ns, (synth_len // world) // ns if ns else 0)
+            else:
+                synth = None
+            ml = MixedLoader(real, synth, B, seed=5, rank=rank, world_size=world)
+            lens.append(len(ml))
+            perms.append(ml._epoch_perm())
+        assert len(set(lens)) == 1, (real_len, factor, world, B, lens)
+        assert len({len(p) for p in perms}) == 1 and lens[0] * ml.n_real <= len(perms[0])
+        allp = np.concatenate(perms)
+        assert len(set(allp.tolist())) == len(allp)          # disjoint slices of one shared permutation
