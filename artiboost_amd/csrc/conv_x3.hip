@@ -31,6 +31,10 @@ int wgrad_gemm2_x3_stem_run(const void* xpad_hi, const void* xpad_lo, const void
 int stem_halo_x3_tiles(int N, int H, int W);                   // stem_halo.hip
 int stem_halo_x3_run(const void* xpad_hi, const void* xpad_lo, const void* w_hi, const void* w_lo, float* y, int N, int H, int W,
                      int Cout, float* stats, hipStream_t st);
+struct GemmRwSam { float* part; int C, D, H, W; };              // gemm_rw.hip
+int gemm_rw_ok(long M, int N, int K);
+int gemm_rw_run(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias, float* out, long M, int N,
+                int K, const GemmRwSam* sam, hipStream_t st);
 int wgrad_launch_reduce(const float* slabs, int ns, long slab_elems, int src_j, int dst_j, float* dst, int accumulate,
                            int stem_mask, hipStream_t st);      // conv_wgrad.hip
 
@@ -79,6 +83,11 @@ static int fwd_x3_impl(const void* x_hi, const void* x_lo, const void* w_hi, con
         int rc = conv3x3_x3_run(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, 0, nullptr, stats, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
+    if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && !stats && !relu && !ep_scale && y && gemm_rw_ok((long)N * H * W, Cout, Cin)) {
+        // plain GEMM with the weights resident in registers (gemm_rw.hip): the final layer of the head
+        int rc = gemm_rw_run(x_hi, x_lo, w_hi, w_lo, bias, y, (long)N * H * W, Cout, Cin, nullptr, as_stream(stream));
+        if (rc != AB_ESHAPE) return rc;
+    }
     ConvGemmArgs g = {};
     g.A = x_hi; g.A_lo = x_lo; g.Bw = w_hi; g.Bw_lo = w_lo; g.Out = y; g.bias = bias; g.stats = stats; g.relu = relu;
     g.ep_scale = ep_scale; g.out_hi = out_hi; g.out_lo = out_lo;
@@ -96,6 +105,22 @@ extern "C" int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* 
                                 int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* bias, float* stats,
                                 int relu, void* stream) {
     return fwd_x3_impl(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, kh, kw, stride, pad, bias, stats, relu, stream);
+}
+
+// Final layer of IntegralDeconvHead + the first stage of its soft-argmax in one launch (simplebaseline.py:95-101,173-175 then 183-189 with
+// 43-71): logits = conv1x1(x, w) + bias as fp32 [B, H, W, C * 32] AND the per-(image, 64-pixel tile, class) softmax statistics
+// `part` [B, H*W/64, C, 8] that ab_softargmax3d_stage2 merges -- the logits are not read back by a statistics pass.  Channel = c * 32 + d,
+// d < D valid (DEPTH_PITCH 32).  AB_ESHAPE when the register-resident GEMM does not take the shape (Cin % 64, Cin > 256, H * W % 64):
+// the caller then runs ab_conv2d_fwd_x3 + ab_softargmax3d_fwd.
+extern "C" int ab_conv1x1_sam_fwd_x3_ok(int B, int H, int W, int Cin, int C, int D) {
+    return D > 0 && D <= 32 && (H * W) % 64 == 0 && gemm_rw_ok((long)B * H * W, C * 32, Cin);
+}
+extern "C" int ab_conv1x1_sam_fwd_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, float* logits,
+                                     int B, int H, int W, int Cin, int C, int D, float* part, void* stream) {
+    if (!x_hi || !x_lo || !w_hi || !w_lo || !logits || !part) return AB_EINVAL;
+    if (!ab_conv1x1_sam_fwd_x3_ok(B, H, W, Cin, C, D)) return AB_ESHAPE;
+    GemmRwSam sam = {part, C, D, H, W};
+    return gemm_rw_run(x_hi, x_lo, w_hi, w_lo, bias, logits, (long)B * H * W, C * 32, Cin, &sam, as_stream(stream));
 }
 
 // Eval-mode forms of the GENERIC convolution and of the transposed convolution (the strided 3x3, the 1x1 downsample and the two

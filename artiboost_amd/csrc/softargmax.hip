@@ -469,6 +469,16 @@ extern "C" int ab_softargmax3d_fwd_norm(const void* logits, int dtype, int B, in
     return sam_fwd_impl(logits, dtype, B, C, D, DP, H, W, part, uvd, conf, stat, norm_type, stream);
 }
 
+// Second stage alone: `part` [B][ntile][C][8] was written by whoever produced the logits (ab_conv1x1_sam_fwd_x3: the final layer's
+// GEMM epilogue), ntile = ab_softargmax3d_ntiles(H, W).  Softmax head only.
+extern "C" int ab_softargmax3d_stage2(const float* part, int B, int C, int ntile, float* uvd, float* conf, float* stat, void* stream) {
+    if (!part || !uvd || !conf || !stat) return AB_EINVAL;
+    if (B <= 0 || C <= 0 || ntile <= 0) return AB_ESHAPE;
+    sam_stage2<<<B * C, 64, 0, as_stream(stream)>>>(part, C, ntile, uvd, conf, stat, 0);
+    AB_LAUNCH_CHECK();
+    return 0;
+}
+
 static int sam_bwd_impl(const void* logits, int dtype, int B, int C, int D, int DP, int H, int W, const float* uvd,
                         const float* conf, const float* stat, const float* g_uvd, const float* g_conf, void* dlogits, int norm, void* stream) {
     if (!logits || !uvd || !conf || !stat || !g_uvd || !dlogits) return AB_EINVAL;

@@ -33,6 +33,18 @@ def softargmax3d_fwd(logits, C, D, DP, norm=0):
     return uvd, conf, stat
 
 
+def softargmax3d_stage2(part, C):
+    """part [B, ntile, C, 8] (written by the final layer's GEMM epilogue: kernels.conv1x1_sam_fwd_x3) -> uvd, conf, stat as softargmax3d_fwd."""
+    B, nt = int(part.shape[0]), int(part.shape[1])
+    dev = part.device
+    uvd = torch.empty((B, C, 3), dtype=torch.float32, device=dev)
+    conf = torch.empty((B, C), dtype=torch.float32, device=dev)
+    stat = torch.empty((B, C, 2), dtype=torch.float32, device=dev)
+    L.check(L.lib().ab_softargmax3d_stage2(L.ptr(part), L.i(B), L.i(C), L.i(nt), L.ptr(uvd), L.ptr(conf), L.ptr(stat), L.stream()),
+            "ab_softargmax3d_stage2")
+    return uvd, conf, stat
+
+
 def softargmax3d_bwd(logits, C, D, DP, uvd, conf, stat, g_uvd, g_conf=None, inplace=False, norm=0):
     """-> dlogits (same shape/dtype as logits; written over `logits` when inplace)."""
     B, H, W, _ = logits.shape

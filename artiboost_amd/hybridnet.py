@@ -25,7 +25,7 @@ import os
 import torch
 
 from . import kernels as K
-from .head import softargmax3d_fwd, softargmax3d_bwd, softargmax3d_bwd_x3
+from .head import softargmax3d_fwd, softargmax3d_bwd, softargmax3d_bwd_x3, softargmax3d_stage2
 
 RESNET34_LAYERS = [3, 4, 6, 3]
 DEPTH_PITCH = 32
@@ -581,7 +581,15 @@ class HybridNet:
             e1, bnpd1 = self._bn(hp + ".deconv_layers.1", d1, st1, N * 4 * h4 * w4)
             d2, st2 = deconv(e1, hp + ".deconv_layers.3.weight", (4 * h4, 4 * w4))
             e2, bnpd2 = self._bn(hp + ".deconv_layers.4", d2, st2, N * 16 * h4 * w4)
-        logits = self._conv_fwd(e2, hp + ".final_layer.weight", 1, 0, bias=p.view(hp + ".final_layer.bias"))
+        # bf16x3, softmax head: the final layer as the register-resident GEMM with the soft-argmax's first stage in its epilogue
+        # (ab_conv1x1_sam_fwd_x3); head_fwd() then only merges the per-tile rows
+        wf = self.w(hp + ".final_layer.weight") if self.x3 else None
+        self._sam_part = None
+        if (self.x3 and self.fuse_sam and self.norm == 0
+                and K.conv1x1_sam_fwd_x3_ok(e2, wf, p.nclasses_pad, p.depth, DEPTH_PITCH)):
+            logits, self._sam_part = K.conv1x1_sam_fwd_x3(e2, wf, p.view(hp + ".final_layer.bias"), p.nclasses_pad, p.depth)
+        else:
+            logits = self._conv_fwd(e2, hp + ".final_layer.weight", 1, 0, bias=p.view(hp + ".final_layer.bias"))
         # ---- MLP_O box head, always f32 (tiny; keeps the 6-D rotation at full precision)
         m0 = fmean.view(N, p.feat_ch)
         if p.box_head:
@@ -672,7 +680,12 @@ class HybridNet:
 
     def head_fwd(self, logits):
         """-> kp3d [N,22,3], conf [N,22], stat (kept for head_bwd)."""
-        kp3d, conf, stat = softargmax3d_fwd(logits, self.p.nclasses_pad, self.p.depth, DEPTH_PITCH, self.norm)
+        part = getattr(self, "_sam_part", None)
+        last = getattr(self, "last", None)
+        if part is not None and last is not None and logits is last.get("logits"):      # statistics from the GEMM epilogue of THIS forward
+            kp3d, conf, stat = softargmax3d_stage2(part, self.p.nclasses_pad)
+        else:
+            kp3d, conf, stat = softargmax3d_fwd(logits, self.p.nclasses_pad, self.p.depth, DEPTH_PITCH, self.norm)
         if self.p.nclasses_pad != self.p.nclasses:        # the padding class: dropped from what the model sees, kept for the backward
             self._head_full = (kp3d, conf)
             return kp3d[:, :self.p.nclasses].contiguous(), conf[:, :self.p.nclasses].contiguous(), stat
@@ -710,6 +723,7 @@ class HybridNet:
     stem_pool_reduce = os.environ.get("AB_STEM_POOL_REDUCE", "1") != "0"   # bf16x3: see _backward_trunk
     res_planes = os.environ.get("AB_RES_PLANES", "1") != "0"     # bf16x3: block outputs only as (hi, lo) planes, no fp32 copy
     pool_win = os.environ.get("AB_POOL_WIN", "1") != "0"          # bf16x3: stem BatchNorm-backward reduction over the pooled elements
+    fuse_sam = os.environ.get("AB_FUSE_SAM", "1") != "0"          # bf16x3: soft-argmax stage 1 in the final layer's GEMM epilogue
     sam_bias = os.environ.get("AB_SAM_BIAS", "1") != "0"          # bf16x3: final-layer bias gradient out of the soft-argmax backward
     fuse_ds_bn = os.environ.get("AB_FUSE_DS_BN", "1") != "0"      # bf16x3: the downsample BatchNorm inside bn2's apply pass
     pair_dgrad = os.environ.get("AB_PAIR_DGRAD", "1") != "0"      # bf16x3: conv1 + downsample data gradients of a block in one launch

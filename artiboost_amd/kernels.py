@@ -479,6 +479,26 @@ def conv2d_fwd_x3(x, w_split, stride, pad, bias=None, want_stats=False, relu=Fal
     return (y, stats) if want_stats else y
 
 
+def conv1x1_sam_fwd_x3_ok(x, w_split, C, D, DP):
+    """True when ab_conv1x1_sam_fwd_x3 takes the final layer's shape (DEPTH_PITCH 32, Cin % 64 == 0, <= 256, H * W % 64 == 0)."""
+    xh, _ = _planes(x) if x.dtype == torch.bfloat16 else (x, None)
+    N, H, W, Cin = xh.shape
+    return DP == 32 and tuple(w_split.shape[1:]) == (C * 32, 1, 1, Cin) and \
+        bool(L.lib().ab_conv1x1_sam_fwd_x3_ok(L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(C), L.i(D)))
+
+
+def conv1x1_sam_fwd_x3(x, w_split, bias, C, D):
+    """Final layer + soft-argmax stage 1 (ab_conv1x1_sam_fwd_x3): x fp32 / split [.., N,H,W,Cin], w_split [2, C*32, 1, 1, Cin] ->
+    (logits fp32 [N,H,W,C*32], part fp32 [N, H*W/64, C, 8])."""
+    xh, xl = _planes(x)
+    N, H, W, Cin = xh.shape
+    y = torch.empty((N, H, W, C * 32), dtype=torch.float32, device=xh.device)
+    part = torch.empty((N, H * W // 64, C, 8), dtype=torch.float32, device=xh.device)
+    L.check(L.lib().ab_conv1x1_sam_fwd_x3(L.ptr(xh), L.ptr(xl), L.ptr(w_split[0]), L.ptr(w_split[1]), L.ptr(bias), L.ptr(y), L.i(N), L.i(H),
+                                          L.i(W), L.i(Cin), L.i(C), L.i(D), L.ptr(part), L.stream()), "ab_conv1x1_sam_fwd_x3")
+    return y, part
+
+
 def conv2d_fwd_x3_evalbn_ok(x, w_split):
     xh = x[0] if x.dtype == torch.bfloat16 else x
     N, H, W, Cin = xh.shape

@@ -136,6 +136,16 @@ int ab_conv2d_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int k
 int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* y, int N, int H, int W,
                      int Cin, int Cout, int kh, int kw, int stride, int pad, const float* bias, float* stats, int relu,
                      void* stream);
+/* The final layer of IntegralDeconvHead and the first stage of its soft-argmax in ONE launch -- replaces final_layer (nn.Conv2d(256,
+ * NCLASSES * DEPTH, 1): anakin/models/simplebaseline.py:95-101,173-175) followed by the softmax statistics of norm_heatmap / integral_heatmap3d
+ * (:16-40, 43-71, 183-189).  x (hi, lo) [B,H,W,Cin]; w (hi, lo) [C*32][Cin] (channel = c*32 + d, d < D valid: DEPTH_PITCH 32, padding bins
+ * carry zero weights); bias [C*32] or NULL; logits fp32 [B,H,W,C*32]; part fp32 [B, H*W/64, C, 8] = the rows ab_softargmax3d_stage2 merges
+ * into uvd / conf / stat (same meaning as ab_softargmax3d_fwd's workspace).  _ok(): 1 when the register-resident GEMM takes the shape
+ * (Cin % 64 == 0, Cin <= 256, H*W % 64 == 0, D <= 32); otherwise AB_ESHAPE and the caller runs ab_conv2d_fwd_x3 + ab_softargmax3d_fwd.  */
+int ab_conv1x1_sam_fwd_x3_ok(int B, int H, int W, int Cin, int C, int D);
+int ab_conv1x1_sam_fwd_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, const float* bias, float* logits,
+                          int B, int H, int W, int Cin, int C, int D, float* part, void* stream);
+int ab_softargmax3d_stage2(const float* part, int B, int C, int ntile, float* uvd, float* conf, float* stat, void* stream);
 /* Eval-mode BasicBlock convolutions (anakin/models/resnet.py:85-101 under model.eval(): train/submit_reload.py:26-79, the TEST
  * pass of train/train_artiboost.py:224-240): 3x3 / stride 1 / pad 1 convolution with the BatchNorm that follows folded into the
  * epilogue -- bnp = [scale Cout | shift Cout | ..] from ab_bn_eval_params; out = relu?(conv * scale + shift + residual) as (hi, lo)
@@ -504,6 +514,8 @@ int ab_mano_lbs(const float* pose, const float* betas, const float* v_template, 
  * @check ab_split_f32: bf16: hi lo; src hi lo >= n
  * @check ab_cast_f32_bf16: bf16: dst; src dst >= n
  * @check ab_conv2d_fwd_x3: bf16: x_hi x_lo w_hi w_lo; x_hi x_lo >= N*H*W*Cin; w_hi w_lo >= Cout*kh*kw*Cin; y >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; bias >= Cout; stats >= ab_conv2d_x3_stat_rows(N,H,W,Cin,Cout,kh,kw,stride,pad)*Cout*2
+ * @check ab_conv1x1_sam_fwd_x3: bf16: x_hi x_lo w_hi w_lo; x_hi x_lo >= B*H*W*Cin; w_hi w_lo >= C*32*Cin; bias >= C*32; logits >= B*H*W*C*32; part >= B*(H*W/64)*C*8
+ * @check ab_softargmax3d_stage2: part >= B*ntile*C*8; uvd >= B*C*3; conf >= B*C; stat >= B*C*2
  * @check ab_conv2d_fwd_x3_evalbn: bf16: x_hi x_lo w_hi w_lo res_hi res_lo out_hi out_lo; x_hi x_lo >= N*H*W*Cin; w_hi w_lo >= Cout*9*Cin; bnp >= 2*Cout; res_hi res_lo res_f32 out_hi out_lo out_f32 >= N*H*W*Cout
  * @check ab_conv2d_fwd_x3_affine: bf16: x_hi x_lo w_hi w_lo out_hi out_lo; x_hi x_lo >= N*H*W*Cin; w_hi w_lo >= Cout*kh*kw*Cin; scale shift >= Cout; out_f32 out_hi out_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout
  * @check ab_conv2d_dgrad_x3: bf16: dy_hi dy_lo wt_hi wt_lo; dy_hi dy_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; wt_hi wt_lo >= Cin*kh*kw*Cout; dx addend >= N*H*W*Cin

@@ -494,3 +494,65 @@ def test_bn_finalize_inside_the_apply_passes(C, rows, resmode):
     torch.testing.assert_close(dg1, dg2, rtol=2e-5, atol=2e-4)
     torch.testing.assert_close(db1, db2, rtol=2e-5, atol=2e-4)
     torch.testing.assert_close(dy1.float().sum(0), dy2.float().sum(0), rtol=1e-4, atol=2e-5)
+
+
+# ---- round 5: the register-resident GEMM of the final layer (gemm_rw.hip) and its fused soft-argmax statistics
+RW_CASES = [
+    # B, H, W, Cin, C (classes; Cout = C * 32), D
+    (2, 8, 8, 256, 22, 28),       # one 64-pixel tile per image, three channel groups (8 + 8 + 6 waves)
+    (3, 16, 8, 256, 22, 28),      # W < 32: a 32-pixel block spans four image rows
+    (2, 32, 32, 256, 22, 28),     # benchmark head geometry (per image)
+    (1, 8, 16, 128, 3, 32),       # K = 128, one partial channel group, no padding bins
+    (5, 8, 8, 64, 9, 17),         # K = 64, two groups, odd unit count
+]
+
+
+@pytest.mark.parametrize("case", RW_CASES)
+def test_final_layer_gemm_rw_and_fused_softargmax(case):
+    """ab_conv2d_fwd_x3 (1x1 route) and ab_conv1x1_sam_fwd_x3 against float64, the per-tile statistics against a float64 softmax of
+    the kernel's own logits, and uvd / conf against the oracle formula (simplebaseline.py:43-71, 183-189)."""
+    from artiboost_amd import kernels as K
+    from artiboost_amd.head import softargmax3d_fwd, softargmax3d_stage2
+    B, H, W, Cin, C, D = case
+    Cout = C * 32
+    g = torch.Generator().manual_seed(hash(case) % 991)
+    x = torch.randn((B, H, W, Cin), generator=g)
+    w = torch.randn((Cout, Cin), generator=g) * (4.0 / Cin) ** 0.5
+    w.view(C, 32, Cin)[:, D:] = 0                       # padding depth bins carry zero weights
+    b = torch.randn(Cout, generator=g)
+    b.view(C, 32)[:, D:] = 0
+    ref = x.double().reshape(-1, Cin) @ w.double().t() + b.double()
+    ws = K.split(w.view(Cout, 1, 1, Cin).contiguous().cuda())
+    xs = K.split(x.cuda())
+    y = K.conv2d_fwd_x3(xs, ws, 1, 0, bias=b.cuda())                      # plain route (no statistics)
+    close(y.cpu().reshape(-1, Cout), ref)
+    assert K.conv1x1_sam_fwd_x3_ok(xs, ws, C, D, 32)
+    y2, part = K.conv1x1_sam_fwd_x3(xs, ws, b.cuda(), C, D)
+    assert torch.equal(y2, y)                                              # the same GEMM, bit for bit
+    # statistics of every (image, tile, class) against float64 on the kernel's logits
+    lg = y2.double().cpu().view(B, H * W // 64, 64, C, 32)[..., :D]        # [B, tile, pix, C, D]
+    m = lg.amax(dim=(2, 4))
+    e = torch.exp(lg - m[:, :, None, :, None])
+    pix = torch.arange(H * W).view(H * W // 64, 64)
+    cu = ((pix % W).double() / W)[None, :, :, None, None]
+    cv = ((pix // W).double() / H)[None, :, :, None, None]
+    cd = (torch.arange(D).double() / D)[None, None, None, None, :]
+    pp = part.double().cpu()
+    np.testing.assert_array_equal(pp[..., 0].numpy(), m.numpy())
+    for k, ref_k in ((1, e.sum((2, 4))), (2, (e * cu).sum((2, 4))), (3, (e * cv).sum((2, 4))), (4, (e * cd).sum((2, 4)))):
+        np.testing.assert_allclose(pp[..., k].numpy(), ref_k.numpy(), rtol=2e-6, atol=1e-7)
+    # stage 2 of the fused rows == the two-stage kernel on the same logits (to rounding), and == the float64 integral
+    uvd, conf, stat = softargmax3d_stage2(part, C)
+    uvd0, conf0, stat0 = softargmax3d_fwd(y2, C, D, 32)
+    np.testing.assert_allclose(uvd.cpu().numpy(), uvd0.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(conf.cpu().numpy(), conf0.cpu().numpy(), rtol=3e-6)
+    np.testing.assert_array_equal(stat[..., 0].cpu().numpy(), stat0[..., 0].cpu().numpy())
+    np.testing.assert_allclose(stat[..., 1].cpu().numpy(), stat0[..., 1].cpu().numpy(), rtol=3e-6)
+    full = y2.double().cpu().view(B, H * W, C, 32)[..., :D]
+    p = torch.softmax(full.permute(0, 2, 1, 3).reshape(B, C, -1), dim=-1).view(B, C, H * W, D)
+    p = p / (p.sum((2, 3), keepdim=True) + 1e-7)
+    allpix = torch.arange(H * W)
+    u = (p.sum(3) * ((allpix % W).double() / W)).sum(2)
+    v = (p.sum(3) * ((allpix // W).double() / H)).sum(2)
+    dd = (p.sum(2) * (torch.arange(D).double() / D)).sum(2)
+    np.testing.assert_allclose(uvd.cpu().numpy(), torch.stack([u, v, dd], -1).numpy(), atol=3e-6)
