@@ -119,3 +119,20 @@ static int clip_adam_impl(float* param, const float* grad, float* m, float* v, l
     AB_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---- measurement aid (bench.py's roofline leg): the device's constant-rate wall clock written to a slot by a one-thread launch.  Captured
+// into the step's hipGraph around every conv-stack call, the slot differences are those launches' durations INSIDE the graph replay
+// (rocprofv3 is not available in the driver's bench run; torch's external timing events are disallowed on ROCm).
+__global__ void wall_stamp_kernel(int64_t* slot) { *slot = (int64_t)wall_clock64(); }
+extern "C" int ab_wall_stamp(int64_t* slot, void* stream) {
+    if (!slot) return AB_EINVAL;
+    wall_stamp_kernel<<<1, 1, 0, as_stream(stream)>>>(slot);
+    AB_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int ab_wall_clock_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+    return khz;
+}

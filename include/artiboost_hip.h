@@ -28,6 +28,12 @@ extern "C" {
 /* library / device info: returns ABI version (integer, bumped on any signature change) */
 int ab_abi_version(void);
 
+/* measurement aid (no reference counterpart; bench.py's roofline leg): a one-thread launch that writes the device's constant-rate wall clock to
+ * *slot (device int64); ab_wall_clock_khz(): its rate.  Captured into a hipGraph around a kernel, the slot difference is that kernel's
+ * duration inside the replay.                                                                                                          */
+int ab_wall_stamp(int64_t* slot, void* stream);
+int ab_wall_clock_khz(void);
+
 /* ---- M3: fused softmax + 3-D integral (soft-argmax) head ------------------------------------------------------
  * replaces: norm_heatmap('softmax') + max + renorm + view_to_bcdhw + integral_heatmap3d
  *           anakin/models/simplebaseline.py:16-40, 43-71, 183-189

@@ -389,3 +389,94 @@ def test_pose_generator_vs_reference_class_golden(golden_dir):
     np.testing.assert_allclose(op.cpu().numpy(), g["final_obj_pose"], rtol=1e-5, atol=5e-6)
     np.testing.assert_allclose(hv.cpu().numpy(), g["final_hand_verts"], rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(jt.cpu().numpy(), g["final_joints"], rtol=1e-5, atol=2e-5)
+
+
+# ---- render <-> ground-truth alignment (the counterpart of the reference's only render check, script/viz_artiboost_render.py:34-129, which
+# overlays the projected GT joints / corners / mesh on the rendered crop): the rasteriser's visibility keys (R3: unpinnable pixel oracle) are
+# tied to the reference-pinned GT of R4 (joints_2d / corners_2d of assemble_gt_batch, tests/golden/misc.npz) through the crop affine.
+def _alignment_stats(keys, inv_affine, joints_2d, joints_3d, root, joints_vis, corners_2d, size, n_hand_faces):
+    """keys: uint64 [H, W] full-frame visibility keys of one sample (depth24 << 32 | face id; all ones = background).
+    -> (joints checked, joints that land within 2 px of a hand pixel, object-pixel bbox in crop space or None, corners bbox in crop space)."""
+    H, W = keys.shape
+    A = inv_affine.reshape(2, 3).astype(np.float64)
+    ys, xs = np.mgrid[0:size, 0:size]
+    src = np.einsum("ij,jhw->ihw", A, np.stack([xs, ys, np.ones_like(xs)]).astype(np.float64))      # crop pixel -> full-frame (x, y)
+    sx, sy = np.rint(src[0]).astype(np.int64), np.rint(src[1]).astype(np.int64)
+    inside = (sx >= 0) & (sx < W) & (sy >= 0) & (sy < H)
+    kc = np.full((size, size), np.uint64(0xFFFFFFFFFFFFFFFF))
+    kc[inside] = keys[sy[inside], sx[inside]]                                                   # the visibility keys seen through the crop
+    cov = kc != np.uint64(0xFFFFFFFFFFFFFFFF)
+    fid = (kc & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    hand, obj = cov & (fid < n_hand_faces), cov & (fid >= n_hand_faces)
+    z24 = (kc >> np.uint64(32)).astype(np.float64) / 16777215.0
+    depth = 1.0 / (20.0 + z24 * (0.01 - 20.0))                                                   # metres (the renderer's depth quantisation)
+    checked = hit = 0
+    for j in range(joints_2d.shape[0]):
+        if joints_vis[j] < 0.5:
+            continue
+        u, v = joints_2d[j]
+        x0, x1, y0, y1 = int(np.floor(u)) - 2, int(np.ceil(u)) + 3, int(np.floor(v)) - 2, int(np.ceil(v)) + 3
+        if x0 < 0 or y0 < 0 or x1 > size or y1 > size:
+            continue                                                                            # too close to the border for a 2-px window
+        win_hand, win_obj, win_d = hand[y0:y1, x0:x1], obj[y0:y1, x0:x1], depth[y0:y1, x0:x1]
+        zj = joints_3d[j, 2] + root[2]
+        if not win_hand.any() and win_obj.any() and (win_d[win_obj] < zj).all():
+            continue                                                                            # the object is in front of this joint: not its surface
+        checked += 1
+        hit += bool(win_hand.any())
+    ob = None
+    if obj.any():
+        yy, xx = np.nonzero(obj)
+        ob = (xx.min(), yy.min(), xx.max(), yy.max())
+    cb = (corners_2d[:, 0].min(), corners_2d[:, 1].min(), corners_2d[:, 0].max(), corners_2d[:, 1].max())
+    return checked, hit, ob, cb
+
+
+@pytest.mark.parametrize("dataset,cfgname,B", [("HO3D", "ho3dv2_clasbased_artiboost_mi355x.yaml", 8), ("DexYCB", "dexycb_clasbased_sym_mi355x.yaml", 2)])
+def test_rendered_pixels_line_up_with_the_ground_truth(dataset, cfgname, B):
+    """(i) every visible GT joint not hidden behind the object lands within 2 px of a HAND pixel of the render; (ii) the bbox of the OBJECT
+    pixels lies inside the bbox of the GT corners_2d (+- 2 px) and spans most of its in-image part; (iii) with the key image mirrored in x or
+    in y the same check FAILS (the test can fail).  Keys from the HIP path and from render_oracle.c (they are bit-identical: both are run)."""
+    import yaml
+    from artiboost_amd.assets import SceneAssets
+    from artiboost_amd.synth import ArtiBoostLoader
+    size = 256
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", cfgname)))
+    cfg["DATA_PRESET"]["IMAGE_SIZE"] = [size, size]
+    assets = SceneAssets(dataset, seed=1)
+    loader = ArtiBoostLoader.from_assets(assets, cfg["MANAGER"], cfg["DATA_PRESET"], B, B, compute_dtype=torch.float32, random_seed=11)
+    loader.prepare()
+    ep = loader.epoch
+    smp = ep["_samples"][:B]
+    o = loader.renderer.render(smp, ep["_hand_verts"][:B], ep["_order"][:B], ep["_factor"][:B], ep["_inv_affine"][:B], size, size,
+                               out_chw=torch.empty((B, 3, size, size), dtype=torch.float32, device=smp.device), want_keys=True)
+    keys_hip = o["keys"].cpu().numpy().view(np.uint64)
+    holder = ro.SceneHolder(assets)
+    _, _, keys_ref = holder.render_batch(smp.cpu().numpy().view(ro.SAMPLE_DTYPE).reshape(-1), ep["_hand_verts"][:B].cpu().numpy(),
+                                         ep["_order"][:B].cpu().numpy(), ep["_factor"][:B].cpu().numpy(), ep["_inv_affine"][:B].cpu().numpy(),
+                                         size, size, blur=ep["_blur"][:B].cpu().numpy())
+    np.testing.assert_array_equal(keys_hip, keys_ref)
+    g = {k: ep[k][:B].cpu().numpy() for k in ("joints_2d", "joints_3d", "root_joint", "joints_vis", "corners_2d", "_inv_affine")}
+    nh = 1538                                                    # MANO faces come first in the scene's face list (test_render_properties)
+    for name, keys in (("hip", keys_hip), ("oracle", keys_ref)):
+        tot = hits = 0
+        mirrored = {"x": [0, 0], "y": [0, 0]}
+        for b in range(B):
+            args = (g["_inv_affine"][b], g["joints_2d"][b], g["joints_3d"][b], g["root_joint"][b], g["joints_vis"][b], g["corners_2d"][b], size, nh)
+            c, h, ob, cb = _alignment_stats(keys[b], *args)
+            tot += c; hits += h
+            assert c >= 8, f"{name}: sample {b}: only {c} joints could be checked"
+            assert h == c, f"{name}: sample {b}: {c - h} of {c} visible joints are not on the rendered hand"
+            assert ob is not None, f"{name}: sample {b}: no object pixel in the crop"
+            assert ob[0] >= cb[0] - 2 and ob[1] >= cb[1] - 2 and ob[2] <= cb[2] + 2 and ob[3] <= cb[3] + 2, (name, b, ob, cb)
+            vis_w = min(cb[2], size - 1) - max(cb[0], 0) + 1                # in-image part of the corners' box
+            vis_h = min(cb[3], size - 1) - max(cb[1], 0) + 1
+            cover = ((ob[2] - ob[0] + 1) * (ob[3] - ob[1] + 1)) / max(vis_w * vis_h, 1.0)
+            assert cover >= 0.35, f"{name}: sample {b}: object pixels span {cover:.2f} of the corners' box"
+            for ax, km in (("x", keys[b][:, ::-1]), ("y", keys[b][::-1, :])):
+                cm, hm, _, _ = _alignment_stats(np.ascontiguousarray(km), *args)
+                mirrored[ax][0] += cm; mirrored[ax][1] += hm
+        assert tot >= 10 * B
+        for ax in ("x", "y"):      # a flipped rasteriser misses a large share of the joints: the check above is not vacuous
+            assert mirrored[ax][1] < 0.8 * mirrored[ax][0], f"{name}: the keys mirrored in {ax} still pass ({mirrored[ax]})"
