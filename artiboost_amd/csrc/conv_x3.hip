@@ -31,6 +31,12 @@ int wgrad_gemm2_x3_stem_run(const void* xpad_hi, const void* xpad_lo, const void
 int stem_halo_x3_tiles(int N, int H, int W);                   // stem_halo.hip
 int stem_halo_x3_run(const void* xpad_hi, const void* xpad_lo, const void* w_hi, const void* w_lo, float* y, int N, int H, int W,
                      int Cout, float* stats, hipStream_t st);
+int conv2x2_tfwd_rows(int N, int H, int W, int Cn, int K);       // conv2x2.hip
+int conv2x2_tfwd_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W, int Cn, int K,
+                     float* stats, hipStream_t st);
+int conv2x2_s2fwd_ok(int N, int H, int W, int C, int Cn);
+int conv2x2_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* out, int N, int H, int W, int C, int Cn,
+                      float* stats, hipStream_t st);
 struct GemmRwSam { float* part; int C, D, H, W; };              // gemm_rw.hip
 int gemm_rw_ok(long M, int N, int K);
 int gemm_rw_run(const void* a_hi, const void* a_lo, const void* w_hi, const void* w_lo, const float* bias, float* out, long M, int N,
@@ -71,6 +77,7 @@ static bool x3_is_c3(int kh, int kw, int stride, int pad) { return kh == 3 && kw
 extern "C" int ab_conv2d_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (x3_is_c3(kh, kw, stride, pad)) { int t = conv3x3_x3_tiles(N, H, W, Cin, Cout); if (t) return t; }
+    if (kh == 4 && kw == 4 && stride == 2 && pad == 1 && conv2x2_s2fwd_ok(N, H, W, Cin, Cout)) return N;      // conv2x2.hip: one row per image
     return conv_gemm2_x3_mtiles(N * Ho * Wo, Cout, kh * kw * (Cin / 32), 0);
 }
 
@@ -86,6 +93,11 @@ static int fwd_x3_impl(const void* x_hi, const void* x_lo, const void* w_hi, con
     if (kh == 1 && kw == 1 && stride == 1 && pad == 0 && !stats && !relu && !ep_scale && y && gemm_rw_ok((long)N * H * W, Cout, Cin)) {
         // plain GEMM with the weights resident in registers (gemm_rw.hip): the final layer of the head
         int rc = gemm_rw_run(x_hi, x_lo, w_hi, w_lo, bias, y, (long)N * H * W, Cout, Cin, nullptr, as_stream(stream));
+        if (rc != AB_ESHAPE) return rc;
+    }
+    if (kh == 4 && kw == 4 && stride == 2 && pad == 1 && !bias && !relu && !ep_scale && y && conv2x2_s2fwd_ok(N, H, W, Cin, Cout)) {
+        // the data gradient of ConvTranspose2d(4x4, s2, p1): four 2x2-tap convolutions over the parity sub-grids (conv2x2.hip)
+        int rc = conv2x2_s2fwd_run(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, stats, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
     ConvGemmArgs g = {};
@@ -154,8 +166,11 @@ extern "C" int ab_conv2d_fwd_x3_evalbn(const void* x_hi, const void* x_lo, const
 }
 
 // ---------------------------------------------------------------- data gradient (== transposed-convolution forward)
+static bool x3_is_tconv(int kh, int kw, int stride, int pad) { return kh == 4 && kw == 4 && stride == 2 && pad == 1; }
+
 extern "C" int ab_conv2d_dgrad_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
     if (stride != 2 || kh > 4 || kw > 4 || (H & 1) || (W & 1) || Cout % 32) return 0;
+    if (x3_is_tconv(kh, kw, stride, pad)) { const int r = conv2x2_tfwd_rows(N, H, W, Cin, Cout); if (r) return r; }
     int maxt = 0;
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
         int nt = 0;
@@ -177,6 +192,11 @@ static int dgrad_x3_impl(const void* dy_hi, const void* dy_lo, const void* wt_hi
     if (stats && (addend || !ab_conv2d_dgrad_x3_stat_rows(N, H, W, Cin, Cout, kh, kw, stride, pad))) return AB_ESHAPE;
     if (x3_is_c3(kh, kw, stride, pad) && !ep_scale) {
         int rc = conv3x3_x3_run(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cout, Cin, 1, addend, nullptr, as_stream(stream));
+        if (rc != AB_ESHAPE) return rc;
+    }
+    if (x3_is_tconv(kh, kw, stride, pad) && !addend && !dy2_hi && !ep_scale && dx && conv2x2_tfwd_rows(N, H, W, Cin, Cout)) {
+        // ConvTranspose2d(4x4, s2, p1) forward: the four output-parity classes as 2x2-tap convolutions on a resident patch (conv2x2.hip)
+        int rc = conv2x2_tfwd_run(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cin, Cout, stats, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
     ConvGemmArgs g = {};

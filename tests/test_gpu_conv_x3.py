@@ -556,3 +556,33 @@ def test_final_layer_gemm_rw_and_fused_softargmax(case):
     v = (p.sum(3) * ((allpix // W).double() / H)).sum(2)
     dd = (p.sum(2) * (torch.arange(D).double() / D)).sum(2)
     np.testing.assert_allclose(uvd.cpu().numpy(), torch.stack([u, v, dd], -1).numpy(), atol=3e-6)
+
+
+# ---- round 5: the transposed convolutions of the head on a resident patch (conv2x2.hip)
+@pytest.mark.parametrize("Ci,Co", [(256, 256), (64, 128), (96, 64)])
+def test_conv_transpose_4x4s2_patch_kernel_32x32(Ci, Co):
+    """ConvTranspose2d(4x4, s2, p1) 16x16 -> 32x32 (deconv_layers.3 of the head): forward with BatchNorm partials, and its data gradient
+    (the 4x4 / s2 convolution over the four parity sub-grids), both against float64."""
+    from artiboost_amd import kernels as K
+    g = torch.Generator().manual_seed(Ci + Co)
+    x = torch.randn(3, Ci, 16, 16, generator=g)
+    w = torch.randn(Ci, Co, 4, 4, generator=g) * (2.0 / (Ci * 4)) ** 0.5          # ConvT weight [Cin_t, Cout_t, kh, kw]
+    ref = F.conv_transpose2d(x.double(), w.double(), stride=2, padding=1)
+    wt = K.split(w.permute(1, 2, 3, 0).contiguous().cuda())                     # [Co][kh][kw][Ci]
+    y, part = K.conv2d_dgrad_x3(nhwc(x).cuda(), wt, (32, 32), 2, 1, want_stats=True)
+    close(nchw(y.cpu()), ref)
+    yy = y.double().cpu().reshape(-1, Co)
+    st = part.double().sum(0).cpu()
+    np.testing.assert_allclose(st[:, 0].numpy(), yy.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(yy.abs().sum(0).max()))
+    np.testing.assert_allclose(st[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)
+    # data gradient of the layer = conv2d(dy, W as [Cin_t (out), Cout_t (in)], 4x4, s2, p1)
+    dy = torch.randn(3, Co, 32, 32, generator=g)
+    refg = F.conv2d(dy.double(), w.double(), stride=2, padding=1)               # weight [out = Ci, in = Co, 4, 4]
+    ws = K.split(w.permute(0, 2, 3, 1).contiguous().cuda())                     # OHWI [Ci][kh][kw][Co]
+    dx = K.conv2d_fwd_x3(nhwc(dy).cuda(), ws, 2, 1)
+    close(nchw(dx.cpu()), refg)
+    dx2, st2 = K.conv2d_fwd_x3(nhwc(dy).cuda(), ws, 2, 1, want_stats=True)
+    assert torch.equal(dx2, dx)
+    dd = dx.double().cpu().reshape(-1, Ci)
+    np.testing.assert_allclose(st2.double().sum(0).cpu()[:, 0].numpy(), dd.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(dd.abs().sum(0).max()))
+    np.testing.assert_allclose(st2.double().sum(0).cpu()[:, 1].numpy(), (dd * dd).sum(0).numpy(), rtol=1e-4)
