@@ -27,6 +27,9 @@ struct C22Args {
     int nclass;                      // output classes in the grid (1 | 4)
     C22Unit unit[4];                 // NSUB == 1: by output class;  NSUB == 4: by input sub-grid
     int cls_oy[4], cls_ox[4];
+    // eval-mode fold of the BatchNorm (+ ReLU) that follows: out = relu?(acc * ep_scale[c] + ep_shift[c]) (conv_gemm2.hip's expression: bit-identical
+    // to this kernel + ab_bn_apply_x3), written as fp32 `Out` or, when out_hi != NULL, as the (hi, lo) planes the next convolution reads
+    const float* ep_scale; const float* ep_shift; int ep_relu; void* out_hi; void* out_lo;
 };
 
 template <int BN, int NSUB>
@@ -220,8 +223,20 @@ __global__ __launch_bounds__(512) void conv2x2_kernel(C22Args g) {
     for (int id = tid; id < BM * CPRF; id += NT) {
         const int row = id / CPRF, c4 = id - row * CPRF;
         const int yy = (row / TW) * g.out_stride + coy, xx = (row % TW) * g.out_stride + cox, col = n0 + c4 * 4;
-        const float4 v = *(const float4*)(smem + row * SPF + c4 * 16);
-        *(float4*)(g.Out + ((((long)img * g.Ho + yy) * g.Wo + xx) * g.Cn + col)) = v;
+        float4 v = *(const float4*)(smem + row * SPF + c4 * 16);
+        const long o = (((long)img * g.Ho + yy) * g.Wo + xx) * g.Cn + col;
+        if (g.ep_scale) {
+            const float4 sc = *(const float4*)(g.ep_scale + col), sh = *(const float4*)(g.ep_shift + col);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            if (g.ep_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        if (g.out_hi) {
+            uint2 h, l;
+            h.x = pack_bf16x2(v.x, v.y); h.y = pack_bf16x2(v.z, v.w);
+            l.x = pack_bf16x2(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
+            l.y = pack_bf16x2(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
+            *(uint2*)((bf16_t*)g.out_hi + o) = h; *(uint2*)((bf16_t*)g.out_lo + o) = l;
+        } else *(float4*)(g.Out + o) = v;
         fs[0] += v.x; fq[0] += v.x * v.x; fs[1] += v.y; fq[1] += v.y * v.y;
         fs[2] += v.z; fq[2] += v.z * v.z; fs[3] += v.w; fq[3] += v.w * v.w;
     }
@@ -272,7 +287,7 @@ int conv2x2_tfwd_rows(int N, int H, int W, int Cn, int K) {
     return N * 4;
 }
 int conv2x2_tfwd_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W, int Cn, int K,
-                     float* stats, hipStream_t st) {
+                     float* stats, hipStream_t st, const float* ep_scale, const float* ep_shift, int ep_relu, void* out_hi, void* out_lo) {
     if (!conv2x2_tfwd_rows(N, H, W, Cn, K)) return AB_ESHAPE;
     const long delta = (const char*)wt_lo - (const char*)wt_hi;
     if (delta < 0 || delta >= (1L << 31)) return AB_EINVAL;
@@ -280,6 +295,7 @@ int conv2x2_tfwd_run(const void* x_hi, const void* x_lo, const void* wt_hi, cons
     g.X = x_hi; g.X_lo = x_lo; g.Wt = wt_hi; g.wlo_delta = (unsigned)delta; g.Out = out; g.stats = stats;
     g.N = N; g.Hi = H / 2; g.Wi = W / 2; g.C = K; g.Cn = Cn; g.ktot = 16 * K;
     g.in_stride = 1; g.Ho = H; g.Wo = W; g.out_stride = 2; g.nclass = 4;
+    g.ep_scale = ep_scale; g.ep_shift = ep_shift; g.ep_relu = ep_relu; g.out_hi = out_hi; g.out_lo = out_lo;
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
         // class (a, b): kernel rows i with (a + 1 - i) even read input row p + (a + 1 - i) / 2: a = 0: i = 1 -> p, i = 3 -> p - 1; a = 1: i = 0 -> p + 1, i = 2 -> p
         C22Unit& u = g.unit[a * 2 + b];

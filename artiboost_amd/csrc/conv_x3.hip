@@ -33,7 +33,8 @@ int stem_halo_x3_run(const void* xpad_hi, const void* xpad_lo, const void* w_hi,
                      int Cout, float* stats, hipStream_t st);
 int conv2x2_tfwd_rows(int N, int H, int W, int Cn, int K);       // conv2x2.hip
 int conv2x2_tfwd_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W, int Cn, int K,
-                     float* stats, hipStream_t st);
+                     float* stats, hipStream_t st, const float* ep_scale = nullptr, const float* ep_shift = nullptr, int ep_relu = 0,
+                     void* out_hi = nullptr, void* out_lo = nullptr);
 int conv2x2_s2fwd_ok(int N, int H, int W, int C, int Cn);
 int conv2x2_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* out, int N, int H, int W, int C, int Cn,
                       float* stats, hipStream_t st);
@@ -194,9 +195,9 @@ static int dgrad_x3_impl(const void* dy_hi, const void* dy_lo, const void* wt_hi
         int rc = conv3x3_x3_run(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cout, Cin, 1, addend, nullptr, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
-    if (x3_is_tconv(kh, kw, stride, pad) && !addend && !dy2_hi && !ep_scale && dx && conv2x2_tfwd_rows(N, H, W, Cin, Cout)) {
+    if (x3_is_tconv(kh, kw, stride, pad) && !addend && !dy2_hi && (dx || out_hi) && conv2x2_tfwd_rows(N, H, W, Cin, Cout)) {
         // ConvTranspose2d(4x4, s2, p1) forward: the four output-parity classes as 2x2-tap convolutions on a resident patch (conv2x2.hip)
-        int rc = conv2x2_tfwd_run(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cin, Cout, stats, as_stream(stream));
+        int rc = conv2x2_tfwd_run(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cin, Cout, stats, as_stream(stream), ep_scale, ep_shift, ep_relu, out_hi, out_lo);
         if (rc != AB_ESHAPE) return rc;
     }
     ConvGemmArgs g = {};
