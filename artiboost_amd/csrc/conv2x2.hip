@@ -32,9 +32,14 @@ struct C22Args {
     const float* ep_scale; const float* ep_shift; int ep_relu; void* out_hi; void* out_lo;
 };
 
-template <int BN, int NSUB>
+// G8 = false: base grid 16 x 16, a tile is one image (BM = 256), patch 17 rows x 18 (17 used), swizzle key (px >> 1) & 7.
+// G8 = true : base grid 8 x 8, a tile is NI = BM / 64 consecutive images, each with its own 9 x 9 patch (pitch 9: consecutive rows alternate
+//             the 128-byte half), swizzle key ((px >> 1) & 3) | ((py & 1) << 2) -- conv3x3.hip's TW = 8 layout: a ds_read_b128 lane group
+//             spans four patch rows there.
+template <int BM, int BN, int NSUB, bool G8>
 __global__ __launch_bounds__(512) void conv2x2_kernel(C22Args g) {
-    constexpr int BM = 256, TW = 16, TH = 16, PW = 18, PH = 17, NPIX = PH * PW;      // 306 patch pixels of 128 bytes ([hi 64 B][lo 64 B] of 32 channels)
+    constexpr int TW = G8 ? 8 : 16, TH = G8 ? 8 : 16, NI = BM / (TW * TH), PW = G8 ? 9 : 18, PH = G8 ? 9 : 17, IPIX = PH * PW, NPIX = NI * IPIX;
+    static_assert(BM == NI * TW * TH && (G8 || NI == 1), "tile = whole images");
     constexpr int WM = 4, WN = 2, NW = 8, NT = 512;
     constexpr int PI = (NPIX + 7) / 8, LP = (PI + NW - 1) / NW, PATCH_BYTES = LP * NW * 1024;
     constexpr int IB = BN / 8, LB = IB / NW, BBYTES = BN * 128;
@@ -47,8 +52,8 @@ __global__ __launch_bounds__(512) void conv2x2_kernel(C22Args g) {
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, within = bid >> 3;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + within;
     const int tiles_n = g.Cn / BN;
-    const int tile_sp = logical / tiles_n, tile_n = logical - tile_sp * tiles_n;      // tile_sp = img * nclass + class: the BatchNorm partial row
-    const int img = tile_sp / g.nclass, cls = tile_sp - img * g.nclass;
+    const int tile_sp = logical / tiles_n, tile_n = logical - tile_sp * tiles_n;      // tile_sp = image group * nclass + class: the BatchNorm partial row
+    const int img = (tile_sp / g.nclass) * NI, cls = tile_sp % g.nclass;                 // first image of the tile
     const int n0 = tile_n * BN;
     const bf16_t* __restrict__ X = (const bf16_t*)g.X;
     const bf16_t* __restrict__ Xlo = (const bf16_t*)g.X_lo;
@@ -68,13 +73,15 @@ __global__ __launch_bounds__(512) void conv2x2_kernel(C22Args g) {
     }
 
     // ---- per-lane patch fill assignment: instruction ii covers patch pixels ii * 8 .. + 7, lane & 7 the 16-byte slot
-    int p_py[LP], p_px[LP]; unsigned p_coff[LP]; bool p_lo[LP], p_in[LP];
+    int p_py[LP], p_px[LP], p_il[LP]; unsigned p_coff[LP]; bool p_lo[LP], p_in[LP];
 #pragma unroll
     for (int j = 0; j < LP; ++j) {
         const int ii = wave * LP + j, pp = ii * 8 + (lane >> 3);
-        p_py[j] = pp / PW; p_px[j] = pp - p_py[j] * PW;
+        p_il[j] = pp / IPIX;
+        const int rem = pp - p_il[j] * IPIX;
+        p_py[j] = rem / PW; p_px[j] = rem - p_py[j] * PW;
         p_in[j] = ii < PI && pp < NPIX && p_px[j] < TW + 1;
-        const int c = (lane & 7) ^ ((p_px[j] >> 1) & 7);
+        const int c = (lane & 7) ^ (G8 ? (((p_px[j] >> 1) & 3) | ((p_py[j] & 1) << 2)) : ((p_px[j] >> 1) & 7));
         p_lo[j] = (c & 4) != 0; p_coff[j] = (unsigned)((c & 3) * 8);
     }
     unsigned b_voff[LB];
@@ -97,12 +104,14 @@ __global__ __launch_bounds__(512) void conv2x2_kernel(C22Args g) {
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int row = (wave_m * TM + i) * 32 + l32, oy = row / TW, ox = row - oy * TW;
+        const int row = (wave_m * TM + i) * 32 + l32, il = row / (TW * TH), rr = row - il * (TW * TH), oy = rr / TW, ox = rr - oy * TW;
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
             const int px = ox + d;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) a_rel[i][d][kk] = lds0 + PATCH0 + (oy * PW + px) * 128 + (((kk * 2 + fhalf) ^ ((px >> 1) & 7)) << 4);
+            for (int kk = 0; kk < 4; ++kk)      // (G8: the patch row's bit of the key is flipped below for the second tap row)
+                a_rel[i][d][kk] = lds0 + PATCH0 + (il * IPIX + oy * PW + px) * 128 +
+                                  (((kk * 2 + fhalf) ^ (G8 ? (((px >> 1) & 3) | ((oy & 1) << 2)) : ((px >> 1) & 7))) << 4);
         }
     }
 
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(512) void conv2x2_kernel(C22Args g) {
             const int ii = wave * LP + j;
             const int r = (oy0 + p_py[j]) * g.in_stride + sy, c = (ox0 + p_px[j]) * g.in_stride + sx;
             const bool ok = p_in[j] && (unsigned)r < (unsigned)g.Hi && (unsigned)c < (unsigned)g.Wi;
-            const bf16_t* src = ok ? (p_lo[j] ? Xlo : X) + ((((long)img * g.Hi + r) * g.Wi + c) * g.C + chunk * 32 + p_coff[j]) : zp;
+            const bf16_t* src = ok ? (p_lo[j] ? Xlo : X) + ((((long)(img + p_il[j]) * g.Hi + r) * g.Wi + c) * g.C + chunk * 32 + p_coff[j]) : zp;
             glds16(src, __builtin_amdgcn_readfirstlane(lds0 + PATCH0 + pbuf * PATCH_BYTES + ii * 1024));
         }
     };
@@ -167,13 +176,14 @@ __global__ __launch_bounds__(512) void conv2x2_kernel(C22Args g) {
                 if (t == 0 && more) issue_patch(sc + 1, (sc + 1) & 1);
                 const int dh = t >> 1, dw = t & 1;
                 const unsigned aoff = pbase + dh * PW * 128;
+                const unsigned aflip = (G8 && dh) ? 64u : 0u;      // the (py & 1) bit of the G8 key: patch row = oy + dh (bases are 128-byte aligned)
                 u32x4 fa[4][TM], fb[4][TN];
 #pragma unroll
                 for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) fa[k2 + 2 * h][i] = *(const lds_u32x4*)(a_rel[i][dw][k2 + 2 * h] + aoff);
+                        for (int i = 0; i < TM; ++i) fa[k2 + 2 * h][i] = *(const lds_u32x4*)((a_rel[i][dw][k2 + 2 * h] ^ aflip) + aoff);
 #pragma unroll
                         for (int j = 0; j < TN; ++j) fb[k2 + 2 * h][j] = *(const lds_u32x4*)(b_rel[j][k2 + 2 * h] + t * BBYTES);
                     }
@@ -222,9 +232,10 @@ __global__ __launch_bounds__(512) void conv2x2_kernel(C22Args g) {
     float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
     for (int id = tid; id < BM * CPRF; id += NT) {
         const int row = id / CPRF, c4 = id - row * CPRF;
-        const int yy = (row / TW) * g.out_stride + coy, xx = (row % TW) * g.out_stride + cox, col = n0 + c4 * 4;
+        const int il = row / (TW * TH), rr = row - il * (TW * TH);
+        const int yy = (rr / TW) * g.out_stride + coy, xx = (rr % TW) * g.out_stride + cox, col = n0 + c4 * 4;
         float4 v = *(const float4*)(smem + row * SPF + c4 * 16);
-        const long o = (((long)img * g.Ho + yy) * g.Wo + xx) * g.Cn + col;
+        const long o = (((long)(img + il) * g.Ho + yy) * g.Wo + xx) * g.Cn + col;
         if (g.ep_scale) {
             const float4 sc = *(const float4*)(g.ep_scale + col), sh = *(const float4*)(g.ep_shift + col);
             v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
@@ -256,19 +267,20 @@ __global__ __launch_bounds__(512) void conv2x2_kernel(C22Args g) {
     }
 }
 
-template <int BN, int NSUB>
+template <int BM, int BN, int NSUB, bool G8>
 static int c22_launch(C22Args& g, hipStream_t st) {
-    constexpr int LP = ((17 * 18 + 7) / 8 + 7) / 8;
-    const size_t ring = (size_t)4 * BN * 128 + 2 * LP * 8 * 1024, stage = (size_t)256 * (BN * 4 + 16);
-    const size_t lds = ring > stage ? ring : stage;
+    constexpr int NI = BM / (G8 ? 64 : 256), NPIX = NI * (G8 ? 81 : 17 * 18), LP = ((NPIX + 7) / 8 + 7) / 8;
+    const size_t ring = (size_t)4 * BN * 128 + 2 * LP * 8 * 1024, stage = (size_t)BM * (BN * 4 + 16), part = (size_t)(512 / (BN / 4)) * BN * 8;
+    size_t lds = ring > stage ? ring : stage;
+    if (part > lds) lds = part;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv2x2_kernel<BN, NSUB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)conv2x2_kernel<BM, BN, NSUB, G8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    const int blocks = g.N * g.nclass * (g.Cn / BN);
-    conv2x2_kernel<BN, NSUB><<<blocks, 512, lds, st>>>(g);
+    const int blocks = (g.N / NI) * g.nclass * (g.Cn / BN);
+    conv2x2_kernel<BM, BN, NSUB, G8><<<blocks, 512, lds, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -279,12 +291,16 @@ static int c22_bn(int Cn) {
     return Cn % 128 == 0 ? 128 : (Cn % 64 == 0 ? 64 : 0);
 }
 static bool c22_off() { static const int off = getenv("AB_C22_OFF") ? atoi(getenv("AB_C22_OFF")) : 0; return off != 0; }
+static bool c22_g8_off() { static const int off = getenv("AB_C22_G8_OFF") ? atoi(getenv("AB_C22_G8_OFF")) : 0; return off != 0; }
 
-// ConvTranspose2d(4x4, s2, p1) forward as the data gradient of the mirrored convolution: dy planes [N, 16, 16, K], wt rows [Cn][4][4][K]
-// ("IHWO"), out fp32 [N, 32, 32, Cn].  Rows of BatchNorm partials: N * 4 (image x parity class).  0 / AB_ESHAPE: shape not taken.
+// ConvTranspose2d(4x4, s2, p1) forward as the data gradient of the mirrored convolution: dy planes [N, H/2, W/2, K], wt rows [Cn][4][4][K]
+// ("IHWO"), out fp32 [N, H, W, Cn]; H = W = 32 (one image per tile) or 16 (four images per tile, N % 4 == 0).  Rows of BatchNorm partials:
+// tiles x 4 parity classes.  0 / AB_ESHAPE: shape not taken.
 int conv2x2_tfwd_rows(int N, int H, int W, int Cn, int K) {
-    if (c22_off() || H != 32 || W != 32 || K % 32 || !c22_bn(Cn)) return 0;
-    return N * 4;
+    if (c22_off() || K % 32) return 0;
+    if (H == 32 && W == 32 && c22_bn(Cn)) return N * 4;
+    if (H == 16 && W == 16 && !c22_g8_off() && N % 4 == 0 && Cn % 64 == 0) return N;
+    return 0;
 }
 int conv2x2_tfwd_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W, int Cn, int K,
                      float* stats, hipStream_t st, const float* ep_scale, const float* ep_shift, int ep_relu, void* out_hi, void* out_lo) {
@@ -307,12 +323,18 @@ int conv2x2_tfwd_run(const void* x_hi, const void* x_lo, const void* wt_hi, cons
         }
         g.cls_oy[a * 2 + b] = a; g.cls_ox[a * 2 + b] = b;
     }
-    return c22_bn(Cn) == 128 ? c22_launch<128, 1>(g, st) : c22_launch<64, 1>(g, st);
+    if (H == 16) return c22_launch<256, 64, 1, true>(g, st);
+    return c22_bn(Cn) == 128 ? c22_launch<256, 128, 1, false>(g, st) : c22_launch<256, 64, 1, false>(g, st);
 }
 
-// 4x4 / stride 2 / pad 1 convolution (the data gradient of that ConvTranspose2d): x planes [N, 32, 32, C], w rows [Cn][4][4][C] (OHWI),
-// out fp32 [N, 16, 16, Cn]; BatchNorm partials: one row per image.
-int conv2x2_s2fwd_ok(int N, int H, int W, int C, int Cn) { return !c22_off() && H == 32 && W == 32 && C % 32 == 0 && Cn % 64 == 0; }
+// 4x4 / stride 2 / pad 1 convolution (the data gradient of that ConvTranspose2d): x planes [N, H, W, C], w rows [Cn][4][4][C] (OHWI),
+// out fp32 [N, H/2, W/2, Cn]; H = W = 32, or 16 (two images per tile, N even).  BatchNorm partials: one row per tile.
+int conv2x2_s2fwd_ok(int N, int H, int W, int C, int Cn) {
+    if (c22_off() || C % 32 || Cn % 64) return 0;
+    if (H == 32 && W == 32) return N;
+    if (H == 16 && W == 16 && !c22_g8_off() && N % 2 == 0) return N / 2;
+    return 0;
+}
 int conv2x2_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* out, int N, int H, int W, int C, int Cn,
                       float* stats, hipStream_t st) {
     if (!conv2x2_s2fwd_ok(N, H, W, C, Cn)) return AB_ESHAPE;
@@ -333,5 +355,6 @@ int conv2x2_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, cons
         }
     }
     g.cls_oy[0] = g.cls_ox[0] = 0;
-    return c22_launch<64, 4>(g, st);
+    if (H == 16) return c22_launch<128, 64, 4, true>(g, st);
+    return c22_launch<256, 64, 4, false>(g, st);
 }

@@ -78,7 +78,7 @@ static bool x3_is_c3(int kh, int kw, int stride, int pad) { return kh == 3 && kw
 extern "C" int ab_conv2d_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (x3_is_c3(kh, kw, stride, pad)) { int t = conv3x3_x3_tiles(N, H, W, Cin, Cout); if (t) return t; }
-    if (kh == 4 && kw == 4 && stride == 2 && pad == 1 && conv2x2_s2fwd_ok(N, H, W, Cin, Cout)) return N;      // conv2x2.hip: one row per image
+    if (kh == 4 && kw == 4 && stride == 2 && pad == 1) { const int r = conv2x2_s2fwd_ok(N, H, W, Cin, Cout); if (r) return r; }      // conv2x2.hip: one row per tile
     return conv_gemm2_x3_mtiles(N * Ho * Wo, Cout, kh * kw * (Cin / 32), 0);
 }
 

@@ -559,30 +559,33 @@ def test_final_layer_gemm_rw_and_fused_softargmax(case):
 
 
 # ---- round 5: the transposed convolutions of the head on a resident patch (conv2x2.hip)
-@pytest.mark.parametrize("Ci,Co", [(256, 256), (64, 128), (96, 64)])
-def test_conv_transpose_4x4s2_patch_kernel_32x32(Ci, Co):
-    """ConvTranspose2d(4x4, s2, p1) 16x16 -> 32x32 (deconv_layers.3 of the head): forward with BatchNorm partials, and its data gradient
-    (the 4x4 / s2 convolution over the four parity sub-grids), both against float64."""
+@pytest.mark.parametrize("Ci,Co,hin,nb", [(256, 256, 16, 3), (64, 128, 16, 3), (96, 64, 16, 3), (512, 256, 8, 4), (64, 64, 8, 8), (96, 128, 8, 4)])
+def test_conv_transpose_4x4s2_patch_kernel_32x32(Ci, Co, hin, nb):
+    """ConvTranspose2d(4x4, s2, p1) 16x16 -> 32x32 and 8x8 -> 16x16 (deconv_layers.3 / .0 of the head): forward with BatchNorm partials, and
+    its data gradient (the 4x4 / s2 convolution over the four parity sub-grids), both against float64."""
     from artiboost_amd import kernels as K
-    g = torch.Generator().manual_seed(Ci + Co)
-    x = torch.randn(3, Ci, 16, 16, generator=g)
+    g = torch.Generator().manual_seed(Ci + Co + hin)
+    x = torch.randn(nb, Ci, hin, hin, generator=g)
     w = torch.randn(Ci, Co, 4, 4, generator=g) * (2.0 / (Ci * 4)) ** 0.5          # ConvT weight [Cin_t, Cout_t, kh, kw]
     ref = F.conv_transpose2d(x.double(), w.double(), stride=2, padding=1)
     wt = K.split(w.permute(1, 2, 3, 0).contiguous().cuda())                     # [Co][kh][kw][Ci]
-    y, part = K.conv2d_dgrad_x3(nhwc(x).cuda(), wt, (32, 32), 2, 1, want_stats=True)
+    y, part = K.conv2d_dgrad_x3(nhwc(x).cuda(), wt, (2 * hin, 2 * hin), 2, 1, want_stats=True)
     close(nchw(y.cpu()), ref)
+    assert part.shape[0] == (nb * 4 if hin == 16 else nb)                       # the patch kernel's rows: the new path ran
     yy = y.double().cpu().reshape(-1, Co)
     st = part.double().sum(0).cpu()
     np.testing.assert_allclose(st[:, 0].numpy(), yy.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(yy.abs().sum(0).max()))
     np.testing.assert_allclose(st[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)
     # data gradient of the layer = conv2d(dy, W as [Cin_t (out), Cout_t (in)], 4x4, s2, p1)
-    dy = torch.randn(3, Co, 32, 32, generator=g)
+    dy = torch.randn(nb, Co, 2 * hin, 2 * hin, generator=g)
     refg = F.conv2d(dy.double(), w.double(), stride=2, padding=1)               # weight [out = Ci, in = Co, 4, 4]
     ws = K.split(w.permute(0, 2, 3, 1).contiguous().cuda())                     # OHWI [Ci][kh][kw][Co]
     dx = K.conv2d_fwd_x3(nhwc(dy).cuda(), ws, 2, 1)
     close(nchw(dx.cpu()), refg)
     dx2, st2 = K.conv2d_fwd_x3(nhwc(dy).cuda(), ws, 2, 1, want_stats=True)
     assert torch.equal(dx2, dx)
+    if Ci % 64 == 0:                                                            # (output channels of the data gradient: the patch kernel's tiling)
+        assert st2.shape[0] == (nb if hin == 16 else nb // 2)
     dd = dx.double().cpu().reshape(-1, Ci)
     np.testing.assert_allclose(st2.double().sum(0).cpu()[:, 0].numpy(), dd.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(dd.abs().sum(0).max()))
     np.testing.assert_allclose(st2.double().sum(0).cpu()[:, 1].numpy(), (dd * dd).sum(0).numpy(), rtol=1e-4)
