@@ -357,9 +357,10 @@ extern "C" int ab_conv2d_stem_x3_stat_rows(int N, int H, int W) {
 
 extern "C" int ab_conv2d_stem_fwd_x3(const void* xpad_hi, const void* xpad_lo, const void* w_hi, const void* w_lo, float* y, int N,
                                      int H, int W, int Cout, float* stats, void* stream) {
-    if (!xpad_hi || !xpad_lo || !w_hi || !w_lo || !y) return AB_EINVAL;
+    if (!xpad_hi || !w_hi || !w_lo || !y) return AB_EINVAL;
     if ((H & 1) || (W & 1) || Cout != 64) return AB_ESHAPE;
     if (stem_halo_x3_tiles(N, H, W)) return stem_halo_x3_run(xpad_hi, xpad_lo, w_hi, w_lo, y, N, H, W, Cout, stats, as_stream(stream));
+    if (!xpad_lo) return AB_ESHAPE;       // the integer image plane (xpad_lo == NULL: AB_DT_U8N) runs on the persistent halo kernel only
     ConvGemmArgs g = {};
     g.A = xpad_hi; g.A_lo = xpad_lo; g.Bw = w_hi; g.Bw_lo = w_lo; g.Out = y; g.stats = stats;
     g.N = N; g.Ha = H + 6; g.Wa = W + 8; g.Ca = 4;
@@ -376,7 +377,7 @@ static int stem_wgrad_x3_impl(const bf16_t* xpad_hi, const bf16_t* xpad_lo, cons
         const long xo = (long)n1 * (H + 6) * (W + 8) * 4, yo = (long)n1 * (H / 2) * (W / 2) * Cout;
         int rc = stem_wgrad_x3_impl(xpad_hi, xpad_lo, dy_hi, dy_lo, dw, n1, H, W, Cout, workspace, accumulate, st);
         if (rc) return rc;
-        return stem_wgrad_x3_impl(xpad_hi + xo, xpad_lo + xo, dy_hi + yo, dy_lo + yo, dw, N - n1, H, W, Cout, workspace, 1, st);
+        return stem_wgrad_x3_impl(xpad_hi + xo, xpad_lo ? xpad_lo + xo : nullptr, dy_hi + yo, dy_lo + yo, dw, N - n1, H, W, Cout, workspace, 1, st);
     }
     int ns = wgrad_gemm2_stem_slices(N, H, W, Cout);
     if (ns <= 0) return AB_ESHAPE;
@@ -387,7 +388,7 @@ static int stem_wgrad_x3_impl(const bf16_t* xpad_hi, const bf16_t* xpad_lo, cons
 
 extern "C" int ab_conv2d_stem_wgrad_x3(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo, float* dw,
                                        int N, int H, int W, int Cout, void* workspace, void* stream) {
-    if (!xpad_hi || !xpad_lo || !dy_hi || !dy_lo || !dw || !workspace) return AB_EINVAL;
+    if (!xpad_hi || !dy_hi || !dy_lo || !dw || !workspace) return AB_EINVAL;          // xpad_lo == NULL: xpad_hi is the integer image plane (AB_DT_U8N)
     if ((H & 1) || (W & 1) || Cout % 64) return AB_ESHAPE;
     return stem_wgrad_x3_impl((const bf16_t*)xpad_hi, (const bf16_t*)xpad_lo, (const bf16_t*)dy_hi, (const bf16_t*)dy_lo, dw, N, H, W, Cout,
                               workspace, 0, as_stream(stream));

@@ -711,7 +711,8 @@ __global__ __launch_bounds__(256) void jitter_stats_kernel(const uint8_t* __rest
 }
 
 // kernel 4: nearest-neighbour affine crop + full jitter chain + normalise; writes zero-bordered NHWC4 and/or CHW f32
-template <typename T>
+// U8N (T = bf16): the padded tensor receives the odd integers 2 v - 255 instead of v / 255 - 0.5 (AB_DT_U8N: the stem's exact image plane)
+template <typename T, bool U8N = false>
 __global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restrict__ rgbx_plain, int W, int H,
                                                           const int32_t* __restrict__ order, const float* __restrict__ factor,
                                                           const float* __restrict__ inv_affine,
@@ -743,7 +744,8 @@ __global__ __launch_bounds__(256) void warp_jitter_kernel(const uint8_t* __restr
     float o[3] = {v[0] / 255.0f - 0.5f, v[1] / 255.0f - 0.5f, v[2] / 255.0f - 0.5f};
     if (out_pad) {
         T* p = out_pad + (((size_t)b * (oh + 6) + (y + 3)) * (ow + 8) + (x + 3)) * 4;
-        st_f32(p, o[0]); st_f32(p + 1, o[1]); st_f32(p + 2, o[2]); st_f32(p + 3, 0.f);
+        if constexpr (U8N) { st_f32(p, 2.f * v[0] - 255.f); st_f32(p + 1, 2.f * v[1] - 255.f); st_f32(p + 2, 2.f * v[2] - 255.f); st_f32(p + 3, 0.f); }
+        else { st_f32(p, o[0]); st_f32(p + 1, o[1]); st_f32(p + 2, o[2]); st_f32(p + 3, 0.f); }
     }
     if (out_chw) {
         size_t plane = (size_t)oh * ow;
@@ -848,6 +850,8 @@ extern "C" int ab_render_batch(const ab_scene* scene_host, const void* samples, 
         warp_jitter_kernel<float><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (float*)out_pad, out_chw, rgbx_blur, blur_radius, nullptr, LSUM_STRIDE);
     else if (out_dtype == AB_DT_BF16)
         warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw, rgbx_blur, blur_radius, nullptr, LSUM_STRIDE);
+    else if (out_dtype == AB_DT_U8N)
+        warp_jitter_kernel<bf16_t, true><<<g, 256, 0, st>>>(rgbx, sc.W, sc.H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw, rgbx_blur, blur_radius, nullptr, LSUM_STRIDE);
     else return AB_EINVAL;
     AB_LAUNCH_CHECK();
     return 0;
@@ -905,6 +909,8 @@ extern "C" int ab_augment_batch(const void* rgbx_in, int B, int W, int H, const 
         warp_jitter_kernel<float><<<g, 256, 0, st>>>(rgbx, W, H, order, factor, inv_affine, lsum, ow, oh, (float*)out_pad, out_chw, rgbx_blur, blur_radius, flip, LSUM_STRIDE);
     else if (out_dtype == AB_DT_BF16)
         warp_jitter_kernel<bf16_t><<<g, 256, 0, st>>>(rgbx, W, H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw, rgbx_blur, blur_radius, flip, LSUM_STRIDE);
+    else if (out_dtype == AB_DT_U8N)
+        warp_jitter_kernel<bf16_t, true><<<g, 256, 0, st>>>(rgbx, W, H, order, factor, inv_affine, lsum, ow, oh, (bf16_t*)out_pad, out_chw, rgbx_blur, blur_radius, flip, LSUM_STRIDE);
     else return AB_EINVAL;
     AB_LAUNCH_CHECK();
     return 0;

@@ -177,6 +177,11 @@ struct StemArgsX3 {
     int Ha, Wa, Ho, Wo, tiles_x, tiles_per_img, ntiles;
 };
 
+// U8N: the image is ONE plane of odd integers n = 2 v - 255 (v the uint8 pixel; exact in bf16) -- what the loaders' warp / jitter pass writes
+// with output code AB_DT_U8N -- and the convolution's input is n / 510 = v / 255 - 0.5 (anakin/datasets/hodata.py:446 after func.to_tensor):
+// a k-slice is TWO MFMAs (n . w_hi, n . w_lo: no rounding of the image at all, where the split of the fp32 image dropped its lo . lo term),
+// one patch plane is DMA'd, the factor 1 / 510 rides in the epilogue.
+template <bool U8N>
 __global__ __launch_bounds__(512) void stem_halo_x3_kernel(StemArgsX3 g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(512) void stem_halo_x3_kernel(StemArgsX3 g) {
                 const int row = s / 20, c16 = s - row * 20;
                 const long e = (((long)img * g.Ha + 2 * ty0 + row) * g.Wa + 2 * tx0 + c16 * 2) * 4;
                 glds16(Xh + e, __builtin_amdgcn_readfirstlane(lds0 + SX_OFF_P + (buf * 2) * SH_PATCH + wave * 1024));
-                glds16(Xl + e, __builtin_amdgcn_readfirstlane(lds0 + SX_OFF_P + (buf * 2 + 1) * SH_PATCH + wave * 1024));
+                if constexpr (!U8N) glds16(Xl + e, __builtin_amdgcn_readfirstlane(lds0 + SX_OFF_P + (buf * 2 + 1) * SH_PATCH + wave * 1024));
             }
         }
     };
@@ -231,10 +236,12 @@ __global__ __launch_bounds__(512) void stem_halo_x3_kernel(StemArgsX3 g) {
 #pragma unroll
         for (int kk = 0; kk < 14; ++kk) {
             const uint4 fah = *(const uint4*)(pah + (kk >> 1) * SH_PROW + (kk & 1) * 32);
-            const uint4 fal = *(const uint4*)(pal + (kk >> 1) * SH_PROW + (kk & 1) * 32);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fah), __builtin_bit_cast(bf16x8, fbh[kk]), acc, 0, 0, 0);
             accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fah), __builtin_bit_cast(bf16x8, fbl[kk]), accx, 0, 0, 0);
-            accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fal), __builtin_bit_cast(bf16x8, fbh[kk]), accx, 0, 0, 0);
+            if constexpr (!U8N) {
+                const uint4 fal = *(const uint4*)(pal + (kk >> 1) * SH_PROW + (kk & 1) * 32);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fal), __builtin_bit_cast(bf16x8, fbh[kk]), accx, 0, 0, 0);
+            }
         }
 
         const int cl = wave_n * 32 + l32;
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(512) void stem_halo_x3_kernel(StemArgsX3 g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = wave_m * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-            const float v = acc[r] + accx[r];
+            const float v = U8N ? (acc[r] + accx[r]) * (1.0f / 510.0f) : acc[r] + accx[r];
             *(float*)(stg + row * SX_SPITCH + cl * 4) = v;
             csum += v; csq += v * v;
         }
@@ -295,11 +302,13 @@ int stem_halo_x3_run(const void* xpad_hi, const void* xpad_lo, const void* w_hi,
     g.tiles_x = g.Wo / SH_TW; g.tiles_per_img = g.tiles_x * (g.Ho / SH_TH); g.ntiles = ntiles;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)stem_halo_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SX_LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)stem_halo_x3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SX_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_halo_x3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SX_LDS);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    stem_halo_x3_kernel<<<stem_halo_x3_grid(ntiles), 512, SX_LDS, st>>>(g);
+    if (!xpad_lo) stem_halo_x3_kernel<true><<<stem_halo_x3_grid(ntiles), 512, SX_LDS, st>>>(g);      // the integer image plane (AB_DT_U8N)
+    else stem_halo_x3_kernel<false><<<stem_halo_x3_grid(ntiles), 512, SX_LDS, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -50,20 +50,23 @@ __device__ __forceinline__ uint4 wg2_tr_pair(unsigned lo_addr, unsigned hi_addr)
 // ab_conv2d_stem_fwd); BJ = 256 covers all of them, the 64-byte segment of kernel row t comes from image row 2p + t.
 // X3 = 1: split-bf16 operands (conv3x3.hip): 32 reduction rows per step, each operand tile staged once per plane
 // ([dy hi][dy lo][x hi][x lo]); the DMA instruction index runs over (plane, row group).
+// X3 = 2 (stem only): dy as (hi, lo) planes, the image as ONE plane of odd integers n = 2 v - 255 (exact in bf16: AB_DT_U8N, stem_halo.hip) --
+// two MFMAs per fragment pair (dy_hi . n, dy_lo . n) instead of three, no lo plane of the image staged, the factor 1 / 510 in the slab store.
 // NBUF = 2 (the 256 x 256 split-bf16 tile: two 64 KB stages): one step in flight instead of two.
 template <int BI, int BJ, bool STEM = false, int WI = 2, int WJ = 2, int X3 = 0, int NBUF = 3>
 __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
     constexpr int NW = WI * WJ;                             // 4 or 8 waves (the LDS fill rate scales with the waves issuing loads)
     constexpr int BR = X3 ? 32 : 64;                        // reduction rows per step
     constexpr int NPL = X3 ? 2 : 1;                         // operand planes
+    constexpr int NPLB = X3 == 1 ? 2 : 1;                   // ... of the x operand
     constexpr int PA = BI * 2, PB = BJ * 2;                 // row pitches (bytes)
     constexpr int RA = 1024 / PA, RB = 1024 / PB;           // rows per 1-KiB DMA instruction
     constexpr int IA1 = BR / RA, IB1 = BR / RB;             // instructions per tile plane
-    constexpr int IA = NPL * IA1, IB = NPL * IB1;           // ... over both planes
+    constexpr int IA = NPL * IA1, IB = NPLB * IB1;          // ... over the planes
     constexpr int LA = IA / NW, LB = IB / NW;               // per wave
     static_assert(IA % NW == 0 && IB % NW == 0, "tile rows must split evenly over the waves");
     constexpr int APL = BR * PA, BPL = BR * PB;             // bytes of one plane of a tile
-    constexpr int ABYTES = NPL * APL, STAGE = NPL * (APL + BPL);
+    constexpr int ABYTES = NPL * APL, STAGE = NPL * APL + NPLB * BPL;
     constexpr int PF = NBUF - 1;                            // steps in flight ahead of the one being multiplied
     constexpr bool PARTIAL_I = BI == 256 && BJ == 256;      // only these launches may have a partial last channel tile (Cout = 704)
     constexpr int TI = BI / WI / 32, TJ = BJ / WJ / 32;     // 32x32 tiles per wave (waves WI x WJ)
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
             int off = s_xoff[slot][b_row[j]];
-            const bf16_t* src = off >= 0 ? ((X3 && b_pl[j]) ? Xl : X) + (off + b_col[j]) : zp;
+            const bf16_t* src = off >= 0 ? ((X3 == 1 && b_pl[j]) ? Xl : X) + (off + b_col[j]) : zp;
             glds16(src, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + ABYTES + (wave * LB + j) * 1024));
         }
     };
@@ -201,7 +204,17 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
                 for (int b = 0; b < TJ; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[a]),
                                                                        __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
-            if constexpr (X3) {
+            if constexpr (X3 == 2) {
+                uint4 fal[TI];
+#pragma unroll
+                for (int a = 0; a < TI; ++a) fal[a] = wg2_tr_pair(a_base[a][0] + so + APL + s * 16 * PA, a_base[a][1] + so + APL + s * 16 * PA);
+#pragma unroll
+                for (int a = 0; a < TI; ++a)
+#pragma unroll
+                    for (int b = 0; b < TJ; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fal[a]),
+                                                                           __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+            } else if constexpr (X3) {
                 uint4 fal[TI], fbl[TJ];
 #pragma unroll
                 for (int a = 0; a < TI; ++a) fal[a] = wg2_tr_pair(a_base[a][0] + so + APL + s * 16 * PA, a_base[a][1] + so + APL + s * 16 * PA);
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
             for (int r = 0; r < 16; ++r) {
                 int row = i0 + (wave_i * TI + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 int col = j0 + (wave_j * TJ + b) * 32 + (lane & 31);
-                if (!PARTIAL_I || row < g.Cout) out[(long)row * g.jtot + col] = acc[a][b][r];
+                if (!PARTIAL_I || row < g.Cout) out[(long)row * g.jtot + col] = X3 == 2 ? acc[a][b][r] * (1.0f / 510.0f) : acc[a][b][r];
             }
 }
 
@@ -404,7 +417,8 @@ int wgrad_gemm2_x3_stem_run(const void* xpad_hi, const void* xpad_lo, const void
     g.rows_per_slice = r;
     g.xcd_map = wg2_xcd_map();
     dim3 grid(Cout / 64, ns);
-    wgrad_gemm2_kernel<64, 256, true, 2, 4, 1><<<grid, 512, 0, st>>>(g);
+    if (!xpad_lo) wgrad_gemm2_kernel<64, 256, true, 2, 4, 2><<<grid, 512, 0, st>>>(g);      // the integer image plane (AB_DT_U8N)
+    else wgrad_gemm2_kernel<64, 256, true, 2, 4, 1><<<grid, 512, 0, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

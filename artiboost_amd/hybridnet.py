@@ -289,6 +289,7 @@ class HybridNet:
         self.x3 = compute_dtype in ("bf16x3", "x3")           # split-bf16 convolutions on fp32 tensors
         self.dtype = torch.float32 if self.x3 else compute_dtype
         self.training = True
+        self.image_plane = "f32" # "u8n": forward(xpad=...) receives the loaders' integer plane 2 v - 255 (bf16; AB_DT_U8N) -- bf16x3 only
         self.norm = 0            # HYBRID_HEAD.NORM_TYPE code (head.NORM_CODE): 0 softmax, 1 sigmoid
         self.frozen_bn = False   # BACKBONE.FREEZE_BATCHNORM: backbone BatchNorms are fixed affine maps (resnet.py:33-69, 146-149)
         self.lp = None           # low-precision copy of the flat params (bf16 mode)
@@ -484,7 +485,12 @@ class HybridNet:
         p, tr, dt = self.p, self.training, self.dtype
         if xpad is None:
             xpad = K.image_pad_nhwc4(image.contiguous().float(), dt)
-        if xpad.dtype != dt:
+        # image_plane == "u8n": a bf16 [N, H+6, W+8, 4] tensor is the loaders' integer plane 2 v - 255 (AB_DT_U8N): the stem's forward and weight
+        # gradient run two MFMA passes on it and there is no split pass over the image (fp32 images keep the three-pass path)
+        u8n = self.x3 and self.image_plane == "u8n" and xpad.dtype == torch.bfloat16 and xpad.dim() == 4
+        if u8n and self.wgrad_1pass:
+            raise NotImplementedError("AB_WGRAD_1PASS (a precision study) with the integer image plane")
+        if not u8n and xpad.dtype != dt:
             # the stem kernels take ONE dtype code for image and weights: a mismatch would read the weights as the image's type
             raise TypeError(f"HybridNet({'bf16x3' if self.x3 else dt}) needs the padded image in {dt}, got {xpad.dtype} "
                             f"(build the loader with compute_dtype=net.dtype)")
@@ -495,7 +501,8 @@ class HybridNet:
         H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
         S = {"xpad": xpad, "N": N, "HW": (H, W), "blocks": []}
         if self.x3:
-            xpad = K.split(xpad)      # planes of THIS step's image (forward and weight gradient of the stem read them)
+            if not u8n:
+                xpad = K.split(xpad)      # planes of THIS step's image (forward and weight gradient of the stem read them)
             S["xpad"] = xpad
             y0, st = K.conv2d_stem_fwd_x3(xpad, self.w("backbone.conv1.weight"), H, W, want_stats=True)
         else:

@@ -721,9 +721,17 @@ def bn_bwd_x3(dout, out, y, bnp, dgamma, dbeta, relu=True, want_dz=False, part=N
     return (dy, dz) if want_dz else dy
 
 
+def _image_planes(xpad):
+    """(hi, lo) planes of the padded image, or (plane, None) for the integer plane 2 v - 255 the loaders write with AB_DT_U8N
+    (bf16 [N, H+6, W+8, 4]: the network input is plane / 510; ab_conv2d_stem_*_x3 take it with xpad_lo = NULL)."""
+    if xpad.dtype == torch.bfloat16 and xpad.dim() == 4:
+        return xpad, None
+    return _planes(xpad)
+
+
 def conv2d_stem_fwd_x3(xpad, w_split, H, W, want_stats=False):
-    """xpad fp32 / split [.., N,H+6,W+8,4], w_split [2,64,7,8,4] -> y fp32 [N,H/2,W/2,64] (+ BN partials)."""
-    xh, xl = _planes(xpad)
+    """xpad fp32 / split [.., N,H+6,W+8,4] / integer plane (see _image_planes), w_split [2,64,7,8,4] -> y fp32 [N,H/2,W/2,64] (+ BN partials)."""
+    xh, xl = _image_planes(xpad)
     N = xh.shape[0]
     Cout = w_split.shape[1]
     y = torch.empty((N, H // 2, W // 2, Cout), dtype=torch.float32, device=xh.device)
@@ -737,7 +745,7 @@ def conv2d_stem_fwd_x3(xpad, w_split, H, W, want_stats=False):
 
 
 def conv2d_stem_wgrad_x3(xpad, dy, H, W, out=None, defer=None):
-    xh, xl = _planes(xpad)
+    xh, xl = _image_planes(xpad)
     dh, dl = _planes(dy)
     N = xh.shape[0]
     Cout = dh.shape[3]

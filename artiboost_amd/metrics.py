@@ -218,7 +218,10 @@ class Vis2DMetric(VisMetric):
         pad = targs["image_nhwc4_padded"]                    # the HIP loader's batch: zero-bordered NHWC4 (fp32 / bf16 or its planes)
         if pad.dim() == 5:
             pad = pad[0].float() + pad[1].float()
+        u8n = pad.dtype == torch.bfloat16 and pad.dim() == 4 and float(pad.abs().max()) > 1.0      # the integer plane 2 v - 255 (AB_DT_U8N)
         pad = pad.detach().float().cpu()
+        if u8n:
+            pad = pad / 510.0
         return (pad[:, 3:-3, 3:-5, :3] + 0.5).clamp(0, 1).numpy()
 
     def _draw(self, images, joints, corners, root, jvis, cvis):

@@ -257,6 +257,8 @@ class HybridBaseline(nn.Module):
             H, W = image.shape[2], image.shape[3]
         else:
             H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
+            if getattr(self.net, "x3", False) and xpad.dtype == torch.bfloat16 and xpad.dim() == 4:
+                self.net.image_plane = "u8n"      # the loaders' integer image plane (compute_dtype "u8n": AB_DT_U8N); see train.TrainStep
         if not self.net._packed or self.flat_param._version != getattr(self, "_seen_version", -1):
             self.net.pack_weights()      # torch-side update (e.g. torch.optim.Adam); the fused optimizer repacks itself
             self._seen_version = self.flat_param._version

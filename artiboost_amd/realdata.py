@@ -129,6 +129,10 @@ class RealBatcher:
 
     def __init__(self, source: HOdataSource, cfg_preset, aug=True, aug_param=None, device="cuda", compute_dtype=torch.bfloat16, seed=1,
                  num_workers=None):
+        # compute_dtype "u8n": the padded frames as ONE bf16 plane of the odd integers 2 v - 255 (AB_DT_U8N; see synth.ArtiBoostLoader)
+        self.image_plane = "u8n" if (isinstance(compute_dtype, str) and compute_dtype == "u8n") else "f32"
+        if self.image_plane == "u8n":
+            compute_dtype = torch.bfloat16
         self.src, self.dev, self.dtype, self.aug = source, torch.device(device), compute_dtype, aug
         # host decode threads (the reference's DataLoader num_workers, anakin/opt.py:16 / train_artiboost.py:175-190): zlib inflates of the
         # PNG path and the Pillow decodes of sources without file bytes run on this many threads (None: AB_DECODE_WORKERS or min(32, cores))
@@ -376,6 +380,8 @@ class RealBatcher:
             frames[..., :3].copy_(rgb)                              # RGBX: the kernels fetch a pixel as one aligned dword
         order, factor, inv, flip, blur = dev["order"], dev["factor"], dev["inv"], dev["flip"], dev.get("blur")
         dt = L.dt(out_pad) if out_pad is not None else 0
+        if self.image_plane == "u8n" and out_pad is not None:
+            dt = 2                         # AB_DT_U8N
         L.check(lib.ab_augment_batch(L.ptr(frames), L.i(n), L.i(W), L.i(H), L.ptr(order), L.ptr(factor), L.ptr(inv), L.ptr(blur),
                                      L.ptr(flip), L.i(ow), L.i(oh), L.i(dt), _ptr(out_pad), L.ptr(out_chw), L.ptr(self._ws), L.stream()),
                 "ab_augment_batch")

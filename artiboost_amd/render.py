@@ -64,7 +64,7 @@ class DeviceRenderer:
         self._ws = None
 
     def render(self, samples_dev, hand_verts, order, factor, inv_affine, ow, oh, out_pad=None, out_chw=None,
-               want_keys=False, want_rgbx=False, blur=None):
+               want_keys=False, want_rgbx=False, blur=None, pad_code=None):
         """samples_dev: uint8 device tensor [B,96] (SAMPLE_DTYPE records); hand_verts [B,778,3] f32; order int32 [B,4];
         factor f32 [B,4]; inv_affine f32 [B,6]; blur: f32 [B] GaussianBlur radii (< 1.41) or None.
         Returns dict(keys=..., rgbx=...) of the optional outputs (rgbx: the render before blur and jitter)."""
@@ -76,6 +76,10 @@ class DeviceRenderer:
         keys = torch.empty((B, self.H, self.W), dtype=torch.int64, device=self.dev) if want_keys else None
         rgbx = torch.empty((B, self.H, self.W, 4), dtype=torch.uint8, device=self.dev) if want_rgbx else None
         dt = L.dt(out_pad) if out_pad is not None else 0
+        if pad_code is not None:          # 2 = AB_DT_U8N: out_pad (bf16) receives the integer plane 2 v - 255
+            if pad_code == 2 and (out_pad is None or out_pad.dtype != torch.bfloat16):
+                raise TypeError("AB_DT_U8N writes a bfloat16 padded image")
+            dt = pad_code
         L.check(lib.ab_render_batch(ctypes.byref(self.sc), L.ptr(samples_dev), L.ptr(hand_verts), L.ptr(order),
                                     L.ptr(factor), L.ptr(inv_affine), L.ptr(blur), L.i(B), L.i(self.max_faces), L.i(ow), L.i(oh),
                                     L.i(dt), L.ptr(out_pad), L.ptr(out_chw), L.ptr(self._ws), L.ptr(keys), L.ptr(rgbx),

@@ -454,7 +454,10 @@ class ArtiBoostLoader:
         self.dev = torch.device(device)
         self.batch_size, self.synth_len = batch_size, int(synth_len)
         self.rank, self.world = rank, world_size
-        self.dtype = compute_dtype
+        # compute_dtype "u8n": the padded image leaves the renderer as ONE bf16 plane of the odd integers 2 v - 255 (AB_DT_U8N) -- what the
+        # bf16x3 stem consumes directly (two MFMA passes, no split pass over the image); the network input is that plane / 510
+        self.image_plane = "u8n" if (isinstance(compute_dtype, str) and compute_dtype == "u8n") else "f32"
+        self.dtype = torch.bfloat16 if self.image_plane == "u8n" else compute_dtype
         ve = cfg["VIEW_ENGINE"]
         self.u_bins, self.theta_bins = ve["PERSP_U_BINS"], ve["PERSP_THETA_BINS"]
         self.z_range = ve["CAMERA_Z_RANGE"]
@@ -744,7 +747,7 @@ class ArtiBoostLoader:
                 chw = static[Queries.IMAGE] = torch.empty((self.batch_size, 3, H, W), dtype=torch.float32, device=self.dev)
         self.renderer.render(static["_samples"], static["_hand_verts"], static["_order"], static["_factor"],
                              static["_inv_affine"], W, H, out_pad=static["image_nhwc4_padded"] if out_pad is None else out_pad, out_chw=chw,
-                             blur=static["_blur"])
+                             blur=static["_blur"], pad_code=2 if self.image_plane == "u8n" else None)
 
     def __iter__(self):
         """Reference-shaped iteration: yields batch dicts (device tensors, `image` as float CHW like the reference's

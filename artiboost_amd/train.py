@@ -77,6 +77,12 @@ class TrainStep:
         self.pipeline_opt = bool(pipeline_render == "opt" and renderer is not None)
         self.g_render = None
         self.pipeline = bool(pipeline_render and not self.pipeline_opt and renderer is not None)
+        # A bfloat16 padded image handed to a bf16x3 model is the loaders' integer plane 2 v - 255 (compute_dtype "u8n" of ArtiBoostLoader /
+        # RealBatcher: AB_DT_U8N) -- a bf16 image of another meaning never was a valid input of that model (TypeError before round 5)
+        pad0 = self.static.get("image_nhwc4_padded") if isinstance(self.static, dict) else None
+        net0 = getattr(self.hb, "net", None)
+        if net0 is not None and getattr(net0, "x3", False) and torch.is_tensor(pad0) and pad0.dtype == torch.bfloat16 and pad0.dim() == 4:
+            net0.image_plane = "u8n"
         self.rstatic = None
         self.render_stream = None
         if self.pipeline_opt:

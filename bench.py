@@ -63,8 +63,11 @@ def build_everything(args, rank, world, device, wgrad_1pass=False):
     assets = SceneAssets(args.dataset, seed=1)
     mgr = dict(cfg["MANAGER"], EPOCH=cfg["TRAIN"]["EPOCH"])
     synth_len = args.bs * world * max(args.steps + args.warmup + 2, 4)
+    # bf16x3: the renderer hands the stem the integer image plane 2 v - 255 (AB_DT_U8N: two MFMA passes, no split pass; --image-plane f32: the
+    # fp32 image and its (hi, lo) split, the round-4 path)
+    u8n = args.dtype == "bf16x3" and getattr(args, "image_plane", "u8n") == "u8n" and not wgrad_1pass
     loader = ArtiBoostLoader.from_assets(assets, mgr, cfg["DATA_PRESET"], args.bs, synth_len, device=device,
-                             compute_dtype=hb.net.dtype, random_seed=cfg["TRAIN"]["MANUAL_SEED"], rank=rank, world_size=world)
+                             compute_dtype="u8n" if u8n else hb.net.dtype, random_seed=cfg["TRAIN"]["MANUAL_SEED"], rank=rank, world_size=world)
     loader.prepare()
     static = loader.new_static_batch()
     loader.load_batch(static, 0)
@@ -283,8 +286,10 @@ def conv_kernel_time_graph_ms(ts, loader, reps=3):
     """Per-step time of the conv-stack launches INSIDE the replayed step: the step is captured once more with a one-thread launch that
     writes the device's constant-rate wall clock (ab_wall_stamp) in front of and behind every conv-stack call; after a replay the slot
     differences are the durations of those launches in graph-replay mode (rocprofv3 is not available in the driver's bench run, torch's
-    external timing events are disallowed on ROCm).  A bracket costs two kernel boundaries; their price is measured from a captured
-    chain of back-to-back stamps and removed.  -> (ms per step, launches, boundary us)."""
+    external timing events are disallowed on ROCm).  A bracket also contains the leading stamp launch itself (its clock read comes first)
+    and two sub-microsecond gaps: that price is the difference between back-to-back stamps of a captured chain of 33, removed once per
+    bracket (checked under rocprofv3: bracket sum - 113 x chain difference = 7.087 ms against 7.073 ms of kernel durations in the same
+    replay, profiles/round5_a).  -> (ms per step, launches, chain difference us)."""
     import torch
     from artiboost_amd import _lib as L
     from artiboost_amd import kernels as K
@@ -339,7 +344,7 @@ def conv_kernel_time_graph_ms(ts, loader, reps=3):
             c = chain.cpu().numpy().astype("float64")
             b = float(sorted(c[1:] - c[:-1])[16]) / khz * 1e3          # us
             d = (t[1::2] - t[0::2]) / khz * 1e3                            # us per bracket
-            tot.append(float((d - 2.0 * b).clip(min=0.0).sum()) / 1e3)
+            tot.append(float((d - b).clip(min=0.0).sum()) / 1e3)
             bnd.append(b)
     finally:
         for n in CONV_FNS:
@@ -702,6 +707,9 @@ def main():
     ap.add_argument("--dataset", default="HO3D", choices=["HO3D", "DexYCB"])
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--image-plane", dest="image_plane", choices=["u8n", "f32"], default="u8n",
+                    help="bf16x3: what the loader writes for the stem -- u8n: ONE bf16 plane of the odd integers 2v-255 (exact; two MFMA passes); "
+                         "f32: the fp32 image, split into (hi, lo) planes by a pass of its own (three passes)")
     ap.add_argument("--pipeline", action="store_true",
                     help="render batch i+1 on a side stream while step i learns (measured slower on one GPU: the conv "
                          "kernels already fill the chip, co-scheduling the rasteriser only evicts their workgroups)")
@@ -872,8 +880,8 @@ def main():
                     "kernel": "implicit-GEMM conv stack: conv3x3_kernel / conv_gemm2_kernel / conv_gemm_kernel (fwd, dgrad) + "
                               "wgrad3x3_kernel / wgrad_gemm2_kernel / wgrad_reduce (weight grad)",
                     "conv_ms_per_step": round(conv_ms, 3), "conv_launches_per_step": nlaunch,
-                    "conv_ms_source": ("graph replay: wall-clock stamps (ab_wall_stamp) captured around every conv-stack call, two kernel "
-                                       "boundaries per bracket removed" if boundary_us is not None else "eager HIP events"),
+                    "conv_ms_source": ("graph replay: wall-clock stamps (ab_wall_stamp) captured around every conv-stack call, the leading stamp "
+                                       "launch of each bracket (= the difference of back-to-back stamps) removed" if boundary_us is not None else "eager HIP events"),
                     "conv_ms_per_step_eager": round(conv_ms_eager, 3), "stamp_boundary_us": None if boundary_us is None else round(boundary_us, 2)}
             if graph_err:
                 roof["graph_stamp_error"] = graph_err

@@ -21,6 +21,9 @@ extern "C" {
 
 #define AB_DT_F32 0
 #define AB_DT_BF16 1
+#define AB_DT_U8N 2         /* loaders only (`out_dtype` of ab_render_batch / ab_augment_batch): the padded image as ONE bf16 plane of the odd integers
+                             * 2 v - 255 (v = the uint8 pixel after the jitter chain); the network input v / 255 - 0.5 (hodata.py:446) is that plane / 510.
+                             * ab_conv2d_stem_fwd_x3 / _stem_wgrad_x3 take it as xpad_hi with xpad_lo == NULL: two MFMA passes, no rounding of the image */
 #define AB_EINVAL (-1)
 #define AB_ESHAPE (-2)
 #define AB_EALIGN (-3)

@@ -589,3 +589,42 @@ def test_conv_transpose_4x4s2_patch_kernel_32x32(Ci, Co, hin, nb):
     dd = dx.double().cpu().reshape(-1, Ci)
     np.testing.assert_allclose(st2.double().sum(0).cpu()[:, 0].numpy(), dd.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(dd.abs().sum(0).max()))
     np.testing.assert_allclose(st2.double().sum(0).cpu()[:, 1].numpy(), (dd * dd).sum(0).numpy(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("nhw", [(2, 64, 64), (3, 128, 96), (2, 256, 256)])
+def test_stem_on_the_integer_image_plane(nhw):
+    """Round 5 (review item 4): the loaders can write the padded image as ONE bf16 plane of the odd integers n = 2 v - 255 (AB_DT_U8N); the
+    stem's forward and weight gradient then run TWO MFMA passes (n . w_hi + n . w_lo; dy_hi . n + dy_lo . n) with 1 / 510 in the epilogue.
+    Against float64 on the exact image v / 255 - 0.5 both are at least as close as the three-pass path on the fp32 image."""
+    from artiboost_amd import kernels as K
+    N, H, W = nhw
+    g = torch.Generator().manual_seed(N * H + 1)
+    v = torch.randint(0, 256, (N, 3, H, W), generator=g)
+    x64 = v.double() / 255.0 - 0.5
+    w = torch.randn((64, 3, 7, 7), generator=g) * 0.1
+    ref = F.conv2d(x64, w.double(), stride=2, padding=3)
+    n = torch.zeros((N, H + 6, W + 8, 4), dtype=torch.bfloat16)
+    n[:, 3:-3, 3:-5, :3] = (2 * v - 255).permute(0, 2, 3, 1).to(torch.bfloat16)
+    assert torch.equal(n[:, 3:-3, 3:-5, :3].float(), (2 * v - 255).permute(0, 2, 3, 1).float())        # exact in bf16
+    xpad32 = K.image_pad_nhwc4((v.float() / 255.0 - 0.5).cuda(), torch.float32)
+    wst = torch.zeros(64, 7, 8, 4)
+    wst[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    ws = K.split(wst.cuda())
+    y, stats = K.conv2d_stem_fwd_x3(n.cuda(), ws, H, W, want_stats=True)
+    y3 = K.conv2d_stem_fwd_x3(xpad32, ws, H, W)
+    close(nchw(y.cpu()), ref)
+    e2 = float((nchw(y.cpu()).double() - ref).abs().max()), float((nchw(y3.cpu()).double() - ref).abs().max())
+    assert e2[0] <= 1.25 * e2[1] + 1e-7, e2                      # not worse than the three-pass path (it is better: the image is exact)
+    yy = y.double().cpu().reshape(-1, 64)
+    st = stats.double().sum(0).cpu()
+    np.testing.assert_allclose(st[:, 0].numpy(), yy.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(yy.abs().sum(0).max()))
+    np.testing.assert_allclose(st[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)
+    dy = torch.randn(ref.shape, generator=g)
+    wr = w.double().clone().requires_grad_(True)
+    F.conv2d(x64, wr, stride=2, padding=3).backward(dy.double())
+    dw = K.conv2d_stem_wgrad_x3(n.cuda(), nhwc(dy).cuda(), H, W).cpu()
+    assert float(dw[:, :, 7, :].abs().max()) == 0.0 and float(dw[:, :, :, 3].abs().max()) == 0.0
+    close(dw[:, :, :7, :3].permute(0, 3, 1, 2), wr.grad)
+    dw3 = K.conv2d_stem_wgrad_x3(xpad32, nhwc(dy).cuda(), H, W).cpu()
+    e = [float((d[:, :, :7, :3].permute(0, 3, 1, 2).double() - wr.grad).abs().max()) for d in (dw, dw3)]
+    assert e[0] <= 1.25 * e[1] + 1e-7, e

@@ -482,3 +482,72 @@ def test_rendered_pixels_line_up_with_the_ground_truth(dataset, cfgname, B):
         print(f"{dataset} {name}: {hits} / {tot} joints on the hand; mirrored x {mirrored['x']}, y {mirrored['y']}")
         for ax in ("x", "y"):      # a flipped rasteriser misses a large share of the joints: the check above is not vacuous
             assert mirrored[ax][1] < 0.8 * mirrored[ax][0], f"{name}: the keys mirrored in {ax} still pass ({mirrored[ax]})"
+
+
+def test_loader_integer_image_plane_is_the_same_image():
+    """compute_dtype "u8n": the padded image leaves the renderer as the bf16 plane 2 v - 255 of the SAME jittered uint8 pixels the fp32 path
+    normalises: plane / 510 == v / 255 - 0.5 to fp32 rounding, every value an odd integer, the border zero."""
+    import yaml
+    from artiboost_amd.assets import SceneAssets
+    from artiboost_amd.synth import ArtiBoostLoader
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["DATA_PRESET"]["IMAGE_SIZE"] = [128, 128]
+    assets = SceneAssets("HO3D", seed=1)
+    mk = lambda dt: ArtiBoostLoader.from_assets(assets, cfg["MANAGER"], cfg["DATA_PRESET"], 4, 8, compute_dtype=dt, random_seed=3)   # noqa: E731
+    a, b = mk(torch.float32), mk("u8n")
+    a.prepare(); b.prepare()
+    assert b.image_plane == "u8n" and b.dtype == torch.bfloat16
+    for ba, bb in zip(a, b):
+        pa, pb = ba["image_nhwc4_padded"], bb["image_nhwc4_padded"]
+        assert pb.dtype == torch.bfloat16 and pb.shape == pa.shape
+        n = pb.float().cpu().numpy()
+        inner = n[:, 3:-3, 3:-5, :3]
+        assert np.all(inner == np.rint(inner)) and np.all(np.abs(inner) <= 255) and np.all(inner.astype(np.int64) % 2 != 0)
+        v = (inner + 255.0) / 2.0
+        np.testing.assert_array_equal((v / 255.0).astype(np.float32) - np.float32(0.5), pa.cpu().numpy()[:, 3:-3, 3:-5, :3])
+        assert np.abs(n[:, :3]).max() == 0 and np.abs(n[:, :, :3]).max() == 0 and np.abs(n[..., 3]).max() == 0
+        np.testing.assert_array_equal(ba["image"].cpu().numpy(), bb["image"].cpu().numpy())       # the float CHW image is unchanged
+
+
+@pytest.mark.gpu
+def test_train_steps_on_the_integer_image_plane_match_the_fp32_image():
+    """The same three graph-replayed bf16x3 steps from the same weights, once with the fp32 padded image (split into planes by its own pass,
+    three MFMA passes in the stem) and once with the loaders' integer plane (AB_DT_U8N, two passes): the image is the same, so losses and
+    the updated weights agree to the stem's operand rounding."""
+    import yaml
+    from artiboost_amd import registry as R
+    from artiboost_amd.criterions import Criterion
+    from artiboost_amd.models import Arch
+    from artiboost_amd.optim import FusedClipAdam
+    from artiboost_amd.train import TrainStep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    res = {}
+    for plane in ("f32", "u8n"):
+        torch.manual_seed(0); np.random.seed(0)
+        import random
+        random.seed(0)
+        assets, loader = _loader(torch.float32 if plane == "f32" else "u8n", bs=8, n=32, size=224)
+        arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16x3", INIT_SEED=7)
+        model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
+        crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
+        hb = model.model_list[0]
+        opt = FusedClipAdam(model.models_params, lr=1e-4, max_norm=1.0, model=hb)
+        loader.prepare()
+        static = loader.new_static_batch()
+        loader.load_batch(static, 0)
+        model.train()
+        ts = TrainStep(model, crit, opt, static, use_graph=True, renderer=loader)
+        ts.static = static
+        assert hb.net.image_plane == plane
+        vals = []
+        for i in range(3):
+            loader.load_batch(static, i % len(loader))
+            _, losses, _ = ts()
+            vals.append(losses.float().cpu().numpy().copy())
+        res[plane] = (np.stack(vals), hb.store.flat.detach().float().cpu().numpy().copy())
+    np.testing.assert_allclose(res["u8n"][0], res["f32"][0], rtol=2e-4, atol=1e-6)
+    dw = np.abs(res["u8n"][1] - res["f32"][1])
+    # three Adam steps at lr 1e-4 move a weight by <= 3e-4; Adam's normalised step amplifies rounding noise of near-zero gradients
+    assert dw.mean() <= 3e-6 and dw.max() <= 1.5e-4, (dw.mean(), dw.max())

@@ -168,12 +168,13 @@ def main():
                              **({"synth_len": total_synth} if real_len > 0 else {}),
                              num_workers=int(arg.workers), pin_memory=True, drop_last=arg.drop_last, collate_fn=ho_collate,
                              random_seed=seed, rank=rank, world_size=world,
-                             compute_dtype=getattr(getattr(model.model_list[0], "net", None), "dtype", torch.float32))
+                             compute_dtype=("u8n" if getattr(getattr(model.model_list[0], "net", None), "x3", False) and os.environ.get("AB_IMAGE_PLANE", "u8n") == "u8n"
+                                            else getattr(getattr(model.model_list[0], "net", None), "dtype", torch.float32)))
     mixed = None
     if real_len > 0:
         tr = cfg["DATASET"]["TRAIN"]
         mixed = MixedLoader(RealBatcher(train_data, cfg["DATA_PRESET"], aug=bool(tr.get("AUG", False)), aug_param=tr.get("AUG_PARAM") or None, device=dev,
-                                        compute_dtype=loader.dtype, seed=seed, num_workers=int(arg.workers) or None),
+                                        compute_dtype=("u8n" if loader.image_plane == "u8n" else loader.dtype), seed=seed, num_workers=int(arg.workers) or None),
                             loader, per_rank, seed=seed, rank=rank, world_size=world, want_chw=False, reuse_buffers=4)      # TrainStep copies a batch in
     epoch0 = 0
     if arg.resume:
@@ -195,7 +196,8 @@ def main():
             if len(test_data) > 0:
                 from artiboost_amd.realdata import RealBatcher
                 if "real" not in test_state:
-                    test_state["real"] = RealBatcher(test_data, cfg["DATA_PRESET"], aug=False, device=dev, compute_dtype=loader.dtype, seed=seed)
+                    test_state["real"] = RealBatcher(test_data, cfg["DATA_PRESET"], aug=False, device=dev,
+                                                    compute_dtype=("u8n" if loader.image_plane == "u8n" else loader.dtype), seed=seed)
                 rb = test_state["real"]
                 # shuffle=True, drop_last=False (train_artiboost.py:113-121).  Every rank evaluates the WHOLE test set (the reference's
                 # DataParallel process does): no cross-rank reduction of the evaluator is needed and rank 0's record covers every frame;
