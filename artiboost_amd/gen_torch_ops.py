@@ -186,7 +186,8 @@ static inline void ck_dtype(const char* op, const char* a, const OptT& t, at::Sc
     if (has(t)) TORCH_CHECK(t->scalar_type() == want, op, ": argument '", a, "' must be ", c10::toString(want), ", got ", c10::toString(t->scalar_type()));
 }
 static inline void ck_dtcode(const char* op, const char* a, const OptT& t, int64_t code) {
-    TORCH_CHECK(code == AB_DT_F32 || code == AB_DT_BF16, op, ": dtype code ", code, " is neither AB_DT_F32 nor AB_DT_BF16");
+    // AB_DT_U8N (the loaders' integer image plane 2 v - 255) is a bfloat16 tensor as well; ops that do not write it refuse the code themselves (AB_EINVAL)
+    TORCH_CHECK(code == AB_DT_F32 || code == AB_DT_BF16 || code == AB_DT_U8N, op, ": dtype code ", code, " is none of AB_DT_F32, AB_DT_BF16, AB_DT_U8N");
     ck_dtype(op, a, t, code == AB_DT_F32 ? at::kFloat : at::kBFloat16);
 }
 static inline void ck_numel(const char* op, const char* a, const OptT& t, int64_t need) {
