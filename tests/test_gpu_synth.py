@@ -547,9 +547,18 @@ def test_train_steps_on_the_integer_image_plane_match_the_fp32_image():
             _, losses, _ = ts()
             vals.append(losses.float().cpu().numpy().copy())
             if i == 0:
-                g1 = hb.store.grad.detach().float().cpu().numpy().copy()
+                g1 = {n: hb.store.gview(n).detach().float().cpu().numpy().ravel().copy() for n in hb.store.entries}
         res[plane] = (np.stack(vals), g1)
     np.testing.assert_allclose(res["u8n"][0][0], res["f32"][0][0], rtol=1e-4, atol=1e-7)          # first step: the same losses
     np.testing.assert_allclose(res["u8n"][0][:, :6], res["f32"][0][:, :6], rtol=5e-2, atol=1e-5)   # three steps: the same trajectory to a few %
-    rel = np.linalg.norm(res["u8n"][1] - res["f32"][1]) / np.linalg.norm(res["f32"][1])
-    assert rel <= 2e-4, rel                                                                         # first step's gradient, whole flat buffer
+    # first step's gradient.  The head sees the same activations to rounding; deeper into the backbone a rounding-level change of the stem output
+    # flips ReLU / max-pool decisions of this randomly initialised net at batch 8: the SAME fp32 image through another stem kernel
+    # (AB_STEM_HALO_X3=0) moves these gradients by up to 1.8 % (cosine 0.9999), the integer plane by up to 3.1 % (cosine 0.9996).
+    gu, gf = res["u8n"][1], res["f32"][1]
+    for n in ("hybrid_head.final_layer.weight", "hybrid_head.final_layer.bias"):
+        assert np.linalg.norm(gu[n] - gf[n]) <= 1e-4 * np.linalg.norm(gf[n]), n
+    for n, a in gf.items():
+        na = np.linalg.norm(a)
+        if na > 1e-3:
+            cos = float(a @ gu[n]) / (na * np.linalg.norm(gu[n]))
+            assert cos >= 0.998 and abs(np.linalg.norm(gu[n]) / na - 1.0) <= 0.02, (n, cos)
