@@ -686,9 +686,15 @@ int c3v_run(Conv3Args& g, int x3, hipStream_t st);
 int c3v_pack(const void* w_hi, const void* w_lo, int C, int Cn, void* out, hipStream_t st);
 long c3v_frag_bytes(int C, int Cn);
 
+// conv3x3r.hip: 64 -> 64 channels with the weights resident in registers (plain forward / data gradient launches of layer 1)
+int conv3x3r_rows(int N, int H, int W, int C, int Cn);
+int conv3x3r_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W, int flip,
+                 float* stats, hipStream_t st);
+
 // BatchNorm partial rows of the split-bf16 launches: of a forward / plain launch, and of a data gradient with the fused reduction
 int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn) {
     if (C % 32) return 0;
+    if (int r = conv3x3r_rows(N, H, W, C, Cn)) return r;
     if (int t = c3v_tiles(N, H, W, C, Cn)) return t;
     return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, true, true), N, H, W);
 }
@@ -704,6 +710,8 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
     if (C % 32) return AB_ESHAPE;
     if (bn_y && (!flip || stats || !bnp || !bn_part)) return AB_EINVAL;
     if (ev && (flip || stats || bn_y || !bnp || !ev->out_hi || !ev->out_lo || (ev->res_hi && (addend || !ev->res_lo)))) return AB_EINVAL;
+    if (!bn_y && !ev && !addend && conv3x3r_rows(N, H, W, C, Cn))
+        return conv3x3r_run(x_hi, x_lo, wt_hi, wt_lo, out, N, H, W, flip, stats, st);
     int cfg = c3_config(N, H, W, (C + 63) / 64 * 64, Cn, /*x3plain=*/!bn_y, /*x3=*/true);
     if (!cfg || Cn % 4) return AB_ESHAPE;
     const long delta = (const char*)wt_lo - (const char*)wt_hi;

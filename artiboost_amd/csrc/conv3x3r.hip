@@ -1,0 +1,198 @@
+// 3x3 / stride 1 / pad 1 convolution, 64 -> 64 channels (layer 1 of the ResNet: anakin/models/resnet.py:85-101 at 64 x 64 maps), split-bf16,
+// with the WEIGHTS RESIDENT IN REGISTERS.
+//
+// Why: at 64 -> 64 channels the K loop of conv3x3.hip is only two 32-channel chunks (18 steps), and every workgroup streams all 147 KB of weight
+// planes through its LDS ring whatever its tile -- 2 048 workgroups x 147 KB = 300 MB of L2 -> LDS fills per launch, six times the activation
+// patches -- with a barrier every 12 MFMAs per wave.  Here a wave owns SIXTEEN output channels and keeps their complete weights (9 taps x 64 input
+// channels x (hi, lo) = 36 B-fragments of v_mfma_f32_16x16x32_bf16 = 144 VGPRs) for the life of a persistent workgroup; the only LDS traffic is
+// the input patch (10 x 18 pixels x 64 channels x (hi, lo) = 46 KB per 128-pixel tile, LDS-DMA, double-buffered, ONE barrier per tile = 216 MFMAs
+// per wave), every fragment address is a lane constant plus an immediate, and the 16 x 16 accumulator tile (lane = channel, register = pixel)
+// stores straight to HBM.  Four waves cover the 64 output channels, two such sets split the tile's eight image rows.
+//   FLIP = 0: forward (weights OHWI, tap t reads input (t/3 - 1, t%3 - 1));  FLIP = 1: data gradient (weights IHWO, taps mirrored).
+//   stats: BatchNorm partial sums (sum, sum of squares) of the stored values, ONE row per workgroup (its tiles in launch order).
+#include "conv3x3.h"
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#ifndef C3R_PIN
+#define C3R_PIN 1
+#endif
+
+struct C3rArgs {
+    const void* X; const void* X_lo; const void* Wt; const void* Wt_lo;      // input planes [N, H, W, 64]; weight planes [64][9][64]
+    float* Out; float* stats;                                                 // [N, H, W, 64]; [grid][64][2] or NULL
+    int N, H, W, tiles_x, tiles_per_img, ntiles;
+};
+
+static __device__ uint4 c3r_zero_page[2];
+
+__device__ __forceinline__ void c3r_store(unsigned voff, float v, const void* sbase) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase));
+}
+
+template <int FLIP>
+__global__ __launch_bounds__(512) void conv3x3r_kernel(C3rArgs g) {
+    constexpr int TH = 8, TW = 16, PW = 18, PH = 10, NPIX = PH * PW;          // tile 8 x 16 pixels, patch 10 x 18
+    constexpr int PI = (NPIX + 7) / 8, CHUNK_BYTES = 24 * 1024, TILE_BYTES = 2 * CHUNK_BYTES;      // 23 (-> 24) 1-KiB instructions per 32-channel chunk
+    constexpr int LPW = 2 * 24 / 8;                                           // fill instructions per wave and tile (both chunks)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wave & 3, ph = wave >> 2;                                   // output-channel quarter, half of the tile's rows
+    const int l16 = lane & 15, kq = lane >> 4;
+    const unsigned lds0 = lds_addr_of(smem);
+    const bf16_t* __restrict__ X = (const bf16_t*)g.X;
+    const bf16_t* __restrict__ Xlo = (const bf16_t*)g.X_lo;
+    const bf16_t* zp = (const bf16_t*)c3r_zero_page;
+
+    // ---- this wave's weights: B fragments (k32 x 16 channels) of every (tap, chunk, plane): lane = (channel l16, k-quarter kq)
+    bf16x8 wh[18], wl[18];
+    {
+        const bf16_t* ph_ = (const bf16_t*)g.Wt + (size_t)(q * 16 + l16) * 576 + kq * 8;
+        const bf16_t* pl_ = (const bf16_t*)g.Wt_lo + (size_t)(q * 16 + l16) * 576 + kq * 8;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                wh[t * 2 + c] = *(const bf16x8*)(ph_ + t * 64 + c * 32);
+                wl[t * 2 + c] = *(const bf16x8*)(pl_ + t * 64 + c * 32);
+            }
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), visible to hipcc's wait-count pass (gemm_rw.hip)
+    }
+
+    // ---- patch fill assignment: instruction ii = wave * LPW + j of 48: chunk = ii / 24, pixels (ii % 24) * 8 .. + 7
+    int f_py[LPW], f_px[LPW]; unsigned f_off[LPW]; bool f_lo[LPW], f_in[LPW];
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) {
+        const int ii = wave * LPW + j, chunk = ii / 24, pp = (ii - chunk * 24) * 8 + (lane >> 3);
+        f_py[j] = pp / PW; f_px[j] = pp - f_py[j] * PW;
+        f_in[j] = pp < NPIX;
+        const int c = (lane & 7) ^ ((f_px[j] >> 1) & 7);
+        f_lo[j] = (c & 4) != 0; f_off[j] = (unsigned)(chunk * 32 + (c & 3) * 8);
+    }
+    auto issue_tile = [&](int tile, int slot) {
+        const int img = tile / g.tiles_per_img, rem = tile - img * g.tiles_per_img;
+        const int ty0 = (rem / g.tiles_x) * TH, tx0 = (rem % g.tiles_x) * TW;
+#pragma unroll
+        for (int j = 0; j < LPW; ++j) {
+            const int y = ty0 + f_py[j] - 1, x = tx0 + f_px[j] - 1;
+            const bool ok = f_in[j] && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+            const bf16_t* src = ok ? (f_lo[j] ? Xlo : X) + ((((size_t)img * g.H + y) * g.W + x) * 64 + f_off[j]) : zp;
+            glds16(src, __builtin_amdgcn_readfirstlane(lds0 + slot * TILE_BYTES + (wave * LPW + j) * 1024));
+        }
+    };
+
+    // ---- fragment addresses: output pixel (row r of the tile, column l16), tap column dw: patch pixel (r + dh, l16 + dw), 16-byte slot
+    // (plane * 4 + kq) ^ (((l16 + dw) >> 1) & 7); rows and chunks are immediates
+    unsigned a_rel[3][2];
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+        const int px = l16 + dw;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) a_rel[dw][pl] = lds0 + px * 128 + (((pl * 4 + kq) ^ ((px >> 1) & 7)) << 4);
+    }
+    const unsigned o_voff = (unsigned)(((kq * 4) * 64 + q * 16 + l16) * 4);      // pixel 4 kq (+ r) of the row, this lane's channel
+
+    float s_sum = 0.f, s_sq = 0.f;
+    int tile = blockIdx.x, slot = 0;
+    if (tile < g.ntiles) issue_tile(tile, 0);
+    bool first = true;
+    for (; tile < g.ntiles; tile += gridDim.x) {
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // behind this tile's fills: the 16 stores of the previous tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        first = false;
+        const int next = tile + gridDim.x;
+        if (next < g.ntiles) issue_tile(next, slot ^ 1);
+        const int img = tile / g.tiles_per_img, rem = tile - img * g.tiles_per_img;
+        const int ty0 = (rem / g.tiles_x) * TH, tx0 = (rem % g.tiles_x) * TW;
+        const unsigned sb = slot * TILE_BYTES;
+        const char* obase = (const char*)g.Out + ((((size_t)img * g.H + ty0 + ph * 4) * g.W + tx0) * 64) * 4;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {                               // four image rows of 16 pixels each
+            const int r = ph * 4 + rb;
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f};
+            // 18 (tap, chunk) steps; the fragment reads run one step ahead of the MFMAs that consume them (pinned: gemm_rw.hip's grw_block)
+            u32x4 fh[2], fl[2];
+            auto rd = [&](int s, int b) {
+                const int t = s >> 1, c = s & 1, t3 = t / 3, tr = t % 3;
+                const int dh = FLIP ? 2 - t3 : t3, dw = FLIP ? 2 - tr : tr;
+                const unsigned off = sb + c * CHUNK_BYTES + (r + dh) * PW * 128;
+                fh[b] = *(const lds_u32x4*)(a_rel[dw][0] + off);
+                fl[b] = *(const lds_u32x4*)(a_rel[dw][1] + off);
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int s = 0; s < 18; ++s) {
+                if (s + 1 < 18) rd(s + 1, (s + 1) & 1);
+                if constexpr (C3R_PIN) __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, fh[s & 1]), al = __builtin_bit_cast(bf16x8, fl[s & 1]);
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[s], accx, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[s], acc, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[s], accx, 0, 0, 0);
+                if constexpr (C3R_PIN) __builtin_amdgcn_sched_barrier(0);
+            }
+            const char* orow_v = obase + (size_t)rb * g.W * 256;
+            const unsigned long long orow_u = (unsigned long long)orow_v;      // (wave-uniform: spelled out for the asm's SGPR operand)
+            const char* orow = (const char*)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(orow_u >> 32)) << 32) |
+                                             (unsigned)__builtin_amdgcn_readfirstlane((unsigned)orow_u));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                               // register i: pixel 4 kq + i of the row
+                const float v = acc[i] + accx[i];
+                s_sum += v; s_sq += v * v;
+                c3r_store(o_voff, v, orow + i * 256);
+            }
+        }
+        slot ^= 1;
+    }
+    // ---- BatchNorm partials: a lane holds (sum, sumsq) of its channel over its pixel quarter (kq) and rows (ph); the eight combinations meet in LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (g.stats) {
+        float* sp = (float*)smem;                                        // [2 ph][4 kq][64 ch][2]
+        sp[(((ph * 4 + kq) * 64) + q * 16 + l16) * 2] = s_sum;
+        sp[(((ph * 4 + kq) * 64) + q * 16 + l16) * 2 + 1] = s_sq;
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f, qq = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s += sp[(k * 64 + tid) * 2]; qq += sp[(k * 64 + tid) * 2 + 1]; }
+            g.stats[((size_t)blockIdx.x * 64 + tid) * 2] = s;
+            g.stats[((size_t)blockIdx.x * 64 + tid) * 2 + 1] = qq;
+        }
+    }
+}
+
+static int c3r_ntiles(int N, int H, int W) { return (H % 8 || W % 16) ? 0 : N * (H / 8) * (W / 16); }
+static int c3r_grid(int ntiles) {
+    static const int wgs = getenv("AB_C3R_WGS") ? atoi(getenv("AB_C3R_WGS")) : 256;
+    return ntiles < wgs ? ntiles : wgs;
+}
+// BatchNorm partial rows (= workgroups) of a launch; 0: shape not taken (64 -> 64 channels, H % 8 == 0, W % 16 == 0, at least 64 tiles)
+int conv3x3r_rows(int N, int H, int W, int C, int Cn) {
+    static const int off = getenv("AB_C3R_OFF") ? atoi(getenv("AB_C3R_OFF")) : 0;
+    if (off || C != 64 || Cn != 64) return 0;
+    const int nt = c3r_ntiles(N, H, W);
+    static const int min_tiles = getenv("AB_C3R_MIN") ? atoi(getenv("AB_C3R_MIN")) : 64;      // (2 images of 64 x 64: what the parity tests run)
+    return nt >= min_tiles ? c3r_grid(nt) : 0;
+}
+int conv3x3r_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W, int flip,
+                 float* stats, hipStream_t st) {
+    if (!conv3x3r_rows(N, H, W, 64, 64)) return AB_ESHAPE;
+    C3rArgs g = {};
+    g.X = x_hi; g.X_lo = x_lo; g.Wt = wt_hi; g.Wt_lo = wt_lo; g.Out = out; g.stats = stats;
+    g.N = N; g.H = H; g.W = W; g.tiles_x = W / 16; g.tiles_per_img = (H / 8) * (W / 16); g.ntiles = c3r_ntiles(N, H, W);
+    const int lds = 2 * 2 * 24 * 1024;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3r_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int grid = c3r_grid(g.ntiles);
+    if (flip) conv3x3r_kernel<1><<<grid, 512, lds, st>>>(g);
+    else conv3x3r_kernel<0><<<grid, 512, lds, st>>>(g);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

@@ -126,10 +126,12 @@ def train_loop(cfg, steps=30, modes=("same stream", "same stream, frames of 4 ba
         src = {"jpeg": JpegFileSource, "png": PngFileSource, "png-pillow": lambda n: PngFileSource(n, device_decode=False)}[source](n=4096)
         synth_len = int(0.6 * len(src))
         n_synth = MixedLoader.n_synth_for(B, len(src), synth_len)
-        synth = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], n_synth, synth_len, compute_dtype=torch.float32)
+        # both halves write the stem's integer image plane (AB_DT_U8N; AB_IMAGE_PLANE=f32: the fp32 image + split pass of round 4)
+        cdt = "u8n" if os.environ.get("AB_IMAGE_PLANE", "u8n") == "u8n" else torch.float32
+        synth = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], n_synth, synth_len, compute_dtype=cdt)
         synth.prepare()
         # as train/train_artiboost.py builds it: no float CHW copy of the frames (TrainStep reads the NHWC4 tensor), image tensors from a ring
-        ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.float32), synth, B, decode_group=4 if "4 batches" in mode else 1,
+        ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=cdt), synth, B, decode_group=4 if "4 batches" in mode else 1,
                          decode_ahead=ahead, want_chw=os.environ.get("AB_MIXED_CHW", "0") == "1", reuse_buffers=int(os.environ.get("AB_MIXED_RING", "4")))
         arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16x3", INIT_SEED=3)
         model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
