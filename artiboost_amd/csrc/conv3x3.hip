@@ -710,7 +710,10 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
     if (C % 32) return AB_ESHAPE;
     if (bn_y && (!flip || stats || !bnp || !bn_part)) return AB_EINVAL;
     if (ev && (flip || stats || bn_y || !bnp || !ev->out_hi || !ev->out_lo || (ev->res_hi && (addend || !ev->res_lo)))) return AB_EINVAL;
-    if (!bn_y && !ev && !addend && conv3x3r_rows(N, H, W, C, Cn))
+    // conv3x3r.hip takes the TRAINING launches of layer 1 (forward with BatchNorm partials, plain data gradient).  A forward without
+    // statistics is an eval-mode one: it stays on this file's kernel, whose eval-fold form (X3 = 3) must remain bit-identical to
+    // conv + ab_bn_apply_x3 (tests/test_gpu_learner.py::test_eval_forward_with_folded_batchnorm_is_bit_identical)
+    if (!bn_y && !ev && !addend && (stats || flip) && conv3x3r_rows(N, H, W, C, Cn))
         return conv3x3r_run(x_hi, x_lo, wt_hi, wt_lo, out, N, H, W, flip, stats, st);
     int cfg = c3_config(N, H, W, (C + 63) / 64 * 64, Cn, /*x3plain=*/!bn_y, /*x3=*/true);
     if (!cfg || Cn % 4) return AB_ESHAPE;

@@ -170,7 +170,8 @@ static int c3r_grid(int ntiles) {
 }
 // BatchNorm partial rows (= workgroups) of a launch; 0: shape not taken (64 -> 64 channels, H % 8 == 0, W % 16 == 0, at least 64 tiles)
 int conv3x3r_rows(int N, int H, int W, int C, int Cn) {
-    static const int off = getenv("AB_C3R_OFF") ? atoi(getenv("AB_C3R_OFF")) : 0;
+    // (AB_C3_L1T16=0 asks for the round-2 tiles of conv3x3.hip on layer 1's plain launches: this kernel stands in the 8 x 16 tile's place)
+    static const int off = (getenv("AB_C3R_OFF") ? atoi(getenv("AB_C3R_OFF")) : 0) || (getenv("AB_C3_L1T16") && !atoi(getenv("AB_C3_L1T16")));
     if (off || C != 64 || Cn != 64) return 0;
     const int nt = c3r_ntiles(N, H, W);
     static const int min_tiles = getenv("AB_C3R_MIN") ? atoi(getenv("AB_C3R_MIN")) : 64;      // (2 images of 64 x 64: what the parity tests run)

@@ -44,7 +44,9 @@ __device__ __forceinline__ uint4 tr_pair(unsigned addr_lo, unsigned addr_hi) {
 // issuing waves, tools/probe_fill.hip) and each holds 80 instead of 144 accumulators.
 // X3 = 1: split-bf16 operands (conv3x3.hip): the band and the patch are staged once per plane ([dy hi][dy lo][x hi][x lo],
 // bands of 64 pixels so that two stages still fit) and every (dy, x) fragment pair feeds hi*hi + hi*lo + lo*hi.
-template <int W, int TH, int NW = 4, int X3 = 0>
+// PIN (X3 only, round 5): the transposed fragment reads of tap t + 1 (and of the next k-slice's dy fragments) are issued in front of the MFMAs of
+// tap t and held there with sched_barrier(0) -- hipcc on its own issues a tap's reads right in front of its first MFMA (gemm_rw.hip's finding).
+template <int W, int TH, int NW = 4, int X3 = 0, bool PIN = false>
 __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
     constexpr int BP = TH * W;                       // band pixels (multiple of 16)
     constexpr int KS = BP / 16;                      // k-slices per band
@@ -158,6 +160,39 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
         unsigned x_cur[3][2];
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) { x_cur[kw][0] = xb + x_base[kw][0]; x_cur[kw][1] = xb + x_base[kw][1]; }
+        if constexpr (X3 && PIN) {
+            // linearised (k-slice, tap) steps with the next step's fragments in flight
+            auto rd_a = [&](int sl, uint4& a, uint4& al) {
+                a = tr_pair(a_cur[0] + sl * 16 * 128, a_cur[1] + sl * 16 * 128);
+                al = tr_pair(a_cur[0] + ABYTES + sl * 16 * 128, a_cur[1] + ABYTES + sl * 16 * 128);
+            };
+            auto rd_b = [&](int sl, int tt, uint4& b, uint4& bl) {
+                const int kh = (T0 + tt) / 3, kw = (T0 + tt) % 3, p0 = 16 * sl;
+                const int disp = ((p0 / W + kh) * PW + p0 % W) * 128;
+                b = tr_pair(x_cur[kw][0] + disp, x_cur[kw][1] + disp);
+                bl = tr_pair(x_cur[kw][0] + XBYTES + disp, x_cur[kw][1] + XBYTES + disp);
+            };
+            uint4 fa[2], fal[2], fb[2], fbl[2];
+            rd_a(0, fa[0], fal[0]);
+            rd_b(0, 0, fb[0], fbl[0]);
+#pragma unroll
+            for (int st = 0; st < KS * NTP; ++st) {
+                const int sl = st / NTP, tt = st - sl * NTP;
+                if (st + 1 < KS * NTP) {
+                    const int sl2 = (st + 1) / NTP, tt2 = (st + 1) - sl2 * NTP;
+                    if (tt2 == 0) rd_a(sl2, fa[sl2 & 1], fal[sl2 & 1]);
+                    rd_b(sl2, tt2, fb[(st + 1) & 1], fbl[(st + 1) & 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 a = __builtin_bit_cast(bf16x8, fa[sl & 1]), al = __builtin_bit_cast(bf16x8, fal[sl & 1]);
+                const bf16x8 b = __builtin_bit_cast(bf16x8, fb[st & 1]), bl = __builtin_bit_cast(bf16x8, fbl[st & 1]);
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[tt], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bl, acc[tt], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b, acc[tt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             // band pixel 16*s + k: same image row for all 16 k when W >= 16; for W == 8 two rows (k >= 8 -> next row),
@@ -230,12 +265,16 @@ static int wg3_launch(Wg3Args& g, int tiles, int nslices, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<W, TH, NW, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if constexpr (X3 != 0) { if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<W, TH, NW, X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     static const int xcd = getenv("AB_WG_XCD") ? atoi(getenv("AB_WG_XCD")) : 0;
     g.xcd_map = xcd;
-    wgrad3x3_kernel<W, TH, NW, X3><<<dim3(tiles, nslices), 64 * NW, lds, st>>>(g);
+    static const int pin = getenv("AB_WG3_PIN") ? atoi(getenv("AB_WG3_PIN")) : 1;      // 9.08 -> 9.02 ms per step over two alternating pairs (round 5)
+    bool launched = false;
+    if constexpr (X3 != 0) { if (pin) { wgrad3x3_kernel<W, TH, NW, X3, true><<<dim3(tiles, nslices), 64 * NW, lds, st>>>(g); launched = true; } }
+    if (!launched) wgrad3x3_kernel<W, TH, NW, X3><<<dim3(tiles, nslices), 64 * NW, lds, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

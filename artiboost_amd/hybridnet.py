@@ -377,6 +377,12 @@ class HybridNet:
 
     # ------------------------------------------------------------------ convolutions in the configured precision
     def _conv_fwd(self, x, name, stride, pad, **kw):
+        if kw.get("want_stats") and not self.training:
+            # eval mode reads the running statistics: no partial sums are needed, and a forward WITHOUT statistics stays on the kernels whose
+            # eval-fold form is bit-identical to conv + ab_bn_apply_x3 (conv3x3r.hip takes the training launches of layer 1 only)
+            kw = dict(kw, want_stats=False)
+            fn = K.conv2d_fwd_x3 if self.x3 else K.conv2d_fwd
+            return fn(x, self.w(name), stride, pad, **kw), None
         if self.x3:
             return K.conv2d_fwd_x3(x, self.w(name), stride, pad, **kw)
         return K.conv2d_fwd(x, self.w(name), stride, pad, **kw)
