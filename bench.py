@@ -125,7 +125,8 @@ def hbm_rooflines(args, loader, static, model):
     out["softargmax"] = {"bound": "hbm", "achieved": round(3 * per / (tf + tb) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(3 * per / (tf + tb) / 8e12, 4), "traffic": None, "ms_fwd": round(tf * 1e3, 3), "ms_bwd": round(tb * 1e3, 3),
                          "kernel": "sam_stage1/2 (logits read once) + sam_bwd (logits read once, dlogits written once; depth pitch 32: the kernels "
-                                   "move 32/28 of the algorithmic bytes)"}
+                                   "move 32/28 of the algorithmic bytes).  The standalone two-stage forward is timed here; in the bf16x3 step its first "
+                                   "stage rides in the final layer's GEMM epilogue (gemm_rw_kernel<4, true>) and only sam_stage2 is launched"}
     return out
 
 
@@ -415,7 +416,7 @@ def pmc_traffic(args):
         return None
 
 
-PMC_FILE = {"bf16": "round1_pmc_hbm_traffic.json", "bf16x3": "round4_c_pmc_hbm_traffic.json", "f32": "none"}
+PMC_FILE = {"bf16": "round1_pmc_hbm_traffic.json", "bf16x3": "round5_b_pmc_hbm_traffic.json", "f32": "none"}
 GFLOP_FWD_PER_SAMPLE = {224: 8.191, 256: 10.698}            # forward only (BASELINE configs[1])
 
 
@@ -877,8 +878,8 @@ def main():
                     "frac": round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4), "traffic": pmc_traffic(args),
                     "traffic_unit": f"HBM bytes per step over the conv-stack launches (PMC passes of this precision: profiles/{PMC_FILE[args.dtype]}; "
                                     "algorithmic bytes of the stack in the same file)",
-                    "kernel": "implicit-GEMM conv stack: conv3x3_kernel / conv_gemm2_kernel / conv_gemm_kernel (fwd, dgrad) + "
-                              "wgrad3x3_kernel / wgrad_gemm2_kernel / wgrad_reduce (weight grad)",
+                    "kernel": "implicit-GEMM conv stack: conv3x3_kernel / conv3x3r_kernel / conv2x2_kernel / conv_gemm2_kernel / gemm_rw_kernel / "
+                              "stem_halo_x3_kernel (fwd, dgrad) + wgrad3x3_kernel / wgrad_gemm2_kernel / wgrad_reduce (weight grad)",
                     "conv_ms_per_step": round(conv_ms, 3), "conv_launches_per_step": nlaunch,
                     "conv_ms_source": ("graph replay: wall-clock stamps (ab_wall_stamp) captured around every conv-stack call, the leading stamp "
                                        "launch of each bracket (= the difference of back-to-back stamps) removed" if boundary_us is not None else "eager HIP events"),
