@@ -461,6 +461,9 @@ class MixedLoader:
         self.n_synth = self.B - self.n_real
         assert self.synth is None or self.n_synth == 0 or self.synth.batch_size == self.n_synth, \
             "construct the ArtiBoostLoader with batch_size == MixedLoader.n_synth_for(...)"
+        if self.synth is not None and self.n_synth and getattr(self.real, "image_plane", "f32") != getattr(self.synth, "image_plane", "f32"):
+            raise ValueError("both halves of a mixed batch write ONE image tensor: build RealBatcher and ArtiBoostLoader with the same compute_dtype "
+                             f"(real: {getattr(self.real, 'image_plane', 'f32')}, synthetic: {getattr(self.synth, 'image_plane', 'f32')})")
 
     @staticmethod
     def n_synth_for(batch_size, real_len, synth_len):

@@ -99,3 +99,32 @@ def test_pooled_inflate_equals_serial():
         ref = np.empty(it.raw_bytes, np.uint8)
         P.inflate_into(d, it, ref)
         np.testing.assert_array_equal(o, ref)
+
+
+def test_filter_type_above_four_and_empty_idat_chunks():
+    """Advisor finding (round 4): a scanline whose filter byte is above 4 is refused on the host (Pillow's ZipDecode raises there; the device
+    kernel's output for it would be undefined), and a legal zero-length IDAT chunk does not break the ctypes inflate path."""
+    w, h = 9, 12
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)
+    rng = np.random.default_rng(7)
+    lines = rng.integers(0, 256, (h, 1 + 3 * w), dtype=np.uint8)
+    lines[:, 0] = rng.integers(0, 5, h)                                   # legal filter types
+    good = P.SIGNATURE + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", zlib.compress(lines.tobytes())) + _chunk(b"IEND", b"")
+    info = P.parse(good)
+    raw = np.empty(info.raw_bytes, np.uint8)
+    P.inflate_into(good, info, raw)                                       # a good stream passes
+    np.testing.assert_array_equal(raw.reshape(h, -1), lines)
+    # (i) scanline 5's filter byte set to 7
+    bad_lines = lines.copy()
+    bad_lines[5, 0] = 7
+    bad = P.SIGNATURE + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", zlib.compress(bad_lines.tobytes())) + _chunk(b"IEND", b"")
+    with pytest.raises(P.PngUnsupported):
+        P.inflate_into(bad, P.parse(bad), np.empty(info.raw_bytes, np.uint8))
+    # (ii) the good stream cut into IDAT chunks with empty ones in between
+    z = zlib.compress(lines.tobytes())
+    cut = len(z) // 2
+    multi = (P.SIGNATURE + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", b"") + _chunk(b"IDAT", z[:cut]) + _chunk(b"IDAT", b"") +
+             _chunk(b"IDAT", z[cut:]) + _chunk(b"IDAT", b"") + _chunk(b"IEND", b""))
+    out = np.empty(info.raw_bytes, np.uint8)
+    P.inflate_into(multi, P.parse(multi), out)
+    np.testing.assert_array_equal(out, raw)
