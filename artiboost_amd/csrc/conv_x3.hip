@@ -36,6 +36,12 @@ int conv2x2_tfwd_run(const void* x_hi, const void* x_lo, const void* wt_hi, cons
                      float* stats, hipStream_t st, const float* ep_scale = nullptr, const float* ep_shift = nullptr, int ep_relu = 0,
                      void* out_hi = nullptr, void* out_lo = nullptr);
 int conv2x2_s2fwd_ok(int N, int H, int W, int C, int Cn);
+int convp_s2fwd_rows(int N, int H, int W, int C, int Cn);           // convp.hip
+int convp_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* out, int N, int H, int W, int C, int Cn,
+                    float* stats, hipStream_t st);
+int convp_s2dgrad_ok(int N, int H, int W, int Cn, int K);
+int convp_s2dgrad_run(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, const void* dy2_hi, const void* dy2_lo,
+                      const void* wt2_hi, const void* wt2_lo, float* dx, int N, int H, int W, int Cn, int K, hipStream_t st);
 int conv2x2_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* out, int N, int H, int W, int C, int Cn,
                       float* stats, hipStream_t st);
 struct GemmRwSam { float* part; int C, D, H, W; };              // gemm_rw.hip
@@ -79,6 +85,7 @@ extern "C" int ab_conv2d_x3_stat_rows(int N, int H, int W, int Cin, int Cout, in
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     if (x3_is_c3(kh, kw, stride, pad)) { int t = conv3x3_x3_tiles(N, H, W, Cin, Cout); if (t) return t; }
     if (kh == 4 && kw == 4 && stride == 2 && pad == 1) { const int r = conv2x2_s2fwd_ok(N, H, W, Cin, Cout); if (r) return r; }      // conv2x2.hip: one row per tile
+    if (kh == 3 && kw == 3 && stride == 2 && pad == 1) { const int r = convp_s2fwd_rows(N, H, W, Cin, Cout); if (r) return r; }      // convp.hip: one row per tile
     return conv_gemm2_x3_mtiles(N * Ho * Wo, Cout, kh * kw * (Cin / 32), 0);
 }
 
@@ -99,6 +106,12 @@ static int fwd_x3_impl(const void* x_hi, const void* x_lo, const void* w_hi, con
     if (kh == 4 && kw == 4 && stride == 2 && pad == 1 && !bias && !relu && !ep_scale && y && conv2x2_s2fwd_ok(N, H, W, Cin, Cout)) {
         // the data gradient of ConvTranspose2d(4x4, s2, p1): four 2x2-tap convolutions over the parity sub-grids (conv2x2.hip)
         int rc = conv2x2_s2fwd_run(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, stats, as_stream(stream));
+        if (rc != AB_ESHAPE) return rc;
+    }
+    if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && !bias && !relu && !ep_scale && y && stats && convp_s2fwd_rows(N, H, W, Cin, Cout)) {
+        // a stage's first convolution, training forward (with BatchNorm partials; the eval-mode forms stay on conv_gemm2.hip, whose folded
+        // epilogue is bit-identical to its own plain launch + ab_bn_apply_x3): the nine taps over four parity sub-grid patches (convp.hip)
+        int rc = convp_s2fwd_run(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, stats, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
     ConvGemmArgs g = {};
@@ -198,6 +211,11 @@ static int dgrad_x3_impl(const void* dy_hi, const void* dy_lo, const void* wt_hi
     if (x3_is_tconv(kh, kw, stride, pad) && !addend && !dy2_hi && (dx || out_hi) && conv2x2_tfwd_rows(N, H, W, Cin, Cout)) {
         // ConvTranspose2d(4x4, s2, p1) forward: the four output-parity classes as 2x2-tap convolutions on a resident patch (conv2x2.hip)
         int rc = conv2x2_tfwd_run(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cin, Cout, stats, as_stream(stream), ep_scale, ep_shift, ep_relu, out_hi, out_lo);
+        if (rc != AB_ESHAPE) return rc;
+    }
+    if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && !addend && !stats && !ep_scale && dx && convp_s2dgrad_ok(N, H, W, Cin, Cout)) {
+        // data gradient of a stage's first convolution (+ its downsample branch): four output-parity classes over one dy patch (convp.hip)
+        int rc = convp_s2dgrad_run(dy_hi, dy_lo, wt_hi, wt_lo, dy2_hi, dy2_lo, wt2_hi, wt2_lo, dx, N, H, W, Cin, Cout, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
     ConvGemmArgs g = {};

@@ -594,6 +594,48 @@ def test_conv_transpose_4x4s2_patch_kernel_32x32(Ci, Co, hin, nb):
     np.testing.assert_allclose(st2.double().sum(0).cpu()[:, 1].numpy(), (dd * dd).sum(0).numpy(), rtol=1e-4)
 
 
+# ---- round 5: the stride-2 3x3 convolutions of the stage entries on resident patches (convp.hip)
+@pytest.mark.parametrize("Ci,Co,hin,nb", [(64, 128, 64, 2), (128, 256, 32, 3), (256, 512, 16, 4), (160, 64, 32, 1), (32, 192, 16, 2), (128, 64, 96, 1), (192, 128, 16, 6)])
+def test_stride2_3x3_patch_kernels(Ci, Co, hin, nb):
+    """layerN.0.conv1 (3x3, s2, p1) forward with BatchNorm partials -- nine taps over the four parity sub-grid patches -- and its data gradient
+    merged with the 1x1 / s2 downsample branch's (four output-parity classes of 1 / 2 / 2 / 4 taps, the downsample as a second unit of class
+    (even, even)), both against float64 and against the tap-by-tap kernel they replace."""
+    import os, subprocess, sys
+    from artiboost_amd import kernels as K
+    g = torch.Generator().manual_seed(Ci * 3 + Co + hin)
+    x = torch.randn(nb, Ci, hin, hin, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (Ci * 9)) ** 0.5
+    wd = torch.randn(Co, Ci, 1, 1, generator=g) * (2.0 / Ci) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), stride=2, padding=1)
+    ws = K.split(w.permute(0, 2, 3, 1).contiguous().cuda())                      # OHWI
+    y, part = K.conv2d_fwd_x3(nhwc(x).cuda(), ws, 2, 1, want_stats=True)
+    close(nchw(y.cpu()), ref)
+    ho = hin // 2
+    if Ci >= 128:                                                                # (two 32-channel chunks at least; 64 input channels stay on the
+        assert part.shape[0] == (nb * (ho // 16) ** 2 if ho % 16 == 0 else nb // 2)     #  tap-by-tap kernel, which is as fast there) the patch kernel's rows
+    yy = y.double().cpu().reshape(-1, Co)
+    st = part.double().sum(0).cpu()
+    np.testing.assert_allclose(st[:, 0].numpy(), yy.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(yy.abs().sum(0).max()))
+    np.testing.assert_allclose(st[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)
+    y0 = K.conv2d_fwd_x3(nhwc(x).cuda(), ws, 2, 1)                                # no statistics asked: the tap-by-tap kernel
+    np.testing.assert_allclose(y.cpu().numpy(), y0.cpu().numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+    # data gradients: conv1 alone, and conv1 + downsample in one launch
+    dy = torch.randn(nb, Co, ho, ho, generator=g)
+    dyd = torch.randn(nb, Co, ho, ho, generator=g)
+    xr = x.double().clone().requires_grad_(True)
+    F.conv2d(xr, w.double(), stride=2, padding=1).backward(dy.double())
+    ref1 = xr.grad.clone()
+    xr.grad = None
+    (F.conv2d(xr, w.double(), stride=2, padding=1) * dy.double()).sum().add((F.conv2d(xr, wd.double(), stride=2) * dyd.double()).sum()).backward()
+    ref2 = xr.grad
+    wt = K.split(w.permute(1, 2, 3, 0).contiguous().cuda())                      # IHWO
+    wdt = K.split(wd.permute(1, 2, 3, 0).contiguous().cuda())
+    dx1 = K.conv2d_dgrad_x3(nhwc(dy).cuda(), wt, (hin, hin), 2, 1)
+    close(nchw(dx1.cpu()), ref1)
+    dx2 = K.conv2d_dgrad_x3_pair(nhwc(dy).cuda(), wt, nhwc(dyd).cuda(), wdt, (hin, hin), 1)
+    close(nchw(dx2.cpu()), ref2)
+
+
 @pytest.mark.parametrize("nhw", [(2, 64, 64), (3, 128, 96), (2, 256, 256)])
 def test_stem_on_the_integer_image_plane(nhw):
     """Round 5 (review item 4): the loaders can write the padded image as ONE bf16 plane of the odd integers n = 2 v - 255 (AB_DT_U8N); the
