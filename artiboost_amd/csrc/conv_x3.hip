@@ -40,8 +40,10 @@ int convp_s2fwd_rows(int N, int H, int W, int C, int Cn);           // convp.hip
 int convp_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* out, int N, int H, int W, int C, int Cn,
                     float* stats, hipStream_t st);
 int convp_s2dgrad_ok(int N, int H, int W, int Cn, int K);
+int convp_s2dgrad_bn_rows(int N, int H, int W, int Cn, int K);
 int convp_s2dgrad_run(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, const void* dy2_hi, const void* dy2_lo,
-                      const void* wt2_hi, const void* wt2_lo, float* dx, int N, int H, int W, int Cn, int K, hipStream_t st);
+                      const void* wt2_hi, const void* wt2_lo, float* dx, int N, int H, int W, int Cn, int K, hipStream_t st,
+                      const float* bn_y = nullptr, const void* bn_out = nullptr, const float* bnp = nullptr, float* bn_part = nullptr);
 int conv2x2_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* out, int N, int H, int W, int C, int Cn,
                       float* stats, hipStream_t st);
 struct GemmRwSam { float* part; int C, D, H, W; };              // gemm_rw.hip
@@ -289,6 +291,23 @@ extern "C" int ab_conv2d_dgrad_x3_pair(const void* dy_hi, const void* dy_lo, con
     if (kh > 3 || kw > 3 || (H & 1) || (W & 1) || (H + 2 * pad - kh) / 2 + 1 != H / 2 || (W + 2 * pad - kw) / 2 + 1 != W / 2) return AB_ESHAPE;
     return dgrad_x3_impl(dy_hi, dy_lo, wt_hi, wt_lo, dx, N, H, W, Cin, Cout, kh, kw, 2, pad, addend, nullptr, stream, dy2_hi, dy2_lo,
                          wt2_hi, wt2_lo);
+}
+
+// ab_conv2d_dgrad_x3_pair whose result arrives at relu(bn(bn_y) [+ residual]) -- the last block of the stage below (resnet.py:85-101, 178-192
+// backwards): dz receives the MASKED gradient, bn_part [rows][Cin][2] the per-tile (sum dz, sum dz * xhat) that ab_bn_bwd_x3 takes as `part`.
+// rows = ab_conv2d_dgrad_x3_pair_bn_rows(...); 0: shape not handled (use ab_conv2d_dgrad_x3_pair + the full ab_bn_bwd_x3).
+extern "C" int ab_conv2d_dgrad_x3_pair_bn_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int pad) {
+    if (kh != 3 || kw != 3 || pad != 1 || getenv("AB_X3_BNFUSE_OFF")) return 0;
+    return convp_s2dgrad_bn_rows(N, H, W, Cin, Cout);
+}
+extern "C" int ab_conv2d_dgrad_x3_pair_bn(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, const void* dy2_hi,
+                                          const void* dy2_lo, const void* wt2_hi, const void* wt2_lo, float* dz, int N, int H, int W,
+                                          int Cin, int Cout, int kh, int kw, int pad, const float* bn_y, const void* bn_out_hi,
+                                          const float* bnp, float* bn_part, void* stream) {
+    if (!dy_hi || !dy_lo || !wt_hi || !wt_lo || !dy2_hi || !dy2_lo || !wt2_hi || !wt2_lo || !dz || !bn_y || !bnp || !bn_part) return AB_EINVAL;
+    if (!ab_conv2d_dgrad_x3_pair_bn_rows(N, H, W, Cin, Cout, kh, kw, pad)) return AB_ESHAPE;
+    return convp_s2dgrad_run(dy_hi, dy_lo, wt_hi, wt_lo, dy2_hi, dy2_lo, wt2_hi, wt2_lo, dz, N, H, W, Cin, Cout, as_stream(stream), bn_y,
+                             bn_out_hi, bnp, bn_part);
 }
 
 // Data gradient whose result is the gradient arriving at  relu(bn(bn_y) [+ residual])  (resnet.py:85-101 backwards): dx receives

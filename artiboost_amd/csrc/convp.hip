@@ -37,6 +37,9 @@ struct CPArgs {
     int Ho, Wo, out_stride;           // output pixel = base * out_stride + (cls_oy, cls_ox)
     int nclass, tiles_y, tiles_x;     // output classes in the grid; tiles of the base grid per image (G8: 1 x 1)
     int nunit[4]; int cls_oy[4], cls_ox[4];
+    // optional (data gradient): the result arrives at relu(bn(bn_y) [+ residual]) -- Out receives the MASKED gradient (mask: hi plane bn_out of the stored
+    // activation, or recomputed from bn_y) and bn_part [rows][Cn][2] the tile's (sum dz, sum dz * xhat): conv3x3.hip's X3 = 2 epilogue
+    const float* bn_y; const void* bn_out; const float* bnp; float* bn_part;
 };
 
 typedef const __attribute__((address_space(4))) int* cp_cint;
@@ -320,17 +323,42 @@ __global__ __launch_bounds__(512) void convp_kernel(CPArgs g) {
     static_assert(NT % CPRF == 0, "a thread keeps one channel group over all its rows");
     const int coy = g.cls_oy[cls], cox = g.cls_ox[cls];
     float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool bnr = MODE == 1 && g.bn_y != nullptr;
+    float e_sc[4] = {}, e_sh[4] = {}, e_mean[4] = {}, e_istd[4] = {};
+    if (bnr) {           // (a thread keeps one channel group: NT % CPRF == 0)
+        const int col = n0 + (tid % CPRF) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { e_sc[k] = g.bnp[col + k]; e_sh[k] = g.bnp[g.Cn + col + k]; e_mean[k] = g.bnp[2 * g.Cn + col + k]; e_istd[k] = g.bnp[3 * g.Cn + col + k]; }
+    }
+    const bf16_t* __restrict__ BnM = (const bf16_t*)g.bn_out;
     for (int id = tid; id < BM * CPRF; id += NT) {
         const int row = id / CPRF, c4 = id - row * CPRF;
         const int il = row / (TW * TH), rr = row - il * (TW * TH);
         const int yy = (by + rr / TW) * g.out_stride + coy, xx = (bx + rr % TW) * g.out_stride + cox, col = n0 + c4 * 4;
-        const float4 v = *(const float4*)(smem + row * SPF + c4 * 16);
-        *(float4*)(g.Out + ((((long)(img + il) * g.Ho + yy) * g.Wo + xx) * g.Cn + col)) = v;
-        fs[0] += v.x; fq[0] += v.x * v.x; fs[1] += v.y; fq[1] += v.y * v.y;
-        fs[2] += v.z; fq[2] += v.z * v.z; fs[3] += v.w; fq[3] += v.w * v.w;
+        const float4 v4 = *(const float4*)(smem + row * SPF + c4 * 16);
+        const long o = (((long)(img + il) * g.Ho + yy) * g.Wo + xx) * g.Cn + col;
+        if (bnr) {
+            const float4 y4 = *(const float4*)(g.bn_y + o);
+            const uint2 m2 = BnM ? *(const uint2*)(BnM + o) : make_uint2(0u, 0u);
+            float v[4] = {v4.x, v4.y, v4.z, v4.w};
+            const float y[4] = {y4.x, y4.y, y4.z, y4.w};
+            const float m[4] = {__uint_as_float(m2.x << 16), __uint_as_float(m2.x & 0xffff0000u), __uint_as_float(m2.y << 16), __uint_as_float(m2.y & 0xffff0000u)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool dead = BnM ? !(m[k] > 0.f) : !(y[k] * e_sc[k] + e_sh[k] > 0.f);
+                v[k] = dead ? 0.f : v[k];
+                fs[k] += v[k]; fq[k] += v[k] * ((y[k] - e_mean[k]) * e_istd[k]);
+            }
+            *(float4*)(g.Out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            continue;
+        }
+        *(float4*)(g.Out + o) = v4;
+        fs[0] += v4.x; fq[0] += v4.x * v4.x; fs[1] += v4.y; fq[1] += v4.y * v4.y;
+        fs[2] += v4.z; fq[2] += v4.z * v4.z; fs[3] += v4.w; fq[3] += v4.w * v4.w;
     }
     __syncthreads();
-    if (g.stats) {
+    float* part_out = bnr ? g.bn_part : g.stats;
+    if (part_out) {
         float* sp = (float*)smem;                          // [NT / CPRF][BN][2], over the consumed staging tile
         const int rg = tid / CPRF, cb = (tid % CPRF) * 4;
 #pragma unroll
@@ -339,8 +367,8 @@ __global__ __launch_bounds__(512) void convp_kernel(CPArgs g) {
         for (int c = tid; c < BN; c += NT) {
             float s2 = 0.f, q2 = 0.f;
             for (int r = 0; r < NT / CPRF; ++r) { s2 += sp[(r * BN + c) * 2]; q2 += sp[(r * BN + c) * 2 + 1]; }
-            g.stats[((long)row_id * g.Cn + n0 + c) * 2] = s2;
-            g.stats[((long)row_id * g.Cn + n0 + c) * 2 + 1] = q2;
+            part_out[((long)row_id * g.Cn + n0 + c) * 2] = s2;
+            part_out[((long)row_id * g.Cn + n0 + c) * 2 + 1] = q2;
         }
     }
 }
@@ -415,9 +443,16 @@ int convp_s2dgrad_ok(int N, int H, int W, int Cn, int K) {
     if (cp_off() || K % 32 || K < 64 || Cn % 64 || (H & 1) || (W & 1)) return 0;
     return cp_rows(N, H / 2, W / 2);
 }
+// rows of bn_part a launch with the BatchNorm-backward epilogue writes (one per base tile and parity class); 0: not taken
+int convp_s2dgrad_bn_rows(int N, int H, int W, int Cn, int K) {
+    static const int off = getenv("AB_CP_BN_OFF") ? atoi(getenv("AB_CP_BN_OFF")) : 0;
+    return off ? 0 : 4 * convp_s2dgrad_ok(N, H, W, Cn, K);
+}
 int convp_s2dgrad_run(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, const void* dy2_hi, const void* dy2_lo,
-                      const void* wt2_hi, const void* wt2_lo, float* dx, int N, int H, int W, int Cn, int K, hipStream_t st) {
+                      const void* wt2_hi, const void* wt2_lo, float* dx, int N, int H, int W, int Cn, int K, hipStream_t st,
+                      const float* bn_y, const void* bn_out, const float* bnp, float* bn_part) {
     if (!convp_s2dgrad_ok(N, H, W, Cn, K)) return AB_ESHAPE;
+    if (bn_y && (!bnp || !bn_part)) return AB_EINVAL;
     const long delta = (const char*)wt_lo - (const char*)wt_hi, delta2 = dy2_hi ? (const char*)wt2_lo - (const char*)wt2_hi : 0;
     if (delta < 0 || delta >= (1L << 31) || delta2 < 0 || delta2 >= (1L << 31)) return AB_EINVAL;
     CPArgs g = {};
@@ -425,6 +460,7 @@ int convp_s2dgrad_run(const void* dy_hi, const void* dy_lo, const void* wt_hi, c
     g.X[1] = dy2_hi ? dy2_hi : dy_hi; g.Xlo[1] = dy2_hi ? dy2_lo : dy_lo;
     g.Wt[1] = dy2_hi ? wt2_hi : wt_hi; g.wlo_delta[1] = dy2_hi ? (unsigned)delta2 : (unsigned)delta; g.ktot[1] = dy2_hi ? K : 9 * K;
     g.Out = dx; g.stats = nullptr;
+    g.bn_y = bn_y; g.bn_out = bn_out; g.bnp = bnp; g.bn_part = bn_part;
     g.N = N; g.Hi = H / 2; g.Wi = W / 2; g.C = K; g.Cn = Cn;
     g.in_stride = 1; g.Ho = H; g.Wo = W; g.out_stride = 2; g.nclass = 4;
     const bool g8 = g.Hi == 8;

@@ -740,6 +740,7 @@ class HybridNet:
     sam_bias = os.environ.get("AB_SAM_BIAS", "1") != "0"          # bf16x3: final-layer bias gradient out of the soft-argmax backward
     fuse_ds_bn = os.environ.get("AB_FUSE_DS_BN", "1") != "0"      # bf16x3: the downsample BatchNorm inside bn2's apply pass
     pair_dgrad = os.environ.get("AB_PAIR_DGRAD", "1") != "0"      # bf16x3: conv1 + downsample data gradients of a block in one launch
+    pair_dgrad_bn = os.environ.get("AB_PAIR_DGRAD_BN", "1") != "0"      # ... with the BatchNorm-backward reduction of the stage below in its epilogue
 
     # AB_WGRAD_BATCH=1: the fixed-order slab reductions of a backward stage's weight gradients run as ONE launch at the end
     # of the stage instead of one per layer right behind its slab kernel.  Bit-identical, 38 graph nodes fewer -- and 2 %
@@ -885,12 +886,14 @@ class HybridNet:
                                gv(pre + ".downsample.1.bias"), relu=False, frozen=fz)
                 self._wgrad_side(self._conv_wgrad, x, dyd, 1, 1, stride, 0, out=gv(pre + ".downsample.0.weight"))
                 if self.x3 and stride == 2 and self.pair_dgrad:      # both branches in one launch (the 1x1 as a tap of the 3x3/s2)
+                    # ... and the BatchNorm-backward mask + reduction of the stage below in its epilogue (convp.hip)
                     dout = K.conv2d_dgrad_x3_pair(dy1, self.tr[pre + ".conv1.weight"], dyd, self.tr[pre + ".downsample.0.weight"],
-                                                  (x.shape[-3], x.shape[-2]), 1)
+                                                  (x.shape[-3], x.shape[-2]), 1, bn=bn_below if self.pair_dgrad_bn else None)
+                    dout, dout_part = dout if isinstance(dout, tuple) else (dout, None)
                 else:
                     dx = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[-3], x.shape[-2]), stride, 1)
                     dout = self._conv_dgrad(dyd, pre + ".downsample.0.weight", (x.shape[-3], x.shape[-2]), stride, 0, addend=dx)
-                dout_part = None
+                    dout_part = None
             elif bn_below is not None:
                 dout, dout_part = self._conv_dgrad(dy1, pre + ".conv1.weight", (x.shape[-3], x.shape[-2]), stride, 1,
                                                    addend=dz, bn=bn_below)

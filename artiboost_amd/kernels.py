@@ -598,9 +598,12 @@ def conv2d_dgrad_x3(dy, wt_split, in_hw, stride, pad, addend=None, want_stats=Fa
     return (dx, None) if bn is not None else dx
 
 
-def conv2d_dgrad_x3_pair(dy, wt_split, dy2, wt2_split, in_hw, pad, addend=None):
+def conv2d_dgrad_x3_pair(dy, wt_split, dy2, wt2_split, in_hw, pad, addend=None, bn=None):
     """dx = dgrad(dy, wt; k x k / stride 2) + dgrad(dy2, wt2; 1x1 / stride 2 / pad 0) [+ addend] in one launch: the conv1 and
-    downsample branches of a down-sampling block (anakin/models/resnet.py:85-101 backwards)."""
+    downsample branches of a down-sampling block (anakin/models/resnet.py:85-101 backwards).
+
+    bn=(bn_y, bn_out_or_None, bnp) (no addend): dx is the gradient arriving at relu(bn(bn_y) [+ residual]), the output of the stage below.
+    Returns (dx, part) as conv2d_dgrad_x3(bn=...) does: masked dx + the BatchNorm-backward partial rows where the kernel can, else (dx, None)."""
     dh, dl = _planes(dy)
     eh, el = _planes(dy2)
     N, Ho, Wo, Cout = dh.shape
@@ -608,11 +611,29 @@ def conv2d_dgrad_x3_pair(dy, wt_split, dy2, wt2_split, in_hw, pad, addend=None):
     assert tuple(eh.shape) == tuple(dh.shape) and tuple(wt2_split.shape[1:]) == (Cin, 1, 1, Cout)
     H, W = in_hw
     dx = torch.empty((N, H, W, Cin), dtype=torch.float32, device=dh.device)
-    L.check(L.lib().ab_conv2d_dgrad_x3_pair(L.ptr(dh), L.ptr(dl), L.ptr(wt_split[0]), L.ptr(wt_split[1]), L.ptr(eh), L.ptr(el),
-                                            L.ptr(wt2_split[0]), L.ptr(wt2_split[1]), L.ptr(dx), L.i(N), L.i(H), L.i(W), L.i(Cin),
-                                            L.i(Cout), L.i(kh), L.i(kw), L.i(pad), L.ptr(addend), L.stream()),
+    lib = L.lib()
+    if bn is not None and addend is None:
+        bn_y, bn_out, bnp = bn
+        rows = lib.ab_conv2d_dgrad_x3_pair_bn_rows(L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.i(kh), L.i(kw), L.i(pad))
+        mask = None
+        if bn_out is not None:
+            sp = bn_out if bn_out.dtype == torch.bfloat16 else getattr(bn_out, "_ab_split", None)
+            if sp is None:
+                rows = 0                   # the mask is read from the hi plane of the stored activation
+            else:
+                mask = sp[0]
+        if rows > 0:
+            part = torch.empty((rows, Cin, 2), dtype=torch.float32, device=dh.device)
+            L.check(lib.ab_conv2d_dgrad_x3_pair_bn(L.ptr(dh), L.ptr(dl), L.ptr(wt_split[0]), L.ptr(wt_split[1]), L.ptr(eh), L.ptr(el),
+                                                   L.ptr(wt2_split[0]), L.ptr(wt2_split[1]), L.ptr(dx), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                                   L.i(Cout), L.i(kh), L.i(kw), L.i(pad), L.ptr(bn_y), L.ptr(mask), L.ptr(bnp), L.ptr(part),
+                                                   L.stream()), "ab_conv2d_dgrad_x3_pair_bn")
+            return dx, part
+    L.check(lib.ab_conv2d_dgrad_x3_pair(L.ptr(dh), L.ptr(dl), L.ptr(wt_split[0]), L.ptr(wt_split[1]), L.ptr(eh), L.ptr(el),
+                                        L.ptr(wt2_split[0]), L.ptr(wt2_split[1]), L.ptr(dx), L.i(N), L.i(H), L.i(W), L.i(Cin),
+                                        L.i(Cout), L.i(kh), L.i(kw), L.i(pad), L.ptr(addend), L.stream()),
             "ab_conv2d_dgrad_x3_pair")
-    return dx
+    return (dx, None) if bn is not None else dx
 
 
 def conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=None, accumulate=False, defer=None):

@@ -183,6 +183,14 @@ int ab_conv2d_dgrad_x3(const void* dy_hi, const void* dy_lo, const void* wt_hi, 
 int ab_conv2d_dgrad_x3_pair(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, const void* dy2_hi,
                             const void* dy2_lo, const void* wt2_hi, const void* wt2_lo, float* dx, int N, int H, int W, int Cin,
                             int Cout, int kh, int kw, int pad, const float* addend, void* stream);
+/* ab_conv2d_dgrad_x3_pair whose result arrives at relu(bn(bn_y) [+ residual]) -- the output of the stage below (anakin/models/resnet.py:85-101,
+ * 178-192 backwards): dz = the MASKED gradient, bn_part[rows][Cin][2] = per-tile (sum dz, sum dz*xhat) for ab_bn_bwd_x3(part, rows); mask as
+ * in ab_conv2d_dgrad_x3_bn.  rows = ab_conv2d_dgrad_x3_pair_bn_rows(...); 0 = not handled (ab_conv2d_dgrad_x3_pair + the full ab_bn_bwd_x3). */
+int ab_conv2d_dgrad_x3_pair_bn_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int pad);
+int ab_conv2d_dgrad_x3_pair_bn(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, const void* dy2_hi,
+                               const void* dy2_lo, const void* wt2_hi, const void* wt2_lo, float* dz, int N, int H, int W, int Cin,
+                               int Cout, int kh, int kw, int pad, const float* bn_y, const void* bn_out_hi, const float* bnp,
+                               float* bn_part, void* stream);
 /* Data gradient of a 3x3/s1 conv whose result arrives at relu(bn(bn_y) [+ residual]) (BasicBlock, anakin/models/resnet.py:85-101,
  * backwards): dz = the MASKED gradient (mask: sign of bn_out_hi, the hi bf16 plane of the stored activation, or recomputed from
  * bn_y and bnp when bn_out_hi is NULL), bn_part[rows][Cin][2] = per-tile (sum dz, sum dz*xhat) for ab_bn_bwd_x3(part, rows).
@@ -529,6 +537,7 @@ int ab_mano_lbs(const float* pose, const float* betas, const float* v_template, 
  * @check ab_conv2d_fwd_x3_affine: bf16: x_hi x_lo w_hi w_lo out_hi out_lo; x_hi x_lo >= N*H*W*Cin; w_hi w_lo >= Cout*kh*kw*Cin; scale shift >= Cout; out_f32 out_hi out_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout
  * @check ab_conv2d_dgrad_x3: bf16: dy_hi dy_lo wt_hi wt_lo; dy_hi dy_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; wt_hi wt_lo >= Cin*kh*kw*Cout; dx addend >= N*H*W*Cin
  * @check ab_conv2d_dgrad_x3_pair: bf16: dy_hi dy_lo wt_hi wt_lo dy2_hi dy2_lo wt2_hi wt2_lo; dy_hi dy_lo dy2_hi dy2_lo >= N*(H/2)*(W/2)*Cout; wt_hi wt_lo >= Cin*kh*kw*Cout; wt2_hi wt2_lo >= Cin*Cout; dx addend >= N*H*W*Cin
+ * @check ab_conv2d_dgrad_x3_pair_bn: bf16: dy_hi dy_lo wt_hi wt_lo dy2_hi dy2_lo wt2_hi wt2_lo bn_out_hi; dy_hi dy_lo dy2_hi dy2_lo >= N*(H/2)*(W/2)*Cout; wt_hi wt_lo >= Cin*kh*kw*Cout; wt2_hi wt2_lo >= Cin*Cout; dz bn_y bn_out_hi >= N*H*W*Cin; bnp >= 4*Cin; bn_part >= ab_conv2d_dgrad_x3_pair_bn_rows(N,H,W,Cin,Cout,kh,kw,pad)*Cin*2
  * @check ab_conv2d_dgrad_x3_bn: bf16: dy_hi dy_lo wt_hi wt_lo bn_out_hi; dy_hi dy_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; wt_hi wt_lo >= Cin*kh*kw*Cout; dz addend bn_y bn_out_hi >= N*H*W*Cin; bnp >= 4*Cin; bn_part >= ab_conv2d_dgrad_x3_bn_rows(N,H,W,Cin,Cout,kh,kw,stride,pad)*Cin*2
  * @check ab_conv2d_wgrad_x3: bf16: x_hi x_lo dy_hi dy_lo; x_hi x_lo >= N*H*W*Cin; dy_hi dy_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; dw >= Cout*kh*kw*Cin; bytes workspace >= ab_conv2d_wgrad_x3_workspace(N,H,W,Cin,Cout,kh,kw,stride,pad)
  * @check ab_conv2d_stem_fwd_x3: bf16: xpad_hi xpad_lo w_hi w_lo; xpad_hi xpad_lo >= N*(H+6)*(W+8)*4; w_hi w_lo >= Cout*7*8*4; y >= N*(H/2)*(W/2)*Cout; stats >= ab_conv2d_stem_x3_stat_rows(N,H,W)*Cout*2

@@ -634,6 +634,34 @@ def test_stride2_3x3_patch_kernels(Ci, Co, hin, nb):
     close(nchw(dx1.cpu()), ref1)
     dx2 = K.conv2d_dgrad_x3_pair(nhwc(dy).cuda(), wt, nhwc(dyd).cuda(), wdt, (hin, hin), 1)
     close(nchw(dx2.cpu()), ref2)
+    # ... arriving at relu(bn(y) + residual) of the stage below: masked gradient + that BatchNorm's backward partial rows from the epilogue
+    ybn = torch.randn((nb, hin, hin, Ci), generator=g) * 2 + 0.3
+    gamma, beta = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    bnp = K.bn_finalize(K.col_stats(ybn.cuda()), nb * hin * hin, gamma.cuda(), beta.cuda(), torch.zeros(Ci).cuda(), torch.ones(Ci).cuda())
+    for with_res in (True, False):
+        res = torch.randn((nb, hin, hin, Ci), generator=g).cuda() if with_res else None
+        out = K.bn_apply_x3(ybn.cuda(), bnp, res=res, relu=True, want_f32=True)
+        dz, part = K.conv2d_dgrad_x3_pair(nhwc(dy).cuda(), wt, nhwc(dyd).cuda(), wdt, (hin, hin), 1, bn=(ybn.cuda(), out if with_res else None, bnp))
+        mask = (out.cpu() > 0).double()
+        ref_dz = nhwc(ref2) * mask
+        if Ci % 64 or (ho % 16 and (ho != 8 or nb % 2)):
+            assert part is None                                                   # not the patch kernel's shape: raw gradient, no rows
+            close(dz.cpu(), nhwc(ref2))
+            continue
+        assert part.shape[0] == 4 * (nb * (ho // 16) ** 2 if ho % 16 == 0 else nb // 2)
+        close(dz.cpu(), ref_dz)
+        xhat = (ybn.double() - bnp[2].double().cpu()) * bnp[3].double().cpu()
+        sums = part.double().sum(0).cpu()
+        scale = float(ref_dz.abs().sum((0, 1, 2)).max())
+        np.testing.assert_allclose(sums[:, 0].numpy(), ref_dz.sum((0, 1, 2)).numpy(), rtol=1e-4, atol=3e-5 * scale)
+        np.testing.assert_allclose(sums[:, 1].numpy(), (ref_dz * xhat).sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-4 * scale)
+        # the BatchNorm backward built on the rows == the one that runs its own reduction pass over the raw gradient
+        dg1, db1, dg2, db2 = (torch.zeros(Ci).cuda() for _ in range(4))
+        dy1 = K.bn_bwd_x3(dz, None, ybn.cuda(), bnp, dg1, db1, part=part, premasked=True)
+        dy2 = K.bn_bwd_x3(dx2.clone(), out if with_res else None, ybn.cuda(), bnp, dg2, db2, relu=True if with_res else "recompute")
+        close((dy1[0].float() + dy1[1].float()).cpu(), (dy2[0].float() + dy2[1].float()).double().cpu(), tol=2e-5)
+        np.testing.assert_allclose(dg1.cpu().numpy(), dg2.cpu().numpy(), rtol=2e-4, atol=1e-4 * float(dg2.abs().max()))
+        np.testing.assert_allclose(db1.cpu().numpy(), db2.cpu().numpy(), rtol=2e-4, atol=1e-4 * float(db2.abs().max()))
 
 
 @pytest.mark.parametrize("nhw", [(2, 64, 64), (3, 128, 96), (2, 256, 256)])
