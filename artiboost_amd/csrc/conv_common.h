@@ -33,6 +33,9 @@ struct ConvGemmArgs {
     // conv_gemm2 X3 only, eval-mode forwards: per-channel affine of the BatchNorm that follows -- out = relu?(acc * ep_scale[c] + bias[c])
     // (`bias` carries the shift) -- and, when out_hi != NULL, the result leaves as (hi, lo) bf16 planes instead of fp32 `Out`
     const float* ep_scale; void* out_hi; void* out_lo;
+    // conv_gemm2 X3 only, data gradients arriving at relu(bn(bn_y)) (no residual: the mask is recomputed from bn_y): Out receives the MASKED
+    // gradient and bn_part [M tiles][Cn][2] the tile's (sum dz, sum dz * xhat) -- conv3x3.hip's X3 = 2 epilogue on the generic kernel
+    const float* bn_y; const float* bnp; float* bn_part;
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -283,6 +283,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
             }
         }
         __syncthreads();
+        float bfs[4] = {0.f, 0.f, 0.f, 0.f}, bfq[4] = {0.f, 0.f, 0.f, 0.f};
+        float e_sc[4] = {}, e_sh[4] = {}, e_mean[4] = {}, e_istd[4] = {};
+        if (g.bn_y) {
+            const int ccol = n0 + (tid % (BN / 4)) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { e_sc[k] = g.bnp[ccol + k]; e_sh[k] = g.bnp[g.Cn + ccol + k]; e_mean[k] = g.bnp[2 * g.Cn + ccol + k]; e_istd[k] = g.bnp[3 * g.Cn + ccol + k]; }
+        }
         {
             constexpr int CPRF = BN / 4;
             const bool vec_ok = (g.Cn & 3) == 0;
@@ -298,6 +305,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
                     l.x = pack_bf16x2(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
                     l.y = pack_bf16x2(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
                     *(uint2*)((bf16_t*)g.out_hi + o) = h; *(uint2*)((bf16_t*)g.out_lo + o) = l;
+                } else if (g.bn_y) {     // (host: Cn % 4 == 0, BN divides Cn, no addend -- a thread keeps its four channels: NT % CPRF == 0)
+                    const float4 y4 = *(const float4*)(g.bn_y + o);
+                    float vv[4] = {v.x, v.y, v.z, v.w};
+                    const float yy[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const bool dead = !(yy[k] * e_sc[k] + e_sh[k] > 0.f);
+                        vv[k] = dead ? 0.f : vv[k];
+                        bfs[k] += vv[k]; bfq[k] += vv[k] * ((yy[k] - e_mean[k]) * e_istd[k]);
+                    }
+                    *(float4*)(OutF + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                 } else if (vec_ok) {
                     if (AddF) { const float4 a = *(const float4*)(AddF + o); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
                     *(float4*)(OutF + o) = v;
@@ -308,6 +326,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm2_kernel(ConvGemmArgs g
             }
         }
         __syncthreads();
+        if (g.bn_y) {
+            constexpr int CPRF = BN / 4;
+            static_assert(NT % CPRF == 0 && (NT / CPRF) * BN * 8 <= RINGSZ, "BatchNorm-backward partials: one channel group per thread, scratch over the staging tile");
+            float* sp = (float*)smem;                          // [NT / CPRF][BN][2]
+            const int rg = tid / CPRF, cb = (tid % CPRF) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sp[(rg * BN + cb + k) * 2] = bfs[k]; sp[(rg * BN + cb + k) * 2 + 1] = bfq[k]; }
+            __syncthreads();
+            for (int c = tid; c < BN; c += NT) {
+                const int col = n0 + c;
+                if (col < g.Cn) {
+                    float s2 = 0.f, q2 = 0.f;
+                    for (int r = 0; r < NT / CPRF; ++r) { s2 += sp[(r * BN + c) * 2]; q2 += sp[(r * BN + c) * 2 + 1]; }
+                    g.bn_part[((long)stat_row * g.Cn + col) * 2] = s2;
+                    g.bn_part[((long)stat_row * g.Cn + col) * 2 + 1] = q2;
+                }
+            }
+            return;
+        }
         if (g.stats) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {

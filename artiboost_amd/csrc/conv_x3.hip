@@ -314,8 +314,16 @@ extern "C" int ab_conv2d_dgrad_x3_pair_bn(const void* dy_hi, const void* dy_lo, 
 // the MASKED gradient dz (mask from bn_out_hi, the hi plane of the stored activation, or recomputed from bn_y when NULL) and
 // bn_part [rows][Cin][2] the per-tile sums (sum dz, sum dz*xhat) that ab_bn_bwd_x3 takes as `part` -- the reduction pass
 // of that BatchNorm backward is gone.  rows = ab_conv2d_dgrad_x3_bn_rows(...); 0: shape not handled (use ab_conv2d_dgrad_x3).
+// (1x1 / s1 / p0 -- the final layer of the head, whose data gradient arrives at relu(bn(deconv output)): the generic kernel's epilogue, mask
+// recomputed from bn_y only, Cin a multiple of the 64- or 128-channel tile)
+static int x3_bn_1x1_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
+    static const int off = getenv("AB_X3_BN1X1_OFF") ? atoi(getenv("AB_X3_BN1X1_OFF")) : 0;
+    if (off || kh != 1 || kw != 1 || stride != 1 || pad != 0 || Cin % 64 || (Cin > 64 && Cin % 128) || Cout % 32) return 0;
+    return conv_gemm2_x3_mtiles(N * H * W, Cin, Cout / 32, 0);
+}
 extern "C" int ab_conv2d_dgrad_x3_bn_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad) {
-    if (!x3_is_c3(kh, kw, stride, pad) || getenv("AB_X3_BNFUSE_OFF")) return 0;
+    if (getenv("AB_X3_BNFUSE_OFF")) return 0;
+    if (!x3_is_c3(kh, kw, stride, pad)) return x3_bn_1x1_rows(N, H, W, Cin, Cout, kh, kw, stride, pad);
     return conv3x3_x3_tiles_bnr(N, H, W, Cout, Cin);
 }
 
@@ -324,6 +332,16 @@ extern "C" int ab_conv2d_dgrad_x3_bn(const void* dy_hi, const void* dy_lo, const
                                      const float* bn_y, const void* bn_out_hi, const float* bnp, float* bn_part, void* stream) {
     if (!dy_hi || !dy_lo || !wt_hi || !wt_lo || !dz || !bn_y || !bnp || !bn_part) return AB_EINVAL;
     if (!ab_conv2d_dgrad_x3_bn_rows(N, H, W, Cin, Cout, kh, kw, stride, pad)) return AB_ESHAPE;
+    if (!x3_is_c3(kh, kw, stride, pad)) {
+        if (addend || bn_out_hi) return AB_ESHAPE;          // the generic kernel's form: no residual below, mask from bn_y
+        ConvGemmArgs g = {};
+        g.A = dy_hi; g.A_lo = dy_lo; g.Bw = wt_hi; g.Bw_lo = wt_lo; g.Out = dz;
+        g.bn_y = bn_y; g.bnp = bnp; g.bn_part = bn_part;
+        g.N = N; g.Ha = H; g.Wa = W; g.Ca = Cout; g.Ho = H; g.Wo = W; g.Cn = Cin;
+        g.a_sh = g.a_sw = 1; g.cpt = Cout / 32; g.ktot = Cout;
+        g.P = H; g.Q = W; g.out_sh = g.out_sw = 1; g.M = N * H * W; g.ntaps = 1;
+        return conv_gemm2_x3_run(g, as_stream(stream));
+    }
     return conv3x3_x3_run(dy_hi, dy_lo, wt_hi, wt_lo, dz, N, H, W, Cout, Cin, 1, addend, nullptr, as_stream(stream), bn_y,
                           bn_out_hi, bnp, bn_part);
 }

@@ -837,9 +837,12 @@ class HybridNet:
             if self.x3:
                 dlogits = K.split(dlogits)        # one split serves the weight and the data gradient
         self._wgrad_side(self._conv_wgrad, e2, dlogits, 1, 1, 1, 0, out=gv(hp + ".final_layer.weight"))
-        de2 = self._conv_dgrad(dlogits, hp + ".final_layer.weight", (e2.shape[-3], e2.shape[-2]), 1, 0)
+        # (bf16x3: the ReLU mask + BatchNorm-backward reduction of the deconvolution below ride in the data gradient's epilogue)
+        de2, part2 = self._conv_dgrad(dlogits, hp + ".final_layer.weight", (e2.shape[-3], e2.shape[-2]), 1, 0,
+                                      bn=(S["d2"], None, S["bnpd2"])) if self.x3 else (
+            self._conv_dgrad(dlogits, hp + ".final_layer.weight", (e2.shape[-3], e2.shape[-2]), 1, 0), None)
         dd2 = self._bn_bwd(de2, e2, S["d2"], S["bnpd2"], gv(hp + ".deconv_layers.4.weight"),
-                       gv(hp + ".deconv_layers.4.bias"), relu="recompute")
+                       gv(hp + ".deconv_layers.4.bias"), relu="recompute", part=part2)
         self._wgrad_side(self._conv_wgrad, dd2, e1, 4, 4, 2, 1, out=gv(hp + ".deconv_layers.3.weight"))
         de1 = self._conv_fwd(dd2, hp + ".deconv_layers.3.weight", 2, 1)
         dd1 = self._bn_bwd(de1, e1, S["d1"], S["bnpd1"], gv(hp + ".deconv_layers.1.weight"),

@@ -194,7 +194,8 @@ int ab_conv2d_dgrad_x3_pair_bn(const void* dy_hi, const void* dy_lo, const void*
 /* Data gradient of a 3x3/s1 conv whose result arrives at relu(bn(bn_y) [+ residual]) (BasicBlock, anakin/models/resnet.py:85-101,
  * backwards): dz = the MASKED gradient (mask: sign of bn_out_hi, the hi bf16 plane of the stored activation, or recomputed from
  * bn_y and bnp when bn_out_hi is NULL), bn_part[rows][Cin][2] = per-tile (sum dz, sum dz*xhat) for ab_bn_bwd_x3(part, rows).
- * rows = ab_conv2d_dgrad_x3_bn_rows(...); 0 = shape not handled here (use ab_conv2d_dgrad_x3 + the full ab_bn_bwd_x3).        */
+ * rows = ab_conv2d_dgrad_x3_bn_rows(...); 0 = shape not handled here (use ab_conv2d_dgrad_x3 + the full ab_bn_bwd_x3).  Also taken: 1x1 / s1 / p0
+ * with addend = bn_out_hi = NULL (final_layer of the head, simplebaseline.py:173-175 backwards, arriving at relu(bn(deconv_layers.3 output))).  */
 int ab_conv2d_dgrad_x3_bn_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 int ab_conv2d_dgrad_x3_bn(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, float* dz, int N, int H,
                           int W, int Cin, int Cout, int kh, int kw, int stride, int pad, const float* addend,

@@ -249,6 +249,40 @@ def test_conv_dgrad_x3_bn_fused(case, mask_src):
     np.testing.assert_allclose(db1.cpu().numpy(), db2.cpu().numpy(), rtol=2e-4, atol=1e-4 * float(db2.abs().max()))
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 256, 704), (3, 16, 16, 64, 96), (1, 32, 32, 128, 64), (2, 24, 20, 256, 160)])
+def test_conv1x1_dgrad_x3_bn_fused(case):
+    """ab_conv2d_dgrad_x3_bn on a 1x1 convolution (the head's final layer, whose data gradient arrives at relu(bn(deconv output))): the masked
+    gradient and the BatchNorm-backward partial rows from the generic kernel's epilogue, against float64 and against the standalone passes."""
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    w = (torch.randn((Cout, Cin, 1, 1), generator=g) * (2.0 / Cin) ** 0.5).double()
+    dy = torch.randn((N, Cout, H, W), generator=g).double()
+    ref_dx = F.conv_transpose2d(dy, w)
+    ybn = torch.randn((N, H, W, Cin), generator=g) * 2 + 0.3
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    bnp = K.bn_finalize(K.col_stats(ybn.cuda()), N * H * W, gamma.cuda(), beta.cuda(), torch.zeros(Cin).cuda(), torch.ones(Cin).cuda())
+    out = K.bn_apply_x3(ybn.cuda(), bnp, relu=True, want_f32=True)
+    wt = K.split(w.float().permute(1, 2, 3, 0).contiguous().cuda())
+    dyd = nhwc(dy.float()).cuda()
+    dz, part = K.conv2d_dgrad_x3(dyd, wt, (H, W), 1, 0, bn=(ybn.cuda(), None, bnp))
+    assert part is not None and part.shape[1:] == (Cin, 2)
+    ref_dz = nhwc(ref_dx) * (out.cpu() > 0).double()
+    close(dz.cpu(), ref_dz)
+    xhat = (ybn.double() - bnp[2].double().cpu()) * bnp[3].double().cpu()
+    sums = part.double().sum(0).cpu()
+    scale = float(ref_dz.abs().sum((0, 1, 2)).max())
+    np.testing.assert_allclose(sums[:, 0].numpy(), ref_dz.sum((0, 1, 2)).numpy(), rtol=1e-4, atol=3e-5 * scale)
+    np.testing.assert_allclose(sums[:, 1].numpy(), (ref_dz * xhat).sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-4 * scale)
+    dg1, db1, dg2, db2 = (torch.zeros(Cin).cuda() for _ in range(4))
+    dy1 = K.bn_bwd_x3(dz, None, ybn.cuda(), bnp, dg1, db1, part=part, premasked=True)
+    raw = K.conv2d_dgrad_x3(dyd, wt, (H, W), 1, 0)
+    dy2 = K.bn_bwd_x3(raw, None, ybn.cuda(), bnp, dg2, db2, relu="recompute")
+    close((dy1[0].float() + dy1[1].float()).cpu(), (dy2[0].float() + dy2[1].float()).double().cpu(), tol=2e-5)
+    np.testing.assert_allclose(dg1.cpu().numpy(), dg2.cpu().numpy(), rtol=2e-4, atol=1e-4 * float(dg2.abs().max()))
+    np.testing.assert_allclose(db1.cpu().numpy(), db2.cpu().numpy(), rtol=2e-4, atol=1e-4 * float(db2.abs().max()))
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 64, 64), (2, 56, 40, 64, 64), (3, 32, 32, 64, 64)])
 def test_conv3x3_x3_256x64_tile(case, monkeypatch):
     """The two tiles of the 64-channel 3x3 layers: 8 x 16 pixels for the forward / plain data gradient (round 3: tools/ab_l1_tiles.py) and
