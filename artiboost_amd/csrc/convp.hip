@@ -61,20 +61,37 @@ struct CPProg {
     // forward (stride-2 input): the unit's parity sub-grid -- taps along an axis <=> the odd rows / columns, origin -1
     static constexpr int sy(int u) { return code(u) == 4 || code(u) == 2; }
     static constexpr int sx(int u) { return code(u) == 4 || code(u) == 3; }
-    // REM = chunks after this one (2 = two or more): a request reaching r chunks ahead is made iff r <= REM
+    // REM = chunks after this one (2 = two or more): a request reaching r chunks ahead is made iff r <= REM.  PL = patch lead in units (1 | 2).
     static constexpr bool b_made(int rem, int k) { return (k + 2) / steps() <= rem; }                 // the weights of step k + 2, at step k
-    static constexpr bool p_made(int rem, int u) { return (u + 2) / NU <= rem; }                      // the patch of unit u + 2, at unit u's first tap
-    // was a patch requested at step j of this chunk (j < 0: of the chunk before / the prologue)?
-    static constexpr bool p_at(bool first, int rem, int j) {
-        if (j < 0) return first ? j == -1 : (tap_of(j + steps()) == 0 && p_made(rem + 1 > 2 ? 2 : rem + 1, unit_of(j + steps())));
-        return tap_of(j) == 0 && p_made(rem, unit_of(j));
+    static constexpr bool p_made(int rem, int u, int PL) { return (u + PL) / NU <= rem; }             // the patch of unit u + PL, at unit u's first tap
+    // Requests in issue order are pairs (step, kind): kind 0 = the weights a step requests, kind 1 = the patch it requests after them.  The prologue
+    // stands for steps -3 .. -1: P(0) at (-3, 1), B(0) at (-2, 0), B(1) at (-1, 0), and with PL = 2 P(1) at (-1, 1).
+    static constexpr bool made(bool first, int rem, int j, int kind, int PL) {
+        if (j < 0) {
+            if (first) return kind == 0 ? j >= -2 : (j == -3 || (j == -1 && PL == 2));
+            const int r1 = rem + 1 > 2 ? 2 : rem + 1, jl = j + steps();          // (steps() >= 2 for every two-step look-back that matters: see below)
+            if (jl < 0) return kind == 0 ? true : tap_of(jl + steps()) == 0;        // two chunks back (one-step programs): everything was requested
+            return kind == 0 ? b_made(r1, jl) : (tap_of(jl) == 0 && p_made(r1, unit_of(jl), PL));
+        }
+        return kind == 0 ? b_made(rem, j) : (tap_of(j) == 0 && p_made(rem, unit_of(j), PL));
     }
-    static constexpr int allowed(bool first, int rem, int k, int LB, int LP) {
-        const bool b1 = (k + 1) / steps() <= rem;                                                    // the weights of step k + 1 (requested at k - 1)
-        // the patch a first tap needs was requested at the first tap of unit u - 2: ntap(u - 2) + ntap(u - 1) steps ago
-        const int u = unit_of(k), ago = ntap((u + NU - 2 % NU + NU) % NU) + ntap((u + NU - 1) % NU);
-        const bool keep2 = tap_of(k) != 0 || (ago >= 3 && !(first && k < 3));
-        return (b1 ? LB : 0) + (p_at(first, rem, k - 1) ? LP : 0) + ((keep2 && p_at(first, rem, k - 2)) ? LP : 0);
+    static constexpr int allowed(bool first, int rem, int k, int LB, int LP, int PL) {
+        // what step k needs: its weights, requested at (k - 2, 0); at a unit's first tap also its patch, requested at the first tap of unit u - PL
+        int ns = k - 2, nk = 0;
+        if (tap_of(k) == 0) {
+            const int u = unit_of(k);
+            int ago = 0;
+            for (int i = 1; i <= PL; ++i) ago += ntap(((u - i) % NU + NU) % NU);
+            int ps = k - ago;
+            if (first && u < PL) ps = u == 0 ? -3 : -1;                              // the prologue's patches
+            if (ps > ns || (ps == ns)) { ns = ps; nk = 1; }
+        }
+        // everything issued after (ns, nk) up to step k - 1 may still be in flight
+        int n = 0;
+        for (int j = ns; j <= k - 1; ++j)
+            for (int kind = 0; kind < 2; ++kind)
+                if ((j > ns || kind > nk) && made(first, rem, j, kind, PL)) n += kind ? LP : LB;
+        return n;
     }
 };
 
@@ -90,15 +107,18 @@ __device__ __forceinline__ void cp_wait_dyn(int n) {      // n is a constant aft
 
 // G8 = false: base tile 16 x 16 of one image (BM = 256), patch 17 rows x 18 (17 used), swizzle key (px >> 1) & 7.
 // G8 = true : base grid 8 x 8, a tile is NI = BM / 64 consecutive images with a 9 x 9 patch each (conv2x2.hip's layout).
-template <int BM, int BN, bool G8, int MODE>
-__global__ __launch_bounds__(512) void convp_kernel(CPArgs g) {
-    constexpr int TW = G8 ? 8 : 16, TH = G8 ? 8 : 16, NI = BM / (TW * TH), PW = G8 ? 9 : 18, PH = G8 ? 9 : 17, IPIX = PH * PW, NPIX = NI * IPIX;
-    static_assert(BM == NI * TW * TH && (G8 || NI == 1), "tile = whole base tiles");
+// NPB = 3 patch buffers + ring of four weight stages: one workgroup per CU.  NPB = 2 (+ ring of three, BM = 128): 72 KB of LDS and <= 128 VGPRs, TWO
+// workgroups per CU -- one's epilogue (fp32 store, BatchNorm operands of the fused reduction) runs under the other's K loop.
+template <int BM, int BN, bool G8, int MODE, int NPB>
+__global__ __launch_bounds__(512, NPB == 2 ? 4 : 2) void convp_kernel(CPArgs g) {
+    constexpr int TW = G8 ? 8 : 16, TH = G8 ? 8 : BM / 16, NI = G8 ? BM / 64 : 1, PW = G8 ? 9 : 18, PH = TH + 1, IPIX = PH * PW, NPIX = NI * IPIX;
+    constexpr int PL = NPB - 1, NRING = NPB == 2 ? 3 : 4;
+    static_assert(BM == NI * TW * TH && (BM == 128 || BM == 256), "tile = whole base tiles");
     constexpr int WM = 4, WN = 2, NW = 8, NT = 512;
     constexpr int PI = (NPIX + 7) / 8, LP = (PI + NW - 1) / NW, PATCH_BYTES = LP * NW * 1024;
     constexpr int IB = BN / 8, LB = IB / NW, BBYTES = BN * 128;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int PATCH0 = 4 * BBYTES;                        // LDS: [weight ring x4][patch 0][patch 1][patch 2]
+    constexpr int PATCH0 = NRING * BBYTES;                    // LDS: [weight ring][patch 0][patch 1]([patch 2])
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WN, wave_n = wave % WN;
@@ -220,28 +240,28 @@ __global__ __launch_bounds__(512) void convp_kernel(CPArgs g) {
             issue_patch(src, -sy, -sx, sy, sx, chunk, pbuf);
         };
         auto weights_of = [&](int k, int chunk, int slot) { issue_b(chunk, u_koff[k], MODE == 1 && P::unit_of(k) == 1, slot); };
-        // prologue: P(0), B(0) | "step -1": B(1), P(1)
+        // prologue: P(0), B(0), B(1) [, P(1)]
         patch_of(0, 0, 0);
         weights_of(0, 0, 0);
         weights_of(1 % S, 1 / S, 1);
-        patch_of(1 % NU, 1 / NU, 1);
-        int st = 0, pb_e = 0, pb_i = 2;              // ring stage of the executing step, patch buffer of its unit, buffer of the next patch request
+        if (PL == 2) patch_of(1 % NU, 1 / NU, 1);
+        int st = 0, pb_e = 0, pb_i = PL == 2 ? 2 : 1;      // ring stage of the executing step, patch buffer of its unit, buffer of the next patch request
         auto body = [&](auto first_c, auto rem_c, int chunk) {
             constexpr bool FIRST = decltype(first_c)::value; constexpr int REM = decltype(rem_c)::value;
 #pragma unroll
             for (int k = 0; k < S; ++k) {
                 // (k is a constant after unrolling; hipcc folds the constexpr lookups below)
                 const int u = P::unit_of(k), t = P::tap_of(k);
-                cp_wait_dyn(P::allowed(FIRST, REM, k, LB, LP));
+                cp_wait_dyn(P::allowed(FIRST, REM, k, LB, LP, PL));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // WAR on the ring stage / patch buffer restaged below
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (P::b_made(REM, k) && !(CP_ABL & 4)) {
-                    weights_of((k + 2) % S, chunk + (k + 2) / S, (st + 2) & 3);
+                    weights_of((k + 2) % S, chunk + (k + 2) / S, (st + 2) % NRING);
                 }
-                if (t == 0 && P::p_made(REM, u) && !(CP_ABL & 2)) {
-                    patch_of((u + 2) % NU, chunk + (u + 2) / NU, pb_i);
-                    pb_i = pb_i == 2 ? 0 : pb_i + 1;
+                if (t == 0 && P::p_made(REM, u, PL) && !(CP_ABL & 2)) {
+                    patch_of((u + PL) % NU, chunk + (u + PL) / NU, pb_i);
+                    pb_i = pb_i == NPB - 1 ? 0 : pb_i + 1;
                 }
                 const int dh = P::dh(u, t), dw = P::dw(u, t);
                 const unsigned aoff = pb_e * PATCH_BYTES + dh * PW * 128;
@@ -275,8 +295,8 @@ __global__ __launch_bounds__(512) void convp_kernel(CPArgs g) {
                             accx[ii][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl, ah, accx[ii][jj], 0, 0, 0);
                         }
                 }
-                st = (st + 1) & 3;
-                if (t + 1 == P::ntap(u)) pb_e = pb_e == 2 ? 0 : pb_e + 1;
+                st = st == NRING - 1 ? 0 : st + 1;
+                if (t + 1 == P::ntap(u)) pb_e = pb_e == NPB - 1 ? 0 : pb_e + 1;
             }
         };
         auto chunk_body = [&](auto first_c, int chunk) {           // nch >= 2 (host)
@@ -373,20 +393,20 @@ __global__ __launch_bounds__(512) void convp_kernel(CPArgs g) {
     }
 }
 
-template <int BM, int BN, bool G8, int MODE>
+template <int BM, int BN, bool G8, int MODE, int NPB = 3>
 static int cp_launch(CPArgs& g, hipStream_t st) {
-    constexpr int NI = BM / (G8 ? 64 : 256), NPIX = NI * (G8 ? 81 : 17 * 18), LP = ((NPIX + 7) / 8 + 7) / 8;
-    const size_t ring = (size_t)4 * BN * 128 + 3 * LP * 8 * 1024, stage = (size_t)BM * (BN * 4 + 16), part = (size_t)(512 / (BN / 4)) * BN * 8;
+    constexpr int NI = G8 ? BM / 64 : 1, NPIX = NI * (G8 ? 81 : (BM / 16 + 1) * 18), LP = ((NPIX + 7) / 8 + 7) / 8;
+    const size_t ring = (size_t)(NPB == 2 ? 3 : 4) * BN * 128 + NPB * LP * 8 * 1024, stage = (size_t)BM * (BN * 4 + 16), part = (size_t)(512 / (BN / 4)) * BN * 8;
     size_t lds = ring > stage ? ring : stage;
     if (part > lds) lds = part;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)convp_kernel<BM, BN, G8, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)convp_kernel<BM, BN, G8, MODE, NPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     const int blocks = (g.N / NI) * g.tiles_y * g.tiles_x * g.nclass * (g.Cn / BN);
-    convp_kernel<BM, BN, G8, MODE><<<blocks, 512, lds, st>>>(g);
+    convp_kernel<BM, BN, G8, MODE, NPB><<<blocks, 512, lds, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -439,9 +459,13 @@ int convp_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const 
 // Data gradient of that convolution, optionally with the 1x1 / stride 2 / pad 0 branch of the same input (resnet.py:59-101 backwards: conv1 and
 // downsample.0 of a stage's first block): dy planes [N, H/2, W/2, K], wt rows [Cn][3][3][K] ("IHWO"), dy2 / wt2 rows [Cn][K] or NULL,
 // dx fp32 [N, H, W, Cn] (every element written).
+// (AB_CP_HALF=1: 16 x 16 base grids and larger run 8 x 16 tiles with two patch buffers, two workgroups per CU -- meant to put one workgroup's
+// epilogue under the other's K loop; measured 9.124 vs 9.115 ms per step over two alternating pairs, i.e. nothing: off by default)
+static bool cp_half() { static const int on = getenv("AB_CP_HALF") ? atoi(getenv("AB_CP_HALF")) : 0; return on != 0; }
 int convp_s2dgrad_ok(int N, int H, int W, int Cn, int K) {
     if (cp_off() || K % 32 || K < 64 || Cn % 64 || (H & 1) || (W & 1)) return 0;
-    return cp_rows(N, H / 2, W / 2);
+    const int r = cp_rows(N, H / 2, W / 2);
+    return (r && H / 2 != 8 && cp_half()) ? 2 * r : r;
 }
 // rows of bn_part a launch with the BatchNorm-backward epilogue writes (one per base tile and parity class); 0: not taken
 int convp_s2dgrad_bn_rows(int N, int H, int W, int Cn, int K) {
@@ -463,8 +487,8 @@ int convp_s2dgrad_run(const void* dy_hi, const void* dy_lo, const void* wt_hi, c
     g.bn_y = bn_y; g.bn_out = bn_out; g.bnp = bnp; g.bn_part = bn_part;
     g.N = N; g.Hi = H / 2; g.Wi = W / 2; g.C = K; g.Cn = Cn;
     g.in_stride = 1; g.Ho = H; g.Wo = W; g.out_stride = 2; g.nclass = 4;
-    const bool g8 = g.Hi == 8;
-    g.tiles_y = g8 ? 1 : g.Hi / 16; g.tiles_x = g8 ? 1 : g.Wi / 16;
+    const bool g8 = g.Hi == 8, half = !g8 && cp_half();
+    g.tiles_y = g8 ? 1 : g.Hi / (half ? 8 : 16); g.tiles_x = g8 ? 1 : g.Wi / 16;
     // dx row 2p + a <- dy row (2p + a + 1 - kh) / 2: a = 0: kh = 1 (row p); a = 1: kh = 2 (row p, patch row 0), kh = 0 (row p + 1, patch row 1).
     // Class order in the grid: (1, 1) first -- its workgroups run four taps per chunk, the others two.
     const int order[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};
@@ -484,5 +508,6 @@ int convp_s2dgrad_run(const void* dy_hi, const void* dy_lo, const void* wt_hi, c
             g.nunit[c] = 2;
         }
     }
+    if (half) return cp_launch<128, 64, false, 1, 2>(g, st);
     return g8 ? cp_launch<128, 64, true, 1>(g, st) : cp_launch<256, 64, false, 1>(g, st);
 }

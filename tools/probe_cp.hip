@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
         for (int mode = 0; mode < 2; ++mode) {
             auto run = [&]() {
                 return mode == 0 ? convp_s2fwd_run(xh, xl, wh, wl, out, N, H, H, Ci, Co, stats, 0)
-                                 : convp_s2dgrad_run(yh, yl, wh, wl, y2h, y2l, w2h, w2l, dx, N, H, H, Ci, Co, 0);
+                                 : convp_s2dgrad_run(yh, yl, wh, wl, y2h, y2l, w2h, w2l, dx, N, H, H, Ci, Co, 0, nullptr, nullptr, nullptr, nullptr);
             };
             int rc = run();
             if (rc == AB_ESHAPE) { us[mode] = 0.f; continue; }        // shape left to the tap-by-tap kernel
