@@ -38,7 +38,8 @@ int conv2x2_tfwd_run(const void* x_hi, const void* x_lo, const void* wt_hi, cons
 int conv2x2_s2fwd_ok(int N, int H, int W, int C, int Cn);
 int convp_s2fwd_rows(int N, int H, int W, int C, int Cn);           // convp.hip
 int convp_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* out, int N, int H, int W, int C, int Cn,
-                    float* stats, hipStream_t st);
+                    float* stats, hipStream_t st, const float* ep_scale = nullptr, const float* ep_shift = nullptr, int ep_relu = 0,
+                    void* out_hi = nullptr, void* out_lo = nullptr);
 int convp_s2dgrad_ok(int N, int H, int W, int Cn, int K);
 int convp_s2dgrad_bn_rows(int N, int H, int W, int Cn, int K);
 int convp_s2dgrad_run(const void* dy_hi, const void* dy_lo, const void* wt_hi, const void* wt_lo, const void* dy2_hi, const void* dy2_lo,
@@ -110,10 +111,10 @@ static int fwd_x3_impl(const void* x_hi, const void* x_lo, const void* w_hi, con
         int rc = conv2x2_s2fwd_run(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, stats, as_stream(stream));
         if (rc != AB_ESHAPE) return rc;
     }
-    if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && !bias && !relu && !ep_scale && y && stats && convp_s2fwd_rows(N, H, W, Cin, Cout)) {
-        // a stage's first convolution, training forward (with BatchNorm partials; the eval-mode forms stay on conv_gemm2.hip, whose folded
-        // epilogue is bit-identical to its own plain launch + ab_bn_apply_x3): the nine taps over four parity sub-grid patches (convp.hip)
-        int rc = convp_s2fwd_run(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, stats, as_stream(stream));
+    if (kh == 3 && kw == 3 && stride == 2 && pad == 1 && (ep_scale ? (bias && !stats) : (!bias && !relu && y)) && convp_s2fwd_rows(N, H, W, Cin, Cout)) {
+        // a stage's first convolution: the nine taps over four parity sub-grid patches (convp.hip); training forward with BatchNorm partials, or
+        // eval mode with the BatchNorm that follows as the epilogue's affine (bit-identical to its own plain launch + ab_bn_apply_x3)
+        int rc = convp_s2fwd_run(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, stats, as_stream(stream), ep_scale, bias, relu, out_hi, out_lo);
         if (rc != AB_ESHAPE) return rc;
     }
     ConvGemmArgs g = {};

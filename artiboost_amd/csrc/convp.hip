@@ -40,6 +40,9 @@ struct CPArgs {
     // optional (data gradient): the result arrives at relu(bn(bn_y) [+ residual]) -- Out receives the MASKED gradient (mask: hi plane bn_out of the stored
     // activation, or recomputed from bn_y) and bn_part [rows][Cn][2] the tile's (sum dz, sum dz * xhat): conv3x3.hip's X3 = 2 epilogue
     const float* bn_y; const void* bn_out; const float* bnp; float* bn_part;
+    // optional (forward, eval mode): the BatchNorm (+ ReLU) that follows as a per-channel affine, out = relu?(acc * ep_scale[c] + ep_shift[c]) -- conv_gemm2.hip's
+    // expression, bit-identical to this kernel + ab_bn_apply_x3 -- written as fp32 `Out` or, when out_hi != NULL, as the (hi, lo) planes the next convolution reads
+    const float* ep_scale; const float* ep_shift; int ep_relu; void* out_hi; void* out_lo;
 };
 
 typedef const __attribute__((address_space(4))) int* cp_cint;
@@ -372,9 +375,21 @@ __global__ __launch_bounds__(512, NPB == 2 ? 4 : 2) void convp_kernel(CPArgs g) 
             *(float4*)(g.Out + o) = make_float4(v[0], v[1], v[2], v[3]);
             continue;
         }
-        *(float4*)(g.Out + o) = v4;
-        fs[0] += v4.x; fq[0] += v4.x * v4.x; fs[1] += v4.y; fq[1] += v4.y * v4.y;
-        fs[2] += v4.z; fq[2] += v4.z * v4.z; fs[3] += v4.w; fq[3] += v4.w * v4.w;
+        float4 v = v4;
+        if (MODE == 0 && g.ep_scale) {
+            const float4 sc = *(const float4*)(g.ep_scale + col), sh = *(const float4*)(g.ep_shift + col);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            if (g.ep_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
+        if (MODE == 0 && g.out_hi) {
+            uint2 h, l;
+            h.x = pack_bf16x2(v.x, v.y); h.y = pack_bf16x2(v.z, v.w);
+            l.x = pack_bf16x2(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
+            l.y = pack_bf16x2(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
+            *(uint2*)((bf16_t*)g.out_hi + o) = h; *(uint2*)((bf16_t*)g.out_lo + o) = l;
+        } else *(float4*)(g.Out + o) = v;
+        fs[0] += v.x; fq[0] += v.x * v.x; fs[1] += v.y; fq[1] += v.y * v.y;
+        fs[2] += v.z; fq[2] += v.z * v.z; fs[3] += v.w; fq[3] += v.w * v.w;
     }
     __syncthreads();
     float* part_out = bnr ? g.bn_part : g.stats;
@@ -427,7 +442,7 @@ int convp_s2fwd_rows(int N, int H, int W, int C, int Cn) {
     return cp_rows(N, H / 2, W / 2);
 }
 int convp_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* out, int N, int H, int W, int C, int Cn,
-                    float* stats, hipStream_t st) {
+                    float* stats, hipStream_t st, const float* ep_scale, const float* ep_shift, int ep_relu, void* out_hi, void* out_lo) {
     if (!convp_s2fwd_rows(N, H, W, C, Cn)) return AB_ESHAPE;
     const long delta = (const char*)w_lo - (const char*)w_hi;
     if (delta < 0 || delta >= (1L << 31)) return AB_EINVAL;
@@ -435,6 +450,7 @@ int convp_s2fwd_run(const void* x_hi, const void* x_lo, const void* w_hi, const 
     g.X[0] = x_hi; g.Xlo[0] = x_lo; g.Wt[0] = w_hi; g.wlo_delta[0] = (unsigned)delta; g.ktot[0] = 9 * C;
     g.X[1] = x_hi; g.Xlo[1] = x_lo; g.Wt[1] = w_hi; g.wlo_delta[1] = (unsigned)delta; g.ktot[1] = 9 * C;
     g.Out = out; g.stats = stats;
+    g.ep_scale = ep_scale; g.ep_shift = ep_shift; g.ep_relu = ep_relu; g.out_hi = out_hi; g.out_lo = out_lo;
     g.N = N; g.Hi = H; g.Wi = W; g.C = C; g.Cn = Cn;
     g.in_stride = 2; g.Ho = H / 2; g.Wo = W / 2; g.out_stride = 1; g.nclass = 1;
     const bool g8 = g.Ho == 8;

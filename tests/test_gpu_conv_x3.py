@@ -651,8 +651,26 @@ def test_stride2_3x3_patch_kernels(Ci, Co, hin, nb):
     st = part.double().sum(0).cpu()
     np.testing.assert_allclose(st[:, 0].numpy(), yy.sum(0).numpy(), rtol=1e-4, atol=1e-4 * float(yy.abs().sum(0).max()))
     np.testing.assert_allclose(st[:, 1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-4)
-    y0 = K.conv2d_fwd_x3(nhwc(x).cuda(), ws, 2, 1)                                # no statistics asked: the tap-by-tap kernel
-    np.testing.assert_allclose(y.cpu().numpy(), y0.cpu().numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+    y0 = K.conv2d_fwd_x3(nhwc(x).cuda(), ws, 2, 1)                                # no statistics asked: the same kernel, the same bits
+    assert torch.equal(y0, y)
+    code = ("import torch; from artiboost_amd import kernels as K; a = torch.load(r'%s'); "
+            "y = K.conv2d_fwd_x3(a['x'].cuda(), K.split(a['w'].cuda()), 2, 1); torch.save(y.cpu(), r'%s')")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:                                     # the tap-by-tap kernel it replaces (AB_CP_OFF=1 in a child process)
+        torch.save({"x": nhwc(x), "w": w.permute(0, 2, 3, 1).contiguous()}, td + "/in.pt")
+        r = subprocess.run([sys.executable, "-c", code % (td + "/in.pt", td + "/out.pt")], env=dict(os.environ, AB_CP_OFF="1"), capture_output=True,
+                           text=True, timeout=600, cwd=os.path.join(os.path.dirname(__file__), ".."))
+        assert r.returncode == 0, r.stderr[-2000:]
+        y1 = torch.load(td + "/out.pt")
+    np.testing.assert_allclose(y.cpu().numpy(), y1.numpy(), rtol=0, atol=2e-5 * float(ref.abs().max()))
+    # eval mode: the following BatchNorm (+ ReLU) as the epilogue's affine == this kernel + ab_bn_apply_x3, bit for bit
+    gam, bet = torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.3
+    bnp = K.bn_eval_params(gam.cuda(), bet.cuda(), (torch.randn(Co, generator=g) * 0.1).cuda(), (torch.rand(Co, generator=g) + 0.5).cuda())
+    fold = K.conv2d_fwd_x3_affine(nhwc(x).cuda(), ws, bnp, 2, 1, relu=True)
+    two = K.bn_apply_x3(y0, bnp, relu=True)
+    assert torch.equal(fold[0], two[0]) and torch.equal(fold[1], two[1])
+    f32 = K.conv2d_fwd_x3_affine(nhwc(x).cuda(), ws, bnp, 2, 1, relu=False, planes=False)
+    close(nchw(f32.cpu()), ref * bnp[0].double().cpu().view(1, -1, 1, 1) + bnp[1].double().cpu().view(1, -1, 1, 1))
     # data gradients: conv1 alone, and conv1 + downsample in one launch
     dy = torch.randn(nb, Co, ho, ho, generator=g)
     dyd = torch.randn(nb, Co, ho, ho, generator=g)

@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
         float us[2];
         for (int mode = 0; mode < 2; ++mode) {
             auto run = [&]() {
-                return mode == 0 ? convp_s2fwd_run(xh, xl, wh, wl, out, N, H, H, Ci, Co, stats, 0)
+                return mode == 0 ? convp_s2fwd_run(xh, xl, wh, wl, out, N, H, H, Ci, Co, stats, 0, nullptr, nullptr, 0, nullptr, nullptr)
                                  : convp_s2dgrad_run(yh, yl, wh, wl, y2h, y2l, w2h, w2l, dx, N, H, H, Ci, Co, 0, nullptr, nullptr, nullptr, nullptr);
             };
             int rc = run();
