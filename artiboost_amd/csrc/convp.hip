@@ -17,6 +17,10 @@
 #include "conv3x3.h"
 #include <cstddef>
 #include <type_traits>
+#ifndef CP_BLEAD
+#define CP_BLEAD 2     // weight requests run this many steps ahead (2: conv2x2.hip's distance; 3 fits the four-stage ring and measured the same:
+                       // tools/probe_cp.hip -DCP_BLEAD=3, forward 34.7 vs 34.9 us, data gradients 53.8 vs 52.8 us on layer 3)
+#endif
 #ifndef CP_ABL
 #define CP_ABL 0      // tools/probe_cp.hip: knock-outs (1 no MFMAs, 2 no patch requests in the loop, 4 no weight requests in the loop, 8 no fragment reads)
 #endif
@@ -65,35 +69,35 @@ struct CPProg {
     static constexpr int sy(int u) { return code(u) == 4 || code(u) == 2; }
     static constexpr int sx(int u) { return code(u) == 4 || code(u) == 3; }
     // REM = chunks after this one (2 = two or more): a request reaching r chunks ahead is made iff r <= REM.  PL = patch lead in units (1 | 2).
-    static constexpr bool b_made(int rem, int k) { return (k + 2) / steps() <= rem; }                 // the weights of step k + 2, at step k
+    static constexpr bool b_made(int rem, int k, int BL) { return (k + BL) / steps() <= rem; }        // the weights of step k + BL, at step k
     static constexpr bool p_made(int rem, int u, int PL) { return (u + PL) / NU <= rem; }             // the patch of unit u + PL, at unit u's first tap
     // Requests in issue order are pairs (step, kind): kind 0 = the weights a step requests, kind 1 = the patch it requests after them.  The prologue
-    // stands for steps -3 .. -1: P(0) at (-3, 1), B(0) at (-2, 0), B(1) at (-1, 0), and with PL = 2 P(1) at (-1, 1).
-    static constexpr bool made(bool first, int rem, int j, int kind, int PL) {
+    // stands for the steps before 0: P(0) at (-BL - 1, 1), B(i) at (i - BL, 0) for i < BL, and with PL = 2 P(1) at (-1, 1).  BL = weight lead in steps (2 | 3).
+    static constexpr bool made(bool first, int rem, int j, int kind, int PL, int BL) {
         if (j < 0) {
-            if (first) return kind == 0 ? j >= -2 : (j == -3 || (j == -1 && PL == 2));
+            if (first) return kind == 0 ? (j >= -BL && b_made(rem, j, BL)) : (j == -BL - 1 || (j == -1 && PL == 2));
             const int r1 = rem + 1 > 2 ? 2 : rem + 1, jl = j + steps();          // (steps() >= 2 for every two-step look-back that matters: see below)
             if (jl < 0) return kind == 0 ? true : tap_of(jl + steps()) == 0;        // two chunks back (one-step programs): everything was requested
-            return kind == 0 ? b_made(r1, jl) : (tap_of(jl) == 0 && p_made(r1, unit_of(jl), PL));
+            return kind == 0 ? b_made(r1, jl, BL) : (tap_of(jl) == 0 && p_made(r1, unit_of(jl), PL));
         }
-        return kind == 0 ? b_made(rem, j) : (tap_of(j) == 0 && p_made(rem, unit_of(j), PL));
+        return kind == 0 ? b_made(rem, j, BL) : (tap_of(j) == 0 && p_made(rem, unit_of(j), PL));
     }
-    static constexpr int allowed(bool first, int rem, int k, int LB, int LP, int PL) {
-        // what step k needs: its weights, requested at (k - 2, 0); at a unit's first tap also its patch, requested at the first tap of unit u - PL
-        int ns = k - 2, nk = 0;
+    static constexpr int allowed(bool first, int rem, int k, int LB, int LP, int PL, int BL) {
+        // what step k needs: its weights, requested at (k - BL, 0); at a unit's first tap also its patch, requested at the first tap of unit u - PL
+        int ns = k - BL, nk = 0;
         if (tap_of(k) == 0) {
             const int u = unit_of(k);
             int ago = 0;
             for (int i = 1; i <= PL; ++i) ago += ntap(((u - i) % NU + NU) % NU);
             int ps = k - ago;
-            if (first && u < PL) ps = u == 0 ? -3 : -1;                              // the prologue's patches
+            if (first && u < PL) ps = u == 0 ? -BL - 1 : -1;                         // the prologue's patches
             if (ps > ns || (ps == ns)) { ns = ps; nk = 1; }
         }
         // everything issued after (ns, nk) up to step k - 1 may still be in flight
         int n = 0;
         for (int j = ns; j <= k - 1; ++j)
             for (int kind = 0; kind < 2; ++kind)
-                if ((j > ns || kind > nk) && made(first, rem, j, kind, PL)) n += kind ? LP : LB;
+                if ((j > ns || kind > nk) && made(first, rem, j, kind, PL, BL)) n += kind ? LP : LB;
         return n;
     }
 };
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(512, NPB == 2 ? 4 : 2) void convp_kernel(CPArgs g) 
     auto run = [&](auto prog) {
         using P = decltype(prog);
         constexpr int NU = P::NU, S = P::steps();
+        constexpr int BL = (NRING == 4 && S >= 2 && CP_BLEAD == 3) ? 3 : 2;      // weights three steps ahead where the ring and the chunk allow
         // per unit: source (the second unit of the data gradient's class (0, 0) is the downsample branch), sub-grid parity and origin (forward
         // only) are properties of the program; the weight-row offsets of its taps come from the host's table
         int u_koff[S];
@@ -243,10 +248,10 @@ __global__ __launch_bounds__(512, NPB == 2 ? 4 : 2) void convp_kernel(CPArgs g) 
             issue_patch(src, -sy, -sx, sy, sx, chunk, pbuf);
         };
         auto weights_of = [&](int k, int chunk, int slot) { issue_b(chunk, u_koff[k], MODE == 1 && P::unit_of(k) == 1, slot); };
-        // prologue: P(0), B(0), B(1) [, P(1)]
+        // prologue: P(0), B(0) .. B(BL - 1) [, P(1)]
         patch_of(0, 0, 0);
-        weights_of(0, 0, 0);
-        weights_of(1 % S, 1 / S, 1);
+#pragma unroll
+        for (int i = 0; i < BL; ++i) if (i / S < nch) weights_of(i % S, i / S, i);
         if (PL == 2) patch_of(1 % NU, 1 / NU, 1);
         int st = 0, pb_e = 0, pb_i = PL == 2 ? 2 : 1;      // ring stage of the executing step, patch buffer of its unit, buffer of the next patch request
         auto body = [&](auto first_c, auto rem_c, int chunk) {
@@ -255,12 +260,12 @@ __global__ __launch_bounds__(512, NPB == 2 ? 4 : 2) void convp_kernel(CPArgs g) 
             for (int k = 0; k < S; ++k) {
                 // (k is a constant after unrolling; hipcc folds the constexpr lookups below)
                 const int u = P::unit_of(k), t = P::tap_of(k);
-                cp_wait_dyn(P::allowed(FIRST, REM, k, LB, LP, PL));
+                cp_wait_dyn(P::allowed(FIRST, REM, k, LB, LP, PL, BL));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // WAR on the ring stage / patch buffer restaged below
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (P::b_made(REM, k) && !(CP_ABL & 4)) {
-                    weights_of((k + 2) % S, chunk + (k + 2) / S, (st + 2) % NRING);
+                if (P::b_made(REM, k, BL) && !(CP_ABL & 4)) {
+                    weights_of((k + BL) % S, chunk + (k + BL) / S, (st + BL) % NRING);
                 }
                 if (t == 0 && P::p_made(REM, u, PL) && !(CP_ABL & 2)) {
                     patch_of((u + PL) % NU, chunk + (u + PL) / NU, pb_i);
