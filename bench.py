@@ -878,7 +878,7 @@ def main():
                     "frac": round(ach / MFMA_PEAK_TFLOPS[args.dtype], 4), "traffic": pmc_traffic(args),
                     "traffic_unit": f"HBM bytes per step over the conv-stack launches (PMC passes of this precision: profiles/{PMC_FILE[args.dtype]}; "
                                     "algorithmic bytes of the stack in the same file)",
-                    "kernel": "implicit-GEMM conv stack: conv3x3_kernel / conv3x3r_kernel / conv2x2_kernel / conv_gemm2_kernel / gemm_rw_kernel / "
+                    "kernel": "implicit-GEMM conv stack: conv3x3_kernel / conv3x3r_kernel / conv2x2_kernel / convp_kernel / conv_gemm2_kernel / gemm_rw_kernel / "
                               "stem_halo_x3_kernel (fwd, dgrad) + wgrad3x3_kernel / wgrad_gemm2_kernel / wgrad_reduce (weight grad)",
                     "conv_ms_per_step": round(conv_ms, 3), "conv_launches_per_step": nlaunch,
                     "conv_ms_source": ("graph replay: wall-clock stamps (ab_wall_stamp) captured around every conv-stack call, the leading stamp "

@@ -15,14 +15,16 @@ import csv
 import gzip
 import io
 import json
+import os
 import sys
 
-CONV = ("conv_gemm_kernel", "conv_gemm2_kernel", "conv3x3_kernel", "stem_halo_kernel", "stem_halo_x3_kernel", "wgrad_kernel", "wgrad3x3_kernel",
-        "wgrad_gemm2_kernel", "wgrad_reduce")
+CONV = ("conv_gemm_kernel", "conv_gemm2_kernel", "conv3x3_kernel", "conv3x3r_kernel", "conv2x2_kernel", "convp_kernel", "gemm_rw_kernel",
+        "stem_halo_kernel", "stem_halo_x3_kernel", "wgrad_kernel", "wgrad3x3_kernel", "wgrad_gemm2_kernel", "wgrad_reduce")
 BN = ("bn_apply_kernel", "bn_apply_x3_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "bn_bwd_apply_x3_kernel", "bn_finalize_kernel",
-      "bn_bwd_finalize_kernel", "pool_bwd_bn_reduce_kernel", "pool_bwd_bn_apply_x3_kernel", "col_stats_kernel", "col_stats_x3_kernel", "maxpool_fwd_kernel", "maxpool_bwd_kernel", "split_f32_kernel", "avgpool_fwd_kernel",
+      "bn_bwd_finalize_kernel", "bn_fin_apply_x3_kernel", "bn_fin_bwd_apply_x3_kernel", "maxpool_fwd_x3_kernel", "pool_win_bn_reduce_kernel",
+      "pool_bwd_bn_reduce_kernel", "pool_bwd_bn_apply_x3_kernel", "col_stats_kernel", "col_stats_x3_kernel", "maxpool_fwd_kernel", "maxpool_bwd_kernel", "split_f32_kernel", "avgpool_fwd_kernel",
       "avgpool_bwd_kernel")
-HEAD = ("sam_stage1", "sam_stage2", "sam_bwd", "pose_loss_kernel", "pose_loss_finalize", "colsum_finalize_kernel", "linear_nt_kernel",
+HEAD = ("sam_stage1", "sam_stage2", "sam_bwd", "sam_bias_finalize", "pose_loss_kernel", "pose_loss_finalize", "colsum_finalize_kernel", "linear_nt_kernel",
         "linear_wgrad_kernel")
 RENDER = ("raster_setup_kernel", "raster_shade_kernel", "gauss_blur_kernel", "jitter_stats_kernel", "warp_jitter_kernel", "zero_words_kernel",
           "mano_lbs_kernel")
@@ -92,17 +94,32 @@ def algorithmic(dtype, B=64, S=256):
 
 
 def main():
-    fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
-    dtype = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
-    cnt = {base(k): v[0] for k, v in fetch.items()}
-    marker = {"learn": cnt.get("pose_loss_kernel", 1), "render": cnt.get("raster_shade_kernel", 1), "optim": cnt.get("clip_adam_kernel", 1)}
-    rows = []
-    for k in fetch:
-        b = base(k)
-        steps = marker["render"] if b in RENDER else marker["optim"] if b in OPTIM else marker["learn"]
-        rd = 2.0 * fetch[k][1] * 1024 / steps
-        wr = write.get(k, [0, 0.0])[1] * 1024 / steps
-        rows.append((k, fetch[k][0] / steps, rd, wr))
+    if sys.argv[1] == "--from-csv":
+        # re-aggregate the per-kernel table of an earlier reduction (the family lists above grow with the kernels: a table written before a kernel
+        # was listed counted it in no family):  pmc_traffic.py --from-csv profiles/<tag>_pmc_hbm_traffic.csv <out-prefix> [dtype]
+        src, out = sys.argv[2], sys.argv[3]
+        dtype = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
+        rows = []
+        for line in open(src):
+            parts = next(csv.reader([line])) if line.startswith('"') else []
+            if len(parts) == 4:
+                try:
+                    rows.append((parts[0], float(parts[1]), float(parts[2]) * 1e6, float(parts[3]) * 1e6))
+                except ValueError:
+                    pass
+        marker = json.load(open(src[:-4] + ".json")).get("steps_in_run") if os.path.exists(src[:-4] + ".json") else None
+    else:
+        fetch, write, out = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+        dtype = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
+        cnt = {base(k): v[0] for k, v in fetch.items()}
+        marker = {"learn": cnt.get("pose_loss_kernel", 1), "render": cnt.get("raster_shade_kernel", 1), "optim": cnt.get("clip_adam_kernel", 1)}
+        rows = []
+        for k in fetch:
+            b = base(k)
+            steps = marker["render"] if b in RENDER else marker["optim"] if b in OPTIM else marker["learn"]
+            rd = 2.0 * fetch[k][1] * 1024 / steps
+            wr = write.get(k, [0, 0.0])[1] * 1024 / steps
+            rows.append((k, fetch[k][0] / steps, rd, wr))
     rows.sort(key=lambda r: -(r[2] + r[3]))
     alg = algorithmic(dtype)
     fam_rows = []
