@@ -62,8 +62,9 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 // (tile, slice) of a workgroup in a (tiles, slices) grid, renumbered so that each XCD (dispatch order mod 8) owns a contiguous
 // range of slices with all their tiles: the tiles of a slice stream the same operand rows, which then come out of that XCD's L2
 // once instead of crossing the fabric once per XCD that happens to host one of them.  Bijective for any grid size.
-// Measured on the weight-gradient kernels (AB_WG_XCD=1): 2 171 vs 2 169 us per step over all their launches -- they are not
-// fabric-bound; off by default.
+// Measured on the weight-gradient kernels (AB_WG_XCD=1): 2 171 vs 2 169 us per step over all their launches (round 2) and 8.975 vs 8.992 ms per
+// step (round 5) -- they are not fabric-bound -- but 2.3 GB per step less crosses the fabric (FETCH_SIZE of the conv stack 16.6 -> 14.2 GB:
+// wgrad3x3 3.27 -> 1.81 GB, wgrad_gemm2 1.88 -> 1.00 GB); on by default since round 5.
 __device__ __forceinline__ void xcd_slice_major(int on, int& tile, int& slice) {
     tile = blockIdx.x; slice = blockIdx.y;
     if (on) {

@@ -269,7 +269,7 @@ static int wg3_launch(Wg3Args& g, int tiles, int nslices, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    static const int xcd = getenv("AB_WG_XCD") ? atoi(getenv("AB_WG_XCD")) : 0;
+    static const int xcd = getenv("AB_WG_XCD") ? atoi(getenv("AB_WG_XCD")) : 1;
     g.xcd_map = xcd;
     static const int pin = getenv("AB_WG3_PIN") ? atoi(getenv("AB_WG3_PIN")) : 1;      // 9.08 -> 9.02 ms per step over two alternating pairs (round 5)
     bool launched = false;

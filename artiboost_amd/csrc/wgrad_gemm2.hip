@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64 * WI * WJ) void wgrad_gemm2_kernel(Wg2Args g) {
             }
 }
 
-static int wg2_xcd_map() { static const int v = getenv("AB_WG_XCD") ? atoi(getenv("AB_WG_XCD")) : 0; return v; }
+static int wg2_xcd_map() { static const int v = getenv("AB_WG_XCD") ? atoi(getenv("AB_WG_XCD")) : 1; return v; }
 
 static void wg2_pick(int M, int Cout, int Cin, int jtot, int* bi, int* bj, int* ns, int* rows) {
     *bi = (Cout % 128 == 0) ? 128 : 64;

@@ -416,7 +416,7 @@ def pmc_traffic(args):
         return None
 
 
-PMC_FILE = {"bf16": "round1_pmc_hbm_traffic.json", "bf16x3": "round5_c_pmc_hbm_traffic.json", "f32": "none"}
+PMC_FILE = {"bf16": "round1_pmc_hbm_traffic.json", "bf16x3": "round5_d_pmc_hbm_traffic.json", "f32": "none"}
 GFLOP_FWD_PER_SAMPLE = {224: 8.191, 256: 10.698}            # forward only (BASELINE configs[1])
 
 
