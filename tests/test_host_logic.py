@@ -412,3 +412,38 @@ def test_frozen_batchnorm_refuses_optimizers_that_would_move_its_buffers():
     assert isinstance(netutils.build_optimizer([p], OPTIMIZER="Adam", LR=1e-4), torch.optim.Adam)      # CPU parameter: torch's Adam, no decay
     owner.store.frozen_bn = False
     assert isinstance(netutils.build_optimizer([p], OPTIMIZER="SGD", LR=1e-4, WEIGHT_DECAY=1e-4), torch.optim.SGD)
+
+
+def test_traffic_table_counts_every_kernel_of_the_step():
+    """bench.py's `roofline.traffic` comes from a committed reduction of the PMC passes (tools/pmc_traffic.py) that sums per-kernel counters
+    into families BY KERNEL NAME: a kernel added to the step and not to those lists is counted nowhere (round 5: four convolution kernels
+    were missing and the conv stack read 14.2 GB instead of 16.6).  Every kernel of the committed per-kernel table that moves more than 2 MB
+    per step must belong to a family -- torch's own elementwise / copy kernels aside -- and the file's totals must be those of its table."""
+    import csv
+    import importlib.util
+    import json
+    import bench
+    root = os.path.join(os.path.dirname(__file__), "..")
+    spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(root, "tools", "pmc_traffic.py"))
+    P = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(P)
+    known = sum((m for _, m in P.FAMILIES), ())
+    name = bench.PMC_FILE["bf16x3"]
+    summ = json.load(open(os.path.join(root, "profiles", name)))
+    conv = total = 0.0
+    for line in open(os.path.join(root, "profiles", name[:-5] + ".csv")):
+        parts = next(csv.reader([line])) if line.startswith('"') else []
+        if len(parts) != 4:
+            continue
+        try:
+            mb = float(parts[2]) + float(parts[3])
+        except ValueError:
+            continue
+        b = P.base(parts[0])
+        if b in known:
+            total += mb
+            conv += mb if b in P.CONV else 0.0
+        else:
+            assert mb < 2.0 or b.startswith("at::") or b.startswith("__amd_rocclr"), f"{b}: {mb:.0f} MB per step in no family"
+    assert abs(conv * 1e6 - summ["conv_stack_bytes_per_step"]) < 1e-3 * summ["conv_stack_bytes_per_step"]
+    assert abs(total * 1e6 - summ["all_kernels_bytes_per_step"]) < 1e-3 * summ["all_kernels_bytes_per_step"]
