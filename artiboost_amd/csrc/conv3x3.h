@@ -20,6 +20,9 @@ struct Conv3Args {
     unsigned long long* dbg; // conv3x3v.hip: per-wave s_memtime stamps (ab_c3v_debug_buffer; NULL: off)
     const void* Wf;          // conv3x3v.hip: the weights in MFMA fragment order (c3v_pack_kernel), both planes
     int flip;                // 0: tap t reads input (t/3-1, t%3-1); 1 (data gradient): (1-t/3, 1-t%3).  Weight K offset = t*C.
+    // tools/probe_c3fold.hip only (C3_FOLD_PROBE): the input as the fp32 conv output `fold_y` of the layer below + its BatchNorm (scale | shift) in
+    // fold_bnp [2][C] -- the patch is built through registers as the planes of relu(fold_y * scale + shift) instead of being DMA'd from X / X_lo
+    const float* fold_y; const float* fold_bnp;
 };                           // (no per-tap tables: a dynamically indexed kernarg array becomes a VMEM load inside the K loop,
                              //  and the vmcnt wait for it would drain the in-flight LDS-DMA prefetch)
 

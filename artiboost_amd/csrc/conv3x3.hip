@@ -41,6 +41,12 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsig
 // epilogue applies them, adds the residual, applies the ReLU and writes the next convolution's operand planes directly -- with
 // the same expression order as bn_apply_x3_kernel (norm_pool.hip), i.e. bit-identical to conv + separate apply pass.  The fp32
 // conv output is never stored (no BatchNorm partials either).
+#ifndef C3_FOLD_PROBE
+#define C3_FOLD_PROBE 0
+#endif
+#if C3_FOLD_PROBE
+static const float* g_c3_fold_y = nullptr; static const float* g_c3_fold_bnp = nullptr;      // set by tools/probe_c3fold.hip around its launches
+#endif
 template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0>
 __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
     constexpr bool BNR = X3 == 2;
@@ -185,6 +191,68 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
         }
     };
 
+#if C3_FOLD_PROBE
+    // ---- review item 2 of round 4, as a probe: the BatchNorm apply of the layer below folded into this kernel's patch fill.  A task = one patch
+    // pixel x 8 channels: two 16-byte loads of the fp32 conv output, relu(y * scale + shift), split into (hi, lo) and two 16-byte LDS stores
+    // at the slots the DMA fill would have written.  Loads are asm (counted by the K loop's vmcnt like the DMA they replace).
+    constexpr int LG = (NPIX * 4 + NT - 1) / NT, NG = 2 * LG + 4;
+    const bool folding = X3 == 1 && g.fold_y != nullptr;
+    const float* f_src[LG]; bool f_in[LG]; unsigned f_hi[LG], f_lo[LG];
+    const int f_cg = lane & 3;
+#pragma unroll
+    for (int j = 0; j < LG; ++j) {
+        const int tk = (wave * LG + j) * 64 + lane, pp = tk >> 2;
+        const int py = pp / PW, px = pp - py * PW;
+        const int y = ty0 + py - 1, x = tx0 + px - 1;
+        f_in[j] = pp < NPIX;
+        const bool ok = f_in[j] && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
+        f_src[j] = ok ? g.fold_y + ((((long)img * g.H + y) * g.W + x) * g.C + f_cg * 8) : nullptr;
+        const int key = TW == 8 ? (((px >> 1) & 3) | ((py & 1) << 2)) : ((px >> 1) & 7);
+        f_hi[j] = pp * 128 + ((f_cg ^ key) << 4); f_lo[j] = pp * 128 + (((f_cg | 4) ^ key) << 4);
+    }
+    u32x4 gy[LG][2], gp[4];
+    auto fold_issue = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < LG; ++j) {
+            const float* s = f_src[j] ? f_src[j] + chunk * CK : (const float*)zp;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gy[j][0]) : "v"(s) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gy[j][1]) : "v"(f_src[j] ? s : (const float*)zp - 4) : "memory");
+        }
+        const float* ps = g.fold_bnp + chunk * CK + f_cg * 8;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gp[0]) : "v"(ps) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gp[1]) : "v"(ps) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gp[2]) : "v"(ps + g.C) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gp[3]) : "v"(ps + g.C) : "memory");
+    };
+    auto fold_store = [&](int pbuf) {          // (call behind a vmcnt wait that covers the loads of fold_issue)
+#pragma unroll
+        for (int j = 0; j < LG; ++j) asm volatile("" : "+v"(gy[j][0]), "+v"(gy[j][1]));
+        asm volatile("" : "+v"(gp[0]), "+v"(gp[1]), "+v"(gp[2]), "+v"(gp[3]));
+        float sc[8], sh[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sc[k] = __uint_as_float(gp[0][k]); sc[4 + k] = __uint_as_float(gp[1][k]); sh[k] = __uint_as_float(gp[2][k]); sh[4 + k] = __uint_as_float(gp[3][k]); }
+#pragma unroll
+        for (int j = 0; j < LG; ++j) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = __uint_as_float(gy[j][0][k]); v[4 + k] = __uint_as_float(gy[j][1][k]); }
+            u32x4 h, l;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = f_src[j] ? fmaxf(v[2 * k] * sc[2 * k] + sh[2 * k], 0.f) : 0.f, b = f_src[j] ? fmaxf(v[2 * k + 1] * sc[2 * k + 1] + sh[2 * k + 1], 0.f) : 0.f;
+                h[k] = pack_bf16x2(a, b);
+                l[k] = pack_bf16x2(a - __uint_as_float(h[k] << 16), b - __uint_as_float(h[k] & 0xffff0000u));
+            }
+            if (f_in[j]) {
+                *(u32x4*)(smem + PATCH0 + pbuf * PATCH_BYTES + f_hi[j]) = h;
+                *(u32x4*)(smem + PATCH0 + pbuf * PATCH_BYTES + f_lo[j]) = l;
+            }
+        }
+    };
+#else
+    constexpr int NG = 0; const bool folding = false;
+#endif
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -206,6 +274,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
 
     // ---- software pipeline.  Issue order: P(0) B(0,0) B(0,1) | per step s after its barrier: B(s+2), and at tap 0
     // of chunk c also P(c+1).  All loads are inline asm (invisible to hipcc's wait counting): the waits below are exact.
+#if C3_FOLD_PROBE
+    if (folding) { fold_issue(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fold_store(0); }
+    else
+#endif
     issue_patch(0, 0);
     issue_b(0, 0, 0);
     issue_b(0, 1, 1);
@@ -217,6 +289,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             // loads issued after B(step): B(step+1) [+ P(chunk+1) for t == 1, 2]
             const bool last = !more && t == 8;
             if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if ((t == 1 || t == 2) && more && folding) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB + NG) : "memory");
             else if ((t == 1 || t == 2) && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB + LP) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // WAR on the ring stage restaged below: see conv_gemm2.hip
@@ -224,6 +297,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             asm volatile("" ::: "memory");
             if (t + 2 < 9) issue_b(chunk, t + 2, (t + 2) % 3);
             else if (more) issue_b(chunk + 1, t + 2 - 9, (t + 2) % 3);
+#if C3_FOLD_PROBE
+            if (folding) {
+                if (t == 0 && more) fold_issue(chunk + 1);
+                if (t == 3 && more) fold_store((chunk + 1) & 1);       // (the wait of step 3 left only B(4) in flight)
+            } else
+#endif
             if (t == 0 && more) issue_patch(chunk + 1, (chunk + 1) & 1);
             const int t3 = t / 3, tr = t % 3;
             const int dh = FLIP ? 2 - t3 : t3, dw = FLIP ? 2 - tr : tr;     // compile-time per unrolled tap
@@ -723,6 +802,9 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
     g.X = x_hi; g.X_lo = x_lo; g.Wt = wt_hi; g.wlo_delta = (unsigned)delta; g.Out = out; g.addend = addend; g.stats = stats;
     g.N = N; g.H = H; g.W = W; g.C = C; g.Cn = Cn; g.ktot = 9 * C; g.flip = flip;
     g.bn_y = bn_y; g.bn_out = bn_out_hi; g.bnp = bnp; g.bn_part = bn_part;
+#if C3_FOLD_PROBE
+    g.fold_y = g_c3_fold_y; g.fold_bnp = g_c3_fold_bnp;
+#endif
     if (ev) { g.Out = ev->out_hi; g.Out_lo = ev->out_lo; g.OutF = ev->out_f32; g.res_hi = ev->res_hi; g.res_lo = ev->res_lo; g.ep_relu = ev->relu; }
     if (c3v_config(N, H, W, C, Cn)) {
         // Opt-in probe (AB_C3V=1, round 4): the second-generation K loop of conv3x3v.hip.  Its fragment-ordered weight

@@ -1,0 +1,87 @@
+// Review item 2 of round 4 as a measurement: layer 3's 3x3 forward (B = 64, 16 x 16, 256 -> 256) with the BatchNorm apply of the layer below
+// folded into its patch fill (C3_FOLD_PROBE in conv3x3.hip: fp32 y through registers -> relu(y * scale + shift) -> (hi, lo) planes -> LDS)
+// against the same kernel on planes that a separate pass wrote.  Same weights, same input: the two outputs must agree bit for bit.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/probe_c3fold.hip -o tools/probe_c3fold
+#define C3_FOLD_PROBE 1
+#include "../artiboost_amd/csrc/conv3x3.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+// the kernels conv3x3.hip hands other shapes to are not linked into the probe
+int c3v_config(int, int, int, int, int) { return 0; }
+int c3v_tiles(int, int, int, int, int) { return 0; }
+int c3v_run(Conv3Args&, int, hipStream_t) { return AB_ESHAPE; }
+int c3v_pack(const void*, const void*, int, int, void*, hipStream_t) { return AB_ESHAPE; }
+long c3v_frag_bytes(int, int) { return 0; }
+int conv3x3r_rows(int, int, int, int, int) { return 0; }
+int conv3x3r_run(const void*, const void*, const void*, const void*, float*, int, int, int, int, float*, hipStream_t) { return AB_ESHAPE; }
+
+__global__ void fill_f32(float* p, long n, unsigned seed, float scale, float bias) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        unsigned h = (unsigned)i * 2654435761u + seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = ((float)(h & 0xffffff) / 16777216.f - 0.5f) * scale + bias;
+    }
+}
+__global__ void split_planes(const float* v, long n, uint16_t* hi, uint16_t* lo) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2; i < n; i += (long)gridDim.x * 512) {
+        const unsigned h = pack_bf16x2(v[i], v[i + 1]);
+        const unsigned l = pack_bf16x2(v[i] - __uint_as_float(h << 16), v[i + 1] - __uint_as_float(h & 0xffff0000u));
+        *(unsigned*)(hi + i) = h; *(unsigned*)(lo + i) = l;
+    }
+}
+// the separate pass the fold replaces: planes of relu(y * scale + shift)
+__global__ void apply_planes(const float* y, const float* bnp, long n, int C, uint16_t* hi, uint16_t* lo) {
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2; i < n; i += (long)gridDim.x * 512) {
+        const int c = (int)(i % C);
+        const float a = fmaxf(y[i] * bnp[c] + bnp[C + c], 0.f), b = fmaxf(y[i + 1] * bnp[c + 1] + bnp[C + c + 1], 0.f);
+        const unsigned h = pack_bf16x2(a, b);
+        const unsigned l = pack_bf16x2(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+        *(unsigned*)(hi + i) = h; *(unsigned*)(lo + i) = l;
+    }
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 50;
+    const int N = 64, H = 16, W = 16, C = 256, Cn = 256;
+    const long nx = (long)N * H * W * C, nw = (long)Cn * 9 * C, no = (long)N * H * W * Cn;
+    float *y, *bnp, *wf, *out0, *out1, *stats; uint16_t *xh, *xl, *wh;
+    CK_(hipMalloc(&y, nx * 4)); CK_(hipMalloc(&bnp, 2 * C * 4)); CK_(hipMalloc(&wf, nw * 4)); CK_(hipMalloc(&out0, no * 4)); CK_(hipMalloc(&out1, no * 4));
+    CK_(hipMalloc(&stats, (long)N * 4 * Cn * 8)); CK_(hipMalloc(&xh, nx * 2)); CK_(hipMalloc(&xl, nx * 2)); CK_(hipMalloc(&wh, nw * 4));
+    uint16_t* wl = wh + nw;
+    fill_f32<<<1024, 256>>>(y, nx, 1, 4.f, 0.2f); fill_f32<<<4, 256>>>(bnp, C, 2, 1.f, 1.f); fill_f32<<<4, 256>>>(bnp + C, C, 3, 1.f, 0.f);
+    fill_f32<<<1024, 256>>>(wf, nw, 4, 0.05f, 0.f);
+    split_planes<<<1024, 256>>>(wf, nw, wh, wl);
+    apply_planes<<<1024, 256>>>(y, bnp, nx, C, xh, xl);
+    CK_(hipDeviceSynchronize());
+    float us[2];
+    for (int mode = 0; mode < 2; ++mode) {
+        g_c3_fold_y = mode ? y : nullptr; g_c3_fold_bnp = mode ? bnp : nullptr;
+        float* out = mode ? out1 : out0;
+        auto run = [&]() { return conv3x3_x3_run(xh, xl, wh, wl, out, N, H, W, C, Cn, 0, nullptr, stats, 0, nullptr, nullptr, nullptr, nullptr, nullptr); };
+        int rc = run();
+        if (rc) { printf("launch failed: mode %d rc %d\n", mode, rc); return 1; }
+        for (int i = 0; i < 3; ++i) run();
+        CK_(hipDeviceSynchronize());
+        hipEvent_t e0, e1; CK_(hipEventCreate(&e0)); CK_(hipEventCreate(&e1));
+        CK_(hipEventRecord(e0));
+        for (int i = 0; i < iters; ++i) run();
+        CK_(hipEventRecord(e1)); CK_(hipEventSynchronize(e1));
+        float ms; CK_(hipEventElapsedTime(&ms, e0, e1));
+        us[mode] = ms * 1e3f / iters;
+    }
+    // the apply pass alone (what the fold would not launch): planes of relu(bn(y)) from fp32 y
+    hipEvent_t e0, e1; CK_(hipEventCreate(&e0)); CK_(hipEventCreate(&e1));
+    CK_(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) apply_planes<<<2048, 256>>>(y, bnp, nx, C, xh, xl);
+    CK_(hipEventRecord(e1)); CK_(hipEventSynchronize(e1));
+    float ms; CK_(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<float> a(no), b(no);
+    CK_(hipMemcpy(a.data(), out0, no * 4, hipMemcpyDeviceToHost)); CK_(hipMemcpy(b.data(), out1, no * 4, hipMemcpyDeviceToHost));
+    long diff = 0; double mx = 0, amax = 0;
+    for (long i = 0; i < no; ++i) { if (a[i] != b[i]) ++diff; double d = fabs((double)a[i] - b[i]); if (d > mx) mx = d; if (fabs(a[i]) > amax) amax = fabs(a[i]); }
+    printf("layer-3 3x3 forward, B = 64: planes from a separate pass %.1f us (+ that pass, a plain elementwise kernel here: %.1f us); apply folded into the patch fill %.1f us\n",
+           us[0], ms * 1e3f / iters, us[1]);
+    printf("outputs: %ld of %ld elements differ, max |diff| %.3g (max |value| %.3g)\n", diff, no, mx, amax);
+    return 0;
+}
