@@ -379,7 +379,10 @@ int wgrad3x3_x3_slices(int N, int H, int W, int Cin, int Cout) {
     if (!th || Cin % 64 || Cout % 64) return 0;
     int nbands = N * (H / th);
     int tiles = (Cin / 64) * (Cout / 64);
-    int want = (256 + tiles - 1) / tiles;
+    // (AB_WG3X_TARGET: workgroups per launch the slice count aims at; 256 = one per CU.  512 was tried for review item 7 -- launches that lose
+    // a CU to a collective's kernel then lose 1/512 of their work instead of running a second round: see DESIGN 14.3)
+    static const int target = getenv("AB_WG3X_TARGET") ? atoi(getenv("AB_WG3X_TARGET")) : 256;
+    int want = (target + tiles - 1) / tiles;
     int ns = want < 1 ? 1 : want;
     if (ns > nbands / 2) ns = nbands / 2 > 0 ? nbands / 2 : 1;
     if (ns > 256) ns = 256;
