@@ -693,7 +693,7 @@ def test_stride2_3x3_patch_kernels(Ci, Co, hin, nb):
     close(dw.cpu().permute(0, 3, 1, 2), wr.grad)
     base = torch.randn(dw.shape, generator=g).cuda()
     dw2 = K.conv2d_wgrad_x3(K.split(nhwc(x).cuda()), K.split(nhwc(dy).cuda()), 3, 3, 2, 1, out=base.clone(), accumulate=True)
-    close((dw2 - base).cpu().permute(0, 3, 1, 2), wr.grad, tol=4e-6)
+    close((dw2 - base).cpu().permute(0, 3, 1, 2), wr.grad)              # (accumulated onto a random base: its rounding rides along)
     # ... arriving at relu(bn(y) + residual) of the stage below: masked gradient + that BatchNorm's backward partial rows from the epilogue
     ybn = torch.randn((nb, hin, hin, Ci), generator=g) * 2 + 0.3
     gamma, beta = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
