@@ -687,13 +687,14 @@ def test_stride2_3x3_patch_kernels(Ci, Co, hin, nb):
     dx2 = K.conv2d_dgrad_x3_pair(nhwc(dy).cuda(), wt, nhwc(dyd).cuda(), wdt, (hin, hin), 1)
     close(nchw(dx2.cpu()), ref2)
     # weight gradient of the strided convolution (the tap-by-tap kernel: an all-taps form over the four parity sub-grids measured slower)
-    wr = w.double().clone().requires_grad_(True)
-    F.conv2d(x.double(), wr, stride=2, padding=1).backward(dy.double())
-    dw = K.conv2d_wgrad_x3(nhwc(x).cuda(), nhwc(dy).cuda(), 3, 3, 2, 1)
-    close(dw.cpu().permute(0, 3, 1, 2), wr.grad)
-    base = torch.randn(dw.shape, generator=g).cuda()
-    dw2 = K.conv2d_wgrad_x3(K.split(nhwc(x).cuda()), K.split(nhwc(dy).cuda()), 3, 3, 2, 1, out=base.clone(), accumulate=True)
-    close((dw2 - base).cpu().permute(0, 3, 1, 2), wr.grad)              # (accumulated onto a random base: its rounding rides along)
+    if Ci % 64 == 0 and Co % 64 == 0:                                             # (the split-bf16 weight gradients take channels in 64s)
+        wr = w.double().clone().requires_grad_(True)
+        F.conv2d(x.double(), wr, stride=2, padding=1).backward(dy.double())
+        dw = K.conv2d_wgrad_x3(nhwc(x).cuda(), nhwc(dy).cuda(), 3, 3, 2, 1)
+        close(dw.cpu().permute(0, 3, 1, 2), wr.grad)
+        base = torch.randn(dw.shape, generator=g).cuda()
+        dw2 = K.conv2d_wgrad_x3(K.split(nhwc(x).cuda()), K.split(nhwc(dy).cuda()), 3, 3, 2, 1, out=base.clone(), accumulate=True)
+        close((dw2 - base).cpu().permute(0, 3, 1, 2), wr.grad)          # (accumulated onto a random base: its rounding rides along)
     # ... arriving at relu(bn(y) + residual) of the stage below: masked gradient + that BatchNorm's backward partial rows from the epilogue
     ybn = torch.randn((nb, hin, hin, Ci), generator=g) * 2 + 0.3
     gamma, beta = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
