@@ -32,8 +32,23 @@ class Metric:
     def get_measures(self, **kwargs):
         return {}
 
+    # Two-phase feeding (Evaluator.feed_all): `feed_device` enqueues the metric's device arithmetic and returns the small tensors its
+    # host bookkeeping needs (None: not deferrable -- the evaluator calls `feed`, which reads the device back at once);
+    # `feed_host` receives them as numpy arrays, one step later.  A metric's `feed` is exactly feed_device + feed_host.
+    def feed_device(self, preds, targs, **kwargs):
+        return None
 
-def _epe_mm(preds, targs, key, mm):
+    def feed_host(self, arrays, **kwargs):
+        pass
+
+
+def _epe_mm(preds, targs, key, mm, memo=None):
+    """(B,) mean end-point error of `key`.  memo: per-feed_all cache (several metrics ask for the same key)."""
+    if memo is not None:
+        mk = ("epe", key, bool(mm))
+        if mk not in memo:
+            memo[mk] = _epe_mm(preds, targs, key, mm)
+        return memo[mk]
     pred = preds[key]
     if "_abs" in key:
         val = targs[key.replace("_abs", "")].to(pred.device) + targs[Queries.ROOT_JOINT].to(pred.device).unsqueeze(1)
@@ -60,16 +75,28 @@ class Mean3DEPE(Metric):
         for m in self.avg_meters.values():
             m.reset()
 
-    def feed(self, preds, targs, **kwargs):
+    def feed_device(self, preds, targs, memo=None, **kwargs):
+        """Per key: [sum of the kept samples' errors, number kept] as one (2,) fp32 tensor (no boolean indexing: no host read)."""
+        out = []
         for key in self.val_keys_list:
-            d = _epe_mm(preds, targs, key, self.to_millimeters)
+            d = _epe_mm(preds, targs, key, self.to_millimeters, memo)
+            n = torch.full((), float(d.shape[0]), dtype=torch.float32, device=d.device)
             if "corners" in key and self.filter_unseen_obj_idxs:
                 oi = targs[Queries.OBJ_IDX].to(d.device)
                 keep = torch.ones_like(oi, dtype=torch.bool)
                 for idx in self.filter_unseen_obj_idxs:
                     keep &= oi != idx
-                d = d[keep]
-            self.avg_meters[key].update(float(d.sum()), n=d.shape[0])
+                d = torch.where(keep, d, torch.zeros_like(d))
+                n = keep.sum().to(torch.float32)
+            out.append(torch.stack([d.sum().to(torch.float32), n]))
+        return out
+
+    def feed_host(self, arrays, **kwargs):
+        for key, a in zip(self.val_keys_list, arrays):
+            self.avg_meters[key].update(float(a[0]), n=int(a[1]))
+
+    def feed(self, preds, targs, **kwargs):
+        self.feed_host([t.cpu().numpy() for t in self.feed_device(preds, targs)])
 
     def get_measures(self, **kwargs):
         return {f"{k}_mepe": m.avg for k, m in self.avg_meters.items()}
@@ -89,15 +116,24 @@ class ValMetricMean3DEPE2(Metric):
         for k in self.storage:
             self.storage[k] = {}
 
-    def feed(self, preds, targs, **kwargs):
-        synth = np.asarray(targs[SynthQueries.IS_SYNTH].cpu()).astype(bool)
-        ids = list(zip(*(np.asarray(targs[k].cpu()).tolist() for k in
-                         (SynthQueries.OBJ_ID, SynthQueries.PERSP_ID, SynthQueries.GRASP_ID))))
-        for key in self.val_keys_list:
-            d = _epe_mm(preds, targs, key, self.to_millimeters).cpu().numpy()
+    def feed_device(self, preds, targs, memo=None, **kwargs):
+        """[(B, 4) int64 (obj, persp, grasp, is_synth)] + one (B,) error vector per key."""
+        d = [_epe_mm(preds, targs, key, self.to_millimeters, memo).to(torch.float32) for key in self.val_keys_list]
+        dev = d[0].device if d else None
+        ids = torch.stack([torch.as_tensor(targs[k]).to(device=dev, dtype=torch.int64) for k in
+                           (SynthQueries.OBJ_ID, SynthQueries.PERSP_ID, SynthQueries.GRASP_ID, SynthQueries.IS_SYNTH)], 1)
+        return [ids] + d
+
+    def feed_host(self, arrays, **kwargs):
+        ids = arrays[0].tolist()
+        for key, d in zip(self.val_keys_list, arrays[1:]):
+            st = self.storage[key]
             for i, t in enumerate(ids):
-                if synth[i]:
-                    self.storage[key][tuple(int(x) for x in t)] = d[i]     # last write wins (val_metric.py:51-52)
+                if t[3]:
+                    st[(t[0], t[1], t[2])] = d[i]                          # last write wins (val_metric.py:51-52)
+
+    def feed(self, preds, targs, **kwargs):
+        self.feed_host([t.cpu().numpy() for t in self.feed_device(preds, targs)])
 
     def get_measures(self, **kwargs):
         return dict(self.storage)
@@ -118,11 +154,29 @@ class LossesMetric(Metric):
     def reset(self):
         self.meters = {}
 
-    def feed(self, preds, targs, losses=None, **kwargs):
+    def feed_device(self, preds, targs, losses=None, **kwargs):
+        """The step's loss scalars stacked into ONE fp32 vector (the reference reads each with .item(): a host round trip per loss);
+        the key order travels on the host side.  Host numbers (python floats) ride along as constants."""
+        keys, vals, dev = [], [], None
         for k, v in (losses or {}).items():
             if v is None:
                 continue
-            self.meters.setdefault(k, AverageMeter()).update(float(v), 1)
+            keys.append(k)
+            vals.append(v)
+            if torch.is_tensor(v) and dev is None:
+                dev = v.device
+        if dev is None:                      # nothing on a device: plain floats
+            return [np.asarray([float(v) for v in vals], np.float32)], keys
+        return [torch.stack([(v.detach() if torch.is_tensor(v) else torch.as_tensor(float(v))).to(device=dev, dtype=torch.float32).reshape(())
+                             for v in vals])], keys
+
+    def feed_host(self, arrays, extra=None, **kwargs):
+        for k, v in zip(extra or [], arrays[0].tolist()):
+            self.meters.setdefault(k, AverageMeter()).update(v, 1)
+
+    def feed(self, preds, targs, losses=None, **kwargs):
+        arrays, keys = self.feed_device(preds, targs, losses=losses)
+        self.feed_host([a.cpu().numpy() if torch.is_tensor(a) else a for a in arrays], extra=keys)
 
     def get_measures(self, **kwargs):
         return {k: m.avg for k, m in self.meters.items()}
@@ -133,27 +187,98 @@ class LossesMetric(Metric):
 
 
 class Evaluator:
-    """anakin/metrics/evaluator.py:12-85."""
+    """anakin/metrics/evaluator.py:12-85, without a device synchronisation per step.
 
-    def __init__(self, cfg, metrics_list):
+    The reference's `feed_all` (called after every batch, train_artiboost.py:96-98) moves tensors to the host inside every metric
+    (`.item()` per loss scalar, `.cpu()` per error vector): on a GPU that runs ahead of the host each of them stalls the loop until the
+    device has drained.  Here a metric with the two-phase API (Metric.feed_device / feed_host: Mean3DEPE, ValMetricMean3DEPE2,
+    LossesMetric) only ENQUEUES its arithmetic; the few hundred bytes it needs on the host are packed into one pinned buffer with one
+    asynchronous copy + an event, and applied when a later feed_all finds the event complete -- at most `max_lag` steps late (1: the
+    progress string of train_artiboost.py:105 shows the numbers through the previous step).  Every read of the measures
+    (`metrics_list`, `get_measures_all*`, `dump_images`, `reset_all`) applies what is still in flight first, so at those points the
+    state equals per-step blocking feeds exactly.  Metrics without the API (PCK, AR, Vis*) are fed at once, as before.
+    AB_EVAL_BLOCKING=1 (or max_lag=0): every feed applied before feed_all returns."""
+
+    def __init__(self, cfg, metrics_list, max_lag=None):
+        import os
         self._metrics_list = metrics_list
+        if max_lag is None:
+            max_lag = 0 if os.environ.get("AB_EVAL_BLOCKING") == "1" else 1
+        self.max_lag = int(max_lag)
+        self._inflight = []        # FIFO of (event, pinned buffer, [(metric, [(offset, nbytes, dtype, shape)], extra)])
+        self._free = []            # pinned buffers to reuse
 
     @property
     def metrics_list(self):
+        self.flush()               # a reader of the metrics (ArtiBoostLoader.step_eval, the recorder) sees every fed batch
         return self._metrics_list
 
     def reset_all(self):
+        self.flush()
         for m in self._metrics_list:
             m.reset()
 
+    # ---- deferred read-back
+    def _apply(self, entry):
+        ev, pin, plan = entry
+        ev.synchronize()
+        host = pin.numpy()
+        for m, lay, extra in plan:
+            arrays = [host[o:o + nb].view(dt).reshape(shp).copy() for o, nb, dt, shp in lay]
+            m.feed_host(arrays, extra=extra)
+        self._free.append(pin)
+
+    def _drain(self, keep):
+        while len(self._inflight) > keep:
+            self._apply(self._inflight.pop(0))
+        while self._inflight and self._inflight[0][0].query():      # already on the host: apply (keeps the progress string fresh)
+            self._apply(self._inflight.pop(0))
+
+    def flush(self):
+        """Apply every feed still in flight (blocks until the device has produced them)."""
+        self._drain(0)
+
     def feed_all(self, preds, targs, losses=None, **kwargs):
+        memo, plan, chunks, off = {}, [], [], 0
+        dev = None
         for m in self._metrics_list:
-            if isinstance(m, LossesMetric):
-                m.feed(preds, targs, losses=losses)
-            else:
-                m.feed(preds, targs)
+            res = m.feed_device(preds, targs, losses=losses, memo=memo) if not isinstance(m, VisMetric) else None
+            if res is None:
+                m.feed(preds, targs, losses=losses) if isinstance(m, LossesMetric) else m.feed(preds, targs)
+                continue
+            tensors, extra = res if isinstance(res, tuple) else (res, None)
+            if not all(torch.is_tensor(t) and t.is_cuda for t in tensors):      # host tensors / numbers: nothing to wait for
+                m.feed_host([t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t) for t in tensors], extra=extra)
+                continue
+            lay = []
+            for t in tensors:
+                t = t.detach().contiguous()
+                dev = t.device
+                nb = t.numel() * t.element_size()
+                lay.append((off, nb, torch.empty(0, dtype=t.dtype).numpy().dtype, tuple(t.shape)))
+                chunks.append(t.view(torch.uint8).reshape(-1) if t.dim() else t.reshape(1).view(torch.uint8))
+                pad = (-nb) % 8
+                if pad:
+                    chunks.append(torch.zeros(pad, dtype=torch.uint8, device=dev))
+                off += nb + pad
+            plan.append((m, lay, extra))
+        if plan:
+            blob = torch.cat(chunks) if len(chunks) > 1 else chunks[0]
+            pin = None
+            for i, b in enumerate(self._free):
+                if b.numel() >= off:
+                    pin = self._free.pop(i)
+                    break
+            if pin is None:
+                pin = torch.empty(max(off, 4096), dtype=torch.uint8).pin_memory()
+            pin[:off].copy_(blob, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._inflight.append((ev, pin, plan))
+        self._drain(self.max_lag)
 
     def get_measures_all(self):
+        self.flush()
         out = {}
         for m in self._metrics_list:
             if isinstance(m, VisMetric):
@@ -163,6 +288,7 @@ class Evaluator:
 
     def get_measures_all_striped(self, return_losses=True):
         """evaluator.py:58-74: {metric class name: {measure: float}} (scalars only) for the recorder / summarizer."""
+        self.flush()
         out = {}
         for m in self._metrics_list:
             if isinstance(m, VisMetric) or (not return_losses and isinstance(m, LossesMetric)):
@@ -176,6 +302,8 @@ class Evaluator:
         return {type(m).__name__: m.image for m in self._metrics_list if isinstance(m, VisMetric)}
 
     def __str__(self):
+        """The progress string (train_artiboost.py:105): never waits for the device -- numbers through the last feed already on the host."""
+        self._drain(self.max_lag)
         return " | ".join(s for s in (str(m) for m in self._metrics_list if not isinstance(m, VisMetric)) if s)
 
 
@@ -218,7 +346,8 @@ class Vis2DMetric(VisMetric):
         pad = targs["image_nhwc4_padded"]                    # the HIP loader's batch: zero-bordered NHWC4 (fp32 / bf16 or its planes)
         if pad.dim() == 5:
             pad = pad[0].float() + pad[1].float()
-        u8n = pad.dtype == torch.bfloat16 and pad.dim() == 4 and float(pad.abs().max()) > 1.0      # the integer plane 2 v - 255 (AB_DT_U8N)
+        from .registry import image_plane_of
+        u8n = image_plane_of(targs, pad) == "u8n"            # the loaders' tag: the integer plane 2 v - 255 (AB_DT_U8N)
         pad = pad.detach().float().cpu()
         if u8n:
             pad = pad / 510.0

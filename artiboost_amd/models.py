@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from .hybridnet import HybridNet, ParamStore
-from .registry import MODEL, Queries, enable_lower_param
+from .registry import MODEL, RUNTIME, Queries, enable_lower_param, image_plane_of
 
 
 def ortho6d_to_rotmat(poses):
@@ -141,6 +141,35 @@ class _NetBridge(torch.autograd.Function):
         return None, None, None, None, None
 
 
+class _AssembleFn(torch.autograd.Function):
+    """hybridbaseline.py:49-96 in grad mode as ONE launch (ab_pose_assemble) instead of ~35 small torch kernels and their autograd nodes.
+    With the fused criterion (Criterion.compute_losses on the raw kp3d / box6d through the `_ab_fuse` link) nothing differentiates through
+    these outputs and the backward below never runs; a criterion that does (registry losses + autograd, FUSED_CRITERION off) gets the
+    gradient by re-running the torch-op assembly under autograd -- same values to fp32 rounding, paid only on that route."""
+    KEYS = ("joints_3d_abs", "corners_3d_abs", "joints_3d", "corners_3d", "uvd2d", "boxroot_3d_abs", "box_rot_rotmat")
+
+    @staticmethod
+    def forward(ctx, kp3d, box6d, root_in, intr, corners_can, owner):
+        from . import kernels as K
+        o = K.pose_assemble(kp3d.contiguous(), box6d if box6d.stride(-1) == 1 else box6d.contiguous(), root_in, intr, corners_can,
+                            owner.center_idx, owner.inp_res)
+        ctx.owner = owner
+        ctx.save_for_backward(kp3d, box6d, root_in, intr, corners_can)
+        return tuple(o[k] for k in _AssembleFn.KEYS)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        kp3d, box6d, root_in, intr, corners_can = ctx.saved_tensors
+        owner = ctx.owner
+        with torch.enable_grad():
+            k_, b_ = kp3d.detach().requires_grad_(True), box6d.detach().requires_grad_(True)
+            out = owner._assemble_torch(k_, b_, root_in, intr, corners_can, float(owner.inp_res[1]), float(owner.inp_res[0]))
+            outs = [out[k if k != "uvd2d" else "2d_uvd"] for k in _AssembleFn.KEYS]
+            pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
+            gk, gb = torch.autograd.grad([o for o, _ in pairs], [k_, b_], [g for _, g in pairs], allow_unused=True)
+        return gk, gb, None, None, None, None
+
+
 # resnet.py:232-276: block type and stage counts of the five registered backbones
 BACKBONES = {"ResNet18": ("basic", (2, 2, 2, 2)), "ResNet34": ("basic", (3, 4, 6, 3)), "ResNet50": ("bottleneck", (3, 4, 6, 3)),
              "ResNet101": ("bottleneck", (3, 4, 23, 3)), "ResNet152": ("bottleneck", (3, 8, 36, 3))}
@@ -194,6 +223,8 @@ class HybridBaseline(nn.Module):
         # both modes, their weight / bias receive no gradient (zero gradient -> Adam leaves them) and carry no num_batches_tracked
         self.net.frozen_bn = self.store.frozen_bn = bool(cfg["BACKBONE"].get("FREEZE_BATCHNORM", False))
         self.net.norm = norm
+        # the padded image this model consumes natively: a loader built afterwards with the reference's keywords follows it (registry.RUNTIME)
+        RUNTIME["loader_compute_dtype"] = ("u8n" if self.net.x3 and os.environ.get("AB_IMAGE_PLANE", "u8n") == "u8n" else self.net.dtype)
         self.flat_param = nn.Parameter(self.store.flat, requires_grad=True)   # shares storage with the store
         self.flat_param._ab_owner = self                                      # netutils.build_optimizer recognises it
         self.segment_graphs = bool(cfg.get("SEGMENT_GRAPHS", os.environ.get("AB_SEGMENT_GRAPHS", "1") != "0"))
@@ -250,15 +281,15 @@ class HybridBaseline(nn.Module):
 
     def forward(self, inputs: Dict):
         dev = self.store.device
-        image = inputs.get(Queries.IMAGE)
         xpad = inputs.get("image_nhwc4_padded")
+        image = None
         if xpad is None:
-            image = image.to(dev, non_blocking=True)
+            image = inputs.get(Queries.IMAGE).to(dev, non_blocking=True)
             H, W = image.shape[2], image.shape[3]
-        else:
+            self.net.image_plane = "f32"
+        else:           # (the batch's lazily made CHW `image` is not touched)
             H, W = xpad.shape[1] - 6, xpad.shape[2] - 8
-            if getattr(self.net, "x3", False) and xpad.dtype == torch.bfloat16 and xpad.dim() == 4:
-                self.net.image_plane = "u8n"      # the loaders' integer image plane (compute_dtype "u8n": AB_DT_U8N); see train.TrainStep
+            self.net.image_plane = self._plane_of(inputs, xpad)
         if not self.net._packed or self.flat_param._version != getattr(self, "_seen_version", -1):
             self.net.pack_weights()      # torch-side update (e.g. torch.optim.Adam); the fused optimizer repacks itself
             self._seen_version = self.flat_param._version
@@ -275,6 +306,21 @@ class HybridBaseline(nn.Module):
                     kp3d, conf, _ = self.net.head_fwd(logits)
         return self._assemble(inputs, kp3d, conf, box6d, H, W)
 
+    def _plane_of(self, inputs, xpad):
+        """The image plane of a padded NHWC4 input, from the tag its loader wrote (registry.tag_image_plane / IMAGE_PLANE_KEY) -- never
+        guessed: an untagged bfloat16 image handed to a bf16x3 model is a TypeError (it could be x / 255 - 0.5 rounded to bf16 or the
+        integer plane 2 v - 255; reading one as the other trains on inputs off by 510x)."""
+        plane = image_plane_of(inputs, xpad)
+        if xpad.dim() == 4 and xpad.dtype == torch.bfloat16 and self.net.x3:
+            if plane != "u8n":
+                raise TypeError("a bfloat16 padded image for a bf16x3 model must be the loaders' integer plane (compute_dtype=\"u8n\", tagged "
+                                f"image_plane 'u8n'); got tag {plane!r} -- build the loader with compute_dtype=\"u8n\" or torch.float32")
+            return "u8n"
+        if plane == "u8n":
+            raise TypeError(f"image_plane 'u8n' (bf16 integers 2 v - 255) needs a bf16x3 model and a bfloat16 [N,H+6,W+8,4] tensor; this model "
+                            f"computes in {'bf16x3' if self.net.x3 else self.net.dtype} and got {xpad.dtype} {tuple(xpad.shape)}")
+        return "f32"
+
     def _assemble(self, inputs, kp3d, conf, box6d, H, W):
         """hybridbaseline.py:49-96: uvd -> xyz, 6-D -> R, canonical corners -> camera frame, 2-D re-projection."""
         dev = self.store.device
@@ -289,10 +335,23 @@ class HybridBaseline(nn.Module):
             return {"joints_3d_abs": o["joints_3d_abs"], "corners_3d_abs": o["corners_3d_abs"], "joints_3d": o["joints_3d"],
                     "corners_3d": o["corners_3d"], "2d_uvd": o["uvd2d"], "boxroot_3d_abs": o["boxroot_3d_abs"],
                     "box_rot_rotmat": o["box_rot_rotmat"], "kp3d": kp3d, "kp3d_confd": conf}
+        if self.fused_assembly and kp3d.is_cuda and (W, H) == tuple(self.inp_res):
+            f32c = lambda t: t.to(dev, torch.float32).contiguous()      # noqa: E731
+            ja, ca, j, c, uvd, br, rot = _AssembleFn.apply(kp3d, box6d, f32c(root_in), f32c(intr), f32c(inputs[Queries.CORNERS_CAN]), self)
+            ja._ab_fuse = dict(kp3d=kp3d, box6d=box6d, inp_res=self.inp_res, center_idx=self.center_idx)
+            return {"joints_3d_abs": ja, "corners_3d_abs": ca, "joints_3d": j, "corners_3d": c, "2d_uvd": uvd, "boxroot_3d_abs": br,
+                    "box_rot_rotmat": rot, "kp3d": kp3d, "kp3d_confd": conf}
+        out = self._assemble_torch(kp3d, box6d, root_in, intr, inputs[Queries.CORNERS_CAN].to(dev), H, W)
+        if kp3d.requires_grad:      # lets Criterion.compute_losses run the fused pose/loss kernel on the raw outputs
+            out["joints_3d_abs"]._ab_fuse = dict(kp3d=kp3d, box6d=box6d, inp_res=self.inp_res, center_idx=self.center_idx)
+        out.update(kp3d=kp3d, kp3d_confd=conf)
+        return out
+
+    def _assemble_torch(self, kp3d, box6d, root_in, intr, corners_can_3d, H, W):
+        """The assembly as differentiable torch ops (CPU tensors, other image sizes, and _AssembleFn's backward)."""
         pose_3d_abs = batch_uvd2xyz(kp3d, root_in, intr, self.inp_res)
         joints_3d_abs = pose_3d_abs[:, 0:21, :]
         boxroot_3d_abs = pose_3d_abs[:, 21:22, :]
-        corners_can_3d = inputs[Queries.CORNERS_CAN].to(dev)
         box_rot_rotmat = ortho6d_to_rotmat(box6d)
         corners_3d_abs = torch.matmul(box_rot_rotmat, corners_can_3d.permute(0, 2, 1)).permute(0, 2, 1) + boxroot_3d_abs
         root_joint = joints_3d_abs[:, self.center_idx, :]
@@ -301,8 +360,6 @@ class HybridBaseline(nn.Module):
         corners_2d = torch.stack([corners_2d[:, :, 0] / W, corners_2d[:, :, 1] / H], dim=2)
         corners_2d_uvd = torch.cat((corners_2d, torch.zeros_like(corners_2d[:, :, 0:1])), dim=2)
         final_2d_uvd = torch.cat((kp3d[:, 0:21, :], corners_2d_uvd, kp3d[:, 21:22, :]), dim=1)
-        if kp3d.requires_grad:      # lets Criterion.compute_losses run the fused pose/loss kernel on the raw outputs
-            joints_3d_abs._ab_fuse = dict(kp3d=kp3d, box6d=box6d, inp_res=self.inp_res, center_idx=self.center_idx)
         return {
             "joints_3d_abs": joints_3d_abs,
             "corners_3d_abs": corners_3d_abs,
@@ -311,8 +368,6 @@ class HybridBaseline(nn.Module):
             "2d_uvd": final_2d_uvd,
             "boxroot_3d_abs": boxroot_3d_abs,
             "box_rot_rotmat": box_rot_rotmat,
-            "kp3d": kp3d,
-            "kp3d_confd": conf,
         }
 
 

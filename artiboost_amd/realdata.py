@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .registry import Queries, SynthQueries
+from .registry import IMAGE_PLANE_KEY, PlaneTag, Queries, SynthQueries, tag_image_plane
 from .synth import get_affine_transform, gt_core_batch
 
 
@@ -381,6 +381,8 @@ class RealBatcher:
         order, factor, inv, flip, blur = dev["order"], dev["factor"], dev["inv"], dev["flip"], dev.get("blur")
         dt = L.dt(out_pad) if out_pad is not None else 0
         if self.image_plane == "u8n" and out_pad is not None:
+            if out_pad.dtype != torch.bfloat16:      # (as DeviceRenderer.render: bf16 integers written into another dtype's buffer otherwise)
+                raise TypeError(f"the integer image plane (compute_dtype \"u8n\") is written as bfloat16; out_pad is {out_pad.dtype}")
             dt = 2                         # AB_DT_U8N
         L.check(lib.ab_augment_batch(L.ptr(frames), L.i(n), L.i(W), L.i(H), L.ptr(order), L.ptr(factor), L.ptr(inv), L.ptr(blur),
                                      L.ptr(flip), L.i(ow), L.i(oh), L.i(dt), _ptr(out_pad), L.ptr(out_chw), L.ptr(self._ws), L.stream()),
@@ -518,12 +520,13 @@ class MixedLoader:
                                  out_chw=None if chw is None else chw[:self.n_real])
             if not self.n_synth:
                 rb["image_nhwc4_padded"] = pad
+                rb[IMAGE_PLANE_KEY] = PlaneTag(self.real.image_plane)
                 yield rb
                 continue
             # both halves write their frames straight into the batch's tensors: the renderer into rows n_real.. (no copy, no concatenation)
             self.synth.load_batch(static, bi)
             self.synth.render_into(static, want_chw=self.want_chw, out_pad=pad[self.n_real:], out_chw=None if chw is None else chw[self.n_real:])
-            out = {"image_nhwc4_padded": pad}
+            out = {"image_nhwc4_padded": pad, IMAGE_PLANE_KEY: PlaneTag(self.real.image_plane)}
             if chw is not None:
                 out[Queries.IMAGE] = chw
             for k, v in rb.items():
@@ -536,7 +539,7 @@ class MixedLoader:
     def _image_buffers(self, H, W):
         """(zero-bordered NHWC4 [B, H + 6, W + 8, 4], float CHW [B, 3, H, W] or None) of the next batch: fresh, or the next of the ring."""
         dev, dt = self.real.dev, self.real.dtype
-        fresh = lambda: (torch.zeros((self.B, H + 6, W + 8, 4), dtype=dt, device=dev),      # noqa: E731
+        fresh = lambda: (tag_image_plane(torch.zeros((self.B, H + 6, W + 8, 4), dtype=dt, device=dev), self.real.image_plane),      # noqa: E731
                          torch.empty((self.B, 3, H, W), dtype=torch.float32, device=dev) if self.want_chw else None)
         if self.reuse_buffers <= 0:
             return fresh()

@@ -124,6 +124,42 @@ def enable_lower_param(func):
     return wrapper
 
 
+# ---- the image plane a padded NHWC4 image tensor carries (never guessed from dtype or value range) ---------------------------------
+# "f32": network input x / 255 - 0.5 in the tensor's own dtype;  "u8n": ONE bf16 plane of the odd integers 2 v - 255 (AB_DT_U8N of the
+# renderer / augmenter; network input = plane / 510), what a bf16x3 model's two-pass stem consumes.  The loaders tag the tensors they
+# write (tag_image_plane) and their batch dicts carry IMAGE_PLANE_KEY; the models and metrics read the tag.
+IMAGE_PLANE_KEY = "image_plane"
+# process-wide hint written by the most recently built model: the compute_dtype its loader should be built with ("u8n" for bf16x3,
+# torch.bfloat16 / torch.float32 otherwise).  A loader constructed with the REFERENCE's keywords (no compute_dtype) follows it, so the
+# unmodified train_artiboost.py:117-190 order (model first, loader second) lands on the model's native plane.
+RUNTIME = {"loader_compute_dtype": None}
+
+
+class PlaneTag(str):
+    """The IMAGE_PLANE_KEY entry of a batch dict: a str that passes through the usual whole-batch idioms
+    ({k: v.clone() ...}, v.to(dev), v.cuda()) unchanged, so a tagged batch survives them with its tag."""
+    __slots__ = ()
+
+    def _same(self, *a, **k):
+        return self
+
+    clone = detach = to = cuda = cpu = contiguous = pin_memory = _same
+
+
+def tag_image_plane(t, plane):
+    assert plane in ("f32", "u8n")
+    t._ab_plane = PlaneTag(plane)
+    return t
+
+
+def image_plane_of(batch, xpad=None):
+    """The plane tag of a batch dict (IMAGE_PLANE_KEY) or of its padded image tensor; None when neither carries one."""
+    plane = batch.get(IMAGE_PLANE_KEY) if isinstance(batch, dict) else None
+    if plane is None and xpad is not None:
+        plane = getattr(xpad, "_ab_plane", None)
+    return None if plane is None else PlaneTag(plane)
+
+
 class TrainMode(Enum):
     TRAIN = 0
     VAL = 1

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .registry import Queries, SynthQueries
+from .registry import IMAGE_PLANE_KEY, RUNTIME, PlaneTag, Queries, SynthQueries, tag_image_plane
 from .render import SAMPLE_DTYPE, DeviceRenderer
 
 
@@ -396,6 +396,44 @@ def gt_core_batch(K, j3d, j2d, c3d, c2d, corners_can, obj_transf, center, scale,
 
 
 # --------------------------------------------------------------------------- the loader
+class LazyImageBatch(dict):
+    """A batch dict whose `image` entry (the reference's collated float CHW image, rendered_dataset.py:267-271) is produced on first
+    access from the padded NHWC4 plane the HIP model consumes: the reference-shaped loop never reads it (the model takes
+    `image_nhwc4_padded`), so the 50 MB CHW store per batch happens only for a consumer that asks (`batch["image"]`, `.get`, `in`)."""
+
+    def __init__(self, items, make_image=None):
+        super().__init__(items)
+        self._make_image = make_image
+
+    def _materialise(self):
+        make, self._make_image = self._make_image, None
+        if make is not None:
+            dict.__setitem__(self, Queries.IMAGE, make())
+
+    def __missing__(self, key):
+        if key == Queries.IMAGE and self._make_image is not None:
+            self._materialise()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        if key == Queries.IMAGE and self._make_image is not None:
+            self._materialise()
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (key == Queries.IMAGE and self._make_image is not None)
+
+
+def chw_from_padded(xpad, plane):
+    """float32 CHW image [B, 3, H, W] = v / 255 - 0.5 from the zero-bordered NHWC4 tensor, bit-identical to the renderer's own CHW
+    store (render.hip warp_jitter_kernel: o = v / 255.0f - 0.5f) for the "u8n" plane (2 v - 255, exact in bf16) and the fp32 image."""
+    x = xpad[:, 3:-3, 3:-5, :3].permute(0, 3, 1, 2)
+    if plane == "u8n":
+        return ((x.float() + 255.0) * 0.5) / 255.0 - 0.5
+    return x.float().contiguous()
+
+
 class ArtiBoostLoader:
     """The reference's ArtiBoostLoader (artiboost_loader.py:49-340) on the on-GPU renderer: same constructor keywords, same
     public surface (prepare / __iter__ / __len__ / step_eval / sample_weight_map / occurence_map / use_synth /
@@ -415,7 +453,10 @@ class ArtiBoostLoader:
         `realdata.HOdataSource`) are mixed in by `realdata.MixedLoader(RealBatcher(real_train_set, ...), self_with_the_synthetic
         share of the batch, batch_size)` -- the MixedDataset of the reference with a static per-batch split.
         Extensions (keyword only): assets (SceneAssets; default: seeded stand-ins for cfg OBJ_ENGINE.OBJ_ORIGIN_DATASET),
-        synth_len, device, compute_dtype (torch.float32: what the bf16x3 / f32 model consumes), rank, world_size, grasps."""
+        synth_len, device, rank, world_size, grasps, compute_dtype -- the padded image the model consumes: torch.float32 / torch.bfloat16,
+        or "u8n" (one bf16 plane of the integers 2 v - 255: the bf16x3 model's native input).  Default (the reference's call, which has
+        no such keyword): whatever the most recently built model asked for (registry.RUNTIME; bf16x3 -> "u8n"), resolved when the first
+        batch is staged; torch.float32 when no model exists yet."""
         if cfg is None or cfg_preset is None:
             raise TypeError("ArtiBoostLoader needs cfg (the MANAGER block) and cfg_preset (the DATA_PRESET block)")
         from .assets import SceneAssets
@@ -433,7 +474,7 @@ class ArtiBoostLoader:
         self.shuffle, self.num_workers, self.pin_memory, self.drop_last, self.collat_fn = shuffle, num_workers, pin_memory, drop_last, collate_fn
         self.cfg_dataset = cfg_dataset
         self._setup(assets, cfg, cfg_preset, int(batch_size), synth_len, device=device,
-                    compute_dtype=kwargs.pop("compute_dtype", torch.float32), random_seed=random_seed,
+                    compute_dtype=kwargs.pop("compute_dtype", None), random_seed=random_seed,
                     rank=kwargs.pop("rank", 0), world_size=kwargs.pop("world_size", 1), grasps=kwargs.pop("grasps", None))
         self.epoch_len_total = self.real_len + self.synth_len        # the reference's epoch_len (real + synthetic samples)
 
@@ -456,8 +497,8 @@ class ArtiBoostLoader:
         self.rank, self.world = rank, world_size
         # compute_dtype "u8n": the padded image leaves the renderer as ONE bf16 plane of the odd integers 2 v - 255 (AB_DT_U8N) -- what the
         # bf16x3 stem consumes directly (two MFMA passes, no split pass over the image); the network input is that plane / 510
-        self.image_plane = "u8n" if (isinstance(compute_dtype, str) and compute_dtype == "u8n") else "f32"
-        self.dtype = torch.bfloat16 if self.image_plane == "u8n" else compute_dtype
+        self._auto_dtype = compute_dtype is None
+        self._set_compute_dtype(torch.float32 if compute_dtype is None else compute_dtype)
         ve = cfg["VIEW_ENGINE"]
         self.u_bins, self.theta_bins = ve["PERSP_U_BINS"], ve["PERSP_THETA_BINS"]
         self.z_range = ve["CAMERA_Z_RANGE"]
@@ -505,6 +546,16 @@ class ArtiBoostLoader:
         self.pose_generator = PoseGenerator(self.mano, sc["HAND_TSL_SIGMA"], sc["HAND_POSE_SIGMA"], refiner=self.refiner)
         self.epoch = None
         self.cursor = 0
+        self._resolve_compute_dtype()
+
+    def _set_compute_dtype(self, compute_dtype):
+        self.image_plane = "u8n" if (isinstance(compute_dtype, str) and compute_dtype == "u8n") else "f32"
+        self.dtype = torch.bfloat16 if self.image_plane == "u8n" else compute_dtype
+
+    def _resolve_compute_dtype(self):
+        """A loader built with the reference's keywords follows the model built before it (see __init__)."""
+        if self._auto_dtype and RUNTIME.get("loader_compute_dtype") is not None:
+            self._set_compute_dtype(RUNTIME["loader_compute_dtype"])
 
     # ------------------------------------------------------------------ CCV sampling (ovg_set.py:104-132,162-178)
     def _sample_ccv(self, is_train=True):
@@ -710,6 +761,7 @@ class ArtiBoostLoader:
 
     def new_static_batch(self):
         """Static device buffers one batch wide (inputs of a captured hipGraph)."""
+        self._resolve_compute_dtype()
         B, (W, H) = self.batch_size, self.image_size
         ep = self.epoch
         st = {}
@@ -719,7 +771,7 @@ class ArtiBoostLoader:
             for k, o, nbytes, dt, shp in lay:
                 st[k] = flat[o:o + nbytes].view(dt).view((B,) + shp)
         assert set(ep) <= set(st)
-        st["image_nhwc4_padded"] = torch.zeros((B, H + 6, W + 8, 4), dtype=self.dtype, device=self.dev)
+        st["image_nhwc4_padded"] = tag_image_plane(torch.zeros((B, H + 6, W + 8, 4), dtype=self.dtype, device=self.dev), self.image_plane)
         return st
 
     def load_batch(self, static, batch_idx, which="all"):
@@ -750,15 +802,22 @@ class ArtiBoostLoader:
                              blur=static["_blur"], pad_code=2 if self.image_plane == "u8n" else None)
 
     def __iter__(self):
-        """Reference-shaped iteration: yields batch dicts (device tensors, `image` as float CHW like the reference's
-        collated batch plus the NHWC4 tensor the HIP model consumes directly)."""
+        """Reference-shaped iteration: yields batch dicts of device tensors -- the NHWC4 tensor the HIP model consumes directly (tagged
+        with its plane, also under IMAGE_PLANE_KEY) and `image`, the reference's float CHW image, made only when something reads it
+        (LazyImageBatch; a bf16 image plane cannot reproduce the fp32 CHW values, so there the renderer writes both as before).
+        The tensors are the loader's static staging buffers: a batch is valid until the next one is asked for, as with the reference's
+        pinned DataLoader batches once the loop has moved on."""
         if self.epoch is None:
             return
         static = self.new_static_batch()
+        pad, plane = static["image_nhwc4_padded"], self.image_plane
+        lazy = plane == "u8n" or pad.dtype == torch.float32
         for bi in range(len(self)):
             self.load_batch(static, bi)
-            self.render_into(static, want_chw=True)
-            yield {k: v for k, v in static.items() if not k.startswith("_")}
+            self.render_into(static, want_chw=not lazy)
+            items = {k: v for k, v in static.items() if not k.startswith("_")}
+            items[IMAGE_PLANE_KEY] = PlaneTag(plane)
+            yield LazyImageBatch(items, (lambda: chw_from_padded(pad, plane)) if lazy else None)
 
     # ------------------------------------------------------------------ mining (artiboost_loader.py:292-340,503-598)
     def get_evaluator_result(self, evaluator):

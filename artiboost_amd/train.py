@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from .registry import Queries, SynthQueries
+from .registry import IMAGE_PLANE_KEY, Queries, SynthQueries, image_plane_of, tag_image_plane
 
 
 # hipGraph captures use thread-local error mode: with a process group alive, RCCL's watchdog / heartbeat threads query
@@ -77,12 +77,16 @@ class TrainStep:
         self.pipeline_opt = bool(pipeline_render == "opt" and renderer is not None)
         self.g_render = None
         self.pipeline = bool(pipeline_render and not self.pipeline_opt and renderer is not None)
-        # A bfloat16 padded image handed to a bf16x3 model is the loaders' integer plane 2 v - 255 (compute_dtype "u8n" of ArtiBoostLoader /
-        # RealBatcher: AB_DT_U8N) -- a bf16 image of another meaning never was a valid input of that model (TypeError before round 5)
+        # the padded image's plane comes from the tag its loader wrote (registry.tag_image_plane / the batch's IMAGE_PLANE_KEY), carried over
+        # to the static clone; HybridBaseline._plane_of refuses an untagged bfloat16 image on a bf16x3 model
         pad0 = self.static.get("image_nhwc4_padded") if isinstance(self.static, dict) else None
         net0 = getattr(self.hb, "net", None)
-        if net0 is not None and getattr(net0, "x3", False) and torch.is_tensor(pad0) and pad0.dtype == torch.bfloat16 and pad0.dim() == 4:
-            net0.image_plane = "u8n"
+        if net0 is not None and torch.is_tensor(pad0):
+            plane = image_plane_of(example_batch, example_batch.get("image_nhwc4_padded"))
+            if plane is not None:
+                tag_image_plane(pad0, plane)
+                self.static[IMAGE_PLANE_KEY] = plane
+            net0.image_plane = self._plane = self.hb._plane_of(self.static, pad0)
         self.rstatic = None
         self.render_stream = None
         if self.pipeline_opt:
@@ -153,6 +157,7 @@ class TrainStep:
         net.training = True
         if not net._packed:
             net.pack_weights()
+        net.image_plane = getattr(self, "_plane", "f32") if st.get("image_nhwc4_padded") is not None else "f32"
         logits, _ = net.forward(image=st.get(Queries.IMAGE), xpad=st.get("image_nhwc4_padded"))
         kp3d, conf, stat = net.head_fwd(logits)
         o = self.fused(kp3d, net.last["box_raw"], net.last["box_raw"].shape[-1], st)

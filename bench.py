@@ -34,6 +34,11 @@ CFG_OF = {"HO3D": "ho3dv2_clasbased_artiboost_mi355x.yaml",             # BASELI
           "DexYCB": "dexycb_clasbased_sym_mi355x.yaml"}                  # BASELINE configs[4]: 21 objects, + SymCornerLoss
 
 
+# the padded image the headline's loader hands the bf16x3 stem: the integer plane 2 v - 255 (tests/test_gpu_fullsize.py pins THIS configuration
+# to the CPU oracle at full size)
+DEFAULT_IMAGE_PLANE = "u8n"
+
+
 def ref_cfg(size, dataset="HO3D"):
     import yaml
     cfg = yaml.safe_load(open(os.path.join(ROOT, "config", CFG_OF[dataset])))
@@ -65,7 +70,7 @@ def build_everything(args, rank, world, device, wgrad_1pass=False):
     synth_len = args.bs * world * max(args.steps + args.warmup + 2, 4)
     # bf16x3: the renderer hands the stem the integer image plane 2 v - 255 (AB_DT_U8N: two MFMA passes, no split pass; --image-plane f32: the
     # fp32 image and its (hi, lo) split, the round-4 path)
-    u8n = args.dtype == "bf16x3" and getattr(args, "image_plane", "u8n") == "u8n" and not wgrad_1pass
+    u8n = args.dtype == "bf16x3" and getattr(args, "image_plane", DEFAULT_IMAGE_PLANE) == "u8n" and not wgrad_1pass
     loader = ArtiBoostLoader.from_assets(assets, mgr, cfg["DATA_PRESET"], args.bs, synth_len, device=device,
                              compute_dtype="u8n" if u8n else hb.net.dtype, random_seed=cfg["TRAIN"]["MANUAL_SEED"], rank=rank, world_size=world)
     loader.prepare()
@@ -219,6 +224,29 @@ def rccl_leg(args, ms_main):
             "parallelism": d["config"]["parallelism"], "render_overlap": d["config"]["render_overlap"], "final_loss": d["final_loss"],
             "what": "init_process_group('nccl', device_id=...), three backward graphs, bucketed ReduceOp.AVG all-reduces on the comm stream, next "
                     "batch rendered under the last range -- over ONE rank: no link time, not a scaling measurement"}
+
+
+def dropin_leg(args, ms_main, steps=30):
+    """The drop-in boundary itself: the REFERENCE-SHAPED loop (train/train_artiboost.py:46-105 epoch_pass -- `for batch in artiboost_loader`
+    -> arch_model(batch) -> compute_losses -> evaluator.feed_all -> zero_grad -> backward -> clip_grad_norm_ -> optimizer.step), every object
+    built through the `anakin.*` import paths with the reference's keyword signatures (tools/bench_dropin.py, a child process: anakin.opt
+    parses sys.argv at import, as the reference's does), same geometry as the headline.  Wall clock over `steps` iterations after 5 of
+    warm-up, with and without feed_all; the ratio to the headline's graph-replayed step says what a user of the reference's own loop gets."""
+    import subprocess
+    out = {"loop": "train_artiboost.py epoch_pass through anakin.* (eager Python, network halves as replayed segment graphs)", "steps": steps}
+    for key, extra in (("ms_per_step", []), ("ms_per_step_no_feed", ["--no-feed"])):
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_dropin.py"), "--steps", str(steps), "--batch", str(args.bs), "--size", str(args.size)] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{"loop"')]
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or r.stdout)[-600:]}
+        d = json.loads(lines[-1])
+        out[key] = d["ms_per_step"]
+        if not extra:
+            out.update(value=d["samples_per_s"], unit="samples/s", final_loss=d["final_loss"], image_plane=d.get("image_plane"))
+    out["ratio_to_headline"] = round(out["ms_per_step"] / ms_main, 3)
+    out["ratio_to_headline_no_feed"] = round(out["ms_per_step_no_feed"] / ms_main, 3)
+    return out
 
 
 def mixed_leg(args, steps=20):
@@ -708,7 +736,7 @@ def main():
     ap.add_argument("--dataset", default="HO3D", choices=["HO3D", "DexYCB"])
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--image-plane", dest="image_plane", choices=["u8n", "f32"], default="u8n",
+    ap.add_argument("--image-plane", dest="image_plane", choices=["u8n", "f32"], default=DEFAULT_IMAGE_PLANE,
                     help="bf16x3: what the loader writes for the stem -- u8n: ONE bf16 plane of the odd integers 2v-255 (exact; two MFMA passes); "
                          "f32: the fp32 image, split into (hi, lo) planes by a pass of its own (three passes)")
     ap.add_argument("--pipeline", action="store_true",
@@ -739,6 +767,7 @@ def main():
                     help="N = 1 only: run the multi-rank schedule (three backward graphs, ReduceOp.AVG all-reduces on the comm stream, render "
                          "overlap) over a ONE-rank RCCL group -- the part of the RCCL path a 1-GPU box can execute; not the headline")
     ap.add_argument("--no-rccl-leg", action="store_true", help="skip the one-rank RCCL schedule sub-object of the default line")
+    ap.add_argument("--no-dropin-leg", action="store_true", help="skip the reference-shaped epoch_pass loop sub-object of the default line")
     ap.add_argument("--no-mixed-leg", action="store_true", help="skip the mixed real + synthetic training-step sub-object of the default line")
     ap.add_argument("--no-jpeg-leg", action="store_true", help="skip the real-frame JPEG decode sub-object of the default line")
     ap.add_argument("--no-study-leg", action="store_true", help="skip the one-pass weight-gradient study sub-object of the default line")
@@ -812,7 +841,7 @@ def main():
             port = sk.getsockname()[1]
         torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                                              device_id=torch.device(device))
-        args.no_eval_leg = args.no_dexycb_leg = args.no_study_leg = args.no_jpeg_leg = args.no_mixed_leg = args.no_rccl_leg = args.no_cpu_baseline = True
+        args.no_eval_leg = args.no_dexycb_leg = args.no_study_leg = args.no_jpeg_leg = args.no_mixed_leg = args.no_rccl_leg = args.no_dropin_leg = args.no_cpu_baseline = True
     cfg, model, crit, opt, loader, ts, static = build_everything(args, rank, world, device)
 
     def barrier():
@@ -925,6 +954,13 @@ def main():
                 mixed = mixed_leg(args)
             except Exception as e:   # noqa: BLE001
                 mixed = {"error": repr(e)}
+        dropin = None
+        if world == 1 and not args.no_dropin_leg and not args.eager and args.dtype == "bf16x3" and args.dataset == "HO3D":
+            try:
+                torch.cuda.synchronize()
+                dropin = dropin_leg(args, ms)
+            except Exception as e:   # noqa: BLE001
+                dropin = {"error": repr(e)}
         rccl1 = None
         if world == 1 and not args.no_rccl_leg and not args.eager and not args.rccl_single_rank:
             try:
@@ -954,6 +990,7 @@ def main():
                "sustained": sustained,                 # same process, >= --sustain seconds after the timed block (+ observed sclk / power)
                "configs1_eval_forward": ev,            # BASELINE configs[1] (forward only) with its own roofline; `bench.py --eval` prints it as the line
                "configs4_dexycb_1gpu": dex,
+               "dropin_epoch_pass": dropin,            # the reference's own loop through the anakin.* aliases (the drop-in boundary)
                "rccl_one_rank_schedule": rccl1,        # the N > 1 code path with the real collective over one rank (the box has one GPU)
                "mixed_real_synth_step": mixed,         # the reference's MixedDataset batch (real .jpg frames + synthetic) as one training step
                "real_half_jpeg_decode": jpg,           # .jpg files -> frames on the device, beside Pillow on this host

@@ -14,14 +14,35 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _oracle_image(xpad, plane, size):
+    """The oracle's input image (x / 255 - 0.5, fp32 CHW) from the padded tensor the GPU step trained on: the fp32 image as is; the
+    integer plane 2 v - 255 (what bench.py's headline runs on) divided by 510 -- the same pixel values to fp32 rounding."""
+    x = xpad.float().cpu()
+    if plane == "u8n":
+        x = x / 510.0
+    return x[:, 3:3 + size, 3:3 + size, :3].permute(0, 3, 1, 2).contiguous()
+
+
+def test_the_benchmarked_image_plane_is_one_of_the_pinned_ones():
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.DEFAULT_IMAGE_PLANE in PLANES and bench.DEFAULT_IMAGE_PLANE == "u8n"
+
+
+PLANES = ("f32", "u8n")
+
+
+@pytest.mark.parametrize("image_plane", PLANES)
 @pytest.mark.parametrize("dataset,cfg_name", [("HO3D", "ho3dv2_clasbased_artiboost_mi355x.yaml"),
                                               ("DexYCB", "dexycb_clasbased_sym_mi355x.yaml")])
-def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name):
+def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name, image_plane):
     """Two graph-replayed bf16x3 steps of the benchmark workload (render -> forward -> fused criterion -> backward -> clip +
     Adam) vs learner_oracle (torch-CPU fp32 restatement pinned to the reference goldens) fed the images the GPU rendered:
     every loss term of both steps within 3e-4 relative (step 2 sees step 1's update), the pre-clip gradient norm within 1 %.
     Two workloads: BASELINE configs[2] (HO3D-like objects, 3 losses) and configs[4] on one GPU (DexYCB-like: 21 objects at 16 k
-    faces, + SymCornerLoss from the DexYCB config, criterions/symcornerloss.py:18-102)."""
+    faces, + SymCornerLoss from the DexYCB config, criterions/symcornerloss.py:18-102); each on both image planes the loader can hand the
+    bf16x3 stem -- the fp32 image (three MFMA passes) and the integer plane "u8n" (two passes: bench.py's configuration)."""
     from artiboost_amd import registry as R
     from artiboost_amd.assets import SceneAssets
     from artiboost_amd.criterions import Criterion
@@ -37,8 +58,8 @@ def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name):
     crit = Criterion(cfg, R.build_criterion_loss_list(cfg["CRITERION"], preset_cfg=cfg["DATA_PRESET"], LAMBDAS=cfg["LAMBDAS"]))
     hb = model.model_list[0]
     opt = FusedClipAdam(model.models_params, lr=lr, max_norm=clip, model=hb)
-    loader = ArtiBoostLoader.from_assets(SceneAssets(dataset, seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], B, 2 * B, compute_dtype=torch.float32,
-                                         random_seed=3)
+    loader = ArtiBoostLoader.from_assets(SceneAssets(dataset, seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], B, 2 * B,
+                                         compute_dtype=torch.float32 if image_plane == "f32" else "u8n", random_seed=3)
     sym = next((l for l in crit.loss_list if type(l).__name__ == "SymCornerLoss"), None)
     assert (sym is not None) == (dataset == "DexYCB")
     lam = cfg["LAMBDAS"]
@@ -50,6 +71,8 @@ def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name):
     ts = TrainStep(model, crit, opt, static, use_graph=True, renderer=loader)
     ts.static = static
     assert (ts.fused.sym is not None) == (sym is not None)
+    assert hb.net.image_plane == image_plane == loader.image_plane
+    assert static["image_nhwc4_padded"].dtype == (torch.bfloat16 if image_plane == "u8n" else torch.float32)
     # ---- oracle state
     leaf = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in params0.items()}
     names = ms = vs = None
@@ -60,8 +83,7 @@ def test_full_size_train_steps_match_cpu_oracle(dataset, cfg_name):
         got = {k: float(v) for k, v in zip(ts.fused.LOSS_KEYS, losses.float().cpu())}
         gnorm = float(opt.total_norm.cpu())
         # the batch the step just trained on, as the oracle's inputs
-        xpad = static["image_nhwc4_padded"].float().cpu()
-        batch = {"image": xpad[:, 3:3 + size, 3:3 + size, :3].permute(0, 3, 1, 2).contiguous()}
+        batch = {"image": _oracle_image(static["image_nhwc4_padded"], image_plane, size)}
         for k in ("root_joint", "cam_intr", "corners_can", "joints_3d", "corners_3d", "joints_vis", "corners_vis", "obj_transf"):
             batch[k] = static[k].float().cpu()
         batch["obj_idx"] = static["obj_idx"].cpu()
@@ -133,7 +155,8 @@ def test_full_size_step_is_deterministic(monkeypatch):
     np.testing.assert_array_equal(w0, w2)
 
 
-def test_full_size_mixed_step_matches_cpu_oracle():
+@pytest.mark.parametrize("image_plane", PLANES)
+def test_full_size_mixed_step_matches_cpu_oracle(image_plane):
     """The benchmarked `mixed_real_synth_step` (the reference's MixedDataset batch as ONE training step) against the oracle: B = 64 =
     40 real 640 x 480 frames served as .jpg files -- decoded on the device (ab_jpeg_decode_batch), flipped / blurred / jittered / cropped by
     ab_augment_batch -- + 24 samples rendered on the device, through MixedLoader's default schedule (frames of four batches per decode call,
@@ -158,9 +181,10 @@ def test_full_size_mixed_step_matches_cpu_oracle():
     src = bench_mixed.JpegFileSource(n=1024)
     synth_len = int(0.6 * len(src))
     n_synth = MixedLoader.n_synth_for(B, len(src), synth_len)
-    synth = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], n_synth, synth_len, compute_dtype=torch.float32)
+    cd = torch.float32 if image_plane == "f32" else "u8n"      # "u8n": what bench.py's mixed_real_synth_step leg (tools/bench_mixed.py) runs
+    synth = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], n_synth, synth_len, compute_dtype=cd)
     synth.prepare()
-    ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=torch.float32), synth, B)      # decode_group 4, decode_ahead: the defaults
+    ml = MixedLoader(RealBatcher(src, cfg["DATA_PRESET"], compute_dtype=cd), synth, B)      # decode_group 4, decode_ahead: the defaults
     assert (ml.n_real, ml.n_synth) == (40, 24)
     arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16x3", INIT_SEED=3)
     model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
@@ -181,8 +205,8 @@ def test_full_size_mixed_step_matches_cpu_oracle():
         got = {k: float(v) for k, v in zip(ts.fused.LOSS_KEYS, losses.float().cpu())}
         gnorm = float(opt.total_norm.cpu())
         assert b["is_synth"].tolist() == [False] * 40 + [True] * 24
-        xpad = b["image_nhwc4_padded"].float().cpu()
-        batch = {"image": xpad[:, 3:3 + size, 3:3 + size, :3].permute(0, 3, 1, 2).contiguous()}
+        batch = {"image": _oracle_image(b["image_nhwc4_padded"], image_plane, size)}
+        assert hb.net.image_plane == image_plane
         assert float(batch["image"][:40].std()) > 0.05 and float(batch["image"][40:].std()) > 0.05      # both halves carry pictures
         for k in ("root_joint", "cam_intr", "corners_can", "joints_3d", "corners_3d", "joints_vis", "corners_vis", "obj_transf"):
             batch[k] = b[k].float().cpu()

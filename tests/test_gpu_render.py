@@ -10,7 +10,7 @@ import render_oracle as ro
 pytestmark = pytest.mark.gpu
 
 
-def _run(dataset, B, seed, res, blur=True):
+def _run(dataset, B, seed, res, blur=True, want_u8n=False):
     from artiboost_amd.assets import SceneAssets
     from artiboost_amd.render import DeviceRenderer
     assets = SceneAssets(dataset)
@@ -30,6 +30,12 @@ def _run(dataset, B, seed, res, blur=True):
                  torch.from_numpy(sc["factor"]).to(dev), torch.from_numpy(sc["inv_affine"]).to(dev), res, res,
                  out_pad=out_pad, out_chw=out_chw, want_keys=True, want_rgbx=True,
                  blur=torch.from_numpy(sc["blur"]).to(dev) if blur else None)
+    if want_u8n:      # the same batch once more into the integer plane (AB_DT_U8N: what bench.py's loader hands the bf16x3 stem)
+        pad8 = torch.zeros((B, res + 6, res + 8, 4), dtype=torch.bfloat16, device=dev)
+        r.render(smp, torch.from_numpy(sc["hand_verts"]).to(dev), torch.from_numpy(sc["order"]).to(dev),
+                 torch.from_numpy(sc["factor"]).to(dev), torch.from_numpy(sc["inv_affine"]).to(dev), res, res, out_pad=pad8, pad_code=2,
+                 blur=torch.from_numpy(sc["blur"]).to(dev) if blur else None)
+        sc["u8n_plane"] = pad8.float().cpu().numpy()
     return sc, (out_ref, rgbx_plain, keys_ref), (out_chw.cpu().numpy(), out_pad.cpu().numpy(), o["rgbx"].cpu().numpy(),
                                                 o["keys"].cpu().numpy().view(np.uint64))
 
@@ -45,6 +51,24 @@ def test_render_bit_exact_vs_oracle(dataset, B, seed, res, blur):
     np.testing.assert_array_equal(out, out_ref)                        # jitter + crop + normalise
     np.testing.assert_array_equal(out_pad[:, 3:-3, 3:-5, :3].transpose(0, 3, 1, 2), out_ref)
     assert np.abs(out_pad[:, :3]).max() == 0 and np.abs(out_pad[:, :, :3]).max() == 0 and np.abs(out_pad[..., 3]).max() == 0
+
+
+@pytest.mark.parametrize("dataset,seed", [("HO3D", 7), ("DexYCB", 8)])
+def test_render_bit_exact_vs_oracle_at_the_benchmark_batch(dataset, seed):
+    """B = 64 at 256 x 256 -- bench.py's batch.  tile_order_kernel compacts the tiles of ALL samples behind two global cursors
+    (render.hip:193-206), so the cross-sample schedule only shows at the full batch: keys, shaded RGBX and the jittered output of all 64
+    samples against the C oracle, plus the integer plane the benchmark's stem reads (2 v - 255 of the same pixels, zero border)."""
+    sc, (out_ref, rgbx_ref, keys_ref), (out, out_pad, rgbx, keys) = _run(dataset, 64, seed, 256, True, want_u8n=True)
+    assert (keys_ref != np.uint64(0xFFFFFFFFFFFFFFFF)).reshape(64, -1).mean(1).min() > 0.005, "every sample should contain geometry"
+    np.testing.assert_array_equal(keys, keys_ref)
+    np.testing.assert_array_equal(rgbx, rgbx_ref)
+    np.testing.assert_array_equal(out, out_ref)
+    np.testing.assert_array_equal(out_pad[:, 3:-3, 3:-5, :3].transpose(0, 3, 1, 2), out_ref)
+    plane = sc["u8n_plane"]
+    v = np.rint((out_ref.astype(np.float64) + 0.5) * 255.0)                      # the uint8 pixels behind out_ref = v / 255 - 0.5
+    np.testing.assert_array_equal((v / 255.0).astype(np.float32) - np.float32(0.5), out_ref)
+    np.testing.assert_array_equal(plane[:, 3:-3, 3:-5, :3].transpose(0, 3, 1, 2), 2.0 * v - 255.0)
+    assert np.abs(plane[:, :3]).max() == 0 and np.abs(plane[:, :, :3]).max() == 0 and np.abs(plane[..., 3]).max() == 0
 
 
 def test_render_properties():

@@ -562,3 +562,115 @@ def test_train_steps_on_the_integer_image_plane_match_the_fp32_image():
         if na > 1e-3:
             cos = float(a @ gu[n]) / (na * np.linalg.norm(gu[n]))
             assert cos >= 0.998 and abs(np.linalg.norm(gu[n]) / na - 1.0) <= 0.02, (n, cos)
+
+
+def test_lazy_chw_image_equals_the_renderers_own_chw_store():
+    """`batch["image"]` of the reference-shaped iteration is made on first access from the padded plane (synth.LazyImageBatch): byte-identical
+    to what the renderer writes when asked for the CHW image directly, for the fp32 image and the integer plane; the model never touches it."""
+    for dt in (torch.float32, "u8n"):
+        _, loader = _loader(dt, bs=4, n=8, size=128)
+        loader.prepare()
+        static = loader.new_static_batch()
+        for bi, batch in enumerate(loader):
+            assert "image" in batch and "image" not in batch.keys()                  # promised, not made yet
+            assert batch["image_plane"] == loader.image_plane
+            loader.load_batch(static, bi)
+            loader.render_into(static, want_chw=True)                                # the renderer's own CHW store of the same samples
+            np.testing.assert_array_equal(batch["image"].cpu().numpy(), static["image"].cpu().numpy())
+            assert "image" in batch.keys() and batch.get("image") is batch["image"]  # made once
+
+
+def test_untagged_bf16_image_is_refused_and_tags_select_the_stem_path():
+    """the image plane is carried by the loaders' tag, never guessed from dtype or value range."""
+    import yaml
+    from artiboost_amd import registry as R
+    from artiboost_amd.models import Arch
+    from artiboost_amd.registry import RUNTIME
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [64, 64], [8, 8]
+    arch = dict(cfg["ARCH"], COMPUTE_DTYPE="bf16x3")
+    model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
+    assert RUNTIME["loader_compute_dtype"] == "u8n"          # what a loader built with the reference's keywords will follow
+    _, loader = _loader("u8n", bs=4, n=4, size=64)
+    loader.prepare()
+    batch = next(iter(loader))
+    model.eval()
+    with torch.no_grad():
+        ref = model(batch)["HybridBaseline"]["joints_3d_abs"].clone()
+        assert model.model_list[0].net.image_plane == "u8n"
+        stripped = {k: v for k, v in batch.items() if k != "image_plane"}
+        stripped["image_nhwc4_padded"] = batch["image_nhwc4_padded"].clone()          # a clone carries no tag
+        with pytest.raises(TypeError, match="integer plane"):
+            model(stripped)
+        # the same pixels as the fp32 image (tagged "f32" by its loader): the three-pass stem, same prediction to operand rounding
+        _, lf = _loader(torch.float32, bs=4, n=4, size=64)
+        lf.prepare()
+        got = model(next(iter(lf)))["HybridBaseline"]["joints_3d_abs"]
+        assert model.model_list[0].net.image_plane == "f32"
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-4)
+
+
+def test_reference_keyword_loader_follows_the_model_it_feeds():
+    """train_artiboost.py:117-190 builds the model, then the loader -- with no compute_dtype keyword.  The loader lands on the model's
+    native image plane (bf16x3 -> "u8n"; an exact-f32 model -> the fp32 image)."""
+    import types, yaml
+    from artiboost_amd import registry as R
+    from artiboost_amd.models import Arch
+    from artiboost_amd.synth import ArtiBoostLoader
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [64, 64], [8, 8]
+    cfg["MANAGER"]["SYNTH_LEN"] = 8
+    cfg["MANAGER"].pop("REFINER", None)
+    for cd, plane, dt in (("bf16x3", "u8n", torch.bfloat16), ("f32", "f32", torch.float32)):
+        arch = dict(cfg["ARCH"], COMPUTE_DTYPE=cd)
+        model = Arch({"ARCH": arch}, R.build_arch_model_list(arch, preset_cfg=cfg["DATA_PRESET"]))
+        loader = ArtiBoostLoader(None, arg=types.SimpleNamespace(device="cuda:0", batch_size=4), cfg=cfg["MANAGER"], cfg_dataset=cfg["DATASET"],
+                                 cfg_preset=cfg["DATA_PRESET"], batch_size=4, random_seed=1)
+        loader.prepare()
+        batch = next(iter(loader))
+        assert loader.image_plane == plane and batch["image_plane"] == plane and batch["image_nhwc4_padded"].dtype == dt
+        model.train()
+        out = model(batch)["HybridBaseline"]
+        assert torch.isfinite(out["joints_3d_abs"]).all() and model.model_list[0].net.image_plane == plane
+
+
+def test_evaluator_late_reads_equal_blocking_feeds():
+    """Evaluator.feed_all reads the device back one step late (pinned buffer + event); at every read of the measures the state equals
+    per-step blocking feeds (max_lag 0) exactly -- Mean3DEPE sums, LossesMetric means, ValMetricMean3DEPE2's last-write-wins table --
+    and the progress string never runs more than one feed behind."""
+    import copy, yaml
+    from artiboost_amd import registry as R
+    from artiboost_amd.metrics import Evaluator
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    mk = lambda lag: Evaluator(cfg, R.build_evaluator_metric_list(copy.deepcopy(cfg["EVALUATOR"]), preset_cfg=cfg["DATA_PRESET"]), max_lag=lag)  # noqa: E731
+    late, block = mk(1), mk(0)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    B = 8
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)      # noqa: E731
+    for step in range(7):
+        targs = {"joints_3d": 0.1 * r(B, 21, 3), "corners_3d": 0.1 * r(B, 8, 3), "root_joint": r(B, 3),
+                 "obj_id": torch.randint(0, 3, (B,), device="cuda", generator=g), "persp_id": torch.randint(0, 2, (B,), device="cuda", generator=g),
+                 "grasp_id": torch.randint(0, 2, (B,), device="cuda", generator=g), "is_synth": torch.rand(B, device="cuda", generator=g) > 0.3}
+        preds = {"joints_3d_abs": targs["joints_3d"] + targs["root_joint"][:, None] + 0.01 * r(B, 21, 3),
+                 "corners_3d_abs": targs["corners_3d"] + targs["root_joint"][:, None] + 0.01 * r(B, 8, 3)}
+        losses = {"final_loss": r(1).abs()[0], "joints_3d_loss": r(1).abs()[0], "sym_corners_3d_loss": None, "host_number": 0.25 * step}
+        late.feed_all(preds, targs, losses)
+        block.feed_all(preds, targs, losses)
+        assert len(late._inflight) <= 1 and len(block._inflight) == 0
+        str(late)                                               # the progress string: no flush
+        assert len(late._inflight) <= 1
+    ma, mb = late.get_measures_all(), block.get_measures_all()
+    assert len(late._inflight) == 0 and set(ma) == set(mb) and len(ma) >= 3
+    for k in ma:
+        if isinstance(ma[k], dict):
+            assert ma[k].keys() == mb[k].keys() and len(ma[k]) > 0
+            assert all(ma[k][t] == mb[k][t] for t in ma[k])
+        else:
+            assert ma[k] == mb[k], k
+    assert str(late) == str(block) and "final_loss" in str(late)
+    for a, b in zip(late.metrics_list, block.metrics_list):
+        if hasattr(a, "get_measures_averaged"):
+            assert a.get_measures_averaged() == b.get_measures_averaged()

@@ -447,3 +447,60 @@ def test_traffic_table_counts_every_kernel_of_the_step():
             assert mb < 2.0 or b.startswith("at::") or b.startswith("__amd_rocclr"), f"{b}: {mb:.0f} MB per step in no family"
     assert abs(conv * 1e6 - summ["conv_stack_bytes_per_step"]) < 1e-3 * summ["conv_stack_bytes_per_step"]
     assert abs(total * 1e6 - summ["all_kernels_bytes_per_step"]) < 1e-3 * summ["all_kernels_bytes_per_step"]
+
+
+def test_lazy_image_batch_and_plane_tag():
+    """synth.LazyImageBatch makes `image` on first access only; registry.PlaneTag survives the whole-batch idioms."""
+    import torch
+    from artiboost_amd.registry import IMAGE_PLANE_KEY, PlaneTag, image_plane_of, tag_image_plane
+    from artiboost_amd.synth import LazyImageBatch, chw_from_padded
+    pad = torch.zeros(2, 8 + 6, 8 + 8, 4, dtype=torch.bfloat16)
+    v = torch.randint(0, 256, (2, 8, 8, 3))
+    pad[:, 3:-3, 3:-5, :3] = (2 * v - 255).to(torch.bfloat16)
+    calls = []
+    b = LazyImageBatch({"image_nhwc4_padded": tag_image_plane(pad, "u8n"), IMAGE_PLANE_KEY: PlaneTag("u8n")},
+                       lambda: calls.append(1) or chw_from_padded(pad, "u8n"))
+    assert "image" in b and "image" not in list(b) and not calls
+    moved = {k: x.clone() for k, x in b.items()}                       # the usual whole-batch idioms keep the tag
+    assert image_plane_of(moved, moved["image_nhwc4_padded"]) == "u8n" and moved[IMAGE_PLANE_KEY].to("cpu") == "u8n"
+    assert image_plane_of({}, pad) == "u8n" and image_plane_of({}, pad.clone()) is None
+    img = b["image"]
+    assert calls == [1] and b.get("image") is img and "image" in list(b) and calls == [1]
+    assert torch.equal(img, v.permute(0, 3, 1, 2).float() / 255.0 - 0.5)
+    import pytest
+    with pytest.raises(KeyError):
+        b["nope"]
+    assert LazyImageBatch({"a": 1}).get("image") is None
+
+
+def test_evaluator_host_feeds_match_the_reference_semantics():
+    """Evaluator.feed_all on host tensors (nothing to defer): Mean3DEPE's running mean in mm, the unseen-object filter on the corner
+    errors (meanepe.py:62-66), LossesMetric's means with None entries skipped, ValMetricMean3DEPE2's last write per CCV triplet."""
+    import types
+    import numpy as np
+    import torch
+    from artiboost_amd.metrics import Evaluator, LossesMetric, Mean3DEPE, ValMetricMean3DEPE2
+    ev = Evaluator({}, [LossesMetric(), Mean3DEPE(VAL_KEYS=["joints_3d_abs", "corners_3d_abs"], MILLIMETERS=True,
+                                                   arg=types.SimpleNamespace(filter_unseen_obj_idxs=[3])),
+                        ValMetricMean3DEPE2(VAL_KEYS=["joints_3d_abs"], MILLIMETERS=True)])
+    g = torch.Generator().manual_seed(0)
+    js, cs, nkeep = [], [], 0
+    for step in range(3):
+        B = 4
+        tj, tc, root = torch.randn(B, 21, 3, generator=g), torch.randn(B, 8, 3, generator=g), torch.randn(B, 3, generator=g)
+        pj, pc = tj + root[:, None] + 0.01 * torch.randn(B, 21, 3, generator=g), tc + root[:, None] + 0.01 * torch.randn(B, 8, 3, generator=g)
+        oi = torch.tensor([1, 3, 2, 3])
+        targs = {"joints_3d": tj, "corners_3d": tc, "root_joint": root, "obj_idx": oi, "obj_id": torch.tensor([0, 0, 1, 1]),
+                 "persp_id": torch.tensor([5, 5, 6, 6]), "grasp_id": torch.tensor([0, 0, 0, step]), "is_synth": torch.tensor([True, True, False, True])}
+        ev.feed_all({"joints_3d_abs": pj, "corners_3d_abs": pc}, targs, {"final_loss": torch.tensor(1.0 + step), "aux": None, "k": 2.0})
+        js.append((1000 * (pj - tj - root[:, None])).norm(dim=2).mean(1))
+        cs.append((1000 * (pc - tc - root[:, None])).norm(dim=2).mean(1)[oi != 3])
+        last_j = js[-1]
+    m = ev.get_measures_all()
+    np.testing.assert_allclose(m["joints_3d_abs_mepe"], torch.cat(js).mean().item(), rtol=1e-6)
+    np.testing.assert_allclose(m["corners_3d_abs_mepe"], torch.cat(cs).mean().item(), rtol=1e-6)
+    assert m["final_loss"] == 2.0 and m["k"] == 2.0 and "aux" not in m
+    table = m["joints_3d_abs"]
+    assert set(table) == {(0, 5, 0), (1, 6, 0), (1, 6, 1), (1, 6, 2)}                 # the real sample (is_synth False) never enters
+    np.testing.assert_allclose(table[(0, 5, 0)], last_j[1].item(), rtol=1e-6)          # later write of the same triplet wins
+    assert "final_loss" in str(ev)

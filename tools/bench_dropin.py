@@ -56,7 +56,7 @@ def main():
     loader.prepare()
     model.train()
     evaluator.reset_all()
-    t_start, n, last = None, 0, None
+    t_start, n, last, bar = None, 0, None, ""
     for batch_idx, batch in enumerate(loader):
         if batch_idx == a.warmup:
             torch.cuda.synchronize()
@@ -73,14 +73,18 @@ def main():
             torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
         optimizer.step()
         last = final_loss
+        if not a.no_feed:
+            bar = f"{evaluator}"              # the progress string of train_artiboost.py:105 (etqdm description), every iteration
         if batch_idx >= a.warmup:
             n += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_start
+    measures = evaluator.get_measures_all_striped() if not a.no_feed else {}      # the epoch-end read: every batch fed
     print(json.dumps({"loop": "reference epoch_pass (eager, drop-in)", "batch": a.batch, "size": a.size, "steps": n,
                       "ms_per_step": round(dt / n * 1e3, 3), "samples_per_s": round(a.batch * n / dt, 1),
                       "feed_all": not a.no_feed, "segment_graphs": os.environ.get("AB_SEGMENT_GRAPHS", "1") != "0",
-                      "final_loss": float(last)}))
+                      "image_plane": str(getattr(loader, "image_plane", None)), "progress": bar[:120],
+                      "epoch_final_loss_mean": measures.get("LossesMetric", {}).get("final_loss"), "final_loss": float(last)}))
 
 
 if __name__ == "__main__":
