@@ -429,8 +429,8 @@ def chw_from_padded(xpad, plane):
     """float32 CHW image [B, 3, H, W] = v / 255 - 0.5 from the zero-bordered NHWC4 tensor, bit-identical to the renderer's own CHW
     store (render.hip warp_jitter_kernel: o = v / 255.0f - 0.5f) for the "u8n" plane (2 v - 255, exact in bf16) and the fp32 image."""
     x = xpad[:, 3:-3, 3:-5, :3].permute(0, 3, 1, 2)
-    if plane == "u8n":
-        return ((x.float() + 255.0) * 0.5) / 255.0 - 0.5
+    if plane == "u8n":      # (a division by a DEVICE tensor: torch turns a division by a python scalar into a multiplication by 1 / 255)
+        return ((x.float() + 255.0) * 0.5) / torch.full((), 255.0, dtype=torch.float32, device=x.device) - 0.5
     return x.float().contiguous()
 
 

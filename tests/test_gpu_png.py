@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "png_cases.npz")
 
 
+
+def _same_entry(a, b, msg):
+    """Batch entries are device tensors -- bit-identical -- or plain tags (the IMAGE_PLANE_KEY string)."""
+    if torch.is_tensor(a):
+        torch.testing.assert_close(a, b, rtol=0, atol=0, msg=str(msg))
+    else:
+        assert a == b, msg
+
+
 def _golden():
     g = np.load(GOLD, allow_pickle=False)
     return [(bytes(g[f"file{i}"]), g[f"rgb{i}"]) for i in range(int(g["n"]))]
@@ -123,7 +132,7 @@ def test_real_batches_from_png_files_equal_the_pillow_path():
     for idxs in ([0, 1, 2, 7], [3, 11]):
         ba, bb = ra.batch(idxs), rb.batch(idxs)
         for k in ba:
-            torch.testing.assert_close(ba[k], bb[k], rtol=0, atol=0, msg=k)
+            _same_entry(ba[k], bb[k], k)
     for seed in (1, 2):
         ref = [{k: v.clone() for k, v in x.items()} for x in
                MixedLoader(RealBatcher(b, cfg, compute_dtype=torch.float32, seed=9), None, 2, seed=seed, decode_group=1, decode_ahead=False)]
@@ -133,4 +142,4 @@ def test_real_batches_from_png_files_equal_the_pillow_path():
         assert len(got) == len(ref) == 6 and ml.real._png_side is not None and not ml.real._jobs
         for x, r in zip(got, ref):
             for k in r:
-                torch.testing.assert_close(x[k], r[k], rtol=0, atol=0, msg=k)
+                _same_entry(x[k], r[k], k)
