@@ -47,8 +47,11 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsig
 #if C3_FOLD_PROBE
 static const float* g_c3_fold_y = nullptr; static const float* g_c3_fold_bnp = nullptr;      // set by tools/probe_c3fold.hip around its launches
 #endif
-template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0>
-__global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
+// EP (X3 = 2 only): which epilogue operands are requested at kernel entry and held in registers over the K loop -- 2: all (bn_y, mask, addend),
+// 1: bn_y only, 0: none (read in the epilogue).  EP < 2 also asks for four waves per SIMD (two 8-wave workgroups per CU), so that one
+// workgroup's epilogue traffic runs under the other's K loop instead of every CU alternating between the two in lock step.
+template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0, int EP = 2>
+__global__ __launch_bounds__(64 * WM * WN, (X3 == 2 && EP < 2) ? 4 : 1) void conv3x3_kernel(Conv3Args g) {
     constexpr bool BNR = X3 == 2;
     constexpr int CK = X3 ? 32 : 64;                   // channels per K chunk
     // NW = WM*WN waves (4 or 8).  Measured (tools/probe_fill.hip): a wave pulls ~10 GB/s of L2-resident data into LDS
@@ -95,10 +98,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
 
     // ---- X3 = 2: this thread's share of the BatchNorm operands of the epilogue (rows er0 + k*ERS, channels ec4*4 .. +3)
     constexpr int ECPR = BN / 4, ERS = NT / ECPR, ER = BNR ? BM / ERS : 1;
-    constexpr bool EPRE = BNR && ER <= 8;               // held in registers from here on (the 256-pixel tile has none to spare)
+    constexpr bool EPRE = BNR && ER <= 8 && EP >= 1;    // held in registers from here on (the 256-pixel tile has none to spare)
+    constexpr bool EPRE2 = EPRE && EP >= 2;             // ... mask and addend too
     const int ec4 = tid % ECPR, er0 = tid / ECPR;
-    float4 e_y[EPRE ? ER : 1], e_add[EPRE ? ER : 1];
-    uint2 e_m[EPRE ? ER : 1];
+    float4 e_y[EPRE ? ER : 1], e_add[EPRE2 ? ER : 1];
+    uint2 e_m[EPRE2 ? ER : 1];
     float e_mean[4], e_istd[4], e_sc[4], e_sh[4];
     if constexpr (BNR) {
         const int col = n0 + ec4 * 4;
@@ -113,12 +117,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
             for (int k = 0; k < ER; ++k) {
                 const int row = er0 + k * ERS;
                 const int yy = ty0 + row / TW, xx = tx0 + row % TW;
-                e_y[k] = make_float4(0.f, 0.f, 0.f, 0.f); e_add[k] = e_y[k]; e_m[k] = make_uint2(0u, 0u);
+                e_y[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (EPRE2) { e_add[k] = e_y[k]; e_m[k] = make_uint2(0u, 0u); }
                 if (yy < g.H && xx < g.W && cok) {
                     const long o = (((long)img * g.H + yy) * g.W + xx) * g.Cn + col;
                     e_y[k] = *(const float4*)((const float*)g.bn_y + o);
-                    if (g.bn_out) e_m[k] = *(const uint2*)((const bf16_t*)g.bn_out + o);
-                    if (g.addend) e_add[k] = *(const float4*)((const float*)g.addend + o);
+                    if constexpr (EPRE2) {
+                        if (g.bn_out) e_m[k] = *(const uint2*)((const bf16_t*)g.bn_out + o);
+                        if (g.addend) e_add[k] = *(const float4*)((const float*)g.addend + o);
+                    }
                 }
             }
         }
@@ -452,9 +459,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
                     const float4 v4 = *(const float4*)(smem + row * SPF + ec4 * 16);
                     const long o = (((long)img * g.H + yy) * g.W + xx) * g.Cn + col;
                     float4 y4, a4; uint2 m2;
-                    if constexpr (EPRE) { y4 = e_y[k]; a4 = e_add[k]; m2 = e_m[k]; }
+                    if constexpr (EPRE) y4 = e_y[k]; else y4 = *(const float4*)(BnY + o);
+                    if constexpr (EPRE2) { a4 = e_add[k]; m2 = e_m[k]; }
                     else {
-                        y4 = *(const float4*)(BnY + o);
                         a4 = AddF ? *(const float4*)(AddF + o) : make_float4(0.f, 0.f, 0.f, 0.f);
                         m2 = BnM ? *(const uint2*)(BnM + o) : make_uint2(0u, 0u);
                     }
@@ -687,7 +694,7 @@ int conv3x3_tiles(int N, int H, int W, int C, int Cn) {
     return N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
 }
 
-template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0>
+template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0, int EP = 2>
 static int c3_launch(Conv3Args& g, hipStream_t st) {
     constexpr int TH = BM / TW;
     if constexpr (TW == 8 && BM == 128) { g.N /= 2; g.H = 16; }        // two 8 x 8 images as one 16-row image: the same bytes
@@ -696,12 +703,12 @@ static int c3_launch(Conv3Args& g, hipStream_t st) {
     size_t lds = c3_lds<BM, TW, BN, WM, WN, X3>(g.C / (X3 ? 32 : 64));
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<BM, TW, BN, WM, WN, FLIP, X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<BM, TW, BN, WM, WN, FLIP, X3, EP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)c3_lds<BM, TW, BN, WM, WN, X3>(2));
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv3x3_kernel<BM, TW, BN, WM, WN, FLIP, X3><<<blocks, 64 * WM * WN, lds, st>>>(g);
+    conv3x3_kernel<BM, TW, BN, WM, WN, FLIP, X3, EP><<<blocks, 64 * WM * WN, lds, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -819,6 +826,11 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
         return c3v_run(g, bn_y ? 2 : (ev ? 3 : 1), st);
     }
     if (bn_y) {      // masked gradient + BatchNorm-backward partials from the epilogue
+        static const int l1ep = getenv("AB_C3_L1EP") ? atoi(getenv("AB_C3_L1EP")) : -1;      // probe: 128-pixel tile, EP = 0 | 1, two workgroups per CU
+        if (l1ep >= 0 && Cn == 64 && C == 64 && W % 16 == 0 && H % 8 == 0) {
+            if (l1ep == 0) return c3_launch<128, 16, 64, 4, 2, 1, 2, 0>(g, st);
+            return c3_launch<128, 16, 64, 4, 2, 1, 2, 1>(g, st);
+        }
         if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, 1, 2>(g, st);
         if (cfg == 2) return c3_launch<256, 32, 128, 4, 2, 1, 2>(g, st);
         if (cfg == 3) return c3_launch<128, 16, 128, 4, 2, 1, 2>(g, st);
