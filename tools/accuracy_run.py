@@ -60,7 +60,7 @@ def _val_batches(pix, gts, bs, plane, dtype):
     return out
 
 
-def run(dtype, steps, at, val, cfg, bs=64, size=256, dev="cuda:0", log=print, per_epoch=500):
+def run(dtype, steps, at, val, cfg, bs=64, size=256, dev="cuda:0", log=print, per_epoch=500, replica=0):
     import numpy as np
     import torch
     from artiboost_amd import registry as R
@@ -83,6 +83,10 @@ def run(dtype, steps, at, val, cfg, bs=64, size=256, dev="cuda:0", log=print, pe
     loader = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), dict(cfg["MANAGER"], EPOCH=1000), cfg["DATA_PRESET"], bs, per_epoch * bs,
                                          device=dev, compute_dtype=cd, random_seed=seed)
     vb = _val_batches(*val, plane=loader.image_plane, dtype=loader.dtype)
+    # replica r > 0: the same weights, samples and pixels; only the host RNG streams behind the ordinal losses' random pair / view draws
+    # (criterions.py: random.shuffle, torch.rand -- reseeded per run by the reference's set_all_seeds too) start elsewhere.  What two runs
+    # of ONE precision differ by is the noise floor any cross-precision difference has to be read against.
+    random.seed(seed + 7919 * replica); torch.manual_seed(seed + 7919 * replica)
     metric = Mean3DEPE(VAL_KEYS=["joints_3d_abs", "corners_3d_abs"], MILLIMETERS=True)
     ts, step, res, t_train = None, 0, {}, 0.0
     w0 = loader.sample_weight_map.clone()
@@ -111,14 +115,14 @@ def run(dtype, steps, at, val, cfg, bs=64, size=256, dev="cuda:0", log=print, pe
                         metric.feed(model(b)["HybridBaseline"], b)
                 m = metric.get_measures()
                 res[step] = {"mpjpe_mm": m["joints_3d_abs_mepe"], "mpcpe_mm": m["corners_3d_abs_mepe"], "train_final_loss": loss}
-                log(f"  {dtype:7s} step {step:5d}: val MPJPE {m['joints_3d_abs_mepe']:8.3f} mm  MPCPE {m['corners_3d_abs_mepe']:8.3f} mm   train final_loss {loss:.4e}")
+                log(f"  {dtype:7s} r{replica} step {step:5d}: val MPJPE {m['joints_3d_abs_mepe']:8.3f} mm  MPCPE {m['corners_3d_abs_mepe']:8.3f} mm   train final_loss {loss:.4e}")
                 model.train()
                 t0 = time.time()
             if step >= steps:
                 break
         torch.cuda.synchronize()
         t_train += time.time() - t0
-    return {"dtype": dtype, "image_plane": loader.image_plane, "checkpoints": res, "train_samples_per_s": round(steps * bs / t_train, 1)}
+    return {"dtype": dtype, "replica": replica, "image_plane": loader.image_plane, "checkpoints": res, "train_samples_per_s": round(steps * bs / t_train, 1)}
 
 
 def main():
@@ -129,6 +133,7 @@ def main():
     ap.add_argument("--bs", type=int, default=64)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--dtypes", default="f32,bf16x3,bf16")
+    ap.add_argument("--replicas", type=int, default=3)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import yaml
@@ -148,16 +153,30 @@ def main():
     val = _val_set(cfg, a.bs, a.val, "cuda:0")
     out = {}
     for dt in a.dtypes.split(","):
-        out[dt] = run(dt, a.steps, at, val, cfg, bs=a.bs, size=a.size, log=log)
-        log(f"  {dt:7s} trained at {out[dt]['train_samples_per_s']} samples/s (image plane {out[dt]['image_plane']})")
+        out[dt] = [run(dt, a.steps, at, val, cfg, bs=a.bs, size=a.size, log=log, replica=r) for r in range(a.replicas)]
+        log(f"  {dt:7s} trained at {out[dt][0]['train_samples_per_s']} samples/s (image plane {out[dt][0]['image_plane']})")
+    import numpy as np
+    log("# mean +- sample standard deviation over the replicas (same weights / samples / pixels; only the losses' random draws differ)")
+    stat = {}
+    for dt, runs in out.items():
+        for s_ in sorted(runs[0]["checkpoints"]):
+            for k in ("mpjpe_mm", "mpcpe_mm"):
+                v = np.array([r["checkpoints"][s_][k] for r in runs])
+                stat[(dt, s_, k)] = (float(v.mean()), float(v.std(ddof=1)) if len(v) > 1 else float("nan"), len(v))
+            (mj, sj, n), (mc, sc, _) = stat[(dt, s_, "mpjpe_mm")], stat[(dt, s_, "mpcpe_mm")]
+            log(f"  {dt:7s} step {s_:5d}: MPJPE {mj:8.3f} +- {sj:6.3f} mm   MPCPE {mc:8.3f} +- {sc:6.3f} mm   (n = {n})")
     if "f32" in out:
+        log("# difference of the means to f32, with the standard error of that difference (sqrt(sd_a^2 / n + sd_b^2 / n))")
         for dt in out:
             if dt == "f32":
                 continue
-            for s in out[dt]["checkpoints"]:
-                dj = out[dt]["checkpoints"][s]["mpjpe_mm"] - out["f32"]["checkpoints"][s]["mpjpe_mm"]
-                dc = out[dt]["checkpoints"][s]["mpcpe_mm"] - out["f32"]["checkpoints"][s]["mpcpe_mm"]
-                log(f"  {dt:7s} - f32 at step {s:5d}: MPJPE {dj:+7.3f} mm   MPCPE {dc:+7.3f} mm")
+            for s_ in sorted(out[dt][0]["checkpoints"]):
+                parts = []
+                for k, name in (("mpjpe_mm", "MPJPE"), ("mpcpe_mm", "MPCPE")):
+                    (ma, sa, n), (mb, sb, _) = stat[(dt, s_, k)], stat[("f32", s_, k)]
+                    se = float(np.sqrt(sa * sa / n + sb * sb / n)) if n > 1 else float("nan")
+                    parts.append(f"{name} {ma - mb:+7.3f} +- {se:5.3f} mm")
+                log(f"  {dt:7s} - f32 at step {s_:5d}: " + "   ".join(parts))
     log(json.dumps(out))
     if a.out:
         with open(a.out, "w") as f:
