@@ -774,8 +774,10 @@ long c3v_frag_bytes(int C, int Cn);
 
 // conv3x3r.hip: 64 -> 64 channels with the weights resident in registers (plain forward / data gradient launches of layer 1)
 int conv3x3r_rows(int N, int H, int W, int C, int Cn);
+int conv3x3rb_rows(int N, int H, int W, int C, int Cn);      // ... and the data gradient with the fused BatchNorm-backward epilogue
 int conv3x3r_run(const void* x_hi, const void* x_lo, const void* wt_hi, const void* wt_lo, float* out, int N, int H, int W, int flip,
-                 float* stats, hipStream_t st);
+                 float* stats, hipStream_t st, const float* bn_y = nullptr, const void* mask = nullptr, const float* addend = nullptr,
+                 const float* bnp = nullptr);
 
 // BatchNorm partial rows of the split-bf16 launches: of a forward / plain launch, and of a data gradient with the fused reduction
 int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn) {
@@ -786,6 +788,7 @@ int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn) {
 }
 int conv3x3_x3_tiles_bnr(int N, int H, int W, int C, int Cn) {
     if (C % 32) return 0;
+    if (int r = conv3x3rb_rows(N, H, W, C, Cn)) return r;
     if (int t = c3v_tiles(N, H, W, C, Cn)) return t;
     return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, false, true), N, H, W);
 }
@@ -801,6 +804,8 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
     // conv + ab_bn_apply_x3 (tests/test_gpu_learner.py::test_eval_forward_with_folded_batchnorm_is_bit_identical)
     if (!bn_y && !ev && !addend && (stats || flip) && conv3x3r_rows(N, H, W, C, Cn))
         return conv3x3r_run(x_hi, x_lo, wt_hi, wt_lo, out, N, H, W, flip, stats, st);
+    if (bn_y && conv3x3rb_rows(N, H, W, C, Cn))      // (conv3x3_x3_tiles_bnr sized bn_part by the same predicate)
+        return conv3x3r_run(x_hi, x_lo, wt_hi, wt_lo, out, N, H, W, flip, bn_part, st, bn_y, bn_out_hi, addend, bnp);
     int cfg = c3_config(N, H, W, (C + 63) / 64 * 64, Cn, /*x3plain=*/!bn_y, /*x3=*/true);
     if (!cfg || Cn % 4) return AB_ESHAPE;
     const long delta = (const char*)wt_lo - (const char*)wt_hi;

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 for v in 0 1; do
 rm -rf /tmp/bnab$v
-AB_BNFIN_FUSE=$v rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bnab$v -o s -- python /root/repo/bench.py --no-cpu-baseline --sustain 0 --no-eval-leg --no-dexycb-leg --no-study-leg --no-jpeg-leg --no-mixed-leg --no-rccl-leg --steps 20 > /dev/null 2>&1
+AB_BNFIN_FUSE=$v rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bnab$v -o s -- python /root/repo/bench.py --no-cpu-baseline --sustain 0 --no-eval-leg --no-dexycb-leg --no-study-leg --no-jpeg-leg --no-mixed-leg --no-rccl-leg --no-dropin-leg --steps 20 > /dev/null 2>&1
 python - <<PY
 import csv, glob
 f = glob.glob('/tmp/bnab$v/**/*kernel_stats.csv', recursive=True)[0]

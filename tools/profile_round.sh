@@ -11,11 +11,11 @@ out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag/stats -o s -- python $root/bench.py --no-cpu-baseline --sustain 0 --no-eval-leg --no-dexycb-leg --no-study-leg --no-jpeg-leg --no-mixed-leg --no-rccl-leg --steps 20 > $out/${tag}_bench_line.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag/stats -o s -- python $root/bench.py --no-cpu-baseline --sustain 0 --no-eval-leg --no-dexycb-leg --no-study-leg --no-jpeg-leg --no-mixed-leg --no-rccl-leg --no-dropin-leg --steps 20 > $out/${tag}_bench_line.txt 2>&1
 cp $(find /tmp/prof_$tag/stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv
 python $root/tools/step_trace.py $(find /tmp/prof_$tag/stats -name "*kernel_trace.csv" | head -1) > $out/${tag}_step_trace.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$tag/$c -o p -- python $root/bench.py --eager --no-cpu-baseline --sustain 0 --no-eval-leg --no-dexycb-leg --no-study-leg --no-jpeg-leg --no-mixed-leg --no-rccl-leg --steps 3 --warmup 1 > /dev/null 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$tag/$c -o p -- python $root/bench.py --eager --no-cpu-baseline --sustain 0 --no-eval-leg --no-dexycb-leg --no-study-leg --no-jpeg-leg --no-mixed-leg --no-rccl-leg --no-dropin-leg --steps 3 --warmup 1 > /dev/null 2>&1
 done
 python $root/tools/pmc_traffic.py $(find /tmp/prof_$tag/FETCH_SIZE -name "*counter_collection.csv" | head -1) \
     $(find /tmp/prof_$tag/WRITE_SIZE -name "*counter_collection.csv" | head -1) $out/${tag}_pmc_hbm_traffic bf16x3

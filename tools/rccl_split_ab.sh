@@ -4,7 +4,7 @@ for i in 1 2 3; do
   for v in base split3 split3_norender unsplit unsplit_norender; do
     cmd="python bench.py --rccl-single-rank"; env="X=1"
     case $v in
-      base) cmd="python bench.py --no-cpu-baseline --sustain 0 --no-eval-leg --no-dexycb-leg --no-study-leg --no-jpeg-leg --no-mixed-leg --no-rccl-leg";;
+      base) cmd="python bench.py --no-cpu-baseline --sustain 0 --no-eval-leg --no-dexycb-leg --no-study-leg --no-jpeg-leg --no-mixed-leg --no-rccl-leg --no-dropin-leg";;
       split3_norender) cmd="$cmd --no-render-overlap";;
       unsplit) env="AB_DDP_SPLIT=0";;
       unsplit_norender) cmd="$cmd --no-render-overlap"; env="AB_DDP_SPLIT=0";;
