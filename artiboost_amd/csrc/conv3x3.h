@@ -1,4 +1,4 @@
-// Shared by conv3x3.hip (LDS weight ring) and conv3x3v.hip (weights streamed L2 -> VGPR in MFMA fragment order).
+// Shared by conv3x3.hip (LDS weight ring) and conv3x3r.hip (weights resident in registers).
 #pragma once
 #include "conv_common.h"
 
@@ -17,12 +17,7 @@ struct Conv3Args {
     // X3 = 3 (eval-mode forward with the BatchNorm that follows folded in): Out / Out_lo are the (hi, lo) planes of
     // relu?(acc * bnp[c] + bnp[Cn + c] + residual); residual = res_hi + res_lo planes, or the fp32 `addend`; OutF (optional) = the fp32 value
     void* Out_lo; const void* res_hi; const void* res_lo; float* OutF; int ep_relu;
-    unsigned long long* dbg; // conv3x3v.hip: per-wave s_memtime stamps (ab_c3v_debug_buffer; NULL: off)
-    const void* Wf;          // conv3x3v.hip: the weights in MFMA fragment order (c3v_pack_kernel), both planes
     int flip;                // 0: tap t reads input (t/3-1, t%3-1); 1 (data gradient): (1-t/3, 1-t%3).  Weight K offset = t*C.
-    // tools/probe_c3fold.hip only (C3_FOLD_PROBE): the input as the fp32 conv output `fold_y` of the layer below + its BatchNorm (scale | shift) in
-    // fold_bnp [2][C] -- the patch is built through registers as the planes of relu(fold_y * scale + shift) instead of being DMA'd from X / X_lo
-    const float* fold_y; const float* fold_bnp;
 };                           // (no per-tap tables: a dynamically indexed kernarg array becomes a VMEM load inside the K loop,
                              //  and the vmcnt wait for it would drain the in-flight LDS-DMA prefetch)
 

@@ -41,17 +41,8 @@ __device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsig
 // epilogue applies them, adds the residual, applies the ReLU and writes the next convolution's operand planes directly -- with
 // the same expression order as bn_apply_x3_kernel (norm_pool.hip), i.e. bit-identical to conv + separate apply pass.  The fp32
 // conv output is never stored (no BatchNorm partials either).
-#ifndef C3_FOLD_PROBE
-#define C3_FOLD_PROBE 0
-#endif
-#if C3_FOLD_PROBE
-static const float* g_c3_fold_y = nullptr; static const float* g_c3_fold_bnp = nullptr;      // set by tools/probe_c3fold.hip around its launches
-#endif
-// EP (X3 = 2 only): which epilogue operands are requested at kernel entry and held in registers over the K loop -- 2: all (bn_y, mask, addend),
-// 1: bn_y only, 0: none (read in the epilogue).  EP < 2 also asks for four waves per SIMD (two 8-wave workgroups per CU), so that one
-// workgroup's epilogue traffic runs under the other's K loop instead of every CU alternating between the two in lock step.
-template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0, int EP = 2>
-__global__ __launch_bounds__(64 * WM * WN, (X3 == 2 && EP < 2) ? 4 : 1) void conv3x3_kernel(Conv3Args g) {
+template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0>
+__global__ __launch_bounds__(64 * WM * WN) void conv3x3_kernel(Conv3Args g) {
     constexpr bool BNR = X3 == 2;
     constexpr int CK = X3 ? 32 : 64;                   // channels per K chunk
     // NW = WM*WN waves (4 or 8).  Measured (tools/probe_fill.hip): a wave pulls ~10 GB/s of L2-resident data into LDS
@@ -98,8 +89,12 @@ __global__ __launch_bounds__(64 * WM * WN, (X3 == 2 && EP < 2) ? 4 : 1) void con
 
     // ---- X3 = 2: this thread's share of the BatchNorm operands of the epilogue (rows er0 + k*ERS, channels ec4*4 .. +3)
     constexpr int ECPR = BN / 4, ERS = NT / ECPR, ER = BNR ? BM / ERS : 1;
-    constexpr bool EPRE = BNR && ER <= 8 && EP >= 1;    // held in registers from here on (the 256-pixel tile has none to spare)
-    constexpr bool EPRE2 = EPRE && EP >= 2;             // ... mask and addend too
+    // held in registers from here on (the 256-pixel x 128-channel tile has none to spare).  Round 6 probe, closed: on layer 1's 128-pixel
+    // tile, prefetching nothing (96 VGPRs) or bn_y only (126) so that TWO workgroups share a CU and one's epilogue runs under the other's
+    // K loop: 85 - 88 / 98 us against 92 / 104 us (no residual / residual) -- 1.06 x, below the 1.15 x bar; the launches moved to
+    // conv3x3r.hip's persistent kernel instead (64 / 87 us)
+    constexpr bool EPRE = BNR && ER <= 8;
+    constexpr bool EPRE2 = EPRE;
     const int ec4 = tid % ECPR, er0 = tid / ECPR;
     float4 e_y[EPRE ? ER : 1], e_add[EPRE2 ? ER : 1];
     uint2 e_m[EPRE2 ? ER : 1];
@@ -198,67 +193,6 @@ __global__ __launch_bounds__(64 * WM * WN, (X3 == 2 && EP < 2) ? 4 : 1) void con
         }
     };
 
-#if C3_FOLD_PROBE
-    // ---- review item 2 of round 4, as a probe: the BatchNorm apply of the layer below folded into this kernel's patch fill.  A task = one patch
-    // pixel x 8 channels: two 16-byte loads of the fp32 conv output, relu(y * scale + shift), split into (hi, lo) and two 16-byte LDS stores
-    // at the slots the DMA fill would have written.  Loads are asm (counted by the K loop's vmcnt like the DMA they replace).
-    constexpr int LG = (NPIX * 4 + NT - 1) / NT, NG = 2 * LG + 4;
-    const bool folding = X3 == 1 && g.fold_y != nullptr;
-    const float* f_src[LG]; bool f_in[LG]; unsigned f_hi[LG], f_lo[LG];
-    const int f_cg = lane & 3;
-#pragma unroll
-    for (int j = 0; j < LG; ++j) {
-        const int tk = (wave * LG + j) * 64 + lane, pp = tk >> 2;
-        const int py = pp / PW, px = pp - py * PW;
-        const int y = ty0 + py - 1, x = tx0 + px - 1;
-        f_in[j] = pp < NPIX;
-        const bool ok = f_in[j] && (unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W;
-        f_src[j] = ok ? g.fold_y + ((((long)img * g.H + y) * g.W + x) * g.C + f_cg * 8) : nullptr;
-        const int key = TW == 8 ? (((px >> 1) & 3) | ((py & 1) << 2)) : ((px >> 1) & 7);
-        f_hi[j] = pp * 128 + ((f_cg ^ key) << 4); f_lo[j] = pp * 128 + (((f_cg | 4) ^ key) << 4);
-    }
-    u32x4 gy[LG][2], gp[4];
-    auto fold_issue = [&](int chunk) {
-#pragma unroll
-        for (int j = 0; j < LG; ++j) {
-            const float* s = f_src[j] ? f_src[j] + chunk * CK : (const float*)zp;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gy[j][0]) : "v"(s) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gy[j][1]) : "v"(f_src[j] ? s : (const float*)zp - 4) : "memory");
-        }
-        const float* ps = g.fold_bnp + chunk * CK + f_cg * 8;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gp[0]) : "v"(ps) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gp[1]) : "v"(ps) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gp[2]) : "v"(ps + g.C) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(gp[3]) : "v"(ps + g.C) : "memory");
-    };
-    auto fold_store = [&](int pbuf) {          // (call behind a vmcnt wait that covers the loads of fold_issue)
-#pragma unroll
-        for (int j = 0; j < LG; ++j) asm volatile("" : "+v"(gy[j][0]), "+v"(gy[j][1]));
-        asm volatile("" : "+v"(gp[0]), "+v"(gp[1]), "+v"(gp[2]), "+v"(gp[3]));
-        float sc[8], sh[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { sc[k] = __uint_as_float(gp[0][k]); sc[4 + k] = __uint_as_float(gp[1][k]); sh[k] = __uint_as_float(gp[2][k]); sh[4 + k] = __uint_as_float(gp[3][k]); }
-#pragma unroll
-        for (int j = 0; j < LG; ++j) {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v[k] = __uint_as_float(gy[j][0][k]); v[4 + k] = __uint_as_float(gy[j][1][k]); }
-            u32x4 h, l;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float a = f_src[j] ? fmaxf(v[2 * k] * sc[2 * k] + sh[2 * k], 0.f) : 0.f, b = f_src[j] ? fmaxf(v[2 * k + 1] * sc[2 * k + 1] + sh[2 * k + 1], 0.f) : 0.f;
-                h[k] = pack_bf16x2(a, b);
-                l[k] = pack_bf16x2(a - __uint_as_float(h[k] << 16), b - __uint_as_float(h[k] & 0xffff0000u));
-            }
-            if (f_in[j]) {
-                *(u32x4*)(smem + PATCH0 + pbuf * PATCH_BYTES + f_hi[j]) = h;
-                *(u32x4*)(smem + PATCH0 + pbuf * PATCH_BYTES + f_lo[j]) = l;
-            }
-        }
-    };
-#else
-    constexpr int NG = 0; const bool folding = false;
-#endif
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -281,10 +215,6 @@ __global__ __launch_bounds__(64 * WM * WN, (X3 == 2 && EP < 2) ? 4 : 1) void con
 
     // ---- software pipeline.  Issue order: P(0) B(0,0) B(0,1) | per step s after its barrier: B(s+2), and at tap 0
     // of chunk c also P(c+1).  All loads are inline asm (invisible to hipcc's wait counting): the waits below are exact.
-#if C3_FOLD_PROBE
-    if (folding) { fold_issue(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fold_store(0); }
-    else
-#endif
     issue_patch(0, 0);
     issue_b(0, 0, 0);
     issue_b(0, 1, 1);
@@ -296,7 +226,6 @@ __global__ __launch_bounds__(64 * WM * WN, (X3 == 2 && EP < 2) ? 4 : 1) void con
             // loads issued after B(step): B(step+1) [+ P(chunk+1) for t == 1, 2]
             const bool last = !more && t == 8;
             if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if ((t == 1 || t == 2) && more && folding) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB + NG) : "memory");
             else if ((t == 1 || t == 2) && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB + LP) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // WAR on the ring stage restaged below: see conv_gemm2.hip
@@ -304,12 +233,6 @@ __global__ __launch_bounds__(64 * WM * WN, (X3 == 2 && EP < 2) ? 4 : 1) void con
             asm volatile("" ::: "memory");
             if (t + 2 < 9) issue_b(chunk, t + 2, (t + 2) % 3);
             else if (more) issue_b(chunk + 1, t + 2 - 9, (t + 2) % 3);
-#if C3_FOLD_PROBE
-            if (folding) {
-                if (t == 0 && more) fold_issue(chunk + 1);
-                if (t == 3 && more) fold_store((chunk + 1) & 1);       // (the wait of step 3 left only B(4) in flight)
-            } else
-#endif
             if (t == 0 && more) issue_patch(chunk + 1, (chunk + 1) & 1);
             const int t3 = t / 3, tr = t % 3;
             const int dh = FLIP ? 2 - t3 : t3, dw = FLIP ? 2 - tr : tr;     // compile-time per unrolled tap
@@ -694,7 +617,7 @@ int conv3x3_tiles(int N, int H, int W, int C, int Cn) {
     return N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
 }
 
-template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0, int EP = 2>
+template <int BM, int TW, int BN, int WM, int WN, int FLIP, int X3 = 0>
 static int c3_launch(Conv3Args& g, hipStream_t st) {
     constexpr int TH = BM / TW;
     if constexpr (TW == 8 && BM == 128) { g.N /= 2; g.H = 16; }        // two 8 x 8 images as one 16-row image: the same bytes
@@ -703,12 +626,12 @@ static int c3_launch(Conv3Args& g, hipStream_t st) {
     size_t lds = c3_lds<BM, TW, BN, WM, WN, X3>(g.C / (X3 ? 32 : 64));
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<BM, TW, BN, WM, WN, FLIP, X3, EP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<BM, TW, BN, WM, WN, FLIP, X3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)c3_lds<BM, TW, BN, WM, WN, X3>(2));
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    conv3x3_kernel<BM, TW, BN, WM, WN, FLIP, X3, EP><<<blocks, 64 * WM * WN, lds, st>>>(g);
+    conv3x3_kernel<BM, TW, BN, WM, WN, FLIP, X3><<<blocks, 64 * WM * WN, lds, st>>>(g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -765,13 +688,6 @@ static int c3_tiles_of(int cfg, int N, int H, int W) {
     return N * ((H + th - 1) / th) * ((W + tw - 1) / tw);
 }
 
-// conv3x3v.hip: weights streamed L2 -> VGPR in fragment order
-int c3v_config(int N, int H, int W, int C, int Cn);
-int c3v_tiles(int N, int H, int W, int C, int Cn);
-int c3v_run(Conv3Args& g, int x3, hipStream_t st);
-int c3v_pack(const void* w_hi, const void* w_lo, int C, int Cn, void* out, hipStream_t st);
-long c3v_frag_bytes(int C, int Cn);
-
 // conv3x3r.hip: 64 -> 64 channels with the weights resident in registers (plain forward / data gradient launches of layer 1)
 int conv3x3r_rows(int N, int H, int W, int C, int Cn);
 int conv3x3rb_rows(int N, int H, int W, int C, int Cn);      // ... and the data gradient with the fused BatchNorm-backward epilogue
@@ -783,13 +699,11 @@ int conv3x3r_run(const void* x_hi, const void* x_lo, const void* wt_hi, const vo
 int conv3x3_x3_tiles(int N, int H, int W, int C, int Cn) {
     if (C % 32) return 0;
     if (int r = conv3x3r_rows(N, H, W, C, Cn)) return r;
-    if (int t = c3v_tiles(N, H, W, C, Cn)) return t;
     return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, true, true), N, H, W);
 }
 int conv3x3_x3_tiles_bnr(int N, int H, int W, int C, int Cn) {
     if (C % 32) return 0;
     if (int r = conv3x3rb_rows(N, H, W, C, Cn)) return r;
-    if (int t = c3v_tiles(N, H, W, C, Cn)) return t;
     return c3_tiles_of(c3_config(N, H, W, (C + 63) / 64 * 64, Cn, false, true), N, H, W);
 }
 
@@ -814,28 +728,8 @@ int conv3x3_x3_run(const void* x_hi, const void* x_lo, const void* wt_hi, const 
     g.X = x_hi; g.X_lo = x_lo; g.Wt = wt_hi; g.wlo_delta = (unsigned)delta; g.Out = out; g.addend = addend; g.stats = stats;
     g.N = N; g.H = H; g.W = W; g.C = C; g.Cn = Cn; g.ktot = 9 * C; g.flip = flip;
     g.bn_y = bn_y; g.bn_out = bn_out_hi; g.bnp = bnp; g.bn_part = bn_part;
-#if C3_FOLD_PROBE
-    g.fold_y = g_c3_fold_y; g.fold_bnp = g_c3_fold_bnp;
-#endif
     if (ev) { g.Out = ev->out_hi; g.Out_lo = ev->out_lo; g.OutF = ev->out_f32; g.res_hi = ev->res_hi; g.res_lo = ev->res_lo; g.ep_relu = ev->relu; }
-    if (c3v_config(N, H, W, C, Cn)) {
-        // Opt-in probe (AB_C3V=1, round 4): the second-generation K loop of conv3x3v.hip.  Its fragment-ordered weight
-        // copy is re-packed into a process-wide scratch buffer on EVERY call (one more ~6 us launch, single stream only): the probe
-        // did not clear its kill criterion, so the copy was never moved into the optimizer's refresh pass.
-        static void* scratch = nullptr; static long scratch_bytes = 0;
-        const long need = c3v_frag_bytes(C, Cn);
-        if (need > scratch_bytes) { if (scratch) (void)hipFree(scratch); if (hipMalloc(&scratch, need) != hipSuccess) return AB_EINVAL; scratch_bytes = need; }
-        int rc = c3v_pack(wt_hi, wt_lo, C, Cn, scratch, st);
-        if (rc) return rc;
-        g.Wf = scratch;
-        return c3v_run(g, bn_y ? 2 : (ev ? 3 : 1), st);
-    }
     if (bn_y) {      // masked gradient + BatchNorm-backward partials from the epilogue
-        static const int l1ep = getenv("AB_C3_L1EP") ? atoi(getenv("AB_C3_L1EP")) : -1;      // probe: 128-pixel tile, EP = 0 | 1, two workgroups per CU
-        if (l1ep >= 0 && Cn == 64 && C == 64 && W % 16 == 0 && H % 8 == 0) {
-            if (l1ep == 0) return c3_launch<128, 16, 64, 4, 2, 1, 2, 0>(g, st);
-            return c3_launch<128, 16, 64, 4, 2, 1, 2, 1>(g, st);
-        }
         if (cfg == 1) return c3_launch<128, 32, 64, 4, 2, 1, 2>(g, st);
         if (cfg == 2) return c3_launch<256, 32, 128, 4, 2, 1, 2>(g, st);
         if (cfg == 3) return c3_launch<128, 16, 128, 4, 2, 1, 2>(g, st);

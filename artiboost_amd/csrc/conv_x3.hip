@@ -117,6 +117,12 @@ static int fwd_x3_impl(const void* x_hi, const void* x_lo, const void* w_hi, con
         int rc = convp_s2fwd_run(x_hi, x_lo, w_hi, w_lo, y, N, H, W, Cin, Cout, stats, as_stream(stream), ep_scale, bias, relu, out_hi, out_lo);
         if (rc != AB_ESHAPE) return rc;
     }
+    // The generic kernel writes one partial row per M tile.  `stats` was sized by ab_conv2d_x3_stat_rows, which describes the kernel a launch
+    // WITHOUT bias / relu takes; a launch that asks for statistics AND a bias or ReLU on a shape the specialised kernels own (3x3/s1, 3x3/s2,
+    // 4x4/s2) lands here with another row count -- refuse instead of writing past the caller's buffer (no model path issues such a launch)
+    if (stats && conv_gemm2_x3_mtiles(N * ((H + 2 * pad - kh) / stride + 1) * ((W + 2 * pad - kw) / stride + 1), Cout, kh * kw * (Cin / 32), 0) !=
+                     ab_conv2d_x3_stat_rows(N, H, W, Cin, Cout, kh, kw, stride, pad))
+        return AB_EINVAL;
     ConvGemmArgs g = {};
     g.A = x_hi; g.A_lo = x_lo; g.Bw = w_hi; g.Bw_lo = w_lo; g.Out = y; g.bias = bias; g.stats = stats; g.relu = relu;
     g.ep_scale = ep_scale; g.out_hi = out_hi; g.out_lo = out_lo;

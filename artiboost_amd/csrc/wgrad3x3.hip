@@ -30,16 +30,7 @@ struct Wg3Args {
     int N, H, Cin, Cout;
     int bands_per_slice, nbands;
     int xcd_map;                // workgroups renumbered slice-major per XCD (conv_common.h)
-    // tools/probe_wg3fan.hip only (WG3_FANIN_PROBE): per-tile arrival counters (zero before the first launch; the last arriver resets its own)
-    // and the gradient [Cout][9][Cin] the last-arriving workgroup of a tile writes after summing the tile's slabs in slice order
-    int* fan_counter; float* fan_out;
 };
-#ifndef WG3_FANIN_PROBE
-#define WG3_FANIN_PROBE 0
-#endif
-#if WG3_FANIN_PROBE
-static int* g_wg3_fan_counter = nullptr; static float* g_wg3_fan_out = nullptr;
-#endif
 
 __device__ __forceinline__ uint4 tr_pair(unsigned addr_lo, unsigned addr_hi) {
     short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(size_t)addr_lo);
@@ -259,35 +250,6 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
             out[(long)row * jt + col] = acc[tt][r];
         }
     }
-#if WG3_FANIN_PROBE
-    // ---- review item 3 of round 4 as a probe: publish the slab (agent-scope release), take a ticket of the tile, and the LAST arriver sums the
-    // tile's slabs in slice order (fixed order: bit-identical to wgrad_reduce's result is not required of a probe, determinism is) and writes
-    // the gradient -- no reduction launch.
-    if (g.fan_counter) {
-        volatile int* fan_last = (volatile int*)smem;       // (the band buffers are done with; some geometries use all 160 KB: no static LDS)
-        __threadfence();
-        __syncthreads();
-        if (tid == 0) *fan_last = atomicAdd(&g.fan_counter[bx], 1) == (int)gridDim.y - 1;
-        __syncthreads();
-        if (*fan_last) {
-            __threadfence();                                   // acquire: the other slices' slabs
-            const long slab = (long)g.Cout * jt;
-            const int ns = gridDim.y;
-            constexpr int NTH = 64 * NW;
-            for (int e = tid; e < 64 * 9 * 16; e += NTH) {        // 64 rows x 9 taps x 16 quads of this tile
-                const int row = e / 144, rem = e - row * 144, tap = rem / 16, q = rem - tap * 16;
-                const long o = (long)(co0 + row) * jt + tap * g.Cin + ci0 + q * 4;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int k = 0; k < ns; ++k) {
-                    const float4 v = *(const float4*)(g.slabs + k * slab + o);
-                    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-                }
-                *(float4*)(g.fan_out + o) = t;
-            }
-            if (tid == 0) g.fan_counter[bx] = 0;
-        }
-    }
-#endif
 }
 
 template <int W, int TH, int NW, int X3 = 0>
@@ -309,9 +271,6 @@ static int wg3_launch(Wg3Args& g, int tiles, int nslices, hipStream_t st) {
     }
     static const int xcd = getenv("AB_WG_XCD") ? atoi(getenv("AB_WG_XCD")) : 1;
     g.xcd_map = xcd;
-#if WG3_FANIN_PROBE
-    g.fan_counter = g_wg3_fan_counter; g.fan_out = g_wg3_fan_out;
-#endif
     static const int pin = getenv("AB_WG3_PIN") ? atoi(getenv("AB_WG3_PIN")) : 1;      // 9.08 -> 9.02 ms per step over two alternating pairs (round 5)
     bool launched = false;
     if constexpr (X3 != 0) { if (pin) { wgrad3x3_kernel<W, TH, NW, X3, true><<<dim3(tiles, nslices), 64 * NW, lds, st>>>(g); launched = true; } }

@@ -597,10 +597,10 @@ class HybridNet:
         # bf16x3, softmax head: the final layer as the register-resident GEMM with the soft-argmax's first stage in its epilogue
         # (ab_conv1x1_sam_fwd_x3); head_fwd() then only merges the per-tile rows
         wf = self.w(hp + ".final_layer.weight") if self.x3 else None
-        self._sam_part = None
+        sam_part = None          # (travels in self.last with the logits it describes: segment graphs swap `last`, not attributes of the net)
         if (self.x3 and self.fuse_sam and self.norm == 0
                 and K.conv1x1_sam_fwd_x3_ok(e2, wf, p.nclasses_pad, p.depth, DEPTH_PITCH)):
-            logits, self._sam_part = K.conv1x1_sam_fwd_x3(e2, wf, p.view(hp + ".final_layer.bias"), p.nclasses_pad, p.depth)
+            logits, sam_part = K.conv1x1_sam_fwd_x3(e2, wf, p.view(hp + ".final_layer.bias"), p.nclasses_pad, p.depth)
         else:
             logits = self._conv_fwd(e2, hp + ".final_layer.weight", 1, 0, bias=p.view(hp + ".final_layer.bias"))
         # ---- MLP_O box head, always f32 (tiny; keeps the 6-D rotation at full precision)
@@ -616,7 +616,7 @@ class HybridNet:
         box6d = b3.view(N, BOX_OUT_PAD)[:, :6]
         S.update(feat=feat, d1=d1, e1=e1, bnpd1=bnpd1, d2=d2, e2=e2, bnpd2=bnpd2, logits=logits, m0=m0, b1=b1, b2=b2)
         self.saved = S if tr else None
-        self.last = dict(feat=feat, fmean=fmean, logits=logits, box_raw=b3.view(N, BOX_OUT_PAD))
+        self.last = dict(feat=feat, fmean=fmean, logits=logits, box_raw=b3.view(N, BOX_OUT_PAD), sam_part=sam_part)
         return logits, box6d
 
     eval_fold = os.environ.get("AB_EVAL_FOLD", "1") != "0"       # bf16x3 eval: BatchNorm folded into the 3x3 conv epilogues
@@ -693,9 +693,9 @@ class HybridNet:
 
     def head_fwd(self, logits):
         """-> kp3d [N,22,3], conf [N,22], stat (kept for head_bwd)."""
-        part = getattr(self, "_sam_part", None)
         last = getattr(self, "last", None)
-        if part is not None and last is not None and logits is last.get("logits"):      # statistics from the GEMM epilogue of THIS forward
+        part = last.get("sam_part") if last is not None and logits is last.get("logits") else None
+        if part is not None and part.shape[0] == logits.shape[0]:      # statistics from the GEMM epilogue of THIS forward
             kp3d, conf, stat = softargmax3d_stage2(part, self.p.nclasses_pad)
         else:
             kp3d, conf, stat = softargmax3d_fwd(logits, self.p.nclasses_pad, self.p.depth, DEPTH_PITCH, self.norm)

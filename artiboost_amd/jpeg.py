@@ -231,10 +231,14 @@ class JpegDecoder:
         self._pins, self._evs, self._k = [None, None], [None, None], 0      # two pinned staging blobs, reused alternately
         self._dev_blob = self._ws = None
 
-    def decode(self, files, out=None, channels=4, infos=None):
+    def decode(self, files, out=None, channels=4, infos=None, timing=None):
         """files: bytes-like JPEG files.  out: uint8 device tensor [n, H, W, channels] every file must fit exactly (as the frames of one
         dataset do), or None: a list of [H_i, W_i, channels] tensors (views of one allocation) is returned.  Raises JpegUnsupported (before
-        any device work) if a file is outside what the kernels cover."""
+        any device work) if a file is outside what the kernels cover.
+        timing: a dict that receives this call's split -- "host_s" (marker walk if infos is None, plan, pack into the pinned blob: host time
+        before any device work is enqueued) and "events" (a HIP event pair around the upload + ab_jpeg_decode_batch on the current stream)."""
+        import time
+        t_host0 = time.perf_counter()
         n = len(files)
         infos = infos or [parse(f) for f in files]
         if out is not None:
@@ -266,6 +270,10 @@ class JpegDecoder:
         if self._evs[k] is not None:
             self._evs[k].synchronize()          # the upload that last read this staging blob (two calls ago) has finished
         offs, used = plan.pack(files, self._pins[k].numpy())
+        if timing is not None:
+            timing["host_s"] = time.perf_counter() - t_host0
+            timing["events"] = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            timing["events"][0].record()
         self._dev_blob[:used].copy_(self._pins[k][:used], non_blocking=True)
         self._evs[k] = torch.cuda.Event()
         self._evs[k].record()
@@ -283,6 +291,8 @@ class JpegDecoder:
                                          L.i(plan.max_w), L.i(plan.max_h), L.i(plan.max_sub), L.i(channels), L.view_ptr(out), L.ptr(self._ws), L.stream()),
                 "ab_jpeg_decode_batch")
         self._last = (plan.total_blocks, plan.total_sub, plan.plane_bytes, plan.data_bytes, nseg, n)
+        if timing is not None:
+            timing["events"][1].record()
         return res
 
     R_MAX = 16          # csrc/jpeg.hip

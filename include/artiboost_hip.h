@@ -141,6 +141,9 @@ int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw, int dtype,
  * Same layouts and meanings as ab_conv2d_fwd / _dgrad / _wgrad; Cin (fwd) / Cout (dgrad) % 32 == 0, wgrad: both % 64.
  * w_lo must lie 0 .. 2^31-1 bytes after w_hi (both planes of one allocation).                                       */
 int ab_split_f32(const float* src, long n, void* hi, void* lo, void* stream);          /* n % 8 == 0 */
+/* rows of BatchNorm partials a forward WITHOUT bias / relu writes for this shape (the specialised 3x3/s1, 3x3/s2 and 4x4/s2 kernels write one
+ * row per tile of theirs).  ab_conv2d_fwd_x3 with stats AND a bias or ReLU runs the generic kernel, whose row count may differ on those
+ * shapes: it then returns AB_EINVAL instead of writing past a buffer sized by this function.                                            */
 int ab_conv2d_x3_stat_rows(int N, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int pad);
 int ab_conv2d_fwd_x3(const void* x_hi, const void* x_lo, const void* w_hi, const void* w_lo, float* y, int N, int H, int W,
                      int Cin, int Cout, int kh, int kw, int stride, int pad, const float* bias, float* stats, int relu,
