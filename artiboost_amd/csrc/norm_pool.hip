@@ -863,18 +863,6 @@ __global__ __launch_bounds__(256) void bn_fin_apply_x3_kernel(BnFinArgs fa, cons
     __shared__ float par[2][BNFIN_SLICE];
     const int nsl = C / BNFIN_SLICE, slice = blockIdx.x % nsl, strip = blockIdx.x / nsl, nstrips = gridDim.x / nsl;
     const int c0 = slice * BNFIN_SLICE;
-    // Round 6: the operands of the FIRST pass are requested before the finalize prologue (a workgroup makes one or two passes on layers 3 - 4:
-    // the prologue -- a dependent chain of partial-row loads, a barrier, the parameter arithmetic, another barrier -- used to run with the
-    // memory system idle, then the body started cold).  Their latency now runs under the prologue.
-    const int j = threadIdx.x & 7, pl = threadIdx.x >> 3;             // 8 channel groups of a pixel, 32 pixels per pass
-    const long p_first = (long)strip * 32 + pl;
-    float f0[8], r0[8]; uint4 h0 = make_uint4(0, 0, 0, 0), l0 = h0;
-    if (p_first < M) {
-        const long e = p_first * C + c0 + j * 8;
-        load8(y + e, f0);
-        if constexpr (RES == 1) { h0 = *(const uint4*)(res_hi + e); l0 = *(const uint4*)(res_lo + e); }
-        else if (res) load8(res + e, r0);
-    }
     double s, q; bnfin_reduce(fa.part, fa.nparts, C, c0, sm, s, q);
     if (threadIdx.x < 64) {
         const int c = c0 + threadIdx.x;
@@ -894,6 +882,7 @@ __global__ __launch_bounds__(256) void bn_fin_apply_x3_kernel(BnFinArgs fa, cons
         }
     }
     __syncthreads();
+    const int j = threadIdx.x & 7, pl = threadIdx.x >> 3;             // 8 channel groups of a pixel, 32 pixels per pass
     float sc[8], sh[8], sc2[RES == 2 ? 8 : 1], sh2[RES == 2 ? 8 : 1];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sc[k] = par[0][j * 8 + k]; sh[k] = par[1][j * 8 + k]; }
@@ -901,27 +890,19 @@ __global__ __launch_bounds__(256) void bn_fin_apply_x3_kernel(BnFinArgs fa, cons
 #pragma unroll
         for (int k = 0; k < 8; ++k) { sc2[k] = res_bnp[c0 + j * 8 + k]; sh2[k] = res_bnp[C + c0 + j * 8 + k]; }
     }
-    for (long p = p_first; p < M; p += (long)nstrips * 32) {
+    for (long p = (long)strip * 32 + pl; p < M; p += (long)nstrips * 32) {
         const long e = p * C + c0 + j * 8;
         float f[8], r[8];
-        uint4 h4, l4;
-        if (p == p_first) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { f[k] = f0[k]; r[k] = r0[k]; }
-            h4 = h0; l4 = l0;
-        } else {
-            load8(y + e, f);
-            if constexpr (RES == 1) { h4 = *(const uint4*)(res_hi + e); l4 = *(const uint4*)(res_lo + e); }
-            else if (res) load8(res + e, r);
-        }
+        load8(y + e, f);
         if constexpr (RES == 1) {
+            const uint4 h4 = *(const uint4*)(res_hi + e), l4 = *(const uint4*)(res_lo + e);
             const uint32_t hw[4] = {h4.x, h4.y, h4.z, h4.w}, lw[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 r[2 * k] = __uint_as_float(hw[k] << 16) + __uint_as_float(lw[k] << 16);
                 r[2 * k + 1] = __uint_as_float(hw[k] & 0xffff0000u) + __uint_as_float(lw[k] & 0xffff0000u);
             }
-        }
+        } else if (res) load8(res + e, r);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float v = f[k] * sc[k] + sh[k];
@@ -946,15 +927,6 @@ __global__ __launch_bounds__(256) void bn_fin_bwd_apply_x3_kernel(const float* _
     __shared__ float par[2][BNFIN_SLICE];
     const int nsl = C / BNFIN_SLICE, slice = blockIdx.x % nsl, strip = blockIdx.x / nsl, nstrips = gridDim.x / nsl;
     const int c0 = slice * BNFIN_SLICE;
-    const int j = threadIdx.x & 7, pl = threadIdx.x >> 3;
-    const long p_first = (long)strip * 32 + pl;          // the first pass's operands are requested before the prologue (see bn_fin_apply_x3_kernel)
-    float g0[8], o0[8], y0[8]; uint4 oh0 = make_uint4(0, 0, 0, 0);
-    if (p_first < M) {
-        const long e = p_first * C + c0 + j * 8;
-        load8(dout + e, g0);
-        load8(y + e, y0);
-        if (relu == 1) { if (out_hi) oh0 = *(const uint4*)(out_hi + e); else load8(out + e, o0); }
-    }
     double s, q; bnfin_reduce(part, nparts, C, c0, sm, s, q);
     if (threadIdx.x < 64) {
         par[0][threadIdx.x] = (float)s; par[1][threadIdx.x] = (float)q;
@@ -965,6 +937,7 @@ __global__ __launch_bounds__(256) void bn_fin_bwd_apply_x3_kernel(const float* _
     }
     __syncthreads();
     const float invM = 1.f / (float)M;
+    const int j = threadIdx.x & 7, pl = threadIdx.x >> 3;
     float ga[8], sh[8], mu[8], is[8], k1[8], k2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -972,23 +945,18 @@ __global__ __launch_bounds__(256) void bn_fin_bwd_apply_x3_kernel(const float* _
         ga[k] = bnp[c]; sh[k] = bnp[C + c]; mu[k] = bnp[2 * C + c]; is[k] = bnp[3 * C + c];
         k1[k] = par[0][j * 8 + k] * invM; k2[k] = par[1][j * 8 + k] * invM;
     }
-    for (long p = p_first; p < M; p += (long)nstrips * 32) {
+    for (long p = (long)strip * 32 + pl; p < M; p += (long)nstrips * 32) {
         const long e = p * C + c0 + j * 8;
         float g[8], o[8], yy[8], d[8];
-        uint4 h;
-        if (p == p_first) {
+        load8(dout + e, g);
+        load8(y + e, yy);
+        if (relu == 1) {
+            if (out_hi) {
+                const uint4 h = *(const uint4*)(out_hi + e);
+                const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { g[k] = g0[k]; yy[k] = y0[k]; o[k] = o0[k]; }
-            h = oh0;
-        } else {
-            load8(dout + e, g);
-            load8(y + e, yy);
-            if (relu == 1) { if (out_hi) h = *(const uint4*)(out_hi + e); else load8(out + e, o); }
-        }
-        if (relu == 1 && out_hi) {
-            const uint32_t hw[4] = {h.x, h.y, h.z, h.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { o[2 * k] = __uint_as_float(hw[k] << 16); o[2 * k + 1] = __uint_as_float(hw[k] & 0xffff0000u); }
+                for (int k = 0; k < 4; ++k) { o[2 * k] = __uint_as_float(hw[k] << 16); o[2 * k + 1] = __uint_as_float(hw[k] & 0xffff0000u); }
+            } else load8(out + e, o);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
