@@ -194,6 +194,12 @@ class WgradReduceDesc(ctypes.Structure):
                 ("src_j", ctypes.c_int), ("dst_j", ctypes.c_int), ("accumulate", ctypes.c_int), ("stem_mask", ctypes.c_int)]
 
 
+class WgradGroupItem(ctypes.Structure):
+    """struct ab_wgrad_group_item (include/artiboost_hip.h)."""
+    _fields_ = [("x_hi", ctypes.c_void_p), ("x_lo", ctypes.c_void_p), ("dy_hi", ctypes.c_void_p), ("dy_lo", ctypes.c_void_p),
+                ("dw", ctypes.c_void_p)]
+
+
 class SymCorner(ctypes.Structure):
     """struct ab_symcorner (include/artiboost_hip.h)."""
     _fields_ = [("R", ctypes.c_void_p), ("t", ctypes.c_void_p), ("K", ctypes.c_int32), ("obj_idx", ctypes.c_void_p),

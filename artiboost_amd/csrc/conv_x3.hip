@@ -20,6 +20,9 @@ int conv_gemm2_x3_run(ConvGemmArgs& g, hipStream_t st);
 int wgrad3x3_x3_slices(int N, int H, int W, int Cin, int Cout);
 int wgrad3x3_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N, int H, int W,
                     int Cin, int Cout, hipStream_t st);
+int wgrad3x3_x3_group_slices(int G, int N, int H, int W, int Cin, int Cout);
+int wgrad3x3_x3_group_run(int G, const void* const* x_hi, const void* const* x_lo, const void* const* dy_hi, const void* const* dy_lo,
+                          float* const* slabs, int N, int H, int W, int Cin, int Cout, hipStream_t st);
 int wgrad_gemm2_x3_slices(int M, int Cout, int Cin, int ntaps);
 int wgrad_gemm2_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N, int H, int W,
                        int Cin, int Cout, int kh, int kw, int stride, int pad, hipStream_t st);
@@ -368,6 +371,34 @@ extern "C" long ab_conv2d_wgrad_x3_workspace(int N, int H, int W, int Cin, int C
     while ((long)n * Mi >= X3_WGRAD_MAX_M_FWD && n > 1) n = n - n / 2;       // the larger half of ab_conv2d_wgrad_x3's batch split
     int ns = wgrad_gemm2_x3_slices((int)(n * Mi), Cout, Cin, kh * kw);
     return ns > 0 ? ns * slab : 0;
+}
+
+// ---- G same-shape 3x3 / stride 1 / pad 1 weight gradients in ONE slab launch + ONE reduction launch (round 6).  The results are those of G
+// ab_conv2d_wgrad_x3 calls up to the summation order over pixel slices (each problem has 1 / G of the slices of its own launch).
+extern "C" long ab_conv2d_wgrad_x3_group_workspace(int G, int N, int H, int W, int Cin, int Cout) {
+    const int ns = wgrad3x3_x3_group_slices(G, N, H, W, Cin, Cout);
+    return ns > 0 ? (long)G * ns * Cout * 9 * Cin * 4 : 0;
+}
+extern "C" int ab_conv2d_wgrad_x3_group(const ab_wgrad_group_item* items_host, int G, int N, int H, int W, int Cin, int Cout, void* workspace,
+                                        int accumulate, void* stream) {
+    if (!items_host || !workspace || G < 1 || G > AB_WGRAD_GROUP_MAX) return AB_EINVAL;
+    const int ns = wgrad3x3_x3_group_slices(G, N, H, W, Cin, Cout);
+    if (!ns) return AB_ESHAPE;
+    const long slab = (long)Cout * 9 * Cin;
+    const void* xh[AB_WGRAD_GROUP_MAX]; const void* xl[AB_WGRAD_GROUP_MAX]; const void* dh[AB_WGRAD_GROUP_MAX]; const void* dl[AB_WGRAD_GROUP_MAX];
+    float* sl[AB_WGRAD_GROUP_MAX];
+    ab_wgrad_reduce_desc d[AB_WGRAD_GROUP_MAX];
+    for (int p = 0; p < G; ++p) {
+        const ab_wgrad_group_item& it = items_host[p];
+        if (!it.x_hi || !it.x_lo || !it.dy_hi || !it.dy_lo || !it.dw) return AB_EINVAL;
+        xh[p] = it.x_hi; xl[p] = it.x_lo; dh[p] = it.dy_hi; dl[p] = it.dy_lo; sl[p] = (float*)workspace + (long)p * ns * slab;
+        d[p] = ab_wgrad_reduce_desc{};
+        d[p].slabs = sl[p]; d[p].dst = it.dw; d[p].slab_elems = slab; d[p].nslices = ns; d[p].src_j = 9 * Cin; d[p].dst_j = 9 * Cin;
+        d[p].accumulate = accumulate; d[p].stem_mask = 0;
+    }
+    int rc = wgrad3x3_x3_group_run(G, xh, xl, dh, dl, sl, N, H, W, Cin, Cout, as_stream(stream));
+    if (rc) return rc;
+    return ab_wgrad_reduce_batch(d, G, stream);
 }
 
 // The generic weight-gradient kernels index pixels with 21-bit magic divisions: larger launches (a stem at batch 128 x 256^2) run

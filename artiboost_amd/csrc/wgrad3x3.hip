@@ -30,6 +30,12 @@ struct Wg3Args {
     int N, H, Cin, Cout;
     int bands_per_slice, nbands;
     int xcd_map;                // workgroups renumbered slice-major per XCD (conv_common.h)
+    // Grouped launch (round 6): up to four SAME-SHAPE layers in one grid.  Slice by of the grid belongs to problem by / ns_per (0: the fields
+    // above, 1..3: entry - 1 of the arrays below) and is that problem's pixel slice by % ns_per.  With the launch held at one workgroup per
+    // CU, G problems get 1 / G of the slices each: every workgroup works through G times the pixels before it writes its 147 KB partial
+    // tile, so the slab bytes written here and read back by the reduction -- 37.7 MB per LAYER at 256 workgroups -- are paid per GROUP.
+    int ns_per;                 // 0: one problem
+    const void* Xg[3]; const void* Xg_lo[3]; const void* DYg[3]; const void* DYg_lo[3]; float* slabsg[3];
 };
 
 __device__ __forceinline__ uint4 tr_pair(unsigned addr_lo, unsigned addr_hi) {
@@ -69,13 +75,20 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
     const int wco = (wave & 1) * 32, wci = ((wave >> 1) & 1) * 32;
     const int tg = wave >> 2;                                // tap group (NW = 8): 0 -> taps 0..4, 1 -> taps 5..8
     const int t0 = (NW == 8 && tg) ? 5 : 0, ntap = NW == 8 ? (tg ? 4 : 5) : 9;
+    int prob = 0;
+    if (g.ns_per) { prob = by / g.ns_per; by -= prob * g.ns_per; }
     const int band_begin = by * g.bands_per_slice;
     const int band_end = min(g.nbands, band_begin + g.bands_per_slice);
     const int bands_per_img = g.H / TH;
-    const bf16_t* __restrict__ X = (const bf16_t*)g.X;
-    const bf16_t* __restrict__ DY = (const bf16_t*)g.DY;
-    const bf16_t* __restrict__ Xl = (const bf16_t*)g.X_lo;
-    const bf16_t* __restrict__ DYl = (const bf16_t*)g.DY_lo;
+    // (uniform selects, not a dynamically indexed kernarg array: that would become a vector load)
+    const void* pX = g.X; const void* pXl = g.X_lo; const void* pDY = g.DY; const void* pDYl = g.DY_lo; float* pslabs = g.slabs;
+    if (prob == 1) { pX = g.Xg[0]; pXl = g.Xg_lo[0]; pDY = g.DYg[0]; pDYl = g.DYg_lo[0]; pslabs = g.slabsg[0]; }
+    else if (prob == 2) { pX = g.Xg[1]; pXl = g.Xg_lo[1]; pDY = g.DYg[1]; pDYl = g.DYg_lo[1]; pslabs = g.slabsg[1]; }
+    else if (prob == 3) { pX = g.Xg[2]; pXl = g.Xg_lo[2]; pDY = g.DYg[2]; pDYl = g.DYg_lo[2]; pslabs = g.slabsg[2]; }
+    const bf16_t* __restrict__ X = (const bf16_t*)pX;
+    const bf16_t* __restrict__ DY = (const bf16_t*)pDY;
+    const bf16_t* __restrict__ Xl = (const bf16_t*)pXl;
+    const bf16_t* __restrict__ DYl = (const bf16_t*)pDYl;
     const bf16_t* zp = (const bf16_t*)wg3_zero_page;
 
     // ---- per-lane fill assignment
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
         buf ^= 1;
     }
     // ---- slab write: dW[co][tap][ci] (row length 9*Cin)
-    float* out = g.slabs + (long)by * g.Cout * 9 * g.Cin;
+    float* out = pslabs + (long)by * g.Cout * 9 * g.Cin;
     const int jt = 9 * g.Cin;
 #pragma unroll
     for (int tt = 0; tt < NACC; ++tt) {
@@ -347,6 +360,42 @@ int wgrad3x3_x3_slices(int N, int H, int W, int Cin, int Cout) {
     if (ns > 256) ns = 256;
     int bps = (nbands + ns - 1) / ns;
     return (nbands + bps - 1) / bps;
+}
+
+// slices PER PROBLEM of a grouped launch over G same-shape layers (0: shape not handled): the single-launch rule with the workgroup target
+// divided by G -- and at least two bands per slice, as there
+int wgrad3x3_x3_group_slices(int G, int N, int H, int W, int Cin, int Cout) {
+    int th = wg3x_th(H, W);
+    if (!th || Cin % 64 || Cout % 64 || G < 1 || G > 4) return 0;
+    int nbands = N * (H / th);
+    int tiles = (Cin / 64) * (Cout / 64);
+    static const int target = getenv("AB_WG3X_TARGET") ? atoi(getenv("AB_WG3X_TARGET")) : 256;
+    int want = (target + tiles * G - 1) / (tiles * G);
+    int ns = want < 1 ? 1 : want;
+    if (ns > nbands / 2) ns = nbands / 2 > 0 ? nbands / 2 : 1;
+    if (ns > 256) ns = 256;
+    int bps = (nbands + ns - 1) / ns;
+    return (nbands + bps - 1) / bps;
+}
+
+// G <= 4 same-shape problems in one grid; slabs[p]: problem p's [ns][Cout][9][Cin] partials
+int wgrad3x3_x3_group_run(int G, const void* const* x_hi, const void* const* x_lo, const void* const* dy_hi, const void* const* dy_lo,
+                          float* const* slabs, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+    int ns = wgrad3x3_x3_group_slices(G, N, H, W, Cin, Cout);
+    if (!ns) return AB_ESHAPE;
+    int th = wg3x_th(H, W);
+    Wg3Args g = {};
+    g.X = x_hi[0]; g.X_lo = x_lo[0]; g.DY = dy_hi[0]; g.DY_lo = dy_lo[0]; g.slabs = slabs[0];
+    for (int p = 1; p < G; ++p) { g.Xg[p - 1] = x_hi[p]; g.Xg_lo[p - 1] = x_lo[p]; g.DYg[p - 1] = dy_hi[p]; g.DYg_lo[p - 1] = dy_lo[p]; g.slabsg[p - 1] = slabs[p]; }
+    g.ns_per = G > 1 ? ns : 0;
+    g.N = N; g.H = H; g.Cin = Cin; g.Cout = Cout;
+    g.nbands = N * (H / th);
+    g.bands_per_slice = (g.nbands + ns - 1) / ns;
+    int tiles = (Cin / 64) * (Cout / 64);
+    if (W == 64) return wg3_launch<64, 1, 8, 1>(g, tiles, ns * G, st);
+    if (W == 32) return wg3_launch<32, 2, 8, 1>(g, tiles, ns * G, st);
+    if (W == 16) return wg3_launch<16, 4, 8, 1>(g, tiles, ns * G, st);
+    return wg3_launch<8, 8, 8, 1>(g, tiles, ns * G, st);
 }
 
 int wgrad3x3_x3_run(const void* x_hi, const void* x_lo, const void* dy_hi, const void* dy_lo, float* slabs, int N, int H, int W,

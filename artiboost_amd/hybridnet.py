@@ -753,7 +753,43 @@ class HybridNet:
     # 10.46 / 10.50 for g = 2 / 3 / 6 / 10 -- the launches saved do not pay for the larger live slab footprint.  Default: off.
     wgrad_group = int(os.environ.get("AB_WGRAD_GROUP", "1"))
 
+    # bf16x3, AB_WGRAD_FUSE=g (default 4; 1: off): up to g consecutive SAME-SHAPE 3x3 / stride-1 weight gradients of the backward (a stage's
+    # blocks: layer 1 has 6 of one shape, layers 2 - 4 have 7 / 11 / 5) run as ONE slab launch + ONE reduction (ab_conv2d_wgrad_x3_group).
+    # At one workgroup per CU every launch writes 256 partial tiles of 147 KB (37.7 MB) and the reduction reads them back: per LAYER before,
+    # per GROUP now, and a workgroup's band pipeline ramps up once per group.  The deferred layers' operand planes are kept until the group
+    # is launched (a shape change, a full group, or the end of a backward stage: _wgrad_join); gradients are complete only after that.
+    # tools/bench_conv_x3.py "probe grp": 72 -> 56 -> 53 us per layer on layer 2 for groups of 1 / 2 / 4, 66 -> 53 -> 48 on layer 3.
+    wgrad_fuse = int(os.environ.get("AB_WGRAD_FUSE", "4"))
+
+    def _wgrad_group_flush(self):
+        items, self._wgrp = getattr(self, "_wgrp", None), None
+        if not items:
+            return
+        if len(items) == 1:
+            x, dy, out = items[0]
+            K.conv2d_wgrad_x3(x, dy, 3, 3, 1, 1, out=out)
+        else:
+            K.conv2d_wgrad_x3_group(items)
+
     def _wgrad_side(self, fn, *args, **kw):
+        if (self.x3 and self.wgrad_fuse > 1 and not self.overlap_wgrad and not self.wgrad_1pass and fn == self._conv_wgrad
+                and len(args) == 6 and tuple(args[2:6]) == (3, 3, 1, 1) and set(kw) == {"out"} and kw["out"] is not None):
+            xp, dp = K._planes(args[0]), K._planes(args[1])          # (split now: the planes, not the fp32 tensors, are what is kept)
+            key = (tuple(xp[0].shape), tuple(dp[0].shape))
+            ok = self.__dict__.setdefault("_wgrp_ok", {})
+            if key not in ok:
+                ok[key] = K.conv2d_wgrad_x3_group_ok(xp, dp, min(self.wgrad_fuse, K.WGRAD_GROUP_MAX))
+            if ok[key]:
+                pend = getattr(self, "_wgrp", None)
+                if pend and (tuple(pend[0][0][0].shape), tuple(pend[0][1][0].shape)) != key:
+                    self._wgrad_group_flush()
+                    pend = None
+                if not pend:
+                    pend = self._wgrp = []
+                pend.append((xp, dp, kw["out"]))
+                if len(pend) >= min(self.wgrad_fuse, K.WGRAD_GROUP_MAX):
+                    self._wgrad_group_flush()
+                return kw["out"]
         if not self.overlap_wgrad:
             grouped = self.x3 and self.wgrad_group > 1
             if (self.batch_wgrad_reduce and not self.x3) or grouped:
@@ -775,6 +811,7 @@ class HybridNet:
         self._wg_keep.append(args)
 
     def _wgrad_join(self):
+        self._wgrad_group_flush()
         if getattr(self, "_pending", None) is not None:
             self._pending.flush()
         if getattr(self, "_wg_stream", None) is not None:

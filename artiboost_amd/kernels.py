@@ -450,6 +450,8 @@ def split(x_f32, out=None):
 
 def _planes(t):
     """(hi, lo) of a split tensor, or of the planes cached on an fp32 tensor by its producer; splits on the fly otherwise."""
+    if isinstance(t, tuple):
+        return t
     if t.dtype == torch.bfloat16:
         return t[0], t[1]
     sp = getattr(t, "_ab_split", None)
@@ -658,6 +660,39 @@ def conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=None, accumulate=False, defe
                                    L.i(Cout), L.i(kh), L.i(kw), L.i(stride), L.i(pad), L.ptr(ws), L.i(1 if accumulate else 0),
                                    L.stream()), "ab_conv2d_wgrad_x3")
     return dw
+
+
+WGRAD_GROUP_MAX = 4
+
+
+def conv2d_wgrad_x3_group_ok(x, dy, G):
+    """True when ab_conv2d_wgrad_x3_group takes G layers of this shape (3x3 / stride 1 / pad 1 on wgrad3x3.hip's map sizes)."""
+    xh, dh = _planes(x)[0], _planes(dy)[0]
+    N, H, W, Cin = xh.shape
+    return dh.shape[:3] == xh.shape[:3] and 1 <= G <= WGRAD_GROUP_MAX and \
+        L.lib().ab_conv2d_wgrad_x3_group_workspace(L.i(G), L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(dh.shape[3])) > 0
+
+
+def conv2d_wgrad_x3_group(items, accumulate=False):
+    """items: [(x, dy, out)] of ONE shape (3x3 / stride 1 / pad 1; x, dy fp32 or split; out fp32 [Cout,3,3,Cin]) -> the G weight gradients
+    from one slab launch + one reduction launch (ab_conv2d_wgrad_x3_group)."""
+    G = len(items)
+    planes = [(_planes(x), _planes(dy), out) for x, dy, out in items]
+    (xh, _), (dh, _), _ = planes[0]
+    N, H, W, Cin = xh.shape
+    Cout = dh.shape[3]
+    lib = L.lib()
+    nbytes = lib.ab_conv2d_wgrad_x3_group_workspace(L.i(G), L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout))
+    if nbytes <= 0:
+        raise RuntimeError(f"conv2d_wgrad_x3_group: shape not handled ({G} x [{N},{H},{W},{Cin}] -> {Cout})")
+    arr = (L.WgradGroupItem * G)()
+    for i, ((a, b), (c, d), out) in enumerate(planes):
+        assert a.shape == xh.shape and c.shape == dh.shape and out.dtype == torch.float32 and out.numel() == Cout * 9 * Cin and out.is_contiguous()
+        arr[i].x_hi, arr[i].x_lo, arr[i].dy_hi, arr[i].dy_lo, arr[i].dw = a.data_ptr(), b.data_ptr(), c.data_ptr(), d.data_ptr(), out.data_ptr()
+    ws = _workspace(nbytes, xh.device)
+    L.check(lib.ab_conv2d_wgrad_x3_group(arr, L.i(G), L.i(N), L.i(H), L.i(W), L.i(Cin), L.i(Cout), L.ptr(ws), L.i(1 if accumulate else 0),
+                                         L.stream()), "ab_conv2d_wgrad_x3_group")
+    return [out for _, _, out in planes]
 
 
 def bn_apply_x3(y, bnp, res=None, relu=True, want_f32=False, res_bnp=None):

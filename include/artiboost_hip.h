@@ -128,6 +128,19 @@ int ab_conv2d_wgrad_x3_deferred(const void* x_hi, const void* x_lo, const void* 
 int ab_conv2d_stem_wgrad_x3_deferred(const void* xpad_hi, const void* xpad_lo, const void* dy_hi, const void* dy_lo, float* dw,
                                      int N, int H, int W, int Cout, void* workspace, ab_wgrad_reduce_desc* pending, void* stream);
 int ab_wgrad_reduce_batch(const ab_wgrad_reduce_desc* desc, int n, void* stream);
+/* Grouped weight gradient (round 6): G <= AB_WGRAD_GROUP_MAX convolutions of ONE shape (3x3 / stride 1 / pad 1, split-bf16 operands: the
+ * layers of a ResNet stage, anakin/models/resnet.py:85-101,158-161) as one slab launch + one reduction launch.  items_host[p]: the planes of
+ * x [N,H,W,Cin] and dy [N,H,W,Cout] and the destination dW [Cout,3,3,Cin] fp32 of problem p (device pointers in a HOST array).  Equal to G
+ * ab_conv2d_wgrad_x3 calls up to the (fixed) summation order over pixel slices.  workspace >= ab_conv2d_wgrad_x3_group_workspace(...) bytes
+ * (0: shape not handled: call ab_conv2d_wgrad_x3 per layer).                                                                              */
+#define AB_WGRAD_GROUP_MAX 4
+typedef struct ab_wgrad_group_item {
+    const void* x_hi; const void* x_lo; const void* dy_hi; const void* dy_lo;
+    float* dw;
+} ab_wgrad_group_item;
+long ab_conv2d_wgrad_x3_group_workspace(int G, int N, int H, int W, int Cin, int Cout);
+int ab_conv2d_wgrad_x3_group(const ab_wgrad_group_item* items_host, int G, int N, int H, int W, int Cin, int Cout, void* workspace,
+                             int accumulate, void* stream);
 long ab_conv2d_stem_wgrad_workspace(int N, int H, int W, int Cout);
 int ab_conv2d_stem_wgrad(const void* xpad, const void* dy, float* dw, int dtype, int N, int H, int W, int Cout,
                          void* workspace, void* stream);
@@ -545,6 +558,7 @@ int ab_mano_lbs(const float* pose, const float* betas, const float* v_template, 
  * @check ab_conv2d_dgrad_x3_bn: bf16: dy_hi dy_lo wt_hi wt_lo bn_out_hi; dy_hi dy_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; wt_hi wt_lo >= Cin*kh*kw*Cout; dz addend bn_y bn_out_hi >= N*H*W*Cin; bnp >= 4*Cin; bn_part >= ab_conv2d_dgrad_x3_bn_rows(N,H,W,Cin,Cout,kh,kw,stride,pad)*Cin*2
  * @check ab_conv2d_wgrad_x3: bf16: x_hi x_lo dy_hi dy_lo; x_hi x_lo >= N*H*W*Cin; dy_hi dy_lo >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; dw >= Cout*kh*kw*Cin; bytes workspace >= ab_conv2d_wgrad_x3_workspace(N,H,W,Cin,Cout,kh,kw,stride,pad)
  * @check ab_conv2d_stem_fwd_x3: bf16: xpad_hi xpad_lo w_hi w_lo; xpad_hi xpad_lo >= N*(H+6)*(W+8)*4; w_hi w_lo >= Cout*7*8*4; y >= N*(H/2)*(W/2)*Cout; stats >= ab_conv2d_stem_x3_stat_rows(N,H,W)*Cout*2
+ * @check ab_conv2d_wgrad_x3_group: bytes workspace >= ab_conv2d_wgrad_x3_group_workspace(G,N,H,W,Cin,Cout)
  * @check ab_conv2d_stem_wgrad_x3: bf16: xpad_hi xpad_lo dy_hi dy_lo; xpad_hi xpad_lo >= N*(H+6)*(W+8)*4; dy_hi dy_lo >= N*(H/2)*(W/2)*Cout; dw >= Cout*7*8*4
  * @check ab_conv2d_fwd: dt(dtype): x w y; x >= N*H*W*Cin; w >= Cout*kh*kw*Cin; y >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; bias >= Cout
  * @check ab_conv2d_dgrad: dt(dtype): dy wt dx addend; dy >= N*co(H,kh,stride,pad)*co(W,kw,stride,pad)*Cout; wt >= Cin*kh*kw*Cout; dx addend >= N*H*W*Cin

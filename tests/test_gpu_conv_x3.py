@@ -368,6 +368,38 @@ def test_conv3x3_x3_256x64_tile(case, monkeypatch):
                                atol=3e-5 * float(ref_dz.abs().sum((0, 1, 2)).max()))
 
 
+@pytest.mark.parametrize("G", [2, 3, 4])
+@pytest.mark.parametrize("shape", [(4, 64, 64, 64, 64), (8, 32, 32, 128, 128), (16, 16, 16, 256, 256), (32, 8, 8, 512, 512), (2, 16, 16, 64, 128)])
+def test_wgrad_x3_group_equals_the_single_launches(shape, G):
+    """ab_conv2d_wgrad_x3_group (round 6): G same-shape 3x3 / stride-1 weight gradients from ONE slab launch + ONE reduction -- against float64
+    and against G ab_conv2d_wgrad_x3 calls (the same products summed over another fixed partition of the pixels: fp32 reassociation only);
+    destinations are slices of one flat buffer, as the model's gradient views are."""
+    from artiboost_amd import kernels as K
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(G * 1000 + sum(shape))
+    flat = torch.full((G + 1, Cout, 3, 3, Cin), 7.0, device="cuda")                 # (the last slot must stay untouched)
+    items, refs = [], []
+    for i in range(G):
+        x = torch.randn((N, H, W, Cin), generator=g) * (1.0 + i)
+        dy = torch.randn((N, H, W, Cout), generator=g)
+        xs, ds = K.split(x.cuda()), K.split(dy.cuda())
+        items.append((xs, ds if i % 2 else (ds[0], ds[1]), flat[i]))               # split tensors and (hi, lo) tuples alike
+        ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (Cout, Cin, 3, 3), dy.permute(0, 3, 1, 2).double(), padding=1)
+        refs.append(ref.permute(0, 2, 3, 1))                                        # [Cout, 3, 3, Cin]
+    assert K.conv2d_wgrad_x3_group_ok(items[0][0], items[0][1], G)
+    K.conv2d_wgrad_x3_group(items)
+    torch.cuda.synchronize()
+    assert torch.all(flat[G] == 7.0)
+    for i in range(G):
+        single = K.conv2d_wgrad_x3(items[i][0], items[i][1], 3, 3, 1, 1)
+        scale = float(refs[i].abs().max())
+        np.testing.assert_allclose(flat[i].double().cpu().numpy(), refs[i].numpy(), rtol=0, atol=3e-5 * scale)
+        np.testing.assert_allclose(flat[i].cpu().numpy(), single.cpu().numpy(), rtol=0, atol=2e-6 * scale)
+    again = torch.empty_like(flat)
+    K.conv2d_wgrad_x3_group([(a, b, again[i]) for i, (a, b, _) in enumerate(items)])
+    assert torch.equal(again[:G], flat[:G])                                          # fixed summation order: bit-identical reruns
+
+
 @pytest.mark.parametrize("case", [(64, 64, 64, 64, 128, 1, 2, 0), (8, 32, 32, 128, 256, 3, 2, 1), (4, 16, 16, 256, 256, 3, 1, 1),
                                   (16, 32, 32, 256, 704, 1, 1, 0)])
 def test_wgrad_x3_deferred_reduction_with_exact_workspace(case):

@@ -26,6 +26,12 @@ SHAPES = [  # name, H, W, Cin, Cout, k, stride, pad, calls per step
     # tile-shape probe: two 8x8 layer-4 images side by side as one 8x16 image (run with AB_C3_FORCE=4: 128 pixels x 64 channels
     # per workgroup = the weight stream of a workgroup halved at the same 256-workgroup grid; timing only, not layer 4's maths)
     ("probe l4 pair-tile 8x16 B32", 8, 16, 512, 512, 3, 1, 1, 0, 32),
+    # weight-gradient grouping probe (round 6): the same layer at twice / four times the batch = what ONE launch over 2 / 4 same-shape layers
+    # costs (same 256 workgroups, slabs written and reduced once): compare with 2 x / 4 x the B = 64 line
+    ("probe grp l1 B128", 64, 64, 64, 64, 3, 1, 1, 0, 128), ("probe grp l1 B256", 64, 64, 64, 64, 3, 1, 1, 0, 256),
+    ("probe grp l2 B128", 32, 32, 128, 128, 3, 1, 1, 0, 128), ("probe grp l2 B256", 32, 32, 128, 128, 3, 1, 1, 0, 256),
+    ("probe grp l3 B128", 16, 16, 256, 256, 3, 1, 1, 0, 128), ("probe grp l3 B256", 16, 16, 256, 256, 3, 1, 1, 0, 256),
+    ("probe grp l4 B128", 8, 8, 512, 512, 3, 1, 1, 0, 128), ("probe grp l4 B256", 8, 8, 512, 512, 3, 1, 1, 0, 256),
 ]
 
 
