@@ -321,8 +321,8 @@ def dexycb_leg(args, device, steps=10, warmup=3):
 # every kernels.py entry that launches conv-stack MFMA kernels of the training step (forward, data gradient, weight gradient + its slab
 # reduction; the final layer's GEMM carries the soft-argmax statistics in its epilogue)
 CONV_FNS = ["conv2d_fwd", "conv2d_stem_fwd", "conv2d_dgrad", "conv2d_wgrad", "conv2d_stem_wgrad",
-            "conv2d_fwd_x3", "conv2d_stem_fwd_x3", "conv2d_dgrad_x3", "conv2d_dgrad_x3_pair", "conv2d_wgrad_x3", "conv2d_stem_wgrad_x3",
-            "conv1x1_sam_fwd_x3"]
+            "conv2d_fwd_x3", "conv2d_stem_fwd_x3", "conv2d_dgrad_x3", "conv2d_dgrad_x3_pair", "conv2d_wgrad_x3", "conv2d_wgrad_x3_group",
+            "conv2d_stem_wgrad_x3", "conv1x1_sam_fwd_x3"]
 
 
 def conv_kernel_time_graph_ms(ts, loader, reps=3):
