@@ -266,7 +266,9 @@ def test_conv_dgrad_x3_bn_fused(case, mask_src):
     dyd = nhwc(dy.float()).cuda()
     dz, part = K.conv2d_dgrad_x3(dyd, wt, (H, W), 1, 1, addend=nhwc(add).cuda(), bn=(ybn.cuda(), out if res is not None else None, bnp))
     assert part is not None
-    if (Cin, Cout) == (64, 64) and H % 8 == 0 and W % 16 == 0 and N * (H // 8) * (W // 16) >= 64:
+    import os
+    c3rb = os.environ.get("AB_C3_L1T16", "1") != "0" and os.environ.get("AB_C3RB", "1") != "0" and os.environ.get("AB_C3R_OFF", "0") == "0"
+    if c3rb and (Cin, Cout) == (64, 64) and H % 8 == 0 and W % 16 == 0 and N * (H // 8) * (W // 16) >= 64:
         assert part.shape[0] == min(N * (H // 8) * (W // 16), 256)        # one partial row per persistent workgroup: conv3x3r.hip took it
         # ... and the same launch without the skip gradient (the form conv2's gradient takes in the block backward)
         dz0, part0 = K.conv2d_dgrad_x3(dyd, wt, (H, W), 1, 1, bn=(ybn.cuda(), out if res is not None else None, bnp))
@@ -361,7 +363,10 @@ def test_conv3x3_x3_256x64_tile(case, monkeypatch):
     ybn = torch.randn((N, H, W, Cin), generator=g)
     bnp = K.bn_finalize(K.col_stats(ybn.cuda()), N * H * W, torch.ones(Cin).cuda(), torch.zeros(Cin).cuda(), torch.zeros(Cin).cuda(), torch.ones(Cin).cuda())
     dz, part = K.conv2d_dgrad_x3(nhwc(dy).cuda(), wt, (H, W), 1, 1, addend=nhwc(add).cuda(), bn=(ybn.cuda(), None, bnp))
-    assert part.shape[0] == N * ((H + 7) // 8) * ((W + 31) // 32)           # the fused epilogue keeps the 8 x 32 tile
+    # the fused epilogue keeps the 8 x 32 tile of conv3x3.hip -- except where conv3x3r.hip's persistent kernel takes the launch (round 6: from
+    # 64 tiles of 8 x 16 on, one partial row per workgroup), with the 8 x 32 tile again under AB_C3RB=0 / AB_C3R_OFF=1
+    rb = nt16 >= 64 and os.environ.get("AB_C3RB", "1") != "0" and os.environ.get("AB_C3R_OFF", "0") == "0"
+    assert part.shape[0] == (min(nt16, 256) if rb else N * ((H + 7) // 8) * ((W + 31) // 32))
     ref_dz = nhwc(ref_dx) * (((ybn - bnp[2].cpu()) * bnp[3].cpu()) > 0).double()
     close(dz.cpu(), ref_dz)
     np.testing.assert_allclose(part.double().sum(0).cpu()[:, 0].numpy(), ref_dz.sum((0, 1, 2)).numpy(), rtol=1e-4,
