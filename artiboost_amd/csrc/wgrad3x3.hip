@@ -30,12 +30,12 @@ struct Wg3Args {
     int N, H, Cin, Cout;
     int bands_per_slice, nbands;
     int xcd_map;                // workgroups renumbered slice-major per XCD (conv_common.h)
-    // Grouped launch (round 6): up to four SAME-SHAPE layers in one grid.  Slice by of the grid belongs to problem by / ns_per (0: the fields
-    // above, 1..3: entry - 1 of the arrays below) and is that problem's pixel slice by % ns_per.  With the launch held at one workgroup per
+    // Grouped launch (round 6): up to eight SAME-SHAPE layers in one grid.  Slice by of the grid belongs to problem by / ns_per (0: the fields
+    // above, 1..7: entry - 1 of the arrays below) and is that problem's pixel slice by % ns_per.  With the launch held at one workgroup per
     // CU, G problems get 1 / G of the slices each: every workgroup works through G times the pixels before it writes its 147 KB partial
     // tile, so the slab bytes written here and read back by the reduction -- 37.7 MB per LAYER at 256 workgroups -- are paid per GROUP.
     int ns_per;                 // 0: one problem
-    const void* Xg[3]; const void* Xg_lo[3]; const void* DYg[3]; const void* DYg_lo[3]; float* slabsg[3];
+    const void* Xg[7]; const void* Xg_lo[7]; const void* DYg[7]; const void* DYg_lo[7]; float* slabsg[7];
 };
 
 __device__ __forceinline__ uint4 tr_pair(unsigned addr_lo, unsigned addr_hi) {
@@ -82,9 +82,9 @@ __global__ __launch_bounds__(64 * NW) void wgrad3x3_kernel(Wg3Args g) {
     const int bands_per_img = g.H / TH;
     // (uniform selects, not a dynamically indexed kernarg array: that would become a vector load)
     const void* pX = g.X; const void* pXl = g.X_lo; const void* pDY = g.DY; const void* pDYl = g.DY_lo; float* pslabs = g.slabs;
-    if (prob == 1) { pX = g.Xg[0]; pXl = g.Xg_lo[0]; pDY = g.DYg[0]; pDYl = g.DYg_lo[0]; pslabs = g.slabsg[0]; }
-    else if (prob == 2) { pX = g.Xg[1]; pXl = g.Xg_lo[1]; pDY = g.DYg[1]; pDYl = g.DYg_lo[1]; pslabs = g.slabsg[1]; }
-    else if (prob == 3) { pX = g.Xg[2]; pXl = g.Xg_lo[2]; pDY = g.DYg[2]; pDYl = g.DYg_lo[2]; pslabs = g.slabsg[2]; }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        if (prob == k + 1) { pX = g.Xg[k]; pXl = g.Xg_lo[k]; pDY = g.DYg[k]; pDYl = g.DYg_lo[k]; pslabs = g.slabsg[k]; }
     const bf16_t* __restrict__ X = (const bf16_t*)pX;
     const bf16_t* __restrict__ DY = (const bf16_t*)pDY;
     const bf16_t* __restrict__ Xl = (const bf16_t*)pXl;
@@ -366,12 +366,13 @@ int wgrad3x3_x3_slices(int N, int H, int W, int Cin, int Cout) {
 // divided by G -- and at least two bands per slice, as there
 int wgrad3x3_x3_group_slices(int G, int N, int H, int W, int Cin, int Cout) {
     int th = wg3x_th(H, W);
-    if (!th || Cin % 64 || Cout % 64 || G < 1 || G > 4) return 0;
+    if (!th || Cin % 64 || Cout % 64 || G < 1 || G > 8) return 0;
     int nbands = N * (H / th);
     int tiles = (Cin / 64) * (Cout / 64);
     static const int target = getenv("AB_WG3X_TARGET") ? atoi(getenv("AB_WG3X_TARGET")) : 256;
     // floor, not the single launch's ceil: 16 tiles x 3 problems x ceil(256 / 48) = 288 workgroups ran as a second round on 32 CUs
     // (measured: the step 0.45 ms SLOWER with groups of three than ungrouped); x 5 = 240 fill 94 % of the chip in one round
+    if (G > 1 && tiles * G > target) return 0;          // (more problems than one round of workgroups holds: the caller groups fewer)
     int want = G > 1 ? target / (tiles * G) : (target + tiles - 1) / tiles;
     int ns = want < 1 ? 1 : want;
     if (ns > nbands / 2) ns = nbands / 2 > 0 ? nbands / 2 : 1;
@@ -380,7 +381,7 @@ int wgrad3x3_x3_group_slices(int G, int N, int H, int W, int Cin, int Cout) {
     return (nbands + bps - 1) / bps;
 }
 
-// G <= 4 same-shape problems in one grid; slabs[p]: problem p's [ns][Cout][9][Cin] partials
+// G <= 8 same-shape problems in one grid; slabs[p]: problem p's [ns][Cout][9][Cin] partials
 int wgrad3x3_x3_group_run(int G, const void* const* x_hi, const void* const* x_lo, const void* const* dy_hi, const void* const* dy_lo,
                           float* const* slabs, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
     int ns = wgrad3x3_x3_group_slices(G, N, H, W, Cin, Cout);

@@ -753,13 +753,15 @@ class HybridNet:
     # 10.46 / 10.50 for g = 2 / 3 / 6 / 10 -- the launches saved do not pay for the larger live slab footprint.  Default: off.
     wgrad_group = int(os.environ.get("AB_WGRAD_GROUP", "1"))
 
-    # bf16x3, AB_WGRAD_FUSE=g (default 4; 1: off): up to g consecutive SAME-SHAPE 3x3 / stride-1 weight gradients of the backward (a stage's
+    # bf16x3, AB_WGRAD_FUSE=g (default 8, the kernel's maximum -- and never more problems than one round of workgroups holds: 4 on layer 4;
+    # 1: off): up to g consecutive SAME-SHAPE 3x3 / stride-1 weight gradients of the backward (a stage's
     # blocks: layer 1 has 6 of one shape, layers 2 - 4 have 7 / 11 / 5) run as ONE slab launch + ONE reduction (ab_conv2d_wgrad_x3_group).
     # At one workgroup per CU every launch writes 256 partial tiles of 147 KB (37.7 MB) and the reduction reads them back: per LAYER before,
     # per GROUP now, and a workgroup's band pipeline ramps up once per group.  The deferred layers' operand planes are kept until the group
     # is launched (a shape change, a full group, or the end of a backward stage: _wgrad_join); gradients are complete only after that.
     # tools/bench_conv_x3.py "probe grp": 72 -> 56 -> 53 us per layer on layer 2 for groups of 1 / 2 / 4, 66 -> 53 -> 48 on layer 3.
-    wgrad_fuse = int(os.environ.get("AB_WGRAD_FUSE", "4"))
+    # The step, same box, alternating processes: 8.68 ms ungrouped -> 8.47 (g = 2); 8.91 (2) -> 8.78 (4) on another; 8.69 (4) -> 8.63 (8).
+    wgrad_fuse = int(os.environ.get("AB_WGRAD_FUSE", "8"))
 
     def _wgrad_group_flush(self):
         items, self._wgrp = getattr(self, "_wgrp", None), None
@@ -777,8 +779,8 @@ class HybridNet:
             xp, dp = K._planes(args[0]), K._planes(args[1])          # (split now: the planes, not the fp32 tensors, are what is kept)
             key = (tuple(xp[0].shape), tuple(dp[0].shape))
             ok = self.__dict__.setdefault("_wgrp_ok", {})
-            if key not in ok:
-                ok[key] = K.conv2d_wgrad_x3_group_ok(xp, dp, min(self.wgrad_fuse, K.WGRAD_GROUP_MAX))
+            if key not in ok:          # the largest group of this shape the kernel takes in one round of workgroups (0: none)
+                ok[key] = next((G for G in range(min(self.wgrad_fuse, K.WGRAD_GROUP_MAX), 1, -1) if K.conv2d_wgrad_x3_group_ok(xp, dp, G)), 0)
             if ok[key]:
                 pend = getattr(self, "_wgrp", None)
                 if pend and (tuple(pend[0][0][0].shape), tuple(pend[0][1][0].shape)) != key:
@@ -787,7 +789,7 @@ class HybridNet:
                 if not pend:
                     pend = self._wgrp = []
                 pend.append((xp, dp, kw["out"]))
-                if len(pend) >= min(self.wgrad_fuse, K.WGRAD_GROUP_MAX):
+                if len(pend) >= ok[key]:
                     self._wgrad_group_flush()
                 return kw["out"]
         if not self.overlap_wgrad:

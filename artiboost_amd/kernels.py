@@ -662,7 +662,7 @@ def conv2d_wgrad_x3(x, dy, kh, kw, stride, pad, out=None, accumulate=False, defe
     return dw
 
 
-WGRAD_GROUP_MAX = 4
+WGRAD_GROUP_MAX = 8
 
 
 def conv2d_wgrad_x3_group_ok(x, dy, G):

@@ -133,7 +133,7 @@ int ab_wgrad_reduce_batch(const ab_wgrad_reduce_desc* desc, int n, void* stream)
  * x [N,H,W,Cin] and dy [N,H,W,Cout] and the destination dW [Cout,3,3,Cin] fp32 of problem p (device pointers in a HOST array).  Equal to G
  * ab_conv2d_wgrad_x3 calls up to the (fixed) summation order over pixel slices.  workspace >= ab_conv2d_wgrad_x3_group_workspace(...) bytes
  * (0: shape not handled: call ab_conv2d_wgrad_x3 per layer).                                                                              */
-#define AB_WGRAD_GROUP_MAX 4
+#define AB_WGRAD_GROUP_MAX 8
 typedef struct ab_wgrad_group_item {
     const void* x_hi; const void* x_lo; const void* dy_hi; const void* dy_lo;
     float* dw;
