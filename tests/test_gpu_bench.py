@@ -120,12 +120,13 @@ def test_roofline_is_timed_inside_the_replayed_step():
     kernels are not slower than the eager ones by more than the instrument's boundary uncertainty (they run 3 - 5 % FASTER: no launch gaps,
     warmer clocks), never below 0.85 of them."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3", "--no-cpu-baseline", "--sustain", "0", "--no-eval-leg",
-           "--no-dexycb-leg", "--no-study-leg", "--no-jpeg-leg", "--no-mixed-leg", "--no-rccl-leg"]
+           "--no-dexycb-leg", "--no-study-leg", "--no-jpeg-leg", "--no-mixed-leg", "--no-rccl-leg", "--no-dropin-leg"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     roof = _last_json(r.stdout)["roofline"]
     assert "graph_stamp_error" not in roof, roof
-    assert roof["conv_ms_source"].startswith("graph replay") and roof["conv_launches_per_step"] >= 100
+    # (113 conv-stack calls per step through round 5; round 6 groups the 29 3x3 weight gradients into 6 launches: 90)
+    assert roof["conv_ms_source"].startswith("graph replay") and roof["conv_launches_per_step"] >= 85
     g, e = roof["conv_ms_per_step"], roof["conv_ms_per_step_eager"]
     assert 0.85 * e <= g <= 1.03 * e, roof
     assert 0.5 < roof["stamp_boundary_us"] < 4.0, roof
