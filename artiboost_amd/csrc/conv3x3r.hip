@@ -191,7 +191,9 @@ __global__ __launch_bounds__(512) void conv3x3r_kernel(C3rArgs g) {
                 else if (next < g.ntiles) issue_eop(next, 0, 0);
             }
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f};
-            // 18 (tap, chunk) steps; the fragment reads run one step ahead of the MFMAs that consume them (pinned: gemm_rw.hip's grw_block)
+            // 18 (tap, chunk) steps; the fragment reads run one step ahead of the MFMAs that consume them (pinned: gemm_rw.hip's grw_block).
+            // (Round 6 knock-out, timing only: reading the fragments on every second / third step only -- what sharing an input row's fragment
+            //  between the three vertical taps of neighbouring output rows could save at best -- 65.1 -> 63.2 / 59.4 us: not worth the rebuild.)
             u32x4 fh[2], fl[2];
             auto rd = [&](int s, int b) {
                 const int t = s >> 1, c = s & 1, t3 = t / 3, tr = t % 3;
