@@ -592,3 +592,107 @@ class StreamPrefetcher:
                     v.record_stream(cur)
             nxt = produce()
             yield batch
+
+
+class ThreadedPrefetcher:
+    """StreamPrefetcher with the HOST side of the batch assembly off the training thread too: a worker thread iterates the loader up to `depth`
+    batches ahead on its own HIP stream (ground-truth assembly in numpy, file parsing, decode planning, ~40 launches per mixed batch) while the
+    training thread replays the step's graphs -- the role of the reference's DataLoader worker PROCESSES (train_artiboost.py: num_workers),
+    as one thread.  Round 6: under the graph-replayed bf16x3 step (8.5 ms of device work) the mixed real + synthetic loop was bound by this
+    host work -- the main queue idled 1.1 ms per step (2.6 under rocprofv3) with everything on one thread.
+
+    Same batches, same order, same bytes as the loader's own iteration.  Hand-over: the worker records an event behind a batch's last launch,
+    the consumer's stream waits on it and `record_stream`s the tensors.  Buffer reuse (MixedLoader's ring of `reuse_buffers` image tensors): when
+    the consumer asks for the next batch, an event is recorded on ITS stream behind everything it enqueued for the previous one; the worker's
+    stream waits on the event of batch j - n before it produces batch j into the same ring slot -- which exists by then because the queue
+    keeps the worker at most depth + 1 batches ahead of the consumer: depth <= reuse_buffers - 2 (checked)."""
+
+    def __init__(self, loader, depth=2, device=None, inline_first=0):
+        self.loader, self.depth = loader, int(depth)
+        self.inline_first = int(inline_first)      # the first batches are produced on the consumer's own thread and stream (see __iter__)
+        self.dev = torch.device(device) if device is not None else None
+        ring = int(getattr(loader, "reuse_buffers", 0))
+        if ring > 0 and self.depth > ring - 2:
+            raise ValueError(f"ThreadedPrefetcher(depth={self.depth}) over a ring of {ring} image buffers: needs depth <= reuse_buffers - 2")
+        self.ring = ring
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        import queue
+        import threading
+        dev = self.dev or torch.device("cuda", torch.cuda.current_device())
+        side = torch.cuda.Stream(device=dev)
+        q = queue.Queue(maxsize=max(self.depth, 1))
+        stop = threading.Event()
+        done = {}                          # batch index -> event on the consumer's stream behind its use of that batch
+        ring = self.ring
+        it = iter(self.loader)
+        k = 0
+        for _ in range(self.inline_first):
+            batch = next(it, None)
+            if batch is None:
+                return
+            yield batch
+            e = torch.cuda.Event()
+            e.record(torch.cuda.current_stream(dev))
+            done[k] = e
+            k += 1
+        start = torch.cuda.Event()
+        start.record(torch.cuda.current_stream(dev))      # the worker's first launches follow whatever the consumer enqueued so far
+        j0 = k
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(side):
+                    side.wait_event(start)
+                    j = j0
+                    while not stop.is_set():
+                        if ring > 0 and j - ring in done:
+                            side.wait_event(done.pop(j - ring))      # the ring slot batch j is written into was last read by batch j - ring
+                        batch = next(it, None)
+                        if batch is None:
+                            break
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        while not stop.is_set():
+                            try:
+                                q.put((batch, ev), timeout=0.1)
+                                break
+                            except queue.Full:
+                                pass
+                        j += 1
+                q.put(None)
+            except BaseException as e:      # noqa: BLE001 -- re-raised in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=work, name="artiboost-prefetch", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                batch, ev = item
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(ev)
+                for v in batch.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
+                yield batch
+                e = torch.cuda.Event()      # (the consumer is back: everything it enqueued for batch k is on its stream by now)
+                e.record(torch.cuda.current_stream(dev))
+                done[k] = e
+                k += 1
+        finally:
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    th.join(timeout=0.05)
+            torch.cuda.current_stream(dev).wait_stream(side)

@@ -273,11 +273,15 @@ def mixed_leg(args, steps=20):
     cfg = yaml.safe_load(open(os.path.join(ROOT, "config", CFG_OF["HO3D"])))
     cfg["DATA_PRESET"]["IMAGE_SIZE"] = [args.size, args.size]
     cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [args.size // 8, args.size // 8]
-    mode = "same stream, frames of 4 batches decoded per call one group ahead on a side stream"
-    r = bench_mixed.train_loop(cfg, steps=steps, modes=(mode,), quiet=True)
+    # round 6: the batch assembly (host + device side) on a worker thread two batches ahead (realdata.ThreadedPrefetcher), as train/train_artiboost.py
+    # runs it; `same_thread_ms_per_step` is the loop with everything on the training thread (what the line reported through round 5)
+    same = "same stream, frames of 4 batches decoded per call one group ahead on a side stream"
+    mode = "worker thread two batches ahead, frames of 4 batches decoded per call one group ahead on a side stream"
+    r = bench_mixed.train_loop(cfg, steps=steps, modes=(same, mode), quiet=True)
     out = {"metric": "mixed samples/sec (40 real .jpg frames decoded + augmented on the device, 24 rendered; fwd+bwd+optimizer)", "value": round(64 / r[mode] * 1e3, 1),
            "unit": "samples/s", "ms_per_step": round(r[mode], 3), "steps": steps, "batch": 64, "final_loss": r["final_loss"],
-           "workload": "MixedLoader (decode_group 4, decode_ahead) + TrainStep graph replay, bf16x3; SURVEY 8f-3"}
+           "same_thread_ms_per_step": round(r[same], 3),
+           "workload": "ThreadedPrefetcher(MixedLoader (decode_group 4, decode_ahead), depth 2) + TrainStep graph replay, bf16x3; SURVEY 8f-3"}
     try:      # the same step over .png files -- HO3D v2's own frame format (ho3d.py:181): zlib inflate on the host pool, reconstruction on the device
         from artiboost_amd import png as P
         rp = bench_mixed.train_loop(cfg, steps=steps, modes=(mode,), quiet=True, source="png")

@@ -129,3 +129,42 @@ def test_color_jitter_all_rgb_values_vs_oracle():
         got = out.cpu().numpy()
         bad = np.argwhere((got[..., :3] != ref[..., :3]).any(axis=-1))
         assert len(bad) == 0, (order, factor, bad[:5], got[tuple(bad[0])], ref[tuple(bad[0])])
+
+
+def test_render_is_bit_stable_beside_mfma_kernels():
+    """Round 6: with packed-fp32 VALU instructions in the shading code, the SAME render differed by a few levels in a few dozen pixels whenever its
+    waves shared a SIMD with waves executing v_mfma_f32_32x32x16_bf16 (another stream: the DDP render overlap, ThreadedPrefetcher) -- the visibility
+    keys stayed exact, the same thread shading the same pixel twice got two answers.  The library is built without packed fp32 (build.py); here the
+    render runs beside this build's layer-3 convolution on a second stream and must equal the solo render byte for byte, every time."""
+    from artiboost_amd import kernels as K
+    from artiboost_amd.assets import SceneAssets
+    from artiboost_amd.render import DeviceRenderer
+    B, res = 24, 256
+    assets = SceneAssets("HO3D", seed=1)
+    Kc = np.array([[435.0, 0, 256.0], [0, 435.0, 256.0], [0, 0, 1.0]])
+    sc = gen_scene.make_samples(assets, B, 7, out_res=(res, res))
+    r = DeviceRenderer(assets, Kc)
+    dev = r.dev
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    args = (t(sc["samples"].view(np.uint8).reshape(B, -1)), t(sc["hand_verts"]), t(sc["order"]), t(sc["factor"]), t(sc["inv_affine"]))
+    blur = t(sc["blur"])
+
+    def render():
+        pad = torch.zeros((B, res + 6, res + 8, 4), dtype=torch.bfloat16, device=dev)
+        o = r.render(*args, res, res, out_pad=pad, want_keys=True, want_rgbx=True, blur=blur, pad_code=2)
+        return o["keys"].clone(), o["rgbx"].clone(), pad
+
+    ref = render()
+    torch.cuda.synchronize()
+    x3, w3 = K.split(torch.randn(64, 16, 16, 256, device=dev)), K.split(torch.randn(256, 3, 3, 256, device=dev) * 0.05)
+    K.conv2d_fwd_x3(x3, w3, 1, 1, want_stats=True)
+    side = torch.cuda.Stream()
+    for it in range(12):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(10):
+                K.conv2d_fwd_x3(x3, w3, 1, 1, want_stats=True)      # 126 VGPRs, 122 KB of LDS: leaves room for the renderer's workgroups on its CU
+        got = render()
+        torch.cuda.synchronize()
+        for name, a, b in zip(("keys", "rgbx", "output plane"), ref, got):
+            assert torch.equal(a, b), (it, name, int((a != b).sum()))

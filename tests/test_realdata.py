@@ -309,8 +309,23 @@ def test_stream_prefetcher_yields_the_loaders_batches():
         junk = junk @ junk * 1e-3
         ahead.append({k: v.clone() for k, v in b.items()})
     torch.cuda.synchronize()
-    assert len(got) == len(plain) == len(grouped) == len(ahead) >= 2
-    for other in (got, grouped, ahead):
+    # ... and the whole assembly on a worker thread two batches ahead (ThreadedPrefetcher), over the buffer ring it must respect
+    from artiboost_amd.realdata import ThreadedPrefetcher
+    threaded = []
+    ml = make(decode_group=2, decode_ahead=True)
+    ml.reuse_buffers, ml.want_chw = 4, True
+    for b in ThreadedPrefetcher(ml, depth=2):
+        junk = junk @ junk * 1e-3
+        threaded.append({k: v.clone() for k, v in b.items()})
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="reuse_buffers"):
+        ThreadedPrefetcher(ml, depth=3)
+    early = []
+    for b in ThreadedPrefetcher(make(), depth=2):      # a consumer that stops early: the worker is released and joined
+        early.append({k: v.clone() for k, v in b.items()})
+        break
+    assert len(got) == len(plain) == len(grouped) == len(ahead) == len(threaded) >= 2 and len(early) == 1
+    for other in (got, grouped, ahead, threaded, early):
         for a, b in zip(plain, other):
             assert a.keys() == b.keys()
             for k in a:

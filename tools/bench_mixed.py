@@ -106,7 +106,8 @@ def jpeg_compare(cfg):
 
 
 def train_loop(cfg, steps=30, modes=("same stream", "same stream, frames of 4 batches decoded per call",
-                                     "same stream, frames of 4 batches decoded per call one group ahead on a side stream", "side stream, one batch ahead"),
+                                     "same stream, frames of 4 batches decoded per call one group ahead on a side stream", "side stream, one batch ahead",
+                                     "worker thread two batches ahead, frames of 4 batches decoded per call one group ahead on a side stream"),
                quiet=False, source="jpeg"):
     """The training step (hipGraph replay, bf16x3, B = 64, 256 x 256) over MixedLoader batches -- 40 real frames served as .jpg files and
     decoded on the device + 24 synthetic samples rendered per batch -- with the batch assembly on the step's own stream, and one batch
@@ -116,7 +117,7 @@ def train_loop(cfg, steps=30, modes=("same stream", "same stream, frames of 4 ba
     from artiboost_amd.criterions import Criterion
     from artiboost_amd.models import Arch
     from artiboost_amd.optim import FusedClipAdam
-    from artiboost_amd.realdata import StreamPrefetcher
+    from artiboost_amd.realdata import StreamPrefetcher, ThreadedPrefetcher
     from artiboost_amd.train import TrainStep
     B = 64
     res = {}
@@ -139,7 +140,7 @@ def train_loop(cfg, steps=30, modes=("same stream", "same stream, frames of 4 ba
         hb = model.model_list[0]
         opt = FusedClipAdam(model.models_params, lr=5e-5, max_norm=0.001, model=hb)
         model.train()
-        loader = StreamPrefetcher(ml) if mode.startswith("side") else ml
+        loader = StreamPrefetcher(ml) if mode.startswith("side") else ThreadedPrefetcher(ml) if mode.startswith("worker thread") else ml
         it = iter(loader)
         first = next(it)
         ts = TrainStep(model, crit, opt, {k: v.clone() for k, v in first.items()}, use_graph=True, renderer=None)
@@ -148,14 +149,20 @@ def train_loop(cfg, steps=30, modes=("same stream", "same stream, frames of 4 ba
         torch.cuda.synchronize()
         t0 = time.time()
         n = 0
+        trail = []
         for b in it:
             _, losses, _ = ts(b)
             n += 1
+            if n <= 6:
+                trail.append(losses[5].clone())
             if n == steps:
                 break
         torch.cuda.synchronize()
         res[mode] = (time.time() - t0) / n * 1e3
         res["final_loss"] = float(losses[5])
+        res["first_losses"] = [round(float(t), 8) for t in trail]
+        if not quiet:
+            print("   first losses:", res["first_losses"])
         if not quiet:
             print(f"training over mixed batches (40 real {source} frames + 24 synthetic, bf16x3), batch assembly on the {mode}: "
                   f"{res[mode]:.2f} ms per step ({n} steps), final loss {float(losses[5]):.5f}")

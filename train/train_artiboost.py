@@ -155,7 +155,7 @@ def main():
     # A real training set that is present (DATA_ROOT holds the download): the reference's MixedDataset (mixed_dataset.py:5-37) -- every batch
     # holds its share of real frames (decoded and augmented on the device) and of the epoch's synthetic samples.  The synthetic loader then
     # renders only ITS share of the per-rank batch; realdata.MixedLoader assembles the batches.
-    from artiboost_amd.realdata import MixedLoader, RealBatcher, StreamPrefetcher
+    from artiboost_amd.realdata import MixedLoader, RealBatcher, ThreadedPrefetcher
     real_len = len(train_data)
     synth_share = per_rank
     if real_len > 0:
@@ -241,12 +241,13 @@ def main():
             model.train()
             evaluator.reset_all()
             if mixed is not None:
-                # real + synthetic batches: assembled one batch ahead on a side stream (the role of the reference's DataLoader workers),
+                # real + synthetic batches: assembled two batches ahead by a worker thread on its own stream (the role of the reference's
+                # DataLoader worker processes: host-side ground truth / parsing / planning AND the device-side decode / augment / render),
                 # the graph-replayed step copies each into its static inputs
                 mixed.update()
                 t0 = time.time()
                 nb = 0
-                for batch in StreamPrefetcher(mixed):
+                for batch in ThreadedPrefetcher(mixed, depth=2):
                     if ts is None:
                         ts = TrainStep(model, criterion, optimizer, {k: v.clone() for k, v in batch.items()}, use_graph=True, renderer=None,
                                        dist_group=torch.distributed.group.WORLD if world > 1 else None)
