@@ -8,24 +8,24 @@ import ctypes
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import gen_scene  # noqa: E402
+sys.path.insert(0, ROOT)
+import yaml  # noqa: E402
 from artiboost_amd import kernels as K  # noqa: E402
 from artiboost_amd.assets import SceneAssets  # noqa: E402
-from artiboost_amd.render import DeviceRenderer  # noqa: E402
+from artiboost_amd.synth import ArtiBoostLoader  # noqa: E402
 
 B, res = 24, 256
-assets = SceneAssets("HO3D", seed=1)
-Kc = np.array([[435.0, 0, 256.0], [0, 435.0, 256.0], [0, 0, 1.0]])
-sc = gen_scene.make_samples(assets, B, 7, out_res=(res, res))
-r = DeviceRenderer(assets, Kc)
-dev = r.dev
-t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
-smp, hv, od, fc, ia, bl = t(sc["samples"].view(np.uint8).reshape(B, -1)), t(sc["hand_verts"]), t(sc["order"]), t(sc["factor"]), t(sc["inv_affine"]), t(sc["blur"])
+cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+cfg["DATA_PRESET"]["IMAGE_SIZE"] = [res, res]
+loader = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], B, B, compute_dtype="u8n", random_seed=7)
+loader.prepare()
+st = loader.new_static_batch()
+loader.load_batch(st, 0)                      # one batch of the loader's own epoch: CCV samples, hand vertices, jitter draws
+r, dev = loader.renderer, loader.dev
+smp, hv, od, fc, ia, bl = st["_samples"], st["_hand_verts"], st["_order"], st["_factor"], st["_inv_affine"], st["_blur"]
 
 
 def render():
