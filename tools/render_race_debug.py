@@ -19,7 +19,7 @@ from artiboost_amd.synth import ArtiBoostLoader  # noqa: E402
 
 B, res = 24, 256
 cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
-cfg["DATA_PRESET"]["IMAGE_SIZE"] = [res, res]
+cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [res, res], [res // 8, res // 8]
 loader = ArtiBoostLoader.from_assets(SceneAssets("HO3D", seed=1), cfg["MANAGER"], cfg["DATA_PRESET"], B, B, compute_dtype="u8n", random_seed=7)
 loader.prepare()
 st = loader.new_static_batch()
