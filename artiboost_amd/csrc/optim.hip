@@ -24,7 +24,7 @@ __global__ __launch_bounds__(OPT_THREADS) void sqnorm_kernel(const float* __rest
     if (threadIdx.x == 0) part[blockIdx.x] = (float)sm[0];
 }
 
-// total_norm_out[0] = sqrt(sum partials) * gscale  (gscale: 1/world_size when the partials are of un-averaged sums)
+// total_norm_out[0] = sqrt(sum partials)
 __global__ void norm_finalize_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out) {
     double s = 0.0;
     for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
@@ -83,6 +83,37 @@ extern "C" int ab_grad_norm(const float* grad, long n, float* part, float* total
     sqnorm_kernel<<<nb, OPT_THREADS, 0, as_stream(stream)>>>(grad, n, part);
     AB_LAUNCH_CHECK();
     norm_finalize_kernel<<<1, 64, 0, as_stream(stream)>>>(part, nb, total_norm);
+    AB_LAUNCH_CHECK();
+    return 0;
+}
+
+// x *= s, in place: the 1 / world_size of the gradient average after a SUM all-reduce (train.allreduce_flat_).  RCCL's ReduceOp.AVG is
+// PreMulSum, whose gfx950 ring kernels multiply with v_pk_mul_f32 -- and run on the comm stream beside this build's MFMA kernels (build.py on
+// -packed-fp32-ops); its plain Sum ring kernels hold no packed fp32, and this library is compiled without it.
+__global__ __launch_bounds__(OPT_THREADS) void scale_kernel(float* __restrict__ x, long n, float s, int head) {
+    // [0, head) scalar up to the first 16-byte boundary, float4 body, scalar tail
+    long nvec = (n - head) / 4;
+    float4* xv = (float4*)(x + head);
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < nvec; i += (long)gridDim.x * OPT_THREADS) {
+        float4 v = xv[i];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        xv[i] = v;
+    }
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < head) x[threadIdx.x] *= s;
+        long t = head + nvec * 4 + threadIdx.x;
+        if (threadIdx.x < 4 && t < n) x[t] *= s;
+    }
+}
+
+extern "C" int ab_scale_f32(float* x, long n, float s, void* stream) {
+    if (!x || n < 0 || (uintptr_t)x % 4) return AB_EINVAL;
+    if (n == 0) return 0;
+    int head = (int)(((16 - (uintptr_t)x % 16) % 16) / 4);
+    if (head > n) head = (int)n;
+    long b = ((n - head) / 4 + OPT_THREADS - 1) / OPT_THREADS;
+    int nb = (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+    scale_kernel<<<nb, OPT_THREADS, 0, as_stream(stream)>>>(x, n, s, head);
     AB_LAUNCH_CHECK();
     return 0;
 }

@@ -236,7 +236,7 @@ def rccl_leg(args, ms_main):
     d = json.loads(lines[-1])
     return {"value": d["value"], "unit": "samples/s", "ms_per_step": d["ms_per_step"], "schedule_overhead_ms": round(d["ms_per_step"] - ms_main, 3),
             "parallelism": d["config"]["parallelism"], "render_overlap": d["config"]["render_overlap"], "final_loss": d["final_loss"],
-            "what": "init_process_group('nccl', device_id=...), three backward graphs, bucketed ReduceOp.AVG all-reduces on the comm stream, next "
+            "what": "init_process_group('nccl', device_id=...), three backward graphs, bucketed SUM all-reduces + 1 / world on the comm stream, next "
                     "batch rendered under the last range -- over ONE rank: no link time, not a scaling measurement"}
 
 
@@ -462,7 +462,7 @@ def pmc_traffic(args):
         return None
 
 
-PMC_FILE = {"bf16": "round1_pmc_hbm_traffic.json", "bf16x3": "round5_d_pmc_hbm_traffic.json", "f32": "none"}
+PMC_FILE = {"bf16": "round1_pmc_hbm_traffic.json", "bf16x3": "round6_c_pmc_hbm_traffic.json", "f32": "none"}
 GFLOP_FWD_PER_SAMPLE = {224: 8.191, 256: 10.698}            # forward only (BASELINE configs[1])
 
 
@@ -782,7 +782,7 @@ def main():
     ap.add_argument("--no-eval-leg", action="store_true", help="skip the configs[1] eval-forward sub-object of the default line")
     ap.add_argument("--no-dexycb-leg", action="store_true", help="skip the configs[4]-on-one-GPU sub-object of the default line")
     ap.add_argument("--rccl-single-rank", action="store_true",
-                    help="N = 1 only: run the multi-rank schedule (three backward graphs, ReduceOp.AVG all-reduces on the comm stream, render "
+                    help="N = 1 only: run the multi-rank schedule (three backward graphs, SUM all-reduces + 1 / world on the comm stream, render "
                          "overlap) over a ONE-rank RCCL group -- the part of the RCCL path a 1-GPU box can execute; not the headline")
     ap.add_argument("--no-rccl-leg", action="store_true", help="skip the one-rank RCCL schedule sub-object of the default line")
     ap.add_argument("--no-dropin-leg", action="store_true", help="skip the reference-shaped epoch_pass loop sub-object of the default line")
@@ -845,6 +845,8 @@ def main():
         if shared:
             torch.distributed.init_process_group("gloo")
         else:
+            from artiboost_amd.train import rccl_env_defaults
+            rccl_env_defaults()
             torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     device = f"cuda:{local}"
     torch.cuda.set_device(local)
@@ -857,6 +859,8 @@ def main():
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
+        from artiboost_amd.train import rccl_env_defaults
+        rccl_env_defaults()
         torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                                              device_id=torch.device(device))
         args.no_eval_leg = args.no_dexycb_leg = args.no_study_leg = args.no_jpeg_leg = args.no_mixed_leg = args.no_rccl_leg = args.no_dropin_leg = args.no_cpu_baseline = True

@@ -349,6 +349,10 @@ int ab_image_pad_nhwc4(const float* img_nchw, int dtype, int N, int H, int W, vo
  * anakin/utils/netutils.py:26-33.  part: float[1024] workspace, total_norm: float[1] (device).  hyper (optional):
  * device float[3] = {lr, 1-beta1^step, sqrt(1-beta2^step)} overriding lr/step (per-step values under graph replay). */
 int ab_grad_norm(const float* grad, long n, float* part, float* total_norm, void* stream);
+/* x[0..n) *= s in place: the 1 / world_size after a SUM all-reduce of the flat gradient -- the averaging torch's
+ * DistributedDataParallel does around train/train_artiboost.py:88 `final_loss.backward()` (the reference wraps the model in DDP at :249-257).
+ * Kept in this library because RCCL's ReduceOp.AVG kernels use packed fp32. */
+int ab_scale_f32(float* x, long n, float s, void* stream);
 int ab_clip_adam(float* param, const float* grad, float* m, float* v, long n, const float* total_norm,
                  float max_norm, float lr, float beta1, float beta2, float eps, int step, const float* hyper,
                  void* lp, void* stream);
@@ -573,6 +577,7 @@ int ab_mano_lbs(const float* pose, const float* betas, const float* v_template, 
  * @check ab_avgpool_fwd: dt(dtype): x; x >= N*HW*C; out >= N*C
  * @check ab_image_pad_nhwc4: dt(dtype): out; img_nchw >= N*3*H*W; out >= N*(H+6)*(W+8)*4
  * @check ab_grad_norm: grad >= n; total_norm >= 1
+ * @check ab_scale_f32: x >= n
  * @check ab_clip_adam: bf16: lp; param grad m v lp >= n; total_norm >= 1
  * @check ab_clip_adam_x3: bf16: lp_hi lp_lo; param grad m v lp_hi lp_lo >= n; total_norm >= 1
  * @check ab_pose_assemble: strided: box6d; kp3d >= B*22*3; root_joint >= B*3; cam_intr >= B*9; corners_can >= B*24; joints_abs joints_rel >= B*63; corners_abs corners_rel >= B*24; rotmat >= B*9; uvd2d >= B*90

@@ -82,7 +82,7 @@ def test_dropin_epoch_pass_leg_is_within_a_tenth_of_the_headline():
 
 def test_rccl_single_rank_schedule():
     """What a 1-GPU box can execute of the RCCL path: tools/ddp_smoke.py under torch.distributed.run with ONE rank and
-    AB_DDP_SINGLE_RANK=1 -- init_process_group("nccl") on the device, the three-graph backward with bucketed ReduceOp.AVG all-reduces on
+    AB_DDP_SINGLE_RANK=1 -- init_process_group("nccl") on the device, the three-graph backward with bucketed SUM all-reduces (+ 1 / world) on
     the comm stream, the render of the next batch under the last range, post-all-reduce clip + Adam.  An average over one rank is the
     identity, so five steps must end in bit-identical weights to the same schedule with the collective replaced by a touch of the same
     bytes (AB_FAKE_COMM=1)."""

@@ -12,6 +12,48 @@ import learner_oracle as lo
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 7, 1000, 4096 * 257 + 5])
+@pytest.mark.parametrize("off", [0, 1, 2, 3])
+def test_scale_f32_is_the_elementwise_product(n, off):
+    """ab_scale_f32 (the 1 / world of the gradient average, train.allreduce_flat_): bit-equal to x * s for any slice offset / length,
+    and leaves the elements either side of the slice alone."""
+    from artiboost_amd import _lib as L
+    base = torch.randn(n + 16, generator=torch.Generator().manual_seed(n + off)).cuda()
+    want = base.clone()
+    want[off:off + n] *= 0.125
+    want3 = base.clone()
+    want3[off:off + n] *= (1.0 / 3.0)
+    for s, ref in ((0.125, want), (1.0 / 3.0, want3)):
+        x = base.clone()
+        L.check(L.lib().ab_scale_f32(L.ptr(x[off:off + n]) if n else L.ptr(x[off:off + 1]), L.l(n), L.f(s), L.stream()), "ab_scale_f32")
+        assert torch.equal(x, ref)
+
+
+def test_allreduce_flat_over_one_rank_rccl_group_is_the_identity():
+    """train.allreduce_flat_ on the GPU path: SUM all-reduce + ab_scale_f32 (no ReduceOp.AVG: its RCCL kernels use packed fp32).  One rank is all a
+    one-GPU box can run: the gradient must come back bit-identical, for ranges that start off a 16-byte boundary too."""
+    import socket
+    import torch.distributed as dist
+    from artiboost_amd.train import allreduce_flat_, rccl_env_defaults
+    if dist.is_initialized():
+        pytest.skip("a process group is already alive in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    rccl_env_defaults()
+    assert os.environ["NCCL_ALGO"]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        g = torch.randn((1 << 22) + 7, device="cuda")
+        ref = g.clone()
+        allreduce_flat_(g, 1, bucket_elems=1 << 20)
+        allreduce_flat_(g[5:-1], 1, bucket_elems=1 << 20)
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref)
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("n,max_norm", [(4, 0.001), (1000, 0.001), (4096 * 257, 0.5), (64, None)])
 def test_clip_adam_matches_oracle(n, max_norm):
     from artiboost_amd.optim import FusedClipAdam

@@ -4,7 +4,7 @@ Checks: the split-graph + side-stream all-reduce path runs -- by default with th
 t+1 on a second stream under the last all-reduce range and the optimizer; AB_DDP_OVERLAP=0 turns it off) in the benchmarked
 precision (AB_DDP_DTYPE, default bf16x3) -- losses are finite, and the ranks hold identical weights.
 With --nproc-per-node 1 and AB_DDP_SINGLE_RANK=1 the same schedule runs with a ONE-rank RCCL group: the real init_process_group("nccl"),
-bucketed ReduceOp.AVG all-reduces on the comm stream between the backward graphs -- what a 1-GPU box can execute of the RCCL path."""
+bucketed SUM all-reduces + 1 / world on the comm stream between the backward graphs -- what a 1-GPU box can execute of the RCCL path."""
 import os, sys
 import torch
 import torch.distributed as dist
@@ -26,6 +26,9 @@ ngpu = torch.cuda.device_count()
 dev = f"cuda:{rank % ngpu}"
 torch.cuda.set_device(dev)
 backend = "nccl" if ngpu >= world else "gloo"
+if backend == "nccl":
+    from artiboost_amd.train import rccl_env_defaults
+    rccl_env_defaults()
 dist.init_process_group(backend)
 root = os.path.join(os.path.dirname(__file__), "..")
 cfg = yaml.safe_load(open(os.path.join(root, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))

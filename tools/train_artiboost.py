@@ -48,6 +48,8 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from artiboost_amd.train import rccl_env_defaults
+        rccl_env_defaults()
         torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     dev = f"cuda:{local}"
     cfg = yaml.safe_load(open(args.cfg))

@@ -102,6 +102,8 @@ def main():
         if world > ngpu:
             torch.distributed.init_process_group("gloo")
         else:
+            from artiboost_amd.train import rccl_env_defaults
+            rccl_env_defaults()
             torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
 
     from anakin.artiboost import ArtiBoostLoader
