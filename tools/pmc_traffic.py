@@ -19,7 +19,7 @@ import os
 import sys
 
 CONV = ("conv_gemm_kernel", "conv_gemm2_kernel", "conv3x3_kernel", "conv3x3r_kernel", "conv2x2_kernel", "convp_kernel", "gemm_rw_kernel",
-        "stem_halo_kernel", "stem_halo_x3_kernel", "wgrad_kernel", "wgrad3x3_kernel", "wgrad_gemm2_kernel", "wgrad_reduce")
+        "stem_halo_kernel", "stem_halo_x3_kernel", "wgrad_kernel", "wgrad3x3_kernel", "wgrad_gemm2_kernel", "wgrad_reduce", "wgrad_reduce_batch_kernel")
 BN = ("bn_apply_kernel", "bn_apply_x3_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_kernel", "bn_bwd_apply_x3_kernel", "bn_finalize_kernel",
       "bn_bwd_finalize_kernel", "bn_fin_apply_x3_kernel", "bn_fin_bwd_apply_x3_kernel", "maxpool_fwd_x3_kernel", "pool_win_bn_reduce_kernel",
       "pool_bwd_bn_reduce_kernel", "pool_bwd_bn_apply_x3_kernel", "col_stats_kernel", "col_stats_x3_kernel", "maxpool_fwd_kernel", "maxpool_bwd_kernel", "split_f32_kernel", "avgpool_fwd_kernel",
