@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libartiboost_hip.so")
 TORCH_LIB = os.path.join(HERE, "libartiboost_torch.so")      # the same entry points as torch.ops.artiboost_hip.* (gen_torch_ops.py)
-# -packed-fp32-ops (round 6): no v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32.  Measured on MI355X (tools/render_race_debug.py + tools/_probe/lds_neighbour.hip):
+# -packed-fp32-ops (round 6): no v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32.  Measured on MI355X (tools/render_race_debug.py + tools/probe_neighbour.hip):
 # while ANOTHER wave on the same SIMD executes v_mfma_f32_32x32x16_bf16, packed-fp32 VALU instructions of a co-resident wave return wrong results
 # (the shading of the renderer evaluated twice in one thread on identical inputs differed; a register-only MFMA loop as the neighbour is enough;
 # scalar-fp32 code beside the same neighbour is exact).  Alone on its stream no kernel here shares a SIMD with another kernel's MFMA waves, but the

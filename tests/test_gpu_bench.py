@@ -132,3 +132,22 @@ def test_roofline_is_timed_inside_the_replayed_step():
     assert 0.5 < roof["stamp_boundary_us"] < 4.0, roof
     line = _last_json(r.stdout)
     assert g < line["ms_per_step"]                        # the dominant family is shorter than the step it is part of
+
+
+def test_training_beside_the_worker_thread_gives_the_same_losses():
+    """The mixed real + synthetic loop with its batch assembly on the training thread and on a worker thread with its own stream
+    (realdata.ThreadedPrefetcher): the same batches in the same order, so the same losses to the last bit.  This is the loop in which
+    the render of the next batch first ran BESIDE the step's MFMA kernels and came out a few grey levels off in a few dozen pixels
+    (packed-fp32 results beside v_mfma_f32_32x32x16_bf16: DESIGN 15.10) -- with packed fp32 in the library the losses of the two
+    modes part at a random step."""
+    import yaml
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_mixed
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", "ho3dv2_clasbased_artiboost_mi355x.yaml")))
+    cfg["DATA_PRESET"]["IMAGE_SIZE"], cfg["DATA_PRESET"]["HEATMAP_SIZE"] = [256, 256], [32, 32]
+    group = "frames of 4 batches decoded per call one group ahead on a side stream"
+    runs = []
+    for mode in ("same stream, " + group, "worker thread two batches ahead, " + group, "worker thread two batches ahead, " + group):
+        r = bench_mixed.train_loop(cfg, steps=24, modes=(mode,), quiet=True)
+        runs.append((r["first_losses"], r["final_loss"]))
+    assert runs[0] == runs[1] == runs[2], runs
